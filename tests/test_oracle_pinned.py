@@ -1,0 +1,82 @@
+"""Pin the plain-C oracle (oracle/restate) before anything trusts it.
+
+(a) bit-for-bit against the golden rollouts generated from the reference's own
+    C++ (tests/golden/*.npz, made by tests/golden/make_golden.py);
+(b) bit-for-bit against oracle/_ref (the reference compiled in place) whenever
+    that library is present (build container only).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.orc import Oracle, have_ref
+from oracle_cases import CASES, sample_actions
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def replay_golden(make_pool, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    acts = g["actions"]
+    n = acts.shape[1]
+    pool = make_pool(n, int(g["seed"]))
+    frames = [pool.reset()]
+    for t in range(acts.shape[0]):
+        frames.append(pool.step(acts[t]))
+    for key in [k for k in g.files if k.startswith("state/")]:
+        want = g[key]
+        got = np.stack([f[key[6:]] for f in frames]).reshape(want.shape)
+        yield key[6:], want, got
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_port_matches_golden(name):
+    c = CASES[name]
+
+    def make(n, seed):
+        return Oracle(c["task"], n, seed=seed, max_episode_steps=c["max_steps"],
+                      extra=c["extra"], kind="port")
+
+    for key, want, got in replay_golden(make, name):
+        assert got.dtype == want.dtype, key
+        assert np.array_equal(got, want), f"{name}:{key} differs from reference"
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built here")
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_port_matches_compiled_reference(name):
+    c = CASES[name]
+    n = 96
+    ref = Oracle(c["task"], n, seed=7, max_episode_steps=c["max_steps"],
+                 extra=c["extra"], kind="reference", num_threads=2)
+    port = Oracle(c["task"], n, seed=7, max_episode_steps=c["max_steps"],
+                  extra=c["extra"], kind="port")
+    assert [k[:2] for k in ref.keys] == [k[:2] for k in port.keys]
+    ra, rb = ref.reset(), port.reset()
+    rng = np.random.default_rng(99)
+    for t in range(700):
+        for k in ra:
+            assert np.array_equal(ra[k], rb[k]), (name, t, k)
+        a = sample_actions(c, rng, n)
+        ra, rb = ref.step(a), port.step(a)
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built here")
+def test_partial_env_id_step_matches_reference():
+    """sync mode, subset of env ids: rows come back in send order
+    (envpool/core/state_buffer.h:94-97, async_envpool.h:170-175)."""
+    c = CASES["CartPole-v1"]
+    n = 16
+    ref = Oracle("CartPole", n, seed=1, max_episode_steps=500, kind="reference",
+                 num_threads=2)
+    port = Oracle("CartPole", n, seed=1, max_episode_steps=500, kind="port")
+    ref.reset(), port.reset()
+    ids = np.array([5, 2, 11, 7], dtype=np.int32)
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        a = sample_actions(c, rng, len(ids))
+        ra, rb = ref.step(a, ids), port.step(a, ids)
+        for k in ra:
+            assert np.array_equal(ra[k], rb[k]), k
+        assert np.array_equal(ra["info:env_id"].ravel(), ids)
