@@ -1,0 +1,185 @@
+"""`DevicePool`: thin object over the C ABI for one env family.
+
+It plays the role of the C++ `EnvPool<Spec>` virtual interface of the reference
+(envpool/core/envpool.h:29-56: Send / Recv / Reset) — the thing
+`PyEnvPool` wraps — with the thread pool replaced by batched HIP kernels.
+"""
+
+from __future__ import annotations
+
+import collections
+import ctypes
+from typing import Any, Sequence
+
+import numpy as np
+
+from . import native
+
+
+class DevicePool:
+    """Low-level pool: numpy in, list-of-numpy out, in `_state_keys` order."""
+
+    def __init__(
+        self,
+        family: str,
+        num_envs: int,
+        batch_size: int = 0,
+        seed: int = 42,
+        env_seed: Sequence[int] | None = None,
+        max_episode_steps: int = 0,
+        device: int = 0,
+        env_id_offset: int = 0,
+        params: dict[str, float] | None = None,
+    ) -> None:
+        self._lib = native.lib()
+        self.family = family
+        self.num_envs = int(num_envs)
+        self.batch_size = int(batch_size) if batch_size else int(num_envs)
+        self.env_id_offset = int(env_id_offset)
+        self.device = int(device)
+        cfg, keep = native.make_config(
+            num_envs, batch_size, seed, env_seed, max_episode_steps, device,
+            env_id_offset, params,
+        )
+        self.state_keys = native.describe(family, params, "state")
+        self.action_keys = native.describe(family, params, "action")
+        self.action_dtype = self.action_keys[-1][1]
+        self.action_shape = self.action_keys[-1][2]
+        h = ctypes.c_void_p()
+        native.check(
+            self._lib.epa_create(family.encode(), ctypes.byref(cfg), ctypes.byref(h))
+        )
+        del keep
+        self._h = h
+        self._pending: collections.deque[int] = collections.deque()
+        self._is_sync = self.batch_size == self.num_envs
+
+    # -- host path ---------------------------------------------------------
+    def send(self, env_id: np.ndarray, action: np.ndarray) -> None:
+        env_id = np.ascontiguousarray(env_id, dtype=np.int32)
+        action = np.ascontiguousarray(action, dtype=self.action_dtype)
+        k = int(env_id.shape[0])
+        want = (k, *self.action_shape)
+        if action.size != int(np.prod(want)):
+            raise RuntimeError(
+                f"Expected action of shape {want}, got {action.shape}"
+            )
+        native.check(
+            self._lib.epa_send(self._h, env_id.ctypes.data, k, action.ctypes.data)
+        )
+        self._pending.append(k)
+
+    def reset(self, env_ids: np.ndarray) -> None:
+        env_ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+        k = int(env_ids.shape[0])
+        native.check(self._lib.epa_reset(self._h, env_ids.ctypes.data, k))
+        self._pending.append(k)
+
+    def recv(self) -> list[np.ndarray]:
+        if self._is_sync:
+            cap = self._pending[0] if self._pending else self.num_envs
+        else:
+            cap = self.batch_size
+        outs = [
+            np.empty((cap, *shape), dtype=dtype)
+            for _, dtype, shape in self.state_keys
+        ]
+        ptrs = (ctypes.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+        k = ctypes.c_int32(0)
+        native.check(
+            self._lib.epa_recv(self._h, ptrs, len(outs), cap, ctypes.byref(k))
+        )
+        if self._is_sync:
+            if self._pending:
+                self._pending.popleft()
+        else:
+            # async: rows drain across submissions in order
+            left = k.value
+            while left > 0 and self._pending:
+                if self._pending[0] <= left:
+                    left -= self._pending.popleft()
+                else:
+                    self._pending[0] -= left
+                    left = 0
+        if k.value != cap:
+            outs = [o[: k.value] for o in outs]
+        return outs
+
+    def recv_dict(self) -> dict[str, np.ndarray]:
+        return {k[0]: v for k, v in zip(self.state_keys, self.recv())}
+
+    # -- device path ---------------------------------------------------------
+    def send_device(self, d_action: int | None, k: int | None = None,
+                    d_env_id: int | None = None) -> None:
+        """`d_action` / `d_env_id` are raw device addresses (ints)."""
+        k = self.num_envs if k is None else int(k)
+        native.check(
+            self._lib.epa_send_device(
+                self._h, ctypes.c_void_p(d_env_id), k, ctypes.c_void_p(d_action)
+            )
+        )
+
+    def recv_device(self) -> tuple[list[int], int]:
+        n = len(self.state_keys)
+        ptrs = (ctypes.c_void_p * n)()
+        k = ctypes.c_int32(0)
+        native.check(self._lib.epa_recv_device(self._h, ptrs, n, ctypes.byref(k)))
+        return [int(p) if p else 0 for p in ptrs], k.value
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.epa_stream(self._h) or 0)
+
+    def synchronize(self) -> None:
+        native.check(self._lib.epa_synchronize(self._h))
+
+    def set_timing(self, on: bool) -> None:
+        native.check(self._lib.epa_set_timing(self._h, 1 if on else 0))
+
+    def kernel_time_ms(self) -> tuple[float, int]:
+        ms = ctypes.c_double(0)
+        n = ctypes.c_int32(0)
+        native.check(
+            self._lib.epa_kernel_time_ms(self._h, ctypes.byref(ms), ctypes.byref(n))
+        )
+        return ms.value, n.value
+
+    # -- test hooks ----------------------------------------------------------
+    def state_dim(self) -> int:
+        d = ctypes.c_int32(0)
+        native.check(self._lib.epa_state_dim(self._h, ctypes.byref(d)))
+        return d.value
+
+    def get_state(self, env_ids: Any = None) -> np.ndarray:
+        ids = self._ids(env_ids)
+        out = np.empty((len(ids), self.state_dim()), dtype=np.float64)
+        native.check(
+            self._lib.epa_get_state(self._h, ids.ctypes.data, len(ids), out.ctypes.data)
+        )
+        return out
+
+    def set_state(self, state: np.ndarray, env_ids: Any = None) -> None:
+        ids = self._ids(env_ids)
+        state = np.ascontiguousarray(state, dtype=np.float64)
+        assert state.shape == (len(ids), self.state_dim()), state.shape
+        native.check(
+            self._lib.epa_set_state(self._h, ids.ctypes.data, len(ids), state.ctypes.data)
+        )
+
+    def _ids(self, env_ids: Any) -> np.ndarray:
+        if env_ids is None:
+            return np.arange(
+                self.env_id_offset, self.env_id_offset + self.num_envs, dtype=np.int32
+            )
+        return np.ascontiguousarray(env_ids, dtype=np.int32)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.epa_destroy(self._h)
+            self._h = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,203 @@
+// Internal C++ side of the C ABI in include/envpool_amd.h.
+//
+// A `Pool` owns: device-resident SoA env state (family specific), one HIP
+// stream, pinned action staging, and a FIFO of result batches.  It replaces
+// AsyncEnvPool + ActionBufferQueue + StateBufferQueue of the reference
+// (envpool/core/async_envpool.h, action_buffer_queue.h, state_buffer_queue.h):
+// "enqueue" = launch one batched step kernel on the stream, "state buffer" = a
+// packed device block holding every state key for the k rows of that launch.
+#ifndef ENVPOOL_AMD_CSRC_ENGINE_H_
+#define ENVPOOL_AMD_CSRC_ENGINE_H_
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/envpool_amd.h"
+
+namespace epa {
+
+struct DeviceError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define EPA_HIP(expr)                                                        \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      throw ::epa::DeviceError(std::string(#expr) + ": " +                   \
+                               hipGetErrorString(_e));                       \
+    }                                                                        \
+  } while (0)
+
+inline int DtypeBytes(int dt) {
+  switch (dt) {
+    case EPA_I32: return 4;
+    case EPA_F32: return 4;
+    case EPA_F64: return 8;
+    default: return 1;
+  }
+}
+
+struct KeySpec {
+  std::string name;
+  int dtype;
+  std::vector<int> shape;  // per row
+  int row_elems() const {
+    int n = 1;
+    for (int d : shape) n *= d;
+    return n;
+  }
+  int row_bytes() const { return row_elems() * DtypeBytes(dtype); }
+};
+
+// Parsed epa_config.
+struct Config {
+  int num_envs{1};
+  int batch_size{0};
+  int seed{42};
+  std::vector<int> env_seed;
+  int max_episode_steps{INT_MAX};
+  int device{0};
+  int env_id_offset{0};
+  std::map<std::string, double> params;
+  double Get(const std::string& k, double dflt) const {
+    auto it = params.find(k);
+    return it == params.end() ? dflt : it->second;
+  }
+  static Config From(const epa_config* c);
+};
+
+// Common state keys of every env (envpool/core/env_spec.h:37-43).
+std::vector<KeySpec> CommonStateKeys();
+constexpr int kNumCommonKeys = 8;
+constexpr int kMaxKeys = 24;
+
+// Output pointers handed to a step kernel: out.p[key] is the base of that
+// key's [k, ...] array inside the batch block.
+struct OutPtrs {
+  void* p[kMaxKeys];
+};
+
+struct Batch {
+  char* dbuf{nullptr};
+  size_t cap_rows{0};
+  int k{0};
+  int consumed{0};                // rows already handed to recv (async mode)
+  std::vector<size_t> offsets;    // byte offset of each key's section
+  hipEvent_t done{nullptr};
+};
+
+// Per-env bookkeeping shared by all families, SoA on device:
+//   cur_step  Env::current_step_ (env.h:86)      init -1
+//   done      XxxEnv::done_                       init 1 (first step resets)
+//   mt/mti    std::mt19937 gen_ (env.h:78)        [624][N] words + index
+struct CommonDev {
+  int* cur_step;
+  unsigned char* done;
+  uint32_t* mt;
+  int* mti;
+  int n;
+};
+
+class Pool {
+ public:
+  Pool(const Config& cfg, std::vector<KeySpec> env_state_keys, KeySpec action,
+       bool needs_rng);
+  virtual ~Pool();
+
+  const Config& cfg() const { return cfg_; }
+  const std::vector<KeySpec>& state_keys() const { return keys_; }
+  const KeySpec& action_key() const { return action_; }
+  hipStream_t stream() const { return stream_; }
+
+  void Send(const int32_t* env_id, int k, const void* action);
+  void Reset(const int32_t* env_ids, int k);
+  void SendDevice(const int32_t* d_env_id, int k, const void* d_action);
+  int Recv(void* const* out_ptrs, int n_ptrs, int cap_rows);
+  int RecvDevice(void** d_out_ptrs, int n_ptrs);
+  int PendingRows();
+  void Synchronize();
+  void SetTiming(bool on);
+  void KernelTime(double* avg_ms, int* launches);
+
+  virtual int StateDim() const = 0;
+  // family hooks: flat double state <-> device SoA, for the listed local ids
+  virtual void GetState(const int* d_ids, int k, double* d_out) = 0;
+  virtual void SetState(const int* d_ids, int k, const double* d_in) = 0;
+  void GetStateHost(const int32_t* ids, int k, double* out);
+  void SetStateHost(const int32_t* ids, int k, const double* in);
+
+ protected:
+  // Launch the family's batched step kernel for k rows on stream_.
+  // d_ids == nullptr means rows 0..k-1 map to local envs 0..k-1.
+  virtual void Launch(const int* d_ids, int k, const void* d_action,
+                      bool force_reset, const OutPtrs& out) = 0;
+  void InitCommon();  // allocates + initialises CommonDev (after derived ctor)
+
+  Config cfg_;
+  std::vector<KeySpec> keys_;
+  KeySpec action_;
+  bool needs_rng_;
+  hipStream_t stream_{nullptr};
+  CommonDev common_{};
+
+ private:
+  Batch* AcquireBatch(int k);
+  void ReleaseBatch(Batch* b);
+  OutPtrs PtrsOf(const Batch& b) const;
+  void Enqueue(const int* d_ids, int k, const void* d_action, bool force);
+  struct Staging {
+    char* h{nullptr};
+    char* d{nullptr};
+    size_t bytes{0};
+    hipEvent_t free_ev{nullptr};
+    bool in_use{false};
+  };
+  Staging& NextStaging(size_t bytes);
+  void CheckIds(const int32_t* ids, int k) const;
+
+  std::mutex mu_;
+  std::deque<Batch*> pending_;
+  std::vector<Batch*> free_;
+  std::vector<std::unique_ptr<Batch>> all_;
+  Batch* lent_[2]{nullptr, nullptr};  // batches handed out by RecvDevice
+  std::vector<Staging> staging_;
+  size_t staging_next_{0};
+  char* recv_stage_{nullptr};  // pinned D2H landing block
+  size_t recv_stage_bytes_{0};
+  // timing
+  bool timing_{false};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timers_;
+  std::vector<hipEvent_t> timer_pool_;
+};
+
+// family factories (defined next to the kernels)
+Pool* MakeClassicControl(const std::string& family, const Config& cfg);
+bool DescribeClassicControl(const std::string& family, const Config& cfg,
+                            std::vector<KeySpec>* state, KeySpec* action);
+Pool* MakeToyText(const std::string& family, const Config& cfg);
+bool DescribeToyText(const std::string& family, const Config& cfg,
+                     std::vector<KeySpec>* state, KeySpec* action);
+Pool* MakeMujoco(const std::string& family, const Config& cfg);
+bool DescribeMujoco(const std::string& family, const Config& cfg,
+                    std::vector<KeySpec>* state, KeySpec* action);
+
+const std::vector<std::string>& FamilyNames();
+
+// Launch helpers shared by the family files.
+void LaunchInitCommon(CommonDev c, int seed, const int* d_env_seed,
+                      int id_offset, bool with_rng, hipStream_t s);
+
+}  // namespace epa
+
+#endif  // ENVPOOL_AMD_CSRC_ENGINE_H_

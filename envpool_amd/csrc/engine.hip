@@ -1,0 +1,704 @@
+// Host side of the engine: Pool (stream, staging, batch FIFO) and the C ABI.
+// See engine.h / include/envpool_amd.h for what each piece replaces in the
+// reference.
+#include "engine.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "device_common.cuh"
+
+namespace epa {
+
+namespace {
+thread_local std::string g_last_error;
+
+size_t Align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+__global__ void InitCommonKernel(CommonDev c, int seed, const int* env_seed,
+                                 int id_offset, int with_rng) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= c.n) return;
+  c.cur_step[e] = -1;  // Env::current_step_{-1}, env.h:86
+  c.done[e] = 1;       // XxxEnv::done_{true}
+  if (with_rng) {
+    // std::mt19937(seed_): seed_ = env_seed[env_id] or seed + env_id
+    // (envpool/core/env.h:101-117)
+    uint32_t s = (uint32_t)(env_seed ? env_seed[e] : seed + id_offset + e);
+    uint32_t* col = c.mt + e;
+    uint32_t x = s;
+    col[0] = x;
+    for (int i = 1; i < 624; ++i) {
+      x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+      col[(size_t)i * c.n] = x;
+    }
+    c.mti[e] = 624;
+  }
+}
+}  // namespace
+
+void LaunchInitCommon(CommonDev c, int seed, const int* d_env_seed,
+                      int id_offset, bool with_rng, hipStream_t s) {
+  int threads = 256, blocks = (c.n + threads - 1) / threads;
+  hipLaunchKernelGGL(InitCommonKernel, dim3(blocks), dim3(threads), 0, s, c,
+                     seed, d_env_seed, id_offset, with_rng ? 1 : 0);
+  EPA_HIP(hipGetLastError());
+}
+
+Config Config::From(const epa_config* c) {
+  Config r;
+  if (c == nullptr) throw std::invalid_argument("null config");
+  r.num_envs = c->num_envs;
+  r.batch_size = c->batch_size;
+  r.seed = c->seed;
+  if (c->env_seed != nullptr) {
+    r.env_seed.assign(c->env_seed, c->env_seed + c->num_envs);
+  }
+  r.max_episode_steps = c->max_episode_steps > 0 ? c->max_episode_steps : INT_MAX;
+  r.device = c->device;
+  r.env_id_offset = c->env_id_offset;
+  for (int i = 0; i < c->n_params; ++i) {
+    r.params[c->param_keys[i]] = c->param_values[i];
+  }
+  if (r.num_envs < 1) throw std::invalid_argument("num_envs must be >= 1");
+  // EnvSpec ctor, envpool/core/env_spec.h:75-83
+  if (r.batch_size > r.num_envs) {
+    throw std::invalid_argument(
+        "It is required that batch_size <= num_envs, got num_envs = " +
+        std::to_string(r.num_envs) +
+        ", batch_size = " + std::to_string(r.batch_size));
+  }
+  if (r.batch_size <= 0) r.batch_size = r.num_envs;
+  return r;
+}
+
+std::vector<KeySpec> CommonStateKeys() {
+  return {{"info:env_id", EPA_I32, {}},  {"info:players.env_id", EPA_I32, {}},
+          {"elapsed_step", EPA_I32, {}}, {"done", EPA_BOOL, {}},
+          {"reward", EPA_F32, {}},       {"discount", EPA_F32, {}},
+          {"step_type", EPA_I32, {}},    {"trunc", EPA_BOOL, {}}};
+}
+
+Pool::Pool(const Config& cfg, std::vector<KeySpec> env_state_keys,
+           KeySpec action, bool needs_rng)
+    : cfg_(cfg), action_(std::move(action)), needs_rng_(needs_rng) {
+  keys_ = CommonStateKeys();
+  for (auto& k : env_state_keys) keys_.push_back(std::move(k));
+  if (keys_.size() > kMaxKeys) throw std::runtime_error("too many state keys");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    throw DeviceError(
+        "no HIP device available: envpool_amd has no CPU fallback "
+        "(hipGetDeviceCount: " +
+        std::string(hipGetErrorString(e)) + ")");
+  }
+  if (cfg_.device < 0 || cfg_.device >= ndev) {
+    throw std::invalid_argument("device ordinal out of range");
+  }
+  EPA_HIP(hipSetDevice(cfg_.device));
+  EPA_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  staging_.resize(3);
+}
+
+void Pool::InitCommon() {
+  EPA_HIP(hipSetDevice(cfg_.device));
+  int n = cfg_.num_envs;
+  common_.n = n;
+  EPA_HIP(hipMalloc(&common_.cur_step, sizeof(int) * n));
+  EPA_HIP(hipMalloc(&common_.done, n));
+  int* d_env_seed = nullptr;
+  if (needs_rng_) {
+    EPA_HIP(hipMalloc(&common_.mt, sizeof(uint32_t) * 624 * (size_t)n));
+    EPA_HIP(hipMalloc(&common_.mti, sizeof(int) * n));
+    if (!cfg_.env_seed.empty()) {
+      EPA_HIP(hipMalloc(&d_env_seed, sizeof(int) * n));
+      EPA_HIP(hipMemcpy(d_env_seed, cfg_.env_seed.data(), sizeof(int) * n,
+                        hipMemcpyHostToDevice));
+    }
+  }
+  LaunchInitCommon(common_, cfg_.seed, d_env_seed, cfg_.env_id_offset,
+                   needs_rng_, stream_);
+  EPA_HIP(hipStreamSynchronize(stream_));
+  if (d_env_seed) EPA_HIP(hipFree(d_env_seed));
+}
+
+Pool::~Pool() {
+  (void)hipSetDevice(cfg_.device);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (auto& b : all_) {
+    if (b->dbuf) (void)hipFree(b->dbuf);
+    if (b->done) (void)hipEventDestroy(b->done);
+  }
+  for (auto& s : staging_) {
+    if (s.h) (void)hipHostFree(s.h);
+    if (s.d) (void)hipFree(s.d);
+    if (s.free_ev) (void)hipEventDestroy(s.free_ev);
+  }
+  for (auto& t : timers_) {
+    (void)hipEventDestroy(t.first);
+    (void)hipEventDestroy(t.second);
+  }
+  for (auto& t : timer_pool_) (void)hipEventDestroy(t);
+  if (recv_stage_) (void)hipHostFree(recv_stage_);
+  if (common_.cur_step) (void)hipFree(common_.cur_step);
+  if (common_.done) (void)hipFree(common_.done);
+  if (common_.mt) (void)hipFree(common_.mt);
+  if (common_.mti) (void)hipFree(common_.mti);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+Batch* Pool::AcquireBatch(int k) {
+  Batch* b = nullptr;
+  if (!free_.empty()) {
+    b = free_.back();
+    free_.pop_back();
+  } else {
+    all_.push_back(std::make_unique<Batch>());
+    b = all_.back().get();
+    b->cap_rows = cfg_.num_envs;
+    size_t total = 0;
+    for (auto& key : keys_) total += Align(b->cap_rows * key.row_bytes());
+    EPA_HIP(hipMalloc(&b->dbuf, total));
+    EPA_HIP(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+  }
+  b->k = k;
+  b->consumed = 0;
+  b->offsets.resize(keys_.size());
+  size_t off = 0;
+  for (size_t i = 0; i < keys_.size(); ++i) {
+    b->offsets[i] = off;
+    off += Align((size_t)k * keys_[i].row_bytes());
+  }
+  return b;
+}
+
+void Pool::ReleaseBatch(Batch* b) { free_.push_back(b); }
+
+OutPtrs Pool::PtrsOf(const Batch& b) const {
+  OutPtrs o{};
+  for (size_t i = 0; i < keys_.size(); ++i) o.p[i] = b.dbuf + b.offsets[i];
+  return o;
+}
+
+void Pool::Enqueue(const int* d_ids, int k, const void* d_action, bool force) {
+  Batch* b = AcquireBatch(k);
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  if (timing_) {
+    auto get = [&]() {
+      hipEvent_t ev;
+      if (!timer_pool_.empty()) {
+        ev = timer_pool_.back();
+        timer_pool_.pop_back();
+      } else {
+        EPA_HIP(hipEventCreate(&ev));
+      }
+      return ev;
+    };
+    t0 = get();
+    t1 = get();
+    EPA_HIP(hipEventRecord(t0, stream_));
+  }
+  Launch(d_ids, k, d_action, force, PtrsOf(*b));
+  EPA_HIP(hipGetLastError());
+  if (timing_) {
+    EPA_HIP(hipEventRecord(t1, stream_));
+    timers_.emplace_back(t0, t1);
+  }
+  EPA_HIP(hipEventRecord(b->done, stream_));
+  pending_.push_back(b);
+}
+
+Pool::Staging& Pool::NextStaging(size_t bytes) {
+  Staging& s = staging_[staging_next_];
+  staging_next_ = (staging_next_ + 1) % staging_.size();
+  if (s.in_use) {
+    EPA_HIP(hipEventSynchronize(s.free_ev));
+    s.in_use = false;
+  }
+  if (s.bytes < bytes) {
+    if (s.h) EPA_HIP(hipHostFree(s.h));
+    if (s.d) EPA_HIP(hipFree(s.d));
+    size_t cap = std::max(bytes, Align((size_t)cfg_.num_envs * 4) +
+                                     Align((size_t)cfg_.num_envs *
+                                           action_.row_bytes()));
+    EPA_HIP(hipHostMalloc(&s.h, cap, hipHostMallocDefault));
+    EPA_HIP(hipMalloc(&s.d, cap));
+    s.bytes = cap;
+  }
+  if (!s.free_ev) {
+    EPA_HIP(hipEventCreateWithFlags(&s.free_ev, hipEventDisableTiming));
+  }
+  return s;
+}
+
+void Pool::CheckIds(const int32_t* ids, int k) const {
+  if (k < 0 || k > cfg_.num_envs) {
+    throw std::invalid_argument("batch of " + std::to_string(k) +
+                                " rows exceeds num_envs");
+  }
+  if (ids == nullptr) return;
+  int lo = cfg_.env_id_offset, hi = lo + cfg_.num_envs;
+  for (int i = 0; i < k; ++i) {
+    if (ids[i] < lo || ids[i] >= hi) {
+      throw std::invalid_argument("env_id " + std::to_string(ids[i]) +
+                                  " out of range");
+    }
+  }
+}
+
+static bool IsIdentity(const int32_t* ids, int k, int offset, int n) {
+  if (k != n) return false;
+  for (int i = 0; i < k; ++i) {
+    if (ids[i] != offset + i) return false;
+  }
+  return true;
+}
+
+void Pool::Send(const int32_t* env_id, int k, const void* action) {
+  if (env_id == nullptr || action == nullptr) {
+    throw std::invalid_argument("send: null env_id/action");
+  }
+  CheckIds(env_id, k);
+  if (k == 0) return;
+  std::lock_guard<std::mutex> lk(mu_);
+  EPA_HIP(hipSetDevice(cfg_.device));
+  size_t id_bytes = Align((size_t)k * 4);
+  size_t act_bytes = (size_t)k * action_.row_bytes();
+  Staging& s = NextStaging(id_bytes + Align(act_bytes));
+  bool identity = IsIdentity(env_id, k, cfg_.env_id_offset, cfg_.num_envs);
+  size_t copy_from = identity ? id_bytes : 0;
+  if (!identity) std::memcpy(s.h, env_id, (size_t)k * 4);
+  std::memcpy(s.h + id_bytes, action, act_bytes);
+  EPA_HIP(hipMemcpyAsync(s.d + copy_from, s.h + copy_from,
+                         id_bytes + act_bytes - copy_from,
+                         hipMemcpyHostToDevice, stream_));
+  Enqueue(identity ? nullptr : reinterpret_cast<const int*>(s.d), k,
+          s.d + id_bytes, false);
+  EPA_HIP(hipEventRecord(s.free_ev, stream_));
+  s.in_use = true;
+}
+
+void Pool::Reset(const int32_t* env_ids, int k) {
+  if (env_ids == nullptr) throw std::invalid_argument("reset: null env_ids");
+  CheckIds(env_ids, k);
+  if (k == 0) return;
+  std::lock_guard<std::mutex> lk(mu_);
+  EPA_HIP(hipSetDevice(cfg_.device));
+  bool identity = IsIdentity(env_ids, k, cfg_.env_id_offset, cfg_.num_envs);
+  if (identity) {
+    Enqueue(nullptr, k, nullptr, true);
+    return;
+  }
+  size_t id_bytes = Align((size_t)k * 4);
+  Staging& s = NextStaging(id_bytes);
+  std::memcpy(s.h, env_ids, (size_t)k * 4);
+  EPA_HIP(hipMemcpyAsync(s.d, s.h, (size_t)k * 4, hipMemcpyHostToDevice,
+                         stream_));
+  Enqueue(reinterpret_cast<const int*>(s.d), k, nullptr, true);
+  EPA_HIP(hipEventRecord(s.free_ev, stream_));
+  s.in_use = true;
+}
+
+void Pool::SendDevice(const int32_t* d_env_id, int k, const void* d_action) {
+  CheckIds(nullptr, k);
+  if (k == 0) return;
+  std::lock_guard<std::mutex> lk(mu_);
+  EPA_HIP(hipSetDevice(cfg_.device));
+  Enqueue(d_env_id, k, d_action, d_action == nullptr);
+}
+
+int Pool::PendingRows() {
+  std::lock_guard<std::mutex> lk(mu_);
+  int rows = 0;
+  for (Batch* b : pending_) rows += b->k - b->consumed;
+  return rows;
+}
+
+int Pool::Recv(void* const* out_ptrs, int n_ptrs, int cap_rows) {
+  std::lock_guard<std::mutex> lk(mu_);
+  EPA_HIP(hipSetDevice(cfg_.device));
+  if (n_ptrs < (int)keys_.size()) {
+    throw std::invalid_argument("recv: need one output pointer per state key");
+  }
+  if (pending_.empty()) {
+    throw std::runtime_error(
+        "recv: nothing pending (the reference would block forever: call "
+        "send/reset/async_reset first)");
+  }
+  bool sync_mode = cfg_.batch_size == cfg_.num_envs;
+  int want = sync_mode ? pending_.front()->k - pending_.front()->consumed
+                       : cfg_.batch_size;
+  int avail = 0;
+  for (Batch* b : pending_) avail += b->k - b->consumed;
+  if (avail < want) {
+    throw std::runtime_error("recv: only " + std::to_string(avail) +
+                             " rows pending, batch_size is " +
+                             std::to_string(want));
+  }
+  if (cap_rows < want) {
+    throw std::invalid_argument("recv: output buffers too small");
+  }
+  // pinned landing block laid out like a batch of `want` rows
+  std::vector<size_t> off(keys_.size());
+  size_t total = 0;
+  for (size_t i = 0; i < keys_.size(); ++i) {
+    off[i] = total;
+    total += Align((size_t)want * keys_[i].row_bytes());
+  }
+  if (recv_stage_bytes_ < total) {
+    if (recv_stage_) EPA_HIP(hipHostFree(recv_stage_));
+    size_t cap = 0;
+    for (auto& key : keys_) cap += Align((size_t)cfg_.num_envs * key.row_bytes());
+    cap = std::max(cap, total);
+    EPA_HIP(hipHostMalloc(&recv_stage_, cap, hipHostMallocDefault));
+    recv_stage_bytes_ = cap;
+  }
+  int got = 0;
+  while (got < want) {
+    Batch* b = pending_.front();
+    int take = std::min(want - got, b->k - b->consumed);
+    // the copies go on the pool's stream: ordered after the kernel that
+    // produced the rows, no extra event needed.
+    if (got == 0 && take == want && b->consumed == 0 && take == b->k) {
+      // whole batch: one D2H of the packed block (offsets coincide)
+      EPA_HIP(hipMemcpyAsync(recv_stage_, b->dbuf, total, hipMemcpyDeviceToHost,
+                             stream_));
+    } else {
+      for (size_t i = 0; i < keys_.size(); ++i) {
+        size_t rb = keys_[i].row_bytes();
+        EPA_HIP(hipMemcpyAsync(recv_stage_ + off[i] + (size_t)got * rb,
+                               b->dbuf + b->offsets[i] + (size_t)b->consumed * rb,
+                               (size_t)take * rb, hipMemcpyDeviceToHost,
+                               stream_));
+      }
+    }
+    b->consumed += take;
+    got += take;
+    if (b->consumed == b->k) {
+      pending_.pop_front();
+      ReleaseBatch(b);  // safe: reuse is ordered behind the copy on stream_
+    }
+  }
+  EPA_HIP(hipStreamSynchronize(stream_));
+  for (size_t i = 0; i < keys_.size(); ++i) {
+    if (out_ptrs[i] != nullptr) {
+      std::memcpy(out_ptrs[i], recv_stage_ + off[i],
+                  (size_t)want * keys_[i].row_bytes());
+    }
+  }
+  return want;
+}
+
+int Pool::RecvDevice(void** d_out_ptrs, int n_ptrs) {
+  std::lock_guard<std::mutex> lk(mu_);
+  if (n_ptrs < (int)keys_.size()) {
+    throw std::invalid_argument("recv_device: need one pointer per state key");
+  }
+  if (pending_.empty()) throw std::runtime_error("recv_device: nothing pending");
+  Batch* b = pending_.front();
+  if (b->consumed != 0) {
+    throw std::runtime_error("recv_device: batch partially consumed by recv");
+  }
+  pending_.pop_front();
+  for (size_t i = 0; i < keys_.size(); ++i) {
+    d_out_ptrs[i] = b->dbuf + b->offsets[i];
+  }
+  if (lent_[1]) ReleaseBatch(lent_[1]);
+  lent_[1] = lent_[0];
+  lent_[0] = b;
+  return b->k;
+}
+
+void Pool::Synchronize() {
+  EPA_HIP(hipSetDevice(cfg_.device));
+  EPA_HIP(hipStreamSynchronize(stream_));
+}
+
+void Pool::SetTiming(bool on) {
+  std::lock_guard<std::mutex> lk(mu_);
+  timing_ = on;
+}
+
+void Pool::KernelTime(double* avg_ms, int* launches) {
+  std::lock_guard<std::mutex> lk(mu_);
+  EPA_HIP(hipSetDevice(cfg_.device));
+  EPA_HIP(hipStreamSynchronize(stream_));
+  double tot = 0;
+  for (auto& t : timers_) {
+    float ms = 0;
+    EPA_HIP(hipEventElapsedTime(&ms, t.first, t.second));
+    tot += ms;
+    timer_pool_.push_back(t.first);
+    timer_pool_.push_back(t.second);
+  }
+  *launches = (int)timers_.size();
+  *avg_ms = timers_.empty() ? 0.0 : tot / timers_.size();
+  timers_.clear();
+}
+
+void Pool::GetStateHost(const int32_t* ids, int k, double* out) {
+  CheckIds(ids, k);
+  std::lock_guard<std::mutex> lk(mu_);
+  EPA_HIP(hipSetDevice(cfg_.device));
+  int dim = StateDim();
+  int* d_ids;
+  double* d_buf;
+  std::vector<int> local(ids, ids + k);
+  for (auto& v : local) v -= cfg_.env_id_offset;
+  EPA_HIP(hipMalloc(&d_ids, sizeof(int) * k));
+  EPA_HIP(hipMalloc(&d_buf, sizeof(double) * k * dim));
+  EPA_HIP(hipMemcpyAsync(d_ids, local.data(), sizeof(int) * k,
+                         hipMemcpyHostToDevice, stream_));
+  GetState(d_ids, k, d_buf);
+  EPA_HIP(hipMemcpyAsync(out, d_buf, sizeof(double) * k * dim,
+                         hipMemcpyDeviceToHost, stream_));
+  EPA_HIP(hipStreamSynchronize(stream_));
+  EPA_HIP(hipFree(d_ids));
+  EPA_HIP(hipFree(d_buf));
+}
+
+void Pool::SetStateHost(const int32_t* ids, int k, const double* in) {
+  CheckIds(ids, k);
+  std::lock_guard<std::mutex> lk(mu_);
+  EPA_HIP(hipSetDevice(cfg_.device));
+  int dim = StateDim();
+  int* d_ids;
+  double* d_buf;
+  std::vector<int> local(ids, ids + k);
+  for (auto& v : local) v -= cfg_.env_id_offset;
+  EPA_HIP(hipMalloc(&d_ids, sizeof(int) * k));
+  EPA_HIP(hipMalloc(&d_buf, sizeof(double) * k * dim));
+  EPA_HIP(hipMemcpyAsync(d_ids, local.data(), sizeof(int) * k,
+                         hipMemcpyHostToDevice, stream_));
+  EPA_HIP(hipMemcpyAsync(d_buf, in, sizeof(double) * k * dim,
+                         hipMemcpyHostToDevice, stream_));
+  SetState(d_ids, k, d_buf);
+  EPA_HIP(hipStreamSynchronize(stream_));
+  EPA_HIP(hipFree(d_ids));
+  EPA_HIP(hipFree(d_buf));
+}
+
+// ---------------------------------------------------------------------------
+// family registry
+// ---------------------------------------------------------------------------
+const std::vector<std::string>& FamilyNames() {
+  static const std::vector<std::string> names = {
+      "CartPole", "Pendulum", "MountainCar", "MountainCarContinuous", "Acrobot",
+      "Catch", "FrozenLake", "Taxi", "NChain", "CliffWalking", "Blackjack",
+      "HalfCheetah", "Ant"};
+  return names;
+}
+
+static bool Describe(const std::string& family, const Config& cfg,
+                     std::vector<KeySpec>* state, KeySpec* action) {
+  std::vector<KeySpec> env_keys;
+  bool ok = DescribeClassicControl(family, cfg, &env_keys, action) ||
+            DescribeToyText(family, cfg, &env_keys, action) ||
+            DescribeMujoco(family, cfg, &env_keys, action);
+  if (!ok) return false;
+  *state = CommonStateKeys();
+  for (auto& k : env_keys) state->push_back(k);
+  return true;
+}
+
+static Pool* Make(const std::string& family, const Config& cfg) {
+  Pool* p = MakeClassicControl(family, cfg);
+  if (!p) p = MakeToyText(family, cfg);
+  if (!p) p = MakeMujoco(family, cfg);
+  return p;
+}
+
+}  // namespace epa
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+struct epa_pool {
+  std::unique_ptr<epa::Pool> impl;
+};
+
+namespace {
+template <typename F>
+int Guard(F&& f) {
+  try {
+    f();
+    return EPA_OK;
+  } catch (const std::invalid_argument& e) {
+    epa::g_last_error = e.what();
+    return EPA_ERR_INVALID;
+  } catch (const epa::DeviceError& e) {
+    epa::g_last_error = e.what();
+    return EPA_ERR_DEVICE;
+  } catch (const std::exception& e) {
+    epa::g_last_error = e.what();
+    return EPA_ERR_RUNTIME;
+  }
+}
+
+thread_local std::vector<std::string> g_key_names;
+
+void FillKeyInfo(const std::vector<epa::KeySpec>& keys, epa_key_info* out,
+                 int cap, int* n) {
+  *n = (int)keys.size();
+  g_key_names.clear();
+  for (auto& k : keys) g_key_names.push_back(k.name);
+  for (int i = 0; i < (int)keys.size() && i < cap; ++i) {
+    out[i].name = g_key_names[i].c_str();
+    out[i].dtype = keys[i].dtype;
+    out[i].ndim = (int)keys[i].shape.size();
+    for (int d = 0; d < 4; ++d) {
+      out[i].shape[d] = d < out[i].ndim ? keys[i].shape[d] : 0;
+    }
+    out[i].row_elems = keys[i].row_elems();
+    out[i].row_bytes = keys[i].row_bytes();
+  }
+}
+
+// Describe must not require a valid num_envs/device.
+epa::Config LenientConfig(const epa_config* c) {
+  epa::Config r;
+  if (c != nullptr) {
+    for (int i = 0; i < c->n_params; ++i) {
+      r.params[c->param_keys[i]] = c->param_values[i];
+    }
+    if (c->num_envs > 0) r.num_envs = c->num_envs;
+  }
+  return r;
+}
+}  // namespace
+
+extern "C" {
+
+int epa_num_families(void) { return (int)epa::FamilyNames().size(); }
+const char* epa_family_name(int i) {
+  auto& n = epa::FamilyNames();
+  return (i >= 0 && i < (int)n.size()) ? n[i].c_str() : nullptr;
+}
+
+int epa_describe_state(const char* family, const epa_config* cfg,
+                       epa_key_info* keys, int cap, int* n) {
+  return Guard([&] {
+    std::vector<epa::KeySpec> st;
+    epa::KeySpec act;
+    if (!epa::Describe(family, LenientConfig(cfg), &st, &act)) {
+      throw std::invalid_argument(std::string("unknown env family: ") + family);
+    }
+    FillKeyInfo(st, keys, cap, n);
+  });
+}
+
+int epa_describe_action(const char* family, const epa_config* cfg,
+                        epa_key_info* keys, int cap, int* n) {
+  return Guard([&] {
+    std::vector<epa::KeySpec> st;
+    epa::KeySpec act;
+    if (!epa::Describe(family, LenientConfig(cfg), &st, &act)) {
+      throw std::invalid_argument(std::string("unknown env family: ") + family);
+    }
+    // common_action_spec, envpool/core/env_spec.h:32-35
+    std::vector<epa::KeySpec> a = {{"env_id", EPA_I32, {}},
+                                   {"players.env_id", EPA_I32, {}},
+                                   act};
+    FillKeyInfo(a, keys, cap, n);
+  });
+}
+
+int epa_create(const char* family, const epa_config* cfg, epa_pool** out) {
+  return Guard([&] {
+    if (out == nullptr || family == nullptr) {
+      throw std::invalid_argument("epa_create: null argument");
+    }
+    epa::Config c = epa::Config::From(cfg);
+    epa::Pool* p = epa::Make(family, c);
+    if (p == nullptr) {
+      throw std::invalid_argument(std::string("unknown env family: ") + family);
+    }
+    *out = new epa_pool{std::unique_ptr<epa::Pool>(p)};
+  });
+}
+
+int epa_destroy(epa_pool* pool) {
+  return Guard([&] { delete pool; });
+}
+
+int epa_send(epa_pool* pool, const int32_t* env_id, int32_t k,
+             const void* action) {
+  return Guard([&] { pool->impl->Send(env_id, k, action); });
+}
+
+int epa_reset(epa_pool* pool, const int32_t* env_ids, int32_t k) {
+  return Guard([&] { pool->impl->Reset(env_ids, k); });
+}
+
+int epa_recv(epa_pool* pool, void* const* out_ptrs, int32_t n_ptrs,
+             int32_t cap_rows, int32_t* k_out) {
+  return Guard([&] { *k_out = pool->impl->Recv(out_ptrs, n_ptrs, cap_rows); });
+}
+
+int epa_pending_rows(epa_pool* pool, int32_t* rows) {
+  return Guard([&] { *rows = pool->impl->PendingRows(); });
+}
+
+int epa_send_device(epa_pool* pool, const int32_t* d_env_id, int32_t k,
+                    const void* d_action) {
+  return Guard([&] { pool->impl->SendDevice(d_env_id, k, d_action); });
+}
+
+int epa_recv_device(epa_pool* pool, void** d_out_ptrs, int32_t n_ptrs,
+                    int32_t* k_out) {
+  return Guard([&] { *k_out = pool->impl->RecvDevice(d_out_ptrs, n_ptrs); });
+}
+
+void* epa_stream(epa_pool* pool) { return (void*)pool->impl->stream(); }
+
+int epa_synchronize(epa_pool* pool) {
+  return Guard([&] { pool->impl->Synchronize(); });
+}
+
+int epa_set_timing(epa_pool* pool, int32_t enabled) {
+  return Guard([&] { pool->impl->SetTiming(enabled != 0); });
+}
+
+int epa_kernel_time_ms(epa_pool* pool, double* avg_ms, int32_t* launches) {
+  return Guard([&] { pool->impl->KernelTime(avg_ms, launches); });
+}
+
+int epa_state_dim(epa_pool* pool, int32_t* dim) {
+  return Guard([&] { *dim = pool->impl->StateDim(); });
+}
+
+int epa_get_state(epa_pool* pool, const int32_t* env_ids, int32_t k,
+                  double* out) {
+  return Guard([&] { pool->impl->GetStateHost(env_ids, k, out); });
+}
+
+int epa_set_state(epa_pool* pool, const int32_t* env_ids, int32_t k,
+                  const double* in) {
+  return Guard([&] { pool->impl->SetStateHost(env_ids, k, in); });
+}
+
+const char* epa_last_error(void) { return epa::g_last_error.c_str(); }
+const char* epa_version(void) { return "envpool_amd 0.1 (gfx950)"; }
+
+int epa_device_count(int32_t* n) {
+  return Guard([&] {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) c = 0;
+    *n = c;
+  });
+}
+
+void* epa_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void epa_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+}  // extern "C"

@@ -1,0 +1,211 @@
+/*
+ * envpool_amd — C ABI of the MI355X-native batched-step engine.
+ *
+ * This is the drop-in boundary for ONE path of sail-sg/envpool: the batched
+ * Send()/Recv()/Reset() execution path.  In the reference that path is the
+ * C++ virtual class `EnvPool<Spec>` (envpool/core/envpool.h:29-56) implemented
+ * by `AsyncEnvPool<Env>` (envpool/core/async_envpool.h:42-238: thread pool +
+ * ActionBufferQueue + StateBufferQueue) and bound to Python by
+ * `PyEnvPool<Pool>` (envpool/core/py_envpool.h:206-288).  Here the thread pool
+ * and the queues are replaced by device-resident SoA env state and one batched
+ * HIP kernel per env family; everything above (`PySend/PyRecv/PyReset`, the
+ * Python adaptors) can stay and bind to the functions below
+ * (see INTEGRATION.md for the pybind11 / ctypes stubs).
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on failure;
+ *    `epa_last_error()` then holds a message (thread local).  Error classes
+ *    follow the reference: EPA_ERR_INVALID  <-> std::invalid_argument
+ *    (-> Python ValueError, envpool/core/env_spec.h:75-80), EPA_ERR_RUNTIME <->
+ *    std::runtime_error (-> RuntimeError).
+ *  - plain pointers and sizes only; no C++/torch types.
+ *  - arrays are C-contiguous, row-major, one row per env in the batch.
+ *  - key order is the reference's (envpool/core/env_spec.h:32-43):
+ *      actions: "env_id", "players.env_id", <env action keys...>
+ *      states : "info:env_id", "info:players.env_id", "elapsed_step", "done",
+ *               "reward", "discount", "step_type", "trunc", <env state keys...>
+ */
+#ifndef ENVPOOL_AMD_H_
+#define ENVPOOL_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPA_OK 0
+#define EPA_ERR_INVALID 1 /* std::invalid_argument in the reference */
+#define EPA_ERR_RUNTIME 2 /* std::runtime_error in the reference */
+#define EPA_ERR_DEVICE 3  /* HIP failure (no reference analogue) */
+
+/* element types of state / action arrays */
+#define EPA_I32 0
+#define EPA_F32 1
+#define EPA_F64 2
+#define EPA_BOOL 3 /* 1 byte, numpy bool_ */
+#define EPA_U8 4
+
+typedef struct epa_pool epa_pool;
+
+/*
+ * Pool configuration = the reference's `common_config`
+ * (envpool/core/env_spec.h:26-31) restricted to what the step path reads, plus
+ * per-family numeric options passed as (key, value) pairs named exactly like
+ * the reference's `XxxEnvFns::DefaultConfig()` keys (e.g. "version" for
+ * Pendulum, "size" for FrozenLake, "frame_skip", "ctrl_cost_weight", ...).
+ */
+typedef struct epa_config {
+  int32_t num_envs;          /* common_config "num_envs" */
+  int32_t batch_size;        /* "batch_size"; 0 => num_envs (env_spec.h:81-83) */
+  int32_t seed;              /* "seed": env i is seeded seed + i (env.h:109) */
+  const int32_t* env_seed;   /* "env_seed": NULL or num_envs explicit seeds */
+  int32_t max_episode_steps; /* "max_episode_steps"; <=0 => INT_MAX */
+  int32_t device;            /* HIP device ordinal (extension) */
+  int32_t env_id_offset;     /* global id of local env 0 when a pool is one
+                                shard of a multi-GPU pool (extension) */
+  int32_t n_params;
+  const char* const* param_keys;
+  const double* param_values;
+} epa_config;
+
+/* One state or action key. `shape` excludes the leading batch dimension
+ * (the reference's -1 player dimension is dropped: all hot-path envs are
+ * single-player). */
+typedef struct epa_key_info {
+  const char* name;
+  int32_t dtype;
+  int32_t ndim;
+  int32_t shape[4];
+  int32_t row_elems; /* product of shape (1 for scalars) */
+  int32_t row_bytes;
+} epa_key_info;
+
+/* ---- spec queries: no GPU needed ------------------------------------- */
+
+/* Number of env families compiled in and their names ("CartPole", ...). */
+int epa_num_families(void);
+const char* epa_family_name(int i);
+
+/* Describe the state/action keys a family would produce for `cfg`
+ * (replaces EnvSpec<Fns>::{state_spec,action_spec}, env_spec.h:48-85).
+ * Writes up to `cap` entries; returns the total number through *n. */
+int epa_describe_state(const char* family, const epa_config* cfg,
+                       epa_key_info* keys, int cap, int* n);
+int epa_describe_action(const char* family, const epa_config* cfg,
+                        epa_key_info* keys, int cap, int* n);
+
+/* ---- pool lifetime ---------------------------------------------------- */
+
+/* Replaces AsyncEnvPool<Env>::AsyncEnvPool(spec) (async_envpool.h:90-149):
+ * allocates SoA state for num_envs envs on `cfg->device`, seeds every env's
+ * mt19937 (env.h:101-117) and marks every env done so that the first step is a
+ * reset (cartpole.h:67 `done_{true}`, async_envpool.h:127). */
+int epa_create(const char* family, const epa_config* cfg, epa_pool** out);
+
+/* Replaces ~AsyncEnvPool (async_envpool.h:151-162). */
+int epa_destroy(epa_pool* pool);
+
+/* ---- host path: the reference's Send / Recv / Reset -------------------- */
+
+/* Replaces AsyncEnvPool::Send(vector<Array>) (async_envpool.h:59-82,163-167).
+ * `env_id[k]` int32, `action` = k rows of the family's action key in its
+ * reference dtype.  Copies both into pinned staging (the caller may free its
+ * buffers on return), enqueues H2D + one batched step kernel on the pool's
+ * stream and returns immediately.  Row i of the resulting batch belongs to
+ * env_id[i] (sync-mode ordering, state_buffer.h:94-97). */
+int epa_send(epa_pool* pool, const int32_t* env_id, int32_t k,
+             const void* action);
+
+/* Replaces AsyncEnvPool::Reset(env_ids) (async_envpool.h:224-237): forced
+ * reset of the listed envs; the result arrives through epa_recv. */
+int epa_reset(epa_pool* pool, const int32_t* env_ids, int32_t k);
+
+/* Replaces AsyncEnvPool::Recv() (async_envpool.h:169-181).  Blocks until the
+ * oldest pending rows are computed, copies them device->host into
+ * `out_ptrs[key]` (one buffer per state key, each with room for `cap_rows`
+ * rows) and returns the number of rows through *k_out.
+ *   sync  mode (batch_size == num_envs): returns the whole oldest send/reset
+ *         batch (k rows, possibly < num_envs for a partial env_id send).
+ *   async mode (batch_size <  num_envs): returns exactly batch_size rows in
+ *         completion (= submission) order, a legal schedule of
+ *         state_buffer_queue.h:123-163.
+ * EPA_ERR_RUNTIME if nothing is pending (the reference would block forever). */
+int epa_recv(epa_pool* pool, void* const* out_ptrs, int32_t n_ptrs,
+             int32_t cap_rows, int32_t* k_out);
+
+/* Rows currently computed-or-in-flight and not yet received. */
+int epa_pending_rows(epa_pool* pool, int32_t* rows);
+
+/* ---- device path (zero-copy; the analogue of envpool/core/xla.h:116-213
+ *      without the host staging the reference does there) ---------------- */
+
+/* Like epa_send but `d_env_id` (may be NULL = all envs in order) and
+ * `d_action` are device pointers on the pool's device; the kernel is enqueued
+ * on the pool's stream after `wait_event` (may be NULL). */
+int epa_send_device(epa_pool* pool, const int32_t* d_env_id, int32_t k,
+                    const void* d_action);
+
+/* Hands out device pointers (one per state key) to the oldest pending batch.
+ * The pointers stay valid until the second next epa_recv_device call on this
+ * pool (batches are double buffered).  Does not synchronise the host: work
+ * enqueued on epa_stream() after this call is ordered after the step kernel. */
+int epa_recv_device(epa_pool* pool, void** d_out_ptrs, int32_t n_ptrs,
+                    int32_t* k_out);
+
+/* hipStream_t of the pool, as void*. */
+void* epa_stream(epa_pool* pool);
+int epa_synchronize(epa_pool* pool);
+
+/* Average duration in ms of the step kernels launched since the last call,
+ * measured with HIP events on the pool's stream; *launches = how many.
+ * Timing must be enabled with epa_set_timing(pool, 1). */
+int epa_set_timing(epa_pool* pool, int32_t enabled);
+int epa_kernel_time_ms(epa_pool* pool, double* avg_ms, int32_t* launches);
+
+/* Test hooks: read / overwrite the persistent state of the listed envs as the
+ * family's flat double vector (CartPole: x,x_dot,theta,theta_dot; HalfCheetah:
+ * qpos[9],qvel[9],qacc_warmstart[9],time ...).  Mirrors the reference's
+ * ENVPOOL_TEST-only `info:qpos0/qvel0` state sync
+ * (envpool/mujoco/gym/half_cheetah.h:50-53,112-115). */
+int epa_state_dim(epa_pool* pool, int32_t* dim);
+int epa_get_state(epa_pool* pool, const int32_t* env_ids, int32_t k,
+                  double* out);
+int epa_set_state(epa_pool* pool, const int32_t* env_ids, int32_t k,
+                  const double* in);
+
+/* ---- Atari post-process (K4): max-pool of the last two ALE frames, resize
+ *      to 84x84, push into the frame stack (replaces AtariEnv::PushStack,
+ *      envpool/atari/atari_env.h:308-346 + envpool/utils/image_process.h:27-36).
+ *      See epa_atari_* in this header's companion section below. */
+typedef struct epa_atari_post epa_atari_post;
+int epa_atari_post_create(int32_t num_envs, int32_t stack_num, int32_t in_h,
+                          int32_t in_w, int32_t out_h, int32_t out_w,
+                          int32_t use_inter_area, int32_t device,
+                          epa_atari_post** out);
+int epa_atari_post_destroy(epa_atari_post* p);
+/* frames: [k, 2, in_h, in_w] u8 (the two max-pool buffers, host memory);
+ * reset_mask[k] u8: 1 => replicate the new frame into every stack slot
+ * (atari_env.h:330-337).  obs_out: [k, stack_num, out_h, out_w] u8 host. */
+int epa_atari_post_push(epa_atari_post* p, const int32_t* env_id, int32_t k,
+                        const uint8_t* frames, const uint8_t* reset_mask,
+                        uint8_t* obs_out);
+/* device-resident variant: all pointers are device pointers. */
+int epa_atari_post_push_device(epa_atari_post* p, const int32_t* d_env_id,
+                               int32_t k, const uint8_t* d_frames,
+                               const uint8_t* d_reset_mask, uint8_t* d_obs_out);
+void* epa_atari_post_stream(epa_atari_post* p);
+
+/* ---- misc -------------------------------------------------------------- */
+const char* epa_last_error(void);
+const char* epa_version(void);
+int epa_device_count(int32_t* n);
+/* pinned host memory for zero-copy numpy hand-off (py_envpool.h:40-49) */
+void* epa_host_alloc(size_t bytes);
+void epa_host_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENVPOOL_AMD_H_ */

@@ -7,3 +7,6 @@ int mjcpu_action_info(void* h, int* d, int* e) { (void)h;(void)d;(void)e; return
 void mjcpu_reset(void* h, const int* ids, int k, void** out) { (void)h;(void)ids;(void)k;(void)out; }
 void mjcpu_step(void* h, const int* ids, int k, const void* a, void** out) { (void)h;(void)ids;(void)k;(void)a;(void)out; }
 void mjcpu_destroy(void* h) { (void)h; }
+int mjcpu_state_dim(void* h) { (void)h; return 0; }
+void mjcpu_get_state(void* h, const int* ids, int k, double* o) { (void)h;(void)ids;(void)k;(void)o; }
+void mjcpu_set_state(void* h, const int* ids, int k, const double* o) { (void)h;(void)ids;(void)k;(void)o; }

@@ -167,6 +167,30 @@ class Oracle:
         assert action.size == self.num_envs * self.action_elems
         return self.lib.orc_time_steps(self.h, steps, action.ctypes.data)
 
+    # teacher-forcing hooks (port oracle only)
+    def state_dim(self) -> int:
+        self.lib.orc_state_dim.argtypes = [ctypes.c_void_p]
+        return self.lib.orc_state_dim(self.h)
+
+    def get_state(self, ids: np.ndarray | None = None) -> np.ndarray:
+        if ids is None:
+            ids = np.arange(self.num_envs, dtype=np.int32)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        out = np.zeros((len(ids), self.state_dim()), dtype=np.float64)
+        self.lib.orc_get_state.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int, ctypes.c_void_p]
+        self.lib.orc_get_state.restype = None
+        self.lib.orc_get_state(self.h, ids.ctypes.data, len(ids), out.ctypes.data)
+        return out
+
+    def set_state(self, state: np.ndarray, ids: np.ndarray | None = None) -> None:
+        if ids is None:
+            ids = np.arange(self.num_envs, dtype=np.int32)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        state = np.ascontiguousarray(state, dtype=np.float64)
+        self.lib.orc_set_state.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int, ctypes.c_void_p]
+        self.lib.orc_set_state.restype = None
+        self.lib.orc_set_state(self.h, ids.ctypes.data, len(ids), state.ctypes.data)
+
     def close(self) -> None:
         if self.h:
             self.lib.orc_destroy(self.h)

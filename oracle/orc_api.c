@@ -15,6 +15,8 @@ int restate_action_info(void*, int*, int*);
 void restate_reset(void*, const int*, int, void**);
 void restate_step(void*, const int*, int, const void*, void**);
 void restate_destroy(void*);
+void restate_get_state(void*, const int*, int, double*);
+void restate_set_state(void*, const int*, int, const double*);
 
 void* mjcpu_create(const char*, int, int, int, const double*, int);
 int mjcpu_num_state_keys(void*);
@@ -23,6 +25,9 @@ int mjcpu_action_info(void*, int*, int*);
 void mjcpu_reset(void*, const int*, int, void**);
 void mjcpu_step(void*, const int*, int, const void*, void**);
 void mjcpu_destroy(void*);
+int mjcpu_state_dim(void*);
+void mjcpu_get_state(void*, const int*, int, double*);
+void mjcpu_set_state(void*, const int*, int, const double*);
 
 typedef struct {
   int kind; /* 0 restate, 1 mjcpu */
@@ -102,6 +107,22 @@ void orc_destroy(void* h) {
   if (hd->kind == 0) restate_destroy(hd->h);
   else mjcpu_destroy(hd->h);
   free(hd);
+}
+
+/* flat per-env state for teacher-forced parity tests */
+int orc_state_dim(void* h) {
+  handle* hd = (handle*)h;
+  return hd->kind == 0 ? 7 : mjcpu_state_dim(hd->h);
+}
+void orc_get_state(void* h, const int* ids, int k, double* out) {
+  handle* hd = (handle*)h;
+  if (hd->kind == 0) restate_get_state(hd->h, ids, k, out);
+  else mjcpu_get_state(hd->h, ids, k, out);
+}
+void orc_set_state(void* h, const int* ids, int k, const double* in) {
+  handle* hd = (handle*)h;
+  if (hd->kind == 0) restate_set_state(hd->h, ids, k, in);
+  else mjcpu_set_state(hd->h, ids, k, in);
 }
 
 const char* orc_kind(void) { return "port"; }

@@ -796,3 +796,25 @@ void restate_destroy(void* h) {
   free(pi->p.envs);
   free(pi);
 }
+
+/* Test hooks: flat per-env state [s0..s4, done, current_step] (classic) so a
+ * test can teacher-force the HIP engine from the oracle's exact fp64 state. */
+void restate_get_state(void* h, const int* ids, int k, double* out) {
+  orc_pool* p = &((pool_impl*)h)->p;
+  for (int i = 0; i < k; ++i) {
+    orc_env* e = &p->envs[ids[i]];
+    for (int j = 0; j < 5; ++j) out[i * 7 + j] = e->s[j];
+    out[i * 7 + 5] = e->done;
+    out[i * 7 + 6] = e->current_step;
+  }
+}
+void restate_set_state(void* h, const int* ids, int k, const double* in) {
+  orc_pool* p = &((pool_impl*)h)->p;
+  for (int i = 0; i < k; ++i) {
+    orc_env* e = &p->envs[ids[i]];
+    for (int j = 0; j < 5; ++j) e->s[j] = in[i * 7 + j];
+    e->done = in[i * 7 + 5] != 0.0;
+    e->current_step = (int)in[i * 7 + 6];
+    e->elapsed_step = e->current_step;
+  }
+}

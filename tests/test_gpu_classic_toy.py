@@ -1,0 +1,196 @@
+"""GPU parity: HIP engine (through the C ABI) vs the pinned oracle.
+
+* toy_text: bit-exact, free running, auto-resets included.
+* classic_control: (a) golden rollouts of the reference; (b) teacher-forced
+  single-step parity <= 4 ulp(fp32) on obs; (c) free-running horizon.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.orc import Oracle
+from oracle_cases import CASES, INTEGER_EXACT, sample_actions
+from hip_util import HipAsOracle, make_hip_pool
+from test_oracle_pinned import replay_golden
+
+pytestmark = pytest.mark.gpu
+
+CLASSIC = sorted(set(CASES) - INTEGER_EXACT)
+NS = {"CartPole": 4, "Pendulum": 2, "MountainCar": 2,
+      "MountainCarContinuous": 2, "Acrobot": 5}
+
+
+def ulp_diff_f32(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)
+
+
+@pytest.mark.parametrize("name", sorted(INTEGER_EXACT))
+def test_toy_text_bit_exact_golden(name):
+    def make(n, seed):
+        return HipAsOracle(make_hip_pool(name, n, seed))
+
+    for key, want, got in replay_golden(make, name):
+        assert got.dtype == want.dtype, key
+        assert np.array_equal(got, want), f"{name}:{key}"
+
+
+@pytest.mark.parametrize("name", sorted(INTEGER_EXACT))
+def test_toy_text_bit_exact_long(name):
+    c = CASES[name]
+    n, steps = 256, 3000
+    hip = HipAsOracle(make_hip_pool(name, n, 11))
+    orc = Oracle(c["task"], n, seed=11, max_episode_steps=c["max_steps"],
+                 extra=c["extra"], kind="port")
+    a, b = hip.reset(), orc.reset()
+    rng = np.random.default_rng(5)
+    n_done = 0
+    for t in range(steps):
+        for k in b:
+            assert np.array_equal(a[k], b[k]), (name, t, k)
+        n_done += int(b["done"].sum())
+        act = sample_actions(c, rng, n)
+        a, b = hip.step(act), orc.step(act)
+    assert n_done > 0  # auto-reset path exercised
+
+
+@pytest.mark.parametrize("name", CLASSIC)
+def test_classic_golden_rollout(name):
+    """Free-running vs the reference's golden rollout: integer keys exact;
+    float keys within 1e-5 rel for the first 50 steps (B.2 #2b)."""
+    def make(n, seed):
+        return HipAsOracle(make_hip_pool(name, n, seed))
+
+    for key, want, got in replay_golden(make, name):
+        if want.dtype == np.float32:
+            np.testing.assert_allclose(got[:51], want[:51], rtol=1e-5, atol=1e-6,
+                                       err_msg=f"{name}:{key}")
+        else:
+            assert np.array_equal(got[:51], want[:51]), f"{name}:{key}"
+
+
+@pytest.mark.parametrize("name", CLASSIC)
+def test_classic_teacher_forced(name):
+    c = CASES[name]
+    n, steps = 512, 400
+    pool = make_hip_pool(name, n, 3)
+    hip = HipAsOracle(pool)
+    orc = Oracle(c["task"], n, seed=3, max_episode_steps=c["max_steps"],
+                 extra=c["extra"], kind="port")
+    a, b = hip.reset(), orc.reset()
+    for k in b:  # resets draw from the bit-exact RNG
+        assert np.array_equal(a[k], b[k]), (name, "reset", k)
+    ns = NS[c["task"]]
+    rng = np.random.default_rng(8)
+    worst = 0
+    for t in range(steps):
+        st = orc.get_state()  # [s0..s4, done, cur_step]
+        pool.set_state(np.concatenate([st[:, :ns], st[:, 5:7]], axis=1))
+        act = sample_actions(c, rng, n)
+        a, b = hip.step(act), orc.step(act)
+        for k in b:
+            if b[k].dtype == np.float32:
+                d = int(ulp_diff_f32(a[k], b[k]).max())
+                worst = max(worst, d)
+                assert d <= 4, (name, t, k, d)
+            else:
+                assert np.array_equal(a[k], b[k]), (name, t, k)
+    print(f"{name}: worst teacher-forced obs/reward diff = {worst} ulp(fp32)")
+
+
+@pytest.mark.parametrize("name", CLASSIC)
+def test_classic_free_running_horizon(name):
+    """Report (and bound from below) how long the HIP rollout stays bit-identical
+    to the oracle when both run freely; device libm sin/cos is the only source
+    of divergence (-ffp-contract=off everywhere else)."""
+    c = CASES[name]
+    n, steps = 256, 600
+    hip = HipAsOracle(make_hip_pool(name, n, 21))
+    orc = Oracle(c["task"], n, seed=21, max_episode_steps=c["max_steps"],
+                 extra=c["extra"], kind="port")
+    a, b = hip.reset(), orc.reset()
+    rng = np.random.default_rng(2)
+    first_bitdiff = None
+    first_1e5 = None
+    for t in range(steps):
+        act = sample_actions(c, rng, n)
+        a, b = hip.step(act), orc.step(act)
+        if first_bitdiff is None and not np.array_equal(a["obs"], b["obs"]):
+            first_bitdiff = t
+        if first_1e5 is None and not np.allclose(a["obs"], b["obs"], rtol=1e-5,
+                                                 atol=1e-6):
+            first_1e5 = t
+    print(f"{name}: first bit difference at step {first_bitdiff}, "
+          f"first >1e-5 rel difference at step {first_1e5}")
+    assert first_1e5 is None or first_1e5 >= 50
+
+
+def test_partial_env_id_and_order():
+    """sync mode with a subset of env ids: rows come back in send order."""
+    n = 64
+    pool = make_hip_pool("CartPole-v1", n, 1)
+    hip = HipAsOracle(pool)
+    orc = Oracle("CartPole", n, seed=1, max_episode_steps=500, kind="port")
+    hip.reset(), orc.reset()
+    ids = np.array([5, 2, 61, 7, 33], dtype=np.int32)
+    rng = np.random.default_rng(0)
+    for _ in range(60):
+        act = sample_actions(CASES["CartPole-v1"], rng, len(ids))
+        a, b = hip.step(act, ids), orc.step(act, ids)
+        assert np.array_equal(a["info:env_id"].ravel(), ids)
+        for k in b:
+            if b[k].dtype == np.float32:
+                np.testing.assert_allclose(a[k], b[k], rtol=1e-6, atol=1e-7)
+            else:
+                assert np.array_equal(a[k], b[k]), k
+
+
+def test_env_seed_list_and_offset():
+    n = 16
+    seeds = [100 - 3 * i for i in range(n)]
+    p1 = make_hip_pool("Taxi-v3", n, 0, env_seed=seeds)
+    a = HipAsOracle(p1).reset()
+    # same seeds expressed as seed + id
+    for i in (0, 5, 15):
+        q = make_hip_pool("Taxi-v3", 1, seeds[i])
+        b = HipAsOracle(q).reset()
+        assert a["obs"][i, 0] == b["obs"][0, 0]
+    # shard offset: local env j of a shard at offset o behaves like global o+j
+    full = HipAsOracle(make_hip_pool("Taxi-v3", n, 7)).reset()
+    shard = make_hip_pool("Taxi-v3", 8, 7, env_id_offset=8)
+    shard.reset(np.arange(8, 16, dtype=np.int32))
+    s = shard.recv_dict()
+    assert np.array_equal(s["obs"].ravel(), full["obs"][8:].ravel())
+    assert np.array_equal(s["info:env_id"].ravel(), np.arange(8, 16))
+
+
+def test_async_mode_batches():
+    """batch_size < num_envs: recv returns exactly batch_size rows."""
+    n, b = 32, 8
+    pool = make_hip_pool("CartPole-v1", n, 0, batch_size=b)
+    pool.reset(np.arange(n, dtype=np.int32))
+    seen = []
+    for _ in range(n // b):
+        d = pool.recv_dict()
+        assert d["obs"].shape == (b, 4)
+        seen += d["info:env_id"].tolist()
+    assert sorted(seen) == list(range(n))
+    ids = np.array(seen[:b], dtype=np.int32)
+    pool.send(ids, np.zeros(b, dtype=np.int32))
+    d = pool.recv_dict()
+    assert d["info:env_id"].tolist() == ids.tolist()
+    assert (d["elapsed_step"] == 1).all()
+
+
+def test_errors():
+    pool = make_hip_pool("CartPole-v1", 4, 0)
+    with pytest.raises(RuntimeError):
+        pool.recv()  # nothing pending
+    with pytest.raises(ValueError):
+        pool.reset(np.array([7], dtype=np.int32))  # id out of range
+    with pytest.raises(ValueError):
+        make_hip_pool("CartPole-v1", 4, 0, batch_size=9)
