@@ -1,0 +1,207 @@
+/* TEST INFRASTRUCTURE — NOT PRODUCT CODE.  See mjcpu.h (PARITY UNPINNED).
+ *
+ * Hand transcription of the two gym MJCF models the reference loads
+ * (envpool/mujoco/gym/mujoco_env.h:50-58 prefers the `_envpool.xml` variants):
+ *   third_party/mujoco_gym_xml_patches/half_cheetah_envpool.xml
+ *   third_party/mujoco_gym_xml_patches/ant_envpool.xml
+ * Numbers are cited by XML line (":NN").
+ */
+#include <math.h>
+#include <string.h>
+
+#include "mjcpu.h"
+
+static const double kZero3[3] = {0, 0, 0};
+
+/* ---- HalfCheetah ------------------------------------------------------------ */
+static int cheetah_geom_defaults(mjc_model* m, int g) {
+  /* <geom conaffinity="0" condim="3" contype="1" friction=".4 .1 .1"
+   *  solimp="0.0 0.8 0.01" solref="0.02 1"/>  :55 */
+  m->geom_conaffinity[g] = 0;
+  m->geom_contype[g] = 1;
+  m->geom_condim[g] = 3;
+  m->geom_friction[g][0] = 0.4;
+  m->geom_friction[g][1] = 0.1;
+  m->geom_friction[g][2] = 0.1;
+  m->geom_solimp[g][0] = 0.0;
+  m->geom_solimp[g][1] = 0.8;
+  m->geom_solimp[g][2] = 0.01;
+  m->geom_solref[g][0] = 0.02;
+  m->geom_solref[g][1] = 1;
+  return g;
+}
+
+static int cheetah_hinge(mjc_model* m, int body, double lo, double hi,
+                         double stiffness, double damping) {
+  /* <joint armature=".1" damping=".01" limited="true" solimplimit="0 .8 .03"
+   *  solreflimit=".02 1" stiffness="8"/>  :54, per-joint overrides :79-97 */
+  const double axis[3] = {0, 1, 0};
+  int j = mjc_add_joint(m, body, MJC_JNT_HINGE, kZero3, axis, 1, lo, hi,
+                        stiffness, damping, 0.1);
+  m->jnt_solimp[j][0] = 0;
+  m->jnt_solimp[j][1] = 0.8;
+  m->jnt_solimp[j][2] = 0.03;
+  m->jnt_solref[j][0] = 0.02;
+  m->jnt_solref[j][1] = 1;
+  return j;
+}
+
+void mjc_build_half_cheetah(mjc_model* m) {
+  const double yaxis[3] = {0, 1, 0}, xaxis[3] = {1, 0, 0}, zaxis[3] = {0, 0, 1};
+  mjc_model_init(m);
+  m->timestep = 0.01; /* :59 */
+  m->gravity[2] = -9.81;
+  m->integrator = MJC_INT_EULER; /* default */
+  m->settotalmass = 14;          /* :52 */
+  /* floor :69 */
+  {
+    const double size[3] = {40, 40, 40}, quat[4] = {1, 0, 0, 0};
+    int g = cheetah_geom_defaults(
+        m, mjc_add_geom(m, 0, MJC_GEOM_PLANE, size, kZero3, quat));
+    m->geom_conaffinity[g] = 1;
+  }
+  /* torso :70-77 */
+  const double torso_pos[3] = {0, 0, 0.7};
+  int torso = mjc_add_body(m, 0, torso_pos);
+  mjc_add_joint(m, torso, MJC_JNT_SLIDE, kZero3, xaxis, 0, 0, 0, 0, 0, 0);
+  mjc_add_joint(m, torso, MJC_JNT_SLIDE, kZero3, zaxis, 0, 0, 0, 0, 0, 0);
+  mjc_add_joint(m, torso, MJC_JNT_HINGE, kZero3, yaxis, 0, 0, 0, 0, 0, 0);
+  {
+    const double from[3] = {-0.5, 0, 0}, to[3] = {0.5, 0, 0};
+    cheetah_geom_defaults(m, mjc_add_capsule_fromto(m, torso, from, to, 0.046));
+    const double hp[3] = {0.6, 0, 0.1};
+    cheetah_geom_defaults(
+        m, mjc_add_capsule_axisangle(m, torso, hp, yaxis, 0.87, 0.046, 0.15));
+  }
+  /* back leg :78-91 */
+  const double bthigh_pos[3] = {-0.5, 0, 0};
+  int bthigh = mjc_add_body(m, torso, bthigh_pos);
+  int j_bthigh = cheetah_hinge(m, bthigh, -0.52, 1.05, 240, 6);
+  {
+    const double p[3] = {0.1, 0, -0.13};
+    cheetah_geom_defaults(
+        m, mjc_add_capsule_axisangle(m, bthigh, p, yaxis, -3.8, 0.046, 0.145));
+  }
+  const double bshin_pos[3] = {0.16, 0, -0.25};
+  int bshin = mjc_add_body(m, bthigh, bshin_pos);
+  int j_bshin = cheetah_hinge(m, bshin, -0.785, 0.785, 180, 4.5);
+  {
+    const double p[3] = {-0.14, 0, -0.07};
+    cheetah_geom_defaults(
+        m, mjc_add_capsule_axisangle(m, bshin, p, yaxis, -2.03, 0.046, 0.15));
+  }
+  const double bfoot_pos[3] = {-0.28, 0, -0.14};
+  int bfoot = mjc_add_body(m, bshin, bfoot_pos);
+  int j_bfoot = cheetah_hinge(m, bfoot, -0.4, 0.785, 120, 3);
+  {
+    const double p[3] = {0.03, 0, -0.097};
+    cheetah_geom_defaults(
+        m, mjc_add_capsule_axisangle(m, bfoot, p, yaxis, -0.27, 0.046, 0.094));
+  }
+  /* front leg :92-105 */
+  const double fthigh_pos[3] = {0.5, 0, 0};
+  int fthigh = mjc_add_body(m, torso, fthigh_pos);
+  int j_fthigh = cheetah_hinge(m, fthigh, -1, 0.7, 180, 4.5);
+  {
+    const double p[3] = {-0.07, 0, -0.12};
+    cheetah_geom_defaults(
+        m, mjc_add_capsule_axisangle(m, fthigh, p, yaxis, 0.52, 0.046, 0.133));
+  }
+  const double fshin_pos[3] = {-0.14, 0, -0.24};
+  int fshin = mjc_add_body(m, fthigh, fshin_pos);
+  int j_fshin = cheetah_hinge(m, fshin, -1.2, 0.87, 120, 3);
+  {
+    const double p[3] = {0.065, 0, -0.09};
+    cheetah_geom_defaults(
+        m, mjc_add_capsule_axisangle(m, fshin, p, yaxis, -0.6, 0.046, 0.106));
+  }
+  const double ffoot_pos[3] = {0.13, 0, -0.18};
+  int ffoot = mjc_add_body(m, fshin, ffoot_pos);
+  int j_ffoot = cheetah_hinge(m, ffoot, -0.5, 0.5, 60, 1.5);
+  {
+    const double p[3] = {0.045, 0, -0.07};
+    cheetah_geom_defaults(
+        m, mjc_add_capsule_axisangle(m, ffoot, p, yaxis, -0.6, 0.046, 0.07));
+  }
+  /* actuators :108-115 */
+  mjc_add_motor(m, j_bthigh, 120);
+  mjc_add_motor(m, j_bshin, 90);
+  mjc_add_motor(m, j_bfoot, 60);
+  mjc_add_motor(m, j_fthigh, 120);
+  mjc_add_motor(m, j_fshin, 60);
+  mjc_add_motor(m, j_ffoot, 30);
+  mjc_compile(m);
+}
+
+/* ---- Ant ----------------------------------------------------------------------- */
+static int ant_geom_defaults(mjc_model* m, int g) {
+  /* <geom conaffinity="0" condim="3" density="5.0" friction="1 0.5 0.5"
+   *  margin="0.01"/>  :25 */
+  m->geom_conaffinity[g] = 0;
+  m->geom_contype[g] = 1;
+  m->geom_condim[g] = 3;
+  m->geom_density[g] = 5.0;
+  m->geom_friction[g][0] = 1;
+  m->geom_friction[g][1] = 0.5;
+  m->geom_friction[g][2] = 0.5;
+  m->geom_margin[g] = 0.01;
+  return g;
+}
+
+static int ant_leg(mjc_model* m, int torso, double sx, double sy,
+                   const double ankle_axis[3], double ankle_lo,
+                   double ankle_hi, int* hip, int* ankle) {
+  const double deg = 3.14159265358979323846 / 180.0; /* angle="degree" :18 */
+  const double zaxis[3] = {0, 0, 1};
+  /* <joint armature="1" damping="1" limited="true"/> :24 */
+  int leg = mjc_add_body(m, torso, kZero3);
+  const double a[3] = {0.2 * sx, 0.2 * sy, 0}, b[3] = {0.4 * sx, 0.4 * sy, 0};
+  ant_geom_defaults(m, mjc_add_capsule_fromto(m, leg, kZero3, a, 0.08));
+  int aux = mjc_add_body(m, leg, a);
+  *hip = mjc_add_joint(m, aux, MJC_JNT_HINGE, kZero3, zaxis, 1, -30 * deg,
+                       30 * deg, 0, 1, 1);
+  ant_geom_defaults(m, mjc_add_capsule_fromto(m, aux, kZero3, a, 0.08));
+  int foot = mjc_add_body(m, aux, a);
+  *ankle = mjc_add_joint(m, foot, MJC_JNT_HINGE, kZero3, ankle_axis, 1,
+                         ankle_lo * deg, ankle_hi * deg, 0, 1, 1);
+  ant_geom_defaults(m, mjc_add_capsule_fromto(m, foot, kZero3, b, 0.08));
+  return leg;
+}
+
+void mjc_build_ant(mjc_model* m) {
+  mjc_model_init(m);
+  m->timestep = 0.01;          /* :19 */
+  m->integrator = MJC_INT_RK4; /* :19 */
+  m->gravity[2] = -9.81;       /* MuJoCo default */
+  {                            /* floor :34 */
+    const double size[3] = {40, 40, 40}, quat[4] = {1, 0, 0, 0};
+    int g = ant_geom_defaults(
+        m, mjc_add_geom(m, 0, MJC_GEOM_PLANE, size, kZero3, quat));
+    m->geom_conaffinity[g] = 1;
+  }
+  const double torso_pos[3] = {0, 0, 0.75}; /* :35 */
+  int torso = mjc_add_body(m, 0, torso_pos);
+  {
+    const double size[3] = {0.25, 0, 0}, quat[4] = {1, 0, 0, 0}; /* :37 */
+    ant_geom_defaults(m,
+                      mjc_add_geom(m, torso, MJC_GEOM_SPHERE, size, kZero3, quat));
+  }
+  /* <joint armature="0" damping="0" limited="false" type="free"/> :38 */
+  mjc_add_joint(m, torso, MJC_JNT_FREE, kZero3, kZero3, 0, 0, 0, 0, 0, 0);
+  int hip[5], ankle[5];
+  const double ax_m11[3] = {-1, 1, 0}, ax_11[3] = {1, 1, 0};
+  ant_leg(m, torso, 1, 1, ax_m11, 30, 70, &hip[1], &ankle[1]);    /* :39-49 */
+  ant_leg(m, torso, -1, 1, ax_11, -70, -30, &hip[2], &ankle[2]);  /* :50-60 */
+  ant_leg(m, torso, -1, -1, ax_m11, -70, -30, &hip[3], &ankle[3]); /* :61-71 */
+  ant_leg(m, torso, 1, -1, ax_11, 30, 70, &hip[4], &ankle[4]);    /* :72-82 */
+  /* actuators :85-94, gear 150 */
+  mjc_add_motor(m, hip[4], 150);
+  mjc_add_motor(m, ankle[4], 150);
+  mjc_add_motor(m, hip[1], 150);
+  mjc_add_motor(m, ankle[1], 150);
+  mjc_add_motor(m, hip[2], 150);
+  mjc_add_motor(m, ankle[2], 150);
+  mjc_add_motor(m, hip[3], 150);
+  mjc_add_motor(m, ankle[3], 150);
+  mjc_compile(m);
+}

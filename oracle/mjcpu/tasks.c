@@ -1,0 +1,399 @@
+/* TEST INFRASTRUCTURE — NOT PRODUCT CODE.  See mjcpu.h (PARITY UNPINNED for
+ * the engine; the task logic below IS pinned to in-tree reference code).
+ *
+ * Restatement of the gym task wrappers around mj_step:
+ *   MujocoEnv::{MujocoReset,MujocoStep}   envpool/mujoco/gym/mujoco_env.h:126-148
+ *   HalfCheetahEnvBase::{MujocoResetModel,Reset,Step,WriteState}
+ *                                         envpool/mujoco/gym/half_cheetah.h:105-185
+ *   AntEnvBase::{MujocoResetModel,Reset,Step,IsHealthy,WriteState}
+ *                                         envpool/mujoco/gym/ant.h:135-278
+ * with the runtime bookkeeping of envpool/core/env.h:184-256 and
+ * async_envpool.h:127, exposed through the `orc_*` oracle API (orc_api.c).
+ * v4 registration defaults: envpool/mujoco/gym/registration.py:84-93
+ * (post_constraint=False, max_episode_steps=1000, frame_skip=5).
+ */
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../restate/rng.h"
+#include "mjcpu.h"
+
+enum { DT_I32 = 0, DT_F32 = 1, DT_F64 = 2, DT_BOOL = 3 };
+
+typedef struct {
+  mjc_data d;
+  orc_mt19937 gen;
+  orc_normal_state nstate; /* dist_qvel_ member: persists across resets */
+  int current_step, done, elapsed_step;
+} mj_env;
+
+typedef struct {
+  int is_ant;
+  mjc_model m;
+  int num_envs, max_episode_steps, frame_skip;
+  double ctrl_cost_weight, forward_reward_weight, reset_noise_scale;
+  double healthy_reward, healthy_z_min, healthy_z_max;
+  int terminate_when_unhealthy, legacy_healthy_reward;
+  int torso;
+  mj_env* envs;
+  int nkeys;
+  const char* key_names[20];
+  int key_dtype[20], key_elems[20];
+} mj_pool;
+
+static const char* kCommonNames[8] = {
+    "info:env_id", "info:players.env_id", "elapsed_step", "done",
+    "reward",      "discount",            "step_type",    "trunc"};
+static const int kCommonDtype[8] = {DT_I32, DT_I32, DT_I32, DT_BOOL,
+                                    DT_F32, DT_F32, DT_I32, DT_BOOL};
+
+static double extra_or(const double* e, int n, int i, double d) {
+  return (e && i < n) ? e[i] : d;
+}
+
+/* extra (optional): [frame_skip, ctrl_cost_weight, forward_reward_weight,
+ * reset_noise_scale, disable_contact, disable_limit, disable_actuation] */
+void* mjcpu_create(const char* task, int num_envs, int seed,
+                   int max_episode_steps, const double* extra, int n_extra) {
+  int is_ant;
+  if (strcmp(task, "HalfCheetah") == 0) {
+    is_ant = 0;
+  } else if (strcmp(task, "Ant") == 0) {
+    is_ant = 1;
+  } else {
+    return NULL;
+  }
+  mj_pool* p = (mj_pool*)calloc(1, sizeof(mj_pool));
+  p->is_ant = is_ant;
+  if (is_ant) {
+    mjc_build_ant(&p->m);
+  } else {
+    mjc_build_half_cheetah(&p->m);
+  }
+  p->num_envs = num_envs;
+  p->max_episode_steps = max_episode_steps > 0 ? max_episode_steps : INT_MAX;
+  p->frame_skip = (int)extra_or(extra, n_extra, 0, 5);
+  /* half_cheetah.h:33-43 / ant.h:33-50 defaults */
+  p->ctrl_cost_weight = extra_or(extra, n_extra, 1, is_ant ? 0.5 : 0.1);
+  p->forward_reward_weight = extra_or(extra, n_extra, 2, 1.0);
+  p->reset_noise_scale = extra_or(extra, n_extra, 3, 0.1);
+  p->m.disable_contact = extra_or(extra, n_extra, 4, 0) != 0;
+  p->m.disable_limit = extra_or(extra, n_extra, 5, 0) != 0;
+  p->m.disable_actuation = extra_or(extra, n_extra, 6, 0) != 0;
+  if (extra_or(extra, n_extra, 7, 0) != 0) { /* invariant tests: no passive */
+    for (int i = 0; i < p->m.nv; ++i) p->m.dof_damping[i] = 0;
+    for (int j = 0; j < p->m.njnt; ++j) p->m.jnt_stiffness[j] = 0;
+  }
+  if (extra_or(extra, n_extra, 8, -1) >= 0) p->m.integrator = (int)extra[8];
+  if (extra_or(extra, n_extra, 9, 0) > 0) p->m.timestep = extra[9];
+  p->healthy_reward = 1.0;
+  p->healthy_z_min = 0.2;
+  p->healthy_z_max = 1.0;
+  p->terminate_when_unhealthy = 1;
+  p->legacy_healthy_reward = 1;
+  p->torso = 1; /* mj_name2id(model, mjOBJ_XBODY, "torso"), ant.h:119 */
+  for (int i = 0; i < 8; ++i) {
+    p->key_names[i] = kCommonNames[i];
+    p->key_dtype[i] = kCommonDtype[i];
+    p->key_elems[i] = 1;
+  }
+  int k = 8;
+  p->key_names[k] = "obs";
+  p->key_dtype[k] = DT_F64;
+  p->key_elems[k++] = is_ant ? 27 : 17;
+  static const char* cheetah_info[4] = {"info:reward_run", "info:reward_ctrl",
+                                        "info:x_position", "info:x_velocity"};
+  static const char* ant_info[9] = {
+      "info:reward_forward", "info:reward_ctrl",  "info:reward_contact",
+      "info:reward_survive", "info:x_position",   "info:y_position",
+      "info:distance_from_origin", "info:x_velocity", "info:y_velocity"};
+  int ninfo = is_ant ? 9 : 4;
+  for (int i = 0; i < ninfo; ++i) {
+    p->key_names[k] = is_ant ? ant_info[i] : cheetah_info[i];
+    p->key_dtype[k] = DT_F64;
+    p->key_elems[k++] = 1;
+  }
+  p->nkeys = k;
+  p->envs = (mj_env*)calloc((size_t)num_envs, sizeof(mj_env));
+  for (int i = 0; i < num_envs; ++i) {
+    mj_env* e = &p->envs[i];
+    mjc_reset_data(&p->m, &e->d);
+    orc_mt_seed(&e->gen, (uint32_t)(seed + i));
+    e->current_step = -1;
+    e->done = 1;
+    e->elapsed_step = p->max_episode_steps + 1;
+  }
+  return p;
+}
+
+int mjcpu_num_state_keys(void* h) { return ((mj_pool*)h)->nkeys; }
+int mjcpu_state_key(void* h, int i, char* name, int* dtype, int* elems) {
+  mj_pool* p = (mj_pool*)h;
+  if (i < 0 || i >= p->nkeys) return -1;
+  strncpy(name, p->key_names[i], 63);
+  name[63] = 0;
+  *dtype = p->key_dtype[i];
+  *elems = p->key_elems[i];
+  return 0;
+}
+int mjcpu_action_info(void* h, int* dtype, int* elems) {
+  mj_pool* p = (mj_pool*)h;
+  *dtype = DT_F64;
+  *elems = p->m.nu;
+  return 0;
+}
+
+static void write_common(mj_pool* p, mj_env* e, int eid, void** out, int row,
+                         float reward) {
+  int done = e->done;
+  ((int*)out[0])[row] = eid;
+  ((int*)out[1])[row] = eid;
+  ((int*)out[2])[row] = e->current_step;
+  ((unsigned char*)out[3])[row] = (unsigned char)done;
+  ((float*)out[4])[row] = reward;
+  ((float*)out[5])[row] = (float)(!done);
+  int st = 1;
+  if (e->current_step == 0) {
+    st = 0;
+  } else if (done) {
+    st = 2;
+  }
+  ((int*)out[6])[row] = st;
+  ((unsigned char*)out[7])[row] =
+      (unsigned char)(done && e->current_step >= p->max_episode_steps);
+}
+
+static void write_obs(mj_pool* p, mj_env* e, void** out, int row) {
+  int skip = p->is_ant ? 2 : 1; /* exclude_current_positions_from_observation */
+  int n = p->is_ant ? 27 : 17;
+  double* obs = (double*)out[8] + (size_t)row * n;
+  for (int i = skip; i < p->m.nq; ++i) *(obs++) = e->d.qpos[i];
+  for (int i = 0; i < p->m.nv; ++i) *(obs++) = e->d.qvel[i];
+}
+
+/* MujocoReset + MujocoResetModel: mujoco_env.h:126-131, half_cheetah.h:105-117 */
+static void mujoco_reset(mj_pool* p, mj_env* e) {
+  double warm[MJC_MAXV];
+  (void)warm;
+  mjc_reset_data(&p->m, &e->d); /* mj_resetData */
+  for (int i = 0; i < p->m.nq; ++i) {
+    e->d.qpos[i] = p->m.qpos0[i] +
+                   orc_uniform_real(&e->gen, -p->reset_noise_scale,
+                                    p->reset_noise_scale);
+  }
+  for (int i = 0; i < p->m.nv; ++i) {
+    e->d.qvel[i] = 0.0 + orc_normal(&e->gen, &e->nstate, 0, p->reset_noise_scale);
+  }
+  mjc_forward(&p->m, &e->d); /* mj_forward */
+}
+
+static int ant_is_healthy(mj_pool* p, mj_env* e) { /* ant.h:214-229 */
+  if (e->d.qpos[2] < p->healthy_z_min || e->d.qpos[2] > p->healthy_z_max) return 0;
+  for (int i = 0; i < p->m.nq; ++i) {
+    if (!isfinite(e->d.qpos[i])) return 0;
+  }
+  for (int i = 0; i < p->m.nv; ++i) {
+    if (!isfinite(e->d.qvel[i])) return 0;
+  }
+  return 1;
+}
+
+static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
+                     void** out, int row) {
+  mj_env* e = &p->envs[eid];
+  int reset = force_reset || e->done; /* async_envpool.h:127 */
+  float reward = 0.0f;
+  int ninfo = p->is_ant ? 9 : 4;
+  double info[9] = {0};
+  if (reset) {
+    e->current_step = 0;
+    e->done = 0;
+    e->elapsed_step = 0;
+    mujoco_reset(p, e);
+    /* WriteState(0.0, 0, ...) on reset: ant.h:160-164 passes zeros */
+    if (p->is_ant) info[6] = sqrt(0.0);
+  } else {
+    ++e->current_step;
+    double dt = p->frame_skip * p->m.timestep;
+    double ctrl_cost = 0;
+    for (int i = 0; i < p->m.nu; ++i) ctrl_cost += p->ctrl_cost_weight * act[i] * act[i];
+    if (!p->is_ant) { /* half_cheetah.h:136-155 */
+      double x_before = e->d.qpos[0];
+      for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
+      for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
+      double x_after = e->d.qpos[0];
+      double xv = (x_after - x_before) / dt;
+      reward = (float)(xv * p->forward_reward_weight - ctrl_cost);
+      e->done = (++e->elapsed_step >= p->max_episode_steps);
+      info[0] = xv * p->forward_reward_weight;
+      info[1] = -ctrl_cost;
+      info[2] = x_after;
+      info[3] = xv;
+    } else { /* ant.h:166-212 */
+      double x_before = e->d.xpos[p->torso][0], y_before = e->d.xpos[p->torso][1];
+      for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
+      for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
+      double x_after = e->d.xpos[p->torso][0], y_after = e->d.xpos[p->torso][1];
+      double xv = (x_after - x_before) / dt, yv = (y_after - y_before) / dt;
+      double contact_cost = 0.0; /* use_contact_force=false for v4 */
+      int healthy = ant_is_healthy(p, e);
+      int give = healthy;
+      if (p->legacy_healthy_reward) give = p->terminate_when_unhealthy || healthy;
+      double healthy_reward = give ? p->healthy_reward : 0.0;
+      reward = (float)(xv * p->forward_reward_weight + healthy_reward -
+                       ctrl_cost - contact_cost);
+      ++e->elapsed_step;
+      e->done = (p->terminate_when_unhealthy ? !healthy : 0) ||
+                (e->elapsed_step >= p->max_episode_steps);
+      info[0] = xv * p->forward_reward_weight;
+      info[1] = -ctrl_cost;
+      info[2] = -contact_cost;
+      info[3] = healthy_reward;
+      info[4] = x_after;
+      info[5] = y_after;
+      info[6] = sqrt(x_after * x_after + y_after * y_after);
+      info[7] = xv;
+      info[8] = yv;
+    }
+  }
+  write_obs(p, e, out, row);
+  for (int i = 0; i < ninfo; ++i) ((double*)out[9 + i])[row] = info[i];
+  write_common(p, e, eid, out, row, reward);
+}
+
+void mjcpu_reset(void* h, const int* ids, int k, void** out) {
+  mj_pool* p = (mj_pool*)h;
+  for (int i = 0; i < k; ++i) env_step(p, ids[i], 1, NULL, out, i);
+}
+
+void mjcpu_step(void* h, const int* ids, int k, const void* action, void** out) {
+  mj_pool* p = (mj_pool*)h;
+  const double* a = (const double*)action;
+  for (int i = 0; i < k; ++i) env_step(p, ids[i], 0, a + (size_t)i * p->m.nu, out, i);
+}
+
+void mjcpu_destroy(void* h) {
+  mj_pool* p = (mj_pool*)h;
+  free(p->envs);
+  free(p);
+}
+
+/* flat state: qpos[nq] qvel[nv] qacc_warmstart[nv] time xlag ylag done
+ * cur_step normal_saved normal_avail */
+int mjcpu_state_dim(void* h) {
+  mj_pool* p = (mj_pool*)h;
+  return p->m.nq + 2 * p->m.nv + 7;
+}
+void mjcpu_get_state(void* h, const int* ids, int k, double* out) {
+  mj_pool* p = (mj_pool*)h;
+  int dim = mjcpu_state_dim(h), nq = p->m.nq, nv = p->m.nv;
+  for (int i = 0; i < k; ++i) {
+    mj_env* e = &p->envs[ids[i]];
+    double* o = out + (size_t)i * dim;
+    memcpy(o, e->d.qpos, sizeof(double) * nq);
+    memcpy(o + nq, e->d.qvel, sizeof(double) * nv);
+    memcpy(o + nq + nv, e->d.qacc_warmstart, sizeof(double) * nv);
+    double* t = o + nq + 2 * nv;
+    t[0] = e->d.time;
+    t[1] = e->d.xpos[p->torso][0];
+    t[2] = e->d.xpos[p->torso][1];
+    t[3] = e->done;
+    t[4] = e->current_step;
+    t[5] = e->nstate.saved;
+    t[6] = e->nstate.saved_available;
+  }
+}
+void mjcpu_set_state(void* h, const int* ids, int k, const double* in) {
+  mj_pool* p = (mj_pool*)h;
+  int dim = mjcpu_state_dim(h), nq = p->m.nq, nv = p->m.nv;
+  for (int i = 0; i < k; ++i) {
+    mj_env* e = &p->envs[ids[i]];
+    const double* o = in + (size_t)i * dim;
+    memcpy(e->d.qpos, o, sizeof(double) * nq);
+    memcpy(e->d.qvel, o + nq, sizeof(double) * nv);
+    memcpy(e->d.qacc_warmstart, o + nq + nv, sizeof(double) * nv);
+    const double* t = o + nq + 2 * nv;
+    e->d.time = t[0];
+    e->d.xpos[p->torso][0] = t[1];
+    e->d.xpos[p->torso][1] = t[2];
+    e->done = t[3] != 0;
+    e->current_step = (int)t[4];
+    e->elapsed_step = e->current_step;
+    e->nstate.saved = t[5];
+    e->nstate.saved_available = t[6] != 0;
+  }
+}
+
+/* debug / invariant hooks (tests only) */
+const mjc_model* mjcpu_model(void* h) { return &((mj_pool*)h)->m; }
+mjc_data* mjcpu_data(void* h, int env) { return &((mj_pool*)h)->envs[env].d; }
+void mjcpu_model_scalars(void* h, double* out) {
+  /* [nq nv nu nbody ngeom meaninertia total_mass] + body_mass[nbody]
+   * + dof_invweight0[nv] + body_invweight0[nbody*2] */
+  mj_pool* p = (mj_pool*)h;
+  const mjc_model* m = &p->m;
+  int k = 0;
+  out[k++] = m->nq; out[k++] = m->nv; out[k++] = m->nu; out[k++] = m->nbody;
+  out[k++] = m->ngeom; out[k++] = m->meaninertia;
+  double tot = 0;
+  for (int b = 0; b < m->nbody; ++b) tot += m->body_mass[b];
+  out[k++] = tot;
+  for (int b = 0; b < m->nbody; ++b) out[k++] = m->body_mass[b];
+  for (int i = 0; i < m->nv; ++i) out[k++] = m->dof_invweight0[i];
+  for (int b = 0; b < m->nbody; ++b) {
+    out[k++] = m->body_invweight0[b][0];
+    out[k++] = m->body_invweight0[b][1];
+  }
+}
+/* raw physics access for invariant tests: set qpos/qvel/ctrl, run n mj_steps,
+ * read back qpos, qvel, energies, contact/efc stats */
+void mjcpu_raw_set(void* h, int env, const double* qpos, const double* qvel,
+                   const double* ctrl) {
+  mj_pool* p = (mj_pool*)h;
+  mjc_data* d = &p->envs[env].d;
+  mjc_reset_data(&p->m, d);
+  memcpy(d->qpos, qpos, sizeof(double) * p->m.nq);
+  memcpy(d->qvel, qvel, sizeof(double) * p->m.nv);
+  memcpy(d->ctrl, ctrl, sizeof(double) * p->m.nu);
+  mjc_forward(&p->m, d);
+}
+void mjcpu_raw_step(void* h, int env, int n) {
+  mj_pool* p = (mj_pool*)h;
+  for (int i = 0; i < n; ++i) mjc_step(&p->m, &p->envs[env].d);
+}
+void mjcpu_raw_get(void* h, int env, double* qpos, double* qvel, double* misc) {
+  mj_pool* p = (mj_pool*)h;
+  mjc_data* d = &p->envs[env].d;
+  memcpy(qpos, d->qpos, sizeof(double) * p->m.nq);
+  memcpy(qvel, d->qvel, sizeof(double) * p->m.nv);
+  /* refresh position-dependent quantities for energy */
+  mjc_data tmp = *d;
+  mjc_forward(&p->m, &tmp);
+  misc[0] = mjc_energy_kinetic(&p->m, &tmp);
+  misc[1] = mjc_energy_potential(&p->m, &tmp);
+  misc[2] = tmp.ncon;
+  misc[3] = tmp.nefc;
+  misc[4] = tmp.solver_iter;
+  misc[5] = d->time;
+  double fmin_ = 0, gn = 0;
+  for (int r = 0; r < tmp.nefc; ++r) fmin_ = fmin(fmin_, tmp.efc_force[r]);
+  /* optimality residual: M qacc - qfrc_smooth - qfrc_constraint */
+  for (int i = 0; i < p->m.nv; ++i) {
+    double s = -tmp.qfrc_smooth[i] - tmp.qfrc_constraint[i];
+    for (int j = 0; j < p->m.nv; ++j) s += tmp.M[i][j] * tmp.qacc[j];
+    gn += s * s;
+  }
+  misc[6] = fmin_;
+  misc[7] = sqrt(gn);
+  double asym = 0;
+  for (int i = 0; i < p->m.nv; ++i) {
+    for (int j = 0; j < p->m.nv; ++j) asym = fmax(asym, fabs(tmp.M[i][j] - tmp.M[j][i]));
+  }
+  misc[8] = asym;
+  misc[9] = tmp.xpos[1][2];
+  double fsum = 0;
+  for (int r = 0; r < tmp.nefc; ++r) fsum += tmp.efc_force[r];
+  misc[10] = fsum;
+}
