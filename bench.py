@@ -1,0 +1,165 @@
+"""bench.py — headline benchmark: env-steps/s of HalfCheetah-v4 at
+num_envs=65536 (per GPU) with uniform random actions, auto-reset on.
+
+One "step" = one batched `step()` of all envs of this rank (frame_skip=5
+mj_steps each) with actions already resident in HBM (epa_send_device /
+epa_recv_device: no PCIe in the timed region; DESIGN.md quotes the
+PCIe-inclusive numpy-API rate).  Ranks are independent shards of the env-id
+range (weak scaling, no collective on the data path).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(num_envs=64, target_s=15.0):
+    """Oracle ("port": oracle/mjcpu fp64 restatement, single thread) on a bounded
+    sample of the same workload.  The reference itself cannot run: mj_step lives
+    in un-vendored MuJoCo 3.6.0."""
+    import subprocess
+
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "port"], check=True)
+    from oracle.orc import Oracle
+
+    o = Oracle("HalfCheetah", num_envs, seed=0, max_episode_steps=1000)
+    o.reset()
+    rng = np.random.default_rng(0)
+    act = rng.uniform(-1, 1, size=(num_envs, 6))
+    t = o.time_steps(5, act)
+    steps = max(5, int(target_s / max(t / 5, 1e-6)))
+    steps = min(steps, 2000)
+    t = o.time_steps(steps, act)
+    return {
+        "value": num_envs * steps / t,
+        "unit": "env-steps/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"oracle/mjcpu fp64, {num_envs} envs x {steps} steps, 1 thread, "
+                  f"{t:.1f}s (reference mj_step not runnable: MuJoCo 3.6.0 un-vendored)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--num-envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--task", default="HalfCheetah")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from envpool_amd.core.device_pool import DevicePool
+
+    n = args.num_envs
+    params = {"precision": 1 if args.precision == "fp64" else 0}
+    pool = DevicePool(args.task, n, seed=0, max_episode_steps=1000, device=local_rank,
+                      env_id_offset=rank * n, params=params)
+    adim = int(np.prod(pool.action_shape))
+    # ring of 16 pre-generated action batches, Philox seed 1234
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    ring = [torch.rand((n, adim), generator=gen, device=dev, dtype=torch.float64) * 2 - 1
+            for _ in range(16)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        pool.send_device(ring[i % 16].data_ptr())
+        pool.recv_device()  # outputs stay on the device
+
+    pool.send_device(None)  # reset all (first step of every env is a reset anyway)
+    pool.recv_device()
+    for i in range(args.warmup):
+        step(i)
+    pool.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    pool.set_timing(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    pool.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = pool.kernel_time_ms()
+    pool.set_timing(False)
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_env_steps = n * world * args.steps
+        value = total_env_steps / elapsed
+        # algorithmic bytes / env-step: action+ids
+        # in, every state key out, persistent fp64 state read + written
+        alg_bytes = 708
+        # counted fp32 flops / env-step from the kernel's ISA
+        achieved_gbs = alg_bytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "env steps/sec (raw FPS) at num_envs=65536, HalfCheetah-v4",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.task}-v4 num_envs={n} per GPU, frame_skip=5, "
+                            "uniform random actions resident in HBM, auto-reset on",
+                "num_envs_per_gpu": n,
+                "frames_per_sec": value * 5,
+                "sharding": f"env ids sharded over {world} GPU(s), no collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved_gbs,
+                "peak": 8000.0,
+                "unit": "GB/s",
+                "frac": achieved_gbs / 8000.0,
+                "traffic": None,
+                "kernel": "CheetahStepKernel",
+                "kernel_ms": kernel_ms,
+                "launches": launches,
+                "algorithmic_bytes_per_env_step": alg_bytes,
+                "note": "physics kernel is VALU/latency-bound, not HBM-bound "
+                        "(~300 flop/B); HBM fraction reported as BASELINE.md asks",
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

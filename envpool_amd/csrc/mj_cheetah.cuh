@@ -1,0 +1,725 @@
+// K3 — HalfCheetah `mj_step` restated as a planar, tree-specialised, fully
+// unrolled per-thread routine (one env per thread).
+//
+// What it replaces: the arithmetic MuJoCo 3.6.0's mj_step performs for the gym
+// HalfCheetah model each time the reference calls it
+// (envpool/mujoco/gym/mujoco_env.h:137-148, `frame_skip x mj_step`), i.e.
+// SURVEY.md §8a stages M1-M9: kinematics, comPos, crb(+factor), collision
+// (plane-capsule), makeConstraint (joint limits + pyramidal frictional
+// contacts), comVel/passive/rne, actuation, Newton solve of the convex
+// constraint objective, Euler with implicit joint damping.
+//
+// MI355X-first design (not a translation of MuJoCo's generic engine):
+//  * the model (third_party/mujoco_gym_xml_patches/half_cheetah_envpool.xml:
+//    2 slides + 7 y-hinges) moves in the x-z plane, so every spatial quantity
+//    is a 3-vector (w_y, v_x, v_z) and every inertia 4 numbers; the y-tangent
+//    friction rows have identically zero tangential Jacobian and fold into the
+//    normal row with weight 2D;
+//  * all tree loops are unrolled at compile time (static_for) so the 9x9
+//    inertia/Hessian, body poses and Jacobian columns live in VGPRs with static
+//    indices; the leg/leg zero blocks of M and H are never materialised;
+//  * M/H are factored as U U^T from the last dof upwards (tree order), which
+//    has no fill between the two legs;
+//  * per-contact constants (contact point, reference accelerations, D) are
+//    staged through LDS, laid out [slot][lane] so a wave's accesses are
+//    bank-conflict free; Jacobian rows are rebuilt from the contact point
+//    instead of being stored;
+//  * model constants arrive as a by-value kernel argument (scalar loads ->
+//    SGPRs), not per-env copies of mjModel.
+// The same source compiles for the host (EPA_HD) so tests can run it in fp64
+// on the CPU against oracle/mjcpu.
+#ifndef ENVPOOL_AMD_CSRC_MJ_CHEETAH_CUH_
+#define ENVPOOL_AMD_CSRC_MJ_CHEETAH_CUH_
+
+#include <cmath>
+#include <type_traits>
+#include <utility>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define EPA_HD __host__ __device__ __forceinline__
+#else
+#define EPA_HD inline
+#endif
+
+namespace epa {
+namespace mj {
+
+// ---- compile-time loops -----------------------------------------------------
+template <int I>
+using IC = std::integral_constant<int, I>;
+
+template <int B, int E, typename F>
+EPA_HD void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(IC<B>{});
+    static_for<B + 1, E>(static_cast<F&&>(f));
+  }
+}
+// descending: B-1, B-2, ..., E
+template <int B, int E, typename F>
+EPA_HD void static_for_down(F&& f) {
+  if constexpr (B > E) {
+    f(IC<B - 1>{});
+    static_for_down<B - 1, E>(static_cast<F&&>(f));
+  }
+}
+
+template <typename T>
+EPA_HD T Sqrt(T x) {
+  return sqrt(x);
+}
+template <typename T>
+EPA_HD void SinCos(T x, T* s, T* c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (std::is_same<T, float>::value) {
+    sincosf(x, s, c);
+  } else {
+    sincos(x, s, c);
+  }
+#else
+  *s = std::sin(x);
+  *c = std::cos(x);
+#endif
+}
+
+// ---- model --------------------------------------------------------------------
+constexpr int kNB = 7;    // torso bthigh bshin bfoot fthigh fshin ffoot
+constexpr int kNV = 9;    // rootx rootz rooty + 6 leg hinges
+constexpr int kNU = 6;
+constexpr int kNEnd = 16; // 8 capsules x 2 end spheres
+constexpr int kSlotsPerEnd = 5;
+constexpr int kLdsSlots = kNEnd * kSlotsPerEnd;
+
+EPA_HD constexpr int Parent(int b) {
+  return b == 0 ? -1 : (b == 4 ? 0 : b - 1);
+}
+EPA_HD constexpr int EndBody(int e) {
+  // geoms in XML order: torso, head (body 0), then one capsule per leg body
+  return e < 4 ? 0 : (e - 4) / 2 + 1;
+}
+// dof j >= 3 is the hinge of body j - 2; dofs 0..2 belong to the torso.
+EPA_HD constexpr int DofBody(int j) { return j < 3 ? 0 : j - 2; }
+// is dof j on the kinematic chain from the world to body b?
+EPA_HD constexpr bool InChain(int j, int b) {
+  if (j < 3) return true;
+  int jb = j - 2;
+  for (int x = b; x > 0; x = Parent(x)) {
+    if (x == jb) return true;
+  }
+  return false;
+}
+// structurally non-zero entry of M / H (i <= j): the two legs never couple.
+EPA_HD constexpr bool NZ(int i, int j) {
+  return !((i >= 3 && i <= 5 && j >= 6) || (j >= 3 && j <= 5 && i >= 6));
+}
+EPA_HD constexpr int TriIdx(int i, int j) {  // i <= j, packed upper triangle
+  return j * (j + 1) / 2 + i;
+}
+constexpr int kTri = kNV * (kNV + 1) / 2;
+
+template <typename T>
+struct CheetahModel {
+  T lx[kNB], lz[kNB];    // body_pos in the parent frame (torso: world)
+  T mass[kNB], iyy[kNB]; // mass, inertia about y through the body COM
+  T cx[kNB], cz[kNB];    // body COM in the body frame
+  T ex[kNEnd], ez[kNEnd];  // capsule end-sphere centres in the body frame
+  T radius;
+  T stiff[kNU], damp[kNU], arm[kNU], lo[kNU], hi[kNU], gear[kNU];
+  T dof_invw[kNU];       // dof_invweight0 of the hinges
+  T body_invw[kNB];      // body_invweight0 (translational)
+  T total_mass;
+  T mu;                  // sliding friction of the pair
+  T con_K, con_B;        // contact reference: aref = -B vel - K imp (pos-margin)
+  T con_d0, con_dmax, con_width;
+  T lim_K, lim_B, lim_d0, lim_dmax, lim_width;
+  T timestep, gravity;   // gravity = 9.81 (magnitude along -z)
+};
+
+// ---- small planar spatial algebra ---------------------------------------------
+template <typename T>
+struct V3 {  // motion (w, vx, vz) or force (tau, fx, fz)
+  T w, x, z;
+};
+template <typename T>
+struct In4 {  // planar spatial inertia about the reference point
+  T I, mdx, mdz, m;
+};
+template <typename T>
+EPA_HD V3<T> MulInert(const In4<T>& i, const V3<T>& v) {
+  return {i.I * v.w + i.mdz * v.x - i.mdx * v.z, i.m * v.x + i.mdz * v.w,
+          i.m * v.z - i.mdx * v.w};
+}
+template <typename T>
+EPA_HD T Dot(const V3<T>& a, const V3<T>& b) {
+  return a.w * b.w + a.x * b.x + a.z * b.z;
+}
+template <typename T>
+EPA_HD V3<T> CrossMotion(const V3<T>& vel, const V3<T>& v) {
+  return {T(0), vel.w * v.z - vel.z * v.w, -vel.w * v.x + vel.x * v.w};
+}
+template <typename T>
+EPA_HD V3<T> CrossForce(const V3<T>& vel, const V3<T>& f) {
+  return {vel.z * f.x - vel.x * f.z, vel.w * f.z, -vel.w * f.x};
+}
+
+// impedance d(r) for power 2, midpoint 0.5 (getimpedance in MuJoCo)
+template <typename T>
+EPA_HD T Impedance(T d0, T dmax, T width, T r) {
+  T x = (r < T(0) ? -r : r) / width;
+  if (x >= T(1)) return dmax;
+  T y = x <= T(0.5) ? T(2) * x * x : T(1) - T(2) * (T(1) - x) * (T(1) - x);
+  return d0 + y * (dmax - d0);
+}
+
+// Upper "tree order" Cholesky A = U U^T on a packed upper triangle with the
+// leg/leg zero blocks skipped.  In place.  Returns false if not SPD.
+template <typename T>
+EPA_HD void FactorUUt(T* A) {
+  static_for_down<kNV, 0>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    T s = A[TriIdx(j, j)];
+    static_for<j + 1, kNV>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (NZ(j, k)) s -= A[TriIdx(j, k)] * A[TriIdx(j, k)];
+    });
+    T d = Sqrt(s);
+    T inv = T(1) / d;
+    A[TriIdx(j, j)] = d;
+    static_for<0, j>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (NZ(i, j)) {
+        T t = A[TriIdx(i, j)];
+        static_for<j + 1, kNV>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          if constexpr (NZ(i, k) && NZ(j, k)) {
+            t -= A[TriIdx(i, k)] * A[TriIdx(j, k)];
+          }
+        });
+        A[TriIdx(i, j)] = t * inv;
+      }
+    });
+  });
+}
+// solve U U^T x = b in place
+template <typename T>
+EPA_HD void SolveUUt(const T* U, T* x) {
+  static_for_down<kNV, 0>([&](auto jc) {  // U y = b
+    constexpr int j = decltype(jc)::value;
+    T s = x[j];
+    static_for<j + 1, kNV>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (NZ(j, k)) s -= U[TriIdx(j, k)] * x[k];
+    });
+    x[j] = s / U[TriIdx(j, j)];
+  });
+  static_for<0, kNV>([&](auto jc) {  // U^T x = y
+    constexpr int j = decltype(jc)::value;
+    T s = x[j];
+    static_for<0, j>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (NZ(i, j)) s -= U[TriIdx(i, j)] * x[i];
+    });
+    x[j] = s / U[TriIdx(j, j)];
+  });
+}
+// y = A x for a packed symmetric matrix with the structural zeros
+template <typename T>
+EPA_HD void SymMul(const T* A, const T* x, T* y) {
+  static_for<0, kNV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    T s = T(0);
+    static_for<0, kNV>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (NZ(i, j)) {
+        s += A[i <= j ? TriIdx(i, j) : TriIdx(j, i)] * x[j];
+      }
+    });
+    y[i] = s;
+  });
+}
+
+// Position-dependent quantities of one forward pass.
+template <typename T>
+struct CheetahPos {
+  T sn[kNB], cs[kNB], px[kNB], pz[kNB];  // body frames (anchors = body origins)
+  T comx, comz;                          // subtree COM of the robot
+  In4<T> cinert[kNB];
+  V3<T> cdof[kNV];
+  T M[kTri];
+};
+
+template <typename T>
+EPA_HD void CheetahKinematics(const CheetahModel<T>& m, const T* q,
+                              CheetahPos<T>& p) {
+  // mj_kinematics: q[0] may be a local (re-centred) x; dynamics are invariant.
+  static_for<0, kNB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    constexpr int par = Parent(b);
+    T sj, cj;
+    SinCos(q[b + 2], &sj, &cj);
+    if constexpr (b == 0) {
+      p.px[0] = m.lx[0] + q[0];
+      p.pz[0] = m.lz[0] + q[1];
+      p.sn[0] = sj;
+      p.cs[0] = cj;
+    } else {
+      p.px[b] = p.px[par] + p.cs[par] * m.lx[b] + p.sn[par] * m.lz[b];
+      p.pz[b] = p.pz[par] - p.sn[par] * m.lx[b] + p.cs[par] * m.lz[b];
+      p.sn[b] = p.sn[par] * cj + p.cs[par] * sj;
+      p.cs[b] = p.cs[par] * cj - p.sn[par] * sj;
+    }
+  });
+  // mj_comPos
+  T xi[kNB], zi[kNB];
+  T sx = T(0), sz = T(0);
+  static_for<0, kNB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    xi[b] = p.px[b] + p.cs[b] * m.cx[b] + p.sn[b] * m.cz[b];
+    zi[b] = p.pz[b] - p.sn[b] * m.cx[b] + p.cs[b] * m.cz[b];
+    sx += m.mass[b] * xi[b];
+    sz += m.mass[b] * zi[b];
+  });
+  p.comx = sx / m.total_mass;
+  p.comz = sz / m.total_mass;
+  static_for<0, kNB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    T dx = xi[b] - p.comx, dz = zi[b] - p.comz;
+    p.cinert[b] = {m.iyy[b] + m.mass[b] * (dx * dx + dz * dz), m.mass[b] * dx,
+                   m.mass[b] * dz, m.mass[b]};
+  });
+  p.cdof[0] = {T(0), T(1), T(0)};
+  p.cdof[1] = {T(0), T(0), T(1)};
+  static_for<2, kNV>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    constexpr int b = DofBody(j);
+    // hinge about +y at the body origin: (1, oz, -ox), o = com - anchor
+    p.cdof[j] = {T(1), p.comz - p.pz[b], -(p.comx - p.px[b])};
+  });
+  // mj_crb
+  In4<T> crb[kNB];
+  static_for<0, kNB>([&](auto bc) { crb[decltype(bc)::value] = p.cinert[decltype(bc)::value]; });
+  static_for_down<kNB, 1>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    constexpr int par = Parent(b);
+    crb[par].I += crb[b].I;
+    crb[par].mdx += crb[b].mdx;
+    crb[par].mdz += crb[b].mdz;
+    crb[par].m += crb[b].m;
+  });
+  static_for<0, kNV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    V3<T> buf = MulInert(crb[DofBody(i)], p.cdof[i]);
+    static_for<0, i + 1>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (InChain(j, DofBody(i))) {
+        p.M[TriIdx(j, i)] = Dot(p.cdof[j], buf);
+      } else if constexpr (NZ(j, i)) {
+        p.M[TriIdx(j, i)] = T(0);
+      }
+    });
+    if constexpr (i >= 3) p.M[TriIdx(i, i)] += m.arm[i - 3];
+  });
+}
+
+// qfrc_smooth = passive - bias + actuator (mj_fwdVelocity, mj_fwdActuation)
+template <typename T>
+EPA_HD void CheetahSmoothForces(const CheetahModel<T>& m,
+                                const CheetahPos<T>& p, const T* q, const T* v,
+                                const T* ctrl, T* qfrc_smooth) {
+  // mj_comVel
+  V3<T> cvel[kNB], cdd[kNV];
+  {
+    V3<T> cv = {T(0), T(0), T(0)};
+    static_for<0, 3>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      cdd[j] = CrossMotion(cv, p.cdof[j]);
+      cv.w += p.cdof[j].w * v[j];
+      cv.x += p.cdof[j].x * v[j];
+      cv.z += p.cdof[j].z * v[j];
+    });
+    cvel[0] = cv;
+  }
+  static_for<1, kNB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    constexpr int j = b + 2;
+    V3<T> cv = cvel[Parent(b)];
+    cdd[j] = CrossMotion(cv, p.cdof[j]);
+    cv.w += p.cdof[j].w * v[j];
+    cv.x += p.cdof[j].x * v[j];
+    cv.z += p.cdof[j].z * v[j];
+    cvel[b] = cv;
+  });
+  // mj_rne (no acceleration term); world cacc = -gravity
+  V3<T> cacc[kNB], cfrc[kNB];
+  static_for<0, kNB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    V3<T> a;
+    if constexpr (b == 0) {
+      a = {T(0), T(0), m.gravity};
+      static_for<0, 3>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        a.w += cdd[j].w * v[j];
+        a.x += cdd[j].x * v[j];
+        a.z += cdd[j].z * v[j];
+      });
+    } else {
+      constexpr int j = b + 2;
+      a = cacc[Parent(b)];
+      a.w += cdd[j].w * v[j];
+      a.x += cdd[j].x * v[j];
+      a.z += cdd[j].z * v[j];
+    }
+    cacc[b] = a;
+    V3<T> f = MulInert(p.cinert[b], a);
+    V3<T> g = CrossForce(cvel[b], MulInert(p.cinert[b], cvel[b]));
+    cfrc[b] = {f.w + g.w, f.x + g.x, f.z + g.z};
+  });
+  static_for_down<kNB, 1>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    constexpr int par = Parent(b);
+    cfrc[par].w += cfrc[b].w;
+    cfrc[par].x += cfrc[b].x;
+    cfrc[par].z += cfrc[b].z;
+  });
+  static_for<0, kNV>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    T bias = Dot(p.cdof[j], cfrc[DofBody(j)]);
+    if constexpr (j < 3) {
+      qfrc_smooth[j] = -bias;
+    } else {
+      // mj_passive (spring about qpos_spring = 0, damper) + motor
+      qfrc_smooth[j] = -m.stiff[j - 3] * q[j] - m.damp[j - 3] * v[j] - bias +
+                       m.gear[j - 3] * ctrl[j - 3];
+    }
+  });
+}
+
+// Jacobian columns of a contact point (cpx, cpz) on body B:
+//   Jn[j] = d(z velocity)/d qdot_j, Jx[j] = d(x velocity)/d qdot_j.
+// f(j, jn, jx) is called for every chain dof.
+template <int B, typename T, typename F>
+EPA_HD void ForChainCols(const CheetahPos<T>& p, T cpx, T cpz, F&& f) {
+  f(IC<0>{}, T(0), T(1));
+  f(IC<1>{}, T(1), T(0));
+  static_for<2, kNV>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (InChain(j, B)) {
+      constexpr int b = DofBody(j);
+      f(jc, -(cpx - p.px[b]), cpz - p.pz[b]);
+    }
+  });
+}
+
+// Limit rows kept in registers; contact rows staged through `lds`
+// (lds(slot) -> T&, slot = 5*e + {0:cpx 1:cpz 2:aref_n 3:B*mu*vx 4:D}).
+template <typename T>
+struct LimitRows {
+  T sgn[kNU], aref[kNU], D[kNU];
+};
+
+template <typename T, typename Lds>
+EPA_HD void CheetahMakeConstraint(const CheetahModel<T>& m,
+                                  const CheetahPos<T>& p, const T* q,
+                                  const T* v, LimitRows<T>& lim, Lds&& lds) {
+  const T kMinVal = T(1e-15);
+  // mj_instantiateLimit + mj_makeImpedance for the 6 limited hinges
+  static_for<0, kNU>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    T qq = q[j + 3];
+    T dlo = qq - m.lo[j], dhi = m.hi[j] - qq;
+    T sgn = T(0), dist = T(0);
+    if (dlo < T(0)) {
+      sgn = T(1);
+      dist = dlo;
+    } else if (dhi < T(0)) {
+      sgn = T(-1);
+      dist = dhi;
+    }
+    T imp = Impedance(m.lim_d0, m.lim_dmax, m.lim_width, dist);
+    T R = (T(1) - imp) * m.dof_invw[j] / imp;
+    R = R < kMinVal ? kMinVal : R;
+    lim.sgn[j] = sgn;
+    lim.D[j] = sgn != T(0) ? T(1) / R : T(0);
+    lim.aref[j] = -m.lim_B * (sgn * v[j + 3]) - m.lim_K * imp * dist;
+  });
+  // mj_collision (plane z=0 vs capsule end spheres) + mj_instantiateContact
+  static_for<0, kNEnd>([&](auto ec) {
+    constexpr int e = decltype(ec)::value;
+    constexpr int b = EndBody(e);
+    T wx = p.px[b] + p.cs[b] * m.ex[e] + p.sn[b] * m.ez[e];
+    T wz = p.pz[b] - p.sn[b] * m.ex[e] + p.cs[b] * m.ez[e];
+    T dist = wz - m.radius;
+    T D = T(0), cpx = wx, cpz = T(0.5) * dist, an = T(0), ax = T(0);
+    if (dist < T(0)) {
+      T vn = T(0), vx = T(0);
+      ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
+        constexpr int j = decltype(jc)::value;
+        vn += jn * v[j];
+        vx += jx * v[j];
+      });
+      T imp = Impedance(m.con_d0, m.con_dmax, m.con_width, dist);
+      // diagApprox (pyramidal) = tran (1 + mu^2); R_py = 2 mu^2 R
+      T diag = m.body_invw[b] * (T(1) + m.mu * m.mu);
+      T R = (T(1) - imp) * diag / imp;
+      R = R < kMinVal ? kMinVal : R;
+      D = T(1) / (T(2) * m.mu * m.mu * R);
+      an = -m.con_B * vn - m.con_K * imp * dist;
+      ax = m.con_B * m.mu * vx;
+    }
+    lds(e * kSlotsPerEnd + 0) = cpx;
+    lds(e * kSlotsPerEnd + 1) = cpz;
+    lds(e * kSlotsPerEnd + 2) = an;
+    lds(e * kSlotsPerEnd + 3) = ax;
+    lds(e * kSlotsPerEnd + 4) = D;
+  });
+}
+
+// One pass over all constraint rows at acceleration `a`:
+// accumulates grad -= J^T f and (if H != nullptr) H += J^T D_active J, returns
+// a 64-bit mask of the active rows.
+template <bool kHess, typename T, typename Lds>
+EPA_HD unsigned long long CheetahRowsPass(const CheetahModel<T>& m,
+                                          const CheetahPos<T>& p,
+                                          const LimitRows<T>& lim, Lds&& lds,
+                                          const T* a, T* grad, T* H) {
+  unsigned long long mask = 0;
+  static_for<0, kNU>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (lim.sgn[j] != T(0)) {
+      T jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
+      if (jar < T(0)) {
+        grad[j + 3] += lim.sgn[j] * lim.D[j] * jar;
+        if constexpr (kHess) H[TriIdx(j + 3, j + 3)] += lim.D[j];
+        mask |= 1ull << j;
+      }
+    }
+  });
+  static_for<0, kNEnd>([&](auto ec) {
+    constexpr int e = decltype(ec)::value;
+    constexpr int b = EndBody(e);
+    T D = lds(e * kSlotsPerEnd + 4);
+    if (D > T(0)) {
+      T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
+      T an = lds(e * kSlotsPerEnd + 2), ax = lds(e * kSlotsPerEnd + 3);
+      T jna = T(0), jxa = T(0);
+      ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
+        constexpr int j = decltype(jc)::value;
+        jna += jn * a[j];
+        jxa += jx * a[j];
+      });
+      // rows: 2 x (Jn), (Jn - mu Jx), (Jn + mu Jx)
+      T jar1 = jna - an;
+      T jar2 = jna - m.mu * jxa - (an + ax);
+      T jar3 = jna + m.mu * jxa - (an - ax);
+      T w1 = jar1 < T(0) ? T(2) * D : T(0);
+      T w2 = jar2 < T(0) ? D : T(0);
+      T w3 = jar3 < T(0) ? D : T(0);
+      mask |= (jar1 < T(0) ? 1ull : 0ull) << (6 + 3 * e);
+      mask |= (jar2 < T(0) ? 1ull : 0ull) << (7 + 3 * e);
+      mask |= (jar3 < T(0) ? 1ull : 0ull) << (8 + 3 * e);
+      T gn = w1 * jar1 + w2 * jar2 + w3 * jar3;   // coefficient of Jn
+      T gx = m.mu * (w3 * jar3 - w2 * jar2);      // coefficient of Jx
+      T A = w1 + w2 + w3, Bc = m.mu * (w3 - w2), C = m.mu * m.mu * (w2 + w3);
+      if (A > T(0)) {
+        ForChainCols<b>(p, cpx, cpz, [&](auto ic, T jni, T jxi) {
+          constexpr int i = decltype(ic)::value;
+          grad[i] += jni * gn + jxi * gx;
+          if constexpr (kHess) {
+            T ui = A * jni + Bc * jxi, wi = Bc * jni + C * jxi;
+            ForChainCols<b>(p, cpx, cpz, [&](auto kc, T jnk, T jxk) {
+              constexpr int k = decltype(kc)::value;
+              if constexpr (k >= i) H[TriIdx(i, k)] += ui * jnk + wi * jxk;
+            });
+          }
+        });
+      }
+    }
+  });
+  return mask;
+}
+
+// phi'(alpha), phi''(alpha) contribution of the rows along `s` from `a`.
+template <typename T, typename Lds>
+EPA_HD void CheetahLineEval(const CheetahModel<T>& m, const CheetahPos<T>& p,
+                            const LimitRows<T>& lim, Lds&& lds, const T* a,
+                            const T* s, T alpha, T* d1, T* d2) {
+  static_for<0, kNU>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (lim.sgn[j] != T(0)) {
+      T jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
+      T jv = lim.sgn[j] * s[j + 3];
+      T x = jar + alpha * jv;
+      if (x < T(0)) {
+        *d1 += lim.D[j] * x * jv;
+        *d2 += lim.D[j] * jv * jv;
+      }
+    }
+  });
+  static_for<0, kNEnd>([&](auto ec) {
+    constexpr int e = decltype(ec)::value;
+    constexpr int b = EndBody(e);
+    T D = lds(e * kSlotsPerEnd + 4);
+    if (D > T(0)) {
+      T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
+      T an = lds(e * kSlotsPerEnd + 2), ax = lds(e * kSlotsPerEnd + 3);
+      T jna = T(0), jxa = T(0), jns = T(0), jxs = T(0);
+      ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
+        constexpr int j = decltype(jc)::value;
+        jna += jn * a[j];
+        jxa += jx * a[j];
+        jns += jn * s[j];
+        jxs += jx * s[j];
+      });
+      T jar1 = jna - an, jv1 = jns;
+      T jar2 = jna - m.mu * jxa - (an + ax), jv2 = jns - m.mu * jxs;
+      T jar3 = jna + m.mu * jxa - (an - ax), jv3 = jns + m.mu * jxs;
+      T x1 = jar1 + alpha * jv1, x2 = jar2 + alpha * jv2, x3 = jar3 + alpha * jv3;
+      if (x1 < T(0)) {
+        *d1 += T(2) * D * x1 * jv1;
+        *d2 += T(2) * D * jv1 * jv1;
+      }
+      if (x2 < T(0)) {
+        *d1 += D * x2 * jv2;
+        *d2 += D * jv2 * jv2;
+      }
+      if (x3 < T(0)) {
+        *d1 += D * x3 * jv3;
+        *d2 += D * jv3 * jv3;
+      }
+    }
+  });
+}
+
+template <typename T>
+struct SolverCfg {
+  int max_iter;
+  T gtol;  // stop when |grad| <= gtol * (1 + |qfrc_smooth|_inf)
+};
+
+// mj_fwdConstraint: exact Newton on the primal objective
+//   1/2 (a-a0)^T M (a-a0) + sum_r 1/2 D_r min(0, J_r a - aref_r)^2
+// started from qacc_warmstart.  Outputs qacc and the final gradient
+// (so that qfrc_constraint = M qacc - qfrc_smooth - grad).
+template <typename T, typename Lds>
+EPA_HD int CheetahSolve(const CheetahModel<T>& m, const CheetahPos<T>& p,
+                        const LimitRows<T>& lim, Lds&& lds,
+                        const T* qfrc_smooth, const SolverCfg<T>& cfg, T* qacc,
+                        T* Ma, T* grad) {
+  T fs = T(0);
+  static_for<0, kNV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    T x = qfrc_smooth[i] < T(0) ? -qfrc_smooth[i] : qfrc_smooth[i];
+    fs = x > fs ? x : fs;
+  });
+  const T gstop = cfg.gtol * (T(1) + fs);
+  unsigned long long prev_mask = ~0ull;
+  bool full_step = false;
+  int iter = 0;
+  for (; iter < cfg.max_iter; ++iter) {
+    T H[kTri];
+    static_for<0, kTri>([&](auto kc) { H[decltype(kc)::value] = p.M[decltype(kc)::value]; });
+    SymMul(p.M, qacc, Ma);
+    static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      grad[i] = Ma[i] - qfrc_smooth[i];
+    });
+    unsigned long long mask =
+        CheetahRowsPass<true>(m, p, lim, lds, qacc, grad, H);
+    T gn = T(0);
+    static_for<0, kNV>([&](auto ic) { gn += grad[decltype(ic)::value] * grad[decltype(ic)::value]; });
+    gn = Sqrt(gn);
+    // finite termination: same active set after a full Newton step
+    if (gn <= gstop || (full_step && mask == prev_mask)) break;
+    prev_mask = mask;
+    T s[kNV];
+    static_for<0, kNV>([&](auto ic) { s[decltype(ic)::value] = -grad[decltype(ic)::value]; });
+    FactorUUt(H);
+    SolveUUt(H, s);
+    // exact line search on the convex piecewise-quadratic phi(alpha)
+    T Ms[kNV];
+    SymMul(p.M, s, Ms);
+    T g1 = T(0), g2 = T(0);
+    static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      g1 += s[i] * (Ma[i] - qfrc_smooth[i]);
+      g2 += s[i] * Ms[i];
+    });
+    T alpha = T(1), lo = T(0), hi = T(-1);
+    const T ag1 = g1 < T(0) ? -g1 : g1;
+    const T ls_tol = (sizeof(T) == 4 ? T(1e-4) : T(1e-12)) * ag1;
+    for (int ls = 0; ls < 24; ++ls) {
+      T d1 = g1 + alpha * g2, d2 = g2;
+      CheetahLineEval(m, p, lim, lds, qacc, s, alpha, &d1, &d2);
+      T ad1 = d1 < T(0) ? -d1 : d1;
+      if (ad1 <= ls_tol) break;
+      if (d1 < T(0)) {
+        lo = alpha;
+      } else {
+        hi = alpha;
+      }
+      T next = alpha - d1 / d2;
+      if (hi >= T(0) && (next <= lo || next >= hi)) next = T(0.5) * (lo + hi);
+      if (next <= T(0)) next = T(0.5) * alpha;
+      if (next == alpha) break;
+      alpha = next;
+    }
+    {
+      T da = alpha - T(1);
+      da = da < T(0) ? -da : da;
+      full_step = da < T(1e-3);
+    }
+    static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      qacc[i] += alpha * s[i];
+    });
+  }
+  if (iter == cfg.max_iter) {  // iteration cap hit: refresh Ma / grad
+    SymMul(p.M, qacc, Ma);
+    static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      grad[i] = Ma[i] - qfrc_smooth[i];
+    });
+    CheetahRowsPass<false>(m, p, lim, lds, qacc, grad, static_cast<T*>(nullptr));
+  }
+  return iter;
+}
+
+// One mj_step.  q[0] is carried as a local offset (caller accumulates the
+// absolute root x in fp64); returns the number of Newton iterations.
+template <typename T, typename Lds>
+EPA_HD int CheetahStep(const CheetahModel<T>& m, const SolverCfg<T>& cfg, T* q,
+                       T* v, T* warm, const T* ctrl, Lds&& lds) {
+  CheetahPos<T> p;
+  CheetahKinematics(m, q, p);
+  T qfrc_smooth[kNV];
+  CheetahSmoothForces(m, p, q, v, ctrl, qfrc_smooth);
+  LimitRows<T> lim;
+  CheetahMakeConstraint(m, p, q, v, lim, lds);
+  T qacc[kNV], Ma[kNV], grad[kNV];
+  static_for<0, kNV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
+  int iters = CheetahSolve(m, p, lim, lds, qfrc_smooth, cfg, qacc, Ma, grad);
+  static_for<0, kNV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
+  // mj_Euler with implicit joint damping:
+  //   (M + h diag(damping)) qacc_d = qfrc_smooth + qfrc_constraint = Ma - grad
+  T A[kTri], rhs[kNV];
+  static_for<0, kTri>([&](auto kc) { A[decltype(kc)::value] = p.M[decltype(kc)::value]; });
+  static_for<0, kNV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    rhs[i] = Ma[i] - grad[i];
+    if constexpr (i >= 3) A[TriIdx(i, i)] += m.timestep * m.damp[i - 3];
+  });
+  FactorUUt(A);
+  SolveUUt(A, rhs);
+  static_for<0, kNV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    v[i] += m.timestep * rhs[i];
+    q[i] += m.timestep * v[i];
+  });
+  return iters;
+}
+
+}  // namespace mj
+}  // namespace epa
+
+#endif  // ENVPOOL_AMD_CSRC_MJ_CHEETAH_CUH_

@@ -1,0 +1,209 @@
+// Host-side "model compiler" for the gym HalfCheetah: turns the MJCF numbers of
+// third_party/mujoco_gym_xml_patches/half_cheetah_envpool.xml (hand
+// transcribed below, cited by XML line; the reference loads that file at
+// envpool/mujoco/gym/mujoco_env.h:50-58,87) into the constants the planar
+// kernel needs — what MuJoCo's compiler + mj_setConst would produce:
+// capsule mass/inertia (inertiafromgeom), settotalmass=14, capsule end-sphere
+// centres, dof_invweight0 / body_invweight0 at qpos0.  Everything in fp64;
+// cast to the kernel's arithmetic type afterwards.
+#ifndef ENVPOOL_AMD_CSRC_MJ_CHEETAH_MODEL_H_
+#define ENVPOOL_AMD_CSRC_MJ_CHEETAH_MODEL_H_
+
+#include <cmath>
+
+#include "mj_cheetah.cuh"
+
+namespace epa {
+namespace mj {
+
+struct CheetahCapsule {  // <geom type="capsule" .../> attached to `body`
+  int body;
+  double px, pz;    // geom centre in the body frame
+  double angle;     // rotation about +y of the capsule's local z axis
+  double half_len;  // size[1]
+};
+
+inline CheetahModel<double> BuildCheetahModel() {
+  const double kPi = 3.14159265358979323846;
+  CheetahModel<double> m{};
+  // body_pos: torso :70, bthigh :78, bshin :81, bfoot :84, fthigh :92,
+  // fshin :95, ffoot :98
+  const double lx[kNB] = {0.0, -0.5, 0.16, -0.28, 0.5, -0.14, 0.13};
+  const double lz[kNB] = {0.7, 0.0, -0.25, -0.14, 0.0, -0.24, -0.18};
+  // capsules (radius 0.046): torso fromto -.5 0 0 .5 0 0 (:75) = centre 0,
+  // axis +x (angle pi/2), half length .5; the others use axisangle about y.
+  const CheetahCapsule caps[8] = {
+      {0, 0.0, 0.0, kPi / 2, 0.5},       // torso :75
+      {0, 0.6, 0.1, 0.87, 0.15},         // head :76
+      {1, 0.1, -0.13, -3.8, 0.145},      // bthigh :80
+      {2, -0.14, -0.07, -2.03, 0.15},    // bshin :83
+      {3, 0.03, -0.097, -0.27, 0.094},   // bfoot :86
+      {4, -0.07, -0.12, 0.52, 0.133},    // fthigh :94
+      {5, 0.065, -0.09, -0.6, 0.106},    // fshin :97
+      {6, 0.045, -0.07, -0.6, 0.07},     // ffoot :100
+  };
+  const double r = 0.046, density = 1000.0;  // MuJoCo default density
+  m.radius = r;
+  double mass[kNB] = {0}, mcx[kNB] = {0}, mcz[kNB] = {0};
+  double gm[8], gi[8];
+  for (int g = 0; g < 8; ++g) {
+    double h = 2 * caps[g].half_len;
+    double vol = kPi * (r * r * h + 4.0 * r * r * r / 3.0);
+    gm[g] = density * vol;
+    double sphere_mass = gm[g] * 4 * r / (4 * r + 3 * h);
+    double cyl_mass = gm[g] - sphere_mass;
+    // inertia about an axis perpendicular to the capsule axis (= world y)
+    gi[g] = cyl_mass * (3 * r * r + h * h) / 12 + 2 * sphere_mass * r * r / 5 +
+            sphere_mass * h * (3 * r + 2 * h) / 8;
+    int b = caps[g].body;
+    mass[b] += gm[g];
+    mcx[b] += gm[g] * caps[g].px;
+    mcz[b] += gm[g] * caps[g].pz;
+    // end-sphere centres: +axis end first, like mjc_PlaneCapsule
+    double ux = std::sin(caps[g].angle), uz = std::cos(caps[g].angle);
+    m.ex[2 * g] = caps[g].px + caps[g].half_len * ux;
+    m.ez[2 * g] = caps[g].pz + caps[g].half_len * uz;
+    m.ex[2 * g + 1] = caps[g].px - caps[g].half_len * ux;
+    m.ez[2 * g + 1] = caps[g].pz - caps[g].half_len * uz;
+  }
+  double total = 0;
+  for (int b = 0; b < kNB; ++b) {
+    m.lx[b] = lx[b];
+    m.lz[b] = lz[b];
+    m.cx[b] = mcx[b] / mass[b];
+    m.cz[b] = mcz[b] / mass[b];
+    m.mass[b] = mass[b];
+    total += mass[b];
+  }
+  for (int g = 0; g < 8; ++g) {
+    int b = caps[g].body;
+    double dx = caps[g].px - m.cx[b], dz = caps[g].pz - m.cz[b];
+    m.iyy[b] += gi[g] + gm[g] * (dx * dx + dz * dz);
+  }
+  const double scale = 14.0 / total;  // settotalmass="14" :52
+  for (int b = 0; b < kNB; ++b) {
+    m.mass[b] *= scale;
+    m.iyy[b] *= scale;
+  }
+  m.total_mass = 14.0;
+  // joints :79-97 (stiffness, damping, range), defaults :54 (armature .1),
+  // actuators :105-110 (gear)
+  const double stiff[kNU] = {240, 180, 120, 180, 120, 60};
+  const double damp[kNU] = {6, 4.5, 3, 4.5, 3, 1.5};
+  const double lo[kNU] = {-0.52, -0.785, -0.4, -1.0, -1.2, -0.5};
+  const double hi[kNU] = {1.05, 0.785, 0.785, 0.7, 0.87, 0.5};
+  const double gear[kNU] = {120, 90, 60, 120, 60, 30};
+  for (int j = 0; j < kNU; ++j) {
+    m.stiff[j] = stiff[j];
+    m.damp[j] = damp[j];
+    m.arm[j] = 0.1;
+    m.lo[j] = lo[j];
+    m.hi[j] = hi[j];
+    m.gear[j] = gear[j];
+  }
+  m.timestep = 0.01;  // :59
+  m.gravity = 9.81;   // :59
+  m.mu = 0.4;         // friction=".4 .1 .1" :55 (max of the pair, identical)
+  // solref=".02 1" :55 / solreflimit=".02 1" :54, refsafe: tc >= 2*timestep
+  const double tc = std::fmax(0.02, 2 * m.timestep), dr = 1.0;
+  // solimp="0 .8 .01" :55, solimplimit="0 .8 .03" :54, d0 clamped to 1e-4
+  m.con_d0 = 0.0001;
+  m.con_dmax = 0.8;
+  m.con_width = 0.01;
+  m.lim_d0 = 0.0001;
+  m.lim_dmax = 0.8;
+  m.lim_width = 0.03;
+  m.con_K = 1.0 / (m.con_dmax * m.con_dmax * tc * tc * dr * dr);
+  m.con_B = 2.0 / (m.con_dmax * tc);
+  m.lim_K = 1.0 / (m.lim_dmax * m.lim_dmax * tc * tc * dr * dr);
+  m.lim_B = 2.0 / (m.lim_dmax * tc);
+  // mj_setConst: M at qpos0 -> dof_invweight0, body_invweight0
+  double q0[kNV] = {0};
+  CheetahPos<double> p;
+  CheetahKinematics(m, q0, p);
+  double U[kTri];
+  for (int k = 0; k < kTri; ++k) U[k] = p.M[k];
+  // structural zeros are never written by the kernel code: clear them here
+  for (int i = 3; i <= 5; ++i) {
+    for (int j = 6; j <= 8; ++j) U[TriIdx(i, j)] = 0;
+  }
+  FactorUUt(U);
+  double Minv[kNV][kNV];
+  for (int c = 0; c < kNV; ++c) {
+    double e[kNV] = {0};
+    e[c] = 1;
+    SolveUUt(U, e);
+    for (int rr = 0; rr < kNV; ++rr) Minv[rr][c] = e[rr];
+  }
+  for (int j = 0; j < kNU; ++j) m.dof_invw[j] = Minv[j + 3][j + 3];
+  for (int b = 0; b < kNB; ++b) {
+    // translational Jacobian of the body COM (x and z rows; y row is zero)
+    double xi = p.px[b] + p.cs[b] * m.cx[b] + p.sn[b] * m.cz[b];
+    double zi = p.pz[b] - p.sn[b] * m.cx[b] + p.cs[b] * m.cz[b];
+    double Jx[kNV] = {0}, Jz[kNV] = {0};
+    Jx[0] = 1;
+    Jz[1] = 1;
+    for (int j = 2; j < kNV; ++j) {
+      if (!InChain(j, b)) continue;
+      int jb = DofBody(j);
+      Jx[j] = zi - p.pz[jb];
+      Jz[j] = -(xi - p.px[jb]);
+    }
+    double a = 0;
+    for (int i = 0; i < kNV; ++i) {
+      for (int j = 0; j < kNV; ++j) {
+        a += Jx[i] * Minv[i][j] * Jx[j] + Jz[i] * Minv[i][j] * Jz[j];
+      }
+    }
+    m.body_invw[b] = a / 3.0;
+  }
+  return m;
+}
+
+template <typename T>
+inline CheetahModel<T> CastCheetahModel(const CheetahModel<double>& d) {
+  CheetahModel<T> m{};
+  for (int b = 0; b < kNB; ++b) {
+    m.lx[b] = (T)d.lx[b];
+    m.lz[b] = (T)d.lz[b];
+    m.mass[b] = (T)d.mass[b];
+    m.iyy[b] = (T)d.iyy[b];
+    m.cx[b] = (T)d.cx[b];
+    m.cz[b] = (T)d.cz[b];
+    m.body_invw[b] = (T)d.body_invw[b];
+  }
+  for (int e = 0; e < kNEnd; ++e) {
+    m.ex[e] = (T)d.ex[e];
+    m.ez[e] = (T)d.ez[e];
+  }
+  for (int j = 0; j < kNU; ++j) {
+    m.stiff[j] = (T)d.stiff[j];
+    m.damp[j] = (T)d.damp[j];
+    m.arm[j] = (T)d.arm[j];
+    m.lo[j] = (T)d.lo[j];
+    m.hi[j] = (T)d.hi[j];
+    m.gear[j] = (T)d.gear[j];
+    m.dof_invw[j] = (T)d.dof_invw[j];
+  }
+  m.radius = (T)d.radius;
+  m.total_mass = (T)d.total_mass;
+  m.mu = (T)d.mu;
+  m.con_K = (T)d.con_K;
+  m.con_B = (T)d.con_B;
+  m.con_d0 = (T)d.con_d0;
+  m.con_dmax = (T)d.con_dmax;
+  m.con_width = (T)d.con_width;
+  m.lim_K = (T)d.lim_K;
+  m.lim_B = (T)d.lim_B;
+  m.lim_d0 = (T)d.lim_d0;
+  m.lim_dmax = (T)d.lim_dmax;
+  m.lim_width = (T)d.lim_width;
+  m.timestep = (T)d.timestep;
+  m.gravity = (T)d.gravity;
+  return m;
+}
+
+}  // namespace mj
+}  // namespace epa
+
+#endif  // ENVPOOL_AMD_CSRC_MJ_CHEETAH_MODEL_H_

@@ -1,6 +1,286 @@
-// placeholder: replaced by the MuJoCo gym kernels
+// K3 — gym-MuJoCo batched step kernels (one env per thread, one wave per block).
+//
+// Replaces, for the whole batch in one launch:
+//   MujocoEnv::{MujocoReset,MujocoStep}     envpool/mujoco/gym/mujoco_env.h:126-148
+//   HalfCheetahEnvBase::{MujocoResetModel,Reset,Step,WriteState}
+//                                           envpool/mujoco/gym/half_cheetah.h:105-185
+// including the `frame_skip x mj_step` physics (mj_cheetah.cuh) and the
+// runtime around it (async_envpool.h:118-132, env.h:184-256).
+//
+// Data layout (HBM): persistent state is SoA float64 — qpos[9][N], qvel[9][N],
+// qacc_warmstart[9][N] (+ the saved value of the env's normal_distribution and
+// the shared done/cur_step/mt19937 arrays).  Arithmetic runs in T = float
+// (BASELINE config "fp32") or double ("precision"=1); the root x is carried
+// as a local offset per step and accumulated in fp64 so fp32 mode keeps the
+// forward-velocity reward accurate far from the origin.  Outputs are written
+// in the reference dtypes (obs/info float64, reward float32).
+//
+// Not HBM-bound: ~708 algorithmic bytes vs ~2e5 flops per env-step
+// => bound by fp32 VALU issue + wave divergence in the Newton iteration count.
+#include "device_common.cuh"
 #include "engine.h"
+#include "mj_cheetah.cuh"
+#include "mj_cheetah_model.h"
+
 namespace epa {
-bool DescribeMujoco(const std::string&, const Config&, std::vector<KeySpec>*, KeySpec*) { return false; }
-Pool* MakeMujoco(const std::string&, const Config&) { return nullptr; }
+namespace {
+
+using mj::CheetahModel;
+using mj::kNU;
+using mj::kNV;
+
+struct CheetahDev {
+  double* qpos;  // [9][N]
+  double* qvel;  // [9][N]
+  double* warm;  // [9][N]
+  double* nsaved;          // normal_distribution::_M_saved
+  unsigned char* navail;   // normal_distribution::_M_saved_available
+};
+
+struct CheetahTask {
+  int frame_skip;
+  int obs_skip;  // 1 if exclude_current_positions_from_observation
+  double ctrl_cost_weight, forward_reward_weight, reset_noise_scale;
+  double dt;     // frame_skip * timestep, computed in fp64 like the reference
+};
+
+constexpr int kCheetahBlock = 64;
+
+template <typename T>
+__global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
+    CheetahDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action,
+    OutPtrs out, CheetahModel<T> m, CheetahTask task,
+    mj::SolverCfg<T> scfg) {
+  __shared__ T lds_buf[mj::kLdsSlots * kCheetahBlock];
+  const int lane = threadIdx.x;
+  const int n = cm.n;
+  const int row = blockIdx.x * kCheetahBlock + lane;
+  if (row >= a.k) return;
+  const int e = a.ids ? a.ids[row] - a.id_offset : row;
+  bool done = cm.done[e] != 0;
+  int cur = cm.cur_step[e];
+  const bool reset = a.force_reset || done;  // async_envpool.h:127
+  double qpos[kNV], qvel[kNV];
+  float reward = 0.0f;
+  double xv = 0.0, ctrl_cost = 0.0;
+  if (reset) {
+    // MujocoReset: mj_resetData + MujocoResetModel (half_cheetah.h:105-117);
+    // the trailing mj_forward only refreshes qacc_warmstart, which the solver
+    // re-derives (unique minimiser), so the warm start is simply cleared.
+    cur = 0;
+    done = false;
+    Mt19937 g(cm, e);
+    double saved = dev.nsaved[e];
+    int avail = dev.navail[e];
+    for (int i = 0; i < kNV; ++i) {
+      qpos[i] = 0.0 + g.UniformReal(-task.reset_noise_scale,
+                                    task.reset_noise_scale);
+    }
+    for (int i = 0; i < kNV; ++i) {
+      qvel[i] = 0.0 + g.Normal(0.0, task.reset_noise_scale, &saved, &avail);
+    }
+    g.Commit();
+    dev.nsaved[e] = saved;
+    dev.navail[e] = (unsigned char)avail;
+    for (int i = 0; i < kNV; ++i) {
+      dev.qpos[(size_t)i * n + e] = qpos[i];
+      dev.qvel[(size_t)i * n + e] = qvel[i];
+      dev.warm[(size_t)i * n + e] = 0.0;
+    }
+  } else {
+    ++cur;
+    T q[kNV], v[kNV], w[kNV], ctrl[kNU];
+    mj::static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      qpos[i] = dev.qpos[(size_t)i * n + e];
+      q[i] = (T)qpos[i];
+      v[i] = (T)dev.qvel[(size_t)i * n + e];
+      w[i] = (T)dev.warm[(size_t)i * n + e];
+    });
+    const double x_before = qpos[0];
+    q[0] = T(0);
+    const double* act = action + (size_t)row * kNU;
+    mj::static_for<0, kNU>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      double ai = act[i];
+      ctrl_cost += task.ctrl_cost_weight * ai * ai;  // half_cheetah.h:143-146
+      // ctrllimited motors: MuJoCo clamps ctrl to ctrlrange [-1, 1]
+      ctrl[i] = (T)(ai < -1.0 ? -1.0 : (ai > 1.0 ? 1.0 : ai));
+    });
+    auto lds = [&](int slot) -> T& { return lds_buf[slot * kCheetahBlock + lane]; };
+    for (int s = 0; s < task.frame_skip; ++s) {  // mujoco_env.h:142-144
+      mj::CheetahStep(m, scfg, q, v, w, ctrl, lds);
+    }
+    const double x_after = x_before + (double)q[0];
+    xv = (x_after - x_before) / task.dt;  // half_cheetah.h:148-149
+    reward = static_cast<float>(xv * task.forward_reward_weight - ctrl_cost);
+    done = cur >= a.max_episode_steps;  // ++elapsed_step_ >= max_episode_steps_
+    qpos[0] = x_after;
+    mj::static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i > 0) qpos[i] = (double)q[i];
+      qvel[i] = (double)v[i];
+      dev.qpos[(size_t)i * n + e] = qpos[i];
+      dev.qvel[(size_t)i * n + e] = qvel[i];
+      dev.warm[(size_t)i * n + e] = (double)w[i];
+    });
+  }
+  cm.done[e] = done ? 1 : 0;
+  cm.cur_step[e] = cur;
+  // WriteState, half_cheetah.h:158-185
+  const int nobs = 2 * kNV - task.obs_skip;
+  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
+  for (int i = task.obs_skip; i < kNV; ++i) *(obs++) = qpos[i];
+  for (int i = 0; i < kNV; ++i) *(obs++) = qvel[i];
+  ((double*)out.p[kKeyEnv0 + 1])[row] = xv * task.forward_reward_weight;
+  ((double*)out.p[kKeyEnv0 + 2])[row] = -ctrl_cost;
+  ((double*)out.p[kKeyEnv0 + 3])[row] = reset ? 0.0 : qpos[0];
+  ((double*)out.p[kKeyEnv0 + 4])[row] = xv;
+  WriteCommon(out, row, e + a.id_offset, cur, done, reward,
+              a.max_episode_steps);
 }
+
+// flat state, same layout as oracle/mjcpu: qpos[9] qvel[9] warm[9] time xlag
+// ylag done cur_step normal_saved normal_avail
+constexpr int kCheetahStateDim = 3 * kNV + 7;
+__global__ void CheetahGetState(CheetahDev dev, CommonDev cm, const int* ids,
+                                int k, double* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  int e = ids[i], n = cm.n;
+  double* o = out + (size_t)i * kCheetahStateDim;
+  for (int j = 0; j < kNV; ++j) {
+    o[j] = dev.qpos[(size_t)j * n + e];
+    o[kNV + j] = dev.qvel[(size_t)j * n + e];
+    o[2 * kNV + j] = dev.warm[(size_t)j * n + e];
+  }
+  double* t = o + 3 * kNV;
+  t[0] = 0;
+  t[1] = 0;
+  t[2] = 0;
+  t[3] = cm.done[e];
+  t[4] = cm.cur_step[e];
+  t[5] = dev.nsaved[e];
+  t[6] = dev.navail[e];
+}
+__global__ void CheetahSetState(CheetahDev dev, CommonDev cm, const int* ids,
+                                int k, const double* in) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  int e = ids[i], n = cm.n;
+  const double* o = in + (size_t)i * kCheetahStateDim;
+  for (int j = 0; j < kNV; ++j) {
+    dev.qpos[(size_t)j * n + e] = o[j];
+    dev.qvel[(size_t)j * n + e] = o[kNV + j];
+    dev.warm[(size_t)j * n + e] = o[2 * kNV + j];
+  }
+  const double* t = o + 3 * kNV;
+  cm.done[e] = t[3] != 0.0;
+  cm.cur_step[e] = (int)t[4];
+  dev.nsaved[e] = t[5];
+  dev.navail[e] = t[6] != 0.0;
+}
+
+std::vector<KeySpec> CheetahKeys(const Config& cfg) {
+  int no_pos = cfg.Get("exclude_current_positions_from_observation", 1) != 0;
+  // half_cheetah.h:44-62 (non-ENVPOOL_TEST build)
+  return {{"obs", EPA_F64, {no_pos ? 17 : 18}},
+          {"info:reward_run", EPA_F64, {}},
+          {"info:reward_ctrl", EPA_F64, {}},
+          {"info:x_position", EPA_F64, {}},
+          {"info:x_velocity", EPA_F64, {}}};
+}
+
+class CheetahPool : public Pool {
+ public:
+  explicit CheetahPool(const Config& cfg)
+      : Pool(cfg, CheetahKeys(cfg), KeySpec{"action", EPA_F64, {kNU}},
+             /*needs_rng=*/true) {
+    if ((int)cfg.Get("frame_stack", 1) != 1) {
+      throw std::invalid_argument("frame_stack != 1 is not supported yet");
+    }
+    fp64_ = (int)cfg.Get("precision", 0) == 1;
+    model_ = mj::BuildCheetahModel();
+    task_.frame_skip = (int)cfg.Get("frame_skip", 5);
+    task_.obs_skip =
+        cfg.Get("exclude_current_positions_from_observation", 1) != 0 ? 1 : 0;
+    task_.ctrl_cost_weight = cfg.Get("ctrl_cost_weight", 0.1);
+    task_.forward_reward_weight = cfg.Get("forward_reward_weight", 1.0);
+    task_.reset_noise_scale = cfg.Get("reset_noise_scale", 0.1);
+    task_.dt = task_.frame_skip * model_.timestep;
+    size_t n = cfg.num_envs;
+    EPA_HIP(hipMalloc(&dev_.qpos, sizeof(double) * kNV * n));
+    EPA_HIP(hipMalloc(&dev_.qvel, sizeof(double) * kNV * n));
+    EPA_HIP(hipMalloc(&dev_.warm, sizeof(double) * kNV * n));
+    EPA_HIP(hipMalloc(&dev_.nsaved, sizeof(double) * n));
+    EPA_HIP(hipMalloc(&dev_.navail, n));
+    EPA_HIP(hipMemsetAsync(dev_.qpos, 0, sizeof(double) * kNV * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.qvel, 0, sizeof(double) * kNV * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.warm, 0, sizeof(double) * kNV * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.nsaved, 0, sizeof(double) * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.navail, 0, n, stream_));
+    InitCommon();
+  }
+  ~CheetahPool() override {
+    (void)hipFree(dev_.qpos);
+    (void)hipFree(dev_.qvel);
+    (void)hipFree(dev_.warm);
+    (void)hipFree(dev_.nsaved);
+    (void)hipFree(dev_.navail);
+  }
+  int StateDim() const override { return kCheetahStateDim; }
+  void GetState(const int* d_ids, int k, double* d_out) override {
+    hipLaunchKernelGGL(CheetahGetState, dim3((k + 255) / 256), dim3(256), 0,
+                       stream_, dev_, common_, d_ids, k, d_out);
+  }
+  void SetState(const int* d_ids, int k, const double* d_in) override {
+    hipLaunchKernelGGL(CheetahSetState, dim3((k + 255) / 256), dim3(256), 0,
+                       stream_, dev_, common_, d_ids, k, d_in);
+  }
+
+ protected:
+  void Launch(const int* d_ids, int k, const void* d_action, bool force_reset,
+              const OutPtrs& out) override {
+    StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps,
+               cfg_.env_id_offset};
+    int blocks = (k + kCheetahBlock - 1) / kCheetahBlock;
+    if (fp64_) {
+      mj::SolverCfg<double> sc{50, 1e-13};
+      hipLaunchKernelGGL(CheetahStepKernel<double>, dim3(blocks),
+                         dim3(kCheetahBlock), 0, stream_, dev_, common_, a,
+                         static_cast<const double*>(d_action), out, model_,
+                         task_, sc);
+    } else {
+      mj::SolverCfg<float> sc{12, 1e-6f};
+      hipLaunchKernelGGL(CheetahStepKernel<float>, dim3(blocks),
+                         dim3(kCheetahBlock), 0, stream_, dev_, common_, a,
+                         static_cast<const double*>(d_action), out,
+                         mj::CastCheetahModel<float>(model_), task_, sc);
+    }
+  }
+
+ private:
+  CheetahDev dev_{};
+  CheetahModel<double> model_;
+  CheetahTask task_{};
+  bool fp64_{false};
+};
+
+}  // namespace
+
+bool DescribeMujoco(const std::string& family, const Config& cfg,
+                    std::vector<KeySpec>* state, KeySpec* action) {
+  if (family == "HalfCheetah") {
+    *state = CheetahKeys(cfg);
+    *action = KeySpec{"action", EPA_F64, {kNU}};
+    return true;
+  }
+  return false;
+}
+
+Pool* MakeMujoco(const std::string& family, const Config& cfg) {
+  if (family == "HalfCheetah") return new CheetahPool(cfg);
+  return nullptr;
+}
+
+}  // namespace epa

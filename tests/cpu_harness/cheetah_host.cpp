@@ -1,0 +1,64 @@
+// TEST HARNESS (not product): compiles the host instantiation of the planar
+// HalfCheetah step template (envpool_amd/csrc/mj_cheetah.cuh, EPA_HD) with g++
+// so the exact kernel source can be diffed against oracle/mjcpu on a CPU box.
+// Nothing in envpool_amd/ links or loads this.
+#include <cstring>
+#include <vector>
+
+#include "../../envpool_amd/csrc/mj_cheetah_model.h"
+
+using namespace epa::mj;
+
+template <typename T>
+static void Run(const double* q, const double* v, const double* warm,
+                const double* ctrl, int nsub, double* qo, double* vo,
+                double* wo, int* iters) {
+  CheetahModel<double> md = BuildCheetahModel();
+  CheetahModel<T> m = CastCheetahModel<T>(md);
+  SolverCfg<T> cfg{sizeof(T) == 4 ? 12 : 50, sizeof(T) == 4 ? T(1e-6) : T(1e-13)};
+  T tq[kNV], tv[kNV], tw[kNV], tc[kNU];
+  double x0 = q[0];
+  for (int i = 0; i < kNV; ++i) {
+    tq[i] = (T)q[i];
+    tv[i] = (T)v[i];
+    tw[i] = (T)warm[i];
+  }
+  tq[0] = 0;  // local x
+  for (int i = 0; i < kNU; ++i) {
+    double c = ctrl[i] < -1 ? -1 : (ctrl[i] > 1 ? 1 : ctrl[i]);
+    tc[i] = (T)c;
+  }
+  T lds[kLdsSlots];
+  int it = 0;
+  for (int s = 0; s < nsub; ++s) {
+    it += CheetahStep(m, cfg, tq, tv, tw, tc, [&](int slot) -> T& { return lds[slot]; });
+  }
+  for (int i = 0; i < kNV; ++i) {
+    qo[i] = tq[i];
+    vo[i] = tv[i];
+    wo[i] = tw[i];
+  }
+  qo[0] += x0;
+  *iters = it;
+}
+
+extern "C" {
+void cheetah_host_step(const double* q, const double* v, const double* warm,
+                       const double* ctrl, int nsub, int use_float, double* qo,
+                       double* vo, double* wo, int* iters) {
+  if (use_float) {
+    Run<float>(q, v, warm, ctrl, nsub, qo, vo, wo, iters);
+  } else {
+    Run<double>(q, v, warm, ctrl, nsub, qo, vo, wo, iters);
+  }
+}
+// [mass(7) iyy(7) dof_invw(6) body_invw(7)]
+void cheetah_host_model(double* out) {
+  CheetahModel<double> m = BuildCheetahModel();
+  int k = 0;
+  for (int b = 0; b < kNB; ++b) out[k++] = m.mass[b];
+  for (int b = 0; b < kNB; ++b) out[k++] = m.iyy[b];
+  for (int j = 0; j < kNU; ++j) out[k++] = m.dof_invw[j];
+  for (int b = 0; b < kNB; ++b) out[k++] = m.body_invw[b];
+}
+}

@@ -1,0 +1,113 @@
+"""GPU parity of the HalfCheetah HIP kernel (through the C ABI) against the
+fp64 oracle (oracle/mjcpu — parity of that oracle vs real MuJoCo is UNPINNED,
+see oracle/mjcpu/mjcpu.h).
+
+Tolerances (stated): teacher-forced per env-step (5 mj_steps):
+  precision=fp64 kernel : obs rtol 1e-9 / atol 1e-10
+  precision=fp32 kernel : obs rtol 2e-4 / atol 2e-4 (fp32 arithmetic, fp64 I/O)
+"""
+import numpy as np
+import pytest
+
+from envpool_amd.core.device_pool import DevicePool
+from oracle.orc import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(n, seed, precision, max_steps=1000):
+    pool = DevicePool("HalfCheetah", n, seed=seed, max_episode_steps=max_steps,
+                      params={"precision": precision})
+    orc = Oracle("HalfCheetah", n, seed=seed, max_episode_steps=max_steps)
+    return pool, orc
+
+
+def hip_reset(pool):
+    pool.reset(np.arange(pool.num_envs, dtype=np.int32))
+    return pool.recv_dict()
+
+
+def hip_step(pool, act):
+    pool.send(np.arange(pool.num_envs, dtype=np.int32), act)
+    return pool.recv_dict()
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_reset_matches_oracle(precision):
+    pool, orc = make_pair(64, 5, precision)
+    a, b = hip_reset(pool), orc.reset()
+    # uniform draws are bit exact; normals go through device log/sqrt
+    np.testing.assert_array_equal(a["obs"][:, :8], b["obs"][:, :8])
+    np.testing.assert_allclose(a["obs"][:, 8:], b["obs"][:, 8:], rtol=1e-14, atol=1e-16)
+    for k in ("elapsed_step", "done", "reward", "discount", "step_type", "trunc",
+              "info:env_id"):
+        np.testing.assert_array_equal(a[k].ravel(), b[k].ravel())
+
+
+@pytest.mark.parametrize("precision,rtol,atol", [(1, 1e-9, 1e-10), (0, 2e-4, 2e-4)])
+def test_teacher_forced_step(precision, rtol, atol):
+    n, steps = 256, 120
+    pool, orc = make_pair(n, 9, precision)
+    hip_reset(pool), orc.reset()
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for t in range(steps):
+        pool.set_state(orc.get_state())
+        act = rng.uniform(-1.2, 1.2, size=(n, 6))
+        a, b = hip_step(pool, act), orc.step(act)
+        np.testing.assert_allclose(a["obs"], b["obs"], rtol=rtol, atol=atol,
+                                   err_msg=f"step {t}")
+        np.testing.assert_allclose(a["reward"].ravel(), b["reward"].ravel(),
+                                   rtol=max(rtol, 1e-6), atol=max(atol * 20, 1e-6))
+        for k in ("info:x_position", "info:x_velocity", "info:reward_ctrl"):
+            np.testing.assert_allclose(a[k].ravel(), b[k].ravel(), rtol=rtol,
+                                       atol=atol * 20)
+        worst = max(worst, float(np.abs(a["obs"] - b["obs"]).max()))
+    print(f"precision={precision}: worst teacher-forced |d obs| = {worst:.3e}")
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_free_running_horizon(precision):
+    n, steps = 128, 300
+    pool, orc = make_pair(n, 1, precision)
+    a, b = hip_reset(pool), orc.reset()
+    rng = np.random.default_rng(7)
+    first = None
+    for t in range(steps):
+        act = rng.uniform(-1, 1, size=(n, 6))
+        a, b = hip_step(pool, act), orc.step(act)
+        rel = np.abs(a["obs"] - b["obs"]) / (1e-2 + np.abs(b["obs"]))
+        if first is None and rel.max() > 1e-5:
+            first = t
+    print(f"precision={precision}: first step with rel obs error > 1e-5: {first} "
+          f"(final max rel {rel.max():.2e})")
+    if precision == 1:
+        assert first is None or first >= 50
+
+
+def test_episode_bookkeeping_and_autoreset():
+    """max_episode_steps=7: done/trunc/step_type/elapsed_step and the
+    auto-reset on the following step follow the reference exactly."""
+    n = 32
+    pool, orc = make_pair(n, 2, 1, max_steps=7)
+    a, b = hip_reset(pool), orc.reset()
+    rng = np.random.default_rng(0)
+    for t in range(30):
+        act = rng.uniform(-1, 1, size=(n, 6))
+        a, b = hip_step(pool, act), orc.step(act)
+        for k in ("elapsed_step", "done", "discount", "step_type", "trunc",
+                  "info:env_id"):
+            np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k}@{t}")
+    assert b["elapsed_step"].max() <= 7
+
+
+def test_fp32_energy_sanity():
+    """The fp32 kernel must stay finite and bounded over a long random rollout."""
+    n = 1024
+    pool = DevicePool("HalfCheetah", n, seed=0, max_episode_steps=1000)
+    hip_reset(pool)
+    rng = np.random.default_rng(0)
+    for t in range(400):
+        d = hip_step(pool, rng.uniform(-1, 1, size=(n, 6)))
+    assert np.isfinite(d["obs"]).all()
+    assert np.abs(d["obs"][:, 8:]).max() < 100
