@@ -35,7 +35,7 @@ def cpu_baseline(num_envs=64, target_s=15.0):
     act = rng.uniform(-1, 1, size=(num_envs, 6))
     t = o.time_steps(5, act)
     steps = max(5, int(target_s / max(t / 5, 1e-6)))
-    steps = min(steps, 2000)
+    steps = min(steps, 20000)
     t = o.time_steps(steps, act)
     return {
         "value": num_envs * steps / t,
@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--num-envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--task", default="HalfCheetah")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp64"])
+    ap.add_argument("--precision", default="fp64", choices=["fp32", "fp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

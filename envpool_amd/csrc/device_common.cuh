@@ -5,8 +5,9 @@
 //    plus `int mti[N]`, and the libstdc++-11 distributions the env bodies use
 //    (generate_canonical / uniform_real / uniform_int(Lemire) / normal(polar)),
 //    bit-exact with /usr/include/c++/11/bits/{random.tcc,uniform_int_dist.h}.
-//    Files using the floating-point distributions are compiled with
-//    -ffp-contract=off (the reference's x86-64 build does not fuse a*b+c).
+//    The floating-point distributions carry `#pragma clang fp contract(off)`
+//    (the reference's x86-64 build does not fuse a*b+c) so they stay bit-exact
+//    even in translation units built with fast contraction (mujoco_gym.hip).
 //  * WriteCommon: the bookkeeping Env::Allocate does for every returned row
 //    (envpool/core/env.h:224-256).
 #ifndef ENVPOOL_AMD_CSRC_DEVICE_COMMON_CUH_
@@ -91,6 +92,7 @@ struct Mt19937 {
 
   // std::generate_canonical<double, 53>: random.tcc:3348-3380
   __device__ double Canonical() {
+#pragma clang fp contract(off)
     double sum = 0.0, tmp = 1.0;
     sum += (double)Next() * tmp;
     tmp *= 4294967296.0;
@@ -102,6 +104,7 @@ struct Mt19937 {
   }
   // std::uniform_real_distribution<double>(a, b)
   __device__ double UniformReal(double a, double b) {
+#pragma clang fp contract(off)
     return (Canonical() * (b - a)) + a;
   }
   // std::uniform_int_distribution<int>(a, b): uniform_int_dist.h:240-268
@@ -122,6 +125,7 @@ struct Mt19937 {
   // live in the distribution object of the env => persistent per-env state.
   __device__ double Normal(double mean, double stddev, double* saved,
                            int* avail) {
+#pragma clang fp contract(off)
     double ret;
     if (*avail) {
       *avail = 0;

@@ -199,7 +199,9 @@ class CheetahPool : public Pool {
     if ((int)cfg.Get("frame_stack", 1) != 1) {
       throw std::invalid_argument("frame_stack != 1 is not supported yet");
     }
-    fp64_ = (int)cfg.Get("precision", 0) == 1;
+    // "precision": 1 = fp64 arithmetic (default: matches the reference's
+    // mjtNum=double), 0 = fp32 arithmetic with fp64 state/IO (BASELINE "fp32").
+    fp64_ = (int)cfg.Get("precision", 1) == 1;
     model_ = mj::BuildCheetahModel();
     task_.frame_skip = (int)cfg.Get("frame_skip", 5);
     task_.obs_skip =
