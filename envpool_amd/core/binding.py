@@ -1,0 +1,271 @@
+"""Native (spec, pool) class pairs for the Python adaptors.
+
+In the reference these classes come out of the pybind11 `REGISTER` macro
+(envpool/core/py_envpool.h:303-332): `_XxxEnvSpec` exposing
+`_config_keys/_default_config_values/_state_keys/_action_keys/_config_values/
+_state_spec/_action_spec`, and `_XxxEnvPool` exposing
+`_spec/_send/_recv/_reset/_render/_xla`.  Here the same surface is produced by
+`make_native_classes(FamilyDef)` on top of the C ABI (core/native.py), so the
+adaptors under envpool_amd/python are oblivious to the swap.
+
+Spec tuples follow SpecTupleHelper (py_envpool.h:103-110):
+  (np.dtype, shape list, (lo, hi), (elementwise lo[], hi[]), is_discrete)
+with the reference's defaults for unbounded specs, i.e.
+std::numeric_limits<T>::min()/max() (envpool/core/spec.h:71-72; note that
+::min() of a float type is the smallest positive normal, as in the reference).
+"""
+
+from __future__ import annotations
+
+import collections
+from dataclasses import dataclass, field
+from typing import Any, Callable, Sequence
+
+import numpy as np
+
+from . import native
+from .device_pool import DevicePool
+
+INT_MAX = 2**31 - 1
+INT_MIN = -(2**31)
+F32_MIN, F32_MAX = float(np.finfo(np.float32).tiny), float(np.finfo(np.float32).max)
+F64_MIN, F64_MAX = float(np.finfo(np.float64).tiny), float(np.finfo(np.float64).max)
+
+_DEFAULT_BOUNDS = {
+    np.dtype(np.int32): (INT_MIN, INT_MAX),
+    np.dtype(np.float32): (F32_MIN, F32_MAX),
+    np.dtype(np.float64): (F64_MIN, F64_MAX),
+    np.dtype(np.bool_): (False, True),
+    np.dtype(np.uint8): (0, 255),
+}
+
+
+def spec(dtype: Any, shape: Sequence[int], bounds: tuple | None = None,
+         elementwise: tuple | None = None, is_discrete: bool = False) -> tuple:
+    dt = np.dtype(dtype)
+    if bounds is None:
+        bounds = _DEFAULT_BOUNDS[dt]
+    if elementwise is None:
+        elementwise = ([], [])
+    return (dt, list(shape), tuple(bounds), (list(elementwise[0]), list(elementwise[1])),
+            bool(is_discrete))
+
+
+# common_config / common_action_spec / common_state_spec: env_spec.h:26-43
+COMMON_CONFIG: list[tuple[str, Any]] = [
+    ("num_envs", 1),
+    ("batch_size", 0),
+    ("num_threads", 0),
+    ("max_num_players", 1),
+    ("thread_affinity_offset", -1),
+    ("base_path", "envpool"),
+    ("seed", 42),
+    ("env_seed", []),
+    ("gym_reset_return_info", True),
+    ("max_episode_steps", INT_MAX),
+]
+# extensions of this engine, appended AFTER the env-specific keys so that the
+# reference's prefix of config keys is unchanged
+EXTENSION_CONFIG: list[tuple[str, Any]] = [
+    ("device", 0),          # HIP device ordinal, or a list of ordinals to shard over
+    ("env_id_offset", 0),   # global id of local env 0 (one shard of a bigger pool)
+]
+COMMON_ACTION_SPEC = [
+    ("env_id", spec(np.int32, [])),
+    ("players.env_id", spec(np.int32, [-1])),
+]
+COMMON_STATE_SPEC = [
+    ("info:env_id", spec(np.int32, [])),
+    ("info:players.env_id", spec(np.int32, [-1])),
+    ("elapsed_step", spec(np.int32, [])),
+    ("done", spec(np.bool_, [])),
+    ("reward", spec(np.float32, [-1])),
+    ("discount", spec(np.float32, [-1], (0.0, 1.0))),
+    ("step_type", spec(np.int32, [])),
+    ("trunc", spec(np.bool_, [])),
+]
+
+
+@dataclass
+class FamilyDef:
+    """Python-side description of `XxxEnvFns` of the reference."""
+
+    name: str                       # class stem, e.g. "CartPole" / "GymHalfCheetah"
+    native: str                     # family name understood by the C ABI
+    default_config: list[tuple[str, Any]]
+    state_spec: Callable[[dict], list[tuple[str, tuple]]]
+    action_spec: Callable[[dict], list[tuple[str, tuple]]]
+    # config -> numeric params forwarded to the C ABI (epa_config.param_*)
+    native_params: Callable[[dict], dict[str, float]] = lambda conf: {}
+    # config keys accepted for API compatibility but not supported when changed
+    unsupported: dict[str, Any] = field(default_factory=dict)
+
+
+class _ShardedPools:
+    """num_envs split contiguously over several GPUs of one process:
+    shard s owns env ids [s*per, (s+1)*per).  Each shard is a DevicePool with
+    its own stream, so the step kernels of all GPUs run concurrently; there is
+    no inter-GPU traffic on the data path."""
+
+    def __init__(self, family: str, devices: Sequence[int], num_envs: int, **kw: Any):
+        if num_envs % len(devices) != 0:
+            raise ValueError("num_envs must be divisible by the number of devices")
+        if kw.get("batch_size", 0) not in (0, num_envs):
+            raise ValueError("async mode (batch_size < num_envs) needs a single device")
+        self.per = num_envs // len(devices)
+        self.offset = kw.pop("env_id_offset", 0)
+        env_seed = kw.pop("env_seed", None)
+        kw.pop("batch_size", None)
+        self.pools = [
+            DevicePool(family, self.per, device=d, env_id_offset=self.offset + s * self.per,
+                       env_seed=(env_seed[s * self.per:(s + 1) * self.per] if env_seed else None),
+                       **kw)
+            for s, d in enumerate(devices)
+        ]
+        self.state_keys = self.pools[0].state_keys
+        self._pending: collections.deque = collections.deque()
+
+    def _split(self, ids: np.ndarray) -> list[np.ndarray]:
+        shard = (ids - self.offset) // self.per
+        return [np.flatnonzero(shard == s) for s in range(len(self.pools))]
+
+    def send(self, env_id: np.ndarray, action: np.ndarray) -> None:
+        env_id = np.ascontiguousarray(env_id, dtype=np.int32)
+        parts = self._split(env_id)
+        for p, idx in zip(self.pools, parts):
+            if len(idx):
+                p.send(env_id[idx], np.ascontiguousarray(action[idx]))
+        self._pending.append((len(env_id), parts))
+
+    def reset(self, env_ids: np.ndarray) -> None:
+        env_ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+        parts = self._split(env_ids)
+        for p, idx in zip(self.pools, parts):
+            if len(idx):
+                p.reset(env_ids[idx])
+        self._pending.append((len(env_ids), parts))
+
+    def recv(self) -> list[np.ndarray]:
+        if not self._pending:
+            raise RuntimeError("recv: nothing pending")
+        k, parts = self._pending.popleft()
+        outs = [np.empty((k, *shape), dtype=dtype) for _, dtype, shape in self.state_keys]
+        for p, idx in zip(self.pools, parts):
+            if len(idx):
+                for o, part in zip(outs, p.recv()):
+                    o[idx] = part
+        return outs
+
+    def close(self) -> None:
+        for p in self.pools:
+            p.close()
+
+
+def make_native_classes(fd: FamilyDef) -> tuple[type, type]:
+    """Build `_<Name>EnvSpec` and `_<Name>EnvPool` for a family."""
+    config_items = COMMON_CONFIG + list(fd.default_config) + EXTENSION_CONFIG
+    config_keys = [k for k, _ in config_items]
+    default_values = tuple(v for _, v in config_items)
+    # key lists are static per class in the reference (py_envpool.h:163-171)
+    default_conf = dict(config_items)
+    state_keys = [k for k, _ in COMMON_STATE_SPEC] + [k for k, _ in fd.state_spec(default_conf)]
+    action_keys = [k for k, _ in COMMON_ACTION_SPEC] + [k for k, _ in fd.action_spec(default_conf)]
+
+    class _Spec:
+        _config_keys = config_keys
+        _default_config_values = default_values
+        _state_keys = state_keys
+        _action_keys = action_keys
+
+        def __init__(self, config_values: Any) -> None:
+            values = list(config_values)
+            if len(values) != len(config_keys):
+                raise TypeError(
+                    f"{type(self).__name__} expects {len(config_keys)} config values"
+                )
+            conf = dict(zip(config_keys, values))
+            # EnvSpec ctor, envpool/core/env_spec.h:75-83
+            if conf["batch_size"] > conf["num_envs"]:
+                raise ValueError(
+                    "It is required that batch_size <= num_envs, got num_envs = "
+                    f"{conf['num_envs']}, batch_size = {conf['batch_size']}"
+                )
+            if conf["batch_size"] == 0:
+                conf["batch_size"] = conf["num_envs"]
+            for key, supported in fd.unsupported.items():
+                if conf.get(key, supported) != supported:
+                    raise ValueError(
+                        f"{fd.name}: {key}={conf[key]!r} is not supported by the "
+                        f"MI355X engine yet (only {supported!r})"
+                    )
+            self._conf = conf
+            self._config_values = tuple(conf[k] for k in config_keys)
+
+        @property
+        def _state_spec(self) -> tuple:
+            return tuple(s for _, s in COMMON_STATE_SPEC) + tuple(
+                s for _, s in fd.state_spec(self._conf))
+
+        @property
+        def _action_spec(self) -> tuple:
+            return tuple(s for _, s in COMMON_ACTION_SPEC) + tuple(
+                s for _, s in fd.action_spec(self._conf))
+
+    class _Pool:
+        _state_keys = state_keys
+        _action_keys = action_keys
+
+        def __init__(self, spec: Any) -> None:
+            conf = dict(zip(spec._config_keys, spec._config_values))
+            if conf["max_num_players"] != 1:
+                raise ValueError("only single-player envs are on the MI355X path")
+            params = {k: float(v) for k, v in fd.native_params(conf).items()}
+            kw = dict(
+                batch_size=conf["batch_size"],
+                seed=conf["seed"],
+                env_seed=list(conf["env_seed"]) or None,
+                max_episode_steps=conf["max_episode_steps"],
+                env_id_offset=conf["env_id_offset"],
+                params=params,
+            )
+            device = conf["device"]
+            if isinstance(device, (list, tuple)) and len(device) > 1:
+                self._pool: Any = _ShardedPools(fd.native, list(device), conf["num_envs"], **kw)
+            else:
+                if isinstance(device, (list, tuple)):
+                    device = device[0]
+                self._pool = DevicePool(fd.native, conf["num_envs"], device=int(device), **kw)
+            self._spec = spec
+            # the C ABI's view of the layout must agree with the Python spec
+            native_keys = [k for k, _, _ in self._pool.state_keys]
+            assert native_keys == state_keys, (native_keys, state_keys)
+
+        def _send(self, action: list[np.ndarray]) -> None:
+            # list order = _action_keys: env_id, players.env_id, <env action>
+            self._pool.send(action[0], action[-1])
+
+        def _recv(self) -> list[np.ndarray]:
+            return self._pool.recv()
+
+        def _reset(self, env_ids: np.ndarray) -> None:
+            self._pool.reset(np.asarray(env_ids, dtype=np.int32))
+
+        def _render(self, env_ids: np.ndarray, width: int, height: int,
+                    camera_id: int) -> np.ndarray:
+            # async_envpool.h:192-194
+            raise RuntimeError("render not implemented for this environment")
+
+        def _xla(self) -> Any:
+            raise RuntimeError("XLA is not available for the MI355X engine")
+
+        def close(self) -> None:
+            self._pool.close()
+
+        @property
+        def device_pool(self) -> Any:
+            """Extension: the underlying DevicePool (zero-copy device path)."""
+            return self._pool
+
+    _Spec.__name__ = _Spec.__qualname__ = f"_{fd.name}EnvSpec"
+    _Pool.__name__ = _Pool.__qualname__ = f"_{fd.name}EnvPool"
+    return _Spec, _Pool

@@ -1,0 +1,22 @@
+"""Task ids of envpool/mujoco/gym/registration.py:21-93 (hot-path tasks only)."""
+from envpool_amd.registration import register
+
+gym_mujoco_envs = [
+    ("HalfCheetah", ("v3", "v4", "v5"), 1000),
+]
+
+for task, versions, max_episode_steps in gym_mujoco_envs:
+    for version in versions:
+        extra_args = {}
+        if version == "v5":
+            extra_args["gymnasium_v5_render_camera"] = True
+        register(
+            task_id=f"{task}-{version}",
+            import_path="envpool_amd.mujoco.gym",
+            spec_cls=f"Gym{task}EnvSpec",
+            dm_cls=f"Gym{task}DMEnvPool",
+            gymnasium_cls=f"Gym{task}GymnasiumEnvPool",
+            post_constraint=(version == "v5"),
+            max_episode_steps=max_episode_steps,
+            **extra_args,
+        )

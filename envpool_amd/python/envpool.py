@@ -1,0 +1,166 @@
+"""EnvPoolMixin: send / recv / step / reset / async_reset on top of the native
+pool's `_send / _recv / _reset`.
+
+Host-side mirror of envpool/python/envpool.py:61-384 (same method names,
+argument meaning and error behaviour).  Rendering stays out of scope: `render`
+keeps the reference's checks and then surfaces the pool's RuntimeError.
+"""
+
+from __future__ import annotations
+
+import pprint
+import warnings
+from abc import ABC
+from typing import Any
+
+import numpy as np
+
+
+def _normalize_env_id(env_id: Any) -> Any:
+    if isinstance(env_id, np.ndarray):
+        env_id = env_id.astype(np.int32, copy=False)
+    elif hasattr(env_id, "astype"):
+        env_id = env_id.astype(np.int32)
+    else:
+        env_id = np.asarray(env_id, dtype=np.int32)
+    if getattr(env_id, "ndim", 0) == 0:
+        env_id = env_id.reshape(1)
+    return env_id
+
+
+def _flatten_action_dict(action: dict, prefix: tuple = ()) -> dict[str, Any]:
+    """{"a": {"b": x}} -> {"a.b": x} (the reference uses optree paths)."""
+    out: dict[str, Any] = {}
+    for k, v in action.items():
+        if isinstance(v, dict):
+            out.update(_flatten_action_dict(v, prefix + (k,)))
+        else:
+            out[".".join(prefix + (k,))] = v
+    return out
+
+
+class EnvPoolMixin(ABC):
+    """Mixin class for EnvPool, exposed to the gymnasium / dm metaclasses."""
+
+    def _check_action(self, actions: list[np.ndarray]) -> None:
+        # envpool.py:151-172 — checked once, then trusted
+        if hasattr(self, "_check_action_finished"):
+            return
+        self._check_action_finished = True
+        for a, (k, v) in zip(actions, self.spec.action_array_spec.items()):
+            if v.dtype != a.dtype:
+                raise RuntimeError(
+                    f'Expected dtype {v.dtype} with action "{k}", got {a.dtype}'
+                )
+            shape = tuple(v.shape)
+            if len(shape) > 0 and shape[0] == -1:
+                if a.shape[1:] != shape[1:]:
+                    raise RuntimeError(
+                        f'Expected shape {shape} with action "{k}", got {a.shape}'
+                    )
+            else:
+                if len(a.shape) == 0 or a.shape[1:] != shape:
+                    raise RuntimeError(
+                        f'Expected shape {("num_env", *shape)} with action "{k}", got {a.shape}'
+                    )
+
+    def _from(self, action: dict[str, Any] | np.ndarray,
+              env_id: np.ndarray | None = None) -> list[np.ndarray]:
+        """Convert an action into the native list (envpool.py:174-208)."""
+        if isinstance(action, dict):
+            adict = _flatten_action_dict(action)
+        else:
+            if not hasattr(self, "_last_action_type"):
+                self._last_action_type = self._spec._action_spec[-1][0]
+            if not hasattr(self, "_last_action_name"):
+                self._last_action_name = self._spec._action_keys[-1]
+            if isinstance(action, np.ndarray):
+                action = action.astype(self._last_action_type, order="C")
+            adict = {self._last_action_name: action}
+        if env_id is None:
+            if "env_id" not in adict:
+                adict["env_id"] = self.all_env_ids
+        else:
+            adict["env_id"] = env_id.astype(np.int32)
+        if "players.env_id" not in adict:
+            # all hot-path envs are single player: players.env_id == env_id
+            adict["players.env_id"] = _normalize_env_id(adict["env_id"])
+        if not hasattr(self, "_action_names"):
+            self._action_names = self._spec._action_keys
+        return [adict[k] for k in self._action_names]
+
+    def __len__(self) -> int:
+        return self.config["num_envs"]
+
+    @property
+    def all_env_ids(self) -> np.ndarray:
+        if not hasattr(self, "_all_env_ids"):
+            self._all_env_ids = np.arange(self.config["num_envs"], dtype=np.int32)
+        return self._all_env_ids
+
+    @property
+    def is_async(self) -> bool:
+        return (self.config["batch_size"] > 0
+                and self.config["num_envs"] != self.config["batch_size"])
+
+    def seed(self, seed: int | list[int] | None = None) -> None:
+        warnings.warn(
+            "The `seed` function in envpool is abandoned. "
+            "You can set seed by envpool.make(..., seed=seed) instead.",
+            stacklevel=2,
+        )
+
+    def render(self, env_ids: Any = None, camera_id: int | None = None) -> Any:
+        render_mode = getattr(self, "_render_mode", None)
+        if render_mode not in {"rgb_array", "human"}:
+            raise RuntimeError(
+                "render_mode must be set to 'rgb_array' or 'human' when creating this env"
+            )
+        if env_ids is None:
+            env_ids = [int(getattr(self, "_render_env_id", 0))]
+        ids = np.atleast_1d(np.asarray(env_ids, dtype=np.int32))
+        return self._render(
+            ids,
+            int(getattr(self, "_render_width", 0)),
+            int(getattr(self, "_render_height", 0)),
+            int(getattr(self, "_render_camera_id", -1) if camera_id is None else camera_id),
+        )
+
+    def send(self, action: dict[str, Any] | np.ndarray,
+             env_id: np.ndarray | None = None) -> None:
+        converted_action = self._from(action, env_id)
+        self._check_action(converted_action)
+        self._send(converted_action)
+
+    def recv(self, reset: bool = False, return_info: bool = True) -> Any:
+        state_list = self._recv()
+        return self._to(state_list, reset, return_info)
+
+    def async_reset(self) -> None:
+        self._reset(self.all_env_ids)
+
+    def step(self, action: dict[str, Any] | np.ndarray,
+             env_id: np.ndarray | None = None) -> Any:
+        self.send(action, env_id)
+        return self.recv(reset=False, return_info=True)
+
+    def reset(self, env_id: np.ndarray | None = None) -> Any:
+        if env_id is None:
+            env_id = self.all_env_ids
+        self._reset(env_id)
+        return self.recv(reset=True, return_info=self.config["gym_reset_return_info"])
+
+    def close(self) -> None:
+        close = getattr(super(), "close", None)
+        if close is not None:
+            close()
+
+    @property
+    def config(self) -> dict[str, Any]:
+        return dict(zip(self._spec._config_keys, self._spec._config_values))
+
+    def __repr__(self) -> str:
+        config_str = ", ".join(f"{k}={pprint.pformat(v)}" for k, v in self.config.items())
+        return f"{self.__class__.__name__}({config_str})"
+
+    __str__ = __repr__
