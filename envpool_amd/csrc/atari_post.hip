@@ -1,9 +1,346 @@
-// placeholder: replaced by the Atari post-process kernel (K4)
+// K4 — Atari observation post-process: max-pool of the last two ALE frames,
+// INTER_AREA resize to img_height x img_width, push into the frame stack.
+//
+// Replaces, for a whole batch of envs in one launch:
+//   AtariEnv::PushStack   envpool/atari/atari_env.h:308-346
+//   Resize                envpool/utils/image_process.h:27-36 (cv::resize INTER_AREA)
+//   the obs part of AtariEnv::WriteState   atari_env.h:283-287
+// ALE emulation itself stays on the host (north star): the caller hands over
+// the two grayscale frames `maxpool_buf_[0/1]` of every env (210x160 u8 each).
+//
+// HBM-streaming kernel, one 256-thread block per env:
+//   in : 2 x 33,600 B frames (coalesced 16-B loads), 3 x 7,056 B old stack frames
+//   out: 7,056 B ring slot + 4 x 7,056 B observation            (~123.6 KB/env)
+// The pooled frame is staged in LDS (33.6 KB/block => 4 blocks/CU), every
+// destination pixel is then produced by one thread from <= 4x3 LDS taps.
+// Arithmetic follows OpenCV's generic area resize bit for bit (float taps from
+// computeResizeAreaTab, horizontal then vertical accumulation in table order,
+// cvRound saturate) — compiled with -ffp-contract=off, so the result equals
+// oracle/atari/atari_post.c exactly.  The frame stack is a per-env ring in HBM
+// (`head` = oldest slot): a push overwrites one slot instead of shifting three.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
 #include "engine.h"
-extern "C" {
-int epa_atari_post_create(int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, epa_atari_post**) { return EPA_ERR_RUNTIME; }
-int epa_atari_post_destroy(epa_atari_post*) { return EPA_ERR_RUNTIME; }
-int epa_atari_post_push(epa_atari_post*, const int32_t*, int32_t, const uint8_t*, const uint8_t*, uint8_t*) { return EPA_ERR_RUNTIME; }
-int epa_atari_post_push_device(epa_atari_post*, const int32_t*, int32_t, const uint8_t*, const uint8_t*, uint8_t*) { return EPA_ERR_RUNTIME; }
-void* epa_atari_post_stream(epa_atari_post*) { return nullptr; }
+
+namespace epa {
+namespace {
+
+constexpr int kMaxTap = 6;
+constexpr int kPostBlock = 256;
+
+struct AreaTab {  // per destination index: first source index, #taps, weights
+  short* ofs;
+  short* cnt;
+  float* alpha;  // [dsize][kMaxTap]
+};
+
+struct PostDev {
+  unsigned char* ring;  // [N][S][dh*dw]
+  int* head;            // [N] oldest slot
+  AreaTab xt, yt;
+  int n, s, sh, sw, dh, dw;
+};
+
+__global__ __launch_bounds__(kPostBlock) void AtariPostKernel(
+    PostDev d, const int* __restrict__ env_id, int k,
+    const unsigned char* __restrict__ frames,
+    const unsigned char* __restrict__ reset_mask, unsigned char* __restrict__ obs) {
+  extern __shared__ __align__(16) unsigned char pooled[];
+  const int row = blockIdx.x;
+  if (row >= k) return;
+  const int e = env_id ? env_id[row] : row;
+  const int fsz = d.sh * d.sw, osz = d.dh * d.dw;
+  const bool rst = reset_mask != nullptr && reset_mask[row] != 0;
+  // 1. max-pool the two frames into LDS (atari_env.h:310-315); on reset there
+  //    is only one observation (maxpool = false)
+  const unsigned char* f0 = frames + (size_t)row * 2 * fsz;
+  const unsigned char* f1 = f0 + fsz;
+  const int nvec = fsz / 16;
+  for (int i = threadIdx.x; i < nvec; i += kPostBlock) {
+    uint4 a = reinterpret_cast<const uint4*>(f0)[i];
+    if (!rst) {
+      uint4 b = reinterpret_cast<const uint4*>(f1)[i];
+      unsigned int* pa = &a.x;
+      const unsigned int* pb = &b.x;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        unsigned int x = pa[w], y = pb[w], r = 0;
+#pragma unroll
+        for (int sft = 0; sft < 32; sft += 8) {
+          unsigned int xb = (x >> sft) & 255u, yb = (y >> sft) & 255u;
+          r |= (xb > yb ? xb : yb) << sft;
+        }
+        pa[w] = r;
+      }
+    }
+    reinterpret_cast<uint4*>(pooled)[i] = a;
+  }
+  for (int i = nvec * 16 + threadIdx.x; i < fsz; i += kPostBlock) {
+    unsigned char a = f0[i], b = f1[i];
+    pooled[i] = rst ? a : (a > b ? a : b);
+  }
+  __syncthreads();
+  // 2. area resize: one destination pixel per thread iteration
+  const int head = d.head[e];
+  unsigned char* ring_e = d.ring + (size_t)e * d.s * osz;
+  unsigned char* obs_e = obs + (size_t)row * d.s * osz;
+  unsigned char* slot = ring_e + (size_t)head * osz;
+  unsigned char* newest = obs_e + (size_t)(d.s - 1) * osz;
+  for (int p = threadIdx.x; p < osz; p += kPostBlock) {
+    int dy = p / d.dw, dx = p - dy * d.dw;
+    int sx0 = d.xt.ofs[dx], xn = d.xt.cnt[dx];
+    int sy0 = d.yt.ofs[dy], yn = d.yt.cnt[dy];
+    const float* xa = d.xt.alpha + dx * kMaxTap;
+    const float* ya = d.yt.alpha + dy * kMaxTap;
+    float sum = 0.0f;
+    for (int yi = 0; yi < yn; ++yi) {
+      const unsigned char* S = pooled + (sy0 + yi) * d.sw + sx0;
+      float buf = 0.0f;
+      for (int xi = 0; xi < xn; ++xi) buf += (float)S[xi] * xa[xi];
+      float t = ya[yi] * buf;
+      sum = yi == 0 ? t : sum + t;
+    }
+    int r = __float2int_rn(sum);  // cvRound
+    unsigned char v = (unsigned char)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    newest[p] = v;
+    if (rst) {
+      for (int s = 0; s < d.s; ++s) ring_e[(size_t)s * osz + p] = v;
+      for (int s = 0; s < d.s - 1; ++s) obs_e[(size_t)s * osz + p] = v;
+    } else {
+      slot[p] = v;
+    }
+  }
+  // 3. older frames: obs[j] = ring[(head + 1 + j) % S], j = 0..S-2
+  if (!rst) {
+    const int ovec = osz / 16;  // 84*84 = 441 * 16
+    for (int j = 0; j < d.s - 1; ++j) {
+      const unsigned char* src = ring_e + (size_t)((head + 1 + j) % d.s) * osz;
+      unsigned char* dst = obs_e + (size_t)j * osz;
+      if ((osz & 15) == 0) {
+        for (int i = threadIdx.x; i < ovec; i += kPostBlock) {
+          reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+        }
+      } else {
+        for (int i = threadIdx.x; i < osz; i += kPostBlock) dst[i] = src[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) d.head[e] = rst ? 0 : (head + 1) % d.s;
 }
+
+// cv::computeResizeAreaTab restated (opencv imgproc/src/resize.cpp)
+bool BuildAreaTab(int ssize, int dsize, std::vector<short>* ofs,
+                  std::vector<short>* cnt, std::vector<float>* alpha) {
+  double scale = (double)ssize / dsize;
+  ofs->assign(dsize, 0);
+  cnt->assign(dsize, 0);
+  alpha->assign((size_t)dsize * kMaxTap, 0.0f);
+  for (int dx = 0; dx < dsize; dx++) {
+    double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+    double cell = std::min(scale, ssize - fsx1);
+    int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+    sx2 = std::min(sx2, ssize - 1);
+    sx1 = std::min(sx1, sx2);
+    int n = 0, first = -1;
+    auto push = [&](int si, float a) {
+      if (n == 0) first = si;
+      if (n < kMaxTap) (*alpha)[(size_t)dx * kMaxTap + n] = a;
+      ++n;
+    };
+    if (sx1 - fsx1 > 1e-3) push(sx1 - 1, (float)((sx1 - fsx1) / cell));
+    for (int sx = sx1; sx < sx2; sx++) push(sx, (float)(1.0 / cell));
+    if (fsx2 - sx2 > 1e-3) {
+      push(sx2, (float)(std::min(std::min(fsx2 - sx2, 1.0), cell) / cell));
+    }
+    if (n > kMaxTap || n == 0) return false;
+    (*ofs)[dx] = (short)first;
+    (*cnt)[dx] = (short)n;
+  }
+  return true;
+}
+
+}  // namespace
+}  // namespace epa
+
+struct epa_atari_post {
+  epa::PostDev d{};
+  int device{0};
+  hipStream_t stream{nullptr};
+  std::mutex mu;
+  // staging for the host path
+  unsigned char* d_frames{nullptr};
+  unsigned char* d_obs{nullptr};
+  unsigned char* d_mask{nullptr};
+  int* d_ids{nullptr};
+  int cap{0};
+};
+
+namespace {
+template <typename F>
+int PostGuard(F&& f) {
+  try {
+    f();
+    return EPA_OK;
+  } catch (const std::invalid_argument& e) {
+    epa::SetLastError(e.what());
+    return EPA_ERR_INVALID;
+  } catch (const epa::DeviceError& e) {
+    epa::SetLastError(e.what());
+    return EPA_ERR_DEVICE;
+  } catch (const std::exception& e) {
+    epa::SetLastError(e.what());
+    return EPA_ERR_RUNTIME;
+  }
+}
+
+void UploadTab(const std::vector<short>& ofs, const std::vector<short>& cnt,
+               const std::vector<float>& alpha, epa::AreaTab* t) {
+  EPA_HIP(hipMalloc(&t->ofs, ofs.size() * sizeof(short)));
+  EPA_HIP(hipMalloc(&t->cnt, cnt.size() * sizeof(short)));
+  EPA_HIP(hipMalloc(&t->alpha, alpha.size() * sizeof(float)));
+  EPA_HIP(hipMemcpy(t->ofs, ofs.data(), ofs.size() * sizeof(short), hipMemcpyHostToDevice));
+  EPA_HIP(hipMemcpy(t->cnt, cnt.data(), cnt.size() * sizeof(short), hipMemcpyHostToDevice));
+  EPA_HIP(hipMemcpy(t->alpha, alpha.data(), alpha.size() * sizeof(float), hipMemcpyHostToDevice));
+}
+
+void LaunchPost(epa_atari_post* p, const int* d_ids, int k,
+                const unsigned char* d_frames, const unsigned char* d_mask,
+                unsigned char* d_obs) {
+  size_t lds = (size_t)p->d.sh * p->d.sw;
+  lds = (lds + 15) / 16 * 16;
+  hipLaunchKernelGGL(epa::AtariPostKernel, dim3(k), dim3(epa::kPostBlock), lds,
+                     p->stream, p->d, d_ids, k, d_frames, d_mask, d_obs);
+  EPA_HIP(hipGetLastError());
+}
+}  // namespace
+
+extern "C" {
+
+int epa_atari_post_create(int32_t num_envs, int32_t stack_num, int32_t in_h,
+                          int32_t in_w, int32_t out_h, int32_t out_w,
+                          int32_t use_inter_area, int32_t device,
+                          epa_atari_post** out) {
+  return PostGuard([&] {
+    if (!use_inter_area) {
+      throw std::invalid_argument(
+          "use_inter_area_resize=false (cv::INTER_LINEAR) is not supported: its "
+          "u8 result depends on OpenCV's SIMD path");
+    }
+    if (num_envs < 1 || stack_num < 1 || out_h > in_h || out_w > in_w ||
+        out_h < 1 || out_w < 1 || (size_t)in_h * in_w > 60000) {
+      throw std::invalid_argument("atari_post: bad dimensions");
+    }
+    if (in_h % out_h == 0 && in_w % out_w == 0) {
+      throw std::invalid_argument(
+          "atari_post: integer scale factors take OpenCV's resizeAreaFast path, "
+          "which is not restated");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+      throw epa::DeviceError("no HIP device available: envpool_amd has no CPU fallback");
+    }
+    if (device < 0 || device >= ndev) throw std::invalid_argument("device out of range");
+    std::vector<short> xo, xc, yo, yc;
+    std::vector<float> xa, ya;
+    if (!epa::BuildAreaTab(in_w, out_w, &xo, &xc, &xa) ||
+        !epa::BuildAreaTab(in_h, out_h, &yo, &yc, &ya)) {
+      throw std::invalid_argument("atari_post: scale factor too large");
+    }
+    auto* p = new epa_atari_post();
+    p->device = device;
+    EPA_HIP(hipSetDevice(device));
+    EPA_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    p->d.n = num_envs;
+    p->d.s = stack_num;
+    p->d.sh = in_h;
+    p->d.sw = in_w;
+    p->d.dh = out_h;
+    p->d.dw = out_w;
+    size_t ring = (size_t)num_envs * stack_num * out_h * out_w;
+    EPA_HIP(hipMalloc(&p->d.ring, ring));
+    EPA_HIP(hipMemset(p->d.ring, 0, ring));
+    EPA_HIP(hipMalloc(&p->d.head, sizeof(int) * num_envs));
+    EPA_HIP(hipMemset(p->d.head, 0, sizeof(int) * num_envs));
+    UploadTab(xo, xc, xa, &p->d.xt);
+    UploadTab(yo, yc, ya, &p->d.yt);
+    *out = p;
+  });
+}
+
+int epa_atari_post_destroy(epa_atari_post* p) {
+  return PostGuard([&] {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipFree(p->d.ring);
+    (void)hipFree(p->d.head);
+    for (epa::AreaTab* t : {&p->d.xt, &p->d.yt}) {
+      (void)hipFree(t->ofs);
+      (void)hipFree(t->cnt);
+      (void)hipFree(t->alpha);
+    }
+    if (p->d_frames) (void)hipFree(p->d_frames);
+    if (p->d_obs) (void)hipFree(p->d_obs);
+    if (p->d_mask) (void)hipFree(p->d_mask);
+    if (p->d_ids) (void)hipFree(p->d_ids);
+    (void)hipStreamDestroy(p->stream);
+    delete p;
+  });
+}
+
+int epa_atari_post_push(epa_atari_post* p, const int32_t* env_id, int32_t k,
+                        const uint8_t* frames, const uint8_t* reset_mask,
+                        uint8_t* obs_out) {
+  return PostGuard([&] {
+    if (k < 0 || k > p->d.n || !env_id || !frames || !obs_out) {
+      throw std::invalid_argument("atari_post_push: bad arguments");
+    }
+    for (int i = 0; i < k; ++i) {
+      if (env_id[i] < 0 || env_id[i] >= p->d.n) {
+        throw std::invalid_argument("atari_post_push: env_id out of range");
+      }
+    }
+    if (k == 0) return;
+    std::lock_guard<std::mutex> lk(p->mu);
+    EPA_HIP(hipSetDevice(p->device));
+    size_t fsz = (size_t)2 * p->d.sh * p->d.sw, osz = (size_t)p->d.s * p->d.dh * p->d.dw;
+    if (p->cap < p->d.n) {
+      EPA_HIP(hipMalloc(&p->d_frames, fsz * p->d.n));
+      EPA_HIP(hipMalloc(&p->d_obs, osz * p->d.n));
+      EPA_HIP(hipMalloc(&p->d_mask, p->d.n));
+      EPA_HIP(hipMalloc(&p->d_ids, sizeof(int) * p->d.n));
+      p->cap = p->d.n;
+    }
+    EPA_HIP(hipMemcpyAsync(p->d_frames, frames, fsz * k, hipMemcpyHostToDevice, p->stream));
+    EPA_HIP(hipMemcpyAsync(p->d_ids, env_id, sizeof(int) * k, hipMemcpyHostToDevice, p->stream));
+    if (reset_mask) {
+      EPA_HIP(hipMemcpyAsync(p->d_mask, reset_mask, k, hipMemcpyHostToDevice, p->stream));
+    }
+    LaunchPost(p, p->d_ids, k, p->d_frames, reset_mask ? p->d_mask : nullptr, p->d_obs);
+    EPA_HIP(hipMemcpyAsync(obs_out, p->d_obs, osz * k, hipMemcpyDeviceToHost, p->stream));
+    EPA_HIP(hipStreamSynchronize(p->stream));
+  });
+}
+
+int epa_atari_post_push_device(epa_atari_post* p, const int32_t* d_env_id,
+                               int32_t k, const uint8_t* d_frames,
+                               const uint8_t* d_reset_mask, uint8_t* d_obs_out) {
+  return PostGuard([&] {
+    if (k < 0 || k > p->d.n || !d_frames || !d_obs_out) {
+      throw std::invalid_argument("atari_post_push_device: bad arguments");
+    }
+    if (k == 0) return;
+    std::lock_guard<std::mutex> lk(p->mu);
+    EPA_HIP(hipSetDevice(p->device));
+    LaunchPost(p, d_env_id, k, d_frames, d_reset_mask, d_obs_out);
+  });
+}
+
+void* epa_atari_post_stream(epa_atari_post* p) { return (void*)p->stream; }
+
+}  // extern "C"

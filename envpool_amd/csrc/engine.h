@@ -193,6 +193,7 @@ bool DescribeMujoco(const std::string& family, const Config& cfg,
                     std::vector<KeySpec>* state, KeySpec* action);
 
 const std::vector<std::string>& FamilyNames();
+void SetLastError(const std::string& msg);  // thread-local epa_last_error()
 
 // Launch helpers shared by the family files.
 void LaunchInitCommon(CommonDev c, int seed, const int* d_env_seed,

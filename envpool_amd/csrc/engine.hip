@@ -38,6 +38,8 @@ __global__ void InitCommonKernel(CommonDev c, int seed, const int* env_seed,
 }
 }  // namespace
 
+void SetLastError(const std::string& msg) { g_last_error = msg; }
+
 void LaunchInitCommon(CommonDev c, int seed, const int* d_env_seed,
                       int id_offset, bool with_rng, hipStream_t s) {
   int threads = 256, blocks = (c.n + threads - 1) / threads;

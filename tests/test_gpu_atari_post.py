@@ -1,0 +1,73 @@
+"""GPU parity of the Atari post-process kernel vs oracle/atari/atari_post.c
+(bit-exact: u8 outputs).  The oracle itself is UNPINNED against OpenCV 4.13
+(not installed; the reference only tests shapes, image_process_test.cc:23-40)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from envpool_amd.atari import AtariPostProcess
+from oracle.orc import PORT_LIB
+
+pytestmark = pytest.mark.gpu
+
+
+class OraclePost:
+    def __init__(self, n, s=4):
+        self.L = ctypes.CDLL(PORT_LIB)
+        self.L.orc_atari_post_create.restype = ctypes.c_void_p
+        self.L.orc_atari_post_push.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 3
+        self.h = ctypes.c_void_p(self.L.orc_atari_post_create(n, s, 210, 160, 84, 84))
+        self.s = s
+
+    def push(self, frames, ids, mask):
+        k = len(ids)
+        obs = np.zeros((k, self.s, 84, 84), np.uint8)
+        self.L.orc_atari_post_push(self.h, ids.ctypes.data, k, frames.ctypes.data,
+                                   mask.ctypes.data if mask is not None else None,
+                                   obs.ctypes.data)
+        return obs
+
+
+def pong_like(rng, k):
+    """Sparse Atari-like frames: background + a few bright rectangles."""
+    f = np.full((k, 2, 210, 160), 87, np.uint8)
+    for i in range(k):
+        for j in range(2):
+            for _ in range(6):
+                y, x = rng.integers(0, 200), rng.integers(0, 150)
+                f[i, j, y:y + rng.integers(2, 16), x:x + rng.integers(1, 8)] = rng.integers(0, 256)
+    return f
+
+
+def test_post_process_bit_exact_with_resets_and_partial_ids():
+    n = 64
+    gpu, orc = AtariPostProcess(n), OraclePost(n)
+    rng = np.random.default_rng(0)
+    ids = np.arange(n, dtype=np.int32)
+    frames = pong_like(rng, n)
+    mask = np.ones(n, np.uint8)  # reset: replicate into every stack slot
+    a, b = gpu.push(frames, ids, mask), orc.push(frames, ids, mask)
+    np.testing.assert_array_equal(a, b)
+    assert (a[:, 0] == a[:, 3]).all()
+    for t in range(12):
+        if t % 3 == 2:  # partial, shuffled ids with some resets
+            sub = rng.permutation(n)[:17].astype(np.int32)
+            frames = rng.integers(0, 256, (17, 2, 210, 160), dtype=np.uint8)
+            mask = (rng.random(17) < 0.3).astype(np.uint8)
+        else:
+            sub, frames, mask = ids, pong_like(rng, n), None
+        a, b = gpu.push(frames, sub, mask), orc.push(frames, sub, mask)
+        np.testing.assert_array_equal(a, b, err_msg=f"push {t}")
+    # stack ordering: newest frame last, previous newest moved to slot 2
+    prev = gpu.push(pong_like(rng, n), ids, None)
+    frames = pong_like(rng, n)
+    a = gpu.push(frames, ids, None)
+    np.testing.assert_array_equal(a[:, :3], prev[:, 1:])
+
+
+def test_post_process_errors():
+    with pytest.raises(ValueError):
+        AtariPostProcess(4, use_inter_area_resize=False)
+    with pytest.raises(ValueError):
+        AtariPostProcess(4, img_height=105, img_width=80)  # integer scale: fast path
