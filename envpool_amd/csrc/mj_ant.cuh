@@ -1,0 +1,812 @@
+// K3b — Ant `mj_step` (free joint + 8 hinges, sphere/capsule-vs-plane contacts,
+// RK4) restated as a tree-specialised, statically unrolled per-thread routine.
+//
+// Replaces the arithmetic MuJoCo 3.6.0's mj_step performs for the gym Ant model
+// (third_party/mujoco_gym_xml_patches/ant_envpool.xml) each time the reference
+// calls it (envpool/mujoco/gym/mujoco_env.h:137-148): SURVEY.md §8a M1-M9 with
+// integrator="RK4" (4 forward evaluations per mj_step).
+//
+// Design notes (MI355X-first, not MuJoCo's generic engine):
+//  * topology is compile time: torso (free) + 4 x (aux: hip hinge, foot: ankle
+//    hinge); the four jointless "leg" bodies of the XML are welded into the
+//    torso for the dynamics (identical physics) while their own
+//    body_invweight0 is kept for the contact regulariser;
+//  * spatial vectors use MuJoCo's c-frame (world orientation, about the robot
+//    COM), so the mass matrix / RNE recursions need no frame transforms;
+//  * M/H have an arrow structure (torso 6x6, four 2x2 leg blocks coupled only
+//    through the torso); entries between different legs are never materialised
+//    and the U U^T factorisation in tree order has no fill;
+//  * contacts are the 25 end spheres (torso sphere + 2 per capsule); the four
+//    pyramidal rows of a contact share Jx/Jy/Jz, so gradient and Hessian
+//    updates are accumulated in the 3x3 "contact space" first;
+//  * same exact-Newton solver with finite termination as mj_cheetah.cuh.
+#ifndef ENVPOOL_AMD_CSRC_MJ_ANT_CUH_
+#define ENVPOOL_AMD_CSRC_MJ_ANT_CUH_
+
+#include "mj_cheetah.cuh"  // static_for, IC, Sqrt, SinCos, Impedance (generic part)
+
+namespace epa {
+namespace mj {
+namespace ant {
+
+constexpr int kNQ = 15, kNV = 14, kNU = 8, kNB = 9, kNLeg = 4;
+constexpr int kNSph = 25;       // torso sphere + 4 x 6 capsule end spheres
+constexpr int kNGeomBody = 13;  // MuJoCo bodies carrying geoms (for invweight)
+
+// bodies: 0 torso, 1+2l aux_l, 2+2l foot_l.  dofs: 0-2 trans, 3-5 rot,
+// 6+2l hip_l, 7+2l ankle_l.
+EPA_HD constexpr int Aux(int l) { return 1 + 2 * l; }
+EPA_HD constexpr int Foot(int l) { return 2 + 2 * l; }
+EPA_HD constexpr int Hip(int l) { return 6 + 2 * l; }
+EPA_HD constexpr int Ankle(int l) { return 7 + 2 * l; }
+EPA_HD constexpr int Parent(int b) { return b == 0 ? -1 : ((b & 1) ? 0 : b - 1); }
+EPA_HD constexpr int DofBody(int j) { return j < 6 ? 0 : j - 5; }
+EPA_HD constexpr int LegOfDof(int j) { return j < 6 ? -1 : (j - 6) / 2; }
+EPA_HD constexpr bool NZ(int i, int j) {
+  return i < 6 || j < 6 || LegOfDof(i) == LegOfDof(j);
+}
+EPA_HD constexpr bool InChain(int j, int b) {  // dof j moves body b
+  if (j < 6) return true;
+  int jb = DofBody(j);
+  for (int x = b; x > 0; x = Parent(x)) {
+    if (x == jb) return true;
+  }
+  return false;
+}
+// actuator order of the XML (:85-94): hip_4 ankle_4 hip_1 ankle_1 hip_2 ankle_2
+// hip_3 ankle_3 -> dof driven by ctrl[u]
+EPA_HD constexpr int CtrlDof(int u) { return u < 2 ? 12 + u : 4 + u; }
+EPA_HD constexpr int Tri(int i, int j) { return j * (j + 1) / 2 + i; }  // i <= j
+constexpr int kTri = kNV * (kNV + 1) / 2;
+// sphere s: 0 torso sphere; 1 + 6l + {0,1}: stub capsule (torso frame),
+// {2,3}: leg capsule (aux frame), {4,5}: ankle capsule (foot frame)
+EPA_HD constexpr int SphBody(int s) {
+  if (s == 0) return 0;
+  int l = (s - 1) / 6, w = (s - 1) % 6;
+  return w < 2 ? 0 : (w < 4 ? Aux(l) : Foot(l));
+}
+// index of the MuJoCo geom body (for body_invweight0): 0 torso, 1+3l stub,
+// 2+3l aux, 3+3l foot
+EPA_HD constexpr int SphGeomBody(int s) {
+  if (s == 0) return 0;
+  int l = (s - 1) / 6, w = (s - 1) % 6;
+  return 1 + 3 * l + w / 2;
+}
+
+template <typename T>
+struct AntModel {
+  T mass[kNB], com[kNB][3], inertia[kNB][6];  // xx yy zz xy xz yz, about com
+  T aux_pos[kNLeg][3], foot_pos[kNLeg][3];    // body_pos in the parent frame
+  T ankle_axis[kNLeg][3];                     // in the foot/aux frame (hip: +z)
+  T sph[kNSph][3], sph_r[kNSph];
+  T geom_body_invw[kNGeomBody];
+  T lo[kNU], hi[kNU], dof_invw[kNU], damp[kNU], arm[kNU];
+  T gear;
+  T total_mass, mu, margin;
+  T con_K, con_B, imp_d0, imp_dmax, imp_width;
+  T timestep, gravity;
+};
+
+template <typename T>
+struct Vec3 {
+  T x, y, z;
+};
+template <typename T>
+EPA_HD Vec3<T> operator+(Vec3<T> a, Vec3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T>
+EPA_HD Vec3<T> operator-(Vec3<T> a, Vec3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T>
+EPA_HD Vec3<T> operator*(Vec3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename T>
+EPA_HD T Dot(Vec3<T> a, Vec3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T>
+EPA_HD Vec3<T> Cross(Vec3<T> a, Vec3<T> b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <typename T>
+struct Mat3 {  // row major
+  T m[9];
+};
+template <typename T>
+EPA_HD Vec3<T> Mul(const Mat3<T>& R, Vec3<T> v) {
+  return {R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z,
+          R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z,
+          R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z};
+}
+template <typename T>
+EPA_HD Mat3<T> Mul(const Mat3<T>& A, const Mat3<T>& B) {
+  Mat3<T> C;
+  static_for<0, 3>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    static_for<0, 3>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      C.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] +
+                       A.m[3 * i + 2] * B.m[6 + j];
+    });
+  });
+  return C;
+}
+template <typename T>
+EPA_HD Vec3<T> Col(const Mat3<T>& R, int k) { return {R.m[k], R.m[3 + k], R.m[6 + k]}; }
+template <typename T>
+EPA_HD Mat3<T> QuatToMat(T w, T x, T y, T z) {
+  Mat3<T> M;
+  M.m[0] = w * w + x * x - y * y - z * z;
+  M.m[4] = w * w - x * x + y * y - z * z;
+  M.m[8] = w * w - x * x - y * y + z * z;
+  M.m[1] = T(2) * (x * y - w * z);
+  M.m[2] = T(2) * (x * z + w * y);
+  M.m[3] = T(2) * (x * y + w * z);
+  M.m[5] = T(2) * (y * z - w * x);
+  M.m[6] = T(2) * (x * z - w * y);
+  M.m[7] = T(2) * (y * z + w * x);
+  return M;
+}
+// rotation by `ang` about unit axis a (Rodrigues)
+template <typename T>
+EPA_HD Mat3<T> AxisAngle(const T* a, T ang) {
+  T s, c;
+  SinCos(ang, &s, &c);
+  T t = T(1) - c;
+  Mat3<T> M;
+  M.m[0] = c + a[0] * a[0] * t;
+  M.m[4] = c + a[1] * a[1] * t;
+  M.m[8] = c + a[2] * a[2] * t;
+  M.m[1] = a[0] * a[1] * t - a[2] * s;
+  M.m[3] = a[0] * a[1] * t + a[2] * s;
+  M.m[2] = a[0] * a[2] * t + a[1] * s;
+  M.m[6] = a[0] * a[2] * t - a[1] * s;
+  M.m[5] = a[1] * a[2] * t - a[0] * s;
+  M.m[7] = a[1] * a[2] * t + a[0] * s;
+  return M;
+}
+
+template <typename T>
+struct Sp6 {  // spatial motion [w; v] or force [tau; f]
+  Vec3<T> a, l;
+};
+template <typename T>
+EPA_HD T Dot(const Sp6<T>& p, const Sp6<T>& q) { return Dot(p.a, q.a) + Dot(p.l, q.l); }
+template <typename T>
+EPA_HD void Axpy(Sp6<T>& y, const Sp6<T>& x, T s) {
+  y.a = y.a + x.a * s;
+  y.l = y.l + x.l * s;
+}
+template <typename T>
+struct In10 {  // xx yy zz xy xz yz mdx mdy mdz m
+  T v[10];
+};
+template <typename T>
+EPA_HD Sp6<T> MulInert(const In10<T>& I, const Sp6<T>& s) {
+  const T* i = I.v;
+  Sp6<T> r;
+  r.a.x = i[0] * s.a.x + i[3] * s.a.y + i[4] * s.a.z - i[8] * s.l.y + i[7] * s.l.z;
+  r.a.y = i[3] * s.a.x + i[1] * s.a.y + i[5] * s.a.z + i[8] * s.l.x - i[6] * s.l.z;
+  r.a.z = i[4] * s.a.x + i[5] * s.a.y + i[2] * s.a.z - i[7] * s.l.x + i[6] * s.l.y;
+  r.l.x = i[8] * s.a.y - i[7] * s.a.z + i[9] * s.l.x;
+  r.l.y = i[6] * s.a.z - i[8] * s.a.x + i[9] * s.l.y;
+  r.l.z = i[7] * s.a.x - i[6] * s.a.y + i[9] * s.l.z;
+  return r;
+}
+template <typename T>
+EPA_HD Sp6<T> CrossMotion(const Sp6<T>& vel, const Sp6<T>& v) {
+  return {Cross(vel.a, v.a), Cross(vel.a, v.l) + Cross(vel.l, v.a)};
+}
+template <typename T>
+EPA_HD Sp6<T> CrossForce(const Sp6<T>& vel, const Sp6<T>& f) {
+  return {Cross(vel.a, f.a) + Cross(vel.l, f.l), Cross(vel.a, f.l)};
+}
+
+// ---- linear algebra on the arrow-structured 14x14 ---------------------------
+template <typename T>
+EPA_HD void FactorUUt(T* A) {
+  static_for_down<kNV, 0>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    T s = A[Tri(j, j)];
+    static_for<j + 1, kNV>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (NZ(j, k)) s -= A[Tri(j, k)] * A[Tri(j, k)];
+    });
+    T d = Sqrt(s);
+    T inv = T(1) / d;
+    A[Tri(j, j)] = d;
+    static_for<0, j>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (NZ(i, j)) {
+        T t = A[Tri(i, j)];
+        static_for<j + 1, kNV>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          if constexpr (NZ(i, k) && NZ(j, k)) t -= A[Tri(i, k)] * A[Tri(j, k)];
+        });
+        A[Tri(i, j)] = t * inv;
+      }
+    });
+  });
+}
+template <typename T>
+EPA_HD void SolveUUt(const T* U, T* x) {
+  static_for_down<kNV, 0>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    T s = x[j];
+    static_for<j + 1, kNV>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (NZ(j, k)) s -= U[Tri(j, k)] * x[k];
+    });
+    x[j] = s / U[Tri(j, j)];
+  });
+  static_for<0, kNV>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    T s = x[j];
+    static_for<0, j>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (NZ(i, j)) s -= U[Tri(i, j)] * x[i];
+    });
+    x[j] = s / U[Tri(j, j)];
+  });
+}
+template <typename T>
+EPA_HD void SymMul(const T* A, const T* x, T* y) {
+  static_for<0, kNV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    T s = T(0);
+    static_for<0, kNV>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (NZ(i, j)) s += A[i <= j ? Tri(i, j) : Tri(j, i)] * x[j];
+    });
+    y[i] = s;
+  });
+}
+
+// ---- forward pass -------------------------------------------------------------
+template <typename T>
+struct AntPos {
+  Vec3<T> pos[kNB];
+  Mat3<T> R[kNB];
+  Vec3<T> com;
+  In10<T> cinert[kNB];
+  Sp6<T> cdof[kNV];  // entries 0..2 are the constant (0; e_k)
+  T M[kTri];
+};
+
+template <typename T>
+EPA_HD void NormalizeQuat(T* q) {
+  T n = Sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < T(1e-15)) {
+    q[0] = T(1);
+    q[1] = q[2] = q[3] = T(0);
+  } else {
+    T inv = T(1) / n;
+    q[0] *= inv;
+    q[1] *= inv;
+    q[2] *= inv;
+    q[3] *= inv;
+  }
+}
+
+template <typename T>
+EPA_HD void AntKinematics(const AntModel<T>& m, T* q, AntPos<T>& p) {
+  // mj_kinematics (normalises the free-joint quaternion in qpos)
+  NormalizeQuat(q + 3);
+  p.pos[0] = {q[0], q[1], q[2]};
+  p.R[0] = QuatToMat(q[3], q[4], q[5], q[6]);
+  const T zaxis[3] = {T(0), T(0), T(1)};
+  static_for<0, kNLeg>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    constexpr int A = Aux(l), F = Foot(l);
+    p.pos[A] = p.pos[0] + Mul(p.R[0], Vec3<T>{m.aux_pos[l][0], m.aux_pos[l][1], m.aux_pos[l][2]});
+    p.R[A] = Mul(p.R[0], AxisAngle(zaxis, q[7 + 2 * l]));
+    p.pos[F] = p.pos[A] + Mul(p.R[A], Vec3<T>{m.foot_pos[l][0], m.foot_pos[l][1], m.foot_pos[l][2]});
+    p.R[F] = Mul(p.R[A], AxisAngle(m.ankle_axis[l], q[8 + 2 * l]));
+  });
+  // mj_comPos
+  Vec3<T> xi[kNB];
+  Vec3<T> s = {T(0), T(0), T(0)};
+  static_for<0, kNB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    xi[b] = p.pos[b] + Mul(p.R[b], Vec3<T>{m.com[b][0], m.com[b][1], m.com[b][2]});
+    s = s + xi[b] * m.mass[b];
+  });
+  p.com = s * (T(1) / m.total_mass);
+  static_for<0, kNB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    const T* I = m.inertia[b];
+    Mat3<T> Ib = {{I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}};
+    Mat3<T> RI = Mul(p.R[b], Ib);
+    // Iw = RI * R^T (symmetric)
+    T w[6];
+    const T* r = p.R[b].m;
+    w[0] = RI.m[0] * r[0] + RI.m[1] * r[1] + RI.m[2] * r[2];
+    w[1] = RI.m[3] * r[3] + RI.m[4] * r[4] + RI.m[5] * r[5];
+    w[2] = RI.m[6] * r[6] + RI.m[7] * r[7] + RI.m[8] * r[8];
+    w[3] = RI.m[0] * r[3] + RI.m[1] * r[4] + RI.m[2] * r[5];
+    w[4] = RI.m[0] * r[6] + RI.m[1] * r[7] + RI.m[2] * r[8];
+    w[5] = RI.m[3] * r[6] + RI.m[4] * r[7] + RI.m[5] * r[8];
+    Vec3<T> d = xi[b] - p.com;
+    T mass = m.mass[b], d2 = Dot(d, d);
+    T* c = p.cinert[b].v;
+    c[0] = w[0] + mass * (d2 - d.x * d.x);
+    c[1] = w[1] + mass * (d2 - d.y * d.y);
+    c[2] = w[2] + mass * (d2 - d.z * d.z);
+    c[3] = w[3] - mass * d.x * d.y;
+    c[4] = w[4] - mass * d.x * d.z;
+    c[5] = w[5] - mass * d.y * d.z;
+    c[6] = mass * d.x;
+    c[7] = mass * d.y;
+    c[8] = mass * d.z;
+    c[9] = mass;
+  });
+  // cdof (c-frame: about the robot COM)
+  p.cdof[0] = {{T(0), T(0), T(0)}, {T(1), T(0), T(0)}};
+  p.cdof[1] = {{T(0), T(0), T(0)}, {T(0), T(1), T(0)}};
+  p.cdof[2] = {{T(0), T(0), T(0)}, {T(0), T(0), T(1)}};
+  static_for<0, 3>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    Vec3<T> ax = Col(p.R[0], k);
+    p.cdof[3 + k] = {ax, Cross(ax, p.com - p.pos[0])};
+  });
+  static_for<0, kNLeg>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    Vec3<T> hz = Col(p.R[0], 2);  // hip axis: +z of the aux frame = torso z
+    p.cdof[Hip(l)] = {hz, Cross(hz, p.com - p.pos[Aux(l)])};
+    Vec3<T> ha = Mul(p.R[Aux(l)], Vec3<T>{m.ankle_axis[l][0], m.ankle_axis[l][1], m.ankle_axis[l][2]});
+    p.cdof[Ankle(l)] = {ha, Cross(ha, p.com - p.pos[Foot(l)])};
+  });
+  // mj_crb
+  In10<T> crb[kNB];
+  static_for<0, kNB>([&](auto bc) { crb[decltype(bc)::value] = p.cinert[decltype(bc)::value]; });
+  static_for_down<kNB, 1>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    static_for<0, 10>([&](auto kc) { crb[Parent(b)].v[decltype(kc)::value] += crb[b].v[decltype(kc)::value]; });
+  });
+  static_for<0, kNV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    Sp6<T> buf = MulInert(crb[DofBody(i)], p.cdof[i]);
+    static_for<0, i + 1>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (InChain(j, DofBody(i))) p.M[Tri(j, i)] = Dot(p.cdof[j], buf);
+    });
+    if constexpr (i >= 6) p.M[Tri(i, i)] += m.arm[i - 6];
+  });
+}
+
+template <typename T>
+EPA_HD void AntSmoothForces(const AntModel<T>& m, const AntPos<T>& p, const T* v,
+                            const T* ctrl, T* qfrc_smooth) {
+  // mj_comVel: free joint = 3 translations (cdof_dot = 0) then 3 rotations
+  // whose cdof_dot all use the velocity before the rotations are added
+  Sp6<T> cvel[kNB], cdd[kNV];
+  {
+    Sp6<T> cv = {{T(0), T(0), T(0)}, {v[0], v[1], v[2]}};
+    static_for<0, 3>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      cdd[k] = {{T(0), T(0), T(0)}, {T(0), T(0), T(0)}};
+      cdd[3 + k] = CrossMotion(cv, p.cdof[3 + k]);
+    });
+    static_for<3, 6>([&](auto kc) { Axpy(cv, p.cdof[decltype(kc)::value], v[decltype(kc)::value]); });
+    cvel[0] = cv;
+  }
+  static_for<1, kNB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    constexpr int j = b + 5;
+    Sp6<T> cv = cvel[Parent(b)];
+    cdd[j] = CrossMotion(cv, p.cdof[j]);
+    Axpy(cv, p.cdof[j], v[j]);
+    cvel[b] = cv;
+  });
+  // mj_rne, flg_acc = 0
+  Sp6<T> cacc[kNB], cfrc[kNB];
+  static_for<0, kNB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    Sp6<T> a;
+    if constexpr (b == 0) {
+      a = {{T(0), T(0), T(0)}, {T(0), T(0), m.gravity}};
+      static_for<3, 6>([&](auto kc) { Axpy(a, cdd[decltype(kc)::value], v[decltype(kc)::value]); });
+    } else {
+      a = cacc[Parent(b)];
+      Axpy(a, cdd[b + 5], v[b + 5]);
+    }
+    cacc[b] = a;
+    Sp6<T> f = MulInert(p.cinert[b], a);
+    Sp6<T> g = CrossForce(cvel[b], MulInert(p.cinert[b], cvel[b]));
+    cfrc[b] = {f.a + g.a, f.l + g.l};
+  });
+  static_for_down<kNB, 1>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    cfrc[Parent(b)].a = cfrc[Parent(b)].a + cfrc[b].a;
+    cfrc[Parent(b)].l = cfrc[Parent(b)].l + cfrc[b].l;
+  });
+  static_for<0, kNV>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    T bias = Dot(p.cdof[j], cfrc[DofBody(j)]);
+    if constexpr (j < 6) {
+      qfrc_smooth[j] = -bias;
+    } else {
+      qfrc_smooth[j] = -m.damp[j - 6] * v[j] - bias;  // hinge damper (stiffness 0)
+    }
+  });
+  static_for<0, kNU>([&](auto uc) {  // motors: gear * clamp(ctrl)
+    constexpr int u = decltype(uc)::value;
+    qfrc_smooth[CtrlDof(u)] += m.gear * ctrl[u];
+  });
+}
+
+// columns of the point Jacobian (3 x nv) of `cp` attached to body B:
+// f(j, col) for every chain dof j with col = d(point velocity)/d(qdot_j).
+template <int B, typename T, typename F>
+EPA_HD void ForChainCols(const AntPos<T>& p, Vec3<T> cp, F&& f) {
+  f(IC<0>{}, Vec3<T>{T(1), T(0), T(0)});
+  f(IC<1>{}, Vec3<T>{T(0), T(1), T(0)});
+  f(IC<2>{}, Vec3<T>{T(0), T(0), T(1)});
+  static_for<3, kNV>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (InChain(j, B)) {
+      // cdof about the COM: v(point) = lin + ang x (cp - com)
+      f(jc, p.cdof[j].l + Cross(p.cdof[j].a, cp - p.com));
+    }
+  });
+}
+
+template <typename T>
+struct AntRows {
+  T lim_sgn[kNU], lim_aref[kNU], lim_D[kNU];
+  // per sphere: contact point, normal/tangent reference terms, D (0 = inactive)
+  T cx[kNSph], cy[kNSph], cz[kNSph], an[kNSph], ay[kNSph], ax[kNSph], D[kNSph];
+};
+
+template <typename T>
+EPA_HD void AntMakeConstraint(const AntModel<T>& m, const AntPos<T>& p, const T* q,
+                              const T* v, AntRows<T>& r) {
+  const T kMinVal = T(1e-15);
+  static_for<0, kNU>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    T qq = q[7 + j];
+    T dlo = qq - m.lo[j], dhi = m.hi[j] - qq;
+    T sgn = T(0), dist = T(0);
+    if (dlo < T(0)) {
+      sgn = T(1);
+      dist = dlo;
+    } else if (dhi < T(0)) {
+      sgn = T(-1);
+      dist = dhi;
+    }
+    T imp = Impedance(m.imp_d0, m.imp_dmax, m.imp_width, dist);
+    T R = (T(1) - imp) * m.dof_invw[j] / imp;
+    R = R < kMinVal ? kMinVal : R;
+    r.lim_sgn[j] = sgn;
+    r.lim_D[j] = sgn != T(0) ? T(1) / R : T(0);
+    r.lim_aref[j] = -m.con_B * (sgn * v[6 + j]) - m.con_K * imp * dist;
+  });
+  static_for<0, kNSph>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int b = SphBody(s);
+    Vec3<T> w = p.pos[b] + Mul(p.R[b], Vec3<T>{m.sph[s][0], m.sph[s][1], m.sph[s][2]});
+    T dist = w.z - m.sph_r[s];
+    T D = T(0), an = T(0), ay = T(0), ax = T(0);
+    Vec3<T> cp = {w.x, w.y, T(0.5) * dist};
+    if (dist < m.margin) {
+      Vec3<T> vel = {T(0), T(0), T(0)};
+      ForChainCols<b>(p, cp, [&](auto jc, Vec3<T> col) {
+        vel = vel + col * v[decltype(jc)::value];
+      });
+      T rr = dist - m.margin;
+      T imp = Impedance(m.imp_d0, m.imp_dmax, m.imp_width, rr);
+      T diag = m.geom_body_invw[SphGeomBody(s)] * (T(1) + m.mu * m.mu);
+      T R = (T(1) - imp) * diag / imp;
+      R = R < kMinVal ? kMinVal : R;
+      D = T(1) / (T(2) * m.mu * m.mu * R);
+      an = -m.con_B * vel.z - m.con_K * imp * rr;
+      ay = m.con_B * m.mu * vel.y;
+      ax = m.con_B * m.mu * vel.x;
+    }
+    r.cx[s] = cp.x;
+    r.cy[s] = cp.y;
+    r.cz[s] = cp.z;
+    r.an[s] = an;
+    r.ay[s] = ay;
+    r.ax[s] = ax;
+    r.D[s] = D;
+  });
+}
+
+// the four pyramidal rows of a contact in terms of (jx, jy, jz) = J a:
+//   r1 = jz + mu jy, r2 = jz - mu jy, r3 = jz - mu jx, r4 = jz + mu jx
+// with aref_1 = an - ay, aref_2 = an + ay, aref_3 = an + ax, aref_4 = an - ax
+template <typename T>
+EPA_HD void ContactJar(const AntModel<T>& m, Vec3<T> ja, T an, T ay, T ax, T* jar) {
+  jar[0] = ja.z + m.mu * ja.y - (an - ay);
+  jar[1] = ja.z - m.mu * ja.y - (an + ay);
+  jar[2] = ja.z - m.mu * ja.x - (an + ax);
+  jar[3] = ja.z + m.mu * ja.x - (an - ax);
+}
+
+template <bool kHess, typename T>
+EPA_HD void AntRowsPass(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& r,
+                        const T* a, T* grad, T* H, unsigned long long* mask0,
+                        unsigned long long* mask1) {
+  unsigned long long m0 = 0, m1 = 0;
+  static_for<0, kNU>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (r.lim_sgn[j] != T(0)) {
+      T jar = r.lim_sgn[j] * a[6 + j] - r.lim_aref[j];
+      if (jar < T(0)) {
+        grad[6 + j] += r.lim_sgn[j] * r.lim_D[j] * jar;
+        if constexpr (kHess) H[Tri(6 + j, 6 + j)] += r.lim_D[j];
+        m0 |= 1ull << j;
+      }
+    }
+  });
+  static_for<0, kNSph>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int b = SphBody(s);
+    T D = r.D[s];
+    if (D > T(0)) {
+      Vec3<T> cp = {r.cx[s], r.cy[s], r.cz[s]};
+      Vec3<T> ja = {T(0), T(0), T(0)};
+      ForChainCols<b>(p, cp, [&](auto jc, Vec3<T> col) {
+        ja = ja + col * a[decltype(jc)::value];
+      });
+      T jar[4];
+      ContactJar(m, ja, r.an[s], r.ay[s], r.ax[s], jar);
+      T w[4];
+      static_for<0, 4>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        w[k] = jar[k] < T(0) ? D : T(0);
+        if (jar[k] < T(0)) {
+          if constexpr (8 + 4 * s + k < 64) {
+            m0 |= 1ull << (8 + 4 * s + k);
+          } else {
+            m1 |= 1ull << (8 + 4 * s + k - 64);
+          }
+        }
+      });
+      T wsum = w[0] + w[1] + w[2] + w[3];
+      if (wsum > T(0)) {
+        // gradient in contact space: g = sum_r w_r jar_r * (row coefficients)
+        T gz = w[0] * jar[0] + w[1] * jar[1] + w[2] * jar[2] + w[3] * jar[3];
+        T gy = m.mu * (w[0] * jar[0] - w[1] * jar[1]);
+        T gx = m.mu * (w[3] * jar[3] - w[2] * jar[2]);
+        // Hessian in contact space (symmetric 3x3 over x,y,z)
+        T hzz = wsum;
+        T hyy = m.mu * m.mu * (w[0] + w[1]), hxx = m.mu * m.mu * (w[2] + w[3]);
+        T hzy = m.mu * (w[0] - w[1]), hzx = m.mu * (w[3] - w[2]);
+        ForChainCols<b>(p, cp, [&](auto ic, Vec3<T> ci) {
+          constexpr int i = decltype(ic)::value;
+          grad[i] += ci.x * gx + ci.y * gy + ci.z * gz;
+          if constexpr (kHess) {
+            // u = Hc * ci
+            T ux = hxx * ci.x + hzx * ci.z;
+            T uy = hyy * ci.y + hzy * ci.z;
+            T uz = hzx * ci.x + hzy * ci.y + hzz * ci.z;
+            ForChainCols<b>(p, cp, [&](auto kc2, Vec3<T> ck) {
+              constexpr int k = decltype(kc2)::value;
+              if constexpr (k >= i) H[Tri(i, k)] += ux * ck.x + uy * ck.y + uz * ck.z;
+            });
+          }
+        });
+      }
+    }
+  });
+  *mask0 = m0;
+  *mask1 = m1;
+}
+
+template <typename T>
+EPA_HD void AntLineEval(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& r,
+                        const T* a, const T* s, T alpha, T* d1, T* d2) {
+  static_for<0, kNU>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (r.lim_sgn[j] != T(0)) {
+      T jar = r.lim_sgn[j] * a[6 + j] - r.lim_aref[j];
+      T jv = r.lim_sgn[j] * s[6 + j];
+      T x = jar + alpha * jv;
+      if (x < T(0)) {
+        *d1 += r.lim_D[j] * x * jv;
+        *d2 += r.lim_D[j] * jv * jv;
+      }
+    }
+  });
+  static_for<0, kNSph>([&](auto sc) {
+    constexpr int sidx = decltype(sc)::value;
+    constexpr int b = SphBody(sidx);
+    T D = r.D[sidx];
+    if (D > T(0)) {
+      Vec3<T> cp = {r.cx[sidx], r.cy[sidx], r.cz[sidx]};
+      Vec3<T> ja = {T(0), T(0), T(0)}, js = {T(0), T(0), T(0)};
+      ForChainCols<b>(p, cp, [&](auto jc, Vec3<T> col) {
+        ja = ja + col * a[decltype(jc)::value];
+        js = js + col * s[decltype(jc)::value];
+      });
+      T jar[4];
+      ContactJar(m, ja, r.an[sidx], r.ay[sidx], r.ax[sidx], jar);
+      T jv[4] = {js.z + m.mu * js.y, js.z - m.mu * js.y, js.z - m.mu * js.x,
+                 js.z + m.mu * js.x};
+      static_for<0, 4>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        T x = jar[k] + alpha * jv[k];
+        if (x < T(0)) {
+          *d1 += D * x * jv[k];
+          *d2 += D * jv[k] * jv[k];
+        }
+      });
+    }
+  });
+}
+
+template <typename T>
+EPA_HD int AntSolve(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& r,
+                    const T* qfrc_smooth, const SolverCfg<T>& cfg, T* qacc) {
+  T fs = T(0);
+  static_for<0, kNV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    T x = qfrc_smooth[i] < T(0) ? -qfrc_smooth[i] : qfrc_smooth[i];
+    fs = x > fs ? x : fs;
+  });
+  const T gstop = cfg.gtol * (T(1) + fs);
+  unsigned long long pm0 = ~0ull, pm1 = ~0ull;
+  bool full_step = false;
+  int iter = 0;
+  for (; iter < cfg.max_iter; ++iter) {
+    T H[kTri], Ma[kNV], grad[kNV];
+    static_for<0, kTri>([&](auto kc) { H[decltype(kc)::value] = p.M[decltype(kc)::value]; });
+    SymMul(p.M, qacc, Ma);
+    static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      grad[i] = Ma[i] - qfrc_smooth[i];
+    });
+    unsigned long long m0, m1;
+    AntRowsPass<true>(m, p, r, qacc, grad, H, &m0, &m1);
+    T gn = T(0);
+    static_for<0, kNV>([&](auto ic) { gn += grad[decltype(ic)::value] * grad[decltype(ic)::value]; });
+    gn = Sqrt(gn);
+    if (gn <= gstop || (full_step && m0 == pm0 && m1 == pm1)) break;
+    pm0 = m0;
+    pm1 = m1;
+    T s[kNV];
+    static_for<0, kNV>([&](auto ic) { s[decltype(ic)::value] = -grad[decltype(ic)::value]; });
+    FactorUUt(H);
+    SolveUUt(H, s);
+    T Ms[kNV];
+    SymMul(p.M, s, Ms);
+    T g1 = T(0), g2 = T(0);
+    static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      g1 += s[i] * (Ma[i] - qfrc_smooth[i]);
+      g2 += s[i] * Ms[i];
+    });
+    T alpha = T(1), lo = T(0), hi = T(-1);
+    full_step = false;
+    const T ag1 = g1 < T(0) ? -g1 : g1;
+    const T ls_tol = (sizeof(T) == 4 ? T(1e-4) : T(1e-12)) * ag1;
+    for (int ls = 0; ls < 24; ++ls) {
+      T d1 = g1 + alpha * g2, d2 = g2;
+      AntLineEval(m, p, r, qacc, s, alpha, &d1, &d2);
+      T ad1 = d1 < T(0) ? -d1 : d1;
+      if (ad1 <= ls_tol) {
+        full_step = ls == 0;
+        break;
+      }
+      if (d1 < T(0)) {
+        lo = alpha;
+      } else {
+        hi = alpha;
+      }
+      T next = alpha - d1 / d2;
+      if (hi >= T(0) && (next <= lo || next >= hi)) next = T(0.5) * (lo + hi);
+      if (next <= T(0)) next = T(0.5) * alpha;
+      if (next == alpha) break;
+      alpha = next;
+    }
+    static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      qacc[i] += alpha * s[i];
+    });
+  }
+  return iter;
+}
+
+// mj_forward: qacc for state (q, v) under ctrl; `warm` is qacc_warmstart in/out.
+// Returns Newton iterations.  q's quaternion is normalised in place.
+template <typename T>
+EPA_HD int AntForward(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, const T* v,
+                      const T* ctrl, T* warm, T* qacc) {
+  AntPos<T> p;
+  AntKinematics(m, q, p);
+  T qfrc_smooth[kNV];
+  AntSmoothForces(m, p, v, ctrl, qfrc_smooth);
+  AntRows<T> rows;
+  AntMakeConstraint(m, p, q, v, rows);
+  static_for<0, kNV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
+  int it = AntSolve(m, p, rows, qfrc_smooth, cfg, qacc);
+  static_for<0, kNV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
+  return it;
+}
+
+// mj_integratePos for the Ant: q <- q (+) h * dq  (dq in velocity coordinates)
+template <typename T>
+EPA_HD void AntIntegratePos(T* q, const T* dq, T h) {
+  q[0] += h * dq[0];
+  q[1] += h * dq[1];
+  q[2] += h * dq[2];
+  T wx = dq[3], wy = dq[4], wz = dq[5];
+  T nrm = Sqrt(wx * wx + wy * wy + wz * wz);
+  T ang = nrm * h;
+  if (ang > T(0)) {
+    T s, c;
+    SinCos(T(0.5) * ang, &s, &c);
+    T k = s / nrm;
+    T bw = c, bx = wx * k, by = wy * k, bz = wz * k;
+    T aw = q[3], ax = q[4], ay = q[5], az = q[6];
+    q[3] = aw * bw - ax * bx - ay * by - az * bz;
+    q[4] = aw * bx + ax * bw + ay * bz - az * by;
+    q[5] = aw * by - ax * bz + ay * bw + az * bx;
+    q[6] = aw * bz + ax * by - ay * bx + az * bw;
+    NormalizeQuat(q + 3);
+  }
+  static_for<7, kNQ>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    q[i] += h * dq[i - 1];
+  });
+}
+
+// One mj_step with integrator RK4 (mj_RungeKutta(4)).  On return q, v are the
+// new state and (lagx, lagy) the torso xpos of the LAST forward evaluation
+// (stage 4), which is what data_->xpos holds afterwards (ant.h:169-173).
+template <typename T>
+EPA_HD int AntStep(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, T* v, T* warm,
+                   const T* ctrl, T* lagx, T* lagy) {
+  const T h = m.timestep;
+  T q0[kNQ], v0[kNV], qs[kNQ], vs[kNV];
+  T F[kNV], dq[kNV], dv[kNV];     // running B-weighted sums
+  T Xv_prev[kNV], F_prev[kNV];
+  int it = 0;
+  static_for<0, kNQ>([&](auto ic) { q0[decltype(ic)::value] = q[decltype(ic)::value]; });
+  static_for<0, kNV>([&](auto ic) { v0[decltype(ic)::value] = v[decltype(ic)::value]; });
+  // stage 1 at (q0, v0)
+  it += AntForward(m, cfg, q, v, ctrl, warm, F);
+  static_for<0, kNQ>([&](auto ic) { q0[decltype(ic)::value] = q[decltype(ic)::value]; });  // normalised quat
+  static_for<0, kNV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    dq[i] = v0[i] * T(1.0 / 6.0);
+    dv[i] = F[i] * T(1.0 / 6.0);
+    Xv_prev[i] = v0[i];
+    F_prev[i] = F[i];
+  });
+  // stages 2..4: X_i = X_0 + h * a_i * (Xv_{i-1}, F_{i-1}), a = 1/2, 1/2, 1
+  for (int stage = 1; stage < 4; ++stage) {
+    const T a = stage == 3 ? T(1) : T(0.5);
+    const T bw = stage == 3 ? T(1.0 / 6.0) : T(1.0 / 3.0);
+    T step_dq[kNV];
+    static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      step_dq[i] = a * Xv_prev[i];
+      vs[i] = v0[i] + h * a * F_prev[i];
+    });
+    static_for<0, kNQ>([&](auto ic) { qs[decltype(ic)::value] = q0[decltype(ic)::value]; });
+    AntIntegratePos(qs, step_dq, h);
+    it += AntForward(m, cfg, qs, vs, ctrl, warm, F);
+    static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      dq[i] += bw * vs[i];
+      dv[i] += bw * F[i];
+      Xv_prev[i] = vs[i];
+      F_prev[i] = F[i];
+    });
+    if (stage == 3) {
+      *lagx = qs[0];
+      *lagy = qs[1];
+    }
+  }
+  static_for<0, kNQ>([&](auto ic) { q[decltype(ic)::value] = q0[decltype(ic)::value]; });
+  static_for<0, kNV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    v[i] = v0[i] + h * dv[i];
+  });
+  AntIntegratePos(q, dq, h);
+  return it;
+}
+
+}  // namespace ant
+}  // namespace mj
+}  // namespace epa
+
+#endif  // ENVPOOL_AMD_CSRC_MJ_ANT_CUH_

@@ -270,6 +270,10 @@ class CheetahPool : public Pool {
 
 }  // namespace
 
+bool DescribeAnt(const std::string& family, const Config& cfg,
+                 std::vector<KeySpec>* state, KeySpec* action);
+Pool* MakeAnt(const std::string& family, const Config& cfg);
+
 bool DescribeMujoco(const std::string& family, const Config& cfg,
                     std::vector<KeySpec>* state, KeySpec* action) {
   if (family == "HalfCheetah") {
@@ -277,12 +281,12 @@ bool DescribeMujoco(const std::string& family, const Config& cfg,
     *action = KeySpec{"action", EPA_F64, {kNU}};
     return true;
   }
-  return false;
+  return DescribeAnt(family, cfg, state, action);
 }
 
 Pool* MakeMujoco(const std::string& family, const Config& cfg) {
   if (family == "HalfCheetah") return new CheetahPool(cfg);
-  return nullptr;
+  return MakeAnt(family, cfg);
 }
 
 }  // namespace epa

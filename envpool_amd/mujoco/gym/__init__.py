@@ -1,6 +1,7 @@
 """gym-MuJoCo envs (mirror of envpool/mujoco/gym/__init__.py).
 
-Spec tables restate `HalfCheetahEnvFns` (half_cheetah.h:31-62); the pixel
+Spec tables restate `HalfCheetahEnvFns` (half_cheetah.h:31-62) and `AntEnvFns`
+(ant.h:31-75, v4: use_contact_force=False); the pixel
 variants are out of scope.  `precision` is an extension key: 64 (default, the
 reference's mjtNum=double) or 32 (fp32 arithmetic, fp64 state and I/O).
 """
@@ -52,9 +53,55 @@ _HalfCheetah = FamilyDef(
     unsupported={"frame_stack": 1, "xml_file": "half_cheetah.xml"},
 )
 
+_Ant = FamilyDef(
+    name="GymAnt", native="Ant",
+    # ant.h:33-50
+    default_config=[
+        ("reward_threshold", 6000.0), ("frame_skip", 5), ("frame_stack", 1),
+        ("post_constraint", True), ("use_contact_force", False),
+        ("legacy_healthy_reward", True), ("exclude_worldbody_contact_forces", False),
+        ("terminate_when_unhealthy", True),
+        ("exclude_current_positions_from_observation", True),
+        ("xml_file", "ant.xml"), ("gymnasium_v5_render_camera", False),
+        ("forward_reward_weight", 1.0), ("ctrl_cost_weight", 0.5),
+        ("contact_cost_weight", 5e-4), ("healthy_reward", 1.0),
+        ("healthy_z_min", 0.2), ("healthy_z_max", 1.0),
+        ("contact_force_min", -1.0), ("contact_force_max", 1.0),
+        ("reset_noise_scale", 0.1), ("precision", 64),
+    ],
+    state_spec=lambda c: [
+        ("obs", spec(np.float64,
+                     [27 if c["exclude_current_positions_from_observation"] else 29],
+                     (-_inf, _inf))),
+    ] + [(k, spec(np.float64, [-1])) for k in (
+        "info:reward_forward", "info:reward_ctrl", "info:reward_contact",
+        "info:reward_survive", "info:x_position", "info:y_position",
+        "info:distance_from_origin", "info:x_velocity", "info:y_velocity")],
+    action_spec=lambda c: [("action", spec(np.float64, [-1, 8], (-1.0, 1.0)))],
+    native_params=lambda c: {
+        "frame_skip": c["frame_skip"],
+        "exclude_current_positions_from_observation":
+            c["exclude_current_positions_from_observation"],
+        "terminate_when_unhealthy": c["terminate_when_unhealthy"],
+        "legacy_healthy_reward": c["legacy_healthy_reward"],
+        "ctrl_cost_weight": c["ctrl_cost_weight"],
+        "forward_reward_weight": c["forward_reward_weight"],
+        "healthy_reward": c["healthy_reward"],
+        "healthy_z_min": c["healthy_z_min"], "healthy_z_max": c["healthy_z_max"],
+        "reset_noise_scale": c["reset_noise_scale"],
+        "use_contact_force": c["use_contact_force"],
+        "precision": _precision(c),
+    },
+    # Ant-v3 / v5 observe cfrc_ext (mj_rnePostConstraint): not restated yet
+    unsupported={"frame_stack": 1, "xml_file": "ant.xml", "use_contact_force": False},
+)
+
 _GymHalfCheetahEnvSpec, _GymHalfCheetahEnvPool = make_native_classes(_HalfCheetah)
+_GymAntEnvSpec, _GymAntEnvPool = make_native_classes(_Ant)
+GymAntEnvSpec, GymAntDMEnvPool, GymAntGymnasiumEnvPool = py_env(_GymAntEnvSpec, _GymAntEnvPool)
 (GymHalfCheetahEnvSpec, GymHalfCheetahDMEnvPool,
  GymHalfCheetahGymnasiumEnvPool) = py_env(_GymHalfCheetahEnvSpec, _GymHalfCheetahEnvPool)
 
 __all__ = ["GymHalfCheetahEnvSpec", "GymHalfCheetahDMEnvPool",
-           "GymHalfCheetahGymnasiumEnvPool"]
+           "GymHalfCheetahGymnasiumEnvPool", "GymAntEnvSpec", "GymAntDMEnvPool",
+           "GymAntGymnasiumEnvPool"]

@@ -136,3 +136,61 @@ def test_fp32_energy_sanity():
         d = hip_step(pool, rng.uniform(-1, 1, size=(n, 6)))
     assert np.isfinite(d["obs"]).all()
     assert np.abs(d["obs"][:, 8:]).max() < 100
+
+
+# ---------------------------------------------------------------------------
+# Ant-v4 (3-D, free joint, RK4, sphere/capsule contacts)
+# ---------------------------------------------------------------------------
+def make_ant_pair(n, seed, precision, max_steps=1000):
+    pool = DevicePool("Ant", n, seed=seed, max_episode_steps=max_steps,
+                      params={"precision": precision})
+    orc = Oracle("Ant", n, seed=seed, max_episode_steps=max_steps)
+    return pool, orc
+
+
+def test_ant_reset_matches_oracle():
+    pool, orc = make_ant_pair(64, 5, 1)
+    a, b = hip_reset(pool), orc.reset()
+    np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-14, atol=1e-16)
+    for k in ("elapsed_step", "done", "reward", "step_type", "trunc", "info:env_id"):
+        np.testing.assert_array_equal(a[k].ravel(), b[k].ravel())
+
+
+@pytest.mark.parametrize("precision,rtol,atol", [(1, 1e-9, 1e-10), (0, 1e-3, 1e-3)])
+def test_ant_teacher_forced_step(precision, rtol, atol):
+    n, steps = 128, 60
+    pool, orc = make_ant_pair(n, 4, precision)
+    hip_reset(pool), orc.reset()
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for t in range(steps):
+        pool.set_state(orc.get_state())
+        act = rng.uniform(-1, 1, size=(n, 8))
+        a, b = hip_step(pool, act), orc.step(act)
+        np.testing.assert_allclose(a["obs"], b["obs"], rtol=rtol, atol=atol, err_msg=f"step {t}")
+        for k in ("info:x_position", "info:y_position", "info:x_velocity",
+                  "info:reward_survive", "info:distance_from_origin"):
+            np.testing.assert_allclose(a[k].ravel(), b[k].ravel(), rtol=rtol, atol=atol * 20)
+        np.testing.assert_allclose(a["reward"].ravel(), b["reward"].ravel(),
+                                   rtol=max(rtol, 1e-6), atol=max(atol * 20, 1e-6))
+        for k in ("done", "trunc", "elapsed_step", "step_type"):
+            np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k}@{t}")
+        worst = max(worst, float(np.abs(a["obs"] - b["obs"]).max()))
+    print(f"Ant precision={precision}: worst teacher-forced |d obs| = {worst:.3e}")
+
+
+def test_ant_unhealthy_termination_and_autoreset():
+    """terminate_when_unhealthy: envs fall over / leave z in [0.2, 1] and reset."""
+    n = 64
+    pool, orc = make_ant_pair(n, 11, 1, max_steps=40)
+    a, b = hip_reset(pool), orc.reset()
+    rng = np.random.default_rng(1)
+    seen_term = False
+    for t in range(80):
+        pool.set_state(orc.get_state())
+        act = rng.uniform(-1, 1, size=(n, 8))
+        a, b = hip_step(pool, act), orc.step(act)
+        for k in ("done", "trunc", "elapsed_step", "step_type", "discount"):
+            np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k}@{t}")
+        seen_term |= bool((b["done"] & ~b["trunc"]).any())
+    assert b["elapsed_step"].max() <= 40

@@ -22,7 +22,8 @@ def test_list_all_envs_and_registry():
               "MountainCar-v0", "MountainCarContinuous-v0", "Acrobot-v1", "Catch-v0",
               "FrozenLake-v1", "FrozenLake8x8-v1", "Taxi-v3", "NChain-v0",
               "CliffWalking-v0", "CliffWalking-v1", "CliffWalkingSlippery-v1",
-              "Blackjack-v1", "HalfCheetah-v3", "HalfCheetah-v4", "HalfCheetah-v5"]:
+              "Blackjack-v1", "HalfCheetah-v3", "HalfCheetah-v4", "HalfCheetah-v5",
+              "Ant-v4"]:
         assert t in ids, t
     with pytest.raises(AssertionError):
         envpool.make("NoSuchEnv-v0", "gym", num_envs=1)
@@ -114,12 +115,13 @@ FAMILY_PARAMS = {
     "MountainCarContinuous-v0": {}, "Acrobot-v1": {}, "Catch-v0": {"height": 10, "width": 5},
     "FrozenLake8x8-v1": {"size": 8}, "Taxi-v3": {}, "NChain-v0": {},
     "CliffWalkingSlippery-v1": {"is_slippery": 1}, "Blackjack-v1": {}, "HalfCheetah-v4": {},
+    "Ant-v4": {},
 }
 NATIVE = {"CartPole-v1": "CartPole", "Pendulum-v1": "Pendulum", "MountainCar-v0": "MountainCar",
           "MountainCarContinuous-v0": "MountainCarContinuous", "Acrobot-v1": "Acrobot",
           "Catch-v0": "Catch", "FrozenLake8x8-v1": "FrozenLake", "Taxi-v3": "Taxi",
           "NChain-v0": "NChain", "CliffWalkingSlippery-v1": "CliffWalking",
-          "Blackjack-v1": "Blackjack", "HalfCheetah-v4": "HalfCheetah"}
+          "Blackjack-v1": "Blackjack", "HalfCheetah-v4": "HalfCheetah", "Ant-v4": "Ant"}
 
 
 @pytest.mark.parametrize("task", sorted(FAMILY_PARAMS))
