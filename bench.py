@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(num_envs=64, target_s=15.0):
+def cpu_baseline(task="HalfCheetah", num_envs=64, target_s=15.0):
     """Oracle ("port": oracle/mjcpu fp64 restatement, single thread) on a bounded
     sample of the same workload.  The reference itself cannot run: mj_step lives
     in un-vendored MuJoCo 3.6.0."""
@@ -29,10 +29,10 @@ def cpu_baseline(num_envs=64, target_s=15.0):
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "port"], check=True)
     from oracle.orc import Oracle
 
-    o = Oracle("HalfCheetah", num_envs, seed=0, max_episode_steps=1000)
+    o = Oracle(task, num_envs, seed=0, max_episode_steps=1000)
     o.reset()
     rng = np.random.default_rng(0)
-    act = rng.uniform(-1, 1, size=(num_envs, 6))
+    act = rng.uniform(-1, 1, size=(num_envs, o.action_elems))
     t = o.time_steps(5, act)
     steps = max(5, int(target_s / max(t / 5, 1e-6)))
     steps = min(steps, 20000)
@@ -116,11 +116,11 @@ def main():
         value = total_env_steps / elapsed
         # algorithmic bytes / env-step: action+ids
         # in, every state key out, persistent fp64 state read + written
-        alg_bytes = 708
+        alg_bytes = {"HalfCheetah": 708, "Ant": 1132}[args.task]
         # counted fp32 flops / env-step from the kernel's ISA
         achieved_gbs = alg_bytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         out = {
-            "metric": "env steps/sec (raw FPS) at num_envs=65536, HalfCheetah-v4",
+            "metric": f"env steps/sec (raw FPS) at num_envs={n}, {args.task}-v4",
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -146,7 +146,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved_gbs / 8000.0,
                 "traffic": None,
-                "kernel": "CheetahStepKernel",
+                "kernel": "CheetahStepKernel" if args.task == "HalfCheetah" else "AntStepKernel",
                 "kernel_ms": kernel_ms,
                 "launches": launches,
                 "algorithmic_bytes_per_env_step": alg_bytes,
@@ -155,7 +155,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.task)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
