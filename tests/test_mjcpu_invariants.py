@@ -1,0 +1,139 @@
+"""Physics invariants of oracle/mjcpu that need no external oracle
+(SURVEY Appendix A.10).  Real-MuJoCo parity of this restatement is UNPINNED;
+these tests pin its internal consistency, and tests/cpu_harness cross-checks it
+against the independently formulated product code."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mj_util import RawMj
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ANT_Q0 = np.array([0, 0, 0.75, 1, 0, 0, 0, 0, 0.9, 0, -0.9, 0, -0.9, 0, 0.9], float)
+# extra = [frame_skip, ctrl_w, fwd_w, noise, no_contact, no_limit, no_act, no_passive, integrator, h]
+FREE = (5, 0.5, 1, 0.1, 1, 1, 1, 1)
+
+
+def test_model_compile_constants():
+    c, a = RawMj("HalfCheetah"), RawMj("Ant")
+    assert (c.nq, c.nv, c.nu, c.nbody, c.ngeom) == (9, 9, 6, 8, 9)
+    assert (a.nq, a.nv, a.nu, a.nbody, a.ngeom) == (15, 14, 8, 14, 14)
+    assert abs(c.total_mass - 14.0) < 1e-12  # settotalmass
+    # Ant torso sphere r=.25 density 5
+    assert abs(a.body_mass[1] - 5 * 4 / 3 * np.pi * 0.25**3) < 1e-12
+    assert (c.dof_invweight0 > 0).all() and (a.dof_invweight0 > 0).all()
+    # free joint: translational / rotational dof_invweight0 are averaged
+    assert np.allclose(a.dof_invweight0[:3], a.dof_invweight0[0])
+    assert np.allclose(a.dof_invweight0[3:6], a.dof_invweight0[3])
+    # four-fold symmetry of the Ant
+    assert np.allclose(a.body_invweight0[2:5], a.body_invweight0[5:8], rtol=1e-9)
+
+
+def test_free_fall_is_exact_under_rk4():
+    a = RawMj("Ant")
+    a.set(ANT_Q0, np.zeros(14))
+    for _ in range(4):
+        a.step(5)
+        q, v, m = a.get()
+        t = m["time"]
+        assert m["ncon"] == 0 and m["nefc"] == 0
+        assert abs(q[2] - (0.75 - 0.5 * 9.81 * t * t)) < 1e-12
+
+
+def test_energy_conservation_rk4_and_euler_order():
+    rng = np.random.default_rng(0)
+    q = ANT_Q0.copy()
+    q[7:] = rng.uniform(-0.3, 0.3, 8)
+    q[3:7] = [0.9, 0.1, 0.3, -0.2]
+    q[3:7] /= np.linalg.norm(q[3:7])
+    a = RawMj("Ant", extra=FREE)
+    a.set(q, rng.normal(0, 1, 14))
+    e0 = sum(a.get()[2][k] for k in ("ke", "pe"))
+    a.step(100)
+    m = a.get()[2]
+    assert abs(m["ke"] + m["pe"] - e0) < 1e-5 * abs(e0)  # O(h^4)
+    assert m["asym"] == 0.0
+    # cheetah: RK4 conserves, semi-implicit Euler drifts linearly in h
+    qc = rng.uniform(-0.3, 0.3, 9)
+    qc[1] = 0
+    vc = rng.normal(0, 1, 9)
+    drift = {}
+    for integ, h in [(1, 0.01), (0, 0.01), (0, 0.005)]:
+        c = RawMj("HalfCheetah", extra=(5, 0.1, 1, 0.1, 1, 1, 1, 1, integ, h))
+        c.set(qc, vc)
+        e0 = sum(c.get()[2][k] for k in ("ke", "pe"))
+        c.step(int(round(0.2 / h)))
+        m = c.get()[2]
+        drift[(integ, h)] = m["ke"] + m["pe"] - e0
+    assert abs(drift[(1, 0.01)]) < 1e-6
+    assert 1.8 < drift[(0, 0.01)] / drift[(0, 0.005)] < 2.2
+
+
+def test_static_equilibrium_supports_weight():
+    c = RawMj("HalfCheetah")
+    c.set(np.zeros(9), np.zeros(9))
+    c.step(500)
+    q, v, m = c.get()
+    assert np.abs(v).max() < 1e-3
+    assert abs(m["fsum"] - 14 * 9.81) < 1e-2  # sum of pyramid forces = m g
+    assert m["fmin"] >= 0 and m["resid"] < 1e-9  # forces >= 0, KKT residual
+    a = RawMj("Ant")
+    a.set(ANT_Q0, np.zeros(14))
+    a.step(150)
+    q, v, m = a.get()
+    assert m["ncon"] == 4 and abs(m["fsum"] - a.total_mass * 9.81) < 2e-3
+    assert m["resid"] < 1e-9
+
+
+def test_cheetah_stays_planar_and_ant_mirror_symmetry():
+    a = RawMj("Ant")
+    a.set(ANT_Q0, np.zeros(14))
+    a.step(120)
+    q, _, _ = a.get()
+    # symmetric initial state, no control: x, y stay 0 and the legs stay mirrored
+    assert abs(q[0]) < 1e-9 and abs(q[1]) < 1e-9
+    assert np.allclose(q[8], [-q[10], -q[12], q[14]], atol=1e-9)
+
+
+def test_product_planar_code_matches_oracle_on_cpu():
+    """Host instantiation of the exact kernel source (mj_cheetah.cuh /
+    mj_ant.cuh) vs the oracle, teacher forced: two independent formulations."""
+    from oracle.orc import Oracle
+
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    for name in ("cheetah", "ant"):
+        so = os.path.join(h, f"lib{name}_host.so")
+        src = os.path.join(h, f"{name}_host.cpp")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so],
+                           check=True)
+    rng = np.random.default_rng(3)
+    for task, lib, nq, nv, nu, skip in (("HalfCheetah", "cheetah", 9, 9, 6, 1),
+                                        ("Ant", "ant", 15, 14, 8, 2)):
+        L = ctypes.CDLL(os.path.join(h, f"lib{lib}_host.so"))
+        n = 8
+        orc = Oracle(task, n, seed=9, max_episode_steps=1000)
+        orc.reset()
+        worst = 0.0
+        for t in range(40):
+            st = orc.get_state()
+            act = rng.uniform(-1, 1, size=(n, nu))
+            b = orc.step(act)
+            for e in range(n):
+                if b["elapsed_step"][e, 0] == 0:
+                    continue
+                q, v, w = st[e, :nq].copy(), st[e, nq:nq + nv].copy(), st[e, nq + nv:nq + 2 * nv].copy()
+                qo, vo, wo = np.zeros(nq), np.zeros(nv), np.zeros(nv)
+                it = ctypes.c_int(0)
+                args = [x.ctypes.data_as(ctypes.c_void_p) for x in (q, v, w, np.ascontiguousarray(act[e]))]
+                outs = [x.ctypes.data_as(ctypes.c_void_p) for x in (qo, vo, wo)]
+                if lib == "ant":
+                    lag = np.zeros(2)
+                    L.ant_host_step(*args, 5, 0, *outs, lag.ctypes.data_as(ctypes.c_void_p), ctypes.byref(it))
+                else:
+                    L.cheetah_host_step(*args, 5, 0, *outs, ctypes.byref(it))
+                worst = max(worst, np.abs(np.concatenate([qo[skip:], vo]) - b["obs"][e]).max())
+        assert worst < 1e-9, (task, worst)
