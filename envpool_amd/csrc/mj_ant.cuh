@@ -642,6 +642,8 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& 
     fs = x > fs ? x : fs;
   });
   const T gstop = cfg.gtol * (T(1) + fs);
+  const T gfloor = (sizeof(T) == 4 ? T(1e-4) : T(1e-9)) * (T(1) + fs);
+  T prev_gn = T(-1);
   unsigned long long pm0 = ~0ull, pm1 = ~0ull;
   bool full_step = false;
   int iter = 0;
@@ -659,6 +661,8 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& 
     static_for<0, kNV>([&](auto ic) { gn += grad[decltype(ic)::value] * grad[decltype(ic)::value]; });
     gn = Sqrt(gn);
     if (gn <= gstop || (full_step && m0 == pm0 && m1 == pm1)) break;
+    if (prev_gn >= T(0) && gn <= gfloor && gn >= T(0.25) * prev_gn) break;
+    prev_gn = gn;
     pm0 = m0;
     pm1 = m1;
     T s[kNV];
@@ -676,7 +680,7 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& 
     T alpha = T(1), lo = T(0), hi = T(-1);
     full_step = false;
     const T ag1 = g1 < T(0) ? -g1 : g1;
-    const T ls_tol = (sizeof(T) == 4 ? T(1e-4) : T(1e-12)) * ag1;
+    const T ls_tol = (sizeof(T) == 4 ? T(1e-4) : T(1e-10)) * ag1;
     for (int ls = 0; ls < 24; ++ls) {
       T d1 = g1 + alpha * g2, d2 = g2;
       AntLineEval(m, p, r, qacc, s, alpha, &d1, &d2);

@@ -427,6 +427,28 @@ EPA_HD void ForChainCols(const CheetahPos<T>& p, T cpx, T cpz, F&& f) {
   });
 }
 
+// Runtime loop over the end spheres with a wave-uniform switch on the body:
+// keeps the per-contact constants in LDS (dynamic slot index => real ds_read,
+// no store-to-load forwarding into long-lived VGPRs) and emits the Jacobian
+// code once per body instead of once per end sphere.
+#if defined(__clang__)
+#define EPA_NO_UNROLL _Pragma("clang loop unroll(disable)")
+#else
+#define EPA_NO_UNROLL
+#endif
+template <typename F>
+EPA_HD void DispatchBody(int b, F&& f) {
+  switch (b) {
+    case 0: f(IC<0>{}); break;
+    case 1: f(IC<1>{}); break;
+    case 2: f(IC<2>{}); break;
+    case 3: f(IC<3>{}); break;
+    case 4: f(IC<4>{}); break;
+    case 5: f(IC<5>{}); break;
+    default: f(IC<6>{}); break;
+  }
+}
+
 // Limit rows kept in registers; contact rows staged through `lds`
 // (lds(slot) -> T&, slot = 5*e + {0:cpx 1:cpz 2:aref_n 3:B*mu*vx 4:D}).
 template <typename T>
@@ -511,47 +533,49 @@ EPA_HD unsigned long long CheetahRowsPass(const CheetahModel<T>& m,
       }
     }
   });
-  static_for<0, kNEnd>([&](auto ec) {
-    constexpr int e = decltype(ec)::value;
-    constexpr int b = EndBody(e);
+  EPA_NO_UNROLL
+  for (int e = 0; e < kNEnd; ++e) {
     T D = lds(e * kSlotsPerEnd + 4);
     if (D > T(0)) {
       T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
       T an = lds(e * kSlotsPerEnd + 2), ax = lds(e * kSlotsPerEnd + 3);
-      T jna = T(0), jxa = T(0);
-      ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
-        constexpr int j = decltype(jc)::value;
-        jna += jn * a[j];
-        jxa += jx * a[j];
-      });
-      // rows: 2 x (Jn), (Jn - mu Jx), (Jn + mu Jx)
-      T jar1 = jna - an;
-      T jar2 = jna - m.mu * jxa - (an + ax);
-      T jar3 = jna + m.mu * jxa - (an - ax);
-      T w1 = jar1 < T(0) ? T(2) * D : T(0);
-      T w2 = jar2 < T(0) ? D : T(0);
-      T w3 = jar3 < T(0) ? D : T(0);
-      mask |= (jar1 < T(0) ? 1ull : 0ull) << (6 + 3 * e);
-      mask |= (jar2 < T(0) ? 1ull : 0ull) << (7 + 3 * e);
-      mask |= (jar3 < T(0) ? 1ull : 0ull) << (8 + 3 * e);
-      T gn = w1 * jar1 + w2 * jar2 + w3 * jar3;   // coefficient of Jn
-      T gx = m.mu * (w3 * jar3 - w2 * jar2);      // coefficient of Jx
-      T A = w1 + w2 + w3, Bc = m.mu * (w3 - w2), C = m.mu * m.mu * (w2 + w3);
-      if (A > T(0)) {
-        ForChainCols<b>(p, cpx, cpz, [&](auto ic, T jni, T jxi) {
-          constexpr int i = decltype(ic)::value;
-          grad[i] += jni * gn + jxi * gx;
-          if constexpr (kHess) {
-            T ui = A * jni + Bc * jxi, wi = Bc * jni + C * jxi;
-            ForChainCols<b>(p, cpx, cpz, [&](auto kc, T jnk, T jxk) {
-              constexpr int k = decltype(kc)::value;
-              if constexpr (k >= i) H[TriIdx(i, k)] += ui * jnk + wi * jxk;
-            });
-          }
+      DispatchBody(EndBody(e), [&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        T jna = T(0), jxa = T(0);
+        ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
+          constexpr int j = decltype(jc)::value;
+          jna += jn * a[j];
+          jxa += jx * a[j];
         });
-      }
+        // rows: 2 x (Jn), (Jn - mu Jx), (Jn + mu Jx)
+        T jar1 = jna - an;
+        T jar2 = jna - m.mu * jxa - (an + ax);
+        T jar3 = jna + m.mu * jxa - (an - ax);
+        T w1 = jar1 < T(0) ? T(2) * D : T(0);
+        T w2 = jar2 < T(0) ? D : T(0);
+        T w3 = jar3 < T(0) ? D : T(0);
+        mask |= (jar1 < T(0) ? 1ull : 0ull) << (6 + 3 * e);
+        mask |= (jar2 < T(0) ? 1ull : 0ull) << (7 + 3 * e);
+        mask |= (jar3 < T(0) ? 1ull : 0ull) << (8 + 3 * e);
+        T gn = w1 * jar1 + w2 * jar2 + w3 * jar3;   // coefficient of Jn
+        T gx = m.mu * (w3 * jar3 - w2 * jar2);      // coefficient of Jx
+        T A = w1 + w2 + w3, Bc = m.mu * (w3 - w2), C = m.mu * m.mu * (w2 + w3);
+        if (A > T(0)) {
+          ForChainCols<b>(p, cpx, cpz, [&](auto ic, T jni, T jxi) {
+            constexpr int i = decltype(ic)::value;
+            grad[i] += jni * gn + jxi * gx;
+            if constexpr (kHess) {
+              T ui = A * jni + Bc * jxi, wi = Bc * jni + C * jxi;
+              ForChainCols<b>(p, cpx, cpz, [&](auto kc, T jnk, T jxk) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k >= i) H[TriIdx(i, k)] += ui * jnk + wi * jxk;
+              });
+            }
+          });
+        }
+      });
     }
-  });
+  }
   return mask;
 }
 
@@ -572,20 +596,22 @@ EPA_HD void CheetahLineEval(const CheetahModel<T>& m, const CheetahPos<T>& p,
       }
     }
   });
-  static_for<0, kNEnd>([&](auto ec) {
-    constexpr int e = decltype(ec)::value;
-    constexpr int b = EndBody(e);
+  EPA_NO_UNROLL
+  for (int e = 0; e < kNEnd; ++e) {
     T D = lds(e * kSlotsPerEnd + 4);
     if (D > T(0)) {
       T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
       T an = lds(e * kSlotsPerEnd + 2), ax = lds(e * kSlotsPerEnd + 3);
       T jna = T(0), jxa = T(0), jns = T(0), jxs = T(0);
-      ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
-        constexpr int j = decltype(jc)::value;
-        jna += jn * a[j];
-        jxa += jx * a[j];
-        jns += jn * s[j];
-        jxs += jx * s[j];
+      DispatchBody(EndBody(e), [&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
+          constexpr int j = decltype(jc)::value;
+          jna += jn * a[j];
+          jxa += jx * a[j];
+          jns += jn * s[j];
+          jxs += jx * s[j];
+        });
       });
       T jar1 = jna - an, jv1 = jns;
       T jar2 = jna - m.mu * jxa - (an + ax), jv2 = jns - m.mu * jxs;
@@ -604,7 +630,7 @@ EPA_HD void CheetahLineEval(const CheetahModel<T>& m, const CheetahPos<T>& p,
         *d2 += D * jv3 * jv3;
       }
     }
-  });
+  }
 }
 
 template <typename T>
@@ -629,6 +655,10 @@ EPA_HD int CheetahSolve(const CheetahModel<T>& m, const CheetahPos<T>& p,
     fs = x > fs ? x : fs;
   });
   const T gstop = cfg.gtol * (T(1) + fs);
+  // rounding floor: once the gradient is this small and has stopped shrinking
+  // the iterate is as converged as the arithmetic allows
+  const T gfloor = (sizeof(T) == 4 ? T(1e-4) : T(1e-9)) * (T(1) + fs);
+  T prev_gn = T(-1);
   unsigned long long prev_mask = ~0ull;
   bool full_step = false;
   int iter = 0;
@@ -647,6 +677,8 @@ EPA_HD int CheetahSolve(const CheetahModel<T>& m, const CheetahPos<T>& p,
     gn = Sqrt(gn);
     // finite termination: same active set after a full Newton step
     if (gn <= gstop || (full_step && mask == prev_mask)) break;
+    if (prev_gn >= T(0) && gn <= gfloor && gn >= T(0.25) * prev_gn) break;
+    prev_gn = gn;
     prev_mask = mask;
     T s[kNV];
     {
@@ -670,7 +702,7 @@ EPA_HD int CheetahSolve(const CheetahModel<T>& m, const CheetahPos<T>& p,
     T alpha = T(1), lo = T(0), hi = T(-1);
     full_step = false;
     const T ag1 = g1 < T(0) ? -g1 : g1;
-    const T ls_tol = (sizeof(T) == 4 ? T(1e-4) : T(1e-12)) * ag1;
+    const T ls_tol = (sizeof(T) == 4 ? T(1e-4) : T(1e-10)) * ag1;
     for (int ls = 0; ls < 24; ++ls) {
       T d1 = g1 + alpha * g2, d2 = g2;
       CheetahLineEval(m, p, lim, lds, qacc, s, alpha, &d1, &d2);

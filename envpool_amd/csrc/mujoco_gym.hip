@@ -33,6 +33,7 @@ struct CheetahDev {
   double* qpos;  // [9][N]
   double* qvel;  // [9][N]
   double* warm;  // [9][N]
+  int* iters;              // Newton iterations of the last step (profiling)
   double* nsaved;          // normal_distribution::_M_saved
   unsigned char* navail;   // normal_distribution::_M_saved_available
 };
@@ -51,6 +52,8 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
     CheetahDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action,
     OutPtrs out, CheetahModel<T> m, CheetahTask task,
     mj::SolverCfg<T> scfg) {
+  // per-contact constants [slot][lane]; read back with a runtime slot index in the
+  // solver passes (see DispatchBody) so they stay in LDS instead of VGPRs/scratch
   __shared__ T lds_buf[mj::kLdsSlots * kCheetahBlock];
   const int lane = threadIdx.x;
   const int n = cm.n;
@@ -108,9 +111,11 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
       ctrl[i] = (T)(ai < -1.0 ? -1.0 : (ai > 1.0 ? 1.0 : ai));
     });
     auto lds = [&](int slot) -> T& { return lds_buf[slot * kCheetahBlock + lane]; };
+    int iters = 0;
     for (int s = 0; s < task.frame_skip; ++s) {  // mujoco_env.h:142-144
-      mj::CheetahStep(m, scfg, q, v, w, ctrl, lds);
+      iters += mj::CheetahStep(m, scfg, q, v, w, ctrl, lds);
     }
+    dev.iters[e] = iters;
     const double x_after = x_before + (double)q[0];
     xv = (x_after - x_before) / task.dt;  // half_cheetah.h:148-149
     reward = static_cast<float>(xv * task.forward_reward_weight - ctrl_cost);
@@ -155,7 +160,7 @@ __global__ void CheetahGetState(CheetahDev dev, CommonDev cm, const int* ids,
     o[2 * kNV + j] = dev.warm[(size_t)j * n + e];
   }
   double* t = o + 3 * kNV;
-  t[0] = 0;
+  t[0] = dev.iters[e];  // (oracle: time) Newton iterations of the last step
   t[1] = 0;
   t[2] = 0;
   t[3] = cm.done[e];
@@ -216,6 +221,8 @@ class CheetahPool : public Pool {
     EPA_HIP(hipMalloc(&dev_.warm, sizeof(double) * kNV * n));
     EPA_HIP(hipMalloc(&dev_.nsaved, sizeof(double) * n));
     EPA_HIP(hipMalloc(&dev_.navail, n));
+    EPA_HIP(hipMalloc(&dev_.iters, sizeof(int) * n));
+    EPA_HIP(hipMemsetAsync(dev_.iters, 0, sizeof(int) * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.qpos, 0, sizeof(double) * kNV * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.qvel, 0, sizeof(double) * kNV * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.warm, 0, sizeof(double) * kNV * n, stream_));
@@ -229,6 +236,7 @@ class CheetahPool : public Pool {
     (void)hipFree(dev_.warm);
     (void)hipFree(dev_.nsaved);
     (void)hipFree(dev_.navail);
+    (void)hipFree(dev_.iters);
   }
   int StateDim() const override { return kCheetahStateDim; }
   void GetState(const int* d_ids, int k, double* d_out) override {

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Profiling recipe for the headline bench (run on the GPU box via gpurun).
+# Kernel trace and every PMC group are separate rocprofv3 runs (the guide:
+# FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2; never combine --pmc with tracing).
+#   usage: tools/profile_bench.sh <tag> [bench args...]
+set -u
+export TMPDIR=/tmp
+TAG=${1:-r1}; shift || true
+OUT=gpurun_out/prof_${TAG}
+mkdir -p "$OUT"
+ARGS="--steps 60 --warmup 10 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python bench.py $ARGS > "$OUT/trace.log" 2>&1
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM" \
+           "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE TCC_HIT TCC_MISS"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc$i" -o p -- python bench.py $ARGS > "$OUT/pmc$i.log" 2>&1
+done
+python tools/summarize_profile.py "$OUT" > "$OUT/summary.md" 2>&1
+cat "$OUT/summary.md"
