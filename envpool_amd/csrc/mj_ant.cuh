@@ -447,10 +447,8 @@ EPA_HD void ForChainCols(const AntPos<T>& p, Vec3<T> cp, F&& f) {
 }
 
 template <typename T>
-struct AntRows {
+struct AntRows {  // joint-limit rows (contacts are re-derived per pass, see below)
   T lim_sgn[kNU], lim_aref[kNU], lim_D[kNU];
-  // per sphere: contact point, normal/tangent reference terms, D (0 = inactive)
-  T cx[kNSph], cy[kNSph], cz[kNSph], an[kNSph], ay[kNSph], ax[kNSph], D[kNSph];
 };
 
 template <typename T>
@@ -476,36 +474,59 @@ EPA_HD void AntMakeConstraint(const AntModel<T>& m, const AntPos<T>& p, const T*
     r.lim_D[j] = sgn != T(0) ? T(1) / R : T(0);
     r.lim_aref[j] = -m.con_B * (sgn * v[6 + j]) - m.con_K * imp * dist;
   });
-  static_for<0, kNSph>([&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    constexpr int b = SphBody(s);
-    Vec3<T> w = p.pos[b] + Mul(p.R[b], Vec3<T>{m.sph[s][0], m.sph[s][1], m.sph[s][2]});
-    T dist = w.z - m.sph_r[s];
-    T D = T(0), an = T(0), ay = T(0), ax = T(0);
-    Vec3<T> cp = {w.x, w.y, T(0.5) * dist};
-    if (dist < m.margin) {
-      Vec3<T> vel = {T(0), T(0), T(0)};
-      ForChainCols<b>(p, cp, [&](auto jc, Vec3<T> col) {
-        vel = vel + col * v[decltype(jc)::value];
-      });
-      T rr = dist - m.margin;
-      T imp = Impedance(m.imp_d0, m.imp_dmax, m.imp_width, rr);
-      T diag = m.geom_body_invw[SphGeomBody(s)] * (T(1) + m.mu * m.mu);
-      T R = (T(1) - imp) * diag / imp;
-      R = R < kMinVal ? kMinVal : R;
-      D = T(1) / (T(2) * m.mu * m.mu * R);
-      an = -m.con_B * vel.z - m.con_K * imp * rr;
-      ay = m.con_B * m.mu * vel.y;
-      ax = m.con_B * m.mu * vel.x;
-    }
-    r.cx[s] = cp.x;
-    r.cy[s] = cp.y;
-    r.cz[s] = cp.z;
-    r.an[s] = an;
-    r.ay[s] = ay;
-    r.ax[s] = ax;
-    r.D[s] = D;
+}
+
+#if defined(__clang__)
+#define EPA_ANT_NO_UNROLL _Pragma("clang loop unroll(disable)")
+#else
+#define EPA_ANT_NO_UNROLL
+#endif
+// wave-uniform switch on the body a sphere is attached to
+template <typename F>
+EPA_HD void DispatchBody(int b, F&& f) {
+  switch (b) {
+    case 0: f(IC<0>{}); break;
+    case 1: f(IC<1>{}); break;
+    case 2: f(IC<2>{}); break;
+    case 3: f(IC<3>{}); break;
+    case 4: f(IC<4>{}); break;
+    case 5: f(IC<5>{}); break;
+    case 6: f(IC<6>{}); break;
+    case 7: f(IC<7>{}); break;
+    default: f(IC<8>{}); break;
+  }
+}
+
+// One contact candidate (end sphere s on body B), re-derived from the body
+// pose each time it is needed instead of being stored: mj_collision
+// (plane-sphere) + mj_instantiateContact + mj_makeImpedance for that sphere.
+// Returns false when the sphere is outside the margin.
+template <typename T>
+struct AntContact {
+  Vec3<T> cp;
+  T an, ay, ax, D;
+};
+template <int B, typename T>
+EPA_HD bool AntMakeContact(const AntModel<T>& m, const AntPos<T>& p, const T* v, int s,
+                           AntContact<T>& c) {
+  Vec3<T> w = p.pos[B] + Mul(p.R[B], Vec3<T>{m.sph[s][0], m.sph[s][1], m.sph[s][2]});
+  T dist = w.z - m.sph_r[s];
+  if (!(dist < m.margin)) return false;
+  c.cp = {w.x, w.y, T(0.5) * dist};
+  Vec3<T> vel = {T(0), T(0), T(0)};
+  ForChainCols<B>(p, c.cp, [&](auto jc, Vec3<T> col) {
+    vel = vel + col * v[decltype(jc)::value];
   });
+  T rr = dist - m.margin;
+  T imp = Impedance(m.imp_d0, m.imp_dmax, m.imp_width, rr);
+  T diag = m.geom_body_invw[SphGeomBody(s)] * (T(1) + m.mu * m.mu);
+  T R = (T(1) - imp) * diag / imp;
+  R = R < T(1e-15) ? T(1e-15) : R;
+  c.D = T(1) / (T(2) * m.mu * m.mu * R);
+  c.an = -m.con_B * vel.z - m.con_K * imp * rr;
+  c.ay = m.con_B * m.mu * vel.y;
+  c.ax = m.con_B * m.mu * vel.x;
+  return true;
 }
 
 // the four pyramidal rows of a contact in terms of (jx, jy, jz) = J a:
@@ -521,7 +542,7 @@ EPA_HD void ContactJar(const AntModel<T>& m, Vec3<T> ja, T an, T ay, T ax, T* ja
 
 template <bool kHess, typename T>
 EPA_HD void AntRowsPass(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& r,
-                        const T* a, T* grad, T* H, unsigned long long* mask0,
+                        const T* v, const T* a, T* grad, T* H, unsigned long long* mask0,
                         unsigned long long* mask1) {
   unsigned long long m0 = 0, m1 = 0;
   static_for<0, kNU>([&](auto jc) {
@@ -535,64 +556,62 @@ EPA_HD void AntRowsPass(const AntModel<T>& m, const AntPos<T>& p, const AntRows<
       }
     }
   });
-  static_for<0, kNSph>([&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    constexpr int b = SphBody(s);
-    T D = r.D[s];
-    if (D > T(0)) {
-      Vec3<T> cp = {r.cx[s], r.cy[s], r.cz[s]};
+  EPA_ANT_NO_UNROLL
+  for (int s = 0; s < kNSph; ++s) {
+    DispatchBody(SphBody(s), [&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      AntContact<T> c;
+      if (!AntMakeContact<b>(m, p, v, s, c)) return;
       Vec3<T> ja = {T(0), T(0), T(0)};
-      ForChainCols<b>(p, cp, [&](auto jc, Vec3<T> col) {
+      ForChainCols<b>(p, c.cp, [&](auto jc, Vec3<T> col) {
         ja = ja + col * a[decltype(jc)::value];
       });
       T jar[4];
-      ContactJar(m, ja, r.an[s], r.ay[s], r.ax[s], jar);
+      ContactJar(m, ja, c.an, c.ay, c.ax, jar);
       T w[4];
       static_for<0, 4>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        w[k] = jar[k] < T(0) ? D : T(0);
+        w[k] = jar[k] < T(0) ? c.D : T(0);
         if (jar[k] < T(0)) {
-          if constexpr (8 + 4 * s + k < 64) {
-            m0 |= 1ull << (8 + 4 * s + k);
+          int bit = 8 + 4 * s + k;
+          if (bit < 64) {
+            m0 |= 1ull << bit;
           } else {
-            m1 |= 1ull << (8 + 4 * s + k - 64);
+            m1 |= 1ull << (bit - 64);
           }
         }
       });
       T wsum = w[0] + w[1] + w[2] + w[3];
       if (wsum > T(0)) {
-        // gradient in contact space: g = sum_r w_r jar_r * (row coefficients)
         T gz = w[0] * jar[0] + w[1] * jar[1] + w[2] * jar[2] + w[3] * jar[3];
         T gy = m.mu * (w[0] * jar[0] - w[1] * jar[1]);
         T gx = m.mu * (w[3] * jar[3] - w[2] * jar[2]);
-        // Hessian in contact space (symmetric 3x3 over x,y,z)
         T hzz = wsum;
         T hyy = m.mu * m.mu * (w[0] + w[1]), hxx = m.mu * m.mu * (w[2] + w[3]);
         T hzy = m.mu * (w[0] - w[1]), hzx = m.mu * (w[3] - w[2]);
-        ForChainCols<b>(p, cp, [&](auto ic, Vec3<T> ci) {
+        ForChainCols<b>(p, c.cp, [&](auto ic, Vec3<T> ci) {
           constexpr int i = decltype(ic)::value;
           grad[i] += ci.x * gx + ci.y * gy + ci.z * gz;
           if constexpr (kHess) {
-            // u = Hc * ci
             T ux = hxx * ci.x + hzx * ci.z;
             T uy = hyy * ci.y + hzy * ci.z;
             T uz = hzx * ci.x + hzy * ci.y + hzz * ci.z;
-            ForChainCols<b>(p, cp, [&](auto kc2, Vec3<T> ck) {
+            ForChainCols<b>(p, c.cp, [&](auto kc2, Vec3<T> ck) {
               constexpr int k = decltype(kc2)::value;
               if constexpr (k >= i) H[Tri(i, k)] += ux * ck.x + uy * ck.y + uz * ck.z;
             });
           }
         });
       }
-    }
-  });
+    });
+  }
   *mask0 = m0;
   *mask1 = m1;
 }
 
 template <typename T>
 EPA_HD void AntLineEval(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& r,
-                        const T* a, const T* s, T alpha, T* d1, T* d2) {
+                        const T* v, const T* a, const T* s, T alpha, T* d1, T* d2) {
   static_for<0, kNU>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     if (r.lim_sgn[j] != T(0)) {
@@ -605,36 +624,36 @@ EPA_HD void AntLineEval(const AntModel<T>& m, const AntPos<T>& p, const AntRows<
       }
     }
   });
-  static_for<0, kNSph>([&](auto sc) {
-    constexpr int sidx = decltype(sc)::value;
-    constexpr int b = SphBody(sidx);
-    T D = r.D[sidx];
-    if (D > T(0)) {
-      Vec3<T> cp = {r.cx[sidx], r.cy[sidx], r.cz[sidx]};
+  EPA_ANT_NO_UNROLL
+  for (int sidx = 0; sidx < kNSph; ++sidx) {
+    DispatchBody(SphBody(sidx), [&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      AntContact<T> c;
+      if (!AntMakeContact<b>(m, p, v, sidx, c)) return;
       Vec3<T> ja = {T(0), T(0), T(0)}, js = {T(0), T(0), T(0)};
-      ForChainCols<b>(p, cp, [&](auto jc, Vec3<T> col) {
+      ForChainCols<b>(p, c.cp, [&](auto jc, Vec3<T> col) {
         ja = ja + col * a[decltype(jc)::value];
         js = js + col * s[decltype(jc)::value];
       });
       T jar[4];
-      ContactJar(m, ja, r.an[sidx], r.ay[sidx], r.ax[sidx], jar);
+      ContactJar(m, ja, c.an, c.ay, c.ax, jar);
       T jv[4] = {js.z + m.mu * js.y, js.z - m.mu * js.y, js.z - m.mu * js.x,
                  js.z + m.mu * js.x};
       static_for<0, 4>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         T x = jar[k] + alpha * jv[k];
         if (x < T(0)) {
-          *d1 += D * x * jv[k];
-          *d2 += D * jv[k] * jv[k];
+          *d1 += c.D * x * jv[k];
+          *d2 += c.D * jv[k] * jv[k];
         }
       });
-    }
-  });
+    });
+  }
 }
 
 template <typename T>
 EPA_HD int AntSolve(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& r,
-                    const T* qfrc_smooth, const SolverCfg<T>& cfg, T* qacc) {
+                    const T* v, const T* qfrc_smooth, const SolverCfg<T>& cfg, T* qacc) {
   T fs = T(0);
   static_for<0, kNV>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -656,7 +675,7 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& 
       grad[i] = Ma[i] - qfrc_smooth[i];
     });
     unsigned long long m0, m1;
-    AntRowsPass<true>(m, p, r, qacc, grad, H, &m0, &m1);
+    AntRowsPass<true>(m, p, r, v, qacc, grad, H, &m0, &m1);
     T gn = T(0);
     static_for<0, kNV>([&](auto ic) { gn += grad[decltype(ic)::value] * grad[decltype(ic)::value]; });
     gn = Sqrt(gn);
@@ -683,7 +702,7 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& 
     const T ls_tol = (sizeof(T) == 4 ? T(1e-4) : T(1e-10)) * ag1;
     for (int ls = 0; ls < 24; ++ls) {
       T d1 = g1 + alpha * g2, d2 = g2;
-      AntLineEval(m, p, r, qacc, s, alpha, &d1, &d2);
+      AntLineEval(m, p, r, v, qacc, s, alpha, &d1, &d2);
       T ad1 = d1 < T(0) ? -d1 : d1;
       if (ad1 <= ls_tol) {
         full_step = ls == 0;
@@ -720,7 +739,7 @@ EPA_HD int AntForward(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, const
   AntRows<T> rows;
   AntMakeConstraint(m, p, q, v, rows);
   static_for<0, kNV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
-  int it = AntSolve(m, p, rows, qfrc_smooth, cfg, qacc);
+  int it = AntSolve(m, p, rows, v, qfrc_smooth, cfg, qacc);
   static_for<0, kNV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
   return it;
 }
