@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--task", default="HalfCheetah")
     ap.add_argument("--precision", default="fp64", choices=["fp32", "fp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allgather", action="store_true",
+                    help="also all-gather the obs batch over RCCL every step (optional "
+                         "exchange of SURVEY §8e; off by default: the path needs no collective)")
     args = ap.parse_args()
 
     import torch
@@ -84,9 +87,23 @@ def main():
             for _ in range(16)]
     torch.cuda.synchronize()
 
+    obs_index = [k for k, _, _ in pool.state_keys].index("obs")
+    obs_shape = pool.state_keys[obs_index][2]
+    pool_stream = torch.cuda.ExternalStream(pool.stream, device=dev)
+    gathered = None
+    if args.allgather and world > 1:
+        gathered = torch.empty((world * n, *obs_shape), device=dev, dtype=torch.float64)
+
     def step(i):
         pool.send_device(ring[i % 16].data_ptr())
-        pool.recv_device()  # outputs stay on the device
+        ptrs, k = pool.recv_device()  # outputs stay on the device
+        if gathered is not None:
+            from envpool_amd.torch_interop import _DevArray
+
+            local = torch.as_tensor(_DevArray(ptrs[obs_index], (k, *obs_shape), np.float64),
+                                    device=dev)
+            with torch.cuda.stream(pool_stream):  # ordered after the step kernel
+                dist.all_gather_into_tensor(gathered, local)
 
     pool.send_device(None)  # reset all (first step of every env is a reset anyway)
     pool.recv_device()
@@ -119,6 +136,26 @@ def main():
         alg_bytes = {"HalfCheetah": 708, "Ant": 1132}[args.task]
         # counted fp32 flops / env-step from the kernel's ISA
         achieved_gbs = alg_bytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # HBM traffic and flop counts come from the committed rocprofv3 PMC passes of
+        # this same command (tools/profile_bench.sh -> profiles/r1_pmc.json): PMC
+        # collection needs its own rocprofv3 runs and cannot happen inside the bench.
+        kname = ("CheetahStepKernel" if args.task == "HalfCheetah" else "AntStepKernel") + \
+            ("<double>" if args.precision == "fp64" else "<float>")
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc.json")) as f:
+                pmc = json.load(f).get(kname, {})
+        except OSError:
+            pass
+        traffic = None
+        valu = None
+        if pmc and pmc.get("num_envs") == n:
+            traffic = pmc["traffic_bytes_per_launch"]
+            peak_tf = 78.6 if args.precision == "fp64" else 157.3
+            tf = pmc["flops_per_launch"] / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+            valu = {"achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf,
+                    "flops_per_env_step": pmc["flops_per_env_step"],
+                    "note": "fp VALU issue is the roofline that binds this kernel"}
         out = {
             "metric": f"env steps/sec (raw FPS) at num_envs={n}, {args.task}-v4",
             "value": value,
@@ -145,7 +182,8 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": achieved_gbs / 8000.0,
-                "traffic": None,
+                "traffic": traffic,
+                "valu": valu,
                 "kernel": "CheetahStepKernel" if args.task == "HalfCheetah" else "AntStepKernel",
                 "kernel_ms": kernel_ms,
                 "launches": launches,

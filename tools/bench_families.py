@@ -1,0 +1,107 @@
+"""Per-family kernel throughput vs the roofline that binds it.
+
+For every env family on the hot path: device-resident random actions, K timed
+steps of all N envs through epa_send_device/epa_recv_device, kernel time from
+HIP events on the pool's stream.  HBM-streaming families (classic_control,
+toy_text, Atari post-process) report achieved algorithmic GB/s against the
+8 TB/s HBM peak; the MuJoCo kernels are VALU-bound and report env-steps/s.
+Prints one JSON line per family and a markdown table (-> profiles/).
+"""
+import argparse
+import json
+import sys
+import os
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+# family, params, max_episode_steps, action kind, algorithmic bytes / env-step
+FAMILIES = [
+    ("CartPole", {}, 500, ("int", 2), 128),
+    ("Pendulum", {"version": 1}, 200, ("float", 2.0), 92),
+    ("MountainCar", {}, 200, ("int", 3), 96),
+    ("MountainCarContinuous", {}, 999, ("float", 1.0), 96),
+    ("Acrobot", {}, 500, ("int", 3), 144),
+    ("Catch", {"height": 10, "width": 5}, 0, ("int", 3), 12 + 26 + 200 + 2 * 9),
+    ("FrozenLake", {"size": 8}, 200, ("int", 4), 72),
+    ("Taxi", {}, 200, ("int", 6), 72),
+    ("NChain", {}, 1000, ("int", 2), 72),
+    ("CliffWalking", {"is_slippery": 1}, 0, ("int", 4), 76),
+    ("Blackjack", {}, 0, ("int", 2), 84),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num-envs", type=int, default=65536)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--big", type=int, default=1 << 22, help="also run at this N (HBM-resident)")
+    args = ap.parse_args()
+    import torch
+
+    from envpool_amd.core.device_pool import DevicePool
+    from envpool_amd.atari import AtariPostProcess
+
+    dev = torch.device("cuda", 0)
+    rows = []
+    for n in (args.num_envs, args.big):
+        for fam, params, max_steps, (kind, p), alg in FAMILIES:
+            pool = DevicePool(fam, n, seed=0, max_episode_steps=max_steps, params=params)
+            if kind == "int":
+                ring = [torch.randint(0, p, (n,), device=dev, dtype=torch.int32) for _ in range(8)]
+            else:
+                ring = [(torch.rand((n, 1), device=dev) * 2 - 1) * p for _ in range(8)]
+            torch.cuda.synchronize()
+            pool.send_device(None)
+            pool.recv_device()
+            for i in range(10):
+                pool.send_device(ring[i % 8].data_ptr())
+                pool.recv_device()
+            pool.synchronize()
+            pool.set_timing(True)
+            for i in range(args.steps):
+                pool.send_device(ring[i % 8].data_ptr())
+                pool.recv_device()
+            ms, launches = pool.kernel_time_ms()
+            gbs = alg * n / (ms * 1e-3) / 1e9
+            rec = {"family": fam, "num_envs": n, "kernel_us": ms * 1e3, "launches": launches,
+                   "env_steps_per_s": n / (ms * 1e-3), "algorithmic_bytes": alg,
+                   "achieved_GBps": gbs, "hbm_frac": gbs / 8000.0}
+            rows.append(rec)
+            print(json.dumps(rec))
+            pool.close()
+    # Atari post-process (K4): frames resident on the device
+    for n in (1024, 16384):
+        post = AtariPostProcess(n)
+        frames = torch.randint(0, 256, (n, 2, 210, 160), device=dev, dtype=torch.uint8)
+        obs = torch.empty((n, 4, 84, 84), device=dev, dtype=torch.uint8)
+        torch.cuda.synchronize()
+        stream = torch.cuda.ExternalStream(post.stream, device=dev)
+        for _ in range(5):
+            post.push_device(frames.data_ptr(), obs.data_ptr(), n)
+        stream.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(stream):
+            t0.record()
+            for _ in range(50):
+                post.push_device(frames.data_ptr(), obs.data_ptr(), n)
+            t1.record()
+        stream.synchronize()
+        ms = t0.elapsed_time(t1) / 50
+        alg = 2 * 33600 + 3 * 7056 + 7056 + 4 * 7056
+        gbs = alg * n / (ms * 1e-3) / 1e9
+        rec = {"family": "AtariPostProcess", "num_envs": n, "kernel_us": ms * 1e3, "launches": 50,
+               "env_steps_per_s": n / (ms * 1e-3), "algorithmic_bytes": alg,
+               "achieved_GBps": gbs, "hbm_frac": gbs / 8000.0}
+        rows.append(rec)
+        print(json.dumps(rec))
+    print("\n| family | N | kernel us | env-steps/s | alg B/step | GB/s | frac of 8 TB/s |")
+    print("|---|---|---|---|---|---|---|")
+    for r in rows:
+        print(f"| {r['family']} | {r['num_envs']} | {r['kernel_us']:.1f} | {r['env_steps_per_s']:.3g} | "
+              f"{r['algorithmic_bytes']} | {r['achieved_GBps']:.0f} | {r['hbm_frac']:.3f} |")
+
+
+if __name__ == "__main__":
+    main()
