@@ -430,20 +430,66 @@ EPA_HD void AntSmoothForces(const AntModel<T>& m, const AntPos<T>& p, const T* v
   });
 }
 
+// Everything the constraint passes need from a forward pass, 60 numbers instead
+// of the full AntPos (27 + 81 + 66 + ...): joint anchors are body origins, every
+// capsule end sphere sits on a body origin (stub: torso -> aux, leg: aux -> foot)
+// except the four foot tips, and a Jacobian column is axis x (point - anchor).
+template <typename T>
+struct AntGeo {
+  Vec3<T> pos[kNB];       // body origins = hinge anchors
+  Vec3<T> tip[kNLeg];     // far end of the ankle capsules
+  Vec3<T> rot[3];         // torso body axes (free-joint rotational dofs); rot[2] = hip axis
+  Vec3<T> ankle[kNLeg];   // ankle axes in the world
+};
+
+template <typename T>
+EPA_HD void AntMakeGeo(const AntModel<T>& m, const AntPos<T>& p, AntGeo<T>& g) {
+  static_for<0, kNB>([&](auto bc) { g.pos[decltype(bc)::value] = p.pos[decltype(bc)::value]; });
+  static_for<0, 3>([&](auto kc) { g.rot[decltype(kc)::value] = p.cdof[3 + decltype(kc)::value].a; });
+  static_for<0, kNLeg>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    constexpr int s = 1 + 6 * l + 4;  // "+axis" end of the ankle capsule
+    g.tip[l] = p.pos[Foot(l)] + Mul(p.R[Foot(l)], Vec3<T>{m.sph[s][0], m.sph[s][1], m.sph[s][2]});
+    g.ankle[l] = p.cdof[Ankle(l)].a;
+  });
+}
+
+// world centre of end sphere s (runtime, wave uniform) known to sit on body B
+template <int B, typename T>
+EPA_HD Vec3<T> SphCenter(const AntGeo<T>& g, int s) {
+  const int l = (s - 1) / 6, w = (s - 1) % 6;
+  if constexpr (B == 0) {
+    if (s == 0 || w == 1) return g.pos[0];
+    Vec3<T> c = g.pos[Aux(0)];
+    if (l == 1) c = g.pos[Aux(1)];
+    if (l == 2) c = g.pos[Aux(2)];
+    if (l == 3) c = g.pos[Aux(3)];
+    return c;
+  } else if constexpr ((B & 1) == 1) {  // aux_l: leg capsule aux -> foot
+    return w == 2 ? g.pos[B + 1] : g.pos[B];
+  } else {  // foot_l: ankle capsule foot -> tip
+    return w == 4 ? g.tip[(B - 2) / 2] : g.pos[B];
+  }
+}
+
 // columns of the point Jacobian (3 x nv) of `cp` attached to body B:
 // f(j, col) for every chain dof j with col = d(point velocity)/d(qdot_j).
 template <int B, typename T, typename F>
-EPA_HD void ForChainCols(const AntPos<T>& p, Vec3<T> cp, F&& f) {
+EPA_HD void ForChainCols(const AntGeo<T>& g, Vec3<T> cp, F&& f) {
   f(IC<0>{}, Vec3<T>{T(1), T(0), T(0)});
   f(IC<1>{}, Vec3<T>{T(0), T(1), T(0)});
   f(IC<2>{}, Vec3<T>{T(0), T(0), T(1)});
-  static_for<3, kNV>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    if constexpr (InChain(j, B)) {
-      // cdof about the COM: v(point) = lin + ang x (cp - com)
-      f(jc, p.cdof[j].l + Cross(p.cdof[j].a, cp - p.com));
-    }
+  static_for<0, 3>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    f(IC<3 + k>{}, Cross(g.rot[k], cp - g.pos[0]));
   });
+  if constexpr (B > 0) {
+    constexpr int l = (B - 1) / 2;
+    f(IC<Hip(l)>{}, Cross(g.rot[2], cp - g.pos[Aux(l)]));
+    if constexpr (B == Foot(l)) {
+      f(IC<Ankle(l)>{}, Cross(g.ankle[l], cp - g.pos[Foot(l)]));
+    }
+  }
 }
 
 template <typename T>
@@ -507,9 +553,9 @@ struct AntContact {
   T an, ay, ax, D;
 };
 template <int B, typename T>
-EPA_HD bool AntMakeContact(const AntModel<T>& m, const AntPos<T>& p, const T* v, int s,
+EPA_HD bool AntMakeContact(const AntModel<T>& m, const AntGeo<T>& p, const T* v, int s,
                            AntContact<T>& c) {
-  Vec3<T> w = p.pos[B] + Mul(p.R[B], Vec3<T>{m.sph[s][0], m.sph[s][1], m.sph[s][2]});
+  Vec3<T> w = SphCenter<B>(p, s);
   T dist = w.z - m.sph_r[s];
   if (!(dist < m.margin)) return false;
   c.cp = {w.x, w.y, T(0.5) * dist};
@@ -541,7 +587,7 @@ EPA_HD void ContactJar(const AntModel<T>& m, Vec3<T> ja, T an, T ay, T ax, T* ja
 }
 
 template <bool kHess, typename T>
-EPA_HD void AntRowsPass(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& r,
+EPA_HD void AntRowsPass(const AntModel<T>& m, const AntGeo<T>& p, const AntRows<T>& r,
                         const T* v, const T* a, T* grad, T* H, unsigned long long* mask0,
                         unsigned long long* mask1) {
   unsigned long long m0 = 0, m1 = 0;
@@ -610,7 +656,7 @@ EPA_HD void AntRowsPass(const AntModel<T>& m, const AntPos<T>& p, const AntRows<
 }
 
 template <typename T>
-EPA_HD void AntLineEval(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& r,
+EPA_HD void AntLineEval(const AntModel<T>& m, const AntGeo<T>& p, const AntRows<T>& r,
                         const T* v, const T* a, const T* s, T alpha, T* d1, T* d2) {
   static_for<0, kNU>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
@@ -652,8 +698,9 @@ EPA_HD void AntLineEval(const AntModel<T>& m, const AntPos<T>& p, const AntRows<
 }
 
 template <typename T>
-EPA_HD int AntSolve(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& r,
-                    const T* v, const T* qfrc_smooth, const SolverCfg<T>& cfg, T* qacc) {
+EPA_HD int AntSolve(const AntModel<T>& m, const AntGeo<T>& p, const T* M,
+                    const AntRows<T>& r, const T* v, const T* qfrc_smooth,
+                    const SolverCfg<T>& cfg, T* qacc) {
   T fs = T(0);
   static_for<0, kNV>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -668,8 +715,8 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& 
   int iter = 0;
   for (; iter < cfg.max_iter; ++iter) {
     T H[kTri], Ma[kNV], grad[kNV];
-    static_for<0, kTri>([&](auto kc) { H[decltype(kc)::value] = p.M[decltype(kc)::value]; });
-    SymMul(p.M, qacc, Ma);
+    static_for<0, kTri>([&](auto kc) { H[decltype(kc)::value] = M[decltype(kc)::value]; });
+    SymMul(M, qacc, Ma);
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       grad[i] = Ma[i] - qfrc_smooth[i];
@@ -689,7 +736,7 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& 
     FactorUUt(H);
     SolveUUt(H, s);
     T Ms[kNV];
-    SymMul(p.M, s, Ms);
+    SymMul(M, s, Ms);
     T g1 = T(0), g2 = T(0);
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
@@ -732,14 +779,19 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntPos<T>& p, const AntRows<T>& 
 template <typename T>
 EPA_HD int AntForward(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, const T* v,
                       const T* ctrl, T* warm, T* qacc) {
-  AntPos<T> p;
-  AntKinematics(m, q, p);
-  T qfrc_smooth[kNV];
-  AntSmoothForces(m, p, v, ctrl, qfrc_smooth);
+  T qfrc_smooth[kNV], M[kTri];
+  AntGeo<T> geo;
   AntRows<T> rows;
-  AntMakeConstraint(m, p, q, v, rows);
+  {
+    AntPos<T> p;  // full kinematics only lives until the solver starts
+    AntKinematics(m, q, p);
+    AntSmoothForces(m, p, v, ctrl, qfrc_smooth);
+    AntMakeConstraint(m, p, q, v, rows);
+    AntMakeGeo(m, p, geo);
+    static_for<0, kTri>([&](auto kc) { M[decltype(kc)::value] = p.M[decltype(kc)::value]; });
+  }
   static_for<0, kNV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
-  int it = AntSolve(m, p, rows, v, qfrc_smooth, cfg, qacc);
+  int it = AntSolve(m, geo, M, rows, v, qfrc_smooth, cfg, qacc);
   static_for<0, kNV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
   return it;
 }

@@ -147,6 +147,8 @@ inline AntModel<double> BuildAntModel() {
     for (int rr = 0; rr < kNV; ++rr) Minv[rr][c] = e[rr];
   }
   for (int j = 0; j < kNU; ++j) m.dof_invw[j] = Minv[6 + j][6 + j];
+  AntGeo<double> geo;
+  AntMakeGeo(m, p, geo);
   // body_invweight0 (translational) of the 13 geom-carrying MuJoCo bodies
   for (int g = 0; g < kNGeomBody; ++g) {
     int body;           // dynamic body the MuJoCo body is attached to
@@ -171,15 +173,15 @@ inline AntModel<double> BuildAntModel() {
       J[2][j] = col.z;
     };
     switch (body) {
-      case 0: ForChainCols<0>(p, P, fill); break;
-      case 1: ForChainCols<1>(p, P, fill); break;
-      case 2: ForChainCols<2>(p, P, fill); break;
-      case 3: ForChainCols<3>(p, P, fill); break;
-      case 4: ForChainCols<4>(p, P, fill); break;
-      case 5: ForChainCols<5>(p, P, fill); break;
-      case 6: ForChainCols<6>(p, P, fill); break;
-      case 7: ForChainCols<7>(p, P, fill); break;
-      default: ForChainCols<8>(p, P, fill); break;
+      case 0: ForChainCols<0>(geo, P, fill); break;
+      case 1: ForChainCols<1>(geo, P, fill); break;
+      case 2: ForChainCols<2>(geo, P, fill); break;
+      case 3: ForChainCols<3>(geo, P, fill); break;
+      case 4: ForChainCols<4>(geo, P, fill); break;
+      case 5: ForChainCols<5>(geo, P, fill); break;
+      case 6: ForChainCols<6>(geo, P, fill); break;
+      case 7: ForChainCols<7>(geo, P, fill); break;
+      default: ForChainCols<8>(geo, P, fill); break;
     }
     double tr = 0;
     for (int rr = 0; rr < 3; ++rr) {
