@@ -200,6 +200,11 @@ def make_native_classes(fd: FamilyDef) -> tuple[type, type]:
                     )
             self._conf = conf
             self._config_values = tuple(conf[k] for k in config_keys)
+            # like EnvSpec's ctor (env_spec.h:70-74) the specs are built -- and
+            # their arguments validated -- at construction time
+            fd.state_spec(conf)
+            fd.action_spec(conf)
+            fd.native_params(conf)
 
         @property
         def _state_spec(self) -> tuple:

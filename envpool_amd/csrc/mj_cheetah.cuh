@@ -172,6 +172,8 @@ EPA_HD T Impedance(T d0, T dmax, T width, T r) {
   return d0 + y * (dmax - d0);
 }
 
+// (Kept on: with fp32 factorisations the Newton loop stalls at its iteration cap
+// on a few percent of the envs - 10x slower kernel, failing parity.)
 // Wider type for the two ill-conditioned 9x9 solves per Newton iteration when
 // the kernel runs in fp32 (cond(H) ~ 1e4: light feet vs 14 kg trunk): the
 // factorisation and substitutions are ~5% of the flops, doing them in fp64
@@ -431,6 +433,10 @@ EPA_HD void ForChainCols(const CheetahPos<T>& p, T cpx, T cpz, F&& f) {
 // keeps the per-contact constants in LDS (dynamic slot index => real ds_read,
 // no store-to-load forwarding into long-lived VGPRs) and emits the Jacobian
 // code once per body instead of once per end sphere.
+// NOTE (ROCm 7.2 / gfx950): the switch must be the OUTERMOST construct of the
+// loop body.  Nested under the lane-divergent `if (D > 0)` the fp64 kernel
+// (512 VGPR+AGPR, spills) produced run-to-run different results; with the
+// uniform switch outside and the divergence inside each case it is bit-stable.
 #if defined(__clang__)
 #define EPA_NO_UNROLL _Pragma("clang loop unroll(disable)")
 #else
@@ -535,12 +541,13 @@ EPA_HD unsigned long long CheetahRowsPass(const CheetahModel<T>& m,
   });
   EPA_NO_UNROLL
   for (int e = 0; e < kNEnd; ++e) {
-    T D = lds(e * kSlotsPerEnd + 4);
-    if (D > T(0)) {
-      T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
-      T an = lds(e * kSlotsPerEnd + 2), ax = lds(e * kSlotsPerEnd + 3);
-      DispatchBody(EndBody(e), [&](auto bc) {
-        constexpr int b = decltype(bc)::value;
+    // wave-uniform switch outermost (scalar branch), lane divergence inside
+    DispatchBody(EndBody(e), [&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      T D = lds(e * kSlotsPerEnd + 4);
+      if (D > T(0)) {
+        T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
+        T an = lds(e * kSlotsPerEnd + 2), ax = lds(e * kSlotsPerEnd + 3);
         T jna = T(0), jxa = T(0);
         ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
           constexpr int j = decltype(jc)::value;
@@ -573,8 +580,8 @@ EPA_HD unsigned long long CheetahRowsPass(const CheetahModel<T>& m,
             }
           });
         }
-      });
-    }
+      }
+    });
   }
   return mask;
 }
@@ -598,13 +605,13 @@ EPA_HD void CheetahLineEval(const CheetahModel<T>& m, const CheetahPos<T>& p,
   });
   EPA_NO_UNROLL
   for (int e = 0; e < kNEnd; ++e) {
-    T D = lds(e * kSlotsPerEnd + 4);
-    if (D > T(0)) {
-      T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
-      T an = lds(e * kSlotsPerEnd + 2), ax = lds(e * kSlotsPerEnd + 3);
-      T jna = T(0), jxa = T(0), jns = T(0), jxs = T(0);
-      DispatchBody(EndBody(e), [&](auto bc) {
-        constexpr int b = decltype(bc)::value;
+    DispatchBody(EndBody(e), [&](auto bc) {  // wave-uniform switch outermost
+      constexpr int b = decltype(bc)::value;
+      T D = lds(e * kSlotsPerEnd + 4);
+      if (D > T(0)) {
+        T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
+        T an = lds(e * kSlotsPerEnd + 2), ax = lds(e * kSlotsPerEnd + 3);
+        T jna = T(0), jxa = T(0), jns = T(0), jxs = T(0);
         ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
           constexpr int j = decltype(jc)::value;
           jna += jn * a[j];
@@ -612,24 +619,24 @@ EPA_HD void CheetahLineEval(const CheetahModel<T>& m, const CheetahPos<T>& p,
           jns += jn * s[j];
           jxs += jx * s[j];
         });
-      });
-      T jar1 = jna - an, jv1 = jns;
-      T jar2 = jna - m.mu * jxa - (an + ax), jv2 = jns - m.mu * jxs;
-      T jar3 = jna + m.mu * jxa - (an - ax), jv3 = jns + m.mu * jxs;
-      T x1 = jar1 + alpha * jv1, x2 = jar2 + alpha * jv2, x3 = jar3 + alpha * jv3;
-      if (x1 < T(0)) {
-        *d1 += T(2) * D * x1 * jv1;
-        *d2 += T(2) * D * jv1 * jv1;
+        T jar1 = jna - an, jv1 = jns;
+        T jar2 = jna - m.mu * jxa - (an + ax), jv2 = jns - m.mu * jxs;
+        T jar3 = jna + m.mu * jxa - (an - ax), jv3 = jns + m.mu * jxs;
+        T x1 = jar1 + alpha * jv1, x2 = jar2 + alpha * jv2, x3 = jar3 + alpha * jv3;
+        if (x1 < T(0)) {
+          *d1 += T(2) * D * x1 * jv1;
+          *d2 += T(2) * D * jv1 * jv1;
+        }
+        if (x2 < T(0)) {
+          *d1 += D * x2 * jv2;
+          *d2 += D * jv2 * jv2;
+        }
+        if (x3 < T(0)) {
+          *d1 += D * x3 * jv3;
+          *d2 += D * jv3 * jv3;
+        }
       }
-      if (x2 < T(0)) {
-        *d1 += D * x2 * jv2;
-        *d2 += D * jv2 * jv2;
-      }
-      if (x3 < T(0)) {
-        *d1 += D * x3 * jv3;
-        *d2 += D * jv3 * jv3;
-      }
-    }
+    });
   }
 }
 

@@ -28,10 +28,11 @@ struct AntDev {
   double* lag;   // [2][N]
   double* nsaved;
   unsigned char* navail;
+  double* stack;  // [N][frame_stack * nobs] obs ring (frame_stack > 1 only)
 };
 
 struct AntTask {
-  int frame_skip, obs_skip;
+  int frame_skip, obs_skip, frame_stack;
   int terminate_when_unhealthy, legacy_healthy_reward;
   double ctrl_cost_weight, forward_reward_weight, healthy_reward;
   double healthy_z_min, healthy_z_max, reset_noise_scale, dt;
@@ -150,9 +151,30 @@ __global__ __launch_bounds__(kAntBlock) void AntStepKernel(
   cm.cur_step[e] = cur;
   // WriteState, ant.h:231-278
   const int nobs = A::kNQ + A::kNV - task.obs_skip;
-  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
-  for (int i = task.obs_skip; i < A::kNQ; ++i) *(obs++) = qpos[i];
-  for (int i = 0; i < A::kNV; ++i) *(obs++) = qvel[i];
+  const int S = task.frame_stack;
+  double* obs0 = (double*)out.p[kKeyEnv0] + (size_t)row * nobs * S;
+  double* newest = obs0 + (size_t)(S - 1) * nobs;
+  {
+    double* obs = newest;
+    for (int i = task.obs_skip; i < A::kNQ; ++i) *(obs++) = qpos[i];
+    for (int i = 0; i < A::kNV; ++i) *(obs++) = qvel[i];
+  }
+  if (S > 1) {  // FrameStackBuffer::Commit, envpool/mujoco/frame_stack.h:109-135
+    double* st = dev.stack + (size_t)e * S * nobs;
+    if (reset) {
+      for (int f = 0; f < S - 1; ++f) {
+        for (int i = 0; i < nobs; ++i) obs0[f * nobs + i] = newest[i];
+      }
+      for (int j = 0; j < S * nobs; ++j) st[j] = obs0[j];
+    } else {
+      for (int j = 0; j < (S - 1) * nobs; ++j) {
+        double x = st[j + nobs];
+        st[j] = x;
+        obs0[j] = x;
+      }
+      for (int i = 0; i < nobs; ++i) st[(S - 1) * nobs + i] = newest[i];
+    }
+  }
   for (int i = 0; i < 9; ++i) ((double*)out.p[kKeyEnv0 + 1 + i])[row] = info[i];
   WriteCommon(out, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
 }
@@ -200,8 +222,11 @@ __global__ void AntSetState(AntDev dev, CommonDev cm, const int* ids, int k, con
 
 std::vector<KeySpec> AntKeys(const Config& cfg) {
   int no_pos = cfg.Get("exclude_current_positions_from_observation", 1) != 0;
-  // ant.h:51-75 with use_contact_force=false
-  std::vector<KeySpec> k = {{"obs", EPA_F64, {no_pos ? 27 : 29}}};
+  int fs = (int)cfg.Get("frame_stack", 1);
+  // ant.h:51-75 with use_contact_force=false; StackSpec, frame_stack.h:42-71
+  std::vector<int> oshape = {no_pos ? 27 : 29};
+  if (fs > 1) oshape.insert(oshape.begin(), fs);
+  std::vector<KeySpec> k = {{"obs", EPA_F64, oshape}};
   for (const char* name :
        {"info:reward_forward", "info:reward_ctrl", "info:reward_contact",
         "info:reward_survive", "info:x_position", "info:y_position",
@@ -215,8 +240,9 @@ class AntPool : public Pool {
  public:
   explicit AntPool(const Config& cfg)
       : Pool(cfg, AntKeys(cfg), KeySpec{"action", EPA_F64, {A::kNU}}, true) {
-    if ((int)cfg.Get("frame_stack", 1) != 1) {
-      throw std::invalid_argument("frame_stack != 1 is not supported yet");
+    task_.frame_stack = (int)cfg.Get("frame_stack", 1);
+    if (task_.frame_stack < 1) {
+      throw std::invalid_argument("frame_stack must be greater than 0");
     }
     if (cfg.Get("use_contact_force", 0) != 0) {
       throw std::invalid_argument(
@@ -249,6 +275,11 @@ class AntPool : public Pool {
     EPA_HIP(hipMemsetAsync(dev_.lag, 0, sizeof(double) * 2 * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.nsaved, 0, sizeof(double) * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.navail, 0, n, stream_));
+    if (task_.frame_stack > 1) {
+      size_t sb = sizeof(double) * n * task_.frame_stack * (A::kNQ + A::kNV - task_.obs_skip);
+      EPA_HIP(hipMalloc(&dev_.stack, sb));
+      EPA_HIP(hipMemsetAsync(dev_.stack, 0, sb, stream_));
+    }
     InitCommon();
   }
   ~AntPool() override {
@@ -258,6 +289,7 @@ class AntPool : public Pool {
     (void)hipFree(dev_.lag);
     (void)hipFree(dev_.nsaved);
     (void)hipFree(dev_.navail);
+    if (dev_.stack) (void)hipFree(dev_.stack);
   }
   int StateDim() const override { return kAntStateDim; }
   void GetState(const int* d_ids, int k, double* d_out) override {

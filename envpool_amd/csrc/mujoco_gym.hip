@@ -34,12 +34,14 @@ struct CheetahDev {
   double* qvel;  // [9][N]
   double* warm;  // [9][N]
   int* iters;              // Newton iterations of the last step (profiling)
+  double* stack;           // [N][frame_stack * nobs] obs ring (frame_stack > 1 only)
   double* nsaved;          // normal_distribution::_M_saved
   unsigned char* navail;   // normal_distribution::_M_saved_available
 };
 
 struct CheetahTask {
   int frame_skip;
+  int frame_stack;  // TypedFrameStackBuffer depth (envpool/mujoco/frame_stack.h:74-146)
   int obs_skip;  // 1 if exclude_current_positions_from_observation
   double ctrl_cost_weight, forward_reward_weight, reset_noise_scale;
   double dt;     // frame_skip * timestep, computed in fp64 like the reference
@@ -134,9 +136,30 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
   cm.cur_step[e] = cur;
   // WriteState, half_cheetah.h:158-185
   const int nobs = 2 * kNV - task.obs_skip;
-  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
-  for (int i = task.obs_skip; i < kNV; ++i) *(obs++) = qpos[i];
-  for (int i = 0; i < kNV; ++i) *(obs++) = qvel[i];
+  const int S = task.frame_stack;
+  double* obs0 = (double*)out.p[kKeyEnv0] + (size_t)row * nobs * S;
+  double* newest = obs0 + (size_t)(S - 1) * nobs;
+  {
+    double* obs = newest;
+    for (int i = task.obs_skip; i < kNV; ++i) *(obs++) = qpos[i];
+    for (int i = 0; i < kNV; ++i) *(obs++) = qvel[i];
+  }
+  if (S > 1) {  // FrameStackBuffer::Commit, frame_stack.h:109-135
+    double* st = dev.stack + (size_t)e * S * nobs;
+    if (reset) {
+      for (int f = 0; f < S - 1; ++f) {
+        for (int i = 0; i < nobs; ++i) obs0[f * nobs + i] = newest[i];
+      }
+      for (int j = 0; j < S * nobs; ++j) st[j] = obs0[j];
+    } else {
+      for (int j = 0; j < (S - 1) * nobs; ++j) {
+        double x = st[j + nobs];
+        st[j] = x;
+        obs0[j] = x;
+      }
+      for (int i = 0; i < nobs; ++i) st[(S - 1) * nobs + i] = newest[i];
+    }
+  }
   ((double*)out.p[kKeyEnv0 + 1])[row] = xv * task.forward_reward_weight;
   ((double*)out.p[kKeyEnv0 + 2])[row] = -ctrl_cost;
   ((double*)out.p[kKeyEnv0 + 3])[row] = reset ? 0.0 : qpos[0];
@@ -188,8 +211,11 @@ __global__ void CheetahSetState(CheetahDev dev, CommonDev cm, const int* ids,
 
 std::vector<KeySpec> CheetahKeys(const Config& cfg) {
   int no_pos = cfg.Get("exclude_current_positions_from_observation", 1) != 0;
-  // half_cheetah.h:44-62 (non-ENVPOOL_TEST build)
-  return {{"obs", EPA_F64, {no_pos ? 17 : 18}},
+  int fs = (int)cfg.Get("frame_stack", 1);
+  // half_cheetah.h:44-62 (non-ENVPOOL_TEST build); StackSpec, frame_stack.h:42-71
+  std::vector<int> oshape = {no_pos ? 17 : 18};
+  if (fs > 1) oshape.insert(oshape.begin(), fs);
+  return {{"obs", EPA_F64, oshape},
           {"info:reward_run", EPA_F64, {}},
           {"info:reward_ctrl", EPA_F64, {}},
           {"info:x_position", EPA_F64, {}},
@@ -201,8 +227,9 @@ class CheetahPool : public Pool {
   explicit CheetahPool(const Config& cfg)
       : Pool(cfg, CheetahKeys(cfg), KeySpec{"action", EPA_F64, {kNU}},
              /*needs_rng=*/true) {
-    if ((int)cfg.Get("frame_stack", 1) != 1) {
-      throw std::invalid_argument("frame_stack != 1 is not supported yet");
+    task_.frame_stack = (int)cfg.Get("frame_stack", 1);
+    if (task_.frame_stack < 1) {
+      throw std::invalid_argument("frame_stack must be greater than 0");
     }
     // "precision": 1 = fp64 arithmetic (default: matches the reference's
     // mjtNum=double), 0 = fp32 arithmetic with fp64 state/IO (BASELINE "fp32").
@@ -222,6 +249,11 @@ class CheetahPool : public Pool {
     EPA_HIP(hipMalloc(&dev_.nsaved, sizeof(double) * n));
     EPA_HIP(hipMalloc(&dev_.navail, n));
     EPA_HIP(hipMalloc(&dev_.iters, sizeof(int) * n));
+    if (task_.frame_stack > 1) {
+      size_t sb = sizeof(double) * n * task_.frame_stack * (2 * kNV - task_.obs_skip);
+      EPA_HIP(hipMalloc(&dev_.stack, sb));
+      EPA_HIP(hipMemsetAsync(dev_.stack, 0, sb, stream_));
+    }
     EPA_HIP(hipMemsetAsync(dev_.iters, 0, sizeof(int) * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.qpos, 0, sizeof(double) * kNV * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.qvel, 0, sizeof(double) * kNV * n, stream_));
@@ -237,6 +269,7 @@ class CheetahPool : public Pool {
     (void)hipFree(dev_.nsaved);
     (void)hipFree(dev_.navail);
     (void)hipFree(dev_.iters);
+    if (dev_.stack) (void)hipFree(dev_.stack);
   }
   int StateDim() const override { return kCheetahStateDim; }
   void GetState(const int* d_ids, int k, double* d_out) override {
@@ -254,10 +287,11 @@ class CheetahPool : public Pool {
     StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps,
                cfg_.env_id_offset};
     int blocks = (k + kCheetahBlock - 1) / kCheetahBlock;
+    static const int pad = getenv("EPA_CHEETAH_LDS_PAD") ? atoi(getenv("EPA_CHEETAH_LDS_PAD")) : 0;
     if (fp64_) {
       mj::SolverCfg<double> sc{50, 1e-13};
       hipLaunchKernelGGL(CheetahStepKernel<double>, dim3(blocks),
-                         dim3(kCheetahBlock), 0, stream_, dev_, common_, a,
+                         dim3(kCheetahBlock), pad, stream_, dev_, common_, a,
                          static_cast<const double*>(d_action), out, model_,
                          task_, sc);
     } else {

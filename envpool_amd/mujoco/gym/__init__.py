@@ -14,6 +14,13 @@ from envpool_amd.python.api import py_env
 _inf = float("inf")
 
 
+def _stack(shape, c):
+    """StackSpec (envpool/mujoco/frame_stack.h:42-71)."""
+    if c["frame_stack"] < 1:
+        raise ValueError("frame_stack must be greater than 0")
+    return [c["frame_stack"], *shape] if c["frame_stack"] > 1 else shape
+
+
 def _precision(c):
     if c["precision"] not in (32, 64):
         raise ValueError("precision must be 32 or 64")
@@ -32,7 +39,7 @@ _HalfCheetah = FamilyDef(
     ],
     state_spec=lambda c: [
         ("obs", spec(np.float64,
-                     [17 if c["exclude_current_positions_from_observation"] else 18],
+                     _stack([17 if c["exclude_current_positions_from_observation"] else 18], c),
                      (-_inf, _inf))),
         ("info:reward_run", spec(np.float64, [-1])),
         ("info:reward_ctrl", spec(np.float64, [-1])),
@@ -42,6 +49,7 @@ _HalfCheetah = FamilyDef(
     action_spec=lambda c: [("action", spec(np.float64, [-1, 6], (-1.0, 1.0)))],
     native_params=lambda c: {
         "frame_skip": c["frame_skip"],
+        "frame_stack": c["frame_stack"],
         "exclude_current_positions_from_observation":
             c["exclude_current_positions_from_observation"],
         "ctrl_cost_weight": c["ctrl_cost_weight"],
@@ -50,7 +58,7 @@ _HalfCheetah = FamilyDef(
         "precision": _precision(c),
     },
     # the model constants are compiled in from half_cheetah_envpool.xml
-    unsupported={"frame_stack": 1, "xml_file": "half_cheetah.xml"},
+    unsupported={"xml_file": "half_cheetah.xml"},
 )
 
 _Ant = FamilyDef(
@@ -71,7 +79,7 @@ _Ant = FamilyDef(
     ],
     state_spec=lambda c: [
         ("obs", spec(np.float64,
-                     [27 if c["exclude_current_positions_from_observation"] else 29],
+                     _stack([27 if c["exclude_current_positions_from_observation"] else 29], c),
                      (-_inf, _inf))),
     ] + [(k, spec(np.float64, [-1])) for k in (
         "info:reward_forward", "info:reward_ctrl", "info:reward_contact",
@@ -80,6 +88,7 @@ _Ant = FamilyDef(
     action_spec=lambda c: [("action", spec(np.float64, [-1, 8], (-1.0, 1.0)))],
     native_params=lambda c: {
         "frame_skip": c["frame_skip"],
+        "frame_stack": c["frame_stack"],
         "exclude_current_positions_from_observation":
             c["exclude_current_positions_from_observation"],
         "terminate_when_unhealthy": c["terminate_when_unhealthy"],
@@ -93,7 +102,7 @@ _Ant = FamilyDef(
         "precision": _precision(c),
     },
     # Ant-v3 / v5 observe cfrc_ext (mj_rnePostConstraint): not restated yet
-    unsupported={"frame_stack": 1, "xml_file": "ant.xml", "use_contact_force": False},
+    unsupported={"xml_file": "ant.xml", "use_contact_force": False},
 )
 
 _GymHalfCheetahEnvSpec, _GymHalfCheetahEnvPool = make_native_classes(_HalfCheetah)

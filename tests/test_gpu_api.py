@@ -88,8 +88,25 @@ def test_send_recv_async_api():
     assert seen == set(range(16))
 
 
+@pytest.mark.parametrize("task,adim,precision", [("HalfCheetah-v4", 6, 32), ("Ant-v4", 8, 64),
+                                                 ("Ant-v4", 8, 32)])
+def test_mujoco_run_to_run_determinism(task, adim, precision):
+    """Same seed, same actions => bit-identical rollouts (the reference's
+    mujoco_gym_deterministic_test.py:70-123), for every kernel variant."""
+    n = 256
+    e0 = envpool.make_gym(task, num_envs=n, seed=5, precision=precision)
+    e1 = envpool.make_gym(task, num_envs=n, seed=5, precision=precision)
+    np.testing.assert_array_equal(e0.reset()[0], e1.reset()[0])
+    rng = np.random.default_rng(1)
+    for _ in range(40):
+        a = rng.uniform(-1, 1, (n, adim))
+        r0, r1 = e0.step(a), e1.step(a)
+        np.testing.assert_array_equal(r0[0], r1[0])
+        np.testing.assert_array_equal(r0[1], r1[1])
+
+
 def test_halfcheetah_api_shapes_and_determinism():
-    n = 64
+    n = 256
     env0 = envpool.make("HalfCheetah-v4", "gymnasium", num_envs=n, seed=7)
     env1 = envpool.make("HalfCheetah-v4", "gymnasium", num_envs=n, seed=7)
     o0, i0 = env0.reset()
@@ -117,3 +134,29 @@ def test_env_seed_list_matches_offset_seeds():
     a = envpool.make_gym("CartPole-v1", num_envs=4, seed=[10, 11, 12, 13])
     b = envpool.make_gym("CartPole-v1", num_envs=4, seed=10)
     np.testing.assert_array_equal(a.reset()[0], b.reset()[0])
+
+
+@pytest.mark.parametrize("task,obs_dim,adim", [("HalfCheetah-v4", 17, 6), ("Ant-v4", 27, 8)])
+def test_mujoco_frame_stack(task, obs_dim, adim):
+    """frame_stack semantics of envpool/mujoco/frame_stack.h:109-135, checked the
+    way the reference does (mujoco_gym_envpool_test.cc:58-112): reset replicates
+    the frame, a step shifts by one; dynamics equal the unstacked pool."""
+    n, S = 16, 4
+    flat = envpool.make_gym(task, num_envs=n, seed=3, max_episode_steps=12)
+    stk = envpool.make_gym(task, num_envs=n, seed=3, max_episode_steps=12, frame_stack=S)
+    assert stk.observation_space.shape == (S, obs_dim)
+    o1, _ = flat.reset()
+    oS, _ = stk.reset()
+    assert oS.shape == (n, S, obs_dim)
+    hist = np.repeat(o1[:, None, :], S, axis=1)
+    np.testing.assert_array_equal(oS, hist)
+    rng = np.random.default_rng(0)
+    for t in range(30):
+        a = rng.uniform(-1, 1, (n, adim))
+        o1, r1, te1, tr1, i1 = flat.step(a)
+        oS, rS, teS, trS, iS = stk.step(a)
+        np.testing.assert_array_equal(r1, rS)
+        fresh = i1["elapsed_step"] == 0  # auto-reset rows replicate the new frame
+        hist = np.concatenate([hist[:, 1:], o1[:, None, :]], axis=1)
+        hist[fresh] = np.repeat(o1[fresh][:, None, :], S, axis=1)
+        np.testing.assert_array_equal(oS, hist)

@@ -90,7 +90,10 @@ def test_kwargs_validation():
     with pytest.raises(ValueError):
         envpool.make("CartPole-v1", "gym", num_envs=1, render_mode="ansi")
     with pytest.raises(ValueError):
-        envpool.make_spec("HalfCheetah-v4", frame_stack=4)
+        envpool.make_spec("HalfCheetah-v4", frame_stack=0)
+    with pytest.raises(ValueError):
+        envpool.make_spec("HalfCheetah-v4", xml_file="other.xml")
+    assert envpool.make_spec("HalfCheetah-v4", frame_stack=4).observation_space.shape == (4, 17)
 
 
 def test_no_cpu_fallback():
