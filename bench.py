@@ -192,7 +192,7 @@ def main():
                         "(~300 flop/B); HBM fraction reported as BASELINE.md asks",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.task)
         print(json.dumps(out))
     if world > 1:
