@@ -195,7 +195,7 @@ inline AntModel<double> BuildAntModel() {
 }
 
 template <typename T>
-inline AntModel<T> CastAntModel(const AntModel<double>& d) {
+constexpr AntModel<T> CastAntModel(const AntModel<double>& d) {
   AntModel<T> m{};
   for (int b = 0; b < kNB; ++b) {
     m.mass[b] = (T)d.mass[b];

@@ -83,6 +83,21 @@ EPA_HD void SinCos(T x, T* s, T* c) {
 #endif
 }
 
+// True if `x` holds for any lane of the wavefront (host: the single "lane").
+// The solver below has no lane-divergent control flow at all: every branch is
+// taken on WaveAny(...) (a scalar branch on a ballot) and per-lane differences
+// are applied as selects / zero weights.  Lanes whose Newton iteration or line
+// search has finished keep executing with frozen iterates until the slowest
+// lane of the wave is done -- which is what the hardware does with a divergent
+// loop anyway -- and the exec mask never changes inside the hot loops.
+EPA_HD bool WaveAny(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(x) != 0;
+#else
+  return x;
+#endif
+}
+
 // ---- model --------------------------------------------------------------------
 constexpr int kNB = 7;    // torso bthigh bshin bfoot fthigh fshin ffoot
 constexpr int kNV = 9;    // rootx rootz rooty + 6 leg hinges
@@ -167,9 +182,8 @@ EPA_HD V3<T> CrossForce(const V3<T>& vel, const V3<T>& f) {
 template <typename T>
 EPA_HD T Impedance(T d0, T dmax, T width, T r) {
   T x = (r < T(0) ? -r : r) / width;
-  if (x >= T(1)) return dmax;
   T y = x <= T(0.5) ? T(2) * x * x : T(1) - T(2) * (T(1) - x) * (T(1) - x);
-  return d0 + y * (dmax - d0);
+  return x >= T(1) ? dmax : d0 + y * (dmax - d0);
 }
 
 // (Kept on: with fp32 factorisations the Newton loop stalls at its iteration cap
@@ -433,10 +447,11 @@ EPA_HD void ForChainCols(const CheetahPos<T>& p, T cpx, T cpz, F&& f) {
 // keeps the per-contact constants in LDS (dynamic slot index => real ds_read,
 // no store-to-load forwarding into long-lived VGPRs) and emits the Jacobian
 // code once per body instead of once per end sphere.
-// NOTE (ROCm 7.2 / gfx950): the switch must be the OUTERMOST construct of the
-// loop body.  Nested under the lane-divergent `if (D > 0)` the fp64 kernel
-// (512 VGPR+AGPR, spills) produced run-to-run different results; with the
-// uniform switch outside and the divergence inside each case it is bit-stable.
+// NOTE (ROCm 7.2 / gfx950): the fp64 instantiation (512 VGPR+AGPR plus spills)
+// was miscompiled -- run-to-run different results, Newton never terminating --
+// whenever this uniform switch sat inside lane-divergent control flow, and again
+// (with a different build) with the divergence inside the cases.  Hence the
+// rule stated at WaveAny(): no lane-divergent branch anywhere in the solver.
 #if defined(__clang__)
 #define EPA_NO_UNROLL _Pragma("clang loop unroll(disable)")
 #else
@@ -472,14 +487,8 @@ EPA_HD void CheetahMakeConstraint(const CheetahModel<T>& m,
     constexpr int j = decltype(jc)::value;
     T qq = q[j + 3];
     T dlo = qq - m.lo[j], dhi = m.hi[j] - qq;
-    T sgn = T(0), dist = T(0);
-    if (dlo < T(0)) {
-      sgn = T(1);
-      dist = dlo;
-    } else if (dhi < T(0)) {
-      sgn = T(-1);
-      dist = dhi;
-    }
+    const T sgn = dlo < T(0) ? T(1) : (dhi < T(0) ? T(-1) : T(0));
+    const T dist = dlo < T(0) ? dlo : (dhi < T(0) ? dhi : T(0));
     T imp = Impedance(m.lim_d0, m.lim_dmax, m.lim_width, dist);
     T R = (T(1) - imp) * m.dof_invw[j] / imp;
     R = R < kMinVal ? kMinVal : R;
@@ -495,7 +504,8 @@ EPA_HD void CheetahMakeConstraint(const CheetahModel<T>& m,
     T wz = p.pz[b] - p.sn[b] * m.ex[e] + p.cs[b] * m.ez[e];
     T dist = wz - m.radius;
     T D = T(0), cpx = wx, cpz = T(0.5) * dist, an = T(0), ax = T(0);
-    if (dist < T(0)) {
+    const bool touch = dist < T(0);
+    if (WaveAny(touch)) {
       T vn = T(0), vx = T(0);
       ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
         constexpr int j = decltype(jc)::value;
@@ -507,9 +517,9 @@ EPA_HD void CheetahMakeConstraint(const CheetahModel<T>& m,
       T diag = m.body_invw[b] * (T(1) + m.mu * m.mu);
       T R = (T(1) - imp) * diag / imp;
       R = R < kMinVal ? kMinVal : R;
-      D = T(1) / (T(2) * m.mu * m.mu * R);
-      an = -m.con_B * vn - m.con_K * imp * dist;
-      ax = m.con_B * m.mu * vx;
+      D = touch ? T(1) / (T(2) * m.mu * m.mu * R) : T(0);
+      an = touch ? -m.con_B * vn - m.con_K * imp * dist : T(0);
+      ax = touch ? m.con_B * m.mu * vx : T(0);
     }
     lds(e * kSlotsPerEnd + 0) = cpx;
     lds(e * kSlotsPerEnd + 1) = cpz;
@@ -520,8 +530,8 @@ EPA_HD void CheetahMakeConstraint(const CheetahModel<T>& m,
 }
 
 // One pass over all constraint rows at acceleration `a`:
-// accumulates grad -= J^T f and (if H != nullptr) H += J^T D_active J, returns
-// a 64-bit mask of the active rows.
+// accumulates grad -= J^T f and (if kHess) H += J^T D_active J, returns a
+// 64-bit mask of the active rows.  Inactive rows enter with weight 0.
 template <bool kHess, typename T, typename Lds>
 EPA_HD unsigned long long CheetahRowsPass(const CheetahModel<T>& m,
                                           const CheetahPos<T>& p,
@@ -530,56 +540,55 @@ EPA_HD unsigned long long CheetahRowsPass(const CheetahModel<T>& m,
   unsigned long long mask = 0;
   static_for<0, kNU>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    if (lim.sgn[j] != T(0)) {
-      T jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
-      if (jar < T(0)) {
-        grad[j + 3] += lim.sgn[j] * lim.D[j] * jar;
-        if constexpr (kHess) H[TriIdx(j + 3, j + 3)] += lim.D[j];
-        mask |= 1ull << j;
-      }
-    }
+    const T jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
+    const bool on = lim.sgn[j] != T(0) && jar < T(0);
+    const T w = on ? lim.D[j] : T(0);
+    grad[j + 3] += lim.sgn[j] * w * jar;
+    if constexpr (kHess) H[TriIdx(j + 3, j + 3)] += w;
+    mask |= (on ? 1ull : 0ull) << j;
   });
   EPA_NO_UNROLL
   for (int e = 0; e < kNEnd; ++e) {
-    // wave-uniform switch outermost (scalar branch), lane divergence inside
-    DispatchBody(EndBody(e), [&](auto bc) {
+    const T D = lds(e * kSlotsPerEnd + 4);
+    if (!WaveAny(D > T(0))) continue;  // no lane of the wave touches with this end
+    DispatchBody(EndBody(e), [&](auto bc) {  // wave-uniform switch
       constexpr int b = decltype(bc)::value;
-      T D = lds(e * kSlotsPerEnd + 4);
-      if (D > T(0)) {
-        T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
-        T an = lds(e * kSlotsPerEnd + 2), ax = lds(e * kSlotsPerEnd + 3);
-        T jna = T(0), jxa = T(0);
-        ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
-          constexpr int j = decltype(jc)::value;
-          jna += jn * a[j];
-          jxa += jx * a[j];
+      const T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
+      const T an = lds(e * kSlotsPerEnd + 2), ax = lds(e * kSlotsPerEnd + 3);
+      T jna = T(0), jxa = T(0);
+      ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
+        constexpr int j = decltype(jc)::value;
+        jna += jn * a[j];
+        jxa += jx * a[j];
+      });
+      // rows: 2 x (Jn), (Jn - mu Jx), (Jn + mu Jx); D == 0 for lanes not in
+      // contact, which zeroes every weight below
+      const T jar1 = jna - an;
+      const T jar2 = jna - m.mu * jxa - (an + ax);
+      const T jar3 = jna + m.mu * jxa - (an - ax);
+      const bool on = D > T(0);
+      const bool a1 = on && jar1 < T(0), a2 = on && jar2 < T(0), a3 = on && jar3 < T(0);
+      const T w1 = a1 ? T(2) * D : T(0);
+      const T w2 = a2 ? D : T(0);
+      const T w3 = a3 ? D : T(0);
+      mask |= (a1 ? 1ull : 0ull) << (6 + 3 * e);
+      mask |= (a2 ? 1ull : 0ull) << (7 + 3 * e);
+      mask |= (a3 ? 1ull : 0ull) << (8 + 3 * e);
+      const T gn = w1 * jar1 + w2 * jar2 + w3 * jar3;   // coefficient of Jn
+      const T gx = m.mu * (w3 * jar3 - w2 * jar2);      // coefficient of Jx
+      const T A = w1 + w2 + w3, Bc = m.mu * (w3 - w2), C = m.mu * m.mu * (w2 + w3);
+      if (WaveAny(A > T(0))) {
+        ForChainCols<b>(p, cpx, cpz, [&](auto ic, T jni, T jxi) {
+          constexpr int i = decltype(ic)::value;
+          grad[i] += jni * gn + jxi * gx;
+          if constexpr (kHess) {
+            T ui = A * jni + Bc * jxi, wi = Bc * jni + C * jxi;
+            ForChainCols<b>(p, cpx, cpz, [&](auto kc, T jnk, T jxk) {
+              constexpr int k = decltype(kc)::value;
+              if constexpr (k >= i) H[TriIdx(i, k)] += ui * jnk + wi * jxk;
+            });
+          }
         });
-        // rows: 2 x (Jn), (Jn - mu Jx), (Jn + mu Jx)
-        T jar1 = jna - an;
-        T jar2 = jna - m.mu * jxa - (an + ax);
-        T jar3 = jna + m.mu * jxa - (an - ax);
-        T w1 = jar1 < T(0) ? T(2) * D : T(0);
-        T w2 = jar2 < T(0) ? D : T(0);
-        T w3 = jar3 < T(0) ? D : T(0);
-        mask |= (jar1 < T(0) ? 1ull : 0ull) << (6 + 3 * e);
-        mask |= (jar2 < T(0) ? 1ull : 0ull) << (7 + 3 * e);
-        mask |= (jar3 < T(0) ? 1ull : 0ull) << (8 + 3 * e);
-        T gn = w1 * jar1 + w2 * jar2 + w3 * jar3;   // coefficient of Jn
-        T gx = m.mu * (w3 * jar3 - w2 * jar2);      // coefficient of Jx
-        T A = w1 + w2 + w3, Bc = m.mu * (w3 - w2), C = m.mu * m.mu * (w2 + w3);
-        if (A > T(0)) {
-          ForChainCols<b>(p, cpx, cpz, [&](auto ic, T jni, T jxi) {
-            constexpr int i = decltype(ic)::value;
-            grad[i] += jni * gn + jxi * gx;
-            if constexpr (kHess) {
-              T ui = A * jni + Bc * jxi, wi = Bc * jni + C * jxi;
-              ForChainCols<b>(p, cpx, cpz, [&](auto kc, T jnk, T jxk) {
-                constexpr int k = decltype(kc)::value;
-                if constexpr (k >= i) H[TriIdx(i, k)] += ui * jnk + wi * jxk;
-              });
-            }
-          });
-        }
       }
     });
   }
@@ -593,49 +602,39 @@ EPA_HD void CheetahLineEval(const CheetahModel<T>& m, const CheetahPos<T>& p,
                             const T* s, T alpha, T* d1, T* d2) {
   static_for<0, kNU>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    if (lim.sgn[j] != T(0)) {
-      T jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
-      T jv = lim.sgn[j] * s[j + 3];
-      T x = jar + alpha * jv;
-      if (x < T(0)) {
-        *d1 += lim.D[j] * x * jv;
-        *d2 += lim.D[j] * jv * jv;
-      }
-    }
+    const T jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
+    const T jv = lim.sgn[j] * s[j + 3];
+    const T x = jar + alpha * jv;
+    const T w = (lim.sgn[j] != T(0) && x < T(0)) ? lim.D[j] : T(0);
+    *d1 += w * x * jv;
+    *d2 += w * jv * jv;
   });
   EPA_NO_UNROLL
   for (int e = 0; e < kNEnd; ++e) {
-    DispatchBody(EndBody(e), [&](auto bc) {  // wave-uniform switch outermost
+    const T D = lds(e * kSlotsPerEnd + 4);
+    if (!WaveAny(D > T(0))) continue;
+    DispatchBody(EndBody(e), [&](auto bc) {  // wave-uniform switch
       constexpr int b = decltype(bc)::value;
-      T D = lds(e * kSlotsPerEnd + 4);
-      if (D > T(0)) {
-        T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
-        T an = lds(e * kSlotsPerEnd + 2), ax = lds(e * kSlotsPerEnd + 3);
-        T jna = T(0), jxa = T(0), jns = T(0), jxs = T(0);
-        ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
-          constexpr int j = decltype(jc)::value;
-          jna += jn * a[j];
-          jxa += jx * a[j];
-          jns += jn * s[j];
-          jxs += jx * s[j];
-        });
-        T jar1 = jna - an, jv1 = jns;
-        T jar2 = jna - m.mu * jxa - (an + ax), jv2 = jns - m.mu * jxs;
-        T jar3 = jna + m.mu * jxa - (an - ax), jv3 = jns + m.mu * jxs;
-        T x1 = jar1 + alpha * jv1, x2 = jar2 + alpha * jv2, x3 = jar3 + alpha * jv3;
-        if (x1 < T(0)) {
-          *d1 += T(2) * D * x1 * jv1;
-          *d2 += T(2) * D * jv1 * jv1;
-        }
-        if (x2 < T(0)) {
-          *d1 += D * x2 * jv2;
-          *d2 += D * jv2 * jv2;
-        }
-        if (x3 < T(0)) {
-          *d1 += D * x3 * jv3;
-          *d2 += D * jv3 * jv3;
-        }
-      }
+      const T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
+      const T an = lds(e * kSlotsPerEnd + 2), ax = lds(e * kSlotsPerEnd + 3);
+      T jna = T(0), jxa = T(0), jns = T(0), jxs = T(0);
+      ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
+        constexpr int j = decltype(jc)::value;
+        jna += jn * a[j];
+        jxa += jx * a[j];
+        jns += jn * s[j];
+        jxs += jx * s[j];
+      });
+      const T jar1 = jna - an, jv1 = jns;
+      const T jar2 = jna - m.mu * jxa - (an + ax), jv2 = jns - m.mu * jxs;
+      const T jar3 = jna + m.mu * jxa - (an - ax), jv3 = jns + m.mu * jxs;
+      const T x1 = jar1 + alpha * jv1, x2 = jar2 + alpha * jv2, x3 = jar3 + alpha * jv3;
+      // D == 0 for lanes not in contact
+      const T c1 = x1 < T(0) ? T(2) * D : T(0);
+      const T c2 = x2 < T(0) ? D : T(0);
+      const T c3 = x3 < T(0) ? D : T(0);
+      *d1 += c1 * x1 * jv1 + c2 * x2 * jv2 + c3 * x3 * jv3;
+      *d2 += c1 * jv1 * jv1 + c2 * jv2 * jv2 + c3 * jv3 * jv3;
     });
   }
 }
@@ -668,8 +667,11 @@ EPA_HD int CheetahSolve(const CheetahModel<T>& m, const CheetahPos<T>& p,
   T prev_gn = T(-1);
   unsigned long long prev_mask = ~0ull;
   bool full_step = false;
+  bool live = true;  // this lane is still iterating
   int iter = 0;
-  for (; iter < cfg.max_iter; ++iter) {
+  for (int it = 0; it < cfg.max_iter; ++it) {
+    // Every lane (also the finished ones, whose qacc is frozen) rebuilds H,
+    // Ma and grad at its current qacc, so all three are current on exit.
     T H[kTri];
     static_for<0, kTri>([&](auto kc) { H[decltype(kc)::value] = p.M[decltype(kc)::value]; });
     SymMul(p.M, qacc, Ma);
@@ -683,8 +685,11 @@ EPA_HD int CheetahSolve(const CheetahModel<T>& m, const CheetahPos<T>& p,
     static_for<0, kNV>([&](auto ic) { gn += grad[decltype(ic)::value] * grad[decltype(ic)::value]; });
     gn = Sqrt(gn);
     // finite termination: same active set after a full Newton step
-    if (gn <= gstop || (full_step && mask == prev_mask)) break;
-    if (prev_gn >= T(0) && gn <= gfloor && gn >= T(0.25) * prev_gn) break;
+    const bool stop = gn <= gstop || (full_step && mask == prev_mask) ||
+                      (prev_gn >= T(0) && gn <= gfloor && gn >= T(0.25) * prev_gn);
+    live = live && !stop;
+    if (!WaveAny(live)) break;
+    iter += live ? 1 : 0;
     prev_gn = gn;
     prev_mask = mask;
     T s[kNV];
@@ -710,38 +715,43 @@ EPA_HD int CheetahSolve(const CheetahModel<T>& m, const CheetahPos<T>& p,
     full_step = false;
     const T ag1 = g1 < T(0) ? -g1 : g1;
     const T ls_tol = (sizeof(T) == 4 ? T(1e-4) : T(1e-10)) * ag1;
+    bool searching = live;
     for (int ls = 0; ls < 24; ++ls) {
       T d1 = g1 + alpha * g2, d2 = g2;
       CheetahLineEval(m, p, lim, lds, qacc, s, alpha, &d1, &d2);
-      T ad1 = d1 < T(0) ? -d1 : d1;
-      if (ad1 <= ls_tol) {
-        // a full Newton step is exact for the active set H was built with
-        full_step = ls == 0;
-        break;
-      }
-      if (d1 < T(0)) {
-        lo = alpha;
-      } else {
-        hi = alpha;
-      }
+      const T ad1 = d1 < T(0) ? -d1 : d1;
+      const bool hit = ad1 <= ls_tol;
+      // a full Newton step is exact for the active set H was built with
+      full_step = full_step || (searching && hit && ls == 0);
+      searching = searching && !hit;
+      lo = (searching && d1 < T(0)) ? alpha : lo;
+      hi = (searching && !(d1 < T(0))) ? alpha : hi;
       T next = alpha - d1 / d2;
-      if (hi >= T(0) && (next <= lo || next >= hi)) next = T(0.5) * (lo + hi);
-      if (next <= T(0)) next = T(0.5) * alpha;
-      if (next == alpha) break;
-      alpha = next;
+      next = (hi >= T(0) && (next <= lo || next >= hi)) ? T(0.5) * (lo + hi) : next;
+      next = next <= T(0) ? T(0.5) * alpha : next;
+      searching = searching && next != alpha;
+      alpha = searching ? next : alpha;
+      if (!WaveAny(searching)) break;
     }
+    const T step = live ? alpha : T(0);
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      qacc[i] += alpha * s[i];
+      qacc[i] += step * s[i];
     });
   }
-  if (iter == cfg.max_iter) {  // iteration cap hit: refresh Ma / grad
-    SymMul(p.M, qacc, Ma);
+  if (WaveAny(live)) {  // iteration cap hit somewhere in the wave: refresh Ma / grad
+    T Ma2[kNV], grad2[kNV];
+    SymMul(p.M, qacc, Ma2);
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      grad[i] = Ma[i] - qfrc_smooth[i];
+      grad2[i] = Ma2[i] - qfrc_smooth[i];
     });
-    CheetahRowsPass<false>(m, p, lim, lds, qacc, grad, static_cast<T*>(nullptr));
+    CheetahRowsPass<false>(m, p, lim, lds, qacc, grad2, static_cast<T*>(nullptr));
+    static_for<0, kNV>([&](auto ic) {  // only for the lanes that did hit the cap
+      constexpr int i = decltype(ic)::value;
+      Ma[i] = live ? Ma2[i] : Ma[i];
+      grad[i] = live ? grad2[i] : grad[i];
+    });
   }
   return iter;
 }

@@ -161,7 +161,7 @@ inline CheetahModel<double> BuildCheetahModel() {
 }
 
 template <typename T>
-inline CheetahModel<T> CastCheetahModel(const CheetahModel<double>& d) {
+constexpr CheetahModel<T> CastCheetahModel(const CheetahModel<double>& d) {
   CheetahModel<T> m{};
   for (int b = 0; b < kNB; ++b) {
     m.lx[b] = (T)d.lx[b];

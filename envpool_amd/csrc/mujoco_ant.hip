@@ -15,6 +15,7 @@
 #include "engine.h"
 #include "mj_ant.cuh"
 #include "mj_ant_model.h"
+#include "build/mj_ant_consts.inc"  // generated: kAntModelConst (gen_mj_consts.cpp)
 
 namespace epa {
 namespace {
@@ -43,7 +44,8 @@ constexpr int kAntBlock = 64;
 template <typename T>
 __global__ __launch_bounds__(kAntBlock) void AntStepKernel(
     AntDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action,
-    OutPtrs out, A::AntModel<T> m, AntTask task, mj::SolverCfg<T> scfg) {
+    OutPtrs out, AntTask task, mj::SolverCfg<T> scfg) {
+  constexpr A::AntModel<T> m = A::CastAntModel<T>(kAntModelConst);
   const int n = cm.n;
   const int row = blockIdx.x * kAntBlock + threadIdx.x;
   if (row >= a.k) return;
@@ -310,12 +312,12 @@ class AntPool : public Pool {
       mj::SolverCfg<double> sc{50, 1e-13};
       hipLaunchKernelGGL(AntStepKernel<double>, dim3(blocks), dim3(kAntBlock), 0, stream_,
                          dev_, common_, a, static_cast<const double*>(d_action), out,
-                         model_, task_, sc);
+                         task_, sc);
     } else {
       mj::SolverCfg<float> sc{12, 1e-6f};
       hipLaunchKernelGGL(AntStepKernel<float>, dim3(blocks), dim3(kAntBlock), 0, stream_,
                          dev_, common_, a, static_cast<const double*>(d_action), out,
-                         A::CastAntModel<float>(model_), task_, sc);
+                         task_, sc);
     }
   }
 

@@ -21,6 +21,7 @@
 #include "engine.h"
 #include "mj_cheetah.cuh"
 #include "mj_cheetah_model.h"
+#include "build/mj_cheetah_consts.inc"  // generated: kCheetahModelConst (gen_mj_consts.cpp)
 
 namespace epa {
 namespace {
@@ -52,8 +53,9 @@ constexpr int kCheetahBlock = 64;
 template <typename T>
 __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
     CheetahDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action,
-    OutPtrs out, CheetahModel<T> m, CheetahTask task,
-    mj::SolverCfg<T> scfg) {
+    OutPtrs out, CheetahTask task, mj::SolverCfg<T> scfg) {
+  // the MuJoCo model as compile-time constants (see gen_mj_consts.cpp)
+  constexpr CheetahModel<T> m = mj::CastCheetahModel<T>(kCheetahModelConst);
   // per-contact constants [slot][lane]; read back with a runtime slot index in the
   // solver passes (see DispatchBody) so they stay in LDS instead of VGPRs/scratch
   __shared__ T lds_buf[mj::kLdsSlots * kCheetahBlock];
@@ -292,14 +294,12 @@ class CheetahPool : public Pool {
       mj::SolverCfg<double> sc{50, 1e-13};
       hipLaunchKernelGGL(CheetahStepKernel<double>, dim3(blocks),
                          dim3(kCheetahBlock), pad, stream_, dev_, common_, a,
-                         static_cast<const double*>(d_action), out, model_,
-                         task_, sc);
+                         static_cast<const double*>(d_action), out, task_, sc);
     } else {
       mj::SolverCfg<float> sc{12, 1e-6f};
       hipLaunchKernelGGL(CheetahStepKernel<float>, dim3(blocks),
                          dim3(kCheetahBlock), 0, stream_, dev_, common_, a,
-                         static_cast<const double*>(d_action), out,
-                         mj::CastCheetahModel<float>(model_), task_, sc);
+                         static_cast<const double*>(d_action), out, task_, sc);
     }
   }
 
