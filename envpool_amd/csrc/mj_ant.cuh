@@ -271,16 +271,12 @@ struct AntPos {
 template <typename T>
 EPA_HD void NormalizeQuat(T* q) {
   T n = Sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  if (n < T(1e-15)) {
-    q[0] = T(1);
-    q[1] = q[2] = q[3] = T(0);
-  } else {
-    T inv = T(1) / n;
-    q[0] *= inv;
-    q[1] *= inv;
-    q[2] *= inv;
-    q[3] *= inv;
-  }
+  const bool tiny = n < T(1e-15);
+  const T inv = T(1) / (tiny ? T(1) : n);
+  q[0] = tiny ? T(1) : q[0] * inv;
+  q[1] = tiny ? T(0) : q[1] * inv;
+  q[2] = tiny ? T(0) : q[2] * inv;
+  q[3] = tiny ? T(0) : q[3] * inv;
 }
 
 template <typename T>
@@ -505,14 +501,8 @@ EPA_HD void AntMakeConstraint(const AntModel<T>& m, const AntPos<T>& p, const T*
     constexpr int j = decltype(jc)::value;
     T qq = q[7 + j];
     T dlo = qq - m.lo[j], dhi = m.hi[j] - qq;
-    T sgn = T(0), dist = T(0);
-    if (dlo < T(0)) {
-      sgn = T(1);
-      dist = dlo;
-    } else if (dhi < T(0)) {
-      sgn = T(-1);
-      dist = dhi;
-    }
+    const T sgn = dlo < T(0) ? T(1) : (dhi < T(0) ? T(-1) : T(0));
+    const T dist = dlo < T(0) ? dlo : (dhi < T(0) ? dhi : T(0));
     T imp = Impedance(m.imp_d0, m.imp_dmax, m.imp_width, dist);
     T R = (T(1) - imp) * m.dof_invw[j] / imp;
     R = R < kMinVal ? kMinVal : R;
@@ -546,7 +536,10 @@ EPA_HD void DispatchBody(int b, F&& f) {
 // One contact candidate (end sphere s on body B), re-derived from the body
 // pose each time it is needed instead of being stored: mj_collision
 // (plane-sphere) + mj_instantiateContact + mj_makeImpedance for that sphere.
-// Returns false when the sphere is outside the margin.
+// Returns false when no lane of the wave has the sphere inside the margin;
+// otherwise every lane gets a contact, with D = 0 (=> zero weight in every
+// row) on the lanes where the sphere is outside.  Like the planar solver
+// (mj_cheetah.cuh, WaveAny) nothing below branches per lane.
 template <typename T>
 struct AntContact {
   Vec3<T> cp;
@@ -557,7 +550,8 @@ EPA_HD bool AntMakeContact(const AntModel<T>& m, const AntGeo<T>& p, const T* v,
                            AntContact<T>& c) {
   Vec3<T> w = SphCenter<B>(p, s);
   T dist = w.z - m.sph_r[s];
-  if (!(dist < m.margin)) return false;
+  const bool touch = dist < m.margin;
+  if (!WaveAny(touch)) return false;
   c.cp = {w.x, w.y, T(0.5) * dist};
   Vec3<T> vel = {T(0), T(0), T(0)};
   ForChainCols<B>(p, c.cp, [&](auto jc, Vec3<T> col) {
@@ -568,10 +562,10 @@ EPA_HD bool AntMakeContact(const AntModel<T>& m, const AntGeo<T>& p, const T* v,
   T diag = m.geom_body_invw[SphGeomBody(s)] * (T(1) + m.mu * m.mu);
   T R = (T(1) - imp) * diag / imp;
   R = R < T(1e-15) ? T(1e-15) : R;
-  c.D = T(1) / (T(2) * m.mu * m.mu * R);
-  c.an = -m.con_B * vel.z - m.con_K * imp * rr;
-  c.ay = m.con_B * m.mu * vel.y;
-  c.ax = m.con_B * m.mu * vel.x;
+  c.D = touch ? T(1) / (T(2) * m.mu * m.mu * R) : T(0);
+  c.an = touch ? -m.con_B * vel.z - m.con_K * imp * rr : T(0);
+  c.ay = touch ? m.con_B * m.mu * vel.y : T(0);
+  c.ax = touch ? m.con_B * m.mu * vel.x : T(0);
   return true;
 }
 
@@ -593,14 +587,12 @@ EPA_HD void AntRowsPass(const AntModel<T>& m, const AntGeo<T>& p, const AntRows<
   unsigned long long m0 = 0, m1 = 0;
   static_for<0, kNU>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    if (r.lim_sgn[j] != T(0)) {
-      T jar = r.lim_sgn[j] * a[6 + j] - r.lim_aref[j];
-      if (jar < T(0)) {
-        grad[6 + j] += r.lim_sgn[j] * r.lim_D[j] * jar;
-        if constexpr (kHess) H[Tri(6 + j, 6 + j)] += r.lim_D[j];
-        m0 |= 1ull << j;
-      }
-    }
+    const T jar = r.lim_sgn[j] * a[6 + j] - r.lim_aref[j];
+    const bool on = r.lim_sgn[j] != T(0) && jar < T(0);
+    const T w = on ? r.lim_D[j] : T(0);
+    grad[6 + j] += r.lim_sgn[j] * w * jar;
+    if constexpr (kHess) H[Tri(6 + j, 6 + j)] += w;
+    m0 |= (on ? 1ull : 0ull) << j;
   });
   EPA_ANT_NO_UNROLL
   for (int s = 0; s < kNSph; ++s) {
@@ -617,18 +609,18 @@ EPA_HD void AntRowsPass(const AntModel<T>& m, const AntGeo<T>& p, const AntRows<
       T w[4];
       static_for<0, 4>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        w[k] = jar[k] < T(0) ? c.D : T(0);
-        if (jar[k] < T(0)) {
-          int bit = 8 + 4 * s + k;
-          if (bit < 64) {
-            m0 |= 1ull << bit;
-          } else {
-            m1 |= 1ull << (bit - 64);
-          }
+        const bool on = c.D > T(0) && jar[k] < T(0);
+        w[k] = on ? c.D : T(0);
+        const int bit = 8 + 4 * s + k;  // s is wave-uniform
+        const unsigned long long one = on ? 1ull : 0ull;
+        if (bit < 64) {
+          m0 |= one << bit;
+        } else {
+          m1 |= one << (bit - 64);
         }
       });
       T wsum = w[0] + w[1] + w[2] + w[3];
-      if (wsum > T(0)) {
+      if (WaveAny(wsum > T(0))) {
         T gz = w[0] * jar[0] + w[1] * jar[1] + w[2] * jar[2] + w[3] * jar[3];
         T gy = m.mu * (w[0] * jar[0] - w[1] * jar[1]);
         T gx = m.mu * (w[3] * jar[3] - w[2] * jar[2]);
@@ -660,15 +652,12 @@ EPA_HD void AntLineEval(const AntModel<T>& m, const AntGeo<T>& p, const AntRows<
                         const T* v, const T* a, const T* s, T alpha, T* d1, T* d2) {
   static_for<0, kNU>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    if (r.lim_sgn[j] != T(0)) {
-      T jar = r.lim_sgn[j] * a[6 + j] - r.lim_aref[j];
-      T jv = r.lim_sgn[j] * s[6 + j];
-      T x = jar + alpha * jv;
-      if (x < T(0)) {
-        *d1 += r.lim_D[j] * x * jv;
-        *d2 += r.lim_D[j] * jv * jv;
-      }
-    }
+    const T jar = r.lim_sgn[j] * a[6 + j] - r.lim_aref[j];
+    const T jv = r.lim_sgn[j] * s[6 + j];
+    const T x = jar + alpha * jv;
+    const T w = (r.lim_sgn[j] != T(0) && x < T(0)) ? r.lim_D[j] : T(0);
+    *d1 += w * x * jv;
+    *d2 += w * jv * jv;
   });
   EPA_ANT_NO_UNROLL
   for (int sidx = 0; sidx < kNSph; ++sidx) {
@@ -687,11 +676,10 @@ EPA_HD void AntLineEval(const AntModel<T>& m, const AntGeo<T>& p, const AntRows<
                  js.z + m.mu * js.x};
       static_for<0, 4>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        T x = jar[k] + alpha * jv[k];
-        if (x < T(0)) {
-          *d1 += c.D * x * jv[k];
-          *d2 += c.D * jv[k] * jv[k];
-        }
+        const T x = jar[k] + alpha * jv[k];
+        const T w = x < T(0) ? c.D : T(0);  // D == 0 on lanes without contact
+        *d1 += w * x * jv[k];
+        *d2 += w * jv[k] * jv[k];
       });
     });
   }
@@ -712,8 +700,9 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntGeo<T>& p, const T* M,
   T prev_gn = T(-1);
   unsigned long long pm0 = ~0ull, pm1 = ~0ull;
   bool full_step = false;
+  bool live = true;  // this lane is still iterating (finished lanes keep a frozen qacc)
   int iter = 0;
-  for (; iter < cfg.max_iter; ++iter) {
+  for (int it = 0; it < cfg.max_iter; ++it) {
     T H[kTri], Ma[kNV], grad[kNV];
     static_for<0, kTri>([&](auto kc) { H[decltype(kc)::value] = M[decltype(kc)::value]; });
     SymMul(M, qacc, Ma);
@@ -726,8 +715,11 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntGeo<T>& p, const T* M,
     T gn = T(0);
     static_for<0, kNV>([&](auto ic) { gn += grad[decltype(ic)::value] * grad[decltype(ic)::value]; });
     gn = Sqrt(gn);
-    if (gn <= gstop || (full_step && m0 == pm0 && m1 == pm1)) break;
-    if (prev_gn >= T(0) && gn <= gfloor && gn >= T(0.25) * prev_gn) break;
+    const bool stop = gn <= gstop || (full_step && m0 == pm0 && m1 == pm1) ||
+                      (prev_gn >= T(0) && gn <= gfloor && gn >= T(0.25) * prev_gn);
+    live = live && !stop;
+    if (!WaveAny(live)) break;
+    iter += live ? 1 : 0;
     prev_gn = gn;
     pm0 = m0;
     pm1 = m1;
@@ -747,28 +739,27 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntGeo<T>& p, const T* M,
     full_step = false;
     const T ag1 = g1 < T(0) ? -g1 : g1;
     const T ls_tol = (sizeof(T) == 4 ? T(1e-4) : T(1e-10)) * ag1;
+    bool searching = live;
     for (int ls = 0; ls < 24; ++ls) {
       T d1 = g1 + alpha * g2, d2 = g2;
       AntLineEval(m, p, r, v, qacc, s, alpha, &d1, &d2);
-      T ad1 = d1 < T(0) ? -d1 : d1;
-      if (ad1 <= ls_tol) {
-        full_step = ls == 0;
-        break;
-      }
-      if (d1 < T(0)) {
-        lo = alpha;
-      } else {
-        hi = alpha;
-      }
+      const T ad1 = d1 < T(0) ? -d1 : d1;
+      const bool hit = ad1 <= ls_tol;
+      full_step = full_step || (searching && hit && ls == 0);
+      searching = searching && !hit;
+      lo = (searching && d1 < T(0)) ? alpha : lo;
+      hi = (searching && !(d1 < T(0))) ? alpha : hi;
       T next = alpha - d1 / d2;
-      if (hi >= T(0) && (next <= lo || next >= hi)) next = T(0.5) * (lo + hi);
-      if (next <= T(0)) next = T(0.5) * alpha;
-      if (next == alpha) break;
-      alpha = next;
+      next = (hi >= T(0) && (next <= lo || next >= hi)) ? T(0.5) * (lo + hi) : next;
+      next = next <= T(0) ? T(0.5) * alpha : next;
+      searching = searching && next != alpha;
+      alpha = searching ? next : alpha;
+      if (!WaveAny(searching)) break;
     }
+    const T step = live ? alpha : T(0);
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      qacc[i] += alpha * s[i];
+      qacc[i] += step * s[i];
     });
   }
   return iter;
@@ -805,17 +796,20 @@ EPA_HD void AntIntegratePos(T* q, const T* dq, T h) {
   T wx = dq[3], wy = dq[4], wz = dq[5];
   T nrm = Sqrt(wx * wx + wy * wy + wz * wz);
   T ang = nrm * h;
-  if (ang > T(0)) {
+  {
+    const bool turn = ang > T(0);  // zero angular velocity leaves the quaternion as is
     T s, c;
     SinCos(T(0.5) * ang, &s, &c);
-    T k = s / nrm;
+    T k = s / (turn ? nrm : T(1));
     T bw = c, bx = wx * k, by = wy * k, bz = wz * k;
     T aw = q[3], ax = q[4], ay = q[5], az = q[6];
-    q[3] = aw * bw - ax * bx - ay * by - az * bz;
-    q[4] = aw * bx + ax * bw + ay * bz - az * by;
-    q[5] = aw * by - ax * bz + ay * bw + az * bx;
-    q[6] = aw * bz + ax * by - ay * bx + az * bw;
-    NormalizeQuat(q + 3);
+    T nq[4] = {aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+               aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw};
+    NormalizeQuat(nq);
+    q[3] = turn ? nq[0] : aw;
+    q[4] = turn ? nq[1] : ax;
+    q[5] = turn ? nq[2] : ay;
+    q[6] = turn ? nq[3] : az;
   }
   static_for<7, kNQ>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
