@@ -69,6 +69,25 @@ template <typename T>
 EPA_HD T Sqrt(T x) {
   return sqrt(x);
 }
+// 1 / sqrt(x), x > 0.  Device fp64: hardware seed (v_rsq_f64) + two Newton
+// steps (a couple of ulp) instead of an IEEE sqrt followed by an IEEE divide,
+// which together cost ~25 dependent instructions per pivot.
+template <typename T>
+EPA_HD T Rsqrt(T x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (std::is_same<T, double>::value) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+  } else {
+    return T(1) / sqrt(x);
+  }
+#else
+  return T(1) / std::sqrt(x);
+#endif
+}
 template <typename T>
 EPA_HD void SinCos(T x, T* s, T* c) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -93,6 +112,15 @@ EPA_HD void SinCos(T x, T* s, T* c) {
 EPA_HD bool WaveAny(bool x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_ballot_w64(x) != 0;
+#else
+  return x;
+#endif
+}
+// Marks an integer that is equal on every lane by construction (it was built
+// from WaveAny results) so that it lives in an SGPR and loops over it are scalar.
+EPA_HD unsigned WaveUniform(unsigned x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_readfirstlane(x);
 #else
   return x;
 #endif
@@ -181,7 +209,7 @@ EPA_HD V3<T> CrossForce(const V3<T>& vel, const V3<T>& f) {
 // impedance d(r) for power 2, midpoint 0.5 (getimpedance in MuJoCo)
 template <typename T>
 EPA_HD T Impedance(T d0, T dmax, T width, T r) {
-  T x = (r < T(0) ? -r : r) / width;
+  T x = (r < T(0) ? -r : r) * (T(1) / width);  // width is a model constant
   T y = x <= T(0.5) ? T(2) * x * x : T(1) - T(2) * (T(1) - x) * (T(1) - x);
   return x >= T(1) ? dmax : d0 + y * (dmax - d0);
 }
@@ -205,7 +233,8 @@ struct Wide {
 };
 
 // Upper "tree order" Cholesky A = U U^T on a packed upper triangle with the
-// leg/leg zero blocks skipped.  In place.
+// leg/leg zero blocks skipped.  In place; the diagonal is returned INVERTED
+// (1 / U_jj), which is all SolveUUt needs.
 template <typename T>
 EPA_HD void FactorUUt(T* A) {
   static_for_down<kNV, 0>([&](auto jc) {
@@ -215,9 +244,8 @@ EPA_HD void FactorUUt(T* A) {
       constexpr int k = decltype(kc)::value;
       if constexpr (NZ(j, k)) s -= A[TriIdx(j, k)] * A[TriIdx(j, k)];
     });
-    T d = Sqrt(s);
-    T inv = T(1) / d;
-    A[TriIdx(j, j)] = d;
+    T inv = Rsqrt(s);
+    A[TriIdx(j, j)] = inv;  // the diagonal holds 1 / U_jj
     static_for<0, j>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       if constexpr (NZ(i, j)) {
@@ -243,7 +271,7 @@ EPA_HD void SolveUUt(const T* U, T* x) {
       constexpr int k = decltype(kc)::value;
       if constexpr (NZ(j, k)) s -= U[TriIdx(j, k)] * x[k];
     });
-    x[j] = s / U[TriIdx(j, j)];
+    x[j] = s * U[TriIdx(j, j)];
   });
   static_for<0, kNV>([&](auto jc) {  // U^T x = y
     constexpr int j = decltype(jc)::value;
@@ -252,7 +280,7 @@ EPA_HD void SolveUUt(const T* U, T* x) {
       constexpr int i = decltype(ic)::value;
       if constexpr (NZ(i, j)) s -= U[TriIdx(i, j)] * x[i];
     });
-    x[j] = s / U[TriIdx(j, j)];
+    x[j] = s * U[TriIdx(j, j)];
   });
 }
 // y = A x for a packed symmetric matrix with the structural zeros
@@ -477,8 +505,10 @@ struct LimitRows {
   T sgn[kNU], aref[kNU], D[kNU];
 };
 
+// Returns the set of end spheres (bit e) that touch the plane on any lane of
+// the wave; the solver passes only visit those.
 template <typename T, typename Lds>
-EPA_HD void CheetahMakeConstraint(const CheetahModel<T>& m,
+EPA_HD unsigned CheetahMakeConstraint(const CheetahModel<T>& m,
                                   const CheetahPos<T>& p, const T* q,
                                   const T* v, LimitRows<T>& lim, Lds&& lds) {
   const T kMinVal = T(1e-15);
@@ -490,13 +520,15 @@ EPA_HD void CheetahMakeConstraint(const CheetahModel<T>& m,
     const T sgn = dlo < T(0) ? T(1) : (dhi < T(0) ? T(-1) : T(0));
     const T dist = dlo < T(0) ? dlo : (dhi < T(0) ? dhi : T(0));
     T imp = Impedance(m.lim_d0, m.lim_dmax, m.lim_width, dist);
-    T R = (T(1) - imp) * m.dof_invw[j] / imp;
-    R = R < kMinVal ? kMinVal : R;
+    // R = max(mjMINVAL, (1 - imp) / imp * diagApprox), D = 1 / R
+    const T num = (T(1) - imp) * m.dof_invw[j];
+    const T Dj = num < kMinVal * imp ? T(1) / kMinVal : imp / num;
     lim.sgn[j] = sgn;
-    lim.D[j] = sgn != T(0) ? T(1) / R : T(0);
+    lim.D[j] = sgn != T(0) ? Dj : T(0);
     lim.aref[j] = -m.lim_B * (sgn * v[j + 3]) - m.lim_K * imp * dist;
   });
   // mj_collision (plane z=0 vs capsule end spheres) + mj_instantiateContact
+  unsigned ends = 0;
   static_for<0, kNEnd>([&](auto ec) {
     constexpr int e = decltype(ec)::value;
     constexpr int b = EndBody(e);
@@ -506,6 +538,7 @@ EPA_HD void CheetahMakeConstraint(const CheetahModel<T>& m,
     T D = T(0), cpx = wx, cpz = T(0.5) * dist, an = T(0), ax = T(0);
     const bool touch = dist < T(0);
     if (WaveAny(touch)) {
+      ends |= 1u << e;
       T vn = T(0), vx = T(0);
       ForChainCols<b>(p, cpx, cpz, [&](auto jc, T jn, T jx) {
         constexpr int j = decltype(jc)::value;
@@ -515,9 +548,9 @@ EPA_HD void CheetahMakeConstraint(const CheetahModel<T>& m,
       T imp = Impedance(m.con_d0, m.con_dmax, m.con_width, dist);
       // diagApprox (pyramidal) = tran (1 + mu^2); R_py = 2 mu^2 R
       T diag = m.body_invw[b] * (T(1) + m.mu * m.mu);
-      T R = (T(1) - imp) * diag / imp;
-      R = R < kMinVal ? kMinVal : R;
-      D = touch ? T(1) / (T(2) * m.mu * m.mu * R) : T(0);
+      const T num = (T(1) - imp) * diag;  // R = max(mjMINVAL, num / imp)
+      const T invR = num < kMinVal * imp ? T(1) / kMinVal : imp / num;
+      D = touch ? invR * (T(1) / (T(2) * m.mu * m.mu)) : T(0);
       an = touch ? -m.con_B * vn - m.con_K * imp * dist : T(0);
       ax = touch ? m.con_B * m.mu * vx : T(0);
     }
@@ -527,6 +560,7 @@ EPA_HD void CheetahMakeConstraint(const CheetahModel<T>& m,
     lds(e * kSlotsPerEnd + 3) = ax;
     lds(e * kSlotsPerEnd + 4) = D;
   });
+  return WaveUniform(ends);
 }
 
 // One pass over all constraint rows at acceleration `a`:
@@ -536,7 +570,8 @@ template <bool kHess, typename T, typename Lds>
 EPA_HD unsigned long long CheetahRowsPass(const CheetahModel<T>& m,
                                           const CheetahPos<T>& p,
                                           const LimitRows<T>& lim, Lds&& lds,
-                                          const T* a, T* grad, T* H) {
+                                          unsigned ends, const T* a, T* grad,
+                                          T* H) {
   unsigned long long mask = 0;
   static_for<0, kNU>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
@@ -548,9 +583,9 @@ EPA_HD unsigned long long CheetahRowsPass(const CheetahModel<T>& m,
     mask |= (on ? 1ull : 0ull) << j;
   });
   EPA_NO_UNROLL
-  for (int e = 0; e < kNEnd; ++e) {
+  for (unsigned rem = ends; rem != 0; rem &= rem - 1) {  // scalar loop
+    const int e = __builtin_ctz(rem);
     const T D = lds(e * kSlotsPerEnd + 4);
-    if (!WaveAny(D > T(0))) continue;  // no lane of the wave touches with this end
     DispatchBody(EndBody(e), [&](auto bc) {  // wave-uniform switch
       constexpr int b = decltype(bc)::value;
       const T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
@@ -598,8 +633,8 @@ EPA_HD unsigned long long CheetahRowsPass(const CheetahModel<T>& m,
 // phi'(alpha), phi''(alpha) contribution of the rows along `s` from `a`.
 template <typename T, typename Lds>
 EPA_HD void CheetahLineEval(const CheetahModel<T>& m, const CheetahPos<T>& p,
-                            const LimitRows<T>& lim, Lds&& lds, const T* a,
-                            const T* s, T alpha, T* d1, T* d2) {
+                            const LimitRows<T>& lim, Lds&& lds, unsigned ends,
+                            const T* a, const T* s, T alpha, T* d1, T* d2) {
   static_for<0, kNU>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const T jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
@@ -610,9 +645,9 @@ EPA_HD void CheetahLineEval(const CheetahModel<T>& m, const CheetahPos<T>& p,
     *d2 += w * jv * jv;
   });
   EPA_NO_UNROLL
-  for (int e = 0; e < kNEnd; ++e) {
+  for (unsigned rem = ends; rem != 0; rem &= rem - 1) {  // scalar loop
+    const int e = __builtin_ctz(rem);
     const T D = lds(e * kSlotsPerEnd + 4);
-    if (!WaveAny(D > T(0))) continue;
     DispatchBody(EndBody(e), [&](auto bc) {  // wave-uniform switch
       constexpr int b = decltype(bc)::value;
       const T cpx = lds(e * kSlotsPerEnd + 0), cpz = lds(e * kSlotsPerEnd + 1);
@@ -651,7 +686,7 @@ struct SolverCfg {
 // (so that qfrc_constraint = M qacc - qfrc_smooth - grad).
 template <typename T, typename Lds>
 EPA_HD int CheetahSolve(const CheetahModel<T>& m, const CheetahPos<T>& p,
-                        const LimitRows<T>& lim, Lds&& lds,
+                        const LimitRows<T>& lim, Lds&& lds, unsigned ends,
                         const T* qfrc_smooth, const SolverCfg<T>& cfg, T* qacc,
                         T* Ma, T* grad) {
   T fs = T(0);
@@ -661,36 +696,38 @@ EPA_HD int CheetahSolve(const CheetahModel<T>& m, const CheetahPos<T>& p,
     fs = x > fs ? x : fs;
   });
   const T gstop = cfg.gtol * (T(1) + fs);
+  const T gstop2 = gstop * gstop;
   // rounding floor: once the gradient is this small and has stopped shrinking
   // the iterate is as converged as the arithmetic allows
   const T gfloor = (sizeof(T) == 4 ? T(1e-4) : T(1e-9)) * (T(1) + fs);
-  T prev_gn = T(-1);
+  const T gfloor2 = gfloor * gfloor;
+  T prev_gn2 = T(-1);  // squared gradient norm of the previous iterate
+  SymMul(p.M, qacc, Ma);  // kept current incrementally: Ma += alpha * M s
   unsigned long long prev_mask = ~0ull;
   bool full_step = false;
   bool live = true;  // this lane is still iterating
   int iter = 0;
   for (int it = 0; it < cfg.max_iter; ++it) {
-    // Every lane (also the finished ones, whose qacc is frozen) rebuilds H,
-    // Ma and grad at its current qacc, so all three are current on exit.
+    // Every lane (also the finished ones, whose qacc and Ma are frozen)
+    // rebuilds H and grad at its current qacc, so both are current on exit.
     T H[kTri];
     static_for<0, kTri>([&](auto kc) { H[decltype(kc)::value] = p.M[decltype(kc)::value]; });
-    SymMul(p.M, qacc, Ma);
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       grad[i] = Ma[i] - qfrc_smooth[i];
     });
     unsigned long long mask =
-        CheetahRowsPass<true>(m, p, lim, lds, qacc, grad, H);
-    T gn = T(0);
-    static_for<0, kNV>([&](auto ic) { gn += grad[decltype(ic)::value] * grad[decltype(ic)::value]; });
-    gn = Sqrt(gn);
-    // finite termination: same active set after a full Newton step
-    const bool stop = gn <= gstop || (full_step && mask == prev_mask) ||
-                      (prev_gn >= T(0) && gn <= gfloor && gn >= T(0.25) * prev_gn);
+        CheetahRowsPass<true>(m, p, lim, lds, ends, qacc, grad, H);
+    T gn2 = T(0);
+    static_for<0, kNV>([&](auto ic) { gn2 += grad[decltype(ic)::value] * grad[decltype(ic)::value]; });
+    // |grad| <= gstop; or finite termination: same active set after a full
+    // Newton step; or at the rounding floor and no longer shrinking (x4)
+    const bool stop = gn2 <= gstop2 || (full_step && mask == prev_mask) ||
+                      (prev_gn2 >= T(0) && gn2 <= gfloor2 && gn2 >= T(0.0625) * prev_gn2);
     live = live && !stop;
     if (!WaveAny(live)) break;
     iter += live ? 1 : 0;
-    prev_gn = gn;
+    prev_gn2 = gn2;
     prev_mask = mask;
     T s[kNV];
     {
@@ -718,7 +755,7 @@ EPA_HD int CheetahSolve(const CheetahModel<T>& m, const CheetahPos<T>& p,
     bool searching = live;
     for (int ls = 0; ls < 24; ++ls) {
       T d1 = g1 + alpha * g2, d2 = g2;
-      CheetahLineEval(m, p, lim, lds, qacc, s, alpha, &d1, &d2);
+      CheetahLineEval(m, p, lim, lds, ends, qacc, s, alpha, &d1, &d2);
       const T ad1 = d1 < T(0) ? -d1 : d1;
       const bool hit = ad1 <= ls_tol;
       // a full Newton step is exact for the active set H was built with
@@ -737,19 +774,18 @@ EPA_HD int CheetahSolve(const CheetahModel<T>& m, const CheetahPos<T>& p,
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       qacc[i] += step * s[i];
+      Ma[i] += step * Ms[i];
     });
   }
-  if (WaveAny(live)) {  // iteration cap hit somewhere in the wave: refresh Ma / grad
-    T Ma2[kNV], grad2[kNV];
-    SymMul(p.M, qacc, Ma2);
+  if (WaveAny(live)) {  // iteration cap hit somewhere in the wave: refresh grad
+    T grad2[kNV];
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      grad2[i] = Ma2[i] - qfrc_smooth[i];
+      grad2[i] = Ma[i] - qfrc_smooth[i];
     });
-    CheetahRowsPass<false>(m, p, lim, lds, qacc, grad2, static_cast<T*>(nullptr));
+    CheetahRowsPass<false>(m, p, lim, lds, ends, qacc, grad2, static_cast<T*>(nullptr));
     static_for<0, kNV>([&](auto ic) {  // only for the lanes that did hit the cap
       constexpr int i = decltype(ic)::value;
-      Ma[i] = live ? Ma2[i] : Ma[i];
       grad[i] = live ? grad2[i] : grad[i];
     });
   }
@@ -766,10 +802,10 @@ EPA_HD int CheetahStep(const CheetahModel<T>& m, const SolverCfg<T>& cfg, T* q,
   T qfrc_smooth[kNV];
   CheetahSmoothForces(m, p, q, v, ctrl, qfrc_smooth);
   LimitRows<T> lim;
-  CheetahMakeConstraint(m, p, q, v, lim, lds);
+  const unsigned ends = CheetahMakeConstraint(m, p, q, v, lim, lds);
   T qacc[kNV], Ma[kNV], grad[kNV];
   static_for<0, kNV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
-  int iters = CheetahSolve(m, p, lim, lds, qfrc_smooth, cfg, qacc, Ma, grad);
+  int iters = CheetahSolve(m, p, lim, lds, ends, qfrc_smooth, cfg, qacc, Ma, grad);
   static_for<0, kNV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
   // mj_Euler with implicit joint damping:
   //   (M + h diag(damping)) qacc_d = qfrc_smooth + qfrc_constraint = Ma - grad
