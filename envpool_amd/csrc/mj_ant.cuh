@@ -207,9 +207,8 @@ EPA_HD void FactorUUt(T* A) {
       constexpr int k = decltype(kc)::value;
       if constexpr (NZ(j, k)) s -= A[Tri(j, k)] * A[Tri(j, k)];
     });
-    T d = Sqrt(s);
-    T inv = T(1) / d;
-    A[Tri(j, j)] = d;
+    T inv = Rsqrt(s);
+    A[Tri(j, j)] = inv;  // the diagonal holds 1 / U_jj
     static_for<0, j>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       if constexpr (NZ(i, j)) {
@@ -232,7 +231,7 @@ EPA_HD void SolveUUt(const T* U, T* x) {
       constexpr int k = decltype(kc)::value;
       if constexpr (NZ(j, k)) s -= U[Tri(j, k)] * x[k];
     });
-    x[j] = s / U[Tri(j, j)];
+    x[j] = s * U[Tri(j, j)];
   });
   static_for<0, kNV>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
@@ -241,7 +240,7 @@ EPA_HD void SolveUUt(const T* U, T* x) {
       constexpr int i = decltype(ic)::value;
       if constexpr (NZ(i, j)) s -= U[Tri(i, j)] * x[i];
     });
-    x[j] = s / U[Tri(j, j)];
+    x[j] = s * U[Tri(j, j)];
   });
 }
 template <typename T>
@@ -436,6 +435,54 @@ struct AntGeo {
   Vec3<T> tip[kNLeg];     // far end of the ankle capsules
   Vec3<T> rot[3];         // torso body axes (free-joint rotational dofs); rot[2] = hip axis
   Vec3<T> ankle[kNLeg];   // ankle axes in the world
+  EPA_HD Vec3<T> Pos(int b) const { return pos[b]; }
+  EPA_HD Vec3<T> Tip(int l) const { return tip[l]; }
+  EPA_HD Vec3<T> Rot(int k) const { return rot[k]; }
+  EPA_HD Vec3<T> AnkleAxis(int l) const { return ankle[l]; }
+};
+
+// ---- per-lane LDS block of a forward pass ---------------------------------------
+// The solver's working set (M 81 + H 81 + geometry 60 + rows + five 14-vectors)
+// is far beyond 512 registers in fp64, and a first version that kept it all in
+// "registers" moved 24 GB of scratch per launch.  M and the geometry are written
+// once per forward pass and only read afterwards, so they live in LDS
+// (slot-major [slot][lane]: conflict free, lane-private => no barriers needed):
+//   slots [0, 81)    structurally non-zero entries of M (MSlot)
+//   slots [81, 141)  AntGeo (pos 27, tip 12, rot 9, ankle 12)
+// fp64: 141 * 64 * 8 B = 72 KB per wave (2 waves per CU); fp32: 36 KB (4 per CU).
+EPA_HD constexpr int MSlot(int i, int j) {  // i <= j, NZ(i, j)
+  int n = 0;
+  for (int jj = 0; jj < kNV; ++jj) {
+    for (int ii = 0; ii <= jj; ++ii) {
+      if (ii == i && jj == j) return n;
+      if (NZ(ii, jj)) ++n;
+    }
+  }
+  return n;
+}
+constexpr int kMSlots = MSlot(kNV - 1, kNV - 1) + 1;  // 81
+constexpr int kGeoBase = kMSlots;
+constexpr int kGeoPos = kGeoBase, kGeoTip = kGeoPos + 3 * kNB, kGeoRot = kGeoTip + 3 * kNLeg,
+              kGeoAnkle = kGeoRot + 9;
+constexpr int kAntLdsSlots = kGeoAnkle + 3 * kNLeg;  // 141
+
+// Compiler-level fence: LDS contents must not be carried in registers across it
+// (otherwise the loads get hoisted out of the solver loops / forwarded from the
+// stores and everything lands in VGPRs -> scratch again).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EPA_LDS_FENCE() asm volatile("" ::: "memory")
+#else
+#define EPA_LDS_FENCE() ((void)0)
+#endif
+
+template <typename T, typename Lds>
+struct AntGeoLds {
+  Lds& lds;
+  EPA_HD Vec3<T> At(int base) const { return {lds(base), lds(base + 1), lds(base + 2)}; }
+  EPA_HD Vec3<T> Pos(int b) const { return At(kGeoPos + 3 * b); }
+  EPA_HD Vec3<T> Tip(int l) const { return At(kGeoTip + 3 * l); }
+  EPA_HD Vec3<T> Rot(int k) const { return At(kGeoRot + 3 * k); }
+  EPA_HD Vec3<T> AnkleAxis(int l) const { return At(kGeoAnkle + 3 * l); }
 };
 
 template <typename T>
@@ -451,39 +498,78 @@ EPA_HD void AntMakeGeo(const AntModel<T>& m, const AntPos<T>& p, AntGeo<T>& g) {
 }
 
 // world centre of end sphere s (runtime, wave uniform) known to sit on body B
-template <int B, typename T>
-EPA_HD Vec3<T> SphCenter(const AntGeo<T>& g, int s) {
+template <int B, typename G>
+EPA_HD auto SphCenter(const G& g, int s) -> decltype(g.Pos(0)) {
   const int l = (s - 1) / 6, w = (s - 1) % 6;
   if constexpr (B == 0) {
-    if (s == 0 || w == 1) return g.pos[0];
-    Vec3<T> c = g.pos[Aux(0)];
-    if (l == 1) c = g.pos[Aux(1)];
-    if (l == 2) c = g.pos[Aux(2)];
-    if (l == 3) c = g.pos[Aux(3)];
-    return c;
+    // s is wave uniform: scalar branches
+    if (s == 0 || w == 1) return g.Pos(0);
+    if (l == 1) return g.Pos(Aux(1));
+    if (l == 2) return g.Pos(Aux(2));
+    if (l == 3) return g.Pos(Aux(3));
+    return g.Pos(Aux(0));
   } else if constexpr ((B & 1) == 1) {  // aux_l: leg capsule aux -> foot
-    return w == 2 ? g.pos[B + 1] : g.pos[B];
+    if (w == 2) return g.Pos(B + 1);
+    return g.Pos(B);
   } else {  // foot_l: ankle capsule foot -> tip
-    return w == 4 ? g.tip[(B - 2) / 2] : g.pos[B];
+    if (w == 4) return g.Tip((B - 2) / 2);
+    return g.Pos(B);
   }
+}
+
+// Publishes M and the geometry of a forward pass into the lane's LDS block and
+// returns the set of end spheres (bit s) that are within the contact margin on
+// any lane of the wave; the solver passes only visit those.
+template <typename T, typename Lds>
+EPA_HD unsigned AntPublish(const AntModel<T>& m, const AntPos<T>& p, Lds&& lds) {
+  static_for<0, kNV>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    static_for<0, j + 1>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (NZ(i, j)) {
+        constexpr int slot = MSlot(i, j);  // forced compile-time evaluation
+        lds(slot) = p.M[Tri(i, j)];
+      }
+    });
+  });
+  AntGeo<T> g;
+  AntMakeGeo(m, p, g);
+  auto put = [&](int base, Vec3<T> v) {
+    lds(base) = v.x;
+    lds(base + 1) = v.y;
+    lds(base + 2) = v.z;
+  };
+  static_for<0, kNB>([&](auto bc) { put(kGeoPos + 3 * decltype(bc)::value, g.pos[decltype(bc)::value]); });
+  static_for<0, kNLeg>([&](auto lc) {
+    put(kGeoTip + 3 * decltype(lc)::value, g.tip[decltype(lc)::value]);
+    put(kGeoAnkle + 3 * decltype(lc)::value, g.ankle[decltype(lc)::value]);
+  });
+  static_for<0, 3>([&](auto kc) { put(kGeoRot + 3 * decltype(kc)::value, g.rot[decltype(kc)::value]); });
+  unsigned mask = 0;
+  static_for<0, kNSph>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    const T z = SphCenter<SphBody(s)>(g, s).z;
+    if (WaveAny(z - m.sph_r[s] < m.margin)) mask |= 1u << s;
+  });
+  return WaveUniform(mask);
 }
 
 // columns of the point Jacobian (3 x nv) of `cp` attached to body B:
 // f(j, col) for every chain dof j with col = d(point velocity)/d(qdot_j).
-template <int B, typename T, typename F>
-EPA_HD void ForChainCols(const AntGeo<T>& g, Vec3<T> cp, F&& f) {
+template <int B, typename G, typename T, typename F>
+EPA_HD void ForChainCols(const G& g, Vec3<T> cp, F&& f) {
   f(IC<0>{}, Vec3<T>{T(1), T(0), T(0)});
   f(IC<1>{}, Vec3<T>{T(0), T(1), T(0)});
   f(IC<2>{}, Vec3<T>{T(0), T(0), T(1)});
   static_for<0, 3>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    f(IC<3 + k>{}, Cross(g.rot[k], cp - g.pos[0]));
+    f(IC<3 + k>{}, Cross(g.Rot(k), cp - g.Pos(0)));
   });
   if constexpr (B > 0) {
     constexpr int l = (B - 1) / 2;
-    f(IC<Hip(l)>{}, Cross(g.rot[2], cp - g.pos[Aux(l)]));
+    f(IC<Hip(l)>{}, Cross(g.Rot(2), cp - g.Pos(Aux(l))));
     if constexpr (B == Foot(l)) {
-      f(IC<Ankle(l)>{}, Cross(g.ankle[l], cp - g.pos[Foot(l)]));
+      f(IC<Ankle(l)>{}, Cross(g.AnkleAxis(l), cp - g.Pos(Foot(l))));
     }
   }
 }
@@ -504,10 +590,10 @@ EPA_HD void AntMakeConstraint(const AntModel<T>& m, const AntPos<T>& p, const T*
     const T sgn = dlo < T(0) ? T(1) : (dhi < T(0) ? T(-1) : T(0));
     const T dist = dlo < T(0) ? dlo : (dhi < T(0) ? dhi : T(0));
     T imp = Impedance(m.imp_d0, m.imp_dmax, m.imp_width, dist);
-    T R = (T(1) - imp) * m.dof_invw[j] / imp;
-    R = R < kMinVal ? kMinVal : R;
+    const T num = (T(1) - imp) * m.dof_invw[j];  // R = max(mjMINVAL, num / imp)
+    const T Dj = num < kMinVal * imp ? T(1) / kMinVal : imp / num;
     r.lim_sgn[j] = sgn;
-    r.lim_D[j] = sgn != T(0) ? T(1) / R : T(0);
+    r.lim_D[j] = sgn != T(0) ? Dj : T(0);
     r.lim_aref[j] = -m.con_B * (sgn * v[6 + j]) - m.con_K * imp * dist;
   });
 }
@@ -536,8 +622,8 @@ EPA_HD void DispatchBody(int b, F&& f) {
 // One contact candidate (end sphere s on body B), re-derived from the body
 // pose each time it is needed instead of being stored: mj_collision
 // (plane-sphere) + mj_instantiateContact + mj_makeImpedance for that sphere.
-// Returns false when no lane of the wave has the sphere inside the margin;
-// otherwise every lane gets a contact, with D = 0 (=> zero weight in every
+// Only called for spheres inside the margin on some lane of the wave (the mask
+// of AntPublish): every lane gets a contact, with D = 0 (=> zero weight in every
 // row) on the lanes where the sphere is outside.  Like the planar solver
 // (mj_cheetah.cuh, WaveAny) nothing below branches per lane.
 template <typename T>
@@ -545,13 +631,12 @@ struct AntContact {
   Vec3<T> cp;
   T an, ay, ax, D;
 };
-template <int B, typename T>
-EPA_HD bool AntMakeContact(const AntModel<T>& m, const AntGeo<T>& p, const T* v, int s,
+template <int B, typename T, typename G>
+EPA_HD void AntMakeContact(const AntModel<T>& m, const G& p, const T* v, int s,
                            AntContact<T>& c) {
   Vec3<T> w = SphCenter<B>(p, s);
   T dist = w.z - m.sph_r[s];
   const bool touch = dist < m.margin;
-  if (!WaveAny(touch)) return false;
   c.cp = {w.x, w.y, T(0.5) * dist};
   Vec3<T> vel = {T(0), T(0), T(0)};
   ForChainCols<B>(p, c.cp, [&](auto jc, Vec3<T> col) {
@@ -560,13 +645,12 @@ EPA_HD bool AntMakeContact(const AntModel<T>& m, const AntGeo<T>& p, const T* v,
   T rr = dist - m.margin;
   T imp = Impedance(m.imp_d0, m.imp_dmax, m.imp_width, rr);
   T diag = m.geom_body_invw[SphGeomBody(s)] * (T(1) + m.mu * m.mu);
-  T R = (T(1) - imp) * diag / imp;
-  R = R < T(1e-15) ? T(1e-15) : R;
-  c.D = touch ? T(1) / (T(2) * m.mu * m.mu * R) : T(0);
+  const T num = (T(1) - imp) * diag;  // R = max(mjMINVAL, num / imp), D_py = 1 / (2 mu^2 R)
+  const T invR = num < T(1e-15) * imp ? T(1e15) : imp / num;
+  c.D = touch ? invR * (T(1) / (T(2) * m.mu * m.mu)) : T(0);
   c.an = touch ? -m.con_B * vel.z - m.con_K * imp * rr : T(0);
   c.ay = touch ? m.con_B * m.mu * vel.y : T(0);
   c.ax = touch ? m.con_B * m.mu * vel.x : T(0);
-  return true;
 }
 
 // the four pyramidal rows of a contact in terms of (jx, jy, jz) = J a:
@@ -580,8 +664,8 @@ EPA_HD void ContactJar(const AntModel<T>& m, Vec3<T> ja, T an, T ay, T ax, T* ja
   jar[3] = ja.z + m.mu * ja.x - (an - ax);
 }
 
-template <bool kHess, typename T>
-EPA_HD void AntRowsPass(const AntModel<T>& m, const AntGeo<T>& p, const AntRows<T>& r,
+template <bool kHess, typename T, typename G>
+EPA_HD void AntRowsPass(const AntModel<T>& m, const G& p, unsigned sph, const AntRows<T>& r,
                         const T* v, const T* a, T* grad, T* H, unsigned long long* mask0,
                         unsigned long long* mask1) {
   unsigned long long m0 = 0, m1 = 0;
@@ -595,11 +679,13 @@ EPA_HD void AntRowsPass(const AntModel<T>& m, const AntGeo<T>& p, const AntRows<
     m0 |= (on ? 1ull : 0ull) << j;
   });
   EPA_ANT_NO_UNROLL
-  for (int s = 0; s < kNSph; ++s) {
+  for (unsigned rem = sph; rem != 0; rem &= rem - 1) {  // scalar loop over touching spheres
+    const int s = __builtin_ctz(rem);
+    EPA_LDS_FENCE();
     DispatchBody(SphBody(s), [&](auto bc) {
       constexpr int b = decltype(bc)::value;
       AntContact<T> c;
-      if (!AntMakeContact<b>(m, p, v, s, c)) return;
+      AntMakeContact<b>(m, p, v, s, c);
       Vec3<T> ja = {T(0), T(0), T(0)};
       ForChainCols<b>(p, c.cp, [&](auto jc, Vec3<T> col) {
         ja = ja + col * a[decltype(jc)::value];
@@ -647,8 +733,8 @@ EPA_HD void AntRowsPass(const AntModel<T>& m, const AntGeo<T>& p, const AntRows<
   *mask1 = m1;
 }
 
-template <typename T>
-EPA_HD void AntLineEval(const AntModel<T>& m, const AntGeo<T>& p, const AntRows<T>& r,
+template <typename T, typename G>
+EPA_HD void AntLineEval(const AntModel<T>& m, const G& p, unsigned sph, const AntRows<T>& r,
                         const T* v, const T* a, const T* s, T alpha, T* d1, T* d2) {
   static_for<0, kNU>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
@@ -660,11 +746,13 @@ EPA_HD void AntLineEval(const AntModel<T>& m, const AntGeo<T>& p, const AntRows<
     *d2 += w * jv * jv;
   });
   EPA_ANT_NO_UNROLL
-  for (int sidx = 0; sidx < kNSph; ++sidx) {
+  for (unsigned rem = sph; rem != 0; rem &= rem - 1) {  // scalar loop over touching spheres
+    const int sidx = __builtin_ctz(rem);
+    EPA_LDS_FENCE();
     DispatchBody(SphBody(sidx), [&](auto bc) {
       constexpr int b = decltype(bc)::value;
       AntContact<T> c;
-      if (!AntMakeContact<b>(m, p, v, sidx, c)) return;
+      AntMakeContact<b>(m, p, v, sidx, c);
       Vec3<T> ja = {T(0), T(0), T(0)}, js = {T(0), T(0), T(0)};
       ForChainCols<b>(p, c.cp, [&](auto jc, Vec3<T> col) {
         ja = ja + col * a[decltype(jc)::value];
@@ -685,10 +773,29 @@ EPA_HD void AntLineEval(const AntModel<T>& m, const AntGeo<T>& p, const AntRows<
   }
 }
 
-template <typename T>
-EPA_HD int AntSolve(const AntModel<T>& m, const AntGeo<T>& p, const T* M,
+// y = M x with M read from the lane's LDS block
+template <typename T, typename Lds>
+EPA_HD void SymMulLds(Lds&& lds, const T* x, T* y) {
+  static_for<0, kNV>([&](auto ic) { y[decltype(ic)::value] = T(0); });
+  static_for<0, kNV>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    static_for<0, j + 1>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (NZ(i, j)) {
+        constexpr int slot = MSlot(i, j);
+        const T mij = lds(slot);
+        y[i] += mij * x[j];
+        if constexpr (i != j) y[j] += mij * x[i];
+      }
+    });
+  });
+}
+
+template <typename T, typename Lds>
+EPA_HD int AntSolve(const AntModel<T>& m, Lds&& lds, unsigned sph,
                     const AntRows<T>& r, const T* v, const T* qfrc_smooth,
                     const SolverCfg<T>& cfg, T* qacc) {
+  const AntGeoLds<T, typename std::remove_reference<Lds>::type> p{lds};
   T fs = T(0);
   static_for<0, kNV>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -697,30 +804,41 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntGeo<T>& p, const T* M,
   });
   const T gstop = cfg.gtol * (T(1) + fs);
   const T gfloor = (sizeof(T) == 4 ? T(1e-4) : T(1e-9)) * (T(1) + fs);
-  T prev_gn = T(-1);
+  const T gstop2 = gstop * gstop, gfloor2 = gfloor * gfloor;
+  T prev_gn2 = T(-1);
   unsigned long long pm0 = ~0ull, pm1 = ~0ull;
+  T Ma[kNV];  // M qacc, kept current incrementally (Ma += alpha * M s)
+  SymMulLds(lds, qacc, Ma);
   bool full_step = false;
   bool live = true;  // this lane is still iterating (finished lanes keep a frozen qacc)
   int iter = 0;
   for (int it = 0; it < cfg.max_iter; ++it) {
-    T H[kTri], Ma[kNV], grad[kNV];
-    static_for<0, kTri>([&](auto kc) { H[decltype(kc)::value] = M[decltype(kc)::value]; });
-    SymMul(M, qacc, Ma);
+    T H[kTri], grad[kNV];
+    EPA_LDS_FENCE();
+    static_for<0, kNV>([&](auto jc) {  // H = M (structural non-zeros only)
+      constexpr int j = decltype(jc)::value;
+      static_for<0, j + 1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (NZ(i, j)) {
+          constexpr int slot = MSlot(i, j);
+          H[Tri(i, j)] = lds(slot);
+        }
+      });
+    });
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       grad[i] = Ma[i] - qfrc_smooth[i];
     });
     unsigned long long m0, m1;
-    AntRowsPass<true>(m, p, r, v, qacc, grad, H, &m0, &m1);
-    T gn = T(0);
-    static_for<0, kNV>([&](auto ic) { gn += grad[decltype(ic)::value] * grad[decltype(ic)::value]; });
-    gn = Sqrt(gn);
-    const bool stop = gn <= gstop || (full_step && m0 == pm0 && m1 == pm1) ||
-                      (prev_gn >= T(0) && gn <= gfloor && gn >= T(0.25) * prev_gn);
+    AntRowsPass<true>(m, p, sph, r, v, qacc, grad, H, &m0, &m1);
+    T gn2 = T(0);
+    static_for<0, kNV>([&](auto ic) { gn2 += grad[decltype(ic)::value] * grad[decltype(ic)::value]; });
+    const bool stop = gn2 <= gstop2 || (full_step && m0 == pm0 && m1 == pm1) ||
+                      (prev_gn2 >= T(0) && gn2 <= gfloor2 && gn2 >= T(0.0625) * prev_gn2);
     live = live && !stop;
     if (!WaveAny(live)) break;
     iter += live ? 1 : 0;
-    prev_gn = gn;
+    prev_gn2 = gn2;
     pm0 = m0;
     pm1 = m1;
     T s[kNV];
@@ -728,7 +846,8 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntGeo<T>& p, const T* M,
     FactorUUt(H);
     SolveUUt(H, s);
     T Ms[kNV];
-    SymMul(M, s, Ms);
+    EPA_LDS_FENCE();
+    SymMulLds(lds, s, Ms);
     T g1 = T(0), g2 = T(0);
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
@@ -742,7 +861,7 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntGeo<T>& p, const T* M,
     bool searching = live;
     for (int ls = 0; ls < 24; ++ls) {
       T d1 = g1 + alpha * g2, d2 = g2;
-      AntLineEval(m, p, r, v, qacc, s, alpha, &d1, &d2);
+      AntLineEval(m, p, sph, r, v, qacc, s, alpha, &d1, &d2);
       const T ad1 = d1 < T(0) ? -d1 : d1;
       const bool hit = ad1 <= ls_tol;
       full_step = full_step || (searching && hit && ls == 0);
@@ -760,6 +879,7 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntGeo<T>& p, const T* M,
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       qacc[i] += step * s[i];
+      Ma[i] += step * Ms[i];
     });
   }
   return iter;
@@ -767,22 +887,23 @@ EPA_HD int AntSolve(const AntModel<T>& m, const AntGeo<T>& p, const T* M,
 
 // mj_forward: qacc for state (q, v) under ctrl; `warm` is qacc_warmstart in/out.
 // Returns Newton iterations.  q's quaternion is normalised in place.
-template <typename T>
+template <typename T, typename Lds>
 EPA_HD int AntForward(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, const T* v,
-                      const T* ctrl, T* warm, T* qacc) {
-  T qfrc_smooth[kNV], M[kTri];
-  AntGeo<T> geo;
+                      const T* ctrl, T* warm, T* qacc, Lds&& lds) {
+  T qfrc_smooth[kNV];
   AntRows<T> rows;
+  unsigned sph;
   {
     AntPos<T> p;  // full kinematics only lives until the solver starts
     AntKinematics(m, q, p);
     AntSmoothForces(m, p, v, ctrl, qfrc_smooth);
     AntMakeConstraint(m, p, q, v, rows);
-    AntMakeGeo(m, p, geo);
-    static_for<0, kTri>([&](auto kc) { M[decltype(kc)::value] = p.M[decltype(kc)::value]; });
+    EPA_LDS_FENCE();
+    sph = AntPublish(m, p, lds);
+    EPA_LDS_FENCE();
   }
   static_for<0, kNV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
-  int it = AntSolve(m, geo, M, rows, v, qfrc_smooth, cfg, qacc);
+  int it = AntSolve(m, lds, sph, rows, v, qfrc_smooth, cfg, qacc);
   static_for<0, kNV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
   return it;
 }
@@ -820,9 +941,9 @@ EPA_HD void AntIntegratePos(T* q, const T* dq, T h) {
 // One mj_step with integrator RK4 (mj_RungeKutta(4)).  On return q, v are the
 // new state and (lagx, lagy) the torso xpos of the LAST forward evaluation
 // (stage 4), which is what data_->xpos holds afterwards (ant.h:169-173).
-template <typename T>
+template <typename T, typename Lds>
 EPA_HD int AntStep(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, T* v, T* warm,
-                   const T* ctrl, T* lagx, T* lagy) {
+                   const T* ctrl, T* lagx, T* lagy, Lds&& lds) {
   const T h = m.timestep;
   T q0[kNQ], v0[kNV], qs[kNQ], vs[kNV];
   T F[kNV], dq[kNV], dv[kNV];     // running B-weighted sums
@@ -831,7 +952,7 @@ EPA_HD int AntStep(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, T* v, T*
   static_for<0, kNQ>([&](auto ic) { q0[decltype(ic)::value] = q[decltype(ic)::value]; });
   static_for<0, kNV>([&](auto ic) { v0[decltype(ic)::value] = v[decltype(ic)::value]; });
   // stage 1 at (q0, v0)
-  it += AntForward(m, cfg, q, v, ctrl, warm, F);
+  it += AntForward(m, cfg, q, v, ctrl, warm, F, lds);
   static_for<0, kNQ>([&](auto ic) { q0[decltype(ic)::value] = q[decltype(ic)::value]; });  // normalised quat
   static_for<0, kNV>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -852,7 +973,7 @@ EPA_HD int AntStep(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, T* v, T*
     });
     static_for<0, kNQ>([&](auto ic) { qs[decltype(ic)::value] = q0[decltype(ic)::value]; });
     AntIntegratePos(qs, step_dq, h);
-    it += AntForward(m, cfg, qs, vs, ctrl, warm, F);
+    it += AntForward(m, cfg, qs, vs, ctrl, warm, F, lds);
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       dq[i] += bw * vs[i];

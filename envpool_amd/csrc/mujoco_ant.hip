@@ -46,6 +46,10 @@ __global__ __launch_bounds__(kAntBlock) void AntStepKernel(
     AntDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action,
     OutPtrs out, AntTask task, mj::SolverCfg<T> scfg) {
   constexpr A::AntModel<T> m = A::CastAntModel<T>(kAntModelConst);
+  // lane-private LDS block [slot][lane]: M and the contact geometry of the
+  // current forward pass (mj_ant.cuh, AntPublish)
+  __shared__ T lds_buf[A::kAntLdsSlots * kAntBlock];
+  const int lane = threadIdx.x;
   const int n = cm.n;
   const int row = blockIdx.x * kAntBlock + threadIdx.x;
   if (row >= a.k) return;
@@ -108,8 +112,9 @@ __global__ __launch_bounds__(kAntBlock) void AntStepKernel(
       ctrl[i] = (T)(ai < -1.0 ? -1.0 : (ai > 1.0 ? 1.0 : ai));
     });
     T lagx = T(0), lagy = T(0);
+    auto lds = [&](int slot) -> T& { return lds_buf[slot * kAntBlock + lane]; };
     for (int s = 0; s < task.frame_skip; ++s) {
-      A::AntStep(m, scfg, q, v, w, ctrl, &lagx, &lagy);
+      A::AntStep(m, scfg, q, v, w, ctrl, &lagx, &lagy, lds);
     }
     const double x_after = (double)lagx, y_after = (double)lagy;
     bool healthy = true;  // IsHealthy, ant.h:214-229

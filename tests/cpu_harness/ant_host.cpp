@@ -18,7 +18,9 @@ static void Run(const double* q, const double* v, const double* warm, const doub
   }
   for (int i = 0; i < kNU; ++i) tc[i] = (T)(ctrl[i] < -1 ? -1 : (ctrl[i] > 1 ? 1 : ctrl[i]));
   int it = 0;
-  for (int s = 0; s < nsub; ++s) it += AntStep(m, cfg, tq, tv, tw, tc, &lx, &ly);
+  T lds_block[kAntLdsSlots];
+  auto lds = [&](int slot) -> T& { return lds_block[slot]; };
+  for (int s = 0; s < nsub; ++s) it += AntStep(m, cfg, tq, tv, tw, tc, &lx, &ly, lds);
   for (int i = 0; i < kNQ; ++i) qo[i] = tq[i];
   for (int i = 0; i < kNV; ++i) {
     vo[i] = tv[i];
