@@ -133,14 +133,17 @@ def main():
         value = total_env_steps / elapsed
         # algorithmic bytes / env-step: action+ids
         # in, every state key out, persistent fp64 state read + written
-        alg_bytes = {"HalfCheetah": 708, "Ant": 1132}[args.task]
+        alg_bytes = {"HalfCheetah": 708, "Ant": 1132, "Walker2d": 692}[args.task]
+        frame_skip = {"HalfCheetah": 5, "Ant": 5, "Walker2d": 4}[args.task]
         # counted fp32 flops / env-step from the kernel's ISA
         achieved_gbs = alg_bytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # HBM traffic and flop counts come from the committed rocprofv3 PMC passes of
         # this same command (tools/profile_bench.sh -> profiles/r1_pmc.json): PMC
         # collection needs its own rocprofv3 runs and cannot happen inside the bench.
-        kname = ("CheetahStepKernel" if args.task == "HalfCheetah" else "AntStepKernel") + \
-            ("<double>" if args.precision == "fp64" else "<float>")
+        kbase = "AntStepKernel" if args.task == "Ant" else "CheetahStepKernel"
+        kname = kbase + ("<double>" if args.precision == "fp64" else "<float>")
+        if args.task == "Walker2d":
+            kname += "[Walker2d]"
         pmc = {}
         try:
             with open(os.path.join(ROOT, "profiles", "r1_pmc.json")) as f:
@@ -170,10 +173,10 @@ def main():
             "dtype": "f32" if args.precision == "fp32" else "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.task}-v4 num_envs={n} per GPU, frame_skip=5, "
+                "workload": f"{args.task}-v4 num_envs={n} per GPU, frame_skip={frame_skip}, "
                             "uniform random actions resident in HBM, auto-reset on",
                 "num_envs_per_gpu": n,
-                "frames_per_sec": value * 5,
+                "frames_per_sec": value * frame_skip,
                 "sharding": f"env ids sharded over {world} GPU(s), no collective",
             },
             "roofline": {
@@ -184,7 +187,7 @@ def main():
                 "frac": achieved_gbs / 8000.0,
                 "traffic": traffic,
                 "valu": valu,
-                "kernel": "CheetahStepKernel" if args.task == "HalfCheetah" else "AntStepKernel",
+                "kernel": kbase,
                 "kernel_ms": kernel_ms,
                 "launches": launches,
                 "algorithmic_bytes_per_env_step": alg_bytes,

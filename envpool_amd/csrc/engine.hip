@@ -489,7 +489,7 @@ const std::vector<std::string>& FamilyNames() {
   static const std::vector<std::string> names = {
       "CartPole", "Pendulum", "MountainCar", "MountainCarContinuous", "Acrobot",
       "Catch", "FrozenLake", "Taxi", "NChain", "CliffWalking", "Blackjack",
-      "HalfCheetah", "Ant"};
+      "HalfCheetah", "Ant", "Walker2d"};
   return names;
 }
 

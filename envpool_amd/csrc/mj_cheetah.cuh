@@ -167,12 +167,12 @@ struct CheetahModel {
   T mass[kNB], iyy[kNB]; // mass, inertia about y through the body COM
   T cx[kNB], cz[kNB];    // body COM in the body frame
   T ex[kNEnd], ez[kNEnd];  // capsule end-sphere centres in the body frame
-  T radius;
+  T er[kNEnd];           // their radii (unused slots: -1e30, can never touch)
   T stiff[kNU], damp[kNU], arm[kNU], lo[kNU], hi[kNU], gear[kNU];
   T dof_invw[kNU];       // dof_invweight0 of the hinges
   T body_invw[kNB];      // body_invweight0 (translational)
   T total_mass;
-  T mu;                  // sliding friction of the pair
+  T bmu[kNB];            // sliding friction of the floor/geom pair, per body
   T con_K, con_B;        // contact reference: aref = -B vel - K imp (pos-margin)
   T con_d0, con_dmax, con_width;
   T lim_K, lim_B, lim_d0, lim_dmax, lim_width;
@@ -534,7 +534,7 @@ EPA_HD unsigned CheetahMakeConstraint(const CheetahModel<T>& m,
     constexpr int b = EndBody(e);
     T wx = p.px[b] + p.cs[b] * m.ex[e] + p.sn[b] * m.ez[e];
     T wz = p.pz[b] - p.sn[b] * m.ex[e] + p.cs[b] * m.ez[e];
-    T dist = wz - m.radius;
+    T dist = wz - m.er[e];
     T D = T(0), cpx = wx, cpz = T(0.5) * dist, an = T(0), ax = T(0);
     const bool touch = dist < T(0);
     if (WaveAny(touch)) {
@@ -547,12 +547,12 @@ EPA_HD unsigned CheetahMakeConstraint(const CheetahModel<T>& m,
       });
       T imp = Impedance(m.con_d0, m.con_dmax, m.con_width, dist);
       // diagApprox (pyramidal) = tran (1 + mu^2); R_py = 2 mu^2 R
-      T diag = m.body_invw[b] * (T(1) + m.mu * m.mu);
+      T diag = m.body_invw[b] * (T(1) + m.bmu[b] * m.bmu[b]);
       const T num = (T(1) - imp) * diag;  // R = max(mjMINVAL, num / imp)
       const T invR = num < kMinVal * imp ? T(1) / kMinVal : imp / num;
-      D = touch ? invR * (T(1) / (T(2) * m.mu * m.mu)) : T(0);
+      D = touch ? invR * (T(1) / (T(2) * m.bmu[b] * m.bmu[b])) : T(0);
       an = touch ? -m.con_B * vn - m.con_K * imp * dist : T(0);
-      ax = touch ? m.con_B * m.mu * vx : T(0);
+      ax = touch ? m.con_B * m.bmu[b] * vx : T(0);
     }
     lds(e * kSlotsPerEnd + 0) = cpx;
     lds(e * kSlotsPerEnd + 1) = cpz;
@@ -598,9 +598,10 @@ EPA_HD unsigned long long CheetahRowsPass(const CheetahModel<T>& m,
       });
       // rows: 2 x (Jn), (Jn - mu Jx), (Jn + mu Jx); D == 0 for lanes not in
       // contact, which zeroes every weight below
+      const T mu = m.bmu[b];
       const T jar1 = jna - an;
-      const T jar2 = jna - m.mu * jxa - (an + ax);
-      const T jar3 = jna + m.mu * jxa - (an - ax);
+      const T jar2 = jna - mu * jxa - (an + ax);
+      const T jar3 = jna + mu * jxa - (an - ax);
       const bool on = D > T(0);
       const bool a1 = on && jar1 < T(0), a2 = on && jar2 < T(0), a3 = on && jar3 < T(0);
       const T w1 = a1 ? T(2) * D : T(0);
@@ -610,8 +611,8 @@ EPA_HD unsigned long long CheetahRowsPass(const CheetahModel<T>& m,
       mask |= (a2 ? 1ull : 0ull) << (7 + 3 * e);
       mask |= (a3 ? 1ull : 0ull) << (8 + 3 * e);
       const T gn = w1 * jar1 + w2 * jar2 + w3 * jar3;   // coefficient of Jn
-      const T gx = m.mu * (w3 * jar3 - w2 * jar2);      // coefficient of Jx
-      const T A = w1 + w2 + w3, Bc = m.mu * (w3 - w2), C = m.mu * m.mu * (w2 + w3);
+      const T gx = mu * (w3 * jar3 - w2 * jar2);      // coefficient of Jx
+      const T A = w1 + w2 + w3, Bc = mu * (w3 - w2), C = mu * mu * (w2 + w3);
       if (WaveAny(A > T(0))) {
         ForChainCols<b>(p, cpx, cpz, [&](auto ic, T jni, T jxi) {
           constexpr int i = decltype(ic)::value;
@@ -660,9 +661,10 @@ EPA_HD void CheetahLineEval(const CheetahModel<T>& m, const CheetahPos<T>& p,
         jns += jn * s[j];
         jxs += jx * s[j];
       });
+      const T mu = m.bmu[b];
       const T jar1 = jna - an, jv1 = jns;
-      const T jar2 = jna - m.mu * jxa - (an + ax), jv2 = jns - m.mu * jxs;
-      const T jar3 = jna + m.mu * jxa - (an - ax), jv3 = jns + m.mu * jxs;
+      const T jar2 = jna - mu * jxa - (an + ax), jv2 = jns - mu * jxs;
+      const T jar3 = jna + mu * jxa - (an - ax), jv3 = jns + mu * jxs;
       const T x1 = jar1 + alpha * jv1, x2 = jar2 + alpha * jv2, x3 = jar3 + alpha * jv3;
       // D == 0 for lanes not in contact
       const T c1 = x1 < T(0) ? T(2) * D : T(0);
@@ -790,6 +792,77 @@ EPA_HD int CheetahSolve(const CheetahModel<T>& m, const CheetahPos<T>& p,
     });
   }
   return iter;
+}
+
+// mj_forward: qacc at (q, v) under ctrl; `warm` is qacc_warmstart in/out.
+// Returns the number of Newton iterations.
+template <typename T, typename Lds>
+EPA_HD int PlanarForward(const CheetahModel<T>& m, const SolverCfg<T>& cfg, const T* q,
+                         const T* v, T* warm, const T* ctrl, Lds&& lds, T* qacc) {
+  CheetahPos<T> p;
+  CheetahKinematics(m, q, p);
+  T qfrc_smooth[kNV];
+  CheetahSmoothForces(m, p, q, v, ctrl, qfrc_smooth);
+  LimitRows<T> lim;
+  const unsigned ends = CheetahMakeConstraint(m, p, q, v, lim, lds);
+  T Ma[kNV], grad[kNV];
+  static_for<0, kNV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
+  int iters = CheetahSolve(m, p, lim, lds, ends, qfrc_smooth, cfg, qacc, Ma, grad);
+  static_for<0, kNV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
+  return iters;
+}
+
+// One mj_step with integrator RK4 (mj_RungeKutta(4)), the Walker2d setting
+// (walker2d_envpool.xml:29): four forward evaluations per step, plain explicit
+// damping (no eulerdamp).  Same scheme as ant::AntStep, without quaternions.
+template <typename T, typename Lds>
+EPA_HD int PlanarStepRK4(const CheetahModel<T>& m, const SolverCfg<T>& cfg, T* q, T* v,
+                         T* warm, const T* ctrl, Lds&& lds) {
+  const T h = m.timestep;
+  T q0[kNV], v0[kNV], qs[kNV], vs[kNV];
+  T F[kNV], dq[kNV], dv[kNV];  // running B-weighted sums
+  T Xv_prev[kNV], F_prev[kNV];
+  int it = PlanarForward(m, cfg, q, v, warm, ctrl, lds, F);  // stage 1 at (q0, v0)
+  static_for<0, kNV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    q0[i] = q[i];
+    v0[i] = v[i];
+    dq[i] = v0[i] * T(1.0 / 6.0);
+    dv[i] = F[i] * T(1.0 / 6.0);
+    Xv_prev[i] = v0[i];
+    F_prev[i] = F[i];
+  });
+  // stages 2..4: X_i = X_0 + h * a_i * (Xv_{i-1}, F_{i-1}), a = 1/2, 1/2, 1
+  for (int stage = 1; stage < 4; ++stage) {
+    const T a = stage == 3 ? T(1) : T(0.5);
+    const T bw = stage == 3 ? T(1.0 / 6.0) : T(1.0 / 3.0);
+    static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      qs[i] = q0[i] + h * (a * Xv_prev[i]);
+      vs[i] = v0[i] + h * a * F_prev[i];
+    });
+    it += PlanarForward(m, cfg, qs, vs, warm, ctrl, lds, F);
+    static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      dq[i] += bw * vs[i];
+      dv[i] += bw * F[i];
+      Xv_prev[i] = vs[i];
+      F_prev[i] = F[i];
+    });
+  }
+  static_for<0, kNV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    v[i] = v0[i] + h * dv[i];
+    q[i] = q0[i] + h * dq[i];
+  });
+  return it;
+}
+
+// Models sharing this kernel.  kSign[j] = -1 where the MJCF hinge rotates about
+// -y: the kernel integrates q' = sign * q (see BuildWalkerModel).
+enum PlanarModelId { kPlanarCheetah = 0, kPlanarWalker = 1, kPlanarWalkerV5 = 2 };
+EPA_HD constexpr int PlanarDofSign(int model, int j) {
+  return (model != kPlanarCheetah && j >= 3) ? -1 : 1;
 }
 
 // One mj_step.  q[0] is carried as a local offset (caller accumulates the

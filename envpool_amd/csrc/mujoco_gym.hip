@@ -22,6 +22,7 @@
 #include "mj_cheetah.cuh"
 #include "mj_cheetah_model.h"
 #include "build/mj_cheetah_consts.inc"  // generated: kCheetahModelConst (gen_mj_consts.cpp)
+#include "build/mj_walker_consts.inc"   // generated: kWalkerModelConst, kWalkerV5ModelConst
 
 namespace epa {
 namespace {
@@ -46,16 +47,33 @@ struct CheetahTask {
   int obs_skip;  // 1 if exclude_current_positions_from_observation
   double ctrl_cost_weight, forward_reward_weight, reset_noise_scale;
   double dt;     // frame_skip * timestep, computed in fp64 like the reference
+  // Walker2d only (walker2d.h:32-47)
+  double healthy_reward, healthy_z_min, healthy_z_max, healthy_angle_min,
+      healthy_angle_max, velocity_min, velocity_max;
+  int terminate_when_unhealthy, legacy_healthy_reward;
 };
+
+// compile-time model of the planar kernel instance (mj_cheetah.cuh, PlanarModelId)
+template <typename T, int kModel>
+constexpr CheetahModel<T> PlanarModel() {
+  if constexpr (kModel == mj::kPlanarCheetah) {
+    return mj::CastCheetahModel<T>(kCheetahModelConst);
+  } else if constexpr (kModel == mj::kPlanarWalker) {
+    return mj::CastCheetahModel<T>(kWalkerModelConst);
+  } else {
+    return mj::CastCheetahModel<T>(kWalkerV5ModelConst);
+  }
+}
 
 constexpr int kCheetahBlock = 64;
 
-template <typename T>
+template <typename T, int kModel>
 __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
     CheetahDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action,
     OutPtrs out, CheetahTask task, mj::SolverCfg<T> scfg) {
   // the MuJoCo model as compile-time constants (see gen_mj_consts.cpp)
-  constexpr CheetahModel<T> m = mj::CastCheetahModel<T>(kCheetahModelConst);
+  constexpr CheetahModel<T> m = PlanarModel<T, kModel>();
+  constexpr bool kWalker = kModel != mj::kPlanarCheetah;
   // per-contact constants [slot][lane]; read back with a runtime slot index in the
   // solver passes (see DispatchBody) so they stay in LDS instead of VGPRs/scratch
   __shared__ T lds_buf[mj::kLdsSlots * kCheetahBlock];
@@ -80,11 +98,16 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
     double saved = dev.nsaved[e];
     int avail = dev.navail[e];
     for (int i = 0; i < kNV; ++i) {
-      qpos[i] = 0.0 + g.UniformReal(-task.reset_noise_scale,
-                                    task.reset_noise_scale);
+      // init_qpos = qpos0: all zero but the Walker2d rootz ref (walker2d_envpool.xml:36)
+      const double q0 = (kWalker && i == 1) ? 1.25 : 0.0;
+      qpos[i] = q0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
     }
     for (int i = 0; i < kNV; ++i) {
-      qvel[i] = 0.0 + g.Normal(0.0, task.reset_noise_scale, &saved, &avail);
+      if constexpr (kWalker) {  // walker2d.h:119-126: uniform noise on qvel too
+        qvel[i] = 0.0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
+      } else {
+        qvel[i] = 0.0 + g.Normal(0.0, task.reset_noise_scale, &saved, &avail);
+      }
     }
     g.Commit();
     dev.nsaved[e] = saved;
@@ -99,10 +122,11 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
     T q[kNV], v[kNV], w[kNV], ctrl[kNU];
     mj::static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
+      constexpr double sg = mj::PlanarDofSign(kModel, i);  // hinge about -y: q' = -q
       qpos[i] = dev.qpos[(size_t)i * n + e];
-      q[i] = (T)qpos[i];
-      v[i] = (T)dev.qvel[(size_t)i * n + e];
-      w[i] = (T)dev.warm[(size_t)i * n + e];
+      q[i] = (T)(sg * qpos[i]);
+      v[i] = (T)(sg * dev.qvel[(size_t)i * n + e]);
+      w[i] = (T)(sg * dev.warm[(size_t)i * n + e]);
     });
     const double x_before = qpos[0];
     q[0] = T(0);
@@ -117,22 +141,39 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
     auto lds = [&](int slot) -> T& { return lds_buf[slot * kCheetahBlock + lane]; };
     int iters = 0;
     for (int s = 0; s < task.frame_skip; ++s) {  // mujoco_env.h:142-144
-      iters += mj::CheetahStep(m, scfg, q, v, w, ctrl, lds);
+      if constexpr (kWalker) {
+        iters += mj::PlanarStepRK4(m, scfg, q, v, w, ctrl, lds);
+      } else {
+        iters += mj::CheetahStep(m, scfg, q, v, w, ctrl, lds);
+      }
     }
     dev.iters[e] = iters;
     const double x_after = x_before + (double)q[0];
     xv = (x_after - x_before) / task.dt;  // half_cheetah.h:148-149
-    reward = static_cast<float>(xv * task.forward_reward_weight - ctrl_cost);
-    done = cur >= a.max_episode_steps;  // ++elapsed_step_ >= max_episode_steps_
     qpos[0] = x_after;
     mj::static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      if constexpr (i > 0) qpos[i] = (double)q[i];
-      qvel[i] = (double)v[i];
+      constexpr double sg = mj::PlanarDofSign(kModel, i);
+      if constexpr (i > 0) qpos[i] = sg * (double)q[i];
+      qvel[i] = sg * (double)v[i];
       dev.qpos[(size_t)i * n + e] = qpos[i];
       dev.qvel[(size_t)i * n + e] = qvel[i];
-      dev.warm[(size_t)i * n + e] = (double)w[i];
+      dev.warm[(size_t)i * n + e] = sg * (double)w[i];
     });
+    if constexpr (kWalker) {  // walker2d.h:162-177,181-190
+      const bool healthy = !(qpos[1] < task.healthy_z_min || qpos[1] > task.healthy_z_max ||
+                             qpos[2] < task.healthy_angle_min ||
+                             qpos[2] > task.healthy_angle_max);
+      bool give = healthy;
+      if (task.legacy_healthy_reward) give = task.terminate_when_unhealthy || healthy;
+      const double healthy_reward = give ? task.healthy_reward : 0.0;
+      reward = static_cast<float>(xv * task.forward_reward_weight + healthy_reward - ctrl_cost);
+      done = (task.terminate_when_unhealthy ? !healthy : false) ||
+             cur >= a.max_episode_steps;
+    } else {
+      reward = static_cast<float>(xv * task.forward_reward_weight - ctrl_cost);
+      done = cur >= a.max_episode_steps;  // ++elapsed_step_ >= max_episode_steps_
+    }
   }
   cm.done[e] = done ? 1 : 0;
   cm.cur_step[e] = cur;
@@ -144,7 +185,14 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
   {
     double* obs = newest;
     for (int i = task.obs_skip; i < kNV; ++i) *(obs++) = qpos[i];
-    for (int i = 0; i < kNV; ++i) *(obs++) = qvel[i];
+    for (int i = 0; i < kNV; ++i) {
+      double x = qvel[i];
+      if constexpr (kWalker) {  // walker2d.h:210-215
+        x = x < task.velocity_max ? x : task.velocity_max;  // std::min(vmax, x)
+        x = x > task.velocity_min ? x : task.velocity_min;  // std::max(vmin, x)
+      }
+      *(obs++) = x;
+    }
   }
   if (S > 1) {  // FrameStackBuffer::Commit, frame_stack.h:109-135
     double* st = dev.stack + (size_t)e * S * nobs;
@@ -162,10 +210,15 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
       for (int i = 0; i < nobs; ++i) st[(S - 1) * nobs + i] = newest[i];
     }
   }
-  ((double*)out.p[kKeyEnv0 + 1])[row] = xv * task.forward_reward_weight;
-  ((double*)out.p[kKeyEnv0 + 2])[row] = -ctrl_cost;
-  ((double*)out.p[kKeyEnv0 + 3])[row] = reset ? 0.0 : qpos[0];
-  ((double*)out.p[kKeyEnv0 + 4])[row] = xv;
+  if constexpr (kWalker) {  // walker2d.h:218-219
+    ((double*)out.p[kKeyEnv0 + 1])[row] = reset ? 0.0 : qpos[0];
+    ((double*)out.p[kKeyEnv0 + 2])[row] = xv;
+  } else {
+    ((double*)out.p[kKeyEnv0 + 1])[row] = xv * task.forward_reward_weight;
+    ((double*)out.p[kKeyEnv0 + 2])[row] = -ctrl_cost;
+    ((double*)out.p[kKeyEnv0 + 3])[row] = reset ? 0.0 : qpos[0];
+    ((double*)out.p[kKeyEnv0 + 4])[row] = xv;
+  }
   WriteCommon(out, row, e + a.id_offset, cur, done, reward,
               a.max_episode_steps);
 }
@@ -211,12 +264,17 @@ __global__ void CheetahSetState(CheetahDev dev, CommonDev cm, const int* ids,
   dev.navail[e] = t[6] != 0.0;
 }
 
-std::vector<KeySpec> CheetahKeys(const Config& cfg) {
+std::vector<KeySpec> CheetahKeys(const Config& cfg, bool walker = false) {
   int no_pos = cfg.Get("exclude_current_positions_from_observation", 1) != 0;
   int fs = (int)cfg.Get("frame_stack", 1);
   // half_cheetah.h:44-62 (non-ENVPOOL_TEST build); StackSpec, frame_stack.h:42-71
   std::vector<int> oshape = {no_pos ? 17 : 18};
   if (fs > 1) oshape.insert(oshape.begin(), fs);
+  if (walker) {  // walker2d.h:49-62
+    return {{"obs", EPA_F64, oshape},
+            {"info:x_position", EPA_F64, {}},
+            {"info:x_velocity", EPA_F64, {}}};
+  }
   return {{"obs", EPA_F64, oshape},
           {"info:reward_run", EPA_F64, {}},
           {"info:reward_ctrl", EPA_F64, {}},
@@ -226,9 +284,13 @@ std::vector<KeySpec> CheetahKeys(const Config& cfg) {
 
 class CheetahPool : public Pool {
  public:
-  explicit CheetahPool(const Config& cfg)
-      : Pool(cfg, CheetahKeys(cfg), KeySpec{"action", EPA_F64, {kNU}},
-             /*needs_rng=*/true) {
+  // model: mj::kPlanarCheetah / kPlanarWalker / kPlanarWalkerV5
+  CheetahPool(const Config& cfg, int model)
+      : Pool(cfg, CheetahKeys(cfg, model != mj::kPlanarCheetah),
+             KeySpec{"action", EPA_F64, {kNU}},
+             /*needs_rng=*/true),
+        model_id_(model) {
+    const bool walker = model != mj::kPlanarCheetah;
     task_.frame_stack = (int)cfg.Get("frame_stack", 1);
     if (task_.frame_stack < 1) {
       throw std::invalid_argument("frame_stack must be greater than 0");
@@ -236,14 +298,24 @@ class CheetahPool : public Pool {
     // "precision": 1 = fp64 arithmetic (default: matches the reference's
     // mjtNum=double), 0 = fp32 arithmetic with fp64 state/IO (BASELINE "fp32").
     fp64_ = (int)cfg.Get("precision", 1) == 1;
-    model_ = mj::BuildCheetahModel();
-    task_.frame_skip = (int)cfg.Get("frame_skip", 5);
+    // defaults: half_cheetah.h:33-43 / walker2d.h:32-47
+    task_.frame_skip = (int)cfg.Get("frame_skip", walker ? 4 : 5);
     task_.obs_skip =
         cfg.Get("exclude_current_positions_from_observation", 1) != 0 ? 1 : 0;
-    task_.ctrl_cost_weight = cfg.Get("ctrl_cost_weight", 0.1);
+    task_.ctrl_cost_weight = cfg.Get("ctrl_cost_weight", walker ? 0.001 : 0.1);
     task_.forward_reward_weight = cfg.Get("forward_reward_weight", 1.0);
-    task_.reset_noise_scale = cfg.Get("reset_noise_scale", 0.1);
-    task_.dt = task_.frame_skip * model_.timestep;
+    task_.reset_noise_scale = cfg.Get("reset_noise_scale", walker ? 0.005 : 0.1);
+    task_.dt = task_.frame_skip * (walker ? kWalkerModelConst.timestep
+                                          : kCheetahModelConst.timestep);
+    task_.healthy_reward = cfg.Get("healthy_reward", 1.0);
+    task_.healthy_z_min = cfg.Get("healthy_z_min", 0.8);
+    task_.healthy_z_max = cfg.Get("healthy_z_max", 2.0);
+    task_.healthy_angle_min = cfg.Get("healthy_angle_min", -1.0);
+    task_.healthy_angle_max = cfg.Get("healthy_angle_max", 1.0);
+    task_.velocity_min = cfg.Get("velocity_min", -10.0);
+    task_.velocity_max = cfg.Get("velocity_max", 10.0);
+    task_.terminate_when_unhealthy = cfg.Get("terminate_when_unhealthy", 1) != 0;
+    task_.legacy_healthy_reward = cfg.Get("legacy_healthy_reward", 1) != 0;
     size_t n = cfg.num_envs;
     EPA_HIP(hipMalloc(&dev_.qpos, sizeof(double) * kNV * n));
     EPA_HIP(hipMalloc(&dev_.qvel, sizeof(double) * kNV * n));
@@ -289,23 +361,26 @@ class CheetahPool : public Pool {
     StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps,
                cfg_.env_id_offset};
     int blocks = (k + kCheetahBlock - 1) / kCheetahBlock;
-    static const int pad = getenv("EPA_CHEETAH_LDS_PAD") ? atoi(getenv("EPA_CHEETAH_LDS_PAD")) : 0;
-    if (fp64_) {
-      mj::SolverCfg<double> sc{50, 1e-13};
-      hipLaunchKernelGGL(CheetahStepKernel<double>, dim3(blocks),
-                         dim3(kCheetahBlock), pad, stream_, dev_, common_, a,
-                         static_cast<const double*>(d_action), out, task_, sc);
-    } else {
-      mj::SolverCfg<float> sc{12, 1e-6f};
-      hipLaunchKernelGGL(CheetahStepKernel<float>, dim3(blocks),
-                         dim3(kCheetahBlock), 0, stream_, dev_, common_, a,
-                         static_cast<const double*>(d_action), out, task_, sc);
+    const double* act = static_cast<const double*>(d_action);
+    const mj::SolverCfg<double> sd{50, 1e-13};
+    const mj::SolverCfg<float> sf{12, 1e-6f};
+#define EPA_LAUNCH_PLANAR(T, MODEL, SC)                                            \
+  hipLaunchKernelGGL((CheetahStepKernel<T, MODEL>), dim3(blocks), dim3(kCheetahBlock), \
+                     0, stream_, dev_, common_, a, act, out, task_, SC)
+    switch (model_id_ * 2 + (fp64_ ? 1 : 0)) {
+      case 1: EPA_LAUNCH_PLANAR(double, mj::kPlanarCheetah, sd); break;
+      case 0: EPA_LAUNCH_PLANAR(float, mj::kPlanarCheetah, sf); break;
+      case 3: EPA_LAUNCH_PLANAR(double, mj::kPlanarWalker, sd); break;
+      case 2: EPA_LAUNCH_PLANAR(float, mj::kPlanarWalker, sf); break;
+      case 5: EPA_LAUNCH_PLANAR(double, mj::kPlanarWalkerV5, sd); break;
+      default: EPA_LAUNCH_PLANAR(float, mj::kPlanarWalkerV5, sf); break;
     }
+#undef EPA_LAUNCH_PLANAR
   }
 
  private:
   CheetahDev dev_{};
-  CheetahModel<double> model_;
+  int model_id_;
   CheetahTask task_{};
   bool fp64_{false};
 };
@@ -318,8 +393,8 @@ Pool* MakeAnt(const std::string& family, const Config& cfg);
 
 bool DescribeMujoco(const std::string& family, const Config& cfg,
                     std::vector<KeySpec>* state, KeySpec* action) {
-  if (family == "HalfCheetah") {
-    *state = CheetahKeys(cfg);
+  if (family == "HalfCheetah" || family == "Walker2d") {
+    *state = CheetahKeys(cfg, family == "Walker2d");
     *action = KeySpec{"action", EPA_F64, {kNU}};
     return true;
   }
@@ -327,7 +402,12 @@ bool DescribeMujoco(const std::string& family, const Config& cfg,
 }
 
 Pool* MakeMujoco(const std::string& family, const Config& cfg) {
-  if (family == "HalfCheetah") return new CheetahPool(cfg);
+  if (family == "HalfCheetah") return new CheetahPool(cfg, mj::kPlanarCheetah);
+  if (family == "Walker2d") {
+    // "xml_v5" = 1: walker2d_v5.xml (gym/registration.py:79-83)
+    return new CheetahPool(cfg, cfg.Get("xml_v5", 0) != 0 ? mj::kPlanarWalkerV5
+                                                         : mj::kPlanarWalker);
+  }
   return MakeAnt(family, cfg);
 }
 

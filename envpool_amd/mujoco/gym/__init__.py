@@ -1,7 +1,8 @@
 """gym-MuJoCo envs (mirror of envpool/mujoco/gym/__init__.py).
 
-Spec tables restate `HalfCheetahEnvFns` (half_cheetah.h:31-62) and `AntEnvFns`
-(ant.h:31-75, v4: use_contact_force=False); the pixel
+Spec tables restate `HalfCheetahEnvFns` (half_cheetah.h:31-62), `AntEnvFns`
+(ant.h:31-75, v4: use_contact_force=False) and `Walker2dEnvFns`
+(walker2d.h:30-67); the pixel
 variants are out of scope.  `precision` is an extension key: 64 (default, the
 reference's mjtNum=double) or 32 (fp32 arithmetic, fp64 state and I/O).
 """
@@ -105,7 +106,65 @@ _Ant = FamilyDef(
     unsupported={"xml_file": "ant.xml", "use_contact_force": False},
 )
 
+
+
+def _walker_xml(c):
+    # the model constants are compiled in from walker2d_envpool.xml /
+    # walker2d_v5_envpool.xml (mujoco_env.h:50-58 resolves them from these names)
+    if c["xml_file"] not in ("walker2d.xml", "walker2d_v5.xml"):
+        raise ValueError(
+            f"GymWalker2d: xml_file={c['xml_file']!r} is not supported by the MI355X "
+            "engine (only 'walker2d.xml' and 'walker2d_v5.xml')")
+    return 1 if c["xml_file"] == "walker2d_v5.xml" else 0
+
+
+_Walker2d = FamilyDef(
+    name="GymWalker2d", native="Walker2d",
+    # walker2d.h:32-47
+    default_config=[
+        ("frame_skip", 4), ("frame_stack", 1), ("post_constraint", True),
+        ("ctrl_cost_weight", 0.001), ("terminate_when_unhealthy", True),
+        ("exclude_current_positions_from_observation", True),
+        ("legacy_healthy_reward", True), ("xml_file", "walker2d.xml"),
+        ("gymnasium_v5_render_camera", False),
+        ("forward_reward_weight", 1.0), ("healthy_reward", 1.0),
+        ("healthy_z_min", 0.8), ("healthy_z_max", 2.0),
+        ("healthy_angle_min", -1.0), ("healthy_angle_max", 1.0),
+        ("velocity_min", -10.0), ("velocity_max", 10.0),
+        ("reset_noise_scale", 0.005), ("precision", 64),
+    ],
+    state_spec=lambda c: [
+        ("obs", spec(np.float64,
+                     _stack([17 if c["exclude_current_positions_from_observation"] else 18], c),
+                     (-_inf, _inf))),
+        ("info:x_position", spec(np.float64, [-1])),
+        ("info:x_velocity", spec(np.float64, [-1])),
+    ],
+    action_spec=lambda c: [("action", spec(np.float64, [-1, 6], (-1.0, 1.0)))],
+    native_params=lambda c: {
+        "frame_skip": c["frame_skip"],
+        "frame_stack": c["frame_stack"],
+        "exclude_current_positions_from_observation":
+            c["exclude_current_positions_from_observation"],
+        "terminate_when_unhealthy": c["terminate_when_unhealthy"],
+        "legacy_healthy_reward": c["legacy_healthy_reward"],
+        "ctrl_cost_weight": c["ctrl_cost_weight"],
+        "forward_reward_weight": c["forward_reward_weight"],
+        "healthy_reward": c["healthy_reward"],
+        "healthy_z_min": c["healthy_z_min"], "healthy_z_max": c["healthy_z_max"],
+        "healthy_angle_min": c["healthy_angle_min"],
+        "healthy_angle_max": c["healthy_angle_max"],
+        "velocity_min": c["velocity_min"], "velocity_max": c["velocity_max"],
+        "reset_noise_scale": c["reset_noise_scale"],
+        "xml_v5": _walker_xml(c),
+        "precision": _precision(c),
+    },
+)
+
 _GymHalfCheetahEnvSpec, _GymHalfCheetahEnvPool = make_native_classes(_HalfCheetah)
+_GymWalker2dEnvSpec, _GymWalker2dEnvPool = make_native_classes(_Walker2d)
+(GymWalker2dEnvSpec, GymWalker2dDMEnvPool,
+ GymWalker2dGymnasiumEnvPool) = py_env(_GymWalker2dEnvSpec, _GymWalker2dEnvPool)
 _GymAntEnvSpec, _GymAntEnvPool = make_native_classes(_Ant)
 GymAntEnvSpec, GymAntDMEnvPool, GymAntGymnasiumEnvPool = py_env(_GymAntEnvSpec, _GymAntEnvPool)
 (GymHalfCheetahEnvSpec, GymHalfCheetahDMEnvPool,
@@ -113,4 +172,5 @@ GymAntEnvSpec, GymAntDMEnvPool, GymAntGymnasiumEnvPool = py_env(_GymAntEnvSpec, 
 
 __all__ = ["GymHalfCheetahEnvSpec", "GymHalfCheetahDMEnvPool",
            "GymHalfCheetahGymnasiumEnvPool", "GymAntEnvSpec", "GymAntDMEnvPool",
-           "GymAntGymnasiumEnvPool"]
+           "GymAntGymnasiumEnvPool", "GymWalker2dEnvSpec", "GymWalker2dDMEnvPool",
+           "GymWalker2dGymnasiumEnvPool"]

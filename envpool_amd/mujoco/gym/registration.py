@@ -6,6 +6,7 @@ gym_mujoco_envs = [
     # the MI355X kernel does not restate yet: only Ant-v4 is registered.
     ("Ant", ("v4",), 1000),
     ("HalfCheetah", ("v3", "v4", "v5"), 1000),
+    ("Walker2d", ("v3", "v4", "v5"), 1000),
 ]
 
 for task, versions, max_episode_steps in gym_mujoco_envs:
@@ -13,6 +14,11 @@ for task, versions, max_episode_steps in gym_mujoco_envs:
         extra_args = {}
         if version == "v5":
             extra_args["gymnasium_v5_render_camera"] = True
+        if task == "Walker2d" and version == "v5":  # gym/registration.py:79-83
+            extra_args.update({
+                "xml_file": "walker2d_v5.xml",
+                "legacy_healthy_reward": False,
+            })
         register(
             task_id=f"{task}-{version}",
             import_path="envpool_amd.mujoco.gym",

@@ -1,8 +1,8 @@
 /* TEST INFRASTRUCTURE — NOT PRODUCT CODE.
  *
  * oracle/mjcpu: float64 CPU restatement of the part of the MuJoCo 3.6.0
- * pipeline that `mj_step` / `mj_forward` execute for the gym HalfCheetah and
- * Ant models, plus the task logic around it.
+ * pipeline that `mj_step` / `mj_forward` execute for the gym HalfCheetah, Ant
+ * and Walker2d models, plus the task logic around it.
  *
  * PARITY UNPINNED for the engine part: the arithmetic lives in the third-party
  * dependency google-deepmind/mujoco tag 3.6.0 (pinned in the reference at
@@ -13,9 +13,11 @@
  * Appendix A) and is anchored on what IS in the reference tree:
  *   - call sites: envpool/mujoco/gym/mujoco_env.h:126-148 (mj_resetData,
  *     mj_forward, ctrl <- action, frame_skip x mj_step)
- *   - task logic: envpool/mujoco/gym/half_cheetah.h:105-185, ant.h:135-278
+ *   - task logic: envpool/mujoco/gym/half_cheetah.h:105-185, ant.h:135-278,
+ *     walker2d.h:119-203
  *   - model constants: third_party/mujoco_gym_xml_patches/half_cheetah_envpool.xml,
- *     ant_envpool.xml (hand-transcribed in models.c, line-cited)
+ *     ant_envpool.xml, walker2d_envpool.xml, walker2d_v5_envpool.xml
+ *     (hand-transcribed in models.c, line-cited)
  * and is checked by physics invariants (tests/test_mjcpu_invariants.py).
  * tools/pin_with_mujoco.py dumps golden vectors wherever `mujoco==3.6.0` is
  * importable; tests/test_mjcpu_golden.py activates when they exist.
@@ -57,6 +59,7 @@ typedef struct {
   double jnt_pos[MJC_MAXJNT][3], jnt_axis[MJC_MAXJNT][3];
   double jnt_range[MJC_MAXJNT][2], jnt_stiffness[MJC_MAXJNT];
   double jnt_margin[MJC_MAXJNT];
+  double jnt_ref[MJC_MAXJNT]; /* <joint ref=...>: qpos0 of a slide / hinge */
   double jnt_solref[MJC_MAXJNT][2], jnt_solimp[MJC_MAXJNT][5];
   /* dofs */
   int dof_body[MJC_MAXV], dof_jnt[MJC_MAXV], dof_parent[MJC_MAXV];
@@ -134,6 +137,7 @@ void mjc_compile(mjc_model* m);
 /* models.c: hand-transcribed gym models */
 void mjc_build_half_cheetah(mjc_model* m);
 void mjc_build_ant(mjc_model* m);
+void mjc_build_walker2d(mjc_model* m, int v5);
 
 /* engine.c */
 void mjc_reset_data(const mjc_model* m, mjc_data* d);

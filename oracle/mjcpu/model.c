@@ -49,6 +49,7 @@ int mjc_add_joint(mjc_model* m, int body, int type, const double pos[3],
   m->jnt_range[j][1] = hi;
   m->jnt_stiffness[j] = stiffness;
   m->jnt_margin[j] = 0;
+  m->jnt_ref[j] = 0;
   /* MuJoCo defaults: solref 0.02 1, solimp 0.9 0.95 0.001 0.5 2 */
   m->jnt_solref[j][0] = 0.02;
   m->jnt_solref[j][1] = 1;
@@ -257,7 +258,7 @@ void mjc_compile(mjc_model* m) {
       for (int i = 0; i < 3; ++i) m->qpos0[a + i] = m->body_pos[b][i];
       for (int i = 0; i < 4; ++i) m->qpos0[a + 3 + i] = m->body_quat[b][i];
     } else {
-      m->qpos0[a] = 0;
+      m->qpos0[a] = m->jnt_ref[j];
     }
   }
   /* constants at qpos0 (MuJoCo mj_setConst / set0) */

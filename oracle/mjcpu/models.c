@@ -1,9 +1,11 @@
 /* TEST INFRASTRUCTURE — NOT PRODUCT CODE.  See mjcpu.h (PARITY UNPINNED).
  *
- * Hand transcription of the two gym MJCF models the reference loads
+ * Hand transcription of the gym MJCF models the reference loads
  * (envpool/mujoco/gym/mujoco_env.h:50-58 prefers the `_envpool.xml` variants):
  *   third_party/mujoco_gym_xml_patches/half_cheetah_envpool.xml
  *   third_party/mujoco_gym_xml_patches/ant_envpool.xml
+ *   third_party/mujoco_gym_xml_patches/walker2d_envpool.xml (v3/v4),
+ *   walker2d_v5_envpool.xml (v5: right foot friction 1.9 instead of 0.9, :47)
  * Numbers are cited by XML line (":NN").
  */
 #include <math.h>
@@ -203,5 +205,95 @@ void mjc_build_ant(mjc_model* m) {
   mjc_add_motor(m, ankle[2], 150);
   mjc_add_motor(m, hip[3], 150);
   mjc_add_motor(m, ankle[3], 150);
+  mjc_compile(m);
+}
+
+/* ---- Walker2d -------------------------------------------------------------------- */
+static int walker_geom(mjc_model* m, int g, double friction) {
+  /* <geom conaffinity="0" condim="3" contype="1" density="1000"
+   *  friction=".7 .1 .1"/>  :27; every body geom overrides friction[0] */
+  m->geom_conaffinity[g] = 0;
+  m->geom_contype[g] = 1;
+  m->geom_condim[g] = 3;
+  m->geom_density[g] = 1000;
+  m->geom_friction[g][0] = friction;
+  m->geom_friction[g][1] = 0.1;
+  m->geom_friction[g][2] = 0.1;
+  return g;
+}
+
+/* <joint armature="0.01" damping=".1" limited="true"/> :26, axis "0 -1 0" */
+static int walker_hinge(mjc_model* m, int body, const double pos[3], double lo_deg,
+                        double hi_deg) {
+  const double deg = 3.14159265358979323846 / 180.0; /* angle="degree" :24 */
+  const double axis[3] = {0, -1, 0};
+  return mjc_add_joint(m, body, MJC_JNT_HINGE, pos, axis, 1, lo_deg * deg,
+                       hi_deg * deg, 0, 0.1, 0.01);
+}
+
+static void walker_leg(mjc_model* m, int torso, double foot_friction, int* j) {
+  const double quat_id[4] = {1, 0, 0, 0};
+  /* thigh :39-41 / :52-54 */
+  const double thigh_pos[3] = {0, 0, -0.19999999999999996};
+  int thigh = mjc_add_body(m, torso, thigh_pos);
+  j[0] = walker_hinge(m, thigh, kZero3, -150, 0);
+  {
+    const double size[3] = {0.050000000000000003, 0.22500000000000003, 0};
+    const double pos[3] = {0, 0, -0.22500000000000009};
+    walker_geom(m, mjc_add_geom(m, thigh, MJC_GEOM_CAPSULE, size, pos, quat_id), 0.9);
+  }
+  /* leg :42-44 / :55-57 */
+  const double leg_pos[3] = {0, 0, -0.70000000000000007};
+  int leg = mjc_add_body(m, thigh, leg_pos);
+  {
+    const double jpos[3] = {0, 0, 0.25};
+    j[1] = walker_hinge(m, leg, jpos, -150, 0);
+    const double size[3] = {0.040000000000000001, 0.25, 0};
+    walker_geom(m, mjc_add_geom(m, leg, MJC_GEOM_CAPSULE, size, kZero3, quat_id), 0.9);
+  }
+  /* foot :45-47 / :58-60 */
+  const double foot_pos[3] = {0.20000000000000001, 0, -0.34999999999999998};
+  int foot = mjc_add_body(m, leg, foot_pos);
+  {
+    const double jpos[3] = {-0.20000000000000001, 0, 0.10000000000000001};
+    j[2] = walker_hinge(m, foot, jpos, -45, 45);
+    const double size[3] = {0.059999999999999998, 0.10000000000000001, 0};
+    const double pos[3] = {-0.10000000000000001, 0, 0.10000000000000001};
+    const double quat[4] = {0.70710678118654757, 0, -0.70710678118654746, 0};
+    walker_geom(m, mjc_add_geom(m, foot, MJC_GEOM_CAPSULE, size, pos, quat),
+                foot_friction);
+  }
+}
+
+void mjc_build_walker2d(mjc_model* m, int v5) {
+  const double yaxis[3] = {0, 1, 0}, xaxis[3] = {1, 0, 0}, zaxis[3] = {0, 0, 1};
+  const double quat_id[4] = {1, 0, 0, 0};
+  mjc_model_init(m);
+  m->timestep = 0.002;         /* :29 */
+  m->integrator = MJC_INT_RK4; /* :29 */
+  m->gravity[2] = -9.81;       /* MuJoCo default */
+  { /* floor :32: default friction .7 .1 .1, conaffinity 1 */
+    const double size[3] = {40, 40, 40};
+    int g = walker_geom(m, mjc_add_geom(m, 0, MJC_GEOM_PLANE, size, kZero3, quat_id), 0.7);
+    m->geom_conaffinity[g] = 1;
+  }
+  /* torso :33-38 */
+  const double torso_pos[3] = {0, 0, 1.25};
+  int torso = mjc_add_body(m, 0, torso_pos);
+  const double root_pos[3] = {0, 0, -1.25};
+  mjc_add_joint(m, torso, MJC_JNT_SLIDE, root_pos, xaxis, 0, 0, 0, 0, 0, 0);
+  int rootz = mjc_add_joint(m, torso, MJC_JNT_SLIDE, root_pos, zaxis, 0, 0, 0, 0, 0, 0);
+  m->jnt_ref[rootz] = 1.25; /* ref="1.25" :36 */
+  mjc_add_joint(m, torso, MJC_JNT_HINGE, kZero3, yaxis, 0, 0, 0, 0, 0, 0);
+  {
+    const double size[3] = {0.050000000000000003, 0.19999999999999996, 0};
+    walker_geom(m, mjc_add_geom(m, torso, MJC_GEOM_CAPSULE, size, kZero3, quat_id), 0.9);
+  }
+  int jr[3], jl[3];
+  walker_leg(m, torso, v5 ? 1.9 : 0.9, jr); /* right: :39-50 */
+  walker_leg(m, torso, 1.9, jl);            /* left: :52-63 */
+  /* actuators :68-73, gear 100 */
+  for (int i = 0; i < 3; ++i) mjc_add_motor(m, jr[i], 100);
+  for (int i = 0; i < 3; ++i) mjc_add_motor(m, jl[i], 100);
   mjc_compile(m);
 }

@@ -29,12 +29,16 @@ typedef struct {
   int current_step, done, elapsed_step;
 } mj_env;
 
+enum { TASK_CHEETAH = 0, TASK_ANT = 1, TASK_WALKER = 2 };
+
 typedef struct {
   int is_ant;
+  int task;
   mjc_model m;
   int num_envs, max_episode_steps, frame_skip;
   double ctrl_cost_weight, forward_reward_weight, reset_noise_scale;
   double healthy_reward, healthy_z_min, healthy_z_max;
+  double healthy_angle_min, healthy_angle_max, velocity_min, velocity_max;
   int terminate_when_unhealthy, legacy_healthy_reward;
   int torso;
   mj_env* envs;
@@ -57,28 +61,37 @@ static double extra_or(const double* e, int n, int i, double d) {
  * reset_noise_scale, disable_contact, disable_limit, disable_actuation] */
 void* mjcpu_create(const char* task, int num_envs, int seed,
                    int max_episode_steps, const double* extra, int n_extra) {
-  int is_ant;
+  int is_ant = 0, kind;
   if (strcmp(task, "HalfCheetah") == 0) {
-    is_ant = 0;
+    kind = TASK_CHEETAH;
   } else if (strcmp(task, "Ant") == 0) {
+    kind = TASK_ANT;
     is_ant = 1;
+  } else if (strcmp(task, "Walker2d") == 0 || strcmp(task, "Walker2dV5") == 0) {
+    kind = TASK_WALKER;
   } else {
     return NULL;
   }
   mj_pool* p = (mj_pool*)calloc(1, sizeof(mj_pool));
   p->is_ant = is_ant;
+  p->task = kind;
+  const int walker = kind == TASK_WALKER;
+  const int v5 = strcmp(task, "Walker2dV5") == 0;
   if (is_ant) {
     mjc_build_ant(&p->m);
+  } else if (walker) {
+    mjc_build_walker2d(&p->m, v5);
   } else {
     mjc_build_half_cheetah(&p->m);
   }
   p->num_envs = num_envs;
   p->max_episode_steps = max_episode_steps > 0 ? max_episode_steps : INT_MAX;
-  p->frame_skip = (int)extra_or(extra, n_extra, 0, 5);
-  /* half_cheetah.h:33-43 / ant.h:33-50 defaults */
-  p->ctrl_cost_weight = extra_or(extra, n_extra, 1, is_ant ? 0.5 : 0.1);
+  p->frame_skip = (int)extra_or(extra, n_extra, 0, walker ? 4 : 5);
+  /* half_cheetah.h:33-43 / ant.h:33-50 / walker2d.h:32-47 defaults */
+  p->ctrl_cost_weight =
+      extra_or(extra, n_extra, 1, is_ant ? 0.5 : (walker ? 0.001 : 0.1));
   p->forward_reward_weight = extra_or(extra, n_extra, 2, 1.0);
-  p->reset_noise_scale = extra_or(extra, n_extra, 3, 0.1);
+  p->reset_noise_scale = extra_or(extra, n_extra, 3, walker ? 0.005 : 0.1);
   p->m.disable_contact = extra_or(extra, n_extra, 4, 0) != 0;
   p->m.disable_limit = extra_or(extra, n_extra, 5, 0) != 0;
   p->m.disable_actuation = extra_or(extra, n_extra, 6, 0) != 0;
@@ -89,10 +102,14 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   if (extra_or(extra, n_extra, 8, -1) >= 0) p->m.integrator = (int)extra[8];
   if (extra_or(extra, n_extra, 9, 0) > 0) p->m.timestep = extra[9];
   p->healthy_reward = 1.0;
-  p->healthy_z_min = 0.2;
-  p->healthy_z_max = 1.0;
+  p->healthy_z_min = walker ? 0.8 : 0.2;
+  p->healthy_z_max = walker ? 2.0 : 1.0;
+  p->healthy_angle_min = -1.0;
+  p->healthy_angle_max = 1.0;
+  p->velocity_min = -10.0;
+  p->velocity_max = 10.0;
   p->terminate_when_unhealthy = 1;
-  p->legacy_healthy_reward = 1;
+  p->legacy_healthy_reward = v5 ? 0 : 1; /* gym/registration.py:79-83 */
   p->torso = 1; /* mj_name2id(model, mjOBJ_XBODY, "torso"), ant.h:119 */
   for (int i = 0; i < 8; ++i) {
     p->key_names[i] = kCommonNames[i];
@@ -109,9 +126,10 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
       "info:reward_forward", "info:reward_ctrl",  "info:reward_contact",
       "info:reward_survive", "info:x_position",   "info:y_position",
       "info:distance_from_origin", "info:x_velocity", "info:y_velocity"};
-  int ninfo = is_ant ? 9 : 4;
+  /* walker2d.h:60-61: info:x_position, info:x_velocity */
+  int ninfo = is_ant ? 9 : (walker ? 2 : 4);
   for (int i = 0; i < ninfo; ++i) {
-    p->key_names[k] = is_ant ? ant_info[i] : cheetah_info[i];
+    p->key_names[k] = is_ant ? ant_info[i] : cheetah_info[(walker ? 2 : 0) + i];
     p->key_dtype[k] = DT_F64;
     p->key_elems[k++] = 1;
   }
@@ -170,7 +188,14 @@ static void write_obs(mj_pool* p, mj_env* e, void** out, int row) {
   int n = p->is_ant ? 27 : 17;
   double* obs = (double*)out[8] + (size_t)row * n;
   for (int i = skip; i < p->m.nq; ++i) *(obs++) = e->d.qpos[i];
-  for (int i = 0; i < p->m.nv; ++i) *(obs++) = e->d.qvel[i];
+  for (int i = 0; i < p->m.nv; ++i) {
+    double x = e->d.qvel[i];
+    if (p->task == TASK_WALKER) { /* walker2d.h:196-201: clip(qvel, vmin, vmax) */
+      x = x < p->velocity_min ? p->velocity_min : x;
+      x = x > p->velocity_max ? p->velocity_max : x;
+    }
+    *(obs++) = x;
+  }
 }
 
 /* MujocoReset + MujocoResetModel: mujoco_env.h:126-131, half_cheetah.h:105-117 */
@@ -184,7 +209,12 @@ static void mujoco_reset(mj_pool* p, mj_env* e) {
                                     p->reset_noise_scale);
   }
   for (int i = 0; i < p->m.nv; ++i) {
-    e->d.qvel[i] = 0.0 + orc_normal(&e->gen, &e->nstate, 0, p->reset_noise_scale);
+    if (p->task == TASK_WALKER) { /* walker2d.h:119-126: uniform for qvel too */
+      e->d.qvel[i] = 0.0 + orc_uniform_real(&e->gen, -p->reset_noise_scale,
+                                            p->reset_noise_scale);
+    } else {
+      e->d.qvel[i] = 0.0 + orc_normal(&e->gen, &e->nstate, 0, p->reset_noise_scale);
+    }
   }
   mjc_forward(&p->m, &e->d); /* mj_forward */
 }
@@ -205,7 +235,7 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
   mj_env* e = &p->envs[eid];
   int reset = force_reset || e->done; /* async_envpool.h:127 */
   float reward = 0.0f;
-  int ninfo = p->is_ant ? 9 : 4;
+  int ninfo = p->is_ant ? 9 : (p->task == TASK_WALKER ? 2 : 4);
   double info[9] = {0};
   if (reset) {
     e->current_step = 0;
@@ -219,7 +249,25 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
     double dt = p->frame_skip * p->m.timestep;
     double ctrl_cost = 0;
     for (int i = 0; i < p->m.nu; ++i) ctrl_cost += p->ctrl_cost_weight * act[i] * act[i];
-    if (!p->is_ant) { /* half_cheetah.h:136-155 */
+    if (p->task == TASK_WALKER) { /* walker2d.h:150-178 */
+      double x_before = e->d.qpos[0];
+      for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
+      for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
+      double x_after = e->d.qpos[0];
+      double xv = (x_after - x_before) / dt;
+      int healthy = !(e->d.qpos[1] < p->healthy_z_min || e->d.qpos[1] > p->healthy_z_max ||
+                      e->d.qpos[2] < p->healthy_angle_min ||
+                      e->d.qpos[2] > p->healthy_angle_max); /* :181-190 */
+      int give = healthy;
+      if (p->legacy_healthy_reward) give = p->terminate_when_unhealthy || healthy;
+      double healthy_reward = give ? p->healthy_reward : 0.0;
+      reward = (float)(xv * p->forward_reward_weight + healthy_reward - ctrl_cost);
+      ++e->elapsed_step;
+      e->done = (p->terminate_when_unhealthy ? !healthy : 0) ||
+                (e->elapsed_step >= p->max_episode_steps);
+      info[0] = x_after;
+      info[1] = xv;
+    } else if (!p->is_ant) { /* half_cheetah.h:136-155 */
       double x_before = e->d.qpos[0];
       for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
       for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);

@@ -215,3 +215,84 @@ def test_ant_unhealthy_termination_and_autoreset():
             np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k}@{t}")
         seen_term |= bool((b["done"] & ~b["trunc"]).any())
     assert b["elapsed_step"].max() <= 40
+
+
+# ---- Walker2d (same planar kernel: mirrored hinges, RK4, healthy termination) ----
+def make_walker_pair(n, seed, precision, task="Walker2d", max_steps=1000):
+    pool = DevicePool("Walker2d", n, seed=seed, max_episode_steps=max_steps,
+                      params={"precision": precision,
+                              "xml_v5": 1 if task == "Walker2dV5" else 0,
+                              "legacy_healthy_reward": 0 if task == "Walker2dV5" else 1})
+    orc = Oracle(task, n, seed=seed, max_episode_steps=max_steps)
+    return pool, orc
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_walker_reset_matches_oracle(precision):
+    pool, orc = make_walker_pair(64, 5, precision)
+    a, b = hip_reset(pool), orc.reset()
+    # both qpos and qvel noise are uniform draws (walker2d.h:119-126): bit exact
+    np.testing.assert_array_equal(a["obs"], b["obs"])
+    assert list(a.keys()) == list(b.keys())
+    for k in ("elapsed_step", "done", "reward", "discount", "step_type", "trunc",
+              "info:env_id", "info:x_position", "info:x_velocity"):
+        np.testing.assert_array_equal(a[k].ravel(), b[k].ravel())
+
+
+@pytest.mark.parametrize("task", ["Walker2d", "Walker2dV5"])
+def test_walker_teacher_forced_step(task):
+    """fp64 kernel, 4 RK4 mj_steps (16 forward evaluations) per env-step:
+    obs rtol 1e-9 / atol 1e-10; bookkeeping (healthy termination, auto-reset) exact."""
+    n, steps = 256, 100
+    pool, orc = make_walker_pair(n, 9, 1, task)
+    hip_reset(pool), orc.reset()
+    rng = np.random.default_rng(3)
+    worst, seen_term = 0.0, False
+    for t in range(steps):
+        pool.set_state(orc.get_state())
+        act = rng.uniform(-1.2, 1.2, size=(n, 6))
+        a, b = hip_step(pool, act), orc.step(act)
+        np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-9, atol=1e-10,
+                                   err_msg=f"step {t}")
+        np.testing.assert_allclose(a["reward"].ravel(), b["reward"].ravel(),
+                                   rtol=1e-6, atol=1e-6)
+        for k in ("info:x_position", "info:x_velocity"):
+            np.testing.assert_allclose(a[k].ravel(), b[k].ravel(), rtol=1e-9, atol=2e-9)
+        for k in ("done", "trunc", "elapsed_step", "step_type", "discount"):
+            np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k}@{t}")
+        seen_term |= bool((b["done"] & ~b["trunc"]).any())
+        worst = max(worst, float(np.abs(a["obs"] - b["obs"]).max()))
+    print(f"{task} fp64: worst teacher-forced |d obs| = {worst:.3e}")
+    assert seen_term  # random actions make the walker fall within ~30 steps
+
+
+def test_walker_teacher_forced_fp32_distribution():
+    n, steps = 256, 100
+    pool, orc = make_walker_pair(n, 9, 0)
+    hip_reset(pool), orc.reset()
+    rng = np.random.default_rng(3)
+    errs = []
+    for t in range(steps):
+        pool.set_state(orc.get_state())
+        act = rng.uniform(-1.2, 1.2, size=(n, 6))
+        a, b = hip_step(pool, act), orc.step(act)
+        errs.append((np.abs(a["obs"] - b["obs"]) / (1.0 + np.abs(b["obs"]))).max(axis=1))
+    errs = np.concatenate(errs)
+    med, p99, mx = np.median(errs), np.percentile(errs, 99), errs.max()
+    print(f"Walker2d fp32 teacher-forced rel |d obs|: median {med:.2e} p99 {p99:.2e} max {mx:.2e}")
+    # fp32 arithmetic through 16 Newton solves with stiff default contacts
+    # (solimp .9 .95 .001): distribution asserted, max only reported
+    assert med <= 5e-5 and p99 <= 2e-3
+
+
+def test_walker_deterministic():
+    n = 512
+    outs = []
+    for _ in range(2):
+        pool = DevicePool("Walker2d", n, seed=3, max_episode_steps=1000, params={"precision": 1})
+        hip_reset(pool)
+        rng = np.random.default_rng(5)
+        for t in range(40):
+            a = hip_step(pool, rng.uniform(-1, 1, size=(n, 6)))
+        outs.append(a["obs"].copy())
+    np.testing.assert_array_equal(outs[0], outs[1])

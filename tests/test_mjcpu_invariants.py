@@ -112,6 +112,8 @@ def test_product_planar_code_matches_oracle_on_cpu():
                            check=True)
     rng = np.random.default_rng(3)
     for task, lib, nq, nv, nu, skip in (("HalfCheetah", "cheetah", 9, 9, 6, 1),
+                                        ("Walker2d", "cheetah", 9, 9, 6, 1),
+                                        ("Walker2dV5", "cheetah", 9, 9, 6, 1),
                                         ("Ant", "ant", 15, 14, 8, 2)):
         L = ctypes.CDLL(os.path.join(h, f"lib{lib}_host.so"))
         n = 8
@@ -133,6 +135,10 @@ def test_product_planar_code_matches_oracle_on_cpu():
                 if lib == "ant":
                     lag = np.zeros(2)
                     L.ant_host_step(*args, 5, 0, *outs, lag.ctypes.data_as(ctypes.c_void_p), ctypes.byref(it))
+                elif task.startswith("Walker2d"):
+                    L.walker_host_step(*args, 4, int(task.endswith("V5")), 0, *outs,
+                                       ctypes.byref(it))
+                    vo = np.clip(vo, -10, 10)
                 else:
                     L.cheetah_host_step(*args, 5, 0, *outs, ctypes.byref(it))
                 worst = max(worst, np.abs(np.concatenate([qo[skip:], vo]) - b["obs"][e]).max())

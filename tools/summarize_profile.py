@@ -11,8 +11,15 @@ KEY = ("StepKernel", "AtariPostKernel")
 
 
 def short(name):
-    for k in ("CheetahStepKernel<float>", "CheetahStepKernel<double>", "AntStepKernel<float>",
-              "AntStepKernel<double>", "ClassicStepKernel", "ToyStepKernel", "AtariPostKernel"):
+    for k, model in (("CheetahStepKernel<float, 0>", ""), ("CheetahStepKernel<double, 0>", ""),
+                     ("CheetahStepKernel<float, 1>", "[Walker2d]"),
+                     ("CheetahStepKernel<double, 1>", "[Walker2d]"),
+                     ("CheetahStepKernel<float, 2>", "[Walker2d-v5]"),
+                     ("CheetahStepKernel<double, 2>", "[Walker2d-v5]")):
+        if k in name:  # planar kernel, second template argument = PlanarModelId
+            return k.split(",")[0] + ">" + model
+    for k in ("AntStepKernel<float>", "AntStepKernel<double>", "ClassicStepKernel",
+              "ToyStepKernel", "AtariPostKernel"):
         if k in name:
             return k
     return name[:60]
