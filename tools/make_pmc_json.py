@@ -1,0 +1,48 @@
+"""Collects the PMC passes of tools/profile_bench.sh (gpurun_out/prof_<tag>/summary.md)
+into profiles/r1_pmc.json, which bench.py reads for `roofline.traffic` and the
+VALU figures.  usage: python tools/make_pmc_json.py <round-tag-prefix> [num_envs]
+
+Conventions (MI355X_MICROARCH.md, HBM / rocprofv3 section):
+  FETCH_SIZE, WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts half the bytes of a
+  coalesced stream -> x2.  flops = 64 lanes x (2 FMA + ADD + MUL + TRANS) wave-level
+  instructions of the arithmetic type (exec mask ignored -> an upper bound).
+"""
+import glob
+import json
+import os
+import re
+import sys
+
+prefix = sys.argv[1] if len(sys.argv) > 1 else "r1f"
+num_envs = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = {}
+for path in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}_*", "summary.md"))):
+    text = open(path).read()
+    m = re.search(r"## PMC per launch \(mean over launches\): (.+)", text)
+    if not m:
+        continue
+    kernel = m.group(1).strip()
+    ctr = {k: float(v) for k, v in re.findall(r"\| (\w+) \| ([0-9.e+-]+) \| \d+ \|", text)}
+    tr = re.search(r"\| %s \| (\d+) \| ([0-9.]+) \|" % re.escape(kernel), text)
+    f64 = "<double>" in kernel
+    sfx = "F64" if f64 else "F32"
+    flops = 64.0 * (2 * ctr.get(f"SQ_INSTS_VALU_FMA_{sfx}", 0) + ctr.get(f"SQ_INSTS_VALU_ADD_{sfx}", 0) +
+                    ctr.get(f"SQ_INSTS_VALU_MUL_{sfx}", 0) + ctr.get(f"SQ_INSTS_VALU_TRANS_{sfx}", 0))
+    waves = (num_envs + 63) // 64
+    out[kernel] = {
+        "fetch_size_kb": ctr.get("FETCH_SIZE"),
+        "write_size_kb": ctr.get("WRITE_SIZE"),
+        "traffic_bytes_per_launch": 1024.0 * (2 * ctr.get("FETCH_SIZE", 0) + ctr.get("WRITE_SIZE", 0)),
+        "flops_per_launch": flops,
+        "flops_per_env_step": flops / num_envs,
+        "valu_insts_per_wave": ctr.get("SQ_INSTS_VALU", 0) / waves,
+        "lds_insts_per_wave": ctr.get("SQ_INSTS_LDS", 0) / waves,
+        "wait_frac_of_wave_cycles": ctr.get("SQ_WAIT_ANY", 0) / max(ctr.get("SQ_WAVE_CYCLES", 1), 1),
+        "rocprof_avg_us": float(tr.group(2)) if tr else None,
+        "note": "gfx950: FETCH_SIZE counts half the bytes of a coalesced stream -> x2",
+        "source": f"profiles/{os.path.basename(os.path.dirname(path)).replace('prof_', '')}_summary.md",
+        "num_envs": num_envs,
+    }
+json.dump(out, open(os.path.join(root, "profiles", "r1_pmc.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
