@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import collections
 import ctypes
+import threading
+import weakref
 from typing import Any, Sequence
 
 import numpy as np
@@ -16,8 +18,54 @@ import numpy as np
 from . import native
 
 
+class _PinnedBlocks:
+    """Free list of pinned host blocks (epa_host_alloc) that back the arrays
+    `recv` returns.  A block is lent to ONE batch: the per-key numpy arrays are
+    views of it, and it only comes back here when the last of them is garbage
+    collected — so, like the reference's capsule-owned buffers
+    (py_envpool.h:40-49), an array is never overwritten by a later step."""
+
+    _MAX_FREE = 4  # per size
+
+    def __init__(self, lib: Any) -> None:
+        self._lib = lib
+        self._free: dict[int, list[int]] = collections.defaultdict(list)
+        self._lock = threading.Lock()
+        self._closed = False
+
+    def take(self, nbytes: int) -> np.ndarray:
+        with self._lock:
+            free = self._free[nbytes]
+            ptr = free.pop() if free else None
+        if ptr is None:
+            ptr = self._lib.epa_host_alloc(nbytes)
+            if not ptr:
+                raise MemoryError(f"epa_host_alloc({nbytes}) failed")
+        base = np.ctypeslib.as_array((ctypes.c_ubyte * nbytes).from_address(ptr))
+        fin = weakref.finalize(base, self._give_back, nbytes, ptr)
+        fin.atexit = False  # process teardown frees pinned memory anyway
+        return base
+
+    def _give_back(self, nbytes: int, ptr: int) -> None:
+        with self._lock:
+            if not self._closed and len(self._free[nbytes]) < self._MAX_FREE:
+                self._free[nbytes].append(ptr)
+                return
+        self._lib.epa_host_free(ptr)
+
+    def close(self) -> None:
+        with self._lock:
+            self._closed = True
+            ptrs = [p for v in self._free.values() for p in v]
+            self._free.clear()
+        for p in ptrs:
+            self._lib.epa_host_free(p)
+
+
 class DevicePool:
     """Low-level pool: numpy in, list-of-numpy out, in `_state_keys` order."""
+
+    _SMALL_BATCH_BYTES = 256 * 1024
 
     def __init__(
         self,
@@ -53,6 +101,8 @@ class DevicePool:
         self._h = h
         self._pending: collections.deque[int] = collections.deque()
         self._is_sync = self.batch_size == self.num_envs
+        self._blocks = _PinnedBlocks(self._lib)
+        self._layouts: dict[int, tuple[list[int], int]] = {}
 
     # -- host path ---------------------------------------------------------
     def send(self, env_id: np.ndarray, action: np.ndarray) -> None:
@@ -75,20 +125,41 @@ class DevicePool:
         native.check(self._lib.epa_reset(self._h, env_ids.ctypes.data, k))
         self._pending.append(k)
 
+    def _layout(self, rows: int) -> tuple[list[int], int]:
+        lay = self._layouts.get(rows)
+        if lay is None:
+            n = len(self.state_keys)
+            offs = (ctypes.c_size_t * n)()
+            total = ctypes.c_size_t(0)
+            native.check(self._lib.epa_recv_layout(self._h, rows, offs, n, ctypes.byref(total)))
+            lay = ([int(o) for o in offs], int(total.value))
+            self._layouts[rows] = lay
+        return lay
+
     def recv(self) -> list[np.ndarray]:
+        """One device->host copy into a pinned block; the returned arrays are
+        views of that block (no host-side memcpy) and own it jointly."""
         if self._is_sync:
             cap = self._pending[0] if self._pending else self.num_envs
         else:
             cap = self.batch_size
-        outs = [
-            np.empty((cap, *shape), dtype=dtype)
-            for _, dtype, shape in self.state_keys
-        ]
-        ptrs = (ctypes.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+        n = len(self.state_keys)
+        _, total = self._layout(cap)
+        small = total < self._SMALL_BATCH_BYTES
         k = ctypes.c_int32(0)
-        native.check(
-            self._lib.epa_recv(self._h, ptrs, len(outs), cap, ctypes.byref(k))
-        )
+        if small:
+            # tiny batches: fresh pageable arrays + epa_recv's memcpy out of its own
+            # pinned landing buffer is cheaper than block bookkeeping
+            outs = [np.empty((cap, *shape), dtype=dtype) for _, dtype, shape in self.state_keys]
+            ptrs = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+            native.check(self._lib.epa_recv(self._h, ptrs, n, cap, ctypes.byref(k)))
+        else:
+            block = self._blocks.take(total)
+            offs = (ctypes.c_size_t * n)()
+            native.check(
+                self._lib.epa_recv_block(self._h, block.ctypes.data, block.nbytes, offs, n,
+                                         ctypes.byref(k))
+            )
         if self._is_sync:
             if self._pending:
                 self._pending.popleft()
@@ -101,8 +172,13 @@ class DevicePool:
                 else:
                     self._pending[0] -= left
                     left = 0
-        if k.value != cap:
-            outs = [o[: k.value] for o in outs]
+        rows = k.value
+        if small:
+            return outs if rows == cap else [o[:rows] for o in outs]
+        outs = []
+        for (_, dtype, shape), off in zip(self.state_keys, offs):
+            nbytes = rows * int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+            outs.append(block[off:off + nbytes].view(dtype).reshape((rows, *shape)))
         return outs
 
     def recv_dict(self) -> dict[str, np.ndarray]:
@@ -177,6 +253,8 @@ class DevicePool:
         if getattr(self, "_h", None):
             self._lib.epa_destroy(self._h)
             self._h = None
+        if getattr(self, "_blocks", None) is not None:
+            self._blocks.close()  # blocks still lent out are freed when their arrays die
 
     def __del__(self) -> None:
         try:

@@ -124,6 +124,9 @@ class Pool {
   void Reset(const int32_t* env_ids, int k);
   void SendDevice(const int32_t* d_env_id, int k, const void* d_action);
   int Recv(void* const* out_ptrs, int n_ptrs, int cap_rows);
+  // zero-copy host recv into a caller-owned block (see epa_recv_block)
+  size_t RecvLayout(int rows, size_t* offsets, int n_keys) const;
+  int RecvBlock(void* block, size_t block_bytes, size_t* offsets, int n_keys);
   int RecvDevice(void** d_out_ptrs, int n_ptrs);
   int PendingRows();
   void Synchronize();
@@ -152,6 +155,8 @@ class Pool {
   CommonDev common_{};
 
  private:
+  int WantRows();  // rows the next Recv returns (validates the pending queue)
+  void CopyRowsToHost(char* dst, const std::vector<size_t>& off, int want);
   Batch* AcquireBatch(int k);
   void ReleaseBatch(Batch* b);
   OutPtrs PtrsOf(const Batch& b) const;

@@ -318,12 +318,7 @@ int Pool::PendingRows() {
   return rows;
 }
 
-int Pool::Recv(void* const* out_ptrs, int n_ptrs, int cap_rows) {
-  std::lock_guard<std::mutex> lk(mu_);
-  EPA_HIP(hipSetDevice(cfg_.device));
-  if (n_ptrs < (int)keys_.size()) {
-    throw std::invalid_argument("recv: need one output pointer per state key");
-  }
+int Pool::WantRows() {
   if (pending_.empty()) {
     throw std::runtime_error(
         "recv: nothing pending (the reference would block forever: call "
@@ -339,24 +334,25 @@ int Pool::Recv(void* const* out_ptrs, int n_ptrs, int cap_rows) {
                              " rows pending, batch_size is " +
                              std::to_string(want));
   }
-  if (cap_rows < want) {
-    throw std::invalid_argument("recv: output buffers too small");
+  return want;
+}
+
+size_t Pool::RecvLayout(int rows, size_t* offsets, int n_keys) const {
+  if (n_keys < (int)keys_.size()) {
+    throw std::invalid_argument("recv_layout: need one offset per state key");
   }
-  // pinned landing block laid out like a batch of `want` rows
-  std::vector<size_t> off(keys_.size());
   size_t total = 0;
   for (size_t i = 0; i < keys_.size(); ++i) {
-    off[i] = total;
-    total += Align((size_t)want * keys_[i].row_bytes());
+    offsets[i] = total;
+    total += Align((size_t)rows * keys_[i].row_bytes());
   }
-  if (recv_stage_bytes_ < total) {
-    if (recv_stage_) EPA_HIP(hipHostFree(recv_stage_));
-    size_t cap = 0;
-    for (auto& key : keys_) cap += Align((size_t)cfg_.num_envs * key.row_bytes());
-    cap = std::max(cap, total);
-    EPA_HIP(hipHostMalloc(&recv_stage_, cap, hipHostMallocDefault));
-    recv_stage_bytes_ = cap;
-  }
+  return total;
+}
+
+// Device -> host copy of the next `want` rows into a host block laid out by
+// RecvLayout(want); waits for completion.
+void Pool::CopyRowsToHost(char* dst, const std::vector<size_t>& off, int want) {
+  size_t total = off.back() + Align((size_t)want * keys_.back().row_bytes());
   int got = 0;
   while (got < want) {
     Batch* b = pending_.front();
@@ -365,12 +361,11 @@ int Pool::Recv(void* const* out_ptrs, int n_ptrs, int cap_rows) {
     // produced the rows, no extra event needed.
     if (got == 0 && take == want && b->consumed == 0 && take == b->k) {
       // whole batch: one D2H of the packed block (offsets coincide)
-      EPA_HIP(hipMemcpyAsync(recv_stage_, b->dbuf, total, hipMemcpyDeviceToHost,
-                             stream_));
+      EPA_HIP(hipMemcpyAsync(dst, b->dbuf, total, hipMemcpyDeviceToHost, stream_));
     } else {
       for (size_t i = 0; i < keys_.size(); ++i) {
         size_t rb = keys_[i].row_bytes();
-        EPA_HIP(hipMemcpyAsync(recv_stage_ + off[i] + (size_t)got * rb,
+        EPA_HIP(hipMemcpyAsync(dst + off[i] + (size_t)got * rb,
                                b->dbuf + b->offsets[i] + (size_t)b->consumed * rb,
                                (size_t)take * rb, hipMemcpyDeviceToHost,
                                stream_));
@@ -384,12 +379,56 @@ int Pool::Recv(void* const* out_ptrs, int n_ptrs, int cap_rows) {
     }
   }
   EPA_HIP(hipStreamSynchronize(stream_));
+}
+
+int Pool::Recv(void* const* out_ptrs, int n_ptrs, int cap_rows) {
+  std::lock_guard<std::mutex> lk(mu_);
+  EPA_HIP(hipSetDevice(cfg_.device));
+  if (n_ptrs < (int)keys_.size()) {
+    throw std::invalid_argument("recv: need one output pointer per state key");
+  }
+  int want = WantRows();
+  if (cap_rows < want) {
+    throw std::invalid_argument("recv: output buffers too small");
+  }
+  // pinned landing block laid out like a batch of `want` rows
+  std::vector<size_t> off(keys_.size());
+  size_t total = RecvLayout(want, off.data(), (int)off.size());
+  if (recv_stage_bytes_ < total) {
+    if (recv_stage_) EPA_HIP(hipHostFree(recv_stage_));
+    size_t cap = 0;
+    for (auto& key : keys_) cap += Align((size_t)cfg_.num_envs * key.row_bytes());
+    cap = std::max(cap, total);
+    EPA_HIP(hipHostMalloc(&recv_stage_, cap, hipHostMallocDefault));
+    recv_stage_bytes_ = cap;
+  }
+  CopyRowsToHost(recv_stage_, off, want);
   for (size_t i = 0; i < keys_.size(); ++i) {
     if (out_ptrs[i] != nullptr) {
       std::memcpy(out_ptrs[i], recv_stage_ + off[i],
                   (size_t)want * keys_[i].row_bytes());
     }
   }
+  return want;
+}
+
+int Pool::RecvBlock(void* block, size_t block_bytes, size_t* offsets, int n_keys) {
+  std::lock_guard<std::mutex> lk(mu_);
+  EPA_HIP(hipSetDevice(cfg_.device));
+  if (block == nullptr) throw std::invalid_argument("recv_block: null block");
+  if (n_keys < (int)keys_.size()) {
+    throw std::invalid_argument("recv_block: need one offset per state key");
+  }
+  int want = WantRows();
+  std::vector<size_t> off(keys_.size());
+  size_t total = RecvLayout(want, off.data(), (int)off.size());
+  if (block_bytes < total) {
+    throw std::invalid_argument("recv_block: block too small (" +
+                                std::to_string(block_bytes) + " < " +
+                                std::to_string(total) + " bytes)");
+  }
+  CopyRowsToHost(static_cast<char*>(block), off, want);
+  for (size_t i = 0; i < off.size(); ++i) offsets[i] = off[i];
   return want;
 }
 
@@ -637,6 +676,19 @@ int epa_reset(epa_pool* pool, const int32_t* env_ids, int32_t k) {
 int epa_recv(epa_pool* pool, void* const* out_ptrs, int32_t n_ptrs,
              int32_t cap_rows, int32_t* k_out) {
   return Guard([&] { *k_out = pool->impl->Recv(out_ptrs, n_ptrs, cap_rows); });
+}
+
+int epa_recv_layout(epa_pool* pool, int32_t rows, size_t* offsets, int32_t n_keys,
+                    size_t* total_bytes) {
+  return Guard([&] {
+    if (rows < 0) throw std::invalid_argument("recv_layout: rows < 0");
+    *total_bytes = pool->impl->RecvLayout(rows, offsets, n_keys);
+  });
+}
+
+int epa_recv_block(epa_pool* pool, void* block, size_t block_bytes,
+                   size_t* offsets, int32_t n_keys, int32_t* k_out) {
+  return Guard([&] { *k_out = pool->impl->RecvBlock(block, block_bytes, offsets, n_keys); });
 }
 
 int epa_pending_rows(epa_pool* pool, int32_t* rows) {

@@ -135,6 +135,21 @@ int epa_reset(epa_pool* pool, const int32_t* env_ids, int32_t k);
 int epa_recv(epa_pool* pool, void* const* out_ptrs, int32_t n_ptrs,
              int32_t cap_rows, int32_t* k_out);
 
+/* Zero-copy variant of epa_recv: the reference hands numpy arrays that OWN
+ * their memory and are never overwritten by later steps (py_envpool.h:40-49,
+ * state_buffer_queue.h:149-163: a fresh buffer per batch).  Here the caller
+ * provides one host block per batch (pinned memory from epa_host_alloc gives the
+ * full PCIe rate), the batch lands in it with ONE device->host copy and no host
+ * memcpy, and the per-key arrays are views at `offsets[key]`.
+ * epa_recv_layout: section offsets (256-B aligned) and total size of a block
+ * holding `rows` rows of every state key.
+ * epa_recv_block: same blocking / batching semantics as epa_recv; `offsets`
+ * (n_keys entries) is filled for the *k_out rows actually returned. */
+int epa_recv_layout(epa_pool* pool, int32_t rows, size_t* offsets, int32_t n_keys,
+                    size_t* total_bytes);
+int epa_recv_block(epa_pool* pool, void* block, size_t block_bytes,
+                   size_t* offsets, int32_t n_keys, int32_t* k_out);
+
 /* Rows currently computed-or-in-flight and not yet received. */
 int epa_pending_rows(epa_pool* pool, int32_t* rows);
 

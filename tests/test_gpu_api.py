@@ -160,3 +160,40 @@ def test_mujoco_frame_stack(task, obs_dim, adim):
         hist = np.concatenate([hist[:, 1:], o1[:, None, :]], axis=1)
         hist[fresh] = np.repeat(o1[fresh][:, None, :], S, axis=1)
         np.testing.assert_array_equal(oS, hist)
+
+
+def test_recv_arrays_own_their_memory_zero_copy():
+    """py_envpool.h:40-49 / state_buffer_queue.h:149-163: arrays handed out by recv
+    are never overwritten by later steps.  Large batches are views of a pinned
+    block (epa_recv_block: one D2H, no host memcpy) that is only recycled once
+    every view of it is gone."""
+    import gc
+
+    from envpool_amd.core.device_pool import DevicePool
+
+    n = 32768
+    pool = DevicePool("CartPole", n, seed=3, max_episode_steps=200)
+    ids = np.arange(n, dtype=np.int32)
+    pool.reset(ids)
+    first = pool.recv()
+    assert first[-1].base is not None  # a view into the pinned block
+    rng = np.random.default_rng(0)
+    held, copies = [first], [[a.copy() for a in first]]
+    for t in range(8):  # more batches in flight than the free list holds
+        pool.send(ids, rng.integers(0, 2, n).astype(np.int32))
+        out = pool.recv()
+        held.append(out)
+        copies.append([a.copy() for a in out])
+    for out, cp in zip(held, copies):
+        for a, c in zip(out, cp):
+            np.testing.assert_array_equal(a, c)
+    # distinct blocks while all are alive
+    addrs = {o[0].__array_interface__["data"][0] for o in held}
+    assert len(addrs) == len(held)
+    del held, out, first
+    gc.collect()
+    assert sum(len(v) for v in pool._blocks._free.values()) <= pool._blocks._MAX_FREE
+    # recycled blocks are reused: steady state allocates nothing new
+    pool.send(ids, rng.integers(0, 2, n).astype(np.int32))
+    a = pool.recv()
+    assert a[0].__array_interface__["data"][0] in addrs

@@ -36,7 +36,8 @@ def run(task, n, steps, adim=None):
 
 
 if __name__ == "__main__":
-    for task, n, steps in (("HalfCheetah-v4", 65536, 50), ("HalfCheetah-v4", 8192, 200),
-                           ("Ant-v4", 32768, 10), ("CartPole-v1", 65536, 200),
+    for task, n, steps in (("HalfCheetah-v4", 65536, 100), ("HalfCheetah-v4", 8192, 300),
+                           ("Walker2d-v4", 65536, 100),
+                           ("Ant-v4", 32768, 20), ("CartPole-v1", 65536, 200),
                            ("CartPole-v1", 64, 2000), ("FrozenLake-v1", 65536, 200)):
         print(json.dumps(run(task, n, steps)))
