@@ -20,29 +20,36 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(task="HalfCheetah", num_envs=64, target_s=15.0):
-    """Oracle ("port": oracle/mjcpu fp64 restatement, single thread) on a bounded
-    sample of the same workload.  The reference itself cannot run: mj_step lives
-    in un-vendored MuJoCo 3.6.0."""
+def cpu_baseline(task="HalfCheetah", target_s=15.0):
+    """Oracle ("port": oracle/mjcpu fp64 restatement) on a bounded sample of the
+    same workload, envs spread over ALL host cores with OpenMP (the analogue of
+    the reference's worker threads).  The reference itself cannot run: mj_step
+    lives in un-vendored MuJoCo 3.6.0."""
+    import ctypes
     import subprocess
 
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "port"], check=True)
     from oracle.orc import Oracle
 
+    probe = Oracle(task, 1, seed=0, max_episode_steps=1000)
+    probe.lib.mjcpu_num_threads.restype = ctypes.c_int
+    cores = int(probe.lib.mjcpu_num_threads())
+    num_envs = 64 * cores
     o = Oracle(task, num_envs, seed=0, max_episode_steps=1000)
     o.reset()
     rng = np.random.default_rng(0)
     act = rng.uniform(-1, 1, size=(num_envs, o.action_elems))
-    t = o.time_steps(5, act)
-    steps = max(5, int(target_s / max(t / 5, 1e-6)))
+    o.time_steps(5, act)  # warm caches / leave the reset steps behind
+    t = o.time_steps(20, act)
+    steps = max(5, int(target_s / max(t / 20, 1e-6)))
     steps = min(steps, 20000)
     t = o.time_steps(steps, act)
     return {
         "value": num_envs * steps / t,
         "unit": "env-steps/s",
-        "cores": 1,
+        "cores": cores,
         "kind": "port",
-        "sample": f"oracle/mjcpu fp64, {num_envs} envs x {steps} steps, 1 thread, "
+        "sample": f"oracle/mjcpu fp64, {num_envs} envs x {steps} steps, {cores} OpenMP threads, "
                   f"{t:.1f}s (reference mj_step not runnable: MuJoCo 3.6.0 un-vendored)",
     }
 

@@ -17,6 +17,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "../restate/rng.h"
 #include "mjcpu.h"
 
@@ -319,7 +322,18 @@ void mjcpu_reset(void* h, const int* ids, int k, void** out) {
 void mjcpu_step(void* h, const int* ids, int k, const void* action, void** out) {
   mj_pool* p = (mj_pool*)h;
   const double* a = (const double*)action;
+  /* envs are independent (one mjData each): spread them over the host cores, like
+   * the reference's worker threads (async_envpool.h:118-132).  Row i is written
+   * by exactly one thread, so the result does not depend on the thread count. */
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < k; ++i) env_step(p, ids[i], 0, a + (size_t)i * p->m.nu, out, i);
+}
+int mjcpu_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
 }
 
 void mjcpu_destroy(void* h) {
