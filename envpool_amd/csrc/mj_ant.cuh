@@ -887,21 +887,247 @@ EPA_HD int AntSolve(const AntModel<T>& m, Lds&& lds, unsigned sph,
 
 // mj_forward: qacc for state (q, v) under ctrl; `warm` is qacc_warmstart in/out.
 // Returns Newton iterations.  q's quaternion is normalised in place.
+// ---- fused front end ------------------------------------------------------------
+// mj_kinematics + mj_comPos + mj_crb + mj_comVel + mj_rne + mj_passive +
+// mj_fwdActuation of one forward pass, restructured around the tree: the torso
+// first, then ONE LEG AT A TIME (aux + foot body, hip + ankle dof).  The phase-
+// by-phase formulation above (AntKinematics / AntSmoothForces, kept for the host
+// model compiler) holds every body's frame, inertia, cdof, velocity and force
+// at once (~600 numbers) and spills; here a leg's quantities die before the next
+// leg starts, its 15 entries of M and its geometry go straight to LDS, and only
+// the torso accumulators (composite inertia, force) stay live (~100 numbers).
+// Legs are visited last to first, the accumulation order of mj_crb / mj_rne.
+template <typename T>
+EPA_HD In10<T> AntCinert(const AntModel<T>& m, int b, const Mat3<T>& R, Vec3<T> d) {
+  // body inertia rotated into the world frame, shifted to offset d = xipos - com
+  const T* I = m.inertia[b];
+  Mat3<T> Ib = {{I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}};
+  Mat3<T> RI = Mul(R, Ib);
+  const T* r = R.m;
+  const T w0 = RI.m[0] * r[0] + RI.m[1] * r[1] + RI.m[2] * r[2];
+  const T w1 = RI.m[3] * r[3] + RI.m[4] * r[4] + RI.m[5] * r[5];
+  const T w2 = RI.m[6] * r[6] + RI.m[7] * r[7] + RI.m[8] * r[8];
+  const T w3 = RI.m[0] * r[3] + RI.m[1] * r[4] + RI.m[2] * r[5];
+  const T w4 = RI.m[0] * r[6] + RI.m[1] * r[7] + RI.m[2] * r[8];
+  const T w5 = RI.m[3] * r[6] + RI.m[4] * r[7] + RI.m[5] * r[8];
+  const T mass = m.mass[b], d2 = Dot(d, d);
+  In10<T> c;
+  c.v[0] = w0 + mass * (d2 - d.x * d.x);
+  c.v[1] = w1 + mass * (d2 - d.y * d.y);
+  c.v[2] = w2 + mass * (d2 - d.z * d.z);
+  c.v[3] = w3 - mass * d.x * d.y;
+  c.v[4] = w4 - mass * d.x * d.z;
+  c.v[5] = w5 - mass * d.y * d.z;
+  c.v[6] = mass * d.x;
+  c.v[7] = mass * d.y;
+  c.v[8] = mass * d.z;
+  c.v[9] = mass;
+  return c;
+}
+
+template <typename T>
+struct AntLegFrames {  // world frames of one leg
+  Vec3<T> posA, posF;
+  Mat3<T> RA, RF;
+};
+template <int L, typename T>
+EPA_HD AntLegFrames<T> AntLegKinematics(const AntModel<T>& m, const T* q, Vec3<T> pos0,
+                                        const Mat3<T>& R0) {
+  const T zaxis[3] = {T(0), T(0), T(1)};
+  AntLegFrames<T> f;
+  f.posA = pos0 + Mul(R0, Vec3<T>{m.aux_pos[L][0], m.aux_pos[L][1], m.aux_pos[L][2]});
+  f.RA = Mul(R0, AxisAngle(zaxis, q[7 + 2 * L]));
+  f.posF = f.posA + Mul(f.RA, Vec3<T>{m.foot_pos[L][0], m.foot_pos[L][1], m.foot_pos[L][2]});
+  f.RF = Mul(f.RA, AxisAngle(m.ankle_axis[L], q[8 + 2 * L]));
+  return f;
+}
+
+// Returns the wave-uniform mask of end spheres inside the contact margin;
+// fills qfrc_smooth, the joint-limit rows and the lane's LDS block (M, geometry).
+template <typename T, typename Lds>
+EPA_HD unsigned AntFrontEnd(const AntModel<T>& m, T* q, const T* v, const T* ctrl, Lds&& lds,
+                            AntRows<T>& rows, T* qfrc_smooth) {
+  auto put = [&](int base, Vec3<T> x) {
+    lds(base) = x.x;
+    lds(base + 1) = x.y;
+    lds(base + 2) = x.z;
+  };
+  auto com_of = [&](int b, Vec3<T> pos, const Mat3<T>& R) {
+    return pos + Mul(R, Vec3<T>{m.com[b][0], m.com[b][1], m.com[b][2]});
+  };
+  unsigned mask = 0;
+  auto probe = [&](int s, T z) {  // s compile-time after unrolling
+    if (WaveAny(z - m.sph_r[s] < m.margin)) mask |= 1u << s;
+  };
+  NormalizeQuat(q + 3);  // mj_kinematics normalises the free-joint quaternion in qpos
+  const Vec3<T> pos0 = {q[0], q[1], q[2]};
+  const Mat3<T> R0 = QuatToMat(q[3], q[4], q[5], q[6]);
+  // pass A: subtree COM of the robot (mj_comPos) needs every body once
+  Vec3<T> com;
+  {
+    Vec3<T> s = com_of(0, pos0, R0) * m.mass[0];
+    static_for<0, kNLeg>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      const AntLegFrames<T> f = AntLegKinematics<l>(m, q, pos0, R0);
+      s = s + com_of(Aux(l), f.posA, f.RA) * m.mass[Aux(l)];
+      s = s + com_of(Foot(l), f.posF, f.RF) * m.mass[Foot(l)];
+    });
+    com = s * (T(1) / m.total_mass);
+  }
+  // torso: cdof of the free joint (translations are (0; e_k)), velocity, acceleration
+  Sp6<T> rdof[3];  // rotational dofs 3..5
+  static_for<0, 3>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    Vec3<T> ax = Col(R0, k);
+    rdof[k] = {ax, Cross(ax, com - pos0)};
+    put(kGeoRot + 3 * k, ax);
+  });
+  put(kGeoPos, pos0);
+  probe(0, pos0.z);
+  Sp6<T> cvel0 = {{T(0), T(0), T(0)}, {v[0], v[1], v[2]}};
+  Sp6<T> cacc0 = {{T(0), T(0), T(0)}, {T(0), T(0), m.gravity}};
+  {
+    // cdof_dot of the three rotations all use the velocity before they are added
+    Sp6<T> before = cvel0;
+    static_for<0, 3>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      Axpy(cacc0, CrossMotion(before, rdof[k]), v[3 + k]);
+      Axpy(cvel0, rdof[k], v[3 + k]);
+    });
+  }
+  const In10<T> cinert0 = AntCinert(m, 0, R0, com_of(0, pos0, R0) - com);
+  In10<T> crb0 = cinert0;  // composite inertia of the whole robot (accumulated)
+  Sp6<T> cfrc0;            // torso force + every leg's (accumulated)
+  {
+    Sp6<T> f = MulInert(cinert0, cacc0);
+    Sp6<T> g = CrossForce(cvel0, MulInert(cinert0, cvel0));
+    cfrc0 = {f.a + g.a, f.l + g.l};
+  }
+  // dot of root dof k (0..5) with a spatial force
+  auto root_dot = [&](auto kc, const Sp6<T>& f) -> T {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k == 0) return f.l.x;
+    if constexpr (k == 1) return f.l.y;
+    if constexpr (k == 2) return f.l.z;
+    if constexpr (k >= 3) return Dot(rdof[k - 3], f);
+  };
+  const T kMinVal = T(1e-15);
+  static_for_down<kNLeg, 0>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    constexpr int A = Aux(l), F = Foot(l), jh = Hip(l), ja = Ankle(l);
+    const AntLegFrames<T> f = AntLegKinematics<l>(m, q, pos0, R0);
+    // geometry block + contact candidates of this leg
+    constexpr int s0 = 1 + 6 * l;
+    const Vec3<T> tip = f.posF + Mul(f.RF, Vec3<T>{m.sph[s0 + 4][0], m.sph[s0 + 4][1], m.sph[s0 + 4][2]});
+    const Vec3<T> hz = Col(R0, 2);  // hip axis: +z of the aux frame = torso z
+    const Vec3<T> ha = Mul(f.RA, Vec3<T>{m.ankle_axis[l][0], m.ankle_axis[l][1], m.ankle_axis[l][2]});
+    put(kGeoPos + 3 * A, f.posA);
+    put(kGeoPos + 3 * F, f.posF);
+    put(kGeoTip + 3 * l, tip);
+    put(kGeoAnkle + 3 * l, ha);
+    probe(s0 + 0, f.posA.z);
+    probe(s0 + 1, pos0.z);
+    probe(s0 + 2, f.posF.z);
+    probe(s0 + 3, f.posA.z);
+    probe(s0 + 4, tip.z);
+    probe(s0 + 5, f.posF.z);
+    // inertias and motion axes about the robot COM
+    const In10<T> ciA = AntCinert(m, A, f.RA, com_of(A, f.posA, f.RA) - com);
+    const In10<T> ciF = AntCinert(m, F, f.RF, com_of(F, f.posF, f.RF) - com);
+    const Sp6<T> dh = {hz, Cross(hz, com - f.posA)};
+    const Sp6<T> da = {ha, Cross(ha, com - f.posF)};
+    // mj_crb: composite inertias foot, aux(+foot); rows of M owned by this leg
+    In10<T> crbA = ciA;
+    static_for<0, 10>([&](auto kc) { crbA.v[decltype(kc)::value] += ciF.v[decltype(kc)::value]; });
+    static_for<0, 10>([&](auto kc) { crb0.v[decltype(kc)::value] += crbA.v[decltype(kc)::value]; });
+    {
+      const Sp6<T> buf = MulInert(ciF, da);  // column of the ankle dof
+      static_for<0, 6>([&](auto kc) {
+        constexpr int slot = MSlot(decltype(kc)::value, ja);
+        lds(slot) = root_dot(kc, buf);
+      });
+      constexpr int s_ha = MSlot(jh, ja), s_aa = MSlot(ja, ja);
+      lds(s_ha) = Dot(dh, buf);
+      lds(s_aa) = Dot(da, buf) + m.arm[ja - 6];
+    }
+    {
+      const Sp6<T> buf = MulInert(crbA, dh);  // column of the hip dof
+      static_for<0, 6>([&](auto kc) {
+        constexpr int slot = MSlot(decltype(kc)::value, jh);
+        lds(slot) = root_dot(kc, buf);
+      });
+      constexpr int s_hh = MSlot(jh, jh);
+      lds(s_hh) = Dot(dh, buf) + m.arm[jh - 6];
+    }
+    // mj_comVel / mj_rne (flg_acc = 0) down the leg and back
+    Sp6<T> cvA = cvel0, caA = cacc0;
+    Axpy(caA, CrossMotion(cvel0, dh), v[jh]);
+    Axpy(cvA, dh, v[jh]);
+    Sp6<T> cvF = cvA, caF = caA;
+    Axpy(caF, CrossMotion(cvA, da), v[ja]);
+    Axpy(cvF, da, v[ja]);
+    Sp6<T> frcF, frcA;
+    {
+      Sp6<T> x = MulInert(ciF, caF);
+      Sp6<T> g = CrossForce(cvF, MulInert(ciF, cvF));
+      frcF = {x.a + g.a, x.l + g.l};
+    }
+    {
+      Sp6<T> x = MulInert(ciA, caA);
+      Sp6<T> g = CrossForce(cvA, MulInert(ciA, cvA));
+      frcA = {x.a + g.a + frcF.a, x.l + g.l + frcF.l};
+    }
+    cfrc0.a = cfrc0.a + frcA.a;
+    cfrc0.l = cfrc0.l + frcA.l;
+    // hinge damper (stiffness 0) - bias; motors are added below
+    qfrc_smooth[jh] = -m.damp[jh - 6] * v[jh] - Dot(dh, frcA);
+    qfrc_smooth[ja] = -m.damp[ja - 6] * v[ja] - Dot(da, frcF);
+  });
+  // root block of M from the composite inertia of the whole robot; root bias
+  static_for<0, 6>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    Sp6<T> di;
+    if constexpr (i < 3) {
+      di = {{T(0), T(0), T(0)}, {T(i == 0), T(i == 1), T(i == 2)}};
+    } else {
+      di = rdof[i - 3];
+    }
+    const Sp6<T> buf = MulInert(crb0, di);
+    static_for<0, i + 1>([&](auto jc) {
+      constexpr int slot = MSlot(decltype(jc)::value, i);
+      lds(slot) = root_dot(jc, buf);
+    });
+    qfrc_smooth[i] = -root_dot(ic, cfrc0);
+  });
+  static_for<0, kNU>([&](auto uc) {  // motors: gear * clamp(ctrl)
+    constexpr int u = decltype(uc)::value;
+    qfrc_smooth[CtrlDof(u)] += m.gear * ctrl[u];
+  });
+  // mj_instantiateLimit + mj_makeImpedance for the 8 limited hinges
+  static_for<0, kNU>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    T qq = q[7 + j];
+    T dlo = qq - m.lo[j], dhi = m.hi[j] - qq;
+    const T sgn = dlo < T(0) ? T(1) : (dhi < T(0) ? T(-1) : T(0));
+    const T dist = dlo < T(0) ? dlo : (dhi < T(0) ? dhi : T(0));
+    T imp = Impedance(m.imp_d0, m.imp_dmax, m.imp_width, dist);
+    const T num = (T(1) - imp) * m.dof_invw[j];  // R = max(mjMINVAL, num / imp)
+    const T Dj = num < kMinVal * imp ? T(1) / kMinVal : imp / num;
+    rows.lim_sgn[j] = sgn;
+    rows.lim_D[j] = sgn != T(0) ? Dj : T(0);
+    rows.lim_aref[j] = -m.con_B * (sgn * v[6 + j]) - m.con_K * imp * dist;
+  });
+  return WaveUniform(mask);
+}
+
 template <typename T, typename Lds>
 EPA_HD int AntForward(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, const T* v,
                       const T* ctrl, T* warm, T* qacc, Lds&& lds) {
   T qfrc_smooth[kNV];
   AntRows<T> rows;
-  unsigned sph;
-  {
-    AntPos<T> p;  // full kinematics only lives until the solver starts
-    AntKinematics(m, q, p);
-    AntSmoothForces(m, p, v, ctrl, qfrc_smooth);
-    AntMakeConstraint(m, p, q, v, rows);
-    EPA_LDS_FENCE();
-    sph = AntPublish(m, p, lds);
-    EPA_LDS_FENCE();
-  }
+  EPA_LDS_FENCE();
+  const unsigned sph = AntFrontEnd(m, q, v, ctrl, lds, rows, qfrc_smooth);
+  EPA_LDS_FENCE();
   static_for<0, kNV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
   int it = AntSolve(m, lds, sph, rows, v, qfrc_smooth, cfg, qacc);
   static_for<0, kNV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
