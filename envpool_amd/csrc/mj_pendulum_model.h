@@ -1,0 +1,163 @@
+// Host-side model compiler for the two gym inverted pendulums: the numbers of
+// third_party/mujoco_gym_xml_patches/inverted_pendulum_envpool.xml and
+// inverted_double_pendulum_envpool.xml (hand transcribed, cited by XML line; the
+// reference loads them at envpool/mujoco/gym/mujoco_env.h:50-58,87) turned into
+// what MuJoCo's compiler + mj_setConst produce: capsule mass / inertia
+// (inertiafromgeom, default density 1000), dof_invweight0 at qpos0 = 0.
+#ifndef ENVPOOL_AMD_CSRC_MJ_PENDULUM_MODEL_H_
+#define ENVPOOL_AMD_CSRC_MJ_PENDULUM_MODEL_H_
+
+#include <cmath>
+
+#include "mj_pendulum.cuh"
+
+namespace epa {
+namespace mj {
+namespace pend {
+
+inline void CapsuleMassInertia(double r, double half, double* mass, double* iperp) {
+  const double kPi = 3.14159265358979323846, density = 1000.0;
+  const double h = 2 * half;
+  const double gm = density * kPi * (r * r * h + 4.0 * r * r * r / 3.0);
+  const double sphere_mass = gm * 4 * r / (4 * r + 3 * h), cyl_mass = gm - sphere_mass;
+  *mass = gm;
+  // about an axis perpendicular to the capsule axis, through its centre
+  *iperp = cyl_mass * (3 * r * r + h * h) / 12 + 2 * sphere_mass * r * r / 5 +
+           sphere_mass * h * (3 * r + 2 * h) / 8;
+}
+
+// total mass + dof_invweight0 = diag(M^-1) at qpos0 = 0 (mj_setConst)
+template <int NL>
+inline void PendSetConst(PendModel<double, NL>& m) {
+  constexpr int NV = NL + 1;
+  m.total_mass = m.cart_mass;
+  for (int i = 0; i < NL; ++i) m.total_mass += m.mass[i];
+  const double q0[NV] = {0};
+  PendPos<double, NL> p;
+  PendKinematics(m, q0, p);
+  for (int c = 0; c < NV; ++c) {
+    double A[NV * NV], e[NV] = {0};
+    for (int k = 0; k < NV * NV; ++k) A[k] = p.M[k];
+    e[c] = 1;
+    CholSolve<double, NV>(A, e);
+    m.dof_invw[c] = e[c];
+  }
+}
+
+inline void PendDefaults(double timestep, double* K, double* B, double* d0, double* dmax,
+                         double* width) {
+  // MuJoCo defaults: solref .02 1 (timeconst clamped to 2 * timestep), solimp .9 .95 .001
+  const double tc = std::fmax(0.02, 2 * timestep), dr = 1.0;
+  *d0 = 0.9;
+  *dmax = 0.95;
+  *width = 0.001;
+  *K = 1.0 / (0.95 * 0.95 * tc * tc * dr * dr);
+  *B = 2.0 / (0.95 * tc);
+}
+
+// inverted_pendulum_envpool.xml
+inline PendModel<double, 1> BuildInvertedPendulum() {
+  const double deg = 3.14159265358979323846 / 180.0;  // <compiler> default angle = degree
+  PendModel<double, 1> m{};
+  double iperp;
+  CapsuleMassInertia(0.1, 0.1, &m.cart_mass, &iperp);  // cart capsule size=".1 .1" :32
+  // pole: fromto="0 0 0 0.001 0 0.6" size="0.049 0.3" :35 (fromto fixes the length)
+  const double tx = 0.001, tz = 0.6, half = 0.5 * std::sqrt(tx * tx + tz * tz);
+  CapsuleMassInertia(0.049, half, &m.mass[0], &m.iyy[0]);
+  m.cx[0] = 0.5 * tx;
+  m.cz[0] = 0.5 * tz;
+  m.lx[0] = tx;  // no site in this model: the far end of the pole
+  m.lz[0] = tz;
+  // <joint armature="0" damping="1" limited="true"/> :20; slider range -1 1 :31,
+  // hinge range -90 90 (degrees) :34
+  m.damp[0] = m.damp[1] = 1.0;
+  m.limited[0] = m.limited[1] = 1;
+  m.lo[0] = -1;
+  m.hi[0] = 1;
+  m.lo[1] = -90 * deg;
+  m.hi[1] = 90 * deg;
+  m.margin[0] = m.margin[1] = 0;
+  m.grav_x = 0;
+  m.grav_z = -9.81;  // :25
+  m.timestep = 0.02;  // :25, integrator RK4
+  m.gear = 100;       // :41, ctrlrange -3 3
+  m.ctrl_lo = -3;
+  m.ctrl_hi = 3;
+  PendDefaults(m.timestep, &m.lim_K, &m.lim_B, &m.lim_d0, &m.lim_dmax, &m.lim_width);
+  PendSetConst(m);
+  return m;
+}
+
+// inverted_double_pendulum_envpool.xml
+inline PendModel<double, 2> BuildInvertedDoublePendulum() {
+  PendModel<double, 2> m{};
+  double iperp;
+  CapsuleMassInertia(0.1, 0.1, &m.cart_mass, &iperp);  // cart :48
+  for (int i = 0; i < 2; ++i) {  // poles: fromto="0 0 0 0 0 0.6" size="0.045 0.3" :51,:54
+    CapsuleMassInertia(0.045, 0.3, &m.mass[i], &m.iyy[i]);
+    m.cx[i] = 0;
+    m.cz[i] = 0.3;
+    m.lx[i] = 0;  // pole2 at pos="0 0 0.6" :52; "tip" site pos="0 0 .6" :55
+    m.lz[i] = 0.6;
+  }
+  // <joint damping="0.05"/> :38; only the slider is limited: range -1 1, margin 0.01 :47
+  for (int j = 0; j < 3; ++j) {
+    m.damp[j] = 0.05;
+    m.limited[j] = 0;
+    m.lo[j] = m.hi[j] = m.margin[j] = 0;
+  }
+  m.limited[0] = 1;
+  m.lo[0] = -1;
+  m.hi[0] = 1;
+  m.margin[0] = 0.01;
+  m.grav_x = 1e-5;  // gravity="1e-5 0 -9.81" :41
+  m.grav_z = -9.81;
+  m.timestep = 0.01;  // :41, integrator RK4
+  m.gear = 500;       // :60, ctrlrange -1 1
+  m.ctrl_lo = -1;
+  m.ctrl_hi = 1;
+  PendDefaults(m.timestep, &m.lim_K, &m.lim_B, &m.lim_d0, &m.lim_dmax, &m.lim_width);
+  PendSetConst(m);
+  return m;
+}
+
+template <typename T, int NL>
+inline PendModel<T, NL> CastPendModel(const PendModel<double, NL>& d) {
+  PendModel<T, NL> m{};
+  m.cart_mass = (T)d.cart_mass;
+  for (int i = 0; i < NL; ++i) {
+    m.mass[i] = (T)d.mass[i];
+    m.iyy[i] = (T)d.iyy[i];
+    m.cx[i] = (T)d.cx[i];
+    m.cz[i] = (T)d.cz[i];
+    m.lx[i] = (T)d.lx[i];
+    m.lz[i] = (T)d.lz[i];
+  }
+  for (int j = 0; j <= NL; ++j) {
+    m.damp[j] = (T)d.damp[j];
+    m.limited[j] = d.limited[j];
+    m.lo[j] = (T)d.lo[j];
+    m.hi[j] = (T)d.hi[j];
+    m.margin[j] = (T)d.margin[j];
+    m.dof_invw[j] = (T)d.dof_invw[j];
+  }
+  m.grav_x = (T)d.grav_x;
+  m.grav_z = (T)d.grav_z;
+  m.gear = (T)d.gear;
+  m.ctrl_lo = (T)d.ctrl_lo;
+  m.ctrl_hi = (T)d.ctrl_hi;
+  m.lim_K = (T)d.lim_K;
+  m.lim_B = (T)d.lim_B;
+  m.lim_d0 = (T)d.lim_d0;
+  m.lim_dmax = (T)d.lim_dmax;
+  m.lim_width = (T)d.lim_width;
+  m.timestep = (T)d.timestep;
+  m.total_mass = (T)d.total_mass;
+  return m;
+}
+
+}  // namespace pend
+}  // namespace mj
+}  // namespace epa
+
+#endif  // ENVPOOL_AMD_CSRC_MJ_PENDULUM_MODEL_H_

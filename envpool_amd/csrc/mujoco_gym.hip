@@ -390,6 +390,9 @@ class CheetahPool : public Pool {
 bool DescribeAnt(const std::string& family, const Config& cfg,
                  std::vector<KeySpec>* state, KeySpec* action);
 Pool* MakeAnt(const std::string& family, const Config& cfg);
+bool DescribePendulum(const std::string& family, const Config& cfg,
+                      std::vector<KeySpec>* state, KeySpec* action);
+Pool* MakePendulum(const std::string& family, const Config& cfg);
 
 bool DescribeMujoco(const std::string& family, const Config& cfg,
                     std::vector<KeySpec>* state, KeySpec* action) {
@@ -398,6 +401,7 @@ bool DescribeMujoco(const std::string& family, const Config& cfg,
     *action = KeySpec{"action", EPA_F64, {kNU}};
     return true;
   }
+  if (DescribePendulum(family, cfg, state, action)) return true;
   return DescribeAnt(family, cfg, state, action);
 }
 
@@ -408,6 +412,7 @@ Pool* MakeMujoco(const std::string& family, const Config& cfg) {
     return new CheetahPool(cfg, cfg.Get("xml_v5", 0) != 0 ? mj::kPlanarWalkerV5
                                                          : mj::kPlanarWalker);
   }
+  if (Pool* p = MakePendulum(family, cfg)) return p;
   return MakeAnt(family, cfg);
 }
 

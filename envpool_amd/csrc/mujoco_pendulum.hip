@@ -1,0 +1,285 @@
+// gym InvertedPendulum / InvertedDoublePendulum batched step kernel (one env
+// per thread).  Replaces, for the whole batch in one launch:
+//   MujocoEnv::{MujocoReset,MujocoStep}        envpool/mujoco/gym/mujoco_env.h:126-148
+//   InvertedPendulumEnvBase::{MujocoResetModel,Reset,Step,WriteState}
+//                                              envpool/mujoco/gym/inverted_pendulum.h:100-185
+//   InvertedDoublePendulumEnvBase::{...}       envpool/mujoco/gym/inverted_double_pendulum.h:108-186
+// with the `frame_skip x mj_step` (RK4) physics of mj_pendulum.cuh.  No contacts
+// (every geom has contype 0), joint limits only; state is 3 x nv doubles per env,
+// so unlike the legged robots this kernel is HBM-streaming: 2 (3) dofs, ~2e3
+// flops and ~250 algorithmic bytes per env-step.
+#include "device_common.cuh"
+#include "engine.h"
+#include "mj_pendulum.cuh"
+#include "mj_pendulum_model.h"
+
+namespace epa {
+namespace {
+
+namespace P = mj::pend;
+
+struct PendDev {
+  double* qpos;  // [nv][N]
+  double* qvel;  // [nv][N]
+  double* warm;  // [nv][N]
+  double* nsaved;          // normal_distribution::_M_saved (double pendulum qvel noise)
+  unsigned char* navail;   // normal_distribution::_M_saved_available
+};
+
+struct PendTask {
+  int frame_skip;
+  int reward_if_not_terminated;
+  int constraint_obs_dim;  // double pendulum: 3 (v2/v4) or 1 (v5)
+  double healthy_reward, healthy_z_min, healthy_z_max, reset_noise_scale;
+  double observation_min, observation_max;
+};
+
+constexpr int kPendBlock = 256;
+
+template <int NL>
+__global__ __launch_bounds__(kPendBlock) void PendStepKernel(
+    PendDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
+    P::PendModel<double, NL> m, PendTask task, mj::SolverCfg<double> scfg) {
+  constexpr int NV = NL + 1;
+  const int n = cm.n;
+  const int row = blockIdx.x * kPendBlock + threadIdx.x;
+  if (row >= a.k) return;
+  const int e = a.ids ? a.ids[row] - a.id_offset : row;
+  bool done = cm.done[e] != 0;
+  int cur = cm.cur_step[e];
+  const bool reset = a.force_reset || done;  // async_envpool.h:127
+  double q[NV], v[NV], w[NV];
+  P::PendAux<double, NL> aux{};
+  float reward = 0.0f;
+  if (reset) {
+    // MujocoReset: mj_resetData, MujocoResetModel, mj_forward (mujoco_env.h:126-131)
+    cur = 0;
+    done = false;
+    Mt19937 g(cm, e);
+    double saved = dev.nsaved[e];
+    int avail = dev.navail[e];
+    for (int i = 0; i < NV; ++i) {
+      q[i] = 0.0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
+    }
+    for (int i = 0; i < NV; ++i) {
+      if constexpr (NL == 1) {  // inverted_pendulum.h:100-107: uniform
+        v[i] = 0.0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
+      } else {  // inverted_double_pendulum.h:117-124: normal
+        v[i] = 0.0 + g.Normal(0.0, task.reset_noise_scale, &saved, &avail);
+      }
+      w[i] = 0.0;
+    }
+    g.Commit();
+    dev.nsaved[e] = saved;
+    dev.navail[e] = (unsigned char)avail;
+    double qacc[NV];
+    P::PendForward(m, scfg, q, v, 0.0, w, qacc, aux);  // ctrl = 0 after mj_resetData
+  } else {
+    ++cur;
+    mj::static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      q[i] = dev.qpos[(size_t)i * n + e];
+      v[i] = dev.qvel[(size_t)i * n + e];
+      w[i] = dev.warm[(size_t)i * n + e];
+    });
+    const double act = action[row];
+    for (int s = 0; s < task.frame_skip; ++s) {  // mujoco_env.h:142-144
+      P::PendStepRK4(m, scfg, q, v, w, act, aux);
+    }
+    bool terminated;
+    if constexpr (NL == 1) {  // inverted_pendulum.h:137-148,151-167
+      bool healthy = !(q[1] < task.healthy_z_min || q[1] > task.healthy_z_max);
+      mj::static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        healthy = healthy && isfinite(q[i]) && isfinite(v[i]);
+      });
+      terminated = !healthy;
+      reward = task.reward_if_not_terminated ? static_cast<float>(!terminated) : 1.0f;
+    } else {  // inverted_double_pendulum.h:126-151; site_xpos of the last RK4 stage
+      const double x = aux.tip_x, y = aux.tip_z;
+      const double dist_penalty = 0.01 * x * x + (y - 2) * (y - 2);
+      const double vel_penalty = 1e-3 * v[1] * v[1] + 5e-3 * v[2] * v[2];
+      terminated = !(y > task.healthy_z_max);
+      const double alive_bonus = task.reward_if_not_terminated
+                                     ? task.healthy_reward * static_cast<int>(!terminated)
+                                     : task.healthy_reward;
+      reward = static_cast<float>(alive_bonus - dist_penalty - vel_penalty);
+    }
+    done = terminated || cur >= a.max_episode_steps;
+  }
+  mj::static_for<0, NV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    dev.qpos[(size_t)i * n + e] = q[i];
+    dev.qvel[(size_t)i * n + e] = v[i];
+    dev.warm[(size_t)i * n + e] = w[i];
+  });
+  cm.done[e] = done ? 1 : 0;
+  cm.cur_step[e] = cur;
+  if constexpr (NL == 1) {  // WriteState, inverted_pendulum.h:169-180
+    double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * 4;
+    obs[0] = q[0];
+    obs[1] = q[1];
+    obs[2] = v[0];
+    obs[3] = v[1];
+  } else {  // inverted_double_pendulum.h:153-182
+    const int nobs = 8 + task.constraint_obs_dim;
+    double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
+    auto clip = [&](double x) {
+      x = task.observation_max < x ? task.observation_max : x;  // std::min(max_, x)
+      x = task.observation_min > x ? task.observation_min : x;  // std::max(min_, x)
+      return x;
+    };
+    obs[0] = q[0];
+    obs[1] = sin(q[1]);
+    obs[2] = sin(q[2]);
+    obs[3] = cos(q[1]);
+    obs[4] = cos(q[2]);
+    mj::static_for<0, NV>([&](auto ic) { obs[5 + decltype(ic)::value] = clip(v[decltype(ic)::value]); });
+    mj::static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if (i < task.constraint_obs_dim) obs[8 + i] = clip(aux.qfrc_constraint[i]);
+    });
+  }
+  WriteCommon(out, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
+}
+
+// flat state, same layout as oracle/mjcpu: qpos[nv] qvel[nv] warm[nv] time xlag
+// ylag done cur_step normal_saved normal_avail
+template <int NV>
+__global__ void PendGetState(PendDev dev, CommonDev cm, const int* ids, int k, double* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  int e = ids[i], n = cm.n;
+  double* o = out + (size_t)i * (3 * NV + 7);
+  for (int j = 0; j < NV; ++j) {
+    o[j] = dev.qpos[(size_t)j * n + e];
+    o[NV + j] = dev.qvel[(size_t)j * n + e];
+    o[2 * NV + j] = dev.warm[(size_t)j * n + e];
+  }
+  double* t = o + 3 * NV;
+  t[0] = t[1] = t[2] = 0;
+  t[3] = cm.done[e];
+  t[4] = cm.cur_step[e];
+  t[5] = dev.nsaved[e];
+  t[6] = dev.navail[e];
+}
+template <int NV>
+__global__ void PendSetState(PendDev dev, CommonDev cm, const int* ids, int k, const double* in) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  int e = ids[i], n = cm.n;
+  const double* o = in + (size_t)i * (3 * NV + 7);
+  for (int j = 0; j < NV; ++j) {
+    dev.qpos[(size_t)j * n + e] = o[j];
+    dev.qvel[(size_t)j * n + e] = o[NV + j];
+    dev.warm[(size_t)j * n + e] = o[2 * NV + j];
+  }
+  const double* t = o + 3 * NV;
+  cm.done[e] = t[3] != 0.0;
+  cm.cur_step[e] = (int)t[4];
+  dev.nsaved[e] = t[5];
+  dev.navail[e] = t[6] != 0.0;
+}
+
+int PendObsDim(const Config& cfg, int nl) {
+  if (nl == 1) return 4;  // inverted_pendulum.h:43-55
+  int c = (int)cfg.Get("constraint_obs_dim", 3);
+  if (c < 0 || c > 3) throw std::invalid_argument("constraint_obs_dim must be in [0, 3]");
+  return 1 + 2 + 2 + 3 + c;  // inverted_double_pendulum.h:46-60
+}
+
+template <int NL>
+class PendPool : public Pool {
+ public:
+  static constexpr int NV = NL + 1;
+  explicit PendPool(const Config& cfg)
+      : Pool(cfg, {{"obs", EPA_F64, {PendObsDim(cfg, NL)}}}, KeySpec{"action", EPA_F64, {1}},
+             /*needs_rng=*/true) {
+    if ((int)cfg.Get("frame_stack", 1) != 1) {
+      throw std::invalid_argument("frame_stack > 1 is not supported for the inverted pendulums yet");
+    }
+    if constexpr (NL == 1) {
+      model1_ = P::BuildInvertedPendulum();
+    } else {
+      model2_ = P::BuildInvertedDoublePendulum();
+    }
+    // defaults: inverted_pendulum.h:32-41 / inverted_double_pendulum.h:32-44
+    task_.frame_skip = (int)cfg.Get("frame_skip", NL == 1 ? 2 : 5);
+    task_.reward_if_not_terminated = cfg.Get("reward_if_not_terminated", 0) != 0;
+    task_.constraint_obs_dim = NL == 1 ? 0 : (int)cfg.Get("constraint_obs_dim", 3);
+    task_.healthy_reward = cfg.Get("healthy_reward", NL == 1 ? 1.0 : 10.0);
+    task_.healthy_z_min = cfg.Get("healthy_z_min", -0.2);
+    task_.healthy_z_max = cfg.Get("healthy_z_max", NL == 1 ? 0.2 : 1.0);
+    task_.reset_noise_scale = cfg.Get("reset_noise_scale", NL == 1 ? 0.01 : 0.1);
+    task_.observation_min = cfg.Get("observation_min", -10.0);
+    task_.observation_max = cfg.Get("observation_max", 10.0);
+    size_t n = cfg.num_envs;
+    EPA_HIP(hipMalloc(&dev_.qpos, sizeof(double) * NV * n));
+    EPA_HIP(hipMalloc(&dev_.qvel, sizeof(double) * NV * n));
+    EPA_HIP(hipMalloc(&dev_.warm, sizeof(double) * NV * n));
+    EPA_HIP(hipMalloc(&dev_.nsaved, sizeof(double) * n));
+    EPA_HIP(hipMalloc(&dev_.navail, n));
+    EPA_HIP(hipMemsetAsync(dev_.qpos, 0, sizeof(double) * NV * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.qvel, 0, sizeof(double) * NV * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.warm, 0, sizeof(double) * NV * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.nsaved, 0, sizeof(double) * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.navail, 0, n, stream_));
+    InitCommon();
+  }
+  ~PendPool() override {
+    (void)hipFree(dev_.qpos);
+    (void)hipFree(dev_.qvel);
+    (void)hipFree(dev_.warm);
+    (void)hipFree(dev_.nsaved);
+    (void)hipFree(dev_.navail);
+  }
+  int StateDim() const override { return 3 * NV + 7; }
+  void GetState(const int* d_ids, int k, double* d_out) override {
+    hipLaunchKernelGGL(PendGetState<NV>, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
+                       common_, d_ids, k, d_out);
+  }
+  void SetState(const int* d_ids, int k, const double* d_in) override {
+    hipLaunchKernelGGL(PendSetState<NV>, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
+                       common_, d_ids, k, d_in);
+  }
+
+ protected:
+  void Launch(const int* d_ids, int k, const void* d_action, bool force_reset,
+              const OutPtrs& out) override {
+    StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps, cfg_.env_id_offset};
+    int blocks = (k + kPendBlock - 1) / kPendBlock;
+    const mj::SolverCfg<double> sc{50, 1e-13};
+    if constexpr (NL == 1) {
+      hipLaunchKernelGGL(PendStepKernel<1>, dim3(blocks), dim3(kPendBlock), 0, stream_, dev_,
+                         common_, a, static_cast<const double*>(d_action), out, model1_, task_, sc);
+    } else {
+      hipLaunchKernelGGL(PendStepKernel<2>, dim3(blocks), dim3(kPendBlock), 0, stream_, dev_,
+                         common_, a, static_cast<const double*>(d_action), out, model2_, task_, sc);
+    }
+  }
+
+ private:
+  PendDev dev_{};
+  P::PendModel<double, 1> model1_{};
+  P::PendModel<double, 2> model2_{};
+  PendTask task_{};
+};
+
+}  // namespace
+
+bool DescribePendulum(const std::string& family, const Config& cfg,
+                      std::vector<KeySpec>* state, KeySpec* action) {
+  int nl = family == "InvertedPendulum" ? 1 : (family == "InvertedDoublePendulum" ? 2 : 0);
+  if (nl == 0) return false;
+  *state = {{"obs", EPA_F64, {PendObsDim(cfg, nl)}}};
+  *action = KeySpec{"action", EPA_F64, {1}};
+  return true;
+}
+
+Pool* MakePendulum(const std::string& family, const Config& cfg) {
+  if (family == "InvertedPendulum") return new PendPool<1>(cfg);
+  if (family == "InvertedDoublePendulum") return new PendPool<2>(cfg);
+  return nullptr;
+}
+
+}  // namespace epa

@@ -2,7 +2,8 @@
 
 Spec tables restate `HalfCheetahEnvFns` (half_cheetah.h:31-62), `AntEnvFns`
 (ant.h:31-75, v4: use_contact_force=False) and `Walker2dEnvFns`
-(walker2d.h:30-67); the pixel
+(walker2d.h:30-67), `InvertedPendulumEnvFns` (inverted_pendulum.h:30-60) and
+`InvertedDoublePendulumEnvFns` (inverted_double_pendulum.h:30-62); the pixel
 variants are out of scope.  `precision` is an extension key: 64 (default, the
 reference's mjtNum=double) or 32 (fp32 arithmetic, fp64 state and I/O).
 """
@@ -161,7 +162,72 @@ _Walker2d = FamilyDef(
     },
 )
 
+_InvertedPendulum = FamilyDef(
+    name="GymInvertedPendulum", native="InvertedPendulum",
+    # inverted_pendulum.h:32-41
+    default_config=[
+        ("reward_threshold", 950.0), ("frame_skip", 2), ("frame_stack", 1),
+        ("post_constraint", True), ("healthy_reward", 1.0),
+        ("reward_if_not_terminated", False), ("xml_file", "inverted_pendulum.xml"),
+        ("gymnasium_v5_render_camera", False), ("healthy_z_min", -0.2),
+        ("healthy_z_max", 0.2), ("reset_noise_scale", 0.01),
+    ],
+    state_spec=lambda c: [("obs", spec(np.float64, _stack([4], c), (-_inf, _inf)))],
+    action_spec=lambda c: [("action", spec(np.float64, [-1, 1], (-3.0, 3.0)))],
+    native_params=lambda c: {
+        "frame_skip": c["frame_skip"], "frame_stack": c["frame_stack"],
+        "healthy_reward": c["healthy_reward"],
+        "reward_if_not_terminated": c["reward_if_not_terminated"],
+        "healthy_z_min": c["healthy_z_min"], "healthy_z_max": c["healthy_z_max"],
+        "reset_noise_scale": c["reset_noise_scale"],
+    },
+    unsupported={"xml_file": "inverted_pendulum.xml", "frame_stack": 1},
+)
+
+
+def _constraint_obs_dim(c):
+    if not 0 <= c["constraint_obs_dim"] <= 3:
+        raise ValueError("constraint_obs_dim must be in [0, 3]")
+    return c["constraint_obs_dim"]
+
+
+_InvertedDoublePendulum = FamilyDef(
+    name="GymInvertedDoublePendulum", native="InvertedDoublePendulum",
+    # inverted_double_pendulum.h:32-44
+    default_config=[
+        ("reward_threshold", 9100.0), ("frame_skip", 5), ("frame_stack", 1),
+        ("post_constraint", True), ("healthy_reward", 10.0),
+        ("reward_if_not_terminated", False), ("constraint_obs_dim", 3),
+        ("xml_file", "inverted_double_pendulum.xml"),
+        ("gymnasium_v5_render_camera", False), ("healthy_z_max", 1.0),
+        ("observation_min", -10.0), ("observation_max", 10.0),
+        ("reset_noise_scale", 0.1),
+    ],
+    state_spec=lambda c: [
+        ("obs", spec(np.float64, _stack([8 + _constraint_obs_dim(c)], c), (-_inf, _inf)))],
+    action_spec=lambda c: [("action", spec(np.float64, [-1, 1], (-1.0, 1.0)))],
+    native_params=lambda c: {
+        "frame_skip": c["frame_skip"], "frame_stack": c["frame_stack"],
+        "healthy_reward": c["healthy_reward"],
+        "reward_if_not_terminated": c["reward_if_not_terminated"],
+        "constraint_obs_dim": _constraint_obs_dim(c),
+        "healthy_z_max": c["healthy_z_max"],
+        "observation_min": c["observation_min"], "observation_max": c["observation_max"],
+        "reset_noise_scale": c["reset_noise_scale"],
+    },
+    unsupported={"xml_file": "inverted_double_pendulum.xml", "frame_stack": 1},
+)
+
 _GymHalfCheetahEnvSpec, _GymHalfCheetahEnvPool = make_native_classes(_HalfCheetah)
+_GymInvertedPendulumEnvSpec, _GymInvertedPendulumEnvPool = make_native_classes(_InvertedPendulum)
+(GymInvertedPendulumEnvSpec, GymInvertedPendulumDMEnvPool,
+ GymInvertedPendulumGymnasiumEnvPool) = py_env(_GymInvertedPendulumEnvSpec,
+                                               _GymInvertedPendulumEnvPool)
+(_GymInvertedDoublePendulumEnvSpec,
+ _GymInvertedDoublePendulumEnvPool) = make_native_classes(_InvertedDoublePendulum)
+(GymInvertedDoublePendulumEnvSpec, GymInvertedDoublePendulumDMEnvPool,
+ GymInvertedDoublePendulumGymnasiumEnvPool) = py_env(_GymInvertedDoublePendulumEnvSpec,
+                                                     _GymInvertedDoublePendulumEnvPool)
 _GymWalker2dEnvSpec, _GymWalker2dEnvPool = make_native_classes(_Walker2d)
 (GymWalker2dEnvSpec, GymWalker2dDMEnvPool,
  GymWalker2dGymnasiumEnvPool) = py_env(_GymWalker2dEnvSpec, _GymWalker2dEnvPool)
@@ -173,4 +239,7 @@ GymAntEnvSpec, GymAntDMEnvPool, GymAntGymnasiumEnvPool = py_env(_GymAntEnvSpec, 
 __all__ = ["GymHalfCheetahEnvSpec", "GymHalfCheetahDMEnvPool",
            "GymHalfCheetahGymnasiumEnvPool", "GymAntEnvSpec", "GymAntDMEnvPool",
            "GymAntGymnasiumEnvPool", "GymWalker2dEnvSpec", "GymWalker2dDMEnvPool",
-           "GymWalker2dGymnasiumEnvPool"]
+           "GymWalker2dGymnasiumEnvPool", "GymInvertedPendulumEnvSpec",
+           "GymInvertedPendulumDMEnvPool", "GymInvertedPendulumGymnasiumEnvPool",
+           "GymInvertedDoublePendulumEnvSpec", "GymInvertedDoublePendulumDMEnvPool",
+           "GymInvertedDoublePendulumGymnasiumEnvPool"]

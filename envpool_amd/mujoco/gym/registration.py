@@ -6,6 +6,8 @@ gym_mujoco_envs = [
     # the MI355X kernel does not restate yet: only Ant-v4 is registered.
     ("Ant", ("v4",), 1000),
     ("HalfCheetah", ("v3", "v4", "v5"), 1000),
+    ("InvertedDoublePendulum", ("v2", "v4", "v5"), 1000),
+    ("InvertedPendulum", ("v2", "v4", "v5"), 1000),
     ("Walker2d", ("v3", "v4", "v5"), 1000),
 ]
 
@@ -14,6 +16,13 @@ for task, versions, max_episode_steps in gym_mujoco_envs:
         extra_args = {}
         if version == "v5":
             extra_args["gymnasium_v5_render_camera"] = True
+        if task == "InvertedDoublePendulum" and version == "v5":  # gym/registration.py:61-65
+            extra_args.update({
+                "constraint_obs_dim": 1,
+                "reward_if_not_terminated": True,
+            })
+        if task == "InvertedPendulum" and version == "v5":  # gym/registration.py:66-67
+            extra_args["reward_if_not_terminated"] = True
         if task == "Walker2d" and version == "v5":  # gym/registration.py:79-83
             extra_args.update({
                 "xml_file": "walker2d_v5.xml",

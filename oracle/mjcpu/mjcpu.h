@@ -1,8 +1,9 @@
 /* TEST INFRASTRUCTURE — NOT PRODUCT CODE.
  *
  * oracle/mjcpu: float64 CPU restatement of the part of the MuJoCo 3.6.0
- * pipeline that `mj_step` / `mj_forward` execute for the gym HalfCheetah, Ant
- * and Walker2d models, plus the task logic around it.
+ * pipeline that `mj_step` / `mj_forward` execute for the gym HalfCheetah, Ant,
+ * Walker2d, InvertedPendulum and InvertedDoublePendulum models, plus the task
+ * logic around it.
  *
  * PARITY UNPINNED for the engine part: the arithmetic lives in the third-party
  * dependency google-deepmind/mujoco tag 3.6.0 (pinned in the reference at
@@ -14,9 +15,11 @@
  *   - call sites: envpool/mujoco/gym/mujoco_env.h:126-148 (mj_resetData,
  *     mj_forward, ctrl <- action, frame_skip x mj_step)
  *   - task logic: envpool/mujoco/gym/half_cheetah.h:105-185, ant.h:135-278,
- *     walker2d.h:119-203
+ *     walker2d.h:119-203, inverted_pendulum.h:100-185,
+ *     inverted_double_pendulum.h:108-186
  *   - model constants: third_party/mujoco_gym_xml_patches/half_cheetah_envpool.xml,
- *     ant_envpool.xml, walker2d_envpool.xml, walker2d_v5_envpool.xml
+ *     ant_envpool.xml, walker2d_envpool.xml, walker2d_v5_envpool.xml,
+ *     inverted_pendulum_envpool.xml, inverted_double_pendulum_envpool.xml
  *     (hand-transcribed in models.c, line-cited)
  * and is checked by physics invariants (tests/test_mjcpu_invariants.py).
  * tools/pin_with_mujoco.py dumps golden vectors wherever `mujoco==3.6.0` is
@@ -138,6 +141,8 @@ void mjc_compile(mjc_model* m);
 void mjc_build_half_cheetah(mjc_model* m);
 void mjc_build_ant(mjc_model* m);
 void mjc_build_walker2d(mjc_model* m, int v5);
+void mjc_build_inverted_pendulum(mjc_model* m);
+void mjc_build_inverted_double_pendulum(mjc_model* m);
 
 /* engine.c */
 void mjc_reset_data(const mjc_model* m, mjc_data* d);

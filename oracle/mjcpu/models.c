@@ -6,6 +6,8 @@
  *   third_party/mujoco_gym_xml_patches/ant_envpool.xml
  *   third_party/mujoco_gym_xml_patches/walker2d_envpool.xml (v3/v4),
  *   walker2d_v5_envpool.xml (v5: right foot friction 1.9 instead of 0.9, :47)
+ *   third_party/mujoco_gym_xml_patches/inverted_pendulum_envpool.xml,
+ *   inverted_double_pendulum_envpool.xml
  * Numbers are cited by XML line (":NN").
  */
 #include <math.h>
@@ -295,5 +297,94 @@ void mjc_build_walker2d(mjc_model* m, int v5) {
   /* actuators :68-73, gear 100 */
   for (int i = 0; i < 3; ++i) mjc_add_motor(m, jr[i], 100);
   for (int i = 0; i < 3; ++i) mjc_add_motor(m, jl[i], 100);
+  mjc_compile(m);
+}
+
+/* ---- InvertedPendulum / InvertedDoublePendulum -------------------------------------- */
+/* every geom: <geom contype="0" friction="1 0.1 0.1"/> (:21 / :39): with the
+ * default conaffinity=1 no pair passes the contype/conaffinity filter => no
+ * contacts at all; the geoms only provide mass and inertia. */
+static int pend_geom(mjc_model* m, int g) {
+  m->geom_contype[g] = 0;
+  m->geom_friction[g][0] = 1;
+  m->geom_friction[g][1] = 0.1;
+  m->geom_friction[g][2] = 0.1;
+  return g;
+}
+
+static void pend_quat_y90(double quat[4]) { /* quat="0.707 0 0.707 0", normalised */
+  const double n = sqrt(0.707 * 0.707 * 2);
+  quat[0] = 0.707 / n;
+  quat[1] = 0;
+  quat[2] = 0.707 / n;
+  quat[3] = 0;
+}
+
+void mjc_build_inverted_pendulum(mjc_model* m) {
+  const double deg = 3.14159265358979323846 / 180.0; /* <compiler> default: degree */
+  const double xaxis[3] = {1, 0, 0}, yaxis[3] = {0, 1, 0};
+  double q90[4];
+  pend_quat_y90(q90);
+  mjc_model_init(m);
+  m->timestep = 0.02;          /* :25 */
+  m->integrator = MJC_INT_RK4; /* :25 */
+  m->gravity[2] = -9.81;       /* :25 */
+  { /* rail :29 (worldbody geom: mass irrelevant) */
+    const double size[3] = {0.02, 1, 0};
+    pend_geom(m, mjc_add_geom(m, 0, MJC_GEOM_CAPSULE, size, kZero3, q90));
+  }
+  /* <joint armature="0" damping="1" limited="true"/> :20 */
+  int cart = mjc_add_body(m, 0, kZero3); /* :30 */
+  int slider = mjc_add_joint(m, cart, MJC_JNT_SLIDE, kZero3, xaxis, 1, -1, 1, 0, 1, 0); /* :31 */
+  {
+    const double size[3] = {0.1, 0.1, 0}; /* :32 */
+    pend_geom(m, mjc_add_geom(m, cart, MJC_GEOM_CAPSULE, size, kZero3, q90));
+  }
+  int pole = mjc_add_body(m, cart, kZero3); /* :33 */
+  mjc_add_joint(m, pole, MJC_JNT_HINGE, kZero3, yaxis, 1, -90 * deg, 90 * deg, 0, 1, 0); /* :34 */
+  {
+    /* fromto="0 0 0 0.001 0 0.6" size="0.049 0.3" :35 (fromto overrides the length) */
+    const double from[3] = {0, 0, 0}, to[3] = {0.001, 0, 0.6};
+    pend_geom(m, mjc_add_capsule_fromto(m, pole, from, to, 0.049));
+  }
+  mjc_add_motor(m, slider, 100); /* :41 gear 100, ctrlrange -3 3 */
+  m->act_ctrlrange[0][0] = -3;
+  m->act_ctrlrange[0][1] = 3;
+  mjc_compile(m);
+}
+
+void mjc_build_inverted_double_pendulum(mjc_model* m) {
+  const double xaxis[3] = {1, 0, 0}, yaxis[3] = {0, 1, 0};
+  const double quat_id[4] = {1, 0, 0, 0};
+  double q90[4];
+  pend_quat_y90(q90);
+  mjc_model_init(m);
+  m->timestep = 0.01;          /* :41 */
+  m->integrator = MJC_INT_RK4; /* :41 */
+  m->gravity[0] = 1e-5;        /* gravity="1e-5 0 -9.81" :41 */
+  m->gravity[2] = -9.81;
+  { /* floor :44 and rail :45 (world geoms, contype 0) */
+    const double fsize[3] = {40, 40, 40}, fpos[3] = {0, 0, -3.0};
+    pend_geom(m, mjc_add_geom(m, 0, MJC_GEOM_PLANE, fsize, fpos, quat_id));
+    const double size[3] = {0.02, 1, 0};
+    pend_geom(m, mjc_add_geom(m, 0, MJC_GEOM_CAPSULE, size, kZero3, q90));
+  }
+  /* <joint damping="0.05"/> :38 (armature 0, not limited unless stated) */
+  int cart = mjc_add_body(m, 0, kZero3); /* :46 */
+  int slider = mjc_add_joint(m, cart, MJC_JNT_SLIDE, kZero3, xaxis, 1, -1, 1, 0, 0.05, 0);
+  m->jnt_margin[slider] = 0.01; /* margin="0.01" :47 */
+  {
+    const double size[3] = {0.1, 0.1, 0}; /* :48 */
+    pend_geom(m, mjc_add_geom(m, cart, MJC_GEOM_CAPSULE, size, kZero3, q90));
+  }
+  int pole = mjc_add_body(m, cart, kZero3); /* :49 */
+  mjc_add_joint(m, pole, MJC_JNT_HINGE, kZero3, yaxis, 0, 0, 0, 0, 0.05, 0); /* :50 */
+  const double from[3] = {0, 0, 0}, to[3] = {0, 0, 0.6};
+  pend_geom(m, mjc_add_capsule_fromto(m, pole, from, to, 0.045)); /* :51 */
+  const double p2[3] = {0, 0, 0.6};
+  int pole2 = mjc_add_body(m, pole, p2); /* :52 */
+  mjc_add_joint(m, pole2, MJC_JNT_HINGE, kZero3, yaxis, 0, 0, 0, 0, 0.05, 0); /* :53 */
+  pend_geom(m, mjc_add_capsule_fromto(m, pole2, from, to, 0.045)); /* :54 */
+  mjc_add_motor(m, slider, 500); /* :60 gear 500, ctrlrange -1 1 */
   mjc_compile(m);
 }

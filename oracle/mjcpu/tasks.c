@@ -32,7 +32,7 @@ typedef struct {
   int current_step, done, elapsed_step;
 } mj_env;
 
-enum { TASK_CHEETAH = 0, TASK_ANT = 1, TASK_WALKER = 2 };
+enum { TASK_CHEETAH = 0, TASK_ANT = 1, TASK_WALKER = 2, TASK_IPEND = 3, TASK_IDPEND = 4 };
 
 typedef struct {
   int is_ant;
@@ -43,6 +43,8 @@ typedef struct {
   double healthy_reward, healthy_z_min, healthy_z_max;
   double healthy_angle_min, healthy_angle_max, velocity_min, velocity_max;
   int terminate_when_unhealthy, legacy_healthy_reward;
+  int reward_if_not_terminated, constraint_obs_dim; /* inverted pendulums */
+  double observation_min, observation_max;
   int torso;
   mj_env* envs;
   int nkeys;
@@ -72,6 +74,10 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
     is_ant = 1;
   } else if (strcmp(task, "Walker2d") == 0 || strcmp(task, "Walker2dV5") == 0) {
     kind = TASK_WALKER;
+  } else if (strcmp(task, "InvertedPendulum") == 0) {
+    kind = TASK_IPEND;
+  } else if (strcmp(task, "InvertedDoublePendulum") == 0) {
+    kind = TASK_IDPEND;
   } else {
     return NULL;
   }
@@ -84,17 +90,28 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
     mjc_build_ant(&p->m);
   } else if (walker) {
     mjc_build_walker2d(&p->m, v5);
+  } else if (kind == TASK_IPEND) {
+    mjc_build_inverted_pendulum(&p->m);
+  } else if (kind == TASK_IDPEND) {
+    mjc_build_inverted_double_pendulum(&p->m);
   } else {
     mjc_build_half_cheetah(&p->m);
   }
   p->num_envs = num_envs;
   p->max_episode_steps = max_episode_steps > 0 ? max_episode_steps : INT_MAX;
-  p->frame_skip = (int)extra_or(extra, n_extra, 0, walker ? 4 : 5);
+  const int pend = kind == TASK_IPEND || kind == TASK_IDPEND;
+  p->frame_skip = (int)extra_or(extra, n_extra, 0, walker ? 4 : (kind == TASK_IPEND ? 2 : 5));
   /* half_cheetah.h:33-43 / ant.h:33-50 / walker2d.h:32-47 defaults */
   p->ctrl_cost_weight =
       extra_or(extra, n_extra, 1, is_ant ? 0.5 : (walker ? 0.001 : 0.1));
   p->forward_reward_weight = extra_or(extra, n_extra, 2, 1.0);
-  p->reset_noise_scale = extra_or(extra, n_extra, 3, walker ? 0.005 : 0.1);
+  /* inverted_pendulum.h:32-41 (noise 0.01), inverted_double_pendulum.h:32-44 (0.1) */
+  p->reset_noise_scale =
+      extra_or(extra, n_extra, 3, walker ? 0.005 : (kind == TASK_IPEND ? 0.01 : 0.1));
+  p->reward_if_not_terminated = extra_or(extra, n_extra, 10, 0) != 0;
+  p->constraint_obs_dim = (int)extra_or(extra, n_extra, 11, 3);
+  p->observation_min = -10.0;
+  p->observation_max = 10.0;
   p->m.disable_contact = extra_or(extra, n_extra, 4, 0) != 0;
   p->m.disable_limit = extra_or(extra, n_extra, 5, 0) != 0;
   p->m.disable_actuation = extra_or(extra, n_extra, 6, 0) != 0;
@@ -104,9 +121,9 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   }
   if (extra_or(extra, n_extra, 8, -1) >= 0) p->m.integrator = (int)extra[8];
   if (extra_or(extra, n_extra, 9, 0) > 0) p->m.timestep = extra[9];
-  p->healthy_reward = 1.0;
-  p->healthy_z_min = walker ? 0.8 : 0.2;
-  p->healthy_z_max = walker ? 2.0 : 1.0;
+  p->healthy_reward = kind == TASK_IDPEND ? 10.0 : 1.0;
+  p->healthy_z_min = walker ? 0.8 : (kind == TASK_IPEND ? -0.2 : 0.2);
+  p->healthy_z_max = walker ? 2.0 : (kind == TASK_IPEND ? 0.2 : 1.0);
   p->healthy_angle_min = -1.0;
   p->healthy_angle_max = 1.0;
   p->velocity_min = -10.0;
@@ -122,7 +139,10 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   int k = 8;
   p->key_names[k] = "obs";
   p->key_dtype[k] = DT_F64;
-  p->key_elems[k++] = is_ant ? 27 : 17;
+  p->key_elems[k++] = is_ant ? 27
+                      : kind == TASK_IPEND ? 4
+                      : kind == TASK_IDPEND ? 8 + p->constraint_obs_dim
+                                            : 17;
   static const char* cheetah_info[4] = {"info:reward_run", "info:reward_ctrl",
                                         "info:x_position", "info:x_velocity"};
   static const char* ant_info[9] = {
@@ -130,7 +150,7 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
       "info:reward_survive", "info:x_position",   "info:y_position",
       "info:distance_from_origin", "info:x_velocity", "info:y_velocity"};
   /* walker2d.h:60-61: info:x_position, info:x_velocity */
-  int ninfo = is_ant ? 9 : (walker ? 2 : 4);
+  int ninfo = is_ant ? 9 : (walker ? 2 : (pend ? 0 : 4));
   for (int i = 0; i < ninfo; ++i) {
     p->key_names[k] = is_ant ? ant_info[i] : cheetah_info[(walker ? 2 : 0) + i];
     p->key_dtype[k] = DT_F64;
@@ -186,7 +206,39 @@ static void write_common(mj_pool* p, mj_env* e, int eid, void** out, int row,
       (unsigned char)(done && e->current_step >= p->max_episode_steps);
 }
 
+static double clip_obs(const mj_pool* p, double x) { /* std::min(max_, x) then std::max(min_, x) */
+  x = p->observation_max < x ? p->observation_max : x;
+  x = p->observation_min > x ? p->observation_min : x;
+  return x;
+}
+
+/* world position of the "tip" site (inverted_double_pendulum_envpool.xml:55):
+ * pos="0 0 .6" in the frame of the last pole */
+static void idp_tip(const mj_pool* p, const mj_env* e, double* x, double* z) {
+  int b = p->m.nbody - 1;
+  const double* R = e->d.xmat[b];
+  *x = e->d.xpos[b][0] + R[2] * 0.6;
+  *z = e->d.xpos[b][2] + R[8] * 0.6;
+}
+
 static void write_obs(mj_pool* p, mj_env* e, void** out, int row) {
+  if (p->task == TASK_IPEND) { /* inverted_pendulum.h:172-178 */
+    double* obs = (double*)out[8] + (size_t)row * 4;
+    for (int i = 0; i < 2; ++i) obs[i] = e->d.qpos[i];
+    for (int i = 0; i < 2; ++i) obs[2 + i] = e->d.qvel[i];
+    return;
+  }
+  if (p->task == TASK_IDPEND) { /* inverted_double_pendulum.h:160-181 */
+    double* obs = (double*)out[8] + (size_t)row * (8 + p->constraint_obs_dim);
+    *(obs++) = e->d.qpos[0];
+    *(obs++) = sin(e->d.qpos[1]);
+    *(obs++) = sin(e->d.qpos[2]);
+    *(obs++) = cos(e->d.qpos[1]);
+    *(obs++) = cos(e->d.qpos[2]);
+    for (int i = 0; i < 3; ++i) *(obs++) = clip_obs(p, e->d.qvel[i]);
+    for (int i = 0; i < p->constraint_obs_dim; ++i) *(obs++) = clip_obs(p, e->d.qfrc_constraint[i]);
+    return;
+  }
   int skip = p->is_ant ? 2 : 1; /* exclude_current_positions_from_observation */
   int n = p->is_ant ? 27 : 17;
   double* obs = (double*)out[8] + (size_t)row * n;
@@ -212,7 +264,8 @@ static void mujoco_reset(mj_pool* p, mj_env* e) {
                                     p->reset_noise_scale);
   }
   for (int i = 0; i < p->m.nv; ++i) {
-    if (p->task == TASK_WALKER) { /* walker2d.h:119-126: uniform for qvel too */
+    if (p->task == TASK_WALKER || p->task == TASK_IPEND) {
+      /* walker2d.h:119-126, inverted_pendulum.h:100-107: uniform for qvel too */
       e->d.qvel[i] = 0.0 + orc_uniform_real(&e->gen, -p->reset_noise_scale,
                                             p->reset_noise_scale);
     } else {
@@ -238,7 +291,7 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
   mj_env* e = &p->envs[eid];
   int reset = force_reset || e->done; /* async_envpool.h:127 */
   float reward = 0.0f;
-  int ninfo = p->is_ant ? 9 : (p->task == TASK_WALKER ? 2 : 4);
+  int ninfo = p->is_ant ? 9 : (p->task == TASK_WALKER ? 2 : (p->task >= TASK_IPEND ? 0 : 4));
   double info[9] = {0};
   if (reset) {
     e->current_step = 0;
@@ -252,7 +305,31 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
     double dt = p->frame_skip * p->m.timestep;
     double ctrl_cost = 0;
     for (int i = 0; i < p->m.nu; ++i) ctrl_cost += p->ctrl_cost_weight * act[i] * act[i];
-    if (p->task == TASK_WALKER) { /* walker2d.h:150-178 */
+    if (p->task == TASK_IPEND) { /* inverted_pendulum.h:137-148 */
+      for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
+      for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
+      int healthy = !(e->d.qpos[1] < p->healthy_z_min || e->d.qpos[1] > p->healthy_z_max);
+      for (int i = 0; i < p->m.nq; ++i) healthy = healthy && isfinite(e->d.qpos[i]);
+      for (int i = 0; i < p->m.nv; ++i) healthy = healthy && isfinite(e->d.qvel[i]);
+      int terminated = !healthy;
+      ++e->elapsed_step;
+      e->done = terminated || (e->elapsed_step >= p->max_episode_steps);
+      reward = p->reward_if_not_terminated ? (float)(!terminated) : 1.0f;
+    } else if (p->task == TASK_IDPEND) { /* inverted_double_pendulum.h:126-148 */
+      for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
+      for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
+      double x, y; /* site_xpos of the last forward evaluation (RK4 stage 4) */
+      idp_tip(p, e, &x, &y);
+      double dist_penalty = 0.01 * x * x + (y - 2) * (y - 2);
+      double v1 = e->d.qvel[1], v2 = e->d.qvel[2];
+      double vel_penalty = 1e-3 * v1 * v1 + 5e-3 * v2 * v2;
+      int terminated = !(y > p->healthy_z_max);
+      double alive_bonus = p->reward_if_not_terminated ? p->healthy_reward * (int)(!terminated)
+                                                       : p->healthy_reward;
+      reward = (float)(alive_bonus - dist_penalty - vel_penalty);
+      ++e->elapsed_step;
+      e->done = terminated || (e->elapsed_step >= p->max_episode_steps);
+    } else if (p->task == TASK_WALKER) { /* walker2d.h:150-178 */
       double x_before = e->d.qpos[0];
       for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
       for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);

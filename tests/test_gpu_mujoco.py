@@ -296,3 +296,48 @@ def test_walker_deterministic():
             a = hip_step(pool, rng.uniform(-1, 1, size=(n, 6)))
         outs.append(a["obs"].copy())
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+# ---- InvertedPendulum / InvertedDoublePendulum (mj_pendulum.cuh: no contacts, RK4) ----
+@pytest.mark.parametrize("task,nv,amax,params,extra", [
+    ("InvertedPendulum", 2, 3.0, {}, ()),
+    ("InvertedDoublePendulum", 3, 1.0, {}, ()),
+    # the v5 registrations: reward only while alive, one constraint-force observation
+    ("InvertedDoublePendulum", 3, 1.0, {"constraint_obs_dim": 1, "reward_if_not_terminated": 1},
+     (5, 0, 0, 0.1, 0, 0, 0, 0, -1, 0, 1, 1)),
+])
+def test_pendulum_matches_oracle(task, nv, amax, params, extra):
+    """Reset (bit-exact uniform draws; device log/sqrt for the normal ones) and
+    free-running + limit-pushing teacher-forced steps: obs rtol 1e-9 / atol 1e-10,
+    reward and bookkeeping (healthy termination, auto-reset) exact."""
+    n = 512
+    pool = DevicePool(task, n, seed=4, max_episode_steps=1000, params=params)
+    orc = Oracle(task, n, seed=4, max_episode_steps=1000, extra=extra)
+    a, b = hip_reset(pool), orc.reset()
+    assert list(a.keys()) == list(b.keys())
+    np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-14, atol=1e-16)
+    rng = np.random.default_rng(8)
+    seen_term, seen_force, worst = False, False, 0.0
+    for t in range(120):
+        st = orc.get_state()
+        if t % 3 == 2:  # push a third of the envs against the joint limits
+            sel = rng.random(n) < 0.33
+            side = rng.choice([-1.0, 1.0], n)
+            st[sel, 0] = (side * rng.uniform(0.97, 1.005, n))[sel]
+            st[sel, nv] = (side * rng.uniform(0, 3, n))[sel]
+            if nv == 2:
+                st[sel, 1] = (side * rng.uniform(1.5, 1.58, n))[sel]
+            orc.set_state(st)
+        pool.set_state(st)
+        act = rng.uniform(-1.2 * amax, 1.2 * amax, size=(n, 1))
+        a, b = hip_step(pool, act), orc.step(act)
+        np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-9, atol=1e-10, err_msg=f"step {t}")
+        np.testing.assert_allclose(a["reward"].ravel(), b["reward"].ravel(), rtol=1e-6, atol=1e-6)
+        for k in ("done", "trunc", "elapsed_step", "step_type", "discount"):
+            np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k}@{t}")
+        seen_term |= bool((b["done"] & ~b["trunc"]).any())
+        if nv == 3:
+            seen_force |= bool((np.abs(b["obs"][:, 8]) > 0).any())
+        worst = max(worst, float(np.abs(a["obs"] - b["obs"]).max()))
+    print(f"{task}: worst teacher-forced |d obs| = {worst:.3e}")
+    assert seen_term and (nv == 2 or seen_force)

@@ -143,3 +143,55 @@ def test_product_planar_code_matches_oracle_on_cpu():
                     L.cheetah_host_step(*args, 5, 0, *outs, ctypes.byref(it))
                 worst = max(worst, np.abs(np.concatenate([qo[skip:], vo]) - b["obs"][e]).max())
         assert worst < 1e-9, (task, worst)
+
+
+def test_product_pendulum_code_matches_oracle_on_cpu():
+    """Host instantiation of mj_pendulum.cuh (cart + 1 / 2 link chain, limit rows,
+    RK4) vs the generic oracle, teacher forced, including states pushed against
+    the slider / hinge limits."""
+    from oracle.orc import Oracle
+
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    so, src = os.path.join(h, "libpendulum_host.so"), os.path.join(h, "pendulum_host.cpp")
+    hdr = os.path.join(ROOT, "envpool_amd", "csrc", "mj_pendulum.cuh")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(so)
+    L.pendulum_host_step.argtypes = ([ctypes.c_int] + [ctypes.c_void_p] * 3 +
+                                     [ctypes.c_double, ctypes.c_int] + [ctypes.c_void_p] * 5)
+    rng = np.random.default_rng(5)
+    for nl, task, amax, fs in ((1, "InvertedPendulum", 3.0, 2), (2, "InvertedDoublePendulum", 1.0, 5)):
+        nv, n = nl + 1, 16
+        orc = Oracle(task, n, seed=9, max_episode_steps=1000)
+        orc.reset()
+        worst, forced = 0.0, 0
+        for t in range(40):
+            st = orc.get_state()
+            if t % 2:
+                side = rng.choice([-1.0, 1.0], n)
+                st[:, 0] = side * rng.uniform(0.97, 1.005, n)
+                st[:, nv] = side * rng.uniform(0, 3, n)
+                if nl == 1:
+                    st[:, 1] = side * rng.uniform(1.5, 1.58, n)
+                st[:, 3 * nv + 3] = 0
+                orc.set_state(st)
+            act = rng.uniform(-amax, amax, size=(n, 1))
+            b = orc.step(act)
+            for e in range(n):
+                if b["elapsed_step"][e, 0] == 0:
+                    continue
+                q, v, w = (st[e, :nv].copy(), st[e, nv:2 * nv].copy(), st[e, 2 * nv:3 * nv].copy())
+                qo, vo, wo, aux = np.zeros(nv), np.zeros(nv), np.zeros(nv), np.zeros(5)
+                it = ctypes.c_int(0)
+                L.pendulum_host_step(nl, q.ctypes.data, v.ctypes.data, w.ctypes.data, float(act[e, 0]), fs,
+                                     qo.ctypes.data, vo.ctypes.data, wo.ctypes.data, aux.ctypes.data,
+                                     ctypes.byref(it))
+                if nl == 1:
+                    got = np.concatenate([qo, vo])
+                else:
+                    got = np.concatenate([[qo[0]], np.sin(qo[1:]), np.cos(qo[1:]), np.clip(vo, -10, 10),
+                                          np.clip(aux[2:5], -10, 10)])
+                    forced += int(abs(b["obs"][e][8]) > 0)
+                worst = max(worst, np.abs(got - b["obs"][e]).max())
+        assert worst < 1e-9, (task, worst)
+        assert nl == 1 or forced > 0
