@@ -449,7 +449,8 @@ struct AntGeo {
 // (slot-major [slot][lane]: conflict free, lane-private => no barriers needed):
 //   slots [0, 81)    structurally non-zero entries of M (MSlot)
 //   slots [81, 141)  AntGeo (pos 27, tip 12, rot 9, ankle 12)
-// fp64: 141 * 64 * 8 B = 72 KB per wave (2 waves per CU); fp32: 36 KB (4 per CU).
+//   slots [141, 144) subtree COM of the robot (reference point of cfrc_ext)
+// fp64: 144 * 64 * 8 B = 72 KB per wave (2 waves per CU); fp32: 36 KB (4 per CU).
 EPA_HD constexpr int MSlot(int i, int j) {  // i <= j, NZ(i, j)
   int n = 0;
   for (int jj = 0; jj < kNV; ++jj) {
@@ -464,7 +465,8 @@ constexpr int kMSlots = MSlot(kNV - 1, kNV - 1) + 1;  // 81
 constexpr int kGeoBase = kMSlots;
 constexpr int kGeoPos = kGeoBase, kGeoTip = kGeoPos + 3 * kNB, kGeoRot = kGeoTip + 3 * kNLeg,
               kGeoAnkle = kGeoRot + 9;
-constexpr int kAntLdsSlots = kGeoAnkle + 3 * kNLeg;  // 141
+constexpr int kGeoCom = kGeoAnkle + 3 * kNLeg;
+constexpr int kAntLdsSlots = kGeoCom + 3;  // 144
 
 // Compiler-level fence: LDS contents must not be carried in registers across it
 // (otherwise the loads get hoisted out of the solver loops / forwarded from the
@@ -974,6 +976,7 @@ EPA_HD unsigned AntFrontEnd(const AntModel<T>& m, T* q, const T* v, const T* ctr
     });
     com = s * (T(1) / m.total_mass);
   }
+  put(kGeoCom, com);
   // torso: cdof of the free joint (translations are (0; e_k)), velocity, acceleration
   Sp6<T> rdof[3];  // rotational dofs 3..5
   static_for<0, 3>([&](auto kc) {
@@ -1120,9 +1123,53 @@ EPA_HD unsigned AntFrontEnd(const AntModel<T>& m, T* q, const T* v, const T* ctr
   return WaveUniform(mask);
 }
 
-template <typename T, typename Lds>
+// mj_rnePostConstraint, cfrc_ext part, for the forward pass that just finished:
+// sink(g, torque, force) is called once per touching end sphere with the spatial
+// force [torque about the robot COM; force] (world frame) the floor applies to
+// the MuJoCo body carrying that sphere's geom (g = SphGeomBody(s): 0 torso,
+// 1+3l stub, 2+3l leg, 3+3l ankle body); the world body receives the opposite.
+// Edge forces f_k = -D min(0, J_k a - aref_k) along (0, mu, 1), (0, -mu, 1),
+// (-mu, 0, 1), (mu, 0, 1) (ContactJar), i.e. mju_decodePyramid in world axes.
+template <typename T, typename Lds, typename Sink>
+EPA_HD void AntContactWrench(const AntModel<T>& m, Lds&& lds, unsigned sph, const T* v,
+                             const T* qacc, Sink&& sink) {
+  const AntGeoLds<T, typename std::remove_reference<Lds>::type> p{lds};
+  EPA_ANT_NO_UNROLL
+  for (unsigned rem = sph; rem != 0; rem &= rem - 1) {
+    const int s = __builtin_ctz(rem);
+    EPA_LDS_FENCE();
+    DispatchBody(SphBody(s), [&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      AntContact<T> c;
+      AntMakeContact<b>(m, p, v, s, c);
+      Vec3<T> ja = {T(0), T(0), T(0)};
+      ForChainCols<b>(p, c.cp, [&](auto jc, Vec3<T> col) {
+        ja = ja + col * qacc[decltype(jc)::value];
+      });
+      T jar[4], f[4];
+      ContactJar(m, ja, c.an, c.ay, c.ax, jar);
+      static_for<0, 4>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        f[k] = jar[k] < T(0) ? -c.D * jar[k] : T(0);  // D == 0 on lanes without contact
+      });
+      const Vec3<T> F = {m.mu * (f[3] - f[2]), m.mu * (f[0] - f[1]), f[0] + f[1] + f[2] + f[3]};
+      const Vec3<T> com = {lds(kGeoCom), lds(kGeoCom + 1), lds(kGeoCom + 2)};
+      sink(SphGeomBody(s), Cross(c.cp - com, F), F);
+    });
+  }
+}
+
+struct AntNoWrench {
+  template <typename V>
+  EPA_HD void operator()(int, V, V) const {}
+};
+
+// kWrench (compile time: the extra pass must not cost the v4 kernel registers):
+// report the contact forces of this evaluation through `sink` when `wrench`.
+template <bool kWrench = false, typename T, typename Lds, typename Sink = AntNoWrench>
 EPA_HD int AntForward(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, const T* v,
-                      const T* ctrl, T* warm, T* qacc, Lds&& lds) {
+                      const T* ctrl, T* warm, T* qacc, Lds&& lds, bool wrench = false,
+                      Sink&& sink = Sink()) {
   T qfrc_smooth[kNV];
   AntRows<T> rows;
   EPA_LDS_FENCE();
@@ -1131,6 +1178,9 @@ EPA_HD int AntForward(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, const
   static_for<0, kNV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
   int it = AntSolve(m, lds, sph, rows, v, qfrc_smooth, cfg, qacc);
   static_for<0, kNV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
+  if constexpr (kWrench) {
+    if (wrench) AntContactWrench(m, lds, sph, v, qacc, sink);  // wave-uniform flag
+  }
   return it;
 }
 
@@ -1167,9 +1217,12 @@ EPA_HD void AntIntegratePos(T* q, const T* dq, T h) {
 // One mj_step with integrator RK4 (mj_RungeKutta(4)).  On return q, v are the
 // new state and (lagx, lagy) the torso xpos of the LAST forward evaluation
 // (stage 4), which is what data_->xpos holds afterwards (ant.h:169-173).
-template <typename T, typename Lds>
+// `wrench`: also report the contact forces of the LAST forward evaluation (RK4
+// stage 4) through `sink` -- the data mj_rnePostConstraint sees after mj_step.
+template <bool kWrench = false, typename T, typename Lds, typename Sink = AntNoWrench>
 EPA_HD int AntStep(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, T* v, T* warm,
-                   const T* ctrl, T* lagx, T* lagy, Lds&& lds) {
+                   const T* ctrl, T* lagx, T* lagy, Lds&& lds, bool wrench = false,
+                   Sink&& sink = Sink()) {
   const T h = m.timestep;
   T q0[kNQ], v0[kNV], qs[kNQ], vs[kNV];
   T F[kNV], dq[kNV], dv[kNV];     // running B-weighted sums
@@ -1199,7 +1252,7 @@ EPA_HD int AntStep(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, T* v, T*
     });
     static_for<0, kNQ>([&](auto ic) { qs[decltype(ic)::value] = q0[decltype(ic)::value]; });
     AntIntegratePos(qs, step_dq, h);
-    it += AntForward(m, cfg, qs, vs, ctrl, warm, F, lds);
+    it += AntForward<kWrench>(m, cfg, qs, vs, ctrl, warm, F, lds, wrench && stage == 3, sink);
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       dq[i] += bw * vs[i];

@@ -5,7 +5,12 @@
 //   AntEnvBase::{MujocoResetModel,Reset,Step,IsHealthy,WriteState}
 //                                         envpool/mujoco/gym/ant.h:135-278
 // with `frame_skip x mj_step` (RK4: 4 forward passes each) from mj_ant.cuh.
-// v4 semantics: use_contact_force=false (no cfrc_ext in obs / contact cost 0).
+// Ant-v4: use_contact_force=false (no cfrc_ext in obs, contact cost 0).
+// Ant-v3: use_contact_force=true but post_constraint=false: MuJoCo 3 fills
+//   cfrc_ext only in mj_rnePostConstraint, which the reference then never calls
+//   (mujoco_env.h:145-147) => 84 zeros in the obs, contact cost 0.
+// Ant-v5: use_contact_force + post_constraint: cfrc_ext of the last forward
+//   evaluation (mj_ant.cuh, AntContactWrench), world body excluded.
 //
 // Persistent state (SoA fp64): qpos[15][N], qvel[14][N], qacc_warmstart[14][N],
 // lag[2][N] = data_->xpos[torso].xy of the last forward pass (the reference
@@ -30,18 +35,25 @@ struct AntDev {
   double* nsaved;
   unsigned char* navail;
   double* stack;  // [N][frame_stack * nobs] obs ring (frame_stack > 1 only)
+  double* cfrc;   // [N][14][6] cfrc_ext accumulator (use_contact_force + post_constraint only)
 };
+
+constexpr int kAntMjBodies = 14;  // world + torso + 4 x (stub, leg, ankle) MuJoCo bodies
 
 struct AntTask {
   int frame_skip, obs_skip, frame_stack;
   int terminate_when_unhealthy, legacy_healthy_reward;
+  int use_contact_force, post_constraint, exclude_worldbody;
   double ctrl_cost_weight, forward_reward_weight, healthy_reward;
   double healthy_z_min, healthy_z_max, reset_noise_scale, dt;
+  double contact_cost_weight, contact_force_min, contact_force_max;
 };
 
 constexpr int kAntBlock = 64;
 
-template <typename T>
+// kWrench: the Ant-v5 variant that also evaluates cfrc_ext (separate instantiation
+// so that Ant-v3/v4 do not pay registers for the extra pass)
+template <typename T, bool kWrench>
 __global__ __launch_bounds__(kAntBlock) void AntStepKernel(
     AntDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action,
     OutPtrs out, AntTask task, mj::SolverCfg<T> scfg) {
@@ -113,8 +125,24 @@ __global__ __launch_bounds__(kAntBlock) void AntStepKernel(
     });
     T lagx = T(0), lagy = T(0);
     auto lds = [&](int slot) -> T& { return lds_buf[slot * kAntBlock + lane]; };
+    // mj_rnePostConstraint after the last mj_step (mujoco_env.h:145-147)
+    const bool wrench = kWrench;
+    double* cf = wrench ? dev.cfrc + (size_t)e * kAntMjBodies * 6 : nullptr;
+    if (wrench) {
+      for (int i = 0; i < kAntMjBodies * 6; ++i) cf[i] = 0.0;
+    }
+    auto sink = [&](int g, A::Vec3<T> tq, A::Vec3<T> f) {
+      // MuJoCo body id of geom body g is 1 + g; the world body (0) gets -[tq; f]
+      const double w6[6] = {(double)tq.x, (double)tq.y, (double)tq.z,
+                            (double)f.x, (double)f.y, (double)f.z};
+      for (int j = 0; j < 6; ++j) {
+        cf[(1 + g) * 6 + j] += w6[j];
+        cf[j] -= w6[j];
+      }
+    };
     for (int s = 0; s < task.frame_skip; ++s) {
-      A::AntStep(m, scfg, q, v, w, ctrl, &lagx, &lagy, lds);
+      A::AntStep<kWrench>(m, scfg, q, v, w, ctrl, &lagx, &lagy, lds,
+                          wrench && s == task.frame_skip - 1, sink);
     }
     const double x_after = (double)lagx, y_after = (double)lagy;
     bool healthy = true;  // IsHealthy, ant.h:214-229
@@ -136,7 +164,15 @@ __global__ __launch_bounds__(kAntBlock) void AntStepKernel(
     dev.lag[(size_t)n + e] = y_after;
     const double xv = (x_after - x_before) / task.dt;
     const double yv = (y_after - y_before) / task.dt;
-    const double contact_cost = 0.0;  // use_contact_force = false (v4)
+    double contact_cost = 0.0;
+    if (wrench) {  // ant.h:183-194 (without post_constraint cfrc_ext stays zero)
+      for (int i = task.exclude_worldbody ? 6 : 0; i < kAntMjBodies * 6; ++i) {
+        double x = cf[i];
+        x = task.contact_force_max < x ? task.contact_force_max : x;  // std::min(max_, x)
+        x = task.contact_force_min > x ? task.contact_force_min : x;  // std::max(min_, x)
+        contact_cost += task.contact_cost_weight * x * x;
+      }
+    }
     bool give = healthy;
     if (task.legacy_healthy_reward) give = task.terminate_when_unhealthy || healthy;
     const double healthy_reward = give ? task.healthy_reward : 0.0;
@@ -157,7 +193,9 @@ __global__ __launch_bounds__(kAntBlock) void AntStepKernel(
   cm.done[e] = done ? 1 : 0;
   cm.cur_step[e] = cur;
   // WriteState, ant.h:231-278
-  const int nobs = A::kNQ + A::kNV - task.obs_skip;
+  const int cf0 = task.exclude_worldbody ? 6 : 0;
+  const int ncf = task.use_contact_force ? kAntMjBodies * 6 - cf0 : 0;
+  const int nobs = A::kNQ + A::kNV - task.obs_skip + ncf;
   const int S = task.frame_stack;
   double* obs0 = (double*)out.p[kKeyEnv0] + (size_t)row * nobs * S;
   double* newest = obs0 + (size_t)(S - 1) * nobs;
@@ -165,6 +203,15 @@ __global__ __launch_bounds__(kAntBlock) void AntStepKernel(
     double* obs = newest;
     for (int i = task.obs_skip; i < A::kNQ; ++i) *(obs++) = qpos[i];
     for (int i = 0; i < A::kNV; ++i) *(obs++) = qvel[i];
+    // ant.h:248-258; a reset (mj_resetData) and Ant-v3 leave cfrc_ext at zero
+    const bool have = !reset && kWrench;
+    const double* cfr = dev.cfrc + (size_t)e * kAntMjBodies * 6;
+    for (int i = 0; i < ncf; ++i) {
+      double x = have ? cfr[cf0 + i] : 0.0;
+      x = x > task.contact_force_min ? x : task.contact_force_min;  // std::max(x, min_)
+      x = x < task.contact_force_max ? x : task.contact_force_max;  // std::min(.., max_)
+      *(obs++) = x;
+    }
   }
   if (S > 1) {  // FrameStackBuffer::Commit, envpool/mujoco/frame_stack.h:109-135
     double* st = dev.stack + (size_t)e * S * nobs;
@@ -230,8 +277,12 @@ __global__ void AntSetState(AntDev dev, CommonDev cm, const int* ids, int k, con
 std::vector<KeySpec> AntKeys(const Config& cfg) {
   int no_pos = cfg.Get("exclude_current_positions_from_observation", 1) != 0;
   int fs = (int)cfg.Get("frame_stack", 1);
-  // ant.h:51-75 with use_contact_force=false; StackSpec, frame_stack.h:42-71
-  std::vector<int> oshape = {no_pos ? 27 : 29};
+  // ant.h:51-75 (obs 27/29 + 6 per body with use_contact_force); StackSpec, frame_stack.h:42-71
+  int ncf = 0;
+  if (cfg.Get("use_contact_force", 0) != 0) {
+    ncf = 6 * (kAntMjBodies - (cfg.Get("exclude_worldbody_contact_forces", 0) != 0 ? 1 : 0));
+  }
+  std::vector<int> oshape = {(no_pos ? 27 : 29) + ncf};
   if (fs > 1) oshape.insert(oshape.begin(), fs);
   std::vector<KeySpec> k = {{"obs", EPA_F64, oshape}};
   for (const char* name :
@@ -251,11 +302,12 @@ class AntPool : public Pool {
     if (task_.frame_stack < 1) {
       throw std::invalid_argument("frame_stack must be greater than 0");
     }
-    if (cfg.Get("use_contact_force", 0) != 0) {
-      throw std::invalid_argument(
-          "use_contact_force=true (Ant-v3/v5) needs mj_rnePostConstraint's cfrc_ext, "
-          "which is not restated yet; Ant-v4 semantics only");
-    }
+    task_.use_contact_force = cfg.Get("use_contact_force", 0) != 0;
+    task_.post_constraint = cfg.Get("post_constraint", 0) != 0;
+    task_.exclude_worldbody = cfg.Get("exclude_worldbody_contact_forces", 0) != 0;
+    task_.contact_cost_weight = cfg.Get("contact_cost_weight", 5e-4);
+    task_.contact_force_min = cfg.Get("contact_force_min", -1.0);
+    task_.contact_force_max = cfg.Get("contact_force_max", 1.0);
     fp64_ = (int)cfg.Get("precision", 1) == 1;
     model_ = A::BuildAntModel();
     task_.frame_skip = (int)cfg.Get("frame_skip", 5);
@@ -282,8 +334,15 @@ class AntPool : public Pool {
     EPA_HIP(hipMemsetAsync(dev_.lag, 0, sizeof(double) * 2 * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.nsaved, 0, sizeof(double) * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.navail, 0, n, stream_));
+    if (task_.use_contact_force && task_.post_constraint) {
+      EPA_HIP(hipMalloc(&dev_.cfrc, sizeof(double) * kAntMjBodies * 6 * n));
+      EPA_HIP(hipMemsetAsync(dev_.cfrc, 0, sizeof(double) * kAntMjBodies * 6 * n, stream_));
+    }
     if (task_.frame_stack > 1) {
-      size_t sb = sizeof(double) * n * task_.frame_stack * (A::kNQ + A::kNV - task_.obs_skip);
+      const int ncf = task_.use_contact_force
+                          ? 6 * (kAntMjBodies - (task_.exclude_worldbody ? 1 : 0)) : 0;
+      size_t sb = sizeof(double) * n * task_.frame_stack *
+                  (A::kNQ + A::kNV - task_.obs_skip + ncf);
       EPA_HIP(hipMalloc(&dev_.stack, sb));
       EPA_HIP(hipMemsetAsync(dev_.stack, 0, sb, stream_));
     }
@@ -297,6 +356,7 @@ class AntPool : public Pool {
     (void)hipFree(dev_.nsaved);
     (void)hipFree(dev_.navail);
     if (dev_.stack) (void)hipFree(dev_.stack);
+    if (dev_.cfrc) (void)hipFree(dev_.cfrc);
   }
   int StateDim() const override { return kAntStateDim; }
   void GetState(const int* d_ids, int k, double* d_out) override {
@@ -313,17 +373,19 @@ class AntPool : public Pool {
               const OutPtrs& out) override {
     StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps, cfg_.env_id_offset};
     int blocks = (k + kAntBlock - 1) / kAntBlock;
+    const double* act = static_cast<const double*>(d_action);
+    const mj::SolverCfg<double> sd{50, 1e-13};
+    const mj::SolverCfg<float> sf{12, 1e-6f};
+    const bool wrench = task_.use_contact_force && task_.post_constraint;
+#define EPA_LAUNCH_ANT(T, W, SC)                                                          \
+  hipLaunchKernelGGL((AntStepKernel<T, W>), dim3(blocks), dim3(kAntBlock), 0, stream_, dev_, \
+                     common_, a, act, out, task_, SC)
     if (fp64_) {
-      mj::SolverCfg<double> sc{50, 1e-13};
-      hipLaunchKernelGGL(AntStepKernel<double>, dim3(blocks), dim3(kAntBlock), 0, stream_,
-                         dev_, common_, a, static_cast<const double*>(d_action), out,
-                         task_, sc);
+      if (wrench) EPA_LAUNCH_ANT(double, true, sd); else EPA_LAUNCH_ANT(double, false, sd);
     } else {
-      mj::SolverCfg<float> sc{12, 1e-6f};
-      hipLaunchKernelGGL(AntStepKernel<float>, dim3(blocks), dim3(kAntBlock), 0, stream_,
-                         dev_, common_, a, static_cast<const double*>(d_action), out,
-                         task_, sc);
+      if (wrench) EPA_LAUNCH_ANT(float, true, sf); else EPA_LAUNCH_ANT(float, false, sf);
     }
+#undef EPA_LAUNCH_ANT
   }
 
  private:

@@ -1,7 +1,7 @@
 """gym-MuJoCo envs (mirror of envpool/mujoco/gym/__init__.py).
 
 Spec tables restate `HalfCheetahEnvFns` (half_cheetah.h:31-62), `AntEnvFns`
-(ant.h:31-75, v4: use_contact_force=False) and `Walker2dEnvFns`
+(ant.h:31-75; v3/v5 add 6 contact-force numbers per body) and `Walker2dEnvFns`
 (walker2d.h:30-67), `InvertedPendulumEnvFns` (inverted_pendulum.h:30-60) and
 `InvertedDoublePendulumEnvFns` (inverted_double_pendulum.h:30-62); the pixel
 variants are out of scope.  `precision` is an extension key: 64 (default, the
@@ -80,8 +80,11 @@ _Ant = FamilyDef(
         ("reset_noise_scale", 0.1), ("precision", 64),
     ],
     state_spec=lambda c: [
+        # ant.h:51-66: + 6 per MuJoCo body (14, world optional) with use_contact_force
         ("obs", spec(np.float64,
-                     _stack([27 if c["exclude_current_positions_from_observation"] else 29], c),
+                     _stack([(27 if c["exclude_current_positions_from_observation"] else 29) +
+                             (6 * (14 - (1 if c["exclude_worldbody_contact_forces"] else 0))
+                              if c["use_contact_force"] else 0)], c),
                      (-_inf, _inf))),
     ] + [(k, spec(np.float64, [-1])) for k in (
         "info:reward_forward", "info:reward_ctrl", "info:reward_contact",
@@ -101,10 +104,14 @@ _Ant = FamilyDef(
         "healthy_z_min": c["healthy_z_min"], "healthy_z_max": c["healthy_z_max"],
         "reset_noise_scale": c["reset_noise_scale"],
         "use_contact_force": c["use_contact_force"],
+        "post_constraint": c["post_constraint"],
+        "exclude_worldbody_contact_forces": c["exclude_worldbody_contact_forces"],
+        "contact_cost_weight": c["contact_cost_weight"],
+        "contact_force_min": c["contact_force_min"],
+        "contact_force_max": c["contact_force_max"],
         "precision": _precision(c),
     },
-    # Ant-v3 / v5 observe cfrc_ext (mj_rnePostConstraint): not restated yet
-    unsupported={"xml_file": "ant.xml", "use_contact_force": False},
+    unsupported={"xml_file": "ant.xml"},
 )
 
 

@@ -2,9 +2,7 @@
 from envpool_amd.registration import register
 
 gym_mujoco_envs = [
-    # Ant-v3 / Ant-v5 set use_contact_force=True (cfrc_ext observations), which
-    # the MI355X kernel does not restate yet: only Ant-v4 is registered.
-    ("Ant", ("v4",), 1000),
+    ("Ant", ("v3", "v4", "v5"), 1000),
     ("HalfCheetah", ("v3", "v4", "v5"), 1000),
     ("InvertedDoublePendulum", ("v2", "v4", "v5"), 1000),
     ("InvertedPendulum", ("v2", "v4", "v5"), 1000),
@@ -16,6 +14,14 @@ for task, versions, max_episode_steps in gym_mujoco_envs:
         extra_args = {}
         if version == "v5":
             extra_args["gymnasium_v5_render_camera"] = True
+        if task == "Ant" and version == "v3":  # gym/registration.py:39-40
+            extra_args["use_contact_force"] = True
+        if task == "Ant" and version == "v5":  # gym/registration.py:41-46
+            extra_args.update({
+                "use_contact_force": True,
+                "legacy_healthy_reward": False,
+                "exclude_worldbody_contact_forces": True,
+            })
         if task == "InvertedDoublePendulum" and version == "v5":  # gym/registration.py:61-65
             extra_args.update({
                 "constraint_obs_dim": 1,

@@ -389,7 +389,9 @@ static void make_constraint(const mjc_model* m, mjc_data* d) {
   /* contacts, pyramidal cones (mj_instantiateContact) */
   for (int c = 0; c < d->ncon; ++c) {
     mjc_contact* con = &d->contact[c];
+    con->efc_address = -1;
     if (con->dist >= con->includemargin) continue;
+    con->efc_address = d->nefc;
     int b1 = m->geom_body[con->geom1], b2 = m->geom_body[con->geom2];
     double jp1[3][MJC_MAXV], jr1[3][MJC_MAXV], jp2[3][MJC_MAXV], jr2[3][MJC_MAXV];
     mjc_jac(m, d, jp1, jr1, con->pos, b1);
@@ -755,6 +757,39 @@ static void rk4(const mjc_model* m, mjc_data* d) {
   for (int k = 0; k < nv; ++k) d->qvel[k] = Xv[0][k] + h * dv[k];
   integrate_pos(m, d->qpos, dq, h);
   d->time = time + h;
+}
+
+/* mj_rnePostConstraint, the cfrc_ext part: external (contact) force on every
+ * body as a spatial force [torque; force] about the subtree COM of its kinematic
+ * tree's root, from the contacts and efc_force of the LAST forward evaluation.
+ * Pyramidal decode as mju_decodePyramid: normal = sum of the 2(dim-1) edge
+ * forces, tangent_k = (f[2k] - f[2k+1]) * mu_k. */
+void mjc_rne_post_constraint(const mjc_model* m, mjc_data* d) {
+  for (int b = 0; b < m->nbody; ++b) {
+    for (int k = 0; k < 6; ++k) d->cfrc_ext[b][k] = 0;
+  }
+  for (int c = 0; c < d->ncon; ++c) {
+    const mjc_contact* con = &d->contact[c];
+    if (con->efc_address < 0) continue;
+    const double* f = d->efc_force + con->efc_address;
+    double lf[3] = {f[0] + f[1] + f[2] + f[3], (f[0] - f[1]) * con->friction,
+                    (f[2] - f[3]) * con->friction};
+    double F[3]; /* world frame: frame^T lf (frame rows: normal, t1, t2) */
+    for (int k = 0; k < 3; ++k) {
+      F[k] = con->frame[k] * lf[0] + con->frame[3 + k] * lf[1] + con->frame[6 + k] * lf[2];
+    }
+    for (int side = 0; side < 2; ++side) {
+      int b = m->geom_body[side == 0 ? con->geom1 : con->geom2];
+      double sgn = side == 0 ? -1.0 : 1.0; /* the force acts on body 2; body 1 gets -F */
+      double off[3], tq[3];
+      v3_sub(off, con->pos, d->subtree_com[m->body_rootid[b]]);
+      v3_cross(tq, off, F);
+      for (int k = 0; k < 3; ++k) {
+        d->cfrc_ext[b][k] += sgn * tq[k];
+        d->cfrc_ext[b][3 + k] += sgn * F[k];
+      }
+    }
+  }
 }
 
 void mjc_step(const mjc_model* m, mjc_data* d) { /* mj_step */

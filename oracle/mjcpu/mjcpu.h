@@ -90,6 +90,7 @@ typedef struct {
   int geom1, geom2;
   double friction, includemargin;
   double solref[2], solimp[5];
+  int efc_address; /* first of its 4 pyramid rows, -1 if outside the margin */
 } mjc_contact;
 
 typedef struct {
@@ -120,6 +121,8 @@ typedef struct {
   double qfrc_actuator[MJC_MAXV], qfrc_smooth[MJC_MAXV];
   double qacc_smooth[MJC_MAXV], qacc[MJC_MAXV], qfrc_constraint[MJC_MAXV];
   int solver_iter;
+  /* mj_rnePostConstraint (only on request, like MuJoCo) */
+  double cfrc_ext[MJC_MAXBODY][6]; /* [torque; force] about subtree_com[rootid] */
 } mjc_data;
 
 /* model.c */
@@ -148,6 +151,7 @@ void mjc_build_inverted_double_pendulum(mjc_model* m);
 void mjc_reset_data(const mjc_model* m, mjc_data* d);
 void mjc_forward(const mjc_model* m, mjc_data* d);
 void mjc_step(const mjc_model* m, mjc_data* d);
+void mjc_rne_post_constraint(const mjc_model* m, mjc_data* d); /* cfrc_ext only */
 void mjc_fwd_position(const mjc_model* m, mjc_data* d);
 double mjc_energy_kinetic(const mjc_model* m, mjc_data* d);
 double mjc_energy_potential(const mjc_model* m, mjc_data* d);

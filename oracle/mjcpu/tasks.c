@@ -44,6 +44,9 @@ typedef struct {
   double healthy_angle_min, healthy_angle_max, velocity_min, velocity_max;
   int terminate_when_unhealthy, legacy_healthy_reward;
   int reward_if_not_terminated, constraint_obs_dim; /* inverted pendulums */
+  /* Ant-v3 / v5 (gym/registration.py:39-46) */
+  int use_contact_force, post_constraint, exclude_worldbody;
+  double contact_cost_weight, contact_force_min, contact_force_max;
   double observation_min, observation_max;
   int torso;
   mj_env* envs;
@@ -112,6 +115,12 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   p->constraint_obs_dim = (int)extra_or(extra, n_extra, 11, 3);
   p->observation_min = -10.0;
   p->observation_max = 10.0;
+  p->use_contact_force = extra_or(extra, n_extra, 12, 0) != 0;
+  p->post_constraint = extra_or(extra, n_extra, 13, 0) != 0;
+  p->exclude_worldbody = extra_or(extra, n_extra, 14, 0) != 0;
+  p->contact_cost_weight = 5e-4; /* ant.h:44-47 */
+  p->contact_force_min = -1.0;
+  p->contact_force_max = 1.0;
   p->m.disable_contact = extra_or(extra, n_extra, 4, 0) != 0;
   p->m.disable_limit = extra_or(extra, n_extra, 5, 0) != 0;
   p->m.disable_actuation = extra_or(extra, n_extra, 6, 0) != 0;
@@ -130,6 +139,7 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   p->velocity_max = 10.0;
   p->terminate_when_unhealthy = 1;
   p->legacy_healthy_reward = v5 ? 0 : 1; /* gym/registration.py:79-83 */
+  if (extra_or(extra, n_extra, 15, -1) >= 0) p->legacy_healthy_reward = extra[15] != 0;
   p->torso = 1; /* mj_name2id(model, mjOBJ_XBODY, "torso"), ant.h:119 */
   for (int i = 0; i < 8; ++i) {
     p->key_names[i] = kCommonNames[i];
@@ -139,7 +149,9 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   int k = 8;
   p->key_names[k] = "obs";
   p->key_dtype[k] = DT_F64;
-  p->key_elems[k++] = is_ant ? 27
+  p->key_elems[k++] = is_ant ? 27 + (p->use_contact_force
+                                         ? 6 * (p->m.nbody - (p->exclude_worldbody ? 1 : 0))
+                                         : 0)
                       : kind == TASK_IPEND ? 4
                       : kind == TASK_IDPEND ? 8 + p->constraint_obs_dim
                                             : 17;
@@ -240,7 +252,7 @@ static void write_obs(mj_pool* p, mj_env* e, void** out, int row) {
     return;
   }
   int skip = p->is_ant ? 2 : 1; /* exclude_current_positions_from_observation */
-  int n = p->is_ant ? 27 : 17;
+  int n = p->is_ant ? p->key_elems[8] : 17;
   double* obs = (double*)out[8] + (size_t)row * n;
   for (int i = skip; i < p->m.nq; ++i) *(obs++) = e->d.qpos[i];
   for (int i = 0; i < p->m.nv; ++i) {
@@ -250,6 +262,15 @@ static void write_obs(mj_pool* p, mj_env* e, void** out, int row) {
       x = x > p->velocity_max ? p->velocity_max : x;
     }
     *(obs++) = x;
+  }
+  if (p->is_ant && p->use_contact_force) { /* ant.h:248-258 */
+    for (int b = p->exclude_worldbody ? 1 : 0; b < p->m.nbody; ++b) {
+      for (int j = 0; j < 6; ++j) {
+        double x = e->d.cfrc_ext[b][j];
+        x = fmin(fmax(x, p->contact_force_min), p->contact_force_max);
+        *(obs++) = x;
+      }
+    }
   }
 }
 
@@ -363,9 +384,22 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
       double x_before = e->d.xpos[p->torso][0], y_before = e->d.xpos[p->torso][1];
       for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
       for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
+      /* mujoco_env.h:145-147; without it cfrc_ext keeps the zeros of mj_resetData
+       * (MuJoCo 3 only fills it in mj_rnePostConstraint) */
+      if (p->post_constraint) mjc_rne_post_constraint(&p->m, &e->d);
       double x_after = e->d.xpos[p->torso][0], y_after = e->d.xpos[p->torso][1];
       double xv = (x_after - x_before) / dt, yv = (y_after - y_before) / dt;
-      double contact_cost = 0.0; /* use_contact_force=false for v4 */
+      double contact_cost = 0.0;
+      if (p->use_contact_force) { /* ant.h:183-194 */
+        for (int b = p->exclude_worldbody ? 1 : 0; b < p->m.nbody; ++b) {
+          for (int j = 0; j < 6; ++j) {
+            double x = e->d.cfrc_ext[b][j];
+            x = fmin(p->contact_force_max, x);
+            x = fmax(p->contact_force_min, x);
+            contact_cost += p->contact_cost_weight * x * x;
+          }
+        }
+      }
       int healthy = ant_is_healthy(p, e);
       int give = healthy;
       if (p->legacy_healthy_reward) give = p->terminate_when_unhealthy || healthy;

@@ -341,3 +341,40 @@ def test_pendulum_matches_oracle(task, nv, amax, params, extra):
         worst = max(worst, float(np.abs(a["obs"] - b["obs"]).max()))
     print(f"{task}: worst teacher-forced |d obs| = {worst:.3e}")
     assert seen_term and (nv == 2 or seen_force)
+
+
+# ---- Ant-v3 / Ant-v5: contact-force observations (cfrc_ext) ----
+@pytest.mark.parametrize("name,params,extra,nobs", [
+    # v3: use_contact_force without mj_rnePostConstraint => cfrc_ext stays zero
+    ("Ant-v3", {"use_contact_force": 1},
+     (5, 0.5, 1.0, 0.1, 0, 0, 0, 0, -1, 0, 0, 3, 1, 0, 0, -1), 111),
+    # v5: cfrc_ext of the last forward evaluation, world body excluded
+    ("Ant-v5", {"use_contact_force": 1, "post_constraint": 1,
+                "exclude_worldbody_contact_forces": 1, "legacy_healthy_reward": 0},
+     (5, 0.5, 1.0, 0.1, 0, 0, 0, 0, -1, 0, 0, 3, 1, 1, 1, 0), 105),
+])
+def test_ant_contact_force_observation(name, params, extra, nobs):
+    n, steps = 128, 60
+    pool = DevicePool("Ant", n, seed=6, max_episode_steps=1000, params={"precision": 1, **params})
+    orc = Oracle("Ant", n, seed=6, max_episode_steps=1000, extra=extra)
+    a, b = hip_reset(pool), orc.reset()
+    assert a["obs"].shape == (n, nobs) == b["obs"].shape
+    np.testing.assert_array_equal(a["obs"][:, 27:], 0.0)  # mj_resetData zeros cfrc_ext
+    rng = np.random.default_rng(2)
+    nz, cost = 0, 0.0
+    for t in range(steps):
+        pool.set_state(orc.get_state())
+        act = rng.uniform(-1, 1, size=(n, 8))
+        a, b = hip_step(pool, act), orc.step(act)
+        np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-8, atol=1e-9, err_msg=f"step {t}")
+        np.testing.assert_allclose(a["reward"].ravel(), b["reward"].ravel(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(a["info:reward_contact"].ravel(),
+                                   b["info:reward_contact"].ravel(), rtol=1e-8, atol=1e-12)
+        for k in ("done", "trunc", "elapsed_step", "step_type"):
+            np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k}@{t}")
+        nz += int((np.abs(b["obs"][:, 27:]) > 0).sum())
+        cost = min(cost, float(b["info:reward_contact"].min()))
+    if name == "Ant-v3":
+        assert nz == 0 and cost == 0.0
+    else:
+        assert nz > 1000 and cost < 0.0  # real forces were compared
