@@ -13,16 +13,16 @@ pytestmark = pytest.mark.gpu
 
 
 class OraclePost:
-    def __init__(self, n, s=4):
+    def __init__(self, n, s=4, oh=84, ow=84):
         self.L = ctypes.CDLL(PORT_LIB)
         self.L.orc_atari_post_create.restype = ctypes.c_void_p
         self.L.orc_atari_post_push.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 3
-        self.h = ctypes.c_void_p(self.L.orc_atari_post_create(n, s, 210, 160, 84, 84))
-        self.s = s
+        self.h = ctypes.c_void_p(self.L.orc_atari_post_create(n, s, 210, 160, oh, ow))
+        self.s, self.oh, self.ow = s, oh, ow
 
     def push(self, frames, ids, mask):
         k = len(ids)
-        obs = np.zeros((k, self.s, 84, 84), np.uint8)
+        obs = np.zeros((k, self.s, self.oh, self.ow), np.uint8)
         self.L.orc_atari_post_push(self.h, ids.ctypes.data, k, frames.ctypes.data,
                                    mask.ctypes.data if mask is not None else None,
                                    obs.ctypes.data)
@@ -64,6 +64,23 @@ def test_post_process_bit_exact_with_resets_and_partial_ids():
     frames = pong_like(rng, n)
     a = gpu.push(frames, ids, None)
     np.testing.assert_array_equal(a[:, :3], prev[:, 1:])
+
+
+@pytest.mark.parametrize("oh,ow", [(64, 64), (96, 75), (40, 30), (100, 150)])
+def test_post_process_other_sizes(oh, ow):
+    """Non-default img_height / img_width: more taps per pixel than the 84x84
+    specialisation allows (generic <6,6> kernel), widths that are not a multiple
+    of 4 (byte-store path), upscaling-free mixes."""
+    n = 16
+    gpu, orc = AtariPostProcess(n, img_height=oh, img_width=ow), OraclePost(n, oh=oh, ow=ow)
+    rng = np.random.default_rng(1)
+    ids = np.arange(n, dtype=np.int32)
+    for t in range(5):
+        frames = rng.integers(0, 256, (n, 2, 210, 160), dtype=np.uint8)
+        mask = np.ones(n, np.uint8) if t == 0 else (rng.random(n) < 0.2).astype(np.uint8)
+        a, b = gpu.push(frames, ids, mask), orc.push(frames, ids, mask)
+        assert a.shape == (n, 4, oh, ow)
+        np.testing.assert_array_equal(a, b, err_msg=f"push {t}")
 
 
 def test_post_process_errors():
