@@ -199,7 +199,7 @@ def main():
                 "launches": launches,
                 "algorithmic_bytes_per_env_step": alg_bytes,
                 "note": "physics kernel is VALU/latency-bound, not HBM-bound "
-                        "(~300 flop/B); HBM fraction reported as BASELINE.md asks",
+                        "(~65 flop/B counted); HBM fraction reported as BASELINE.md asks",
             },
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only

@@ -11,7 +11,10 @@ from mj_util import RawMj
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.mark.parametrize("name,task", [("half_cheetah", "HalfCheetah"), ("ant", "Ant")])
+@pytest.mark.parametrize("name,task", [
+    ("half_cheetah", "HalfCheetah"), ("ant", "Ant"), ("walker2d", "Walker2d"),
+    ("walker2d_v5", "Walker2dV5"), ("inverted_pendulum", "InvertedPendulum"),
+    ("inverted_double_pendulum", "InvertedDoublePendulum")])
 def test_oracle_matches_real_mujoco(name, task):
     path = os.path.join(GOLD, f"mujoco_{name}.npz")
     if not os.path.exists(path):
@@ -22,7 +25,7 @@ def test_oracle_matches_real_mujoco(name, task):
     np.testing.assert_allclose(o.dof_invweight0, g["dof_invweight0"], rtol=1e-7)
     for i in range(0, len(g["qpos0"]), 7):
         o.set(g["qpos0"][i], g["qvel0"][i], g["ctrl"][i])
-        o.step(5)
+        o.step(int(g["frame_skip"]) if "frame_skip" in g else 5)
         q, v, _ = o.get()
         # the reference's own alignment tolerance (mujoco_gym_align_test.py:38-80)
         np.testing.assert_allclose(q, g["qpos1"][i], atol=1e-6, rtol=1e-7)

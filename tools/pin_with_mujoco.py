@@ -7,7 +7,8 @@ that has `mujoco==3.6.0` and a checkout of the reference:
 
     python tools/pin_with_mujoco.py /path/to/envpool/third_party/mujoco_gym_xml_patches
 
-It writes tests/golden/mujoco_{half_cheetah,ant}.npz; tests/test_mjcpu_golden.py
+It writes tests/golden/mujoco_{half_cheetah,ant,walker2d,walker2d_v5,
+inverted_pendulum,inverted_double_pendulum}.npz; tests/test_mjcpu_golden.py
 activates automatically when those files exist and checks oracle/mjcpu (and,
 with a GPU, the HIP kernels) against them with the reference's own tolerance
 (obs atol 1e-6, rtol 1e-7: envpool/mujoco/gym/mujoco_gym_align_test.py:38-80).
@@ -25,21 +26,28 @@ def main(xml_dir: str) -> None:
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                            "tests", "golden")
     rng = np.random.default_rng(2024)
-    for name, xml, frame_skip in (("half_cheetah", "half_cheetah_envpool.xml", 5),
-                                  ("ant", "ant_envpool.xml", 5)):
+    # name, xml, frame_skip, action range, episode length before a re-randomised reset
+    for name, xml, frame_skip, amax, horizon in (
+            ("half_cheetah", "half_cheetah_envpool.xml", 5, 1.0, 200),
+            ("ant", "ant_envpool.xml", 5, 1.0, 200),
+            ("walker2d", "walker2d_envpool.xml", 4, 1.0, 40),
+            ("walker2d_v5", "walker2d_v5_envpool.xml", 4, 1.0, 40),
+            ("inverted_pendulum", "inverted_pendulum_envpool.xml", 2, 3.0, 25),
+            ("inverted_double_pendulum", "inverted_double_pendulum_envpool.xml", 5, 1.0, 25)):
         m = mujoco.MjModel.from_xml_path(os.path.join(xml_dir, xml))
         d = mujoco.MjData(m)
-        rec = {k: [] for k in ("qpos0", "qvel0", "warm0", "ctrl", "qpos1", "qvel1", "xpos1")}
-        for ep in range(8):
+        rec = {k: [] for k in ("qpos0", "qvel0", "warm0", "ctrl", "qpos1", "qvel1", "xpos1",
+                               "qfrc_constraint1", "cfrc_ext1")}
+        for ep in range(8 * 200 // horizon):
             mujoco.mj_resetData(m, d)
             d.qpos[:] = m.qpos0 + rng.uniform(-0.1, 0.1, m.nq)
             d.qvel[:] = rng.normal(0, 0.1, m.nv)
             mujoco.mj_forward(m, d)
-            for t in range(200):
+            for t in range(horizon):
                 rec["qpos0"].append(d.qpos.copy())
                 rec["qvel0"].append(d.qvel.copy())
                 rec["warm0"].append(d.qacc_warmstart.copy())
-                ctrl = rng.uniform(-1, 1, m.nu)
+                ctrl = rng.uniform(-amax, amax, m.nu)
                 rec["ctrl"].append(ctrl)
                 d.ctrl[:] = ctrl
                 for _ in range(frame_skip):
@@ -47,7 +55,11 @@ def main(xml_dir: str) -> None:
                 rec["qpos1"].append(d.qpos.copy())
                 rec["qvel1"].append(d.qvel.copy())
                 rec["xpos1"].append(d.xpos[1].copy())
-        extra = dict(body_mass=m.body_mass.copy(), dof_invweight0=m.dof_invweight0.copy(),
+                # lagged mjData fields the tasks observe (last RK4 stage) and cfrc_ext
+                rec["qfrc_constraint1"].append(d.qfrc_constraint.copy())
+                mujoco.mj_rnePostConstraint(m, d)
+                rec["cfrc_ext1"].append(d.cfrc_ext.copy())
+        extra = dict(frame_skip=frame_skip, body_mass=m.body_mass.copy(), dof_invweight0=m.dof_invweight0.copy(),
                      body_invweight0=m.body_invweight0.copy())
         np.savez_compressed(os.path.join(out_dir, f"mujoco_{name}.npz"),
                             **{k: np.array(v) for k, v in rec.items()}, **extra)
