@@ -1,13 +1,16 @@
-// Cart + N-link planar pendulum (gym InvertedPendulum N=1, InvertedDoublePendulum
-// N=2): the MuJoCo 3.6.0 forward pipeline restated for this chain, same scheme
+// Planar N-link chain, optionally on a sliding cart (gym InvertedPendulum N=1 and
+// InvertedDoublePendulum N=2 with cart; Reacher N=2 without: its arm moves in the
+// xy plane about +z, which is this file's (x, z) plane about +y after z := -y):
+// the MuJoCo 3.6.0 forward pipeline restated for this chain, same scheme
 // as mj_cheetah.cuh (planar spatial algebra about the system COM, CRB, RNE,
 // primal Newton on the constraint objective, RK4) -- without contacts: every
 // geom of inverted_pendulum_envpool.xml:21 / inverted_double_pendulum_envpool.xml:39
-// has contype=0, so joint limits are the only constraint rows.
+// (reacher_envpool.xml:21) has contype=0, so joint limits are the only constraint rows.
 // Call sites in the reference: envpool/mujoco/gym/mujoco_env.h:126-148
 // (mj_resetData, mj_forward, frame_skip x mj_step); the arithmetic itself lives
 // in un-vendored MuJoCo, see oracle/mjcpu/mjcpu.h (PARITY UNPINNED).
-// One env per thread; dofs: 0 = cart slide (x), j >= 1 = hinge j about +y.
+// One env per thread; with a cart dof 0 is its slide (x) and hinge j is dof j,
+// without one the hinges are dofs 0..N-1 and the first anchor is the origin.
 #ifndef ENVPOOL_AMD_CSRC_MJ_PENDULUM_CUH_
 #define ENVPOOL_AMD_CSRC_MJ_PENDULUM_CUH_
 
@@ -17,16 +20,18 @@ namespace epa {
 namespace mj {
 namespace pend {
 
-template <typename T, int NL>
+template <typename T, int NL, bool kCart = true>
 struct PendModel {
-  static constexpr int kNV = NL + 1;
-  T cart_mass;
-  T mass[NL], iyy[NL];  // link mass, inertia about y through its COM
+  static constexpr int kC = kCart ? 1 : 0;
+  static constexpr int kNV = NL + kC;
+  T cart_mass;          // 0 without a cart
+  T mass[NL], iyy[NL];  // link mass, inertia about the plane normal through its COM
   T cx[NL], cz[NL];     // link COM in the link frame (origin = its hinge)
-  T lx[NL], lz[NL];     // next hinge (last link: the "tip" site) in the link frame
-  T damp[NL + 1];
-  T grav_x, grav_z;     // <option gravity>: (1e-5, -9.81) for the double pendulum
-  T gear, ctrl_lo, ctrl_hi;
+  T lx[NL], lz[NL];     // next hinge (last link: the "tip" point) in the link frame
+  T damp[NL + 1], arm[NL + 1];  // per dof (entry NL unused without a cart)
+  T grav_x, grav_z;     // in-plane gravity: (1e-5, -9.81) for the double pendulum, 0 for Reacher
+  T gear[NL + 1];       // motor gear per dof (0: not actuated); ctrl is indexed by dof
+  T ctrl_lo, ctrl_hi;
   int limited[NL + 1];
   T lo[NL + 1], hi[NL + 1], margin[NL + 1], dof_invw[NL + 1];
   T lim_K, lim_B, lim_d0, lim_dmax, lim_width;
@@ -40,6 +45,8 @@ struct PendAux {
   T tip_x, tip_z;
   T qfrc_constraint[NL + 1];
 };
+template <typename T, int NL, bool kCart>
+using PendM = PendModel<T, NL, kCart>;
 
 template <typename T, int N>
 EPA_HD void CholSolve(T* A, T* x) {  // A: full N x N SPD (row major), in place; x <- A^-1 x
@@ -79,30 +86,30 @@ struct PendPos {
   T tip_x, tip_z;
 };
 
-// mj_kinematics + mj_comPos + mj_crb
-template <typename T, int NL>
-EPA_HD void PendKinematics(const PendModel<T, NL>& m, const T* q, PendPos<T, NL>& p) {
-  constexpr int NV = NL + 1, NB = NL + 1;  // body 0 = cart, body i = link i
-  T ax[NB], az[NB], sn[NB], cs[NB], px[NB], pz[NB];  // hinge anchors / frames, body COMs
-  ax[0] = q[0];
-  az[0] = T(0);
-  sn[0] = T(0);
-  cs[0] = T(1);
-  px[0] = q[0];
-  pz[0] = T(0);
+// mj_kinematics + mj_comPos + mj_crb.  Bodies/dofs: [cart,] link 0 .. link NL-1.
+template <typename T, int NL, bool kCart>
+EPA_HD void PendKinematics(const PendModel<T, NL, kCart>& m, const T* q, PendPos<T, NL>& p) {
+  constexpr int C = kCart ? 1 : 0, NV = NL + C, NB = NL + C;
+  T ax[NL], az[NL], px[NB], pz[NB];  // hinge anchors, body COMs
+  const T x0 = kCart ? q[0] : T(0);
+  if constexpr (kCart) {
+    px[0] = x0;
+    pz[0] = T(0);
+  }
   {
     T phi = T(0);
-    T nx = q[0], nz = T(0);  // anchor of the next link
-    static_for<1, NB>([&](auto bc) {
-      constexpr int b = decltype(bc)::value;
-      phi += q[b];
-      SinCos(phi, &sn[b], &cs[b]);
-      ax[b] = nx;
-      az[b] = nz;
-      px[b] = nx + cs[b] * m.cx[b - 1] + sn[b] * m.cz[b - 1];
-      pz[b] = nz - sn[b] * m.cx[b - 1] + cs[b] * m.cz[b - 1];
-      const T tx = nx + cs[b] * m.lx[b - 1] + sn[b] * m.lz[b - 1];
-      const T tz = nz - sn[b] * m.lx[b - 1] + cs[b] * m.lz[b - 1];
+    T nx = x0, nz = T(0);  // anchor of the next link
+    static_for<0, NL>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      T sn, cs;
+      phi += q[l + C];
+      SinCos(phi, &sn, &cs);
+      ax[l] = nx;
+      az[l] = nz;
+      px[l + C] = nx + cs * m.cx[l] + sn * m.cz[l];
+      pz[l + C] = nz - sn * m.cx[l] + cs * m.cz[l];
+      const T tx = nx + cs * m.lx[l] + sn * m.lz[l];
+      const T tz = nz - sn * m.lx[l] + cs * m.lz[l];
       nx = tx;
       nz = tz;
     });
@@ -110,24 +117,26 @@ EPA_HD void PendKinematics(const PendModel<T, NL>& m, const T* q, PendPos<T, NL>
     p.tip_z = nz;
   }
   // mj_comPos
-  T comx = m.cart_mass * px[0], comz = T(0);
-  static_for<1, NB>([&](auto bc) {
-    constexpr int b = decltype(bc)::value;
-    comx += m.mass[b - 1] * px[b];
-    comz += m.mass[b - 1] * pz[b];
+  T comx = kCart ? m.cart_mass * px[0] : T(0), comz = T(0);
+  static_for<0, NL>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    comx += m.mass[l] * px[l + C];
+    comz += m.mass[l] * pz[l + C];
   });
   comx /= m.total_mass;
   comz /= m.total_mass;
   static_for<0, NB>([&](auto bc) {
     constexpr int b = decltype(bc)::value;
-    const T mass = b == 0 ? m.cart_mass : m.mass[b == 0 ? 0 : b - 1];
-    const T iyy = b == 0 ? T(0) : m.iyy[b == 0 ? 0 : b - 1];  // the cart never rotates
+    constexpr bool cart = kCart && b == 0;
+    constexpr int l = cart ? 0 : b - C;
+    const T mass = cart ? m.cart_mass : m.mass[l];
+    const T iyy = cart ? T(0) : m.iyy[l];  // the cart never rotates
     const T dx = px[b] - comx, dz = pz[b] - comz;
     p.cinert[b] = {iyy + mass * (dx * dx + dz * dz), mass * dx, mass * dz, mass};
-    if constexpr (b == 0) {
+    if constexpr (cart) {
       p.cdof[0] = {T(0), T(1), T(0)};
     } else {
-      p.cdof[b] = {T(1), comz - az[b], -(comx - ax[b])};
+      p.cdof[b] = {T(1), comz - az[l], -(comx - ax[l])};
     }
   });
   // mj_crb
@@ -145,19 +154,19 @@ EPA_HD void PendKinematics(const PendModel<T, NL>& m, const T* q, PendPos<T, NL>
     V3<T> buf = MulInert(crb[i], p.cdof[i]);
     static_for<0, i + 1>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      const T x = Dot(p.cdof[j], buf);
+      const T x = Dot(p.cdof[j], buf) + (i == j ? m.arm[i] : T(0));
       p.M[i * NV + j] = x;
       p.M[j * NV + i] = x;
     });
-  });  // armature 0 in both models
+  });
 }
 
-// mj_forward.  q, v: state; ctrl: raw action (clamped to ctrlrange here, the
-// motor is ctrllimited); warm: qacc_warmstart in/out.
-template <typename T, int NL>
-EPA_HD int PendForward(const PendModel<T, NL>& m, const SolverCfg<T>& cfg, const T* q,
-                       const T* v, T ctrl, T* warm, T* qacc, PendAux<T, NL>& aux) {
-  constexpr int NV = NL + 1, NB = NL + 1;
+// mj_forward.  q, v: state; ctrl[dof]: raw action of the motor on that dof
+// (clamped to ctrlrange here, the motors are ctrllimited); warm: qacc_warmstart in/out.
+template <typename T, int NL, bool kCart>
+EPA_HD int PendForward(const PendModel<T, NL, kCart>& m, const SolverCfg<T>& cfg, const T* q,
+                       const T* v, const T* ctrl, T* warm, T* qacc, PendAux<T, NL>& aux) {
+  constexpr int NV = NL + (kCart ? 1 : 0), NB = NV;
   PendPos<T, NL> pp;
   PendKinematics(m, q, pp);
   aux.tip_x = pp.tip_x;
@@ -196,8 +205,11 @@ EPA_HD int PendForward(const PendModel<T, NL>& m, const SolverCfg<T>& cfg, const
       constexpr int j = decltype(jc)::value;
       qfrc_smooth[j] = -m.damp[j] * v[j] - Dot(cdof[j], cfrc[j]);
     });
-    const T c = ctrl < m.ctrl_lo ? m.ctrl_lo : (ctrl > m.ctrl_hi ? m.ctrl_hi : ctrl);
-    qfrc_smooth[0] += m.gear * c;
+    static_for<0, NV>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const T c = ctrl[j] < m.ctrl_lo ? m.ctrl_lo : (ctrl[j] > m.ctrl_hi ? m.ctrl_hi : ctrl[j]);
+      qfrc_smooth[j] += m.gear[j] * c;
+    });
   }
   // mj_instantiateLimit + mj_makeImpedance: row j is J = sgn e_j when joint j
   // is within `margin` of a bound
@@ -309,10 +321,10 @@ EPA_HD int PendForward(const PendModel<T, NL>& m, const SolverCfg<T>& cfg, const
 }
 
 // mj_step with integrator RK4 (both models: <option integrator="RK4">).
-template <typename T, int NL>
-EPA_HD int PendStepRK4(const PendModel<T, NL>& m, const SolverCfg<T>& cfg, T* q, T* v, T* warm,
-                       T ctrl, PendAux<T, NL>& aux) {
-  constexpr int NV = NL + 1;
+template <typename T, int NL, bool kCart>
+EPA_HD int PendStepRK4(const PendModel<T, NL, kCart>& m, const SolverCfg<T>& cfg, T* q, T* v,
+                       T* warm, const T* ctrl, PendAux<T, NL>& aux) {
+  constexpr int NV = NL + (kCart ? 1 : 0);
   const T h = m.timestep;
   T q0[NV], v0[NV], qs[NV], vs[NV], F[NV], dq[NV], dv[NV], Xv[NV], Fp[NV];
   int it = PendForward(m, cfg, q, v, ctrl, warm, F, aux);

@@ -1,6 +1,6 @@
-// Host-side model compiler for the two gym inverted pendulums: the numbers of
-// third_party/mujoco_gym_xml_patches/inverted_pendulum_envpool.xml and
-// inverted_double_pendulum_envpool.xml (hand transcribed, cited by XML line; the
+// Host-side model compiler for the two gym inverted pendulums and Reacher: the
+// numbers of third_party/mujoco_gym_xml_patches/inverted_pendulum_envpool.xml,
+// inverted_double_pendulum_envpool.xml and reacher_envpool.xml (hand transcribed, cited by XML line; the
 // reference loads them at envpool/mujoco/gym/mujoco_env.h:50-58,87) turned into
 // what MuJoCo's compiler + mj_setConst produce: capsule mass / inertia
 // (inertiafromgeom, default density 1000), dof_invweight0 at qpos0 = 0.
@@ -27,9 +27,9 @@ inline void CapsuleMassInertia(double r, double half, double* mass, double* iper
 }
 
 // total mass + dof_invweight0 = diag(M^-1) at qpos0 = 0 (mj_setConst)
-template <int NL>
-inline void PendSetConst(PendModel<double, NL>& m) {
-  constexpr int NV = NL + 1;
+template <int NL, bool kCart>
+inline void PendSetConst(PendModel<double, NL, kCart>& m) {
+  constexpr int NV = NL + (kCart ? 1 : 0);
   m.total_mass = m.cart_mass;
   for (int i = 0; i < NL; ++i) m.total_mass += m.mass[i];
   const double q0[NV] = {0};
@@ -80,7 +80,7 @@ inline PendModel<double, 1> BuildInvertedPendulum() {
   m.grav_x = 0;
   m.grav_z = -9.81;  // :25
   m.timestep = 0.02;  // :25, integrator RK4
-  m.gear = 100;       // :41, ctrlrange -3 3
+  m.gear[0] = 100;    // :41, ctrlrange -3 3
   m.ctrl_lo = -3;
   m.ctrl_hi = 3;
   PendDefaults(m.timestep, &m.lim_K, &m.lim_B, &m.lim_d0, &m.lim_dmax, &m.lim_width);
@@ -113,7 +113,7 @@ inline PendModel<double, 2> BuildInvertedDoublePendulum() {
   m.grav_x = 1e-5;  // gravity="1e-5 0 -9.81" :41
   m.grav_z = -9.81;
   m.timestep = 0.01;  // :41, integrator RK4
-  m.gear = 500;       // :60, ctrlrange -1 1
+  m.gear[0] = 500;    // :60, ctrlrange -1 1
   m.ctrl_lo = -1;
   m.ctrl_hi = 1;
   PendDefaults(m.timestep, &m.lim_K, &m.lim_B, &m.lim_d0, &m.lim_dmax, &m.lim_width);
@@ -121,9 +121,56 @@ inline PendModel<double, 2> BuildInvertedDoublePendulum() {
   return m;
 }
 
-template <typename T, int NL>
-inline PendModel<T, NL> CastPendModel(const PendModel<double, NL>& d) {
-  PendModel<T, NL> m{};
+// reacher_envpool.xml: the two-link arm (hinges about +z in the xy plane; see the
+// header of mj_pendulum.cuh for the z := -y mapping).  The target body only has
+// two undamped slides along x / y with zero velocity and no in-plane force (gravity
+// is along -z), so it never moves: its qpos are constants of an episode and are
+// handled by the step kernel, not by the dynamics.
+inline PendModel<double, 2, false> BuildReacher() {
+  const double kPi = 3.14159265358979323846, density = 1000.0;
+  PendModel<double, 2, false> m{};
+  m.cart_mass = 0;
+  double cm, ci;
+  CapsuleMassInertia(0.01, 0.05, &cm, &ci);  // link0 / link1: fromto 0 0 0 .1 0 0, size .01 :35,:39
+  // link 0 (body0 :34): one capsule, next hinge at pos=".1 0 0" :37
+  m.mass[0] = cm;
+  m.iyy[0] = ci;
+  m.cx[0] = 0.05;
+  m.cz[0] = 0;
+  m.lx[0] = 0.1;
+  m.lz[0] = 0;
+  // link 1 (body1 :37) + the jointless fingertip body (:40-42: sphere r=.01 at .11 0 0)
+  const double sm = density * 4.0 / 3.0 * kPi * 1e-6, si = 0.4 * sm * 1e-4;
+  const double mt = cm + sm, c1 = (cm * 0.05 + sm * 0.11) / mt;
+  m.mass[1] = mt;
+  m.cx[1] = c1;
+  m.cz[1] = 0;
+  m.iyy[1] = ci + cm * (0.05 - c1) * (0.05 - c1) + si + sm * (0.11 - c1) * (0.11 - c1);
+  m.lx[1] = 0.11;  // the fingertip body origin
+  m.lz[1] = 0;
+  // <joint armature="1" damping="1" limited="true"/> :20; joint0 limited="false" :36,
+  // joint1 range -3 3 (radian) :38
+  for (int j = 0; j < 2; ++j) {
+    m.damp[j] = 1;
+    m.arm[j] = 1;
+    m.gear[j] = 200;  // :53-54, ctrlrange -1 1
+    m.limited[j] = j == 1;
+    m.lo[j] = j == 1 ? -3.0 : 0;
+    m.hi[j] = j == 1 ? 3.0 : 0;
+    m.margin[j] = 0;
+  }
+  m.ctrl_lo = -1;
+  m.ctrl_hi = 1;
+  m.grav_x = m.grav_z = 0;  // gravity "0 0 -9.81" :23 is normal to the plane of motion
+  m.timestep = 0.01;        // :23, integrator RK4
+  PendDefaults(m.timestep, &m.lim_K, &m.lim_B, &m.lim_d0, &m.lim_dmax, &m.lim_width);
+  PendSetConst(m);
+  return m;
+}
+
+template <typename T, int NL, bool kCart>
+inline PendModel<T, NL, kCart> CastPendModel(const PendModel<double, NL, kCart>& d) {
+  PendModel<T, NL, kCart> m{};
   m.cart_mass = (T)d.cart_mass;
   for (int i = 0; i < NL; ++i) {
     m.mass[i] = (T)d.mass[i];
@@ -135,6 +182,8 @@ inline PendModel<T, NL> CastPendModel(const PendModel<double, NL>& d) {
   }
   for (int j = 0; j <= NL; ++j) {
     m.damp[j] = (T)d.damp[j];
+    m.arm[j] = (T)d.arm[j];
+    m.gear[j] = (T)d.gear[j];
     m.limited[j] = d.limited[j];
     m.lo[j] = (T)d.lo[j];
     m.hi[j] = (T)d.hi[j];
@@ -143,7 +192,6 @@ inline PendModel<T, NL> CastPendModel(const PendModel<double, NL>& d) {
   }
   m.grav_x = (T)d.grav_x;
   m.grav_z = (T)d.grav_z;
-  m.gear = (T)d.gear;
   m.ctrl_lo = (T)d.ctrl_lo;
   m.ctrl_hi = (T)d.ctrl_hi;
   m.lim_K = (T)d.lim_K;

@@ -4,6 +4,7 @@
 //   InvertedPendulumEnvBase::{MujocoResetModel,Reset,Step,WriteState}
 //                                              envpool/mujoco/gym/inverted_pendulum.h:100-185
 //   InvertedDoublePendulumEnvBase::{...}       envpool/mujoco/gym/inverted_double_pendulum.h:108-186
+//   ReacherEnvBase::{...}                      envpool/mujoco/gym/reacher.h:112-221
 // with the `frame_skip x mj_step` (RK4) physics of mj_pendulum.cuh.  No contacts
 // (every geom has contype 0), joint limits only; state is 3 x nv doubles per env,
 // so unlike the legged robots this kernel is HBM-streaming: 2 (3) dofs, ~2e3
@@ -39,7 +40,7 @@ constexpr int kPendBlock = 256;
 template <int NL>
 __global__ __launch_bounds__(kPendBlock) void PendStepKernel(
     PendDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
-    P::PendModel<double, NL> m, PendTask task, mj::SolverCfg<double> scfg) {
+    P::PendModel<double, NL, true> m, PendTask task, mj::SolverCfg<double> scfg) {
   constexpr int NV = NL + 1;
   const int n = cm.n;
   const int row = blockIdx.x * kPendBlock + threadIdx.x;
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(kPendBlock) void PendStepKernel(
     dev.nsaved[e] = saved;
     dev.navail[e] = (unsigned char)avail;
     double qacc[NV];
-    P::PendForward(m, scfg, q, v, 0.0, w, qacc, aux);  // ctrl = 0 after mj_resetData
+    const double zero[NV] = {0};
+    P::PendForward(m, scfg, q, v, zero, w, qacc, aux);  // ctrl = 0 after mj_resetData
   } else {
     ++cur;
     mj::static_for<0, NV>([&](auto ic) {
@@ -82,7 +84,8 @@ __global__ __launch_bounds__(kPendBlock) void PendStepKernel(
       v[i] = dev.qvel[(size_t)i * n + e];
       w[i] = dev.warm[(size_t)i * n + e];
     });
-    const double act = action[row];
+    double act[NV] = {0};  // the only motor drives the slider (dof 0)
+    act[0] = action[row];
     for (int s = 0; s < task.frame_skip; ++s) {  // mujoco_env.h:142-144
       P::PendStepRK4(m, scfg, q, v, w, act, aux);
     }
@@ -181,6 +184,221 @@ __global__ void PendSetState(PendDev dev, CommonDev cm, const int* ids, int k, c
   dev.navail[e] = t[6] != 0.0;
 }
 
+// ---- Reacher ------------------------------------------------------------------
+// qpos = [joint0, joint1, target_x, target_y]; the target never moves (see
+// BuildReacher), so the dynamics only see the two arm hinges.  The reference reads
+// body positions from mjData (reacher.h:175-181): after an RK4 mj_step those are
+// the fingertip position of the LAST stage's evaluation, kept in `lag`.
+struct ReacherDev {
+  double* qpos;  // [4][N]
+  double* qvel;  // [4][N]
+  double* warm;  // [4][N]
+  double* lag;   // [2][N] fingertip xpos (x, y) as left by the last forward evaluation
+};
+
+struct ReacherTask {
+  int frame_skip, reward_after_step, obs_include_z;
+  double ctrl_cost_weight, dist_cost_weight;
+  double reset_qpos_scale, reset_qvel_scale, reset_goal_scale;
+};
+
+__global__ __launch_bounds__(kPendBlock) void ReacherStepKernel(
+    ReacherDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
+    P::PendModel<double, 2, false> m, ReacherTask task, mj::SolverCfg<double> scfg) {
+  const int n = cm.n;
+  const int row = blockIdx.x * kPendBlock + threadIdx.x;
+  if (row >= a.k) return;
+  const int e = a.ids ? a.ids[row] - a.id_offset : row;
+  bool done = cm.done[e] != 0;
+  int cur = cm.cur_step[e];
+  const bool reset = a.force_reset || done;  // async_envpool.h:127
+  double q[2], v[2], w[2], tx, ty, fx, fy;  // arm state, target qpos, lagged fingertip
+  P::PendAux<double, 2> aux{};
+  float reward = 0.0f;
+  double dist_cost = 0.0, ctrl_cost = 0.0;
+  if (reset) {  // MujocoReset + MujocoResetModel, reacher.h:112-132
+    cur = 0;
+    done = false;
+    Mt19937 g(cm, e);
+    for (int i = 0; i < 2; ++i) q[i] = 0.0 + g.UniformReal(-task.reset_qpos_scale, task.reset_qpos_scale);
+    for (;;) {  // goal: rejection sampling inside the disc of radius reset_goal_scale
+      const double x = g.UniformReal(-task.reset_goal_scale, task.reset_goal_scale);
+      const double y = g.UniformReal(-task.reset_goal_scale, task.reset_goal_scale);
+      if (sqrt(x * x + y * y) < task.reset_goal_scale) {
+        tx = x;
+        ty = y;
+        break;
+      }
+    }
+    for (int i = 0; i < 2; ++i) v[i] = 0.0 + g.UniformReal(-task.reset_qvel_scale, task.reset_qvel_scale);
+    g.Commit();
+    w[0] = w[1] = 0.0;
+    double qacc[2];
+    const double zero[2] = {0.0, 0.0};
+    P::PendForward(m, scfg, q, v, zero, w, qacc, aux);  // mj_forward: xpos, warm start
+    fx = aux.tip_x;
+    fy = -aux.tip_z;  // the kernel's z axis is -y of the model (mj_pendulum.cuh)
+    dev.qpos[(size_t)2 * n + e] = tx;
+    dev.qpos[(size_t)3 * n + e] = ty;
+    dev.qvel[(size_t)2 * n + e] = 0.0;
+    dev.qvel[(size_t)3 * n + e] = 0.0;
+    dev.warm[(size_t)2 * n + e] = 0.0;
+    dev.warm[(size_t)3 * n + e] = 0.0;
+  } else {
+    ++cur;
+    for (int i = 0; i < 2; ++i) {
+      q[i] = dev.qpos[(size_t)i * n + e];
+      v[i] = dev.qvel[(size_t)i * n + e];
+      w[i] = dev.warm[(size_t)i * n + e];
+    }
+    tx = dev.qpos[(size_t)2 * n + e];
+    ty = dev.qpos[(size_t)3 * n + e];
+    fx = dev.lag[e];
+    fy = dev.lag[(size_t)n + e];
+    // target xpos = body pos (.1, -.1) + (qpos - ref (.1, -.1)) = (qpos_x, qpos_y);
+    // fingertip and target share z = .01, so dist[2] is exactly 0
+    double dx = fx - tx, dy = fy - ty;  // GetDist before the step (reacher.h:155-158)
+    const double act[2] = {action[(size_t)row * 2], action[(size_t)row * 2 + 1]};
+    for (int s = 0; s < task.frame_skip; ++s) P::PendStepRK4(m, scfg, q, v, w, act, aux);
+    fx = aux.tip_x;
+    fy = -aux.tip_z;
+    if (task.reward_after_step) {
+      dx = fx - tx;
+      dy = fy - ty;
+    }
+    dist_cost = task.dist_cost_weight * sqrt(dx * dx + dy * dy + 0.0 * 0.0);
+    for (int i = 0; i < 2; ++i) ctrl_cost += task.ctrl_cost_weight * act[i] * act[i];
+    reward = static_cast<float>(-dist_cost - ctrl_cost);
+    done = cur >= a.max_episode_steps;
+  }
+  for (int i = 0; i < 2; ++i) {
+    dev.qpos[(size_t)i * n + e] = q[i];
+    dev.qvel[(size_t)i * n + e] = v[i];
+    dev.warm[(size_t)i * n + e] = w[i];
+  }
+  dev.lag[e] = fx;
+  dev.lag[(size_t)n + e] = fy;
+  cm.done[e] = done ? 1 : 0;
+  cm.cur_step[e] = cur;
+  // WriteState, reacher.h:184-221
+  const int nobs = task.obs_include_z ? 11 : 10;
+  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
+  obs[0] = cos(q[0]);
+  obs[1] = cos(q[1]);
+  obs[2] = sin(q[0]);
+  obs[3] = sin(q[1]);
+  obs[4] = tx;
+  obs[5] = ty;
+  obs[6] = v[0];
+  obs[7] = v[1];
+  obs[8] = fx - tx;
+  obs[9] = fy - ty;
+  if (task.obs_include_z) obs[10] = 0.0;
+  ((double*)out.p[kKeyEnv0 + 1])[row] = -dist_cost;
+  ((double*)out.p[kKeyEnv0 + 2])[row] = -ctrl_cost;
+  WriteCommon(out, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
+}
+
+// flat state like oracle/mjcpu: qpos[4] qvel[4] warm[4] time xlag ylag done cur_step 0 0
+__global__ void ReacherGetState(ReacherDev dev, CommonDev cm, const int* ids, int k, double* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  int e = ids[i], n = cm.n;
+  double* o = out + (size_t)i * 19;
+  for (int j = 0; j < 4; ++j) {
+    o[j] = dev.qpos[(size_t)j * n + e];
+    o[4 + j] = dev.qvel[(size_t)j * n + e];
+    o[8 + j] = dev.warm[(size_t)j * n + e];
+  }
+  o[12] = 0;
+  o[13] = dev.lag[e];
+  o[14] = dev.lag[(size_t)n + e];
+  o[15] = cm.done[e];
+  o[16] = cm.cur_step[e];
+  o[17] = o[18] = 0;
+}
+__global__ void ReacherSetState(ReacherDev dev, CommonDev cm, const int* ids, int k,
+                                const double* in) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  int e = ids[i], n = cm.n;
+  const double* o = in + (size_t)i * 19;
+  for (int j = 0; j < 4; ++j) {
+    dev.qpos[(size_t)j * n + e] = o[j];
+    dev.qvel[(size_t)j * n + e] = o[4 + j];
+    dev.warm[(size_t)j * n + e] = o[8 + j];
+  }
+  dev.lag[e] = o[13];
+  dev.lag[(size_t)n + e] = o[14];
+  cm.done[e] = o[15] != 0.0;
+  cm.cur_step[e] = (int)o[16];
+}
+
+std::vector<KeySpec> ReacherKeys(const Config& cfg) {  // reacher.h:44-60
+  int nobs = cfg.Get("obs_include_z_distance", 1) != 0 ? 11 : 10;
+  return {{"obs", EPA_F64, {nobs}},
+          {"info:reward_dist", EPA_F64, {}},
+          {"info:reward_ctrl", EPA_F64, {}}};
+}
+
+class ReacherPool : public Pool {
+ public:
+  explicit ReacherPool(const Config& cfg)
+      : Pool(cfg, ReacherKeys(cfg), KeySpec{"action", EPA_F64, {2}}, /*needs_rng=*/true) {
+    if ((int)cfg.Get("frame_stack", 1) != 1) {
+      throw std::invalid_argument("frame_stack > 1 is not supported for Reacher yet");
+    }
+    model_ = P::BuildReacher();
+    // defaults: reacher.h:32-43
+    task_.frame_skip = (int)cfg.Get("frame_skip", 2);
+    task_.reward_after_step = cfg.Get("reward_after_step", 0) != 0;
+    task_.obs_include_z = cfg.Get("obs_include_z_distance", 1) != 0;
+    task_.ctrl_cost_weight = cfg.Get("ctrl_cost_weight", 1.0);
+    task_.dist_cost_weight = cfg.Get("dist_cost_weight", 1.0);
+    task_.reset_qpos_scale = cfg.Get("reset_qpos_scale", 0.1);
+    task_.reset_qvel_scale = cfg.Get("reset_qvel_scale", 0.005);
+    task_.reset_goal_scale = cfg.Get("reset_goal_scale", 0.2);
+    size_t n = cfg.num_envs;
+    for (double** p : {&dev_.qpos, &dev_.qvel, &dev_.warm}) {
+      EPA_HIP(hipMalloc(p, sizeof(double) * 4 * n));
+      EPA_HIP(hipMemsetAsync(*p, 0, sizeof(double) * 4 * n, stream_));
+    }
+    EPA_HIP(hipMalloc(&dev_.lag, sizeof(double) * 2 * n));
+    EPA_HIP(hipMemsetAsync(dev_.lag, 0, sizeof(double) * 2 * n, stream_));
+    InitCommon();
+  }
+  ~ReacherPool() override {
+    (void)hipFree(dev_.qpos);
+    (void)hipFree(dev_.qvel);
+    (void)hipFree(dev_.warm);
+    (void)hipFree(dev_.lag);
+  }
+  int StateDim() const override { return 19; }
+  void GetState(const int* d_ids, int k, double* d_out) override {
+    hipLaunchKernelGGL(ReacherGetState, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
+                       common_, d_ids, k, d_out);
+  }
+  void SetState(const int* d_ids, int k, const double* d_in) override {
+    hipLaunchKernelGGL(ReacherSetState, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
+                       common_, d_ids, k, d_in);
+  }
+
+ protected:
+  void Launch(const int* d_ids, int k, const void* d_action, bool force_reset,
+              const OutPtrs& out) override {
+    StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps, cfg_.env_id_offset};
+    int blocks = (k + kPendBlock - 1) / kPendBlock;
+    const mj::SolverCfg<double> sc{50, 1e-13};
+    hipLaunchKernelGGL(ReacherStepKernel, dim3(blocks), dim3(kPendBlock), 0, stream_, dev_,
+                       common_, a, static_cast<const double*>(d_action), out, model_, task_, sc);
+  }
+
+ private:
+  ReacherDev dev_{};
+  P::PendModel<double, 2, false> model_{};
+  ReacherTask task_{};
+};
+
 int PendObsDim(const Config& cfg, int nl) {
   if (nl == 1) return 4;  // inverted_pendulum.h:43-55
   int c = (int)cfg.Get("constraint_obs_dim", 3);
@@ -260,8 +478,8 @@ class PendPool : public Pool {
 
  private:
   PendDev dev_{};
-  P::PendModel<double, 1> model1_{};
-  P::PendModel<double, 2> model2_{};
+  P::PendModel<double, 1, true> model1_{};
+  P::PendModel<double, 2, true> model2_{};
   PendTask task_{};
 };
 
@@ -269,6 +487,11 @@ class PendPool : public Pool {
 
 bool DescribePendulum(const std::string& family, const Config& cfg,
                       std::vector<KeySpec>* state, KeySpec* action) {
+  if (family == "Reacher") {
+    *state = ReacherKeys(cfg);
+    *action = KeySpec{"action", EPA_F64, {2}};
+    return true;
+  }
   int nl = family == "InvertedPendulum" ? 1 : (family == "InvertedDoublePendulum" ? 2 : 0);
   if (nl == 0) return false;
   *state = {{"obs", EPA_F64, {PendObsDim(cfg, nl)}}};
@@ -279,6 +502,7 @@ bool DescribePendulum(const std::string& family, const Config& cfg,
 Pool* MakePendulum(const std::string& family, const Config& cfg) {
   if (family == "InvertedPendulum") return new PendPool<1>(cfg);
   if (family == "InvertedDoublePendulum") return new PendPool<2>(cfg);
+  if (family == "Reacher") return new ReacherPool(cfg);
   return nullptr;
 }
 

@@ -3,7 +3,8 @@
 Spec tables restate `HalfCheetahEnvFns` (half_cheetah.h:31-62), `AntEnvFns`
 (ant.h:31-75; v3/v5 add 6 contact-force numbers per body) and `Walker2dEnvFns`
 (walker2d.h:30-67), `InvertedPendulumEnvFns` (inverted_pendulum.h:30-60) and
-`InvertedDoublePendulumEnvFns` (inverted_double_pendulum.h:30-62); the pixel
+`InvertedDoublePendulumEnvFns` (inverted_double_pendulum.h:30-62) and
+`ReacherEnvFns` (reacher.h:30-65); the pixel
 variants are out of scope.  `precision` is an extension key: 64 (default, the
 reference's mjtNum=double) or 32 (fp32 arithmetic, fp64 state and I/O).
 """
@@ -225,7 +226,41 @@ _InvertedDoublePendulum = FamilyDef(
     unsupported={"xml_file": "inverted_double_pendulum.xml", "frame_stack": 1},
 )
 
+_Reacher = FamilyDef(
+    name="GymReacher", native="Reacher",
+    # reacher.h:32-43
+    default_config=[
+        ("reward_threshold", -3.75), ("frame_skip", 2), ("frame_stack", 1),
+        ("post_constraint", True), ("ctrl_cost_weight", 1.0),
+        ("reward_after_step", False), ("obs_include_z_distance", True),
+        ("dist_cost_weight", 1.0), ("xml_file", "reacher.xml"),
+        ("gymnasium_v5_render_camera", False), ("reset_qpos_scale", 0.1),
+        ("reset_qvel_scale", 0.005), ("reset_goal_scale", 0.2),
+    ],
+    state_spec=lambda c: [
+        ("obs", spec(np.float64, _stack([11 if c["obs_include_z_distance"] else 10], c),
+                     (-_inf, _inf))),
+        ("info:reward_dist", spec(np.float64, [-1])),
+        ("info:reward_ctrl", spec(np.float64, [-1])),
+    ],
+    action_spec=lambda c: [("action", spec(np.float64, [-1, 2], (-1.0, 1.0)))],
+    native_params=lambda c: {
+        "frame_skip": c["frame_skip"], "frame_stack": c["frame_stack"],
+        "ctrl_cost_weight": c["ctrl_cost_weight"],
+        "reward_after_step": c["reward_after_step"],
+        "obs_include_z_distance": c["obs_include_z_distance"],
+        "dist_cost_weight": c["dist_cost_weight"],
+        "reset_qpos_scale": c["reset_qpos_scale"],
+        "reset_qvel_scale": c["reset_qvel_scale"],
+        "reset_goal_scale": c["reset_goal_scale"],
+    },
+    unsupported={"xml_file": "reacher.xml", "frame_stack": 1},
+)
+
 _GymHalfCheetahEnvSpec, _GymHalfCheetahEnvPool = make_native_classes(_HalfCheetah)
+_GymReacherEnvSpec, _GymReacherEnvPool = make_native_classes(_Reacher)
+(GymReacherEnvSpec, GymReacherDMEnvPool,
+ GymReacherGymnasiumEnvPool) = py_env(_GymReacherEnvSpec, _GymReacherEnvPool)
 _GymInvertedPendulumEnvSpec, _GymInvertedPendulumEnvPool = make_native_classes(_InvertedPendulum)
 (GymInvertedPendulumEnvSpec, GymInvertedPendulumDMEnvPool,
  GymInvertedPendulumGymnasiumEnvPool) = py_env(_GymInvertedPendulumEnvSpec,
@@ -249,4 +284,5 @@ __all__ = ["GymHalfCheetahEnvSpec", "GymHalfCheetahDMEnvPool",
            "GymWalker2dGymnasiumEnvPool", "GymInvertedPendulumEnvSpec",
            "GymInvertedPendulumDMEnvPool", "GymInvertedPendulumGymnasiumEnvPool",
            "GymInvertedDoublePendulumEnvSpec", "GymInvertedDoublePendulumDMEnvPool",
-           "GymInvertedDoublePendulumGymnasiumEnvPool"]
+           "GymInvertedDoublePendulumGymnasiumEnvPool", "GymReacherEnvSpec",
+           "GymReacherDMEnvPool", "GymReacherGymnasiumEnvPool"]

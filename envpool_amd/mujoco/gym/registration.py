@@ -6,6 +6,7 @@ gym_mujoco_envs = [
     ("HalfCheetah", ("v3", "v4", "v5"), 1000),
     ("InvertedDoublePendulum", ("v2", "v4", "v5"), 1000),
     ("InvertedPendulum", ("v2", "v4", "v5"), 1000),
+    ("Reacher", ("v2", "v4", "v5"), 50),
     ("Walker2d", ("v3", "v4", "v5"), 1000),
 ]
 
@@ -29,6 +30,11 @@ for task, versions, max_episode_steps in gym_mujoco_envs:
             })
         if task == "InvertedPendulum" and version == "v5":  # gym/registration.py:66-67
             extra_args["reward_if_not_terminated"] = True
+        if task == "Reacher" and version == "v5":  # gym/registration.py:74-78
+            extra_args.update({
+                "reward_after_step": True,
+                "obs_include_z_distance": False,
+            })
         if task == "Walker2d" and version == "v5":  # gym/registration.py:79-83
             extra_args.update({
                 "xml_file": "walker2d_v5.xml",

@@ -146,6 +146,7 @@ void mjc_build_ant(mjc_model* m);
 void mjc_build_walker2d(mjc_model* m, int v5);
 void mjc_build_inverted_pendulum(mjc_model* m);
 void mjc_build_inverted_double_pendulum(mjc_model* m);
+void mjc_build_reacher(mjc_model* m);
 
 /* engine.c */
 void mjc_reset_data(const mjc_model* m, mjc_data* d);

@@ -7,7 +7,7 @@
  *   third_party/mujoco_gym_xml_patches/walker2d_envpool.xml (v3/v4),
  *   walker2d_v5_envpool.xml (v5: right foot friction 1.9 instead of 0.9, :47)
  *   third_party/mujoco_gym_xml_patches/inverted_pendulum_envpool.xml,
- *   inverted_double_pendulum_envpool.xml
+ *   inverted_double_pendulum_envpool.xml, reacher_envpool.xml
  * Numbers are cited by XML line (":NN").
  */
 #include <math.h>
@@ -386,5 +386,48 @@ void mjc_build_inverted_double_pendulum(mjc_model* m) {
   mjc_add_joint(m, pole2, MJC_JNT_HINGE, kZero3, yaxis, 0, 0, 0, 0, 0.05, 0); /* :53 */
   pend_geom(m, mjc_add_capsule_fromto(m, pole2, from, to, 0.045)); /* :54 */
   mjc_add_motor(m, slider, 500); /* :60 gear 500, ctrlrange -1 1 */
+  mjc_compile(m);
+}
+
+/* ---- Reacher ------------------------------------------------------------------------- */
+void mjc_build_reacher(mjc_model* m) {
+  const double xaxis[3] = {1, 0, 0}, yaxis[3] = {0, 1, 0}, zaxis[3] = {0, 0, 1};
+  const double quat_id[4] = {1, 0, 0, 0};
+  mjc_model_init(m);
+  m->timestep = 0.01;          /* :23 */
+  m->integrator = MJC_INT_RK4; /* :23 */
+  m->gravity[2] = -9.81;       /* :23 */
+  /* world geoms (ground, side walls, root cylinder :26-32) carry contype 0 /
+   * conaffinity 0 and belong to the world body: neither mass nor contacts.
+   * <joint armature="1" damping="1" limited="true"/> :20, <geom contype="0"/> :21,
+   * angle="radian" :18 */
+  const double p0[3] = {0, 0, 0.01};
+  int body0 = mjc_add_body(m, 0, p0); /* :33 */
+  const double from[3] = {0, 0, 0}, to[3] = {0.1, 0, 0};
+  pend_geom(m, mjc_add_capsule_fromto(m, body0, from, to, 0.01)); /* link0 :34 */
+  int j0 = mjc_add_joint(m, body0, MJC_JNT_HINGE, kZero3, zaxis, 0, 0, 0, 0, 1, 1); /* :35 */
+  const double p1[3] = {0.1, 0, 0};
+  int body1 = mjc_add_body(m, body0, p1); /* :36 */
+  int j1 = mjc_add_joint(m, body1, MJC_JNT_HINGE, kZero3, zaxis, 1, -3.0, 3.0, 0, 1, 1); /* :37 */
+  pend_geom(m, mjc_add_capsule_fromto(m, body1, from, to, 0.01)); /* link1 :38 */
+  const double pf[3] = {0.11, 0, 0};
+  int tip = mjc_add_body(m, body1, pf); /* fingertip :39, no joint */
+  {
+    const double size[3] = {0.01, 0, 0};
+    pend_geom(m, mjc_add_geom(m, tip, MJC_GEOM_SPHERE, size, kZero3, quat_id)); /* :40 */
+  }
+  const double pt[3] = {0.1, -0.1, 0.01};
+  int target = mjc_add_body(m, 0, pt); /* :44 */
+  int tx = mjc_add_joint(m, target, MJC_JNT_SLIDE, kZero3, xaxis, 1, -0.27, 0.27, 0, 0, 0); /* :45 */
+  int ty = mjc_add_joint(m, target, MJC_JNT_SLIDE, kZero3, yaxis, 1, -0.27, 0.27, 0, 0, 0); /* :46 */
+  m->jnt_ref[tx] = 0.1;
+  m->jnt_ref[ty] = -0.1;
+  {
+    const double size[3] = {0.009, 0, 0};
+    int g = pend_geom(m, mjc_add_geom(m, target, MJC_GEOM_SPHERE, size, kZero3, quat_id)); /* :47 */
+    m->geom_conaffinity[g] = 0;
+  }
+  mjc_add_motor(m, j0, 200); /* :51-52 */
+  mjc_add_motor(m, j1, 200);
   mjc_compile(m);
 }

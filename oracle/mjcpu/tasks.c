@@ -32,7 +32,7 @@ typedef struct {
   int current_step, done, elapsed_step;
 } mj_env;
 
-enum { TASK_CHEETAH = 0, TASK_ANT = 1, TASK_WALKER = 2, TASK_IPEND = 3, TASK_IDPEND = 4 };
+enum { TASK_CHEETAH = 0, TASK_ANT = 1, TASK_WALKER = 2, TASK_IPEND = 3, TASK_IDPEND = 4, TASK_REACHER = 5 };
 
 typedef struct {
   int is_ant;
@@ -46,6 +46,9 @@ typedef struct {
   int reward_if_not_terminated, constraint_obs_dim; /* inverted pendulums */
   /* Ant-v3 / v5 (gym/registration.py:39-46) */
   int use_contact_force, post_constraint, exclude_worldbody;
+  /* Reacher (reacher.h:32-43) */
+  int reward_after_step, obs_include_z, target;
+  double dist_cost_weight, reset_qpos_scale, reset_qvel_scale, reset_goal_scale;
   double contact_cost_weight, contact_force_min, contact_force_max;
   double observation_min, observation_max;
   int torso;
@@ -81,6 +84,8 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
     kind = TASK_IPEND;
   } else if (strcmp(task, "InvertedDoublePendulum") == 0) {
     kind = TASK_IDPEND;
+  } else if (strcmp(task, "Reacher") == 0) {
+    kind = TASK_REACHER;
   } else {
     return NULL;
   }
@@ -97,16 +102,26 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
     mjc_build_inverted_pendulum(&p->m);
   } else if (kind == TASK_IDPEND) {
     mjc_build_inverted_double_pendulum(&p->m);
+  } else if (kind == TASK_REACHER) {
+    mjc_build_reacher(&p->m);
   } else {
     mjc_build_half_cheetah(&p->m);
   }
   p->num_envs = num_envs;
   p->max_episode_steps = max_episode_steps > 0 ? max_episode_steps : INT_MAX;
   const int pend = kind == TASK_IPEND || kind == TASK_IDPEND;
-  p->frame_skip = (int)extra_or(extra, n_extra, 0, walker ? 4 : (kind == TASK_IPEND ? 2 : 5));
+  const int reacher = kind == TASK_REACHER;
+  p->frame_skip = (int)extra_or(
+      extra, n_extra, 0, walker ? 4 : ((kind == TASK_IPEND || reacher) ? 2 : 5));
   /* half_cheetah.h:33-43 / ant.h:33-50 / walker2d.h:32-47 defaults */
   p->ctrl_cost_weight =
-      extra_or(extra, n_extra, 1, is_ant ? 0.5 : (walker ? 0.001 : 0.1));
+      extra_or(extra, n_extra, 1, is_ant ? 0.5 : (walker ? 0.001 : (reacher ? 1.0 : 0.1)));
+  p->reward_after_step = extra_or(extra, n_extra, 16, 0) != 0; /* Reacher-v5 */
+  p->obs_include_z = extra_or(extra, n_extra, 17, 1) != 0;
+  p->dist_cost_weight = 1.0;
+  p->reset_qpos_scale = 0.1;
+  p->reset_qvel_scale = 0.005;
+  p->reset_goal_scale = 0.2;
   p->forward_reward_weight = extra_or(extra, n_extra, 2, 1.0);
   /* inverted_pendulum.h:32-41 (noise 0.01), inverted_double_pendulum.h:32-44 (0.1) */
   p->reset_noise_scale =
@@ -141,6 +156,10 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   p->legacy_healthy_reward = v5 ? 0 : 1; /* gym/registration.py:79-83 */
   if (extra_or(extra, n_extra, 15, -1) >= 0) p->legacy_healthy_reward = extra[15] != 0;
   p->torso = 1; /* mj_name2id(model, mjOBJ_XBODY, "torso"), ant.h:119 */
+  if (reacher) { /* the lagged body of this task is the fingertip (reacher.h:175-181) */
+    p->torso = 3;
+    p->target = 4;
+  }
   for (int i = 0; i < 8; ++i) {
     p->key_names[i] = kCommonNames[i];
     p->key_dtype[i] = kCommonDtype[i];
@@ -154,6 +173,7 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
                                          : 0)
                       : kind == TASK_IPEND ? 4
                       : kind == TASK_IDPEND ? 8 + p->constraint_obs_dim
+                      : reacher ? (p->obs_include_z ? 11 : 10)
                                             : 17;
   static const char* cheetah_info[4] = {"info:reward_run", "info:reward_ctrl",
                                         "info:x_position", "info:x_velocity"};
@@ -162,9 +182,12 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
       "info:reward_survive", "info:x_position",   "info:y_position",
       "info:distance_from_origin", "info:x_velocity", "info:y_velocity"};
   /* walker2d.h:60-61: info:x_position, info:x_velocity */
-  int ninfo = is_ant ? 9 : (walker ? 2 : (pend ? 0 : 4));
+  static const char* reacher_info[2] = {"info:reward_dist", "info:reward_ctrl"};
+  int ninfo = is_ant ? 9 : (walker || reacher ? 2 : (pend ? 0 : 4));
   for (int i = 0; i < ninfo; ++i) {
-    p->key_names[k] = is_ant ? ant_info[i] : cheetah_info[(walker ? 2 : 0) + i];
+    p->key_names[k] = is_ant ? ant_info[i]
+                      : reacher ? reacher_info[i]
+                                : cheetah_info[(walker ? 2 : 0) + i];
     p->key_dtype[k] = DT_F64;
     p->key_elems[k++] = 1;
   }
@@ -233,7 +256,26 @@ static void idp_tip(const mj_pool* p, const mj_env* e, double* x, double* z) {
   *z = e->d.xpos[b][2] + R[8] * 0.6;
 }
 
+static void reacher_dist(const mj_pool* p, const mj_env* e, double* dist) {
+  for (int k = 0; k < 3; ++k) dist[k] = e->d.xpos[p->torso][k] - e->d.xpos[p->target][k];
+}
+
 static void write_obs(mj_pool* p, mj_env* e, void** out, int row) {
+  if (p->task == TASK_REACHER) { /* reacher.h:196-216 */
+    int n = p->obs_include_z ? 11 : 10;
+    double* obs = (double*)out[8] + (size_t)row * n, dist[3];
+    *(obs++) = cos(e->d.qpos[0]);
+    *(obs++) = cos(e->d.qpos[1]);
+    *(obs++) = sin(e->d.qpos[0]);
+    *(obs++) = sin(e->d.qpos[1]);
+    for (int i = 2; i < 4; ++i) *(obs++) = e->d.qpos[i];
+    for (int i = 0; i < 2; ++i) *(obs++) = e->d.qvel[i];
+    reacher_dist(p, e, dist);
+    *(obs++) = dist[0];
+    *(obs++) = dist[1];
+    if (p->obs_include_z) *(obs++) = dist[2];
+    return;
+  }
   if (p->task == TASK_IPEND) { /* inverted_pendulum.h:172-178 */
     double* obs = (double*)out[8] + (size_t)row * 4;
     for (int i = 0; i < 2; ++i) obs[i] = e->d.qpos[i];
@@ -279,6 +321,29 @@ static void mujoco_reset(mj_pool* p, mj_env* e) {
   double warm[MJC_MAXV];
   (void)warm;
   mjc_reset_data(&p->m, &e->d); /* mj_resetData */
+  if (p->task == TASK_REACHER) { /* reacher.h:112-132 */
+    int nq = p->m.nq, nv = p->m.nv;
+    for (int i = 0; i < nq - 2; ++i) {
+      e->d.qpos[i] = p->m.qpos0[i] +
+                     orc_uniform_real(&e->gen, -p->reset_qpos_scale, p->reset_qpos_scale);
+    }
+    for (;;) {
+      double x = orc_uniform_real(&e->gen, -p->reset_goal_scale, p->reset_goal_scale);
+      double y = orc_uniform_real(&e->gen, -p->reset_goal_scale, p->reset_goal_scale);
+      if (sqrt(x * x + y * y) < p->reset_goal_scale) {
+        e->d.qpos[nq - 2] = x;
+        e->d.qpos[nq - 1] = y;
+        break;
+      }
+    }
+    for (int i = 0; i < nv; ++i) {
+      e->d.qvel[i] = i < nv - 2 ? 0.0 + orc_uniform_real(&e->gen, -p->reset_qvel_scale,
+                                                         p->reset_qvel_scale)
+                                : 0.0;
+    }
+    mjc_forward(&p->m, &e->d);
+    return;
+  }
   for (int i = 0; i < p->m.nq; ++i) {
     e->d.qpos[i] = p->m.qpos0[i] +
                    orc_uniform_real(&e->gen, -p->reset_noise_scale,
@@ -312,7 +377,9 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
   mj_env* e = &p->envs[eid];
   int reset = force_reset || e->done; /* async_envpool.h:127 */
   float reward = 0.0f;
-  int ninfo = p->is_ant ? 9 : (p->task == TASK_WALKER ? 2 : (p->task >= TASK_IPEND ? 0 : 4));
+  int ninfo = p->is_ant ? 9
+              : (p->task == TASK_WALKER || p->task == TASK_REACHER) ? 2
+              : (p->task >= TASK_IPEND ? 0 : 4);
   double info[9] = {0};
   if (reset) {
     e->current_step = 0;
@@ -326,7 +393,19 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
     double dt = p->frame_skip * p->m.timestep;
     double ctrl_cost = 0;
     for (int i = 0; i < p->m.nu; ++i) ctrl_cost += p->ctrl_cost_weight * act[i] * act[i];
-    if (p->task == TASK_IPEND) { /* inverted_pendulum.h:137-148 */
+    if (p->task == TASK_REACHER) { /* reacher.h:152-177 */
+      double dist[3] = {0, 0, 0};
+      if (!p->reward_after_step) reacher_dist(p, e, dist);
+      for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
+      for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
+      if (p->reward_after_step) reacher_dist(p, e, dist);
+      double dist_cost =
+          p->dist_cost_weight * sqrt(dist[0] * dist[0] + dist[1] * dist[1] + dist[2] * dist[2]);
+      reward = (float)(-dist_cost - ctrl_cost);
+      e->done = (++e->elapsed_step >= p->max_episode_steps);
+      info[0] = -dist_cost;
+      info[1] = -ctrl_cost;
+    } else if (p->task == TASK_IPEND) { /* inverted_pendulum.h:137-148 */
       for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
       for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
       int healthy = !(e->d.qpos[1] < p->healthy_z_min || e->d.qpos[1] > p->healthy_z_max);

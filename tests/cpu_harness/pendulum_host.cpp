@@ -5,11 +5,11 @@
 using epa::mj::SolverCfg;
 using namespace epa::mj::pend;
 
-template <int NL>
-static void Run(const PendModel<double, NL>& m, const double* q, const double* v,
-                const double* warm, double ctrl, int nsub, double* qo, double* vo, double* wo,
-                double* aux_out, int* iters) {
-  constexpr int NV = NL + 1;
+template <int NL, bool kCart>
+static void Run(const PendModel<double, NL, kCart>& m, const double* q, const double* v,
+                const double* warm, const double* ctrl, int nsub, double* qo, double* vo,
+                double* wo, double* aux_out, int* iters) {
+  constexpr int NV = NL + (kCart ? 1 : 0);
   SolverCfg<double> cfg{50, 1e-13};
   double tq[NV], tv[NV], tw[NV];
   for (int i = 0; i < NV; ++i) {
@@ -32,15 +32,28 @@ static void Run(const PendModel<double, NL>& m, const double* q, const double* v
 }
 
 extern "C" {
-// nl = 1: InvertedPendulum, nl = 2: InvertedDoublePendulum
+// nl = 1: InvertedPendulum, nl = 2: InvertedDoublePendulum (ctrl acts on dof 0)
 void pendulum_host_step(int nl, const double* q, const double* v, const double* warm,
                         double ctrl, int nsub, double* qo, double* vo, double* wo,
                         double* aux_out, int* iters) {
+  const double c[3] = {ctrl, 0, 0};
   if (nl == 1) {
-    Run<1>(BuildInvertedPendulum(), q, v, warm, ctrl, nsub, qo, vo, wo, aux_out, iters);
+    Run<1, true>(BuildInvertedPendulum(), q, v, warm, c, nsub, qo, vo, wo, aux_out, iters);
   } else {
-    Run<2>(BuildInvertedDoublePendulum(), q, v, warm, ctrl, nsub, qo, vo, wo, aux_out, iters);
+    Run<2, true>(BuildInvertedDoublePendulum(), q, v, warm, c, nsub, qo, vo, wo, aux_out, iters);
   }
+}
+// Reacher arm: q, v, warm, ctrl have 2 entries; aux_out[0..1] = fingertip (x, z = -y)
+void reacher_host_step(const double* q, const double* v, const double* warm, const double* ctrl,
+                       int nsub, double* qo, double* vo, double* wo, double* aux_out,
+                       int* iters) {
+  Run<2, false>(BuildReacher(), q, v, warm, ctrl, nsub, qo, vo, wo, aux_out, iters);
+}
+void reacher_host_model(double* out) {  // [total_mass, dof_invw0, dof_invw1]
+  auto m = BuildReacher();
+  out[0] = m.total_mass;
+  out[1] = m.dof_invw[0];
+  out[2] = m.dof_invw[1];
 }
 // [total_mass, dof_invw...]
 void pendulum_host_model(int nl, double* out) {

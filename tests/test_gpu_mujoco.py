@@ -378,3 +378,42 @@ def test_ant_contact_force_observation(name, params, extra, nobs):
         assert nz == 0 and cost == 0.0
     else:
         assert nz > 1000 and cost < 0.0  # real forces were compared
+
+
+# ---- Reacher (chain kernel without cart; lagged fingertip position; goal rejection sampling) ----
+@pytest.mark.parametrize("name,params,extra,nobs", [
+    ("Reacher-v4", {}, (), 11),
+    ("Reacher-v5", {"reward_after_step": 1, "obs_include_z_distance": 0},
+     (2, 1.0, 0, 0, 0, 0, 0, 0, -1, 0, 0, 3, 0, 0, 0, -1, 1, 0), 10),
+])
+def test_reacher_matches_oracle(name, params, extra, nobs):
+    n = 512
+    pool = DevicePool("Reacher", n, seed=4, max_episode_steps=50, params=params)
+    orc = Oracle("Reacher", n, seed=4, max_episode_steps=50, extra=extra)
+    a, b = hip_reset(pool), orc.reset()
+    assert list(a.keys()) == list(b.keys()) and a["obs"].shape == (n, nobs)
+    # reset: all draws are uniform (incl. the goal's rejection loop) => exact qpos / qvel
+    np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-14, atol=1e-16)
+    rng = np.random.default_rng(8)
+    worst = 0.0
+    # free running across several 50-step episodes (auto-resets redraw goals); the arm
+    # has armature 1 >> link inertia, so trajectories do not diverge chaotically
+    for t in range(130):
+        if t % 10 == 9:  # push joint1 against its +-3 rad limit
+            st = orc.get_state()
+            sel = rng.random(n) < 0.3
+            side = rng.choice([-1.0, 1.0], n)
+            st[sel, 1] = (side * rng.uniform(2.9, 3.05, n))[sel]
+            st[sel, 5] = (side * rng.uniform(0, 5, n))[sel]
+            orc.set_state(st)
+            pool.set_state(st)
+        act = rng.uniform(-1.2, 1.2, size=(n, 2))
+        a, b = hip_step(pool, act), orc.step(act)
+        np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-9, atol=1e-10, err_msg=f"step {t}")
+        np.testing.assert_allclose(a["reward"].ravel(), b["reward"].ravel(), rtol=1e-6, atol=1e-6)
+        for k in ("info:reward_dist", "info:reward_ctrl"):
+            np.testing.assert_allclose(a[k].ravel(), b[k].ravel(), rtol=1e-9, atol=1e-10)
+        for k in ("done", "trunc", "elapsed_step", "step_type", "discount"):
+            np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k}@{t}")
+        worst = max(worst, float(np.abs(a["obs"] - b["obs"]).max()))
+    print(f"{name}: worst free-running |d obs| over 130 steps = {worst:.3e}")

@@ -195,3 +195,44 @@ def test_product_pendulum_code_matches_oracle_on_cpu():
                 worst = max(worst, np.abs(got - b["obs"][e]).max())
         assert worst < 1e-9, (task, worst)
         assert nl == 1 or forced > 0
+
+
+def test_product_reacher_code_matches_oracle_on_cpu():
+    """Host instantiation of the cart-less chain (mj_pendulum.cuh, Reacher model) vs
+    the generic oracle: arm state and the lagged fingertip position."""
+    from oracle.orc import Oracle
+
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    so, src = os.path.join(h, "libpendulum_host.so"), os.path.join(h, "pendulum_host.cpp")
+    hdr = os.path.join(ROOT, "envpool_amd", "csrc", "mj_pendulum.cuh")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(so)
+    L.reacher_host_step.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 5
+    rng = np.random.default_rng(3)
+    n = 16
+    orc = Oracle("Reacher", n, seed=9, max_episode_steps=50)
+    orc.reset()
+    worst = 0.0
+    for t in range(60):
+        st = orc.get_state()
+        if t % 4 == 3:
+            st[:, 1] = rng.choice([-1.0, 1.0], n) * rng.uniform(2.9, 3.05, n)
+            st[:, 5] = np.sign(st[:, 1]) * rng.uniform(0, 5, n)
+            st[:, 15] = 0
+            orc.set_state(st)
+        act = rng.uniform(-1.2, 1.2, (n, 2))
+        b = orc.step(act)
+        st1 = orc.get_state()
+        for e in range(n):
+            if b["elapsed_step"][e, 0] == 0:
+                continue
+            q, v, w = st[e, 0:2].copy(), st[e, 4:6].copy(), st[e, 8:10].copy()
+            qo, vo, wo, aux = np.zeros(2), np.zeros(2), np.zeros(2), np.zeros(5)
+            it, a = ctypes.c_int(0), np.ascontiguousarray(act[e])
+            L.reacher_host_step(q.ctypes.data, v.ctypes.data, w.ctypes.data, a.ctypes.data, 2,
+                                qo.ctypes.data, vo.ctypes.data, wo.ctypes.data, aux.ctypes.data,
+                                ctypes.byref(it))
+            worst = max(worst, np.abs(qo - st1[e, 0:2]).max(), np.abs(vo - st1[e, 4:6]).max(),
+                        abs(aux[0] - st1[e, 13]), abs(-aux[1] - st1[e, 14]))
+    assert worst < 1e-10, worst

@@ -32,6 +32,7 @@ FAMILIES = [
     # gym-MuJoCo pendulums (mj_pendulum.cuh): 16 in + 26 + obs out + 2 x (3 nv doubles + 5) state
     ("InvertedPendulum", {}, 1000, ("float64", 3.0), 16 + 58 + 106),
     ("InvertedDoublePendulum", {}, 1000, ("float64", 1.0), 16 + 114 + 172),
+    ("Reacher", {}, 50, ("float64x2", 1.0), 24 + 26 + 88 + 16 + 2 * (12 * 8 + 16 + 5)),
 ]
 
 
@@ -53,6 +54,9 @@ def main():
             pool = DevicePool(fam, n, seed=0, max_episode_steps=max_steps, params=params)
             if kind == "int":
                 ring = [torch.randint(0, p, (n,), device=dev, dtype=torch.int32) for _ in range(8)]
+            elif kind == "float64x2":
+                ring = [(torch.rand((n, 2), device=dev, dtype=torch.float64) * 2 - 1) * p
+                        for _ in range(8)]
             elif kind == "float64":
                 ring = [(torch.rand((n, 1), device=dev, dtype=torch.float64) * 2 - 1) * p
                         for _ in range(8)]
