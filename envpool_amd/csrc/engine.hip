@@ -528,7 +528,7 @@ const std::vector<std::string>& FamilyNames() {
   static const std::vector<std::string> names = {
       "CartPole", "Pendulum", "MountainCar", "MountainCarContinuous", "Acrobot",
       "Catch", "FrozenLake", "Taxi", "NChain", "CliffWalking", "Blackjack",
-      "HalfCheetah", "Ant", "Walker2d", "InvertedPendulum", "InvertedDoublePendulum", "Reacher"};
+      "HalfCheetah", "Ant", "Walker2d", "InvertedPendulum", "InvertedDoublePendulum", "Reacher", "Swimmer"};
   return names;
 }
 

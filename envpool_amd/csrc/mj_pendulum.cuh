@@ -1,16 +1,21 @@
-// Planar N-link chain, optionally on a sliding cart (gym InvertedPendulum N=1 and
-// InvertedDoublePendulum N=2 with cart; Reacher N=2 without: its arm moves in the
-// xy plane about +z, which is this file's (x, z) plane about +y after z := -y):
-// the MuJoCo 3.6.0 forward pipeline restated for this chain, same scheme
+// Planar N-link serial chain on one of three bases (gym InvertedPendulum N=1 and
+// InvertedDoublePendulum N=2: sliding cart; Reacher N=2: fixed base; Swimmer N=3:
+// planar floating base = two slides + a hinge on the first link).  Reacher and
+// Swimmer move in the xy plane about +z, which is this file's (x, z) plane about
+// +y after z := -y.  The MuJoCo 3.6.0 forward pipeline restated for this chain, same scheme
 // as mj_cheetah.cuh (planar spatial algebra about the system COM, CRB, RNE,
 // primal Newton on the constraint objective, RK4) -- without contacts: every
-// geom of inverted_pendulum_envpool.xml:21 / inverted_double_pendulum_envpool.xml:39
-// (reacher_envpool.xml:21) has contype=0, so joint limits are the only constraint rows.
+// geom of inverted_pendulum_envpool.xml:21 / inverted_double_pendulum_envpool.xml:39 /
+// reacher_envpool.xml:21 / swimmer_envpool.xml:21 has contype=0, so joint limits
+// are the only constraint rows.  Swimmer adds MuJoCo's inertia-box fluid forces
+// (mj_passive with <option density viscosity>, swimmer_envpool.xml:19).
 // Call sites in the reference: envpool/mujoco/gym/mujoco_env.h:126-148
 // (mj_resetData, mj_forward, frame_skip x mj_step); the arithmetic itself lives
 // in un-vendored MuJoCo, see oracle/mjcpu/mjcpu.h (PARITY UNPINNED).
-// One env per thread; with a cart dof 0 is its slide (x) and hinge j is dof j,
-// without one the hinges are dofs 0..N-1 and the first anchor is the origin.
+// One env per thread.  Dofs: [base dofs,] then one hinge per link:
+//   kBaseFixed: hinge l = dof l, first anchor at the origin
+//   kBaseCart : dof 0 = cart slide x, hinge l = dof l + 1
+//   kBaseFree : dofs 0, 1 = slides x, z and dof 2 = hinge of link 0, hinge l = dof l + 2
 #ifndef ENVPOOL_AMD_CSRC_MJ_PENDULUM_CUH_
 #define ENVPOOL_AMD_CSRC_MJ_PENDULUM_CUH_
 
@@ -20,21 +25,28 @@ namespace epa {
 namespace mj {
 namespace pend {
 
-template <typename T, int NL, bool kCart = true>
+enum { kBaseFixed = 0, kBaseCart = 1, kBaseFree = 2 };
+
+template <typename T, int NL, int kBase = kBaseCart>
 struct PendModel {
-  static constexpr int kC = kCart ? 1 : 0;
-  static constexpr int kNV = NL + kC;
-  T cart_mass;          // 0 without a cart
+  static constexpr int kNV = NL + kBase;        // 0 / 1 / 2 extra dofs
+  static constexpr int kNB = NL + (kBase == kBaseCart ? 1 : 0);
+  T cart_mass;          // kBaseCart only
   T mass[NL], iyy[NL];  // link mass, inertia about the plane normal through its COM
   T cx[NL], cz[NL];     // link COM in the link frame (origin = its hinge)
   T lx[NL], lz[NL];     // next hinge (last link: the "tip" point) in the link frame
-  T damp[NL + 1], arm[NL + 1];  // per dof (entry NL unused without a cart)
-  T grav_x, grav_z;     // in-plane gravity: (1e-5, -9.81) for the double pendulum, 0 for Reacher
-  T gear[NL + 1];       // motor gear per dof (0: not actuated); ctrl is indexed by dof
+  T damp[NL + 2], arm[NL + 2];  // per dof
+  T grav_x, grav_z;     // in-plane gravity: (1e-5, -9.81) for the double pendulum, else 0 / -9.81
+  T gear[NL + 2];       // motor gear per dof (0: not actuated); ctrl is indexed by dof
   T ctrl_lo, ctrl_hi;
-  int limited[NL + 1];
-  T lo[NL + 1], hi[NL + 1], margin[NL + 1], dof_invw[NL + 1];
+  int limited[NL + 2];
+  T lo[NL + 2], hi[NL + 2], margin[NL + 2], dof_invw[NL + 2];
   T lim_K, lim_B, lim_d0, lim_dmax, lim_width;
+  // inertia-box fluid model (mj_inertiaBoxFluidModel): medium density / viscosity
+  // and the equivalent box of every link: [0] along the link x axis, [1] the
+  // in-plane lateral axis, [2] the plane normal (full sizes)
+  T fluid_density, fluid_viscosity;
+  T box[NL][3];
   T timestep, total_mass;
 };
 
@@ -43,10 +55,14 @@ struct PendModel {
 template <typename T, int NL>
 struct PendAux {
   T tip_x, tip_z;
-  T qfrc_constraint[NL + 1];
+  T qfrc_constraint[NL + 2];
 };
-template <typename T, int NL, bool kCart>
-using PendM = PendModel<T, NL, kCart>;
+
+// dof j -> index of the body (in [cart,] link order) it moves
+template <int kBase>
+EPA_HD constexpr int PendDofBody(int j) {
+  return kBase == kBaseFree ? (j < 3 ? 0 : j - 2) : j;
+}
 
 template <typename T, int N>
 EPA_HD void CholSolve(T* A, T* x) {  // A: full N x N SPD (row major), in place; x <- A^-1 x
@@ -81,33 +97,39 @@ EPA_HD void CholSolve(T* A, T* x) {  // A: full N x N SPD (row major), in place;
 template <typename T, int NL>
 struct PendPos {
   In4<T> cinert[NL + 1];
-  V3<T> cdof[NL + 1];
-  T M[(NL + 1) * (NL + 1)];
+  V3<T> cdof[NL + 2];
+  T M[(NL + 2) * (NL + 2)];
+  T px[NL + 1], pz[NL + 1];  // body COMs
+  T sn[NL], cs[NL];          // link frames
+  T comx, comz;              // system COM (reference point of the spatial vectors)
   T tip_x, tip_z;
 };
 
-// mj_kinematics + mj_comPos + mj_crb.  Bodies/dofs: [cart,] link 0 .. link NL-1.
-template <typename T, int NL, bool kCart>
-EPA_HD void PendKinematics(const PendModel<T, NL, kCart>& m, const T* q, PendPos<T, NL>& p) {
-  constexpr int C = kCart ? 1 : 0, NV = NL + C, NB = NL + C;
-  T ax[NL], az[NL], px[NB], pz[NB];  // hinge anchors, body COMs
-  const T x0 = kCart ? q[0] : T(0);
-  if constexpr (kCart) {
-    px[0] = x0;
-    pz[0] = T(0);
+// mj_kinematics + mj_comPos + mj_crb.  Bodies: [cart,] link 0 .. link NL-1.
+template <typename T, int NL, int kBase>
+EPA_HD void PendKinematics(const PendModel<T, NL, kBase>& m, const T* q, PendPos<T, NL>& p) {
+  constexpr int C = kBase == kBaseCart ? 1 : 0;   // body index of link 0
+  constexpr int H = kBase == kBaseFree ? 2 : C;   // dof index of the hinge of link 0
+  constexpr int NV = NL + kBase, NB = NL + C;
+  T ax[NL], az[NL];  // hinge anchors
+  const T x0 = kBase == kBaseFixed ? T(0) : q[0];
+  const T z0 = kBase == kBaseFree ? q[1] : T(0);
+  if constexpr (kBase == kBaseCart) {
+    p.px[0] = x0;
+    p.pz[0] = T(0);
   }
   {
     T phi = T(0);
-    T nx = x0, nz = T(0);  // anchor of the next link
+    T nx = x0, nz = z0;  // anchor of the next link
     static_for<0, NL>([&](auto lc) {
       constexpr int l = decltype(lc)::value;
-      T sn, cs;
-      phi += q[l + C];
-      SinCos(phi, &sn, &cs);
+      phi += q[l + H];
+      SinCos(phi, &p.sn[l], &p.cs[l]);
+      const T sn = p.sn[l], cs = p.cs[l];
       ax[l] = nx;
       az[l] = nz;
-      px[l + C] = nx + cs * m.cx[l] + sn * m.cz[l];
-      pz[l + C] = nz - sn * m.cx[l] + cs * m.cz[l];
+      p.px[l + C] = nx + cs * m.cx[l] + sn * m.cz[l];
+      p.pz[l + C] = nz - sn * m.cx[l] + cs * m.cz[l];
       const T tx = nx + cs * m.lx[l] + sn * m.lz[l];
       const T tz = nz - sn * m.lx[l] + cs * m.lz[l];
       nx = tx;
@@ -117,27 +139,30 @@ EPA_HD void PendKinematics(const PendModel<T, NL, kCart>& m, const T* q, PendPos
     p.tip_z = nz;
   }
   // mj_comPos
-  T comx = kCart ? m.cart_mass * px[0] : T(0), comz = T(0);
+  T comx = kBase == kBaseCart ? m.cart_mass * p.px[0] : T(0), comz = T(0);
   static_for<0, NL>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
-    comx += m.mass[l] * px[l + C];
-    comz += m.mass[l] * pz[l + C];
+    comx += m.mass[l] * p.px[l + C];
+    comz += m.mass[l] * p.pz[l + C];
   });
   comx /= m.total_mass;
   comz /= m.total_mass;
+  p.comx = comx;
+  p.comz = comz;
   static_for<0, NB>([&](auto bc) {
     constexpr int b = decltype(bc)::value;
-    constexpr bool cart = kCart && b == 0;
+    constexpr bool cart = kBase == kBaseCart && b == 0;
     constexpr int l = cart ? 0 : b - C;
     const T mass = cart ? m.cart_mass : m.mass[l];
     const T iyy = cart ? T(0) : m.iyy[l];  // the cart never rotates
-    const T dx = px[b] - comx, dz = pz[b] - comz;
+    const T dx = p.px[b] - comx, dz = p.pz[b] - comz;
     p.cinert[b] = {iyy + mass * (dx * dx + dz * dz), mass * dx, mass * dz, mass};
-    if constexpr (cart) {
-      p.cdof[0] = {T(0), T(1), T(0)};
-    } else {
-      p.cdof[b] = {T(1), comz - az[l], -(comx - ax[l])};
-    }
+  });
+  if constexpr (kBase != kBaseFixed) p.cdof[0] = {T(0), T(1), T(0)};
+  if constexpr (kBase == kBaseFree) p.cdof[1] = {T(0), T(0), T(1)};
+  static_for<0, NL>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    p.cdof[l + H] = {T(1), comz - az[l], -(comx - ax[l])};
   });
   // mj_crb
   In4<T> crb[NB];
@@ -151,8 +176,8 @@ EPA_HD void PendKinematics(const PendModel<T, NL, kCart>& m, const T* q, PendPos
   });
   static_for<0, NV>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
-    V3<T> buf = MulInert(crb[i], p.cdof[i]);
-    static_for<0, i + 1>([&](auto jc) {
+    V3<T> buf = MulInert(crb[PendDofBody<kBase>(i)], p.cdof[i]);
+    static_for<0, i + 1>([&](auto jc) {  // a serial chain: every lower dof is an ancestor
       constexpr int j = decltype(jc)::value;
       const T x = Dot(p.cdof[j], buf) + (i == j ? m.arm[i] : T(0));
       p.M[i * NV + j] = x;
@@ -163,10 +188,11 @@ EPA_HD void PendKinematics(const PendModel<T, NL, kCart>& m, const T* q, PendPos
 
 // mj_forward.  q, v: state; ctrl[dof]: raw action of the motor on that dof
 // (clamped to ctrlrange here, the motors are ctrllimited); warm: qacc_warmstart in/out.
-template <typename T, int NL, bool kCart>
-EPA_HD int PendForward(const PendModel<T, NL, kCart>& m, const SolverCfg<T>& cfg, const T* q,
+template <typename T, int NL, int kBase>
+EPA_HD int PendForward(const PendModel<T, NL, kBase>& m, const SolverCfg<T>& cfg, const T* q,
                        const T* v, const T* ctrl, T* warm, T* qacc, PendAux<T, NL>& aux) {
-  constexpr int NV = NL + (kCart ? 1 : 0), NB = NV;
+  constexpr int C = kBase == kBaseCart ? 1 : 0;
+  constexpr int NV = NL + kBase, NB = NL + C;
   PendPos<T, NL> pp;
   PendKinematics(m, q, pp);
   aux.tip_x = pp.tip_x;
@@ -177,23 +203,52 @@ EPA_HD int PendForward(const PendModel<T, NL, kCart>& m, const SolverCfg<T>& cfg
   // mj_comVel + mj_rne (flg_acc = 0) + mj_passive + mj_fwdActuation
   T qfrc_smooth[NV];
   {
-    V3<T> cvel[NB], cacc[NB], cfrc[NB];
+    // cfrc[b]: RNE bias force of body b; with a medium, minus the fluid force on it
+    V3<T> cfrc[NB];
     V3<T> cv = {T(0), T(0), T(0)};
     V3<T> ca = {T(0), -m.grav_x, -m.grav_z};  // world cacc = -gravity
-    static_for<0, NB>([&](auto bc) {
-      constexpr int b = decltype(bc)::value;
-      V3<T> cdd = CrossMotion(cv, cdof[b]);
-      ca.w += cdd.w * v[b];
-      ca.x += cdd.x * v[b];
-      ca.z += cdd.z * v[b];
-      cv.w += cdof[b].w * v[b];
-      cv.x += cdof[b].x * v[b];
-      cv.z += cdof[b].z * v[b];
-      cvel[b] = cv;
-      cacc[b] = ca;
-      V3<T> f = MulInert(cinert[b], ca);
-      V3<T> g = CrossForce(cv, MulInert(cinert[b], cv));
-      cfrc[b] = {f.w + g.w, f.x + g.x, f.z + g.z};
+    static_for<0, NV>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int b = PendDofBody<kBase>(j);
+      // dofs of a body in joint order: cdof_dot uses the velocity accumulated so far
+      V3<T> cdd = CrossMotion(cv, cdof[j]);
+      ca.w += cdd.w * v[j];
+      ca.x += cdd.x * v[j];
+      ca.z += cdd.z * v[j];
+      cv.w += cdof[j].w * v[j];
+      cv.x += cdof[j].x * v[j];
+      cv.z += cdof[j].z * v[j];
+      if constexpr (j + 1 == NV || PendDofBody<kBase>(j + 1 < NV ? j + 1 : j) != b) {  // last dof of b
+        V3<T> f = MulInert(cinert[b], ca);
+        V3<T> g = CrossForce(cv, MulInert(cinert[b], cv));
+        cfrc[b] = {f.w + g.w, f.x + g.x, f.z + g.z};
+        if constexpr (kBase == kBaseFree) {  // fluid forces exist only in the Swimmer model
+          constexpr int l = b - C;
+          // velocity of the link COM (spatial velocity is about the system COM), in link axes
+          const T dx = pp.px[b] - pp.comx, dz = pp.pz[b] - pp.comz;
+          const T vx = cv.x + cv.w * dz, vz = cv.z - cv.w * dx, om = cv.w;
+          const T sn = pp.sn[l], cs = pp.cs[l];
+          const T vl0 = vx * cs - vz * sn, vl1 = vx * sn + vz * cs;  // along / across the link
+          const T b0 = m.box[l][0], b1 = m.box[l][1], b2 = m.box[l][2];
+          const T diam = (b0 + b1 + b2) / T(3);
+          const T kPi = T(3.14159265358979323846);
+          const T a0 = vl0 < T(0) ? -vl0 : vl0, a1 = vl1 < T(0) ? -vl1 : vl1;
+          const T ao = om < T(0) ? -om : om;
+          // mj_inertiaBoxFluidModel: viscous (Stokes, equivalent sphere) + quadratic drag
+          const T f0 = -T(3) * kPi * diam * m.fluid_viscosity * vl0 -
+                       T(0.5) * m.fluid_density * b1 * b2 * a0 * vl0;
+          const T f1 = -T(3) * kPi * diam * m.fluid_viscosity * vl1 -
+                       T(0.5) * m.fluid_density * b0 * b2 * a1 * vl1;
+          const T tq = -kPi * diam * diam * diam * m.fluid_viscosity * om -
+                       m.fluid_density * b2 * (b0 * b0 * b0 * b0 + b1 * b1 * b1 * b1) * ao * om / T(64);
+          const T fx = f0 * cs + f1 * sn, fz = -f0 * sn + f1 * cs;  // back to plane axes
+          // spatial force about the system COM; passive forces enter with the opposite
+          // sign of the bias
+          cfrc[b].w -= tq + dz * fx - dx * fz;
+          cfrc[b].x -= fx;
+          cfrc[b].z -= fz;
+        }
+      }
     });
     static_for_down<NB, 1>([&](auto bc) {
       constexpr int b = decltype(bc)::value;
@@ -203,7 +258,7 @@ EPA_HD int PendForward(const PendModel<T, NL, kCart>& m, const SolverCfg<T>& cfg
     });
     static_for<0, NV>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      qfrc_smooth[j] = -m.damp[j] * v[j] - Dot(cdof[j], cfrc[j]);
+      qfrc_smooth[j] = -m.damp[j] * v[j] - Dot(cdof[j], cfrc[PendDofBody<kBase>(j)]);
     });
     static_for<0, NV>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
@@ -320,11 +375,11 @@ EPA_HD int PendForward(const PendModel<T, NL, kCart>& m, const SolverCfg<T>& cfg
   return iter;
 }
 
-// mj_step with integrator RK4 (both models: <option integrator="RK4">).
-template <typename T, int NL, bool kCart>
-EPA_HD int PendStepRK4(const PendModel<T, NL, kCart>& m, const SolverCfg<T>& cfg, T* q, T* v,
+// mj_step with integrator RK4 (all four models: <option integrator="RK4">).
+template <typename T, int NL, int kBase>
+EPA_HD int PendStepRK4(const PendModel<T, NL, kBase>& m, const SolverCfg<T>& cfg, T* q, T* v,
                        T* warm, const T* ctrl, PendAux<T, NL>& aux) {
-  constexpr int NV = NL + (kCart ? 1 : 0);
+  constexpr int NV = NL + kBase;
   const T h = m.timestep;
   T q0[NV], v0[NV], qs[NV], vs[NV], F[NV], dq[NV], dv[NV], Xv[NV], Fp[NV];
   int it = PendForward(m, cfg, q, v, ctrl, warm, F, aux);

@@ -27,10 +27,10 @@ inline void CapsuleMassInertia(double r, double half, double* mass, double* iper
 }
 
 // total mass + dof_invweight0 = diag(M^-1) at qpos0 = 0 (mj_setConst)
-template <int NL, bool kCart>
-inline void PendSetConst(PendModel<double, NL, kCart>& m) {
-  constexpr int NV = NL + (kCart ? 1 : 0);
-  m.total_mass = m.cart_mass;
+template <int NL, int kBase>
+inline void PendSetConst(PendModel<double, NL, kBase>& m) {
+  constexpr int NV = NL + kBase;
+  m.total_mass = kBase == kBaseCart ? m.cart_mass : 0.0;
   for (int i = 0; i < NL; ++i) m.total_mass += m.mass[i];
   const double q0[NV] = {0};
   PendPos<double, NL> p;
@@ -56,9 +56,9 @@ inline void PendDefaults(double timestep, double* K, double* B, double* d0, doub
 }
 
 // inverted_pendulum_envpool.xml
-inline PendModel<double, 1> BuildInvertedPendulum() {
+inline PendModel<double, 1, kBaseCart> BuildInvertedPendulum() {
   const double deg = 3.14159265358979323846 / 180.0;  // <compiler> default angle = degree
-  PendModel<double, 1> m{};
+  PendModel<double, 1, kBaseCart> m{};
   double iperp;
   CapsuleMassInertia(0.1, 0.1, &m.cart_mass, &iperp);  // cart capsule size=".1 .1" :32
   // pole: fromto="0 0 0 0.001 0 0.6" size="0.049 0.3" :35 (fromto fixes the length)
@@ -89,8 +89,8 @@ inline PendModel<double, 1> BuildInvertedPendulum() {
 }
 
 // inverted_double_pendulum_envpool.xml
-inline PendModel<double, 2> BuildInvertedDoublePendulum() {
-  PendModel<double, 2> m{};
+inline PendModel<double, 2, kBaseCart> BuildInvertedDoublePendulum() {
+  PendModel<double, 2, kBaseCart> m{};
   double iperp;
   CapsuleMassInertia(0.1, 0.1, &m.cart_mass, &iperp);  // cart :48
   for (int i = 0; i < 2; ++i) {  // poles: fromto="0 0 0 0 0 0.6" size="0.045 0.3" :51,:54
@@ -126,9 +126,9 @@ inline PendModel<double, 2> BuildInvertedDoublePendulum() {
 // two undamped slides along x / y with zero velocity and no in-plane force (gravity
 // is along -z), so it never moves: its qpos are constants of an episode and are
 // handled by the step kernel, not by the dynamics.
-inline PendModel<double, 2, false> BuildReacher() {
+inline PendModel<double, 2, kBaseFixed> BuildReacher() {
   const double kPi = 3.14159265358979323846, density = 1000.0;
-  PendModel<double, 2, false> m{};
+  PendModel<double, 2, kBaseFixed> m{};
   m.cart_mass = 0;
   double cm, ci;
   CapsuleMassInertia(0.01, 0.05, &cm, &ci);  // link0 / link1: fromto 0 0 0 .1 0 0, size .01 :35,:39
@@ -168,9 +168,59 @@ inline PendModel<double, 2, false> BuildReacher() {
   return m;
 }
 
-template <typename T, int NL, bool kCart>
-inline PendModel<T, NL, kCart> CastPendModel(const PendModel<double, NL, kCart>& d) {
-  PendModel<T, NL, kCart> m{};
+// swimmer_envpool.xml: three capsules in the xy plane on a planar floating base
+// (slider1 x, slider2 y, free_body_rot z :36-38), two motorised hinges, a medium
+// with density 4000 / viscosity 0.1 (:19).  y maps to -z of the kernel's plane.
+inline PendModel<double, 3, kBaseFree> BuildSwimmer() {
+  const double kPi = 3.14159265358979323846, deg = kPi / 180.0;  // angle="degree" :18
+  PendModel<double, 3, kBaseFree> m{};
+  // every link: capsule of length 1, size=".1", density 1000 (:35,:40,:43) running along -x
+  // from its hinge (torso: fromto 1.5 0 0 .5 0 0 with the hinge at the origin)
+  const double r = 0.1, half = 0.5, h = 2 * half, density = 1000.0;
+  const double gm = density * kPi * (r * r * h + 4.0 * r * r * r / 3.0);
+  const double sphere_mass = gm * 4 * r / (4 * r + 3 * h), cyl_mass = gm - sphere_mass;
+  const double iperp = cyl_mass * (3 * r * r + h * h) / 12 + 2 * sphere_mass * r * r / 5 +
+                       sphere_mass * h * (3 * r + 2 * h) / 8;
+  const double iax = cyl_mass * r * r / 2 + 2 * sphere_mass * r * r / 5;
+  const double com_x[3] = {1.0, -0.5, -0.5};   // capsule centre in the link frame
+  const double next_x[3] = {0.5, -1.0, -1.0};  // mid at pos=".5 0 0" :39, back at "-1 0 0" :42
+  for (int l = 0; l < 3; ++l) {
+    m.mass[l] = gm;
+    m.iyy[l] = iperp;
+    m.cx[l] = com_x[l];
+    m.cz[l] = 0;
+    m.lx[l] = next_x[l];
+    m.lz[l] = 0;
+    // equivalent inertia box (mj_inertiaBoxFluidModel): full sizes from the principal inertias
+    m.box[l][0] = std::sqrt(6.0 * (iperp + iperp - iax) / gm);
+    m.box[l][1] = std::sqrt(6.0 * (iax + iperp - iperp) / gm);
+    m.box[l][2] = m.box[l][1];
+  }
+  m.fluid_density = 4000;
+  m.fluid_viscosity = 0.1;
+  // <joint armature='0.1'/> :22 on all five joints, no damping; motor1_rot / motor2_rot
+  // limited to +-100 deg (:41,:44), gear 150 (:50-51)
+  for (int j = 0; j < 5; ++j) {
+    m.damp[j] = 0;
+    m.arm[j] = 0.1;
+    m.gear[j] = j >= 3 ? 150.0 : 0.0;
+    m.limited[j] = j >= 3;
+    m.lo[j] = j >= 3 ? -100 * deg : 0;
+    m.hi[j] = j >= 3 ? 100 * deg : 0;
+    m.margin[j] = 0;
+  }
+  m.ctrl_lo = -1;
+  m.ctrl_hi = 1;
+  m.grav_x = m.grav_z = 0;  // default gravity (0 0 -9.81) is normal to the plane of motion
+  m.timestep = 0.01;        // :19, integrator RK4
+  PendDefaults(m.timestep, &m.lim_K, &m.lim_B, &m.lim_d0, &m.lim_dmax, &m.lim_width);
+  PendSetConst(m);
+  return m;
+}
+
+template <typename T, int NL, int kBase>
+inline PendModel<T, NL, kBase> CastPendModel(const PendModel<double, NL, kBase>& d) {
+  PendModel<T, NL, kBase> m{};
   m.cart_mass = (T)d.cart_mass;
   for (int i = 0; i < NL; ++i) {
     m.mass[i] = (T)d.mass[i];
@@ -180,7 +230,12 @@ inline PendModel<T, NL, kCart> CastPendModel(const PendModel<double, NL, kCart>&
     m.lx[i] = (T)d.lx[i];
     m.lz[i] = (T)d.lz[i];
   }
-  for (int j = 0; j <= NL; ++j) {
+  for (int l = 0; l < NL; ++l) {
+    for (int k = 0; k < 3; ++k) m.box[l][k] = (T)d.box[l][k];
+  }
+  m.fluid_density = (T)d.fluid_density;
+  m.fluid_viscosity = (T)d.fluid_viscosity;
+  for (int j = 0; j < NL + 2; ++j) {
     m.damp[j] = (T)d.damp[j];
     m.arm[j] = (T)d.arm[j];
     m.gear[j] = (T)d.gear[j];

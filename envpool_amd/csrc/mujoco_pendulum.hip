@@ -5,6 +5,7 @@
 //                                              envpool/mujoco/gym/inverted_pendulum.h:100-185
 //   InvertedDoublePendulumEnvBase::{...}       envpool/mujoco/gym/inverted_double_pendulum.h:108-186
 //   ReacherEnvBase::{...}                      envpool/mujoco/gym/reacher.h:112-221
+//   SwimmerEnvBase::{...}                      envpool/mujoco/gym/swimmer.h:110-186
 // with the `frame_skip x mj_step` (RK4) physics of mj_pendulum.cuh.  No contacts
 // (every geom has contype 0), joint limits only; state is 3 x nv doubles per env,
 // so unlike the legged robots this kernel is HBM-streaming: 2 (3) dofs, ~2e3
@@ -40,7 +41,7 @@ constexpr int kPendBlock = 256;
 template <int NL>
 __global__ __launch_bounds__(kPendBlock) void PendStepKernel(
     PendDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
-    P::PendModel<double, NL, true> m, PendTask task, mj::SolverCfg<double> scfg) {
+    P::PendModel<double, NL, P::kBaseCart> m, PendTask task, mj::SolverCfg<double> scfg) {
   constexpr int NV = NL + 1;
   const int n = cm.n;
   const int row = blockIdx.x * kPendBlock + threadIdx.x;
@@ -204,7 +205,7 @@ struct ReacherTask {
 
 __global__ __launch_bounds__(kPendBlock) void ReacherStepKernel(
     ReacherDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
-    P::PendModel<double, 2, false> m, ReacherTask task, mj::SolverCfg<double> scfg) {
+    P::PendModel<double, 2, P::kBaseFixed> m, ReacherTask task, mj::SolverCfg<double> scfg) {
   const int n = cm.n;
   const int row = blockIdx.x * kPendBlock + threadIdx.x;
   if (row >= a.k) return;
@@ -395,9 +396,103 @@ class ReacherPool : public Pool {
 
  private:
   ReacherDev dev_{};
-  P::PendModel<double, 2, false> model_{};
+  P::PendModel<double, 2, P::kBaseFixed> model_{};
   ReacherTask task_{};
 };
+
+// ---- Swimmer -------------------------------------------------------------------
+// qpos = [slider1 x, slider2 y, free_body_rot, motor1_rot, motor2_rot]; the kernel's
+// plane is (x, z = -y), so the y slide changes sign on load / store.
+struct SwimmerTask {
+  int frame_skip, obs_skip;
+  double ctrl_cost_weight, forward_reward_weight, reset_noise_scale, dt;
+};
+
+__global__ __launch_bounds__(kPendBlock) void SwimmerStepKernel(
+    PendDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
+    P::PendModel<double, 3, P::kBaseFree> m, SwimmerTask task, mj::SolverCfg<double> scfg) {
+  constexpr int NV = 5;
+  const int n = cm.n;
+  const int row = blockIdx.x * kPendBlock + threadIdx.x;
+  if (row >= a.k) return;
+  const int e = a.ids ? a.ids[row] - a.id_offset : row;
+  bool done = cm.done[e] != 0;
+  int cur = cm.cur_step[e];
+  const bool reset = a.force_reset || done;  // async_envpool.h:127
+  double q[NV], v[NV], w[NV];  // kernel coordinates (y mirrored)
+  P::PendAux<double, 3> aux{};
+  float reward = 0.0f;
+  double info[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (reset) {  // MujocoReset + MujocoResetModel, swimmer.h:110-121
+    cur = 0;
+    done = false;
+    Mt19937 g(cm, e);
+    for (int i = 0; i < NV; ++i) q[i] = 0.0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
+    for (int i = 0; i < NV; ++i) v[i] = 0.0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
+    g.Commit();
+    q[1] = -q[1];
+    v[1] = -v[1];
+    for (int i = 0; i < NV; ++i) w[i] = 0.0;
+    double qacc[NV];
+    const double zero[NV] = {0, 0, 0, 0, 0};
+    P::PendForward(m, scfg, q, v, zero, w, qacc, aux);  // mj_forward (warm start)
+    info[4] = sqrt(0.0);  // WriteState(0, 0, 0, 0, 0, 0, true): swimmer.h:127
+  } else {
+    ++cur;
+    mj::static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr double sg = i == 1 ? -1.0 : 1.0;
+      q[i] = sg * dev.qpos[(size_t)i * n + e];
+      v[i] = sg * dev.qvel[(size_t)i * n + e];
+      w[i] = sg * dev.warm[(size_t)i * n + e];
+    });
+    const double x_before = q[0], y_before = -q[1];
+    const double a0 = action[(size_t)row * 2], a1 = action[(size_t)row * 2 + 1];
+    const double act[NV] = {0, 0, 0, a0, a1};  // motors on motor1_rot / motor2_rot
+    for (int s = 0; s < task.frame_skip; ++s) P::PendStepRK4(m, scfg, q, v, w, act, aux);
+    const double x_after = q[0], y_after = -q[1];
+    const double ctrl_cost = task.ctrl_cost_weight * a0 * a0 + task.ctrl_cost_weight * a1 * a1;
+    const double xv = (x_after - x_before) / task.dt, yv = (y_after - y_before) / task.dt;
+    reward = static_cast<float>(xv * task.forward_reward_weight - ctrl_cost);
+    done = cur >= a.max_episode_steps;
+    info[0] = xv * task.forward_reward_weight;
+    info[1] = -ctrl_cost;
+    info[2] = x_after;
+    info[3] = y_after;
+    info[4] = sqrt(x_after * x_after + y_after * y_after);
+    info[5] = xv;
+    info[6] = yv;
+  }
+  double qm[NV], vm[NV];  // model coordinates
+  mj::static_for<0, NV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    constexpr double sg = i == 1 ? -1.0 : 1.0;
+    qm[i] = sg * q[i];
+    vm[i] = sg * v[i];
+    dev.qpos[(size_t)i * n + e] = qm[i];
+    dev.qvel[(size_t)i * n + e] = vm[i];
+    dev.warm[(size_t)i * n + e] = sg * w[i];
+  });
+  cm.done[e] = done ? 1 : 0;
+  cm.cur_step[e] = cur;
+  // WriteState, swimmer.h:155-186
+  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * (2 * NV - task.obs_skip);
+  for (int i = task.obs_skip; i < NV; ++i) *(obs++) = qm[i];
+  for (int i = 0; i < NV; ++i) *(obs++) = vm[i];
+  for (int i = 0; i < 7; ++i) ((double*)out.p[kKeyEnv0 + 1 + i])[row] = info[i];
+  WriteCommon(out, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
+}
+
+std::vector<KeySpec> SwimmerKeys(const Config& cfg) {  // swimmer.h:44-61
+  int no_pos = cfg.Get("exclude_current_positions_from_observation", 1) != 0;
+  std::vector<KeySpec> k = {{"obs", EPA_F64, {no_pos ? 8 : 10}}};
+  for (const char* name : {"info:reward_fwd", "info:reward_ctrl", "info:x_position",
+                           "info:y_position", "info:distance_from_origin", "info:x_velocity",
+                           "info:y_velocity"}) {
+    k.push_back({name, EPA_F64, {}});
+  }
+  return k;
+}
 
 int PendObsDim(const Config& cfg, int nl) {
   if (nl == 1) return 4;  // inverted_pendulum.h:43-55
@@ -478,17 +573,77 @@ class PendPool : public Pool {
 
  private:
   PendDev dev_{};
-  P::PendModel<double, 1, true> model1_{};
-  P::PendModel<double, 2, true> model2_{};
+  P::PendModel<double, 1, P::kBaseCart> model1_{};
+  P::PendModel<double, 2, P::kBaseCart> model2_{};
   PendTask task_{};
+};
+
+class SwimmerPool : public Pool {
+ public:
+  static constexpr int NV = 5;
+  explicit SwimmerPool(const Config& cfg)
+      : Pool(cfg, SwimmerKeys(cfg), KeySpec{"action", EPA_F64, {2}}, /*needs_rng=*/true) {
+    if ((int)cfg.Get("frame_stack", 1) != 1) {
+      throw std::invalid_argument("frame_stack > 1 is not supported for Swimmer yet");
+    }
+    model_ = P::BuildSwimmer();
+    // defaults: swimmer.h:32-42
+    task_.frame_skip = (int)cfg.Get("frame_skip", 4);
+    task_.obs_skip = cfg.Get("exclude_current_positions_from_observation", 1) != 0 ? 2 : 0;
+    task_.ctrl_cost_weight = cfg.Get("ctrl_cost_weight", 1e-4);
+    task_.forward_reward_weight = cfg.Get("forward_reward_weight", 1.0);
+    task_.reset_noise_scale = cfg.Get("reset_noise_scale", 0.1);
+    task_.dt = task_.frame_skip * model_.timestep;
+    size_t n = cfg.num_envs;
+    for (double** p : {&dev_.qpos, &dev_.qvel, &dev_.warm}) {
+      EPA_HIP(hipMalloc(p, sizeof(double) * NV * n));
+      EPA_HIP(hipMemsetAsync(*p, 0, sizeof(double) * NV * n, stream_));
+    }
+    EPA_HIP(hipMalloc(&dev_.nsaved, sizeof(double) * n));  // unused (uniform noise only);
+    EPA_HIP(hipMalloc(&dev_.navail, n));                   // kept for the shared state layout
+    EPA_HIP(hipMemsetAsync(dev_.nsaved, 0, sizeof(double) * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.navail, 0, n, stream_));
+    InitCommon();
+  }
+  ~SwimmerPool() override {
+    (void)hipFree(dev_.qpos);
+    (void)hipFree(dev_.qvel);
+    (void)hipFree(dev_.warm);
+    (void)hipFree(dev_.nsaved);
+    (void)hipFree(dev_.navail);
+  }
+  int StateDim() const override { return 3 * NV + 7; }
+  void GetState(const int* d_ids, int k, double* d_out) override {
+    hipLaunchKernelGGL(PendGetState<NV>, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
+                       common_, d_ids, k, d_out);
+  }
+  void SetState(const int* d_ids, int k, const double* d_in) override {
+    hipLaunchKernelGGL(PendSetState<NV>, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
+                       common_, d_ids, k, d_in);
+  }
+
+ protected:
+  void Launch(const int* d_ids, int k, const void* d_action, bool force_reset,
+              const OutPtrs& out) override {
+    StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps, cfg_.env_id_offset};
+    int blocks = (k + kPendBlock - 1) / kPendBlock;
+    const mj::SolverCfg<double> sc{50, 1e-13};
+    hipLaunchKernelGGL(SwimmerStepKernel, dim3(blocks), dim3(kPendBlock), 0, stream_, dev_,
+                       common_, a, static_cast<const double*>(d_action), out, model_, task_, sc);
+  }
+
+ private:
+  PendDev dev_{};
+  P::PendModel<double, 3, P::kBaseFree> model_{};
+  SwimmerTask task_{};
 };
 
 }  // namespace
 
 bool DescribePendulum(const std::string& family, const Config& cfg,
                       std::vector<KeySpec>* state, KeySpec* action) {
-  if (family == "Reacher") {
-    *state = ReacherKeys(cfg);
+  if (family == "Reacher" || family == "Swimmer") {
+    *state = family == "Reacher" ? ReacherKeys(cfg) : SwimmerKeys(cfg);
     *action = KeySpec{"action", EPA_F64, {2}};
     return true;
   }
@@ -503,6 +658,7 @@ Pool* MakePendulum(const std::string& family, const Config& cfg) {
   if (family == "InvertedPendulum") return new PendPool<1>(cfg);
   if (family == "InvertedDoublePendulum") return new PendPool<2>(cfg);
   if (family == "Reacher") return new ReacherPool(cfg);
+  if (family == "Swimmer") return new SwimmerPool(cfg);
   return nullptr;
 }
 

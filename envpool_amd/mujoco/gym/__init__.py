@@ -4,7 +4,7 @@ Spec tables restate `HalfCheetahEnvFns` (half_cheetah.h:31-62), `AntEnvFns`
 (ant.h:31-75; v3/v5 add 6 contact-force numbers per body) and `Walker2dEnvFns`
 (walker2d.h:30-67), `InvertedPendulumEnvFns` (inverted_pendulum.h:30-60) and
 `InvertedDoublePendulumEnvFns` (inverted_double_pendulum.h:30-62) and
-`ReacherEnvFns` (reacher.h:30-65); the pixel
+`ReacherEnvFns` (reacher.h:30-65), `SwimmerEnvFns` (swimmer.h:30-66); the pixel
 variants are out of scope.  `precision` is an extension key: 64 (default, the
 reference's mjtNum=double) or 32 (fp32 arithmetic, fp64 state and I/O).
 """
@@ -257,7 +257,40 @@ _Reacher = FamilyDef(
     unsupported={"xml_file": "reacher.xml", "frame_stack": 1},
 )
 
+_Swimmer = FamilyDef(
+    name="GymSwimmer", native="Swimmer",
+    # swimmer.h:32-42
+    default_config=[
+        ("reward_threshold", 360.0), ("frame_skip", 4), ("frame_stack", 1),
+        ("post_constraint", True),
+        ("exclude_current_positions_from_observation", True),
+        ("xml_file", "swimmer.xml"), ("gymnasium_v5_render_camera", False),
+        ("forward_reward_weight", 1.0), ("ctrl_cost_weight", 1e-4),
+        ("reset_noise_scale", 0.1),
+    ],
+    state_spec=lambda c: [
+        ("obs", spec(np.float64,
+                     _stack([8 if c["exclude_current_positions_from_observation"] else 10], c),
+                     (-_inf, _inf))),
+    ] + [(k, spec(np.float64, [-1])) for k in (
+        "info:reward_fwd", "info:reward_ctrl", "info:x_position", "info:y_position",
+        "info:distance_from_origin", "info:x_velocity", "info:y_velocity")],
+    action_spec=lambda c: [("action", spec(np.float64, [-1, 2], (-1.0, 1.0)))],
+    native_params=lambda c: {
+        "frame_skip": c["frame_skip"], "frame_stack": c["frame_stack"],
+        "exclude_current_positions_from_observation":
+            c["exclude_current_positions_from_observation"],
+        "forward_reward_weight": c["forward_reward_weight"],
+        "ctrl_cost_weight": c["ctrl_cost_weight"],
+        "reset_noise_scale": c["reset_noise_scale"],
+    },
+    unsupported={"xml_file": "swimmer.xml", "frame_stack": 1},
+)
+
 _GymHalfCheetahEnvSpec, _GymHalfCheetahEnvPool = make_native_classes(_HalfCheetah)
+_GymSwimmerEnvSpec, _GymSwimmerEnvPool = make_native_classes(_Swimmer)
+(GymSwimmerEnvSpec, GymSwimmerDMEnvPool,
+ GymSwimmerGymnasiumEnvPool) = py_env(_GymSwimmerEnvSpec, _GymSwimmerEnvPool)
 _GymReacherEnvSpec, _GymReacherEnvPool = make_native_classes(_Reacher)
 (GymReacherEnvSpec, GymReacherDMEnvPool,
  GymReacherGymnasiumEnvPool) = py_env(_GymReacherEnvSpec, _GymReacherEnvPool)
@@ -285,4 +318,5 @@ __all__ = ["GymHalfCheetahEnvSpec", "GymHalfCheetahDMEnvPool",
            "GymInvertedPendulumDMEnvPool", "GymInvertedPendulumGymnasiumEnvPool",
            "GymInvertedDoublePendulumEnvSpec", "GymInvertedDoublePendulumDMEnvPool",
            "GymInvertedDoublePendulumGymnasiumEnvPool", "GymReacherEnvSpec",
-           "GymReacherDMEnvPool", "GymReacherGymnasiumEnvPool"]
+           "GymReacherDMEnvPool", "GymReacherGymnasiumEnvPool", "GymSwimmerEnvSpec",
+           "GymSwimmerDMEnvPool", "GymSwimmerGymnasiumEnvPool"]

@@ -7,6 +7,7 @@ gym_mujoco_envs = [
     ("InvertedDoublePendulum", ("v2", "v4", "v5"), 1000),
     ("InvertedPendulum", ("v2", "v4", "v5"), 1000),
     ("Reacher", ("v2", "v4", "v5"), 50),
+    ("Swimmer", ("v3", "v4", "v5"), 1000),
     ("Walker2d", ("v3", "v4", "v5"), 1000),
 ]
 

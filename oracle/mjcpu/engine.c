@@ -8,6 +8,7 @@
  * the subtree COM of the kinematic tree's root body, as MuJoCo's c-frame.
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "mjcpu.h"
@@ -477,6 +478,53 @@ static void fwd_velocity(const mjc_model* m, mjc_data* d) {
     int qa = m->jnt_qposadr[j];
     d->qfrc_passive[m->jnt_dofadr[j]] -=
         m->jnt_stiffness[j] * (d->qpos[qa] - m->qpos0[qa]);
+  }
+  /* mj_passive, fluid part (mj_inertiaBoxFluidModel): viscous + quadratic drag of
+   * the body's equivalent inertia box in a medium of density rho / viscosity beta,
+   * applied at the body COM (mj_applyFT).  Principal inertia axes are taken to be
+   * the body axes (true for the swimmer's x-aligned capsules; checked). */
+  if (m->opt_density > 0 || m->opt_viscosity > 0) {
+    const double pi = 3.14159265358979323846;
+    for (int b = 1; b < m->nbody; ++b) {
+      if (m->body_mass[b] < 1e-15) continue;
+      const double* I = m->body_inertia[b];
+      if (fabs(I[1]) + fabs(I[2]) + fabs(I[5]) > 1e-12 * (I[0] + I[4] + I[8])) abort();
+      double mass = m->body_mass[b];
+      double box[3] = {sqrt(fmax(1e-15, I[4] + I[8] - I[0]) / mass * 6.0),
+                       sqrt(fmax(1e-15, I[0] + I[8] - I[4]) / mass * 6.0),
+                       sqrt(fmax(1e-15, I[0] + I[4] - I[8]) / mass * 6.0)};
+      /* 6D velocity at the body COM in body axes: cvel is about subtree_com[root] */
+      double off[3], w[3], v[3], lw[3], lv[3], tmp[3];
+      v3_sub(off, d->xipos[b], d->subtree_com[m->body_rootid[b]]);
+      for (int k = 0; k < 3; ++k) w[k] = d->cvel[b][k];
+      v3_cross(tmp, w, off);
+      for (int k = 0; k < 3; ++k) v[k] = d->cvel[b][3 + k] + tmp[k];
+      const double* R = d->xmat[b]; /* columns = body axes in the world */
+      for (int k = 0; k < 3; ++k) {
+        lw[k] = R[k] * w[0] + R[3 + k] * w[1] + R[6 + k] * w[2];
+        lv[k] = R[k] * v[0] + R[3 + k] * v[1] + R[6 + k] * v[2];
+      }
+      double lf[3], lt[3];
+      double diam = (box[0] + box[1] + box[2]) / 3.0;
+      for (int k = 0; k < 3; ++k) {
+        int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        lt[k] = -pi * diam * diam * diam * m->opt_viscosity * lw[k] -
+                m->opt_density * box[k] * (pow(box[k1], 4) + pow(box[k2], 4)) * fabs(lw[k]) *
+                    lw[k] / 64.0;
+        lf[k] = -3.0 * pi * diam * m->opt_viscosity * lv[k] -
+                0.5 * m->opt_density * box[k1] * box[k2] * fabs(lv[k]) * lv[k];
+      }
+      double F[3], Tq[3];
+      for (int k = 0; k < 3; ++k) {
+        F[k] = R[3 * k] * lf[0] + R[3 * k + 1] * lf[1] + R[3 * k + 2] * lf[2];
+        Tq[k] = R[3 * k] * lt[0] + R[3 * k + 1] * lt[1] + R[3 * k + 2] * lt[2];
+      }
+      double jp[3][MJC_MAXV], jr[3][MJC_MAXV];
+      mjc_jac(m, d, jp, jr, d->xipos[b], b);
+      for (int i = 0; i < nv; ++i) {
+        for (int k = 0; k < 3; ++k) d->qfrc_passive[i] += jp[k][i] * F[k] + jr[k][i] * Tq[k];
+      }
+    }
   }
   /* mj_rne(flg_acc = 0) */
   double cacc[MJC_MAXBODY][6], cfrc[MJC_MAXBODY][6];

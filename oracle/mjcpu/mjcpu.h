@@ -45,6 +45,7 @@ typedef struct {
   int nq, nv, nu, nbody, njnt, ngeom;
   /* options */
   double timestep, gravity[3];
+  double opt_density, opt_viscosity; /* <option density viscosity>: medium for the fluid forces */
   int integrator;
   int disable_contact, disable_limit, disable_actuation; /* invariant tests */
   /* bodies */
@@ -147,6 +148,7 @@ void mjc_build_walker2d(mjc_model* m, int v5);
 void mjc_build_inverted_pendulum(mjc_model* m);
 void mjc_build_inverted_double_pendulum(mjc_model* m);
 void mjc_build_reacher(mjc_model* m);
+void mjc_build_swimmer(mjc_model* m);
 
 /* engine.c */
 void mjc_reset_data(const mjc_model* m, mjc_data* d);

@@ -7,7 +7,7 @@
  *   third_party/mujoco_gym_xml_patches/walker2d_envpool.xml (v3/v4),
  *   walker2d_v5_envpool.xml (v5: right foot friction 1.9 instead of 0.9, :47)
  *   third_party/mujoco_gym_xml_patches/inverted_pendulum_envpool.xml,
- *   inverted_double_pendulum_envpool.xml, reacher_envpool.xml
+ *   inverted_double_pendulum_envpool.xml, reacher_envpool.xml, swimmer_envpool.xml
  * Numbers are cited by XML line (":NN").
  */
 #include <math.h>
@@ -429,5 +429,50 @@ void mjc_build_reacher(mjc_model* m) {
   }
   mjc_add_motor(m, j0, 200); /* :51-52 */
   mjc_add_motor(m, j1, 200);
+  mjc_compile(m);
+}
+
+/* ---- Swimmer -------------------------------------------------------------------------- */
+static int swimmer_capsule(mjc_model* m, int body, double x0, double x1) {
+  /* <geom conaffinity="0" condim="1" contype="0"/> :21, density="1000" size="0.1" */
+  const double from[3] = {x0, 0, 0}, to[3] = {x1, 0, 0};
+  int g = mjc_add_capsule_fromto(m, body, from, to, 0.1);
+  m->geom_contype[g] = 0;
+  m->geom_conaffinity[g] = 0;
+  m->geom_condim[g] = 1;
+  return g;
+}
+
+void mjc_build_swimmer(mjc_model* m) {
+  const double deg = 3.14159265358979323846 / 180.0; /* angle="degree" :18 */
+  const double xaxis[3] = {1, 0, 0}, yaxis[3] = {0, 1, 0}, zaxis[3] = {0, 0, 1};
+  mjc_model_init(m);
+  m->timestep = 0.01;          /* :19 */
+  m->integrator = MJC_INT_RK4; /* :19 */
+  m->gravity[2] = -9.81;       /* MuJoCo default */
+  m->opt_density = 4000;       /* :19 */
+  m->opt_viscosity = 0.1;      /* :19 */
+  { /* floor :32: contype 0 (default :21) => never collides */
+    const double size[3] = {40, 40, 0.1}, pos[3] = {0, 0, -0.1}, quat[4] = {1, 0, 0, 0};
+    int g = mjc_add_geom(m, 0, MJC_GEOM_PLANE, size, pos, quat);
+    m->geom_contype[g] = 0;
+    m->geom_conaffinity[g] = 0;
+  }
+  /* <joint armature='0.1'/> :22 */
+  int torso = mjc_add_body(m, 0, kZero3); /* :34 */
+  swimmer_capsule(m, torso, 1.5, 0.5);    /* :36 */
+  mjc_add_joint(m, torso, MJC_JNT_SLIDE, kZero3, xaxis, 0, 0, 0, 0, 0, 0.1); /* slider1 :37 */
+  mjc_add_joint(m, torso, MJC_JNT_SLIDE, kZero3, yaxis, 0, 0, 0, 0, 0, 0.1); /* slider2 :38 */
+  mjc_add_joint(m, torso, MJC_JNT_HINGE, kZero3, zaxis, 0, 0, 0, 0, 0, 0.1); /* free_body_rot :39 */
+  const double pm[3] = {0.5, 0, 0};
+  int mid = mjc_add_body(m, torso, pm); /* :40 */
+  swimmer_capsule(m, mid, 0, -1);       /* :41 */
+  int j1 = mjc_add_joint(m, mid, MJC_JNT_HINGE, kZero3, zaxis, 1, -100 * deg, 100 * deg, 0, 0, 0.1);
+  const double pb[3] = {-1, 0, 0};
+  int back = mjc_add_body(m, mid, pb); /* :43 */
+  swimmer_capsule(m, back, 0, -1);     /* :44 */
+  int j2 = mjc_add_joint(m, back, MJC_JNT_HINGE, kZero3, zaxis, 1, -100 * deg, 100 * deg, 0, 0, 0.1);
+  mjc_add_motor(m, j1, 150); /* :50-51 */
+  mjc_add_motor(m, j2, 150);
   mjc_compile(m);
 }

@@ -32,7 +32,7 @@ typedef struct {
   int current_step, done, elapsed_step;
 } mj_env;
 
-enum { TASK_CHEETAH = 0, TASK_ANT = 1, TASK_WALKER = 2, TASK_IPEND = 3, TASK_IDPEND = 4, TASK_REACHER = 5 };
+enum { TASK_CHEETAH = 0, TASK_ANT = 1, TASK_WALKER = 2, TASK_IPEND = 3, TASK_IDPEND = 4, TASK_REACHER = 5, TASK_SWIMMER = 6 };
 
 typedef struct {
   int is_ant;
@@ -86,6 +86,8 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
     kind = TASK_IDPEND;
   } else if (strcmp(task, "Reacher") == 0) {
     kind = TASK_REACHER;
+  } else if (strcmp(task, "Swimmer") == 0) {
+    kind = TASK_SWIMMER;
   } else {
     return NULL;
   }
@@ -104,18 +106,21 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
     mjc_build_inverted_double_pendulum(&p->m);
   } else if (kind == TASK_REACHER) {
     mjc_build_reacher(&p->m);
+  } else if (kind == TASK_SWIMMER) {
+    mjc_build_swimmer(&p->m);
   } else {
     mjc_build_half_cheetah(&p->m);
   }
   p->num_envs = num_envs;
   p->max_episode_steps = max_episode_steps > 0 ? max_episode_steps : INT_MAX;
   const int pend = kind == TASK_IPEND || kind == TASK_IDPEND;
-  const int reacher = kind == TASK_REACHER;
+  const int reacher = kind == TASK_REACHER, swimmer = kind == TASK_SWIMMER;
   p->frame_skip = (int)extra_or(
-      extra, n_extra, 0, walker ? 4 : ((kind == TASK_IPEND || reacher) ? 2 : 5));
+      extra, n_extra, 0, (walker || swimmer) ? 4 : ((kind == TASK_IPEND || reacher) ? 2 : 5));
   /* half_cheetah.h:33-43 / ant.h:33-50 / walker2d.h:32-47 defaults */
   p->ctrl_cost_weight =
-      extra_or(extra, n_extra, 1, is_ant ? 0.5 : (walker ? 0.001 : (reacher ? 1.0 : 0.1)));
+      extra_or(extra, n_extra, 1,
+               is_ant ? 0.5 : (walker ? 0.001 : (reacher ? 1.0 : (swimmer ? 1e-4 : 0.1))));
   p->reward_after_step = extra_or(extra, n_extra, 16, 0) != 0; /* Reacher-v5 */
   p->obs_include_z = extra_or(extra, n_extra, 17, 1) != 0;
   p->dist_cost_weight = 1.0;
@@ -174,6 +179,7 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
                       : kind == TASK_IPEND ? 4
                       : kind == TASK_IDPEND ? 8 + p->constraint_obs_dim
                       : reacher ? (p->obs_include_z ? 11 : 10)
+                      : swimmer ? 8
                                             : 17;
   static const char* cheetah_info[4] = {"info:reward_run", "info:reward_ctrl",
                                         "info:x_position", "info:x_velocity"};
@@ -183,9 +189,14 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
       "info:distance_from_origin", "info:x_velocity", "info:y_velocity"};
   /* walker2d.h:60-61: info:x_position, info:x_velocity */
   static const char* reacher_info[2] = {"info:reward_dist", "info:reward_ctrl"};
-  int ninfo = is_ant ? 9 : (walker || reacher ? 2 : (pend ? 0 : 4));
+  /* swimmer.h:51-60 */
+  static const char* swimmer_info[7] = {"info:reward_fwd", "info:reward_ctrl", "info:x_position",
+                                        "info:y_position", "info:distance_from_origin",
+                                        "info:x_velocity", "info:y_velocity"};
+  int ninfo = is_ant ? 9 : (swimmer ? 7 : (walker || reacher ? 2 : (pend ? 0 : 4)));
   for (int i = 0; i < ninfo; ++i) {
     p->key_names[k] = is_ant ? ant_info[i]
+                      : swimmer ? swimmer_info[i]
                       : reacher ? reacher_info[i]
                                 : cheetah_info[(walker ? 2 : 0) + i];
     p->key_dtype[k] = DT_F64;
@@ -293,8 +304,8 @@ static void write_obs(mj_pool* p, mj_env* e, void** out, int row) {
     for (int i = 0; i < p->constraint_obs_dim; ++i) *(obs++) = clip_obs(p, e->d.qfrc_constraint[i]);
     return;
   }
-  int skip = p->is_ant ? 2 : 1; /* exclude_current_positions_from_observation */
-  int n = p->is_ant ? p->key_elems[8] : 17;
+  int skip = (p->is_ant || p->task == TASK_SWIMMER) ? 2 : 1; /* exclude_current_positions... */
+  int n = (p->is_ant || p->task == TASK_SWIMMER) ? p->key_elems[8] : 17;
   double* obs = (double*)out[8] + (size_t)row * n;
   for (int i = skip; i < p->m.nq; ++i) *(obs++) = e->d.qpos[i];
   for (int i = 0; i < p->m.nv; ++i) {
@@ -350,7 +361,7 @@ static void mujoco_reset(mj_pool* p, mj_env* e) {
                                     p->reset_noise_scale);
   }
   for (int i = 0; i < p->m.nv; ++i) {
-    if (p->task == TASK_WALKER || p->task == TASK_IPEND) {
+    if (p->task == TASK_WALKER || p->task == TASK_IPEND || p->task == TASK_SWIMMER) {
       /* walker2d.h:119-126, inverted_pendulum.h:100-107: uniform for qvel too */
       e->d.qvel[i] = 0.0 + orc_uniform_real(&e->gen, -p->reset_noise_scale,
                                             p->reset_noise_scale);
@@ -378,6 +389,7 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
   int reset = force_reset || e->done; /* async_envpool.h:127 */
   float reward = 0.0f;
   int ninfo = p->is_ant ? 9
+              : p->task == TASK_SWIMMER ? 7
               : (p->task == TASK_WALKER || p->task == TASK_REACHER) ? 2
               : (p->task >= TASK_IPEND ? 0 : 4);
   double info[9] = {0};
@@ -393,7 +405,22 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
     double dt = p->frame_skip * p->m.timestep;
     double ctrl_cost = 0;
     for (int i = 0; i < p->m.nu; ++i) ctrl_cost += p->ctrl_cost_weight * act[i] * act[i];
-    if (p->task == TASK_REACHER) { /* reacher.h:152-177 */
+    if (p->task == TASK_SWIMMER) { /* swimmer.h:131-152 */
+      double x_before = e->d.qpos[0], y_before = e->d.qpos[1];
+      for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
+      for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
+      double x_after = e->d.qpos[0], y_after = e->d.qpos[1];
+      double xv = (x_after - x_before) / dt, yv = (y_after - y_before) / dt;
+      reward = (float)(xv * p->forward_reward_weight - ctrl_cost);
+      e->done = (++e->elapsed_step >= p->max_episode_steps);
+      info[0] = xv * p->forward_reward_weight;
+      info[1] = -ctrl_cost;
+      info[2] = x_after;
+      info[3] = y_after;
+      info[4] = sqrt(x_after * x_after + y_after * y_after);
+      info[5] = xv;
+      info[6] = yv;
+    } else if (p->task == TASK_REACHER) { /* reacher.h:152-177 */
       double dist[3] = {0, 0, 0};
       if (!p->reward_after_step) reacher_dist(p, e, dist);
       for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];

@@ -5,11 +5,11 @@
 using epa::mj::SolverCfg;
 using namespace epa::mj::pend;
 
-template <int NL, bool kCart>
-static void Run(const PendModel<double, NL, kCart>& m, const double* q, const double* v,
+template <int NL, int kBase>
+static void Run(const PendModel<double, NL, kBase>& m, const double* q, const double* v,
                 const double* warm, const double* ctrl, int nsub, double* qo, double* vo,
                 double* wo, double* aux_out, int* iters) {
-  constexpr int NV = NL + (kCart ? 1 : 0);
+  constexpr int NV = NL + kBase;
   SolverCfg<double> cfg{50, 1e-13};
   double tq[NV], tv[NV], tw[NV];
   for (int i = 0; i < NV; ++i) {
@@ -38,16 +38,27 @@ void pendulum_host_step(int nl, const double* q, const double* v, const double* 
                         double* aux_out, int* iters) {
   const double c[3] = {ctrl, 0, 0};
   if (nl == 1) {
-    Run<1, true>(BuildInvertedPendulum(), q, v, warm, c, nsub, qo, vo, wo, aux_out, iters);
+    Run<1, kBaseCart>(BuildInvertedPendulum(), q, v, warm, c, nsub, qo, vo, wo, aux_out, iters);
   } else {
-    Run<2, true>(BuildInvertedDoublePendulum(), q, v, warm, c, nsub, qo, vo, wo, aux_out, iters);
+    Run<2, kBaseCart>(BuildInvertedDoublePendulum(), q, v, warm, c, nsub, qo, vo, wo, aux_out, iters);
   }
 }
 // Reacher arm: q, v, warm, ctrl have 2 entries; aux_out[0..1] = fingertip (x, z = -y)
 void reacher_host_step(const double* q, const double* v, const double* warm, const double* ctrl,
                        int nsub, double* qo, double* vo, double* wo, double* aux_out,
                        int* iters) {
-  Run<2, false>(BuildReacher(), q, v, warm, ctrl, nsub, qo, vo, wo, aux_out, iters);
+  Run<2, kBaseFixed>(BuildReacher(), q, v, warm, ctrl, nsub, qo, vo, wo, aux_out, iters);
+}
+// Swimmer: 5 dofs in the kernel's coordinates (slide y already mirrored by the caller)
+void swimmer_host_step(const double* q, const double* v, const double* warm, const double* ctrl,
+                       int nsub, double* qo, double* vo, double* wo, double* aux_out,
+                       int* iters) {
+  Run<3, kBaseFree>(BuildSwimmer(), q, v, warm, ctrl, nsub, qo, vo, wo, aux_out, iters);
+}
+void swimmer_host_model(double* out) {  // [total_mass, dof_invw x5]
+  auto m = BuildSwimmer();
+  out[0] = m.total_mass;
+  for (int j = 0; j < 5; ++j) out[1 + j] = m.dof_invw[j];
 }
 void reacher_host_model(double* out) {  // [total_mass, dof_invw0, dof_invw1]
   auto m = BuildReacher();

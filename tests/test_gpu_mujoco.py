@@ -417,3 +417,37 @@ def test_reacher_matches_oracle(name, params, extra, nobs):
             np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k}@{t}")
         worst = max(worst, float(np.abs(a["obs"] - b["obs"]).max()))
     print(f"{name}: worst free-running |d obs| over 130 steps = {worst:.3e}")
+
+
+# ---- Swimmer (planar floating chain + inertia-box fluid forces) ----
+def test_swimmer_matches_oracle():
+    n = 512
+    pool = DevicePool("Swimmer", n, seed=4, max_episode_steps=1000)
+    orc = Oracle("Swimmer", n, seed=4, max_episode_steps=1000)
+    a, b = hip_reset(pool), orc.reset()
+    assert list(a.keys()) == list(b.keys()) and a["obs"].shape == (n, 8)
+    np.testing.assert_array_equal(a["obs"], b["obs"])  # uniform draws only: bit exact
+    rng = np.random.default_rng(8)
+    worst, hit = 0.0, False
+    for t in range(150):
+        st = orc.get_state()
+        if t % 10 == 9:  # push the two motor hinges against their +-100 deg limits
+            sel = rng.random(n) < 0.3
+            side = rng.choice([-1.0, 1.0], n)
+            st[sel, 3] = (side * rng.uniform(1.70, 1.78, n))[sel]
+            st[sel, 8] = (side * rng.uniform(0, 3, n))[sel]
+            orc.set_state(st)
+        pool.set_state(st)
+        act = rng.uniform(-1.2, 1.2, size=(n, 2))
+        a, b = hip_step(pool, act), orc.step(act)
+        np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-9, atol=1e-10, err_msg=f"step {t}")
+        np.testing.assert_allclose(a["reward"].ravel(), b["reward"].ravel(), rtol=1e-6, atol=1e-6)
+        for k in ("info:reward_fwd", "info:reward_ctrl", "info:x_position", "info:y_position",
+                  "info:distance_from_origin", "info:x_velocity", "info:y_velocity"):
+            np.testing.assert_allclose(a[k].ravel(), b[k].ravel(), rtol=1e-9, atol=2e-9, err_msg=k)
+        for k in ("done", "trunc", "elapsed_step", "step_type", "discount"):
+            np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k}@{t}")
+        hit |= bool((np.abs(b["obs"][:, 1:3]) > 1.74).any())
+        worst = max(worst, float(np.abs(a["obs"] - b["obs"]).max()))
+    print(f"Swimmer: worst teacher-forced |d obs| = {worst:.3e}")
+    assert hit  # the hinge limit rows were exercised

@@ -236,3 +236,42 @@ def test_product_reacher_code_matches_oracle_on_cpu():
             worst = max(worst, np.abs(qo - st1[e, 0:2]).max(), np.abs(vo - st1[e, 4:6]).max(),
                         abs(aux[0] - st1[e, 13]), abs(-aux[1] - st1[e, 14]))
     assert worst < 1e-10, worst
+
+
+def test_product_swimmer_code_matches_oracle_on_cpu():
+    """Host instantiation of the planar floating chain with the inertia-box fluid
+    forces (mj_pendulum.cuh, Swimmer model; y mirrored) vs the generic 3-D oracle."""
+    from oracle.orc import Oracle
+
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    so, src = os.path.join(h, "libpendulum_host.so"), os.path.join(h, "pendulum_host.cpp")
+    hdr = os.path.join(ROOT, "envpool_amd", "csrc", "mj_pendulum.cuh")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(so)
+    L.swimmer_host_step.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 5
+    sg = np.array([1, -1, 1, 1, 1.0])
+    rng = np.random.default_rng(3)
+    n = 16
+    orc = Oracle("Swimmer", n, seed=9, max_episode_steps=1000)
+    orc.reset()
+    worst = 0.0
+    for t in range(60):
+        st = orc.get_state()
+        if t % 5 == 4:
+            st[:, 3] = rng.choice([-1.0, 1.0], n) * rng.uniform(1.70, 1.78, n)
+            st[:, 8] = np.sign(st[:, 3]) * rng.uniform(0, 3, n)
+            orc.set_state(st)
+        act = rng.uniform(-1.2, 1.2, (n, 2))
+        orc.step(act)
+        st1 = orc.get_state()
+        for e in range(n):
+            q, v, w = sg * st[e, 0:5], sg * st[e, 5:10], sg * st[e, 10:15]
+            c = np.array([0, 0, 0, act[e, 0], act[e, 1]])
+            qo, vo, wo, aux = np.zeros(5), np.zeros(5), np.zeros(5), np.zeros(8)
+            it = ctypes.c_int(0)
+            L.swimmer_host_step(q.ctypes.data, v.ctypes.data, w.ctypes.data, c.ctypes.data, 4,
+                                qo.ctypes.data, vo.ctypes.data, wo.ctypes.data, aux.ctypes.data,
+                                ctypes.byref(it))
+            worst = max(worst, np.abs(sg * qo - st1[e, 0:5]).max(), np.abs(sg * vo - st1[e, 5:10]).max())
+    assert worst < 1e-10, worst

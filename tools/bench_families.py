@@ -33,6 +33,7 @@ FAMILIES = [
     ("InvertedPendulum", {}, 1000, ("float64", 3.0), 16 + 58 + 106),
     ("InvertedDoublePendulum", {}, 1000, ("float64", 1.0), 16 + 114 + 172),
     ("Reacher", {}, 50, ("float64x2", 1.0), 24 + 26 + 88 + 16 + 2 * (12 * 8 + 16 + 5)),
+    ("Swimmer", {}, 1000, ("float64x2", 1.0), 24 + 26 + 64 + 56 + 2 * (15 * 8 + 5)),
 ]
 
 

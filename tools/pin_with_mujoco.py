@@ -34,7 +34,8 @@ def main(xml_dir: str) -> None:
             ("walker2d_v5", "walker2d_v5_envpool.xml", 4, 1.0, 40),
             ("inverted_pendulum", "inverted_pendulum_envpool.xml", 2, 3.0, 25),
             ("inverted_double_pendulum", "inverted_double_pendulum_envpool.xml", 5, 1.0, 25),
-            ("reacher", "reacher_envpool.xml", 2, 1.0, 50)):
+            ("reacher", "reacher_envpool.xml", 2, 1.0, 50),
+            ("swimmer", "swimmer_envpool.xml", 4, 1.0, 200)):
         m = mujoco.MjModel.from_xml_path(os.path.join(xml_dir, xml))
         d = mujoco.MjData(m)
         rec = {k: [] for k in ("qpos0", "qvel0", "warm0", "ctrl", "qpos1", "qvel1", "xpos1",
