@@ -1,7 +1,11 @@
 // Internal C++ side of the C ABI in include/envpool_amd.h.
 //
-// A `Pool` owns: device-resident SoA env state (family specific), one HIP
-// stream, pinned action staging, and a FIFO of result batches.  It replaces
+// A `Pool` owns: device-resident SoA env state (family specific), a HIP stream
+// for the step kernels plus one each for action uploads and result downloads
+// (so that in async mode -- several batches in flight, async_envpool.h's whole
+// point -- the copies of one batch overlap the kernel of the next, and recv of
+// the oldest batch does not wait for work enqueued after it), pinned action
+// staging, and a FIFO of result batches.  It replaces
 // AsyncEnvPool + ActionBufferQueue + StateBufferQueue of the reference
 // (envpool/core/async_envpool.h, action_buffer_queue.h, state_buffer_queue.h):
 // "enqueue" = launch one batched step kernel on the stream, "state buffer" = a
@@ -151,7 +155,9 @@ class Pool {
   std::vector<KeySpec> keys_;
   KeySpec action_;
   bool needs_rng_;
-  hipStream_t stream_{nullptr};
+  hipStream_t stream_{nullptr};       // step kernels (and device-path consumers)
+  hipStream_t h2d_stream_{nullptr};   // action uploads of the host path
+  hipStream_t d2h_stream_{nullptr};   // result downloads of the host path
   CommonDev common_{};
 
  private:
@@ -165,7 +171,8 @@ class Pool {
     char* h{nullptr};
     char* d{nullptr};
     size_t bytes{0};
-    hipEvent_t free_ev{nullptr};
+    hipEvent_t free_ev{nullptr};   // the kernel that read this slot has finished
+    hipEvent_t h2d_ev{nullptr};    // the upload into this slot has finished
     bool in_use{false};
   };
   Staging& NextStaging(size_t bytes);

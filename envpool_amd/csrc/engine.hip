@@ -101,6 +101,8 @@ Pool::Pool(const Config& cfg, std::vector<KeySpec> env_state_keys,
   }
   EPA_HIP(hipSetDevice(cfg_.device));
   EPA_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  EPA_HIP(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
+  EPA_HIP(hipStreamCreateWithFlags(&d2h_stream_, hipStreamNonBlocking));
   staging_.resize(3);
 }
 
@@ -128,7 +130,9 @@ void Pool::InitCommon() {
 
 Pool::~Pool() {
   (void)hipSetDevice(cfg_.device);
+  if (h2d_stream_) (void)hipStreamSynchronize(h2d_stream_);
   if (stream_) (void)hipStreamSynchronize(stream_);
+  if (d2h_stream_) (void)hipStreamSynchronize(d2h_stream_);
   for (auto& b : all_) {
     if (b->dbuf) (void)hipFree(b->dbuf);
     if (b->done) (void)hipEventDestroy(b->done);
@@ -137,6 +141,7 @@ Pool::~Pool() {
     if (s.h) (void)hipHostFree(s.h);
     if (s.d) (void)hipFree(s.d);
     if (s.free_ev) (void)hipEventDestroy(s.free_ev);
+    if (s.h2d_ev) (void)hipEventDestroy(s.h2d_ev);
   }
   for (auto& t : timers_) {
     (void)hipEventDestroy(t.first);
@@ -149,6 +154,8 @@ Pool::~Pool() {
   if (common_.mt) (void)hipFree(common_.mt);
   if (common_.mti) (void)hipFree(common_.mti);
   if (stream_) (void)hipStreamDestroy(stream_);
+  if (h2d_stream_) (void)hipStreamDestroy(h2d_stream_);
+  if (d2h_stream_) (void)hipStreamDestroy(d2h_stream_);
 }
 
 Batch* Pool::AcquireBatch(int k) {
@@ -231,6 +238,7 @@ Pool::Staging& Pool::NextStaging(size_t bytes) {
   }
   if (!s.free_ev) {
     EPA_HIP(hipEventCreateWithFlags(&s.free_ev, hipEventDisableTiming));
+    EPA_HIP(hipEventCreateWithFlags(&s.h2d_ev, hipEventDisableTiming));
   }
   return s;
 }
@@ -273,9 +281,13 @@ void Pool::Send(const int32_t* env_id, int k, const void* action) {
   size_t copy_from = identity ? id_bytes : 0;
   if (!identity) std::memcpy(s.h, env_id, (size_t)k * 4);
   std::memcpy(s.h + id_bytes, action, act_bytes);
+  // upload on its own stream: it overlaps the kernel of the previous batch; the
+  // step kernel only waits for this slot's upload
   EPA_HIP(hipMemcpyAsync(s.d + copy_from, s.h + copy_from,
                          id_bytes + act_bytes - copy_from,
-                         hipMemcpyHostToDevice, stream_));
+                         hipMemcpyHostToDevice, h2d_stream_));
+  EPA_HIP(hipEventRecord(s.h2d_ev, h2d_stream_));
+  EPA_HIP(hipStreamWaitEvent(stream_, s.h2d_ev, 0));
   Enqueue(identity ? nullptr : reinterpret_cast<const int*>(s.d), k,
           s.d + id_bytes, false);
   EPA_HIP(hipEventRecord(s.free_ev, stream_));
@@ -297,7 +309,9 @@ void Pool::Reset(const int32_t* env_ids, int k) {
   Staging& s = NextStaging(id_bytes);
   std::memcpy(s.h, env_ids, (size_t)k * 4);
   EPA_HIP(hipMemcpyAsync(s.d, s.h, (size_t)k * 4, hipMemcpyHostToDevice,
-                         stream_));
+                         h2d_stream_));
+  EPA_HIP(hipEventRecord(s.h2d_ev, h2d_stream_));
+  EPA_HIP(hipStreamWaitEvent(stream_, s.h2d_ev, 0));
   Enqueue(reinterpret_cast<const int*>(s.d), k, nullptr, true);
   EPA_HIP(hipEventRecord(s.free_ev, stream_));
   s.in_use = true;
@@ -357,28 +371,30 @@ void Pool::CopyRowsToHost(char* dst, const std::vector<size_t>& off, int want) {
   while (got < want) {
     Batch* b = pending_.front();
     int take = std::min(want - got, b->k - b->consumed);
-    // the copies go on the pool's stream: ordered after the kernel that
-    // produced the rows, no extra event needed.
+    // the copies go on the download stream, behind the kernel that produced the
+    // rows (its `done` event) but NOT behind kernels enqueued after it
+    EPA_HIP(hipStreamWaitEvent(d2h_stream_, b->done, 0));
     if (got == 0 && take == want && b->consumed == 0 && take == b->k) {
       // whole batch: one D2H of the packed block (offsets coincide)
-      EPA_HIP(hipMemcpyAsync(dst, b->dbuf, total, hipMemcpyDeviceToHost, stream_));
+      EPA_HIP(hipMemcpyAsync(dst, b->dbuf, total, hipMemcpyDeviceToHost, d2h_stream_));
     } else {
       for (size_t i = 0; i < keys_.size(); ++i) {
         size_t rb = keys_[i].row_bytes();
         EPA_HIP(hipMemcpyAsync(dst + off[i] + (size_t)got * rb,
                                b->dbuf + b->offsets[i] + (size_t)b->consumed * rb,
                                (size_t)take * rb, hipMemcpyDeviceToHost,
-                               stream_));
+                               d2h_stream_));
       }
     }
     b->consumed += take;
     got += take;
     if (b->consumed == b->k) {
       pending_.pop_front();
-      ReleaseBatch(b);  // safe: reuse is ordered behind the copy on stream_
+      ReleaseBatch(b);  // safe: the copy is complete (synchronised below) before any
+                        // later Send can hand the buffer to another kernel (mu_ is held)
     }
   }
-  EPA_HIP(hipStreamSynchronize(stream_));
+  EPA_HIP(hipStreamSynchronize(d2h_stream_));
 }
 
 int Pool::Recv(void* const* out_ptrs, int n_ptrs, int cap_rows) {
@@ -454,7 +470,9 @@ int Pool::RecvDevice(void** d_out_ptrs, int n_ptrs) {
 
 void Pool::Synchronize() {
   EPA_HIP(hipSetDevice(cfg_.device));
+  EPA_HIP(hipStreamSynchronize(h2d_stream_));
   EPA_HIP(hipStreamSynchronize(stream_));
+  EPA_HIP(hipStreamSynchronize(d2h_stream_));
 }
 
 void Pool::SetTiming(bool on) {
