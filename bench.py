@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--task", default="HalfCheetah")
     ap.add_argument("--precision", default="fp64", choices=["fp32", "fp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend (nccl = RCCL; gloo only to exercise the "
+                         "multi-process path on a box with fewer GPUs than ranks)")
     ap.add_argument("--allgather", action="store_true",
                     help="also all-gather the obs batch over RCCL every step (optional "
                          "exchange of SURVEY §8e; off by default: the path needs no collective)")
@@ -74,17 +77,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ngpu = torch.cuda.device_count()
+    if args.backend == "nccl" and world > 1 and local_rank >= ngpu:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ngpu} GPU(s) visible")
+    dev_index = local_rank % max(ngpu, 1)  # gloo test mode may share a GPU between ranks
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     from envpool_amd.core.device_pool import DevicePool
 
     n = args.num_envs
     params = {"precision": 1 if args.precision == "fp64" else 0}
-    pool = DevicePool(args.task, n, seed=0, max_episode_steps=1000, device=local_rank,
+    pool = DevicePool(args.task, n, seed=0, max_episode_steps=1000, device=dev_index,
                       env_id_offset=rank * n, params=params)
     adim = int(np.prod(pool.action_shape))
     # ring of 16 pre-generated action batches, Philox seed 1234
@@ -131,7 +142,7 @@ def main():
     pool.set_timing(False)
     if world > 1:
         dist.barrier()
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
