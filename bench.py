@@ -151,8 +151,8 @@ def main():
         value = total_env_steps / elapsed
         # algorithmic bytes / env-step: action+ids
         # in, every state key out, persistent fp64 state read + written
-        alg_bytes = {"HalfCheetah": 708, "Ant": 1132, "Walker2d": 692}[args.task]
-        frame_skip = {"HalfCheetah": 5, "Ant": 5, "Walker2d": 4}[args.task]
+        alg_bytes = {"HalfCheetah": 708, "Ant": 1132, "Walker2d": 692, "Hopper": 476}[args.task]
+        frame_skip = {"HalfCheetah": 5, "Ant": 5, "Walker2d": 4, "Hopper": 4}[args.task]
         # counted fp32 flops / env-step from the kernel's ISA
         achieved_gbs = alg_bytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # HBM traffic and flop counts come from the committed rocprofv3 PMC passes of
@@ -160,8 +160,8 @@ def main():
         # collection needs its own rocprofv3 runs and cannot happen inside the bench.
         kbase = "AntStepKernel" if args.task == "Ant" else "CheetahStepKernel"
         kname = kbase + ("<double>" if args.precision == "fp64" else "<float>")
-        if args.task == "Walker2d":
-            kname += "[Walker2d]"
+        if args.task in ("Walker2d", "Hopper"):
+            kname += f"[{args.task}]"
         pmc = {}
         try:
             with open(os.path.join(ROOT, "profiles", "r1_pmc.json")) as f:

@@ -177,7 +177,20 @@ struct CheetahModel {
   T con_d0, con_dmax, con_width;
   T lim_K, lim_B, lim_d0, lim_dmax, lim_width;
   T timestep, gravity;   // gravity = 9.81 (magnitude along -z)
+  T con_margin;          // contact margin of every geom pair (Hopper: 0.001, else 0)
+  int n_pairs;           // 3: the Hopper's body-body capsule pairs (kPairBody*), else 0
 };
+
+// Body-body collision candidates of the single-leg Hopper model (its geoms have
+// contype = conaffinity = 1; parent-child pairs are filtered by MuJoCo): torso-leg,
+// torso-foot, thigh-foot.  condim 1 => one frictionless row per contact.
+constexpr int kNPair = 3;
+EPA_HD constexpr int PairBody1(int k) { return k == 2 ? 1 : 0; }
+EPA_HD constexpr int PairBody2(int k) { return k == 0 ? 2 : 3; }
+// first end sphere of the (only) capsule of body b in the one-capsule-per-body layout
+EPA_HD constexpr int BodyEnd0(int b) { return b == 0 ? 0 : 2 * b + 2; }
+constexpr int kPairSlot0 = 50;     // LDS slots of the unused second-leg ends 10..15
+constexpr int kSlotsPerPair = 6;   // nx nz px pz aref D
 
 // ---- small planar spatial algebra ---------------------------------------------
 template <typename T>
@@ -532,11 +545,12 @@ EPA_HD unsigned CheetahMakeConstraint(const CheetahModel<T>& m,
   static_for<0, kNEnd>([&](auto ec) {
     constexpr int e = decltype(ec)::value;
     constexpr int b = EndBody(e);
+    if (m.er[e] < T(-1e29)) return;  // unused end slot of this model (folds at compile time)
     T wx = p.px[b] + p.cs[b] * m.ex[e] + p.sn[b] * m.ez[e];
     T wz = p.pz[b] - p.sn[b] * m.ex[e] + p.cs[b] * m.ez[e];
     T dist = wz - m.er[e];
     T D = T(0), cpx = wx, cpz = T(0.5) * dist, an = T(0), ax = T(0);
-    const bool touch = dist < T(0);
+    const bool touch = dist < m.con_margin;
     if (WaveAny(touch)) {
       ends |= 1u << e;
       T vn = T(0), vx = T(0);
@@ -545,13 +559,14 @@ EPA_HD unsigned CheetahMakeConstraint(const CheetahModel<T>& m,
         vn += jn * v[j];
         vx += jx * v[j];
       });
-      T imp = Impedance(m.con_d0, m.con_dmax, m.con_width, dist);
+      const T r = dist - m.con_margin;
+      T imp = Impedance(m.con_d0, m.con_dmax, m.con_width, r);
       // diagApprox (pyramidal) = tran (1 + mu^2); R_py = 2 mu^2 R
       T diag = m.body_invw[b] * (T(1) + m.bmu[b] * m.bmu[b]);
       const T num = (T(1) - imp) * diag;  // R = max(mjMINVAL, num / imp)
       const T invR = num < kMinVal * imp ? T(1) / kMinVal : imp / num;
       D = touch ? invR * (T(1) / (T(2) * m.bmu[b] * m.bmu[b])) : T(0);
-      an = touch ? -m.con_B * vn - m.con_K * imp * dist : T(0);
+      an = touch ? -m.con_B * vn - m.con_K * imp * r : T(0);
       ax = touch ? m.con_B * m.bmu[b] * vx : T(0);
     }
     lds(e * kSlotsPerEnd + 0) = cpx;
@@ -560,7 +575,113 @@ EPA_HD unsigned CheetahMakeConstraint(const CheetahModel<T>& m,
     lds(e * kSlotsPerEnd + 3) = ax;
     lds(e * kSlotsPerEnd + 4) = D;
   });
+  // body-body capsule pairs (mjc_CapsuleCapsule: closest points of the two axis
+  // segments, then sphere-sphere), Hopper model only
+  if (m.n_pairs > 0) {
+    static_for<0, kNPair>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int b1 = PairBody1(k), b2 = PairBody2(k);
+      constexpr int e1 = BodyEnd0(b1), e2 = BodyEnd0(b2);
+      auto end_pos = [&](auto bc, int e, T* x, T* z) {
+        constexpr int b = decltype(bc)::value;
+        *x = p.px[b] + p.cs[b] * m.ex[e] + p.sn[b] * m.ez[e];
+        *z = p.pz[b] - p.sn[b] * m.ex[e] + p.cs[b] * m.ez[e];
+      };
+      T ax1, az1, bx1, bz1, ax2, az2, bx2, bz2;
+      end_pos(IC<b1>{}, e1, &ax1, &az1);
+      end_pos(IC<b1>{}, e1 + 1, &bx1, &bz1);
+      end_pos(IC<b2>{}, e2, &ax2, &az2);
+      end_pos(IC<b2>{}, e2 + 1, &bx2, &bz2);
+      // centres and half axes (towards the first end = +z of the geom frame)
+      const T c1x = T(0.5) * (ax1 + bx1), c1z = T(0.5) * (az1 + bz1);
+      const T c2x = T(0.5) * (ax2 + bx2), c2z = T(0.5) * (az2 + bz2);
+      const T h1x = T(0.5) * (ax1 - bx1), h1z = T(0.5) * (az1 - bz1);
+      const T h2x = T(0.5) * (ax2 - bx2), h2z = T(0.5) * (az2 - bz2);
+      const T dfx = c1x - c2x, dfz = c1z - c2z;
+      const T ma = h1x * h1x + h1z * h1z, mb = -(h1x * h2x + h1z * h2z), mc = h2x * h2x + h2z * h2z;
+      const T u = -(h1x * dfx + h1z * dfz), w = h2x * dfx + h2z * dfz;
+      const T det = ma * mc - mb * mb;
+      auto clamp1 = [](T x) { return x > T(1) ? T(1) : (x < T(-1) ? T(-1) : x); };
+      // general position (|det| >= mjMINVAL); the exactly parallel case falls back to
+      // the midpoint of the overlap like oracle/mjcpu (measure zero)
+      const bool par = (det < T(0) ? -det : det) < kMinVal;
+      T x1 = (mc * u - mb * w) / (par ? T(1) : det);
+      T x2 = (ma * w - mb * u) / (par ? T(1) : det);
+      {
+        const bool hi1 = x1 > T(1), lo1 = x1 < T(-1);
+        x2 = hi1 ? (w - mb) / mc : (lo1 ? (w + mb) / mc : x2);
+        x1 = clamp1(x1);
+        const bool hi2 = x2 > T(1), lo2 = x2 < T(-1);
+        const T x1b = clamp1(hi2 ? (u - mb) / ma : (u + mb) / ma);
+        x1 = (hi2 || lo2) ? x1b : x1;
+        x2 = clamp1(x2);
+      }
+      {
+        const T amb = mb < T(0) ? -mb : mb;
+        T lo = (u - amb) / ma, hi = (u + amb) / ma;
+        lo = lo < T(-1) ? T(-1) : lo;
+        hi = hi > T(1) ? T(1) : hi;
+        const T xp1 = lo <= hi ? T(0.5) * (lo + hi) : (lo > T(1) ? T(1) : T(-1));
+        const T xp2 = clamp1((w - mb * xp1) / mc);
+        x1 = par ? xp1 : x1;
+        x2 = par ? xp2 : x2;
+      }
+      const T p1x = c1x + h1x * x1, p1z = c1z + h1z * x1;
+      const T p2x = c2x + h2x * x2, p2z = c2z + h2z * x2;
+      const T ddx = p2x - p1x, ddz = p2z - p1z;
+      const T cd = Sqrt(ddx * ddx + ddz * ddz);
+      const T r1 = m.er[e1], r2 = m.er[e2];
+      const T dist = cd - r1 - r2;
+      const bool touch = dist < m.con_margin;
+      T nx = T(1), nz = T(0), cx = T(0), cz = T(0), aref = T(0), D = T(0);
+      if (WaveAny(touch)) {
+        ends |= 1u << (16 + k);
+        const T inv = T(1) / (cd < kMinVal ? T(1) : cd);
+        nx = cd < kMinVal ? T(1) : ddx * inv;
+        nz = cd < kMinVal ? T(0) : ddz * inv;
+        cx = p1x + nx * (r1 + T(0.5) * dist);
+        cz = p1z + nz * (r1 + T(0.5) * dist);
+        // relative normal velocity: only the hinges between the two bodies contribute
+        // (the dofs shared by both chains move both bodies alike)
+        T vel = T(0);
+        static_for<3, kNV>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if constexpr (InChain(j, b2) && !InChain(j, b1)) {
+            constexpr int jb = DofBody(j);
+            vel += (nx * (cz - p.pz[jb]) - nz * (cx - p.px[jb])) * v[j];
+          }
+        });
+        const T r = dist - m.con_margin;
+        const T imp = Impedance(m.con_d0, m.con_dmax, m.con_width, r);
+        const T num = (T(1) - imp) * (m.body_invw[b1] + m.body_invw[b2]);  // condim 1: tran1 + tran2
+        const T invR = num < kMinVal * imp ? T(1) / kMinVal : imp / num;
+        D = touch ? invR : T(0);
+        aref = touch ? -m.con_B * vel - m.con_K * imp * r : T(0);
+      }
+      lds(kPairSlot0 + k * kSlotsPerPair + 0) = nx;
+      lds(kPairSlot0 + k * kSlotsPerPair + 1) = nz;
+      lds(kPairSlot0 + k * kSlotsPerPair + 2) = cx;
+      lds(kPairSlot0 + k * kSlotsPerPair + 3) = cz;
+      lds(kPairSlot0 + k * kSlotsPerPair + 4) = aref;
+      lds(kPairSlot0 + k * kSlotsPerPair + 5) = D;
+    });
+  }
   return WaveUniform(ends);
+}
+
+// Jacobian entries of pair contact k: f(j, J_j) for the hinges between its two bodies
+template <int K, typename T, typename Lds, typename F>
+EPA_HD void ForPairCols(const CheetahPos<T>& p, Lds&& lds, F&& f) {
+  constexpr int b1 = PairBody1(K), b2 = PairBody2(K);
+  const T nx = lds(kPairSlot0 + K * kSlotsPerPair + 0), nz = lds(kPairSlot0 + K * kSlotsPerPair + 1);
+  const T cx = lds(kPairSlot0 + K * kSlotsPerPair + 2), cz = lds(kPairSlot0 + K * kSlotsPerPair + 3);
+  static_for<3, kNV>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (InChain(j, b2) && !InChain(j, b1)) {
+      constexpr int jb = DofBody(j);
+      f(jc, nx * (cz - p.pz[jb]) - nz * (cx - p.px[jb]));
+    }
+  });
 }
 
 // One pass over all constraint rows at acceleration `a`:
@@ -583,7 +704,7 @@ EPA_HD unsigned long long CheetahRowsPass(const CheetahModel<T>& m,
     mask |= (on ? 1ull : 0ull) << j;
   });
   EPA_NO_UNROLL
-  for (unsigned rem = ends; rem != 0; rem &= rem - 1) {  // scalar loop
+  for (unsigned rem = ends & 0xffffu; rem != 0; rem &= rem - 1) {  // scalar loop over end spheres
     const int e = __builtin_ctz(rem);
     const T D = lds(e * kSlotsPerEnd + 4);
     DispatchBody(EndBody(e), [&](auto bc) {  // wave-uniform switch
@@ -628,6 +749,31 @@ EPA_HD unsigned long long CheetahRowsPass(const CheetahModel<T>& m,
       }
     });
   }
+  if (m.n_pairs > 0) {  // frictionless body-body rows (bits 16.. of `ends`)
+    static_for<0, kNPair>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if ((ends >> (16 + k)) & 1u) {  // wave uniform
+        const T aref = lds(kPairSlot0 + k * kSlotsPerPair + 4);
+        const T D = lds(kPairSlot0 + k * kSlotsPerPair + 5);
+        T ja = T(0);
+        ForPairCols<k>(p, lds, [&](auto jc, T J) { ja += J * a[decltype(jc)::value]; });
+        const T jar = ja - aref;
+        const bool on = D > T(0) && jar < T(0);
+        const T w = on ? D : T(0);
+        mask |= (on ? 1ull : 0ull) << (54 + k);
+        ForPairCols<k>(p, lds, [&](auto ic, T Ji) {
+          constexpr int i = decltype(ic)::value;
+          grad[i] += Ji * w * jar;
+          if constexpr (kHess) {
+            ForPairCols<k>(p, lds, [&](auto jc2, T Jk) {
+              constexpr int kk = decltype(jc2)::value;
+              if constexpr (kk >= i) H[TriIdx(i, kk)] += w * Ji * Jk;
+            });
+          }
+        });
+      }
+    });
+  }
   return mask;
 }
 
@@ -646,7 +792,7 @@ EPA_HD void CheetahLineEval(const CheetahModel<T>& m, const CheetahPos<T>& p,
     *d2 += w * jv * jv;
   });
   EPA_NO_UNROLL
-  for (unsigned rem = ends; rem != 0; rem &= rem - 1) {  // scalar loop
+  for (unsigned rem = ends & 0xffffu; rem != 0; rem &= rem - 1) {  // scalar loop over end spheres
     const int e = __builtin_ctz(rem);
     const T D = lds(e * kSlotsPerEnd + 4);
     DispatchBody(EndBody(e), [&](auto bc) {  // wave-uniform switch
@@ -672,6 +818,24 @@ EPA_HD void CheetahLineEval(const CheetahModel<T>& m, const CheetahPos<T>& p,
       const T c3 = x3 < T(0) ? D : T(0);
       *d1 += c1 * x1 * jv1 + c2 * x2 * jv2 + c3 * x3 * jv3;
       *d2 += c1 * jv1 * jv1 + c2 * jv2 * jv2 + c3 * jv3 * jv3;
+    });
+  }
+  if (m.n_pairs > 0) {
+    static_for<0, kNPair>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if ((ends >> (16 + k)) & 1u) {
+        const T aref = lds(kPairSlot0 + k * kSlotsPerPair + 4);
+        const T D = lds(kPairSlot0 + k * kSlotsPerPair + 5);
+        T ja = T(0), js = T(0);
+        ForPairCols<k>(p, lds, [&](auto jc, T J) {
+          ja += J * a[decltype(jc)::value];
+          js += J * s[decltype(jc)::value];
+        });
+        const T x = ja - aref + alpha * js;
+        const T w = x < T(0) ? D : T(0);  // D == 0 on lanes without this contact
+        *d1 += w * x * js;
+        *d2 += w * js * js;
+      }
     });
   }
 }
@@ -860,7 +1024,7 @@ EPA_HD int PlanarStepRK4(const CheetahModel<T>& m, const SolverCfg<T>& cfg, T* q
 
 // Models sharing this kernel.  kSign[j] = -1 where the MJCF hinge rotates about
 // -y: the kernel integrates q' = sign * q (see BuildWalkerModel).
-enum PlanarModelId { kPlanarCheetah = 0, kPlanarWalker = 1, kPlanarWalkerV5 = 2 };
+enum PlanarModelId { kPlanarCheetah = 0, kPlanarWalker = 1, kPlanarWalkerV5 = 2, kPlanarHopper = 3 };
 EPA_HD constexpr int PlanarDofSign(int model, int j) {
   return (model != kPlanarCheetah && j >= 3) ? -1 : 1;
 }

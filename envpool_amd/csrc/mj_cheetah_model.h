@@ -261,6 +261,95 @@ inline CheetahModel<double> BuildWalkerModel(bool v5) {
   return m;
 }
 
+// ---- Hopper -----------------------------------------------------------------------
+// third_party/mujoco_gym_xml_patches/hopper_envpool.xml (hopper.h:38).  One leg:
+// the torso + thigh/leg/foot chain occupies bodies 0..3 of the planar tree; the
+// second leg (bodies 4..6) is a massless ghost with armature 1 on its hinges, so
+// its three dofs stay at rest and never couple (M rows = diag(1)).  Frames are
+// re-centred on the hinge anchors and the -y hinges mirrored like BuildWalkerModel.
+// Unlike the other planar models the geoms collide with each other (contype =
+// conaffinity = 1, condim 1, margin 0.001 :26): see kPairBody* in mj_cheetah.cuh.
+inline CheetahModel<double> BuildHopperModel() {
+  const double kPi = 3.14159265358979323846, deg = kPi / 180.0;  // angle="degree" :23
+  CheetahModel<double> m{};
+  // original body_pos / joint pos (x, z): torso :36 (rootz ref=1.25), thigh :42,
+  // leg :45-46, foot :48-49; ghost bodies at their parents' origins
+  const double bpx[kNB] = {0, 0, 0, 0.13, 0, 0, 0};
+  const double bpz[kNB] = {0, -0.19999999999999996, -0.70000000000000007, -0.35, 0, 0, 0};
+  const double jpx[kNB] = {0, 0, 0, -0.13, 0, 0, 0};
+  const double jpz[kNB] = {0, 0, 0.25, 0.1, 0, 0, 0};
+  for (int b = 0; b < kNB; ++b) {
+    const int par = Parent(b);
+    m.lx[b] = bpx[b] + jpx[b] - (par >= 0 ? jpx[par] : 0.0);
+    m.lz[b] = bpz[b] + jpz[b] - (par >= 0 ? jpz[par] : 0.0);
+  }
+  // capsules :41,:44,:47,:50: centre (original frame), rotation of the local z axis
+  // about +y (foot quat = -90 deg), radius, half length
+  const double gpx[4] = {0, 0, 0, -0.065}, gpz[4] = {0, -0.22500000000000009, 0, 0.1};
+  const double gang[4] = {0, 0, 0, -kPi / 2};
+  const double grad[4] = {0.05, 0.05, 0.04, 0.06};
+  const double ghalf[4] = {0.19999999999999996, 0.22500000000000003, 0.25, 0.195};
+  const double density = 1000.0;  // MuJoCo default
+  for (int e = 0; e < kNEnd; ++e) {
+    m.ex[e] = m.ez[e] = 0;
+    m.er[e] = -1e30;  // unused: torso ends 2, 3 and the whole ghost leg
+  }
+  for (int b = 0; b < 4; ++b) {
+    const double r = grad[b], h = 2 * ghalf[b];
+    const double vol = kPi * (r * r * h + 4.0 * r * r * r / 3.0);
+    const double gm = density * vol;
+    const double sphere_mass = gm * 4 * r / (4 * r + 3 * h), cyl_mass = gm - sphere_mass;
+    m.mass[b] = gm;
+    m.iyy[b] = cyl_mass * (3 * r * r + h * h) / 12 + 2 * sphere_mass * r * r / 5 +
+               sphere_mass * h * (3 * r + 2 * h) / 8;
+    m.cx[b] = gpx[b] - jpx[b];
+    m.cz[b] = gpz[b] - jpz[b];
+    const double ux = std::sin(gang[b]), uz = std::cos(gang[b]);
+    const int e0 = BodyEnd0(b);
+    m.ex[e0] = m.cx[b] + ghalf[b] * ux;
+    m.ez[e0] = m.cz[b] + ghalf[b] * uz;
+    m.ex[e0 + 1] = m.cx[b] - ghalf[b] * ux;
+    m.ez[e0 + 1] = m.cz[b] - ghalf[b] * uz;
+    m.er[e0] = m.er[e0 + 1] = r;
+    m.total_mass += gm;
+  }
+  // friction of the floor pair: max(floor 1 (MuJoCo default, :35), geom): .9 -> 1, foot 2.0 (:50)
+  for (int b = 0; b < kNB; ++b) m.bmu[b] = 1.0;
+  m.bmu[3] = 2.0;
+  // <joint armature="1" damping="1" limited="true"/> :25; ranges :43,:46,:49 mirrored for
+  // q' = -q; motors gear 200 (:57-59) negated.  Ghost hinges: armature only.
+  const double lo_deg[3] = {-150, -150, -45}, hi_deg[3] = {0, 0, 45};
+  for (int j = 0; j < kNU; ++j) {
+    const bool real = j < 3;
+    m.stiff[j] = 0;
+    m.damp[j] = real ? 1.0 : 0.0;
+    m.arm[j] = 1.0;
+    m.lo[j] = real ? -hi_deg[j] * deg : -1e30;
+    m.hi[j] = real ? -lo_deg[j] * deg : 1e30;
+    m.gear[j] = real ? -200.0 : 0.0;
+  }
+  m.timestep = 0.002;  // :29, integrator RK4
+  m.gravity = 9.81;
+  // contacts: solref ".02 1", solimp ".8 .8 .01" (:26, both geoms of every pair);
+  // limits: MuJoCo defaults solref .02 1, solimp .9 .95 .001
+  const double tc = std::fmax(0.02, 2 * m.timestep), dr = 1.0;
+  m.con_d0 = 0.8;
+  m.con_dmax = 0.8;
+  m.con_width = 0.01;
+  m.con_K = 1.0 / (0.8 * 0.8 * tc * tc * dr * dr);
+  m.con_B = 2.0 / (0.8 * tc);
+  m.lim_d0 = 0.9;
+  m.lim_dmax = 0.95;
+  m.lim_width = 0.001;
+  m.lim_K = 1.0 / (0.95 * 0.95 * tc * tc * dr * dr);
+  m.lim_B = 2.0 / (0.95 * tc);
+  m.con_margin = 0.001;  // margin="0.001" :26
+  m.n_pairs = kNPair;
+  const double q0[kNV] = {0, 1.25, 0, 0, 0, 0, 0, 0, 0};
+  PlanarSetConst(m, q0);
+  return m;
+}
+
 template <typename T>
 constexpr CheetahModel<T> CastCheetahModel(const CheetahModel<double>& d) {
   CheetahModel<T> m{};
@@ -301,6 +390,8 @@ constexpr CheetahModel<T> CastCheetahModel(const CheetahModel<double>& d) {
   m.lim_width = (T)d.lim_width;
   m.timestep = (T)d.timestep;
   m.gravity = (T)d.gravity;
+  m.con_margin = (T)d.con_margin;
+  m.n_pairs = d.n_pairs;
   return m;
 }
 

@@ -22,7 +22,7 @@
 #include "mj_cheetah.cuh"
 #include "mj_cheetah_model.h"
 #include "build/mj_cheetah_consts.inc"  // generated: kCheetahModelConst (gen_mj_consts.cpp)
-#include "build/mj_walker_consts.inc"   // generated: kWalkerModelConst, kWalkerV5ModelConst
+#include "build/mj_walker_consts.inc"   // generated: kWalkerModelConst, kWalkerV5ModelConst, kHopperModelConst
 
 namespace epa {
 namespace {
@@ -47,9 +47,9 @@ struct CheetahTask {
   int obs_skip;  // 1 if exclude_current_positions_from_observation
   double ctrl_cost_weight, forward_reward_weight, reset_noise_scale;
   double dt;     // frame_skip * timestep, computed in fp64 like the reference
-  // Walker2d only (walker2d.h:32-47)
+  // Walker2d (walker2d.h:32-47) and Hopper (hopper.h:32-49; healthy_z_max unused there)
   double healthy_reward, healthy_z_min, healthy_z_max, healthy_angle_min,
-      healthy_angle_max, velocity_min, velocity_max;
+      healthy_angle_max, velocity_min, velocity_max, healthy_state_min, healthy_state_max;
   int terminate_when_unhealthy, legacy_healthy_reward;
 };
 
@@ -60,6 +60,8 @@ constexpr CheetahModel<T> PlanarModel() {
     return mj::CastCheetahModel<T>(kCheetahModelConst);
   } else if constexpr (kModel == mj::kPlanarWalker) {
     return mj::CastCheetahModel<T>(kWalkerModelConst);
+  } else if constexpr (kModel == mj::kPlanarHopper) {
+    return mj::CastCheetahModel<T>(kHopperModelConst);
   } else {
     return mj::CastCheetahModel<T>(kWalkerV5ModelConst);
   }
@@ -73,7 +75,10 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
     OutPtrs out, CheetahTask task, mj::SolverCfg<T> scfg) {
   // the MuJoCo model as compile-time constants (see gen_mj_consts.cpp)
   constexpr CheetahModel<T> m = PlanarModel<T, kModel>();
-  constexpr bool kWalker = kModel != mj::kPlanarCheetah;
+  constexpr bool kWalker = kModel != mj::kPlanarCheetah;  // Walker2d or Hopper: RK4, mirrored hinges
+  constexpr bool kHopper = kModel == mj::kPlanarHopper;
+  // the Hopper model only owns dofs 0..5 / motors 0..2 of the tree (ghost second leg)
+  constexpr int kNVr = kHopper ? 6 : kNV, kNUr = kHopper ? 3 : kNU;
   // per-contact constants [slot][lane]; read back with a runtime slot index in the
   // solver passes (see DispatchBody) so they stay in LDS instead of VGPRs/scratch
   __shared__ T lds_buf[mj::kLdsSlots * kCheetahBlock];
@@ -97,13 +102,14 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
     Mt19937 g(cm, e);
     double saved = dev.nsaved[e];
     int avail = dev.navail[e];
-    for (int i = 0; i < kNV; ++i) {
-      // init_qpos = qpos0: all zero but the Walker2d rootz ref (walker2d_envpool.xml:36)
+    for (int i = kNVr; i < kNV; ++i) qpos[i] = qvel[i] = 0.0;  // ghost leg
+    for (int i = 0; i < kNVr; ++i) {
+      // init_qpos = qpos0: all zero but the rootz ref 1.25 (walker2d_envpool.xml:36, hopper :39)
       const double q0 = (kWalker && i == 1) ? 1.25 : 0.0;
       qpos[i] = q0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
     }
-    for (int i = 0; i < kNV; ++i) {
-      if constexpr (kWalker) {  // walker2d.h:119-126: uniform noise on qvel too
+    for (int i = 0; i < kNVr; ++i) {
+      if constexpr (kWalker) {  // walker2d.h:119-126, hopper.h:121-128: uniform noise on qvel too
         qvel[i] = 0.0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
       } else {
         qvel[i] = 0.0 + g.Normal(0.0, task.reset_noise_scale, &saved, &avail);
@@ -130,13 +136,17 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
     });
     const double x_before = qpos[0];
     q[0] = T(0);
-    const double* act = action + (size_t)row * kNU;
+    const double* act = action + (size_t)row * kNUr;
     mj::static_for<0, kNU>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      double ai = act[i];
-      ctrl_cost += task.ctrl_cost_weight * ai * ai;  // half_cheetah.h:143-146
-      // ctrllimited motors: MuJoCo clamps ctrl to ctrlrange [-1, 1]
-      ctrl[i] = (T)(ai < -1.0 ? -1.0 : (ai > 1.0 ? 1.0 : ai));
+      if constexpr (i < kNUr) {
+        double ai = act[i];
+        ctrl_cost += task.ctrl_cost_weight * ai * ai;  // half_cheetah.h:143-146
+        // ctrllimited motors: MuJoCo clamps ctrl to ctrlrange [-1, 1]
+        ctrl[i] = (T)(ai < -1.0 ? -1.0 : (ai > 1.0 ? 1.0 : ai));
+      } else {
+        ctrl[i] = T(0);
+      }
     });
     auto lds = [&](int slot) -> T& { return lds_buf[slot * kCheetahBlock + lane]; };
     int iters = 0;
@@ -160,10 +170,21 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
       dev.qvel[(size_t)i * n + e] = qvel[i];
       dev.warm[(size_t)i * n + e] = sg * (double)w[i];
     });
-    if constexpr (kWalker) {  // walker2d.h:162-177,181-190
-      const bool healthy = !(qpos[1] < task.healthy_z_min || qpos[1] > task.healthy_z_max ||
-                             qpos[2] < task.healthy_angle_min ||
-                             qpos[2] > task.healthy_angle_max);
+    if constexpr (kWalker) {  // walker2d.h:162-177,181-190 / hopper.h:170-203
+      bool healthy;
+      if constexpr (kHopper) {
+        healthy = !(qpos[2] <= task.healthy_angle_min || qpos[2] >= task.healthy_angle_max ||
+                    qpos[1] <= task.healthy_z_min);
+        for (int i = 2; i < kNVr; ++i) {
+          if (qpos[i] <= task.healthy_state_min || qpos[i] >= task.healthy_state_max) healthy = false;
+        }
+        for (int i = 0; i < kNVr; ++i) {
+          if (qvel[i] <= task.healthy_state_min || qvel[i] >= task.healthy_state_max) healthy = false;
+        }
+      } else {
+        healthy = !(qpos[1] < task.healthy_z_min || qpos[1] > task.healthy_z_max ||
+                    qpos[2] < task.healthy_angle_min || qpos[2] > task.healthy_angle_max);
+      }
       bool give = healthy;
       if (task.legacy_healthy_reward) give = task.terminate_when_unhealthy || healthy;
       const double healthy_reward = give ? task.healthy_reward : 0.0;
@@ -178,14 +199,14 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
   cm.done[e] = done ? 1 : 0;
   cm.cur_step[e] = cur;
   // WriteState, half_cheetah.h:158-185
-  const int nobs = 2 * kNV - task.obs_skip;
+  const int nobs = 2 * kNVr - task.obs_skip;
   const int S = task.frame_stack;
   double* obs0 = (double*)out.p[kKeyEnv0] + (size_t)row * nobs * S;
   double* newest = obs0 + (size_t)(S - 1) * nobs;
   {
     double* obs = newest;
-    for (int i = task.obs_skip; i < kNV; ++i) *(obs++) = qpos[i];
-    for (int i = 0; i < kNV; ++i) {
+    for (int i = task.obs_skip; i < kNVr; ++i) *(obs++) = qpos[i];
+    for (int i = 0; i < kNVr; ++i) {
       double x = qvel[i];
       if constexpr (kWalker) {  // walker2d.h:210-215
         x = x < task.velocity_max ? x : task.velocity_max;  // std::min(vmax, x)
@@ -225,19 +246,19 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
 
 // flat state, same layout as oracle/mjcpu: qpos[9] qvel[9] warm[9] time xlag
 // ylag done cur_step normal_saved normal_avail
-constexpr int kCheetahStateDim = 3 * kNV + 7;
+// `nv`: dofs of the model (9, Hopper: 6 -- its ghost dofs are not part of the state)
 __global__ void CheetahGetState(CheetahDev dev, CommonDev cm, const int* ids,
-                                int k, double* out) {
+                                int k, double* out, int nv) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;
   int e = ids[i], n = cm.n;
-  double* o = out + (size_t)i * kCheetahStateDim;
-  for (int j = 0; j < kNV; ++j) {
+  double* o = out + (size_t)i * (3 * nv + 7);
+  for (int j = 0; j < nv; ++j) {
     o[j] = dev.qpos[(size_t)j * n + e];
-    o[kNV + j] = dev.qvel[(size_t)j * n + e];
-    o[2 * kNV + j] = dev.warm[(size_t)j * n + e];
+    o[nv + j] = dev.qvel[(size_t)j * n + e];
+    o[2 * nv + j] = dev.warm[(size_t)j * n + e];
   }
-  double* t = o + 3 * kNV;
+  double* t = o + 3 * nv;
   t[0] = dev.iters[e];  // (oracle: time) Newton iterations of the last step
   t[1] = 0;
   t[2] = 0;
@@ -247,28 +268,33 @@ __global__ void CheetahGetState(CheetahDev dev, CommonDev cm, const int* ids,
   t[6] = dev.navail[e];
 }
 __global__ void CheetahSetState(CheetahDev dev, CommonDev cm, const int* ids,
-                                int k, const double* in) {
+                                int k, const double* in, int nv) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k) return;
   int e = ids[i], n = cm.n;
-  const double* o = in + (size_t)i * kCheetahStateDim;
-  for (int j = 0; j < kNV; ++j) {
+  const double* o = in + (size_t)i * (3 * nv + 7);
+  for (int j = 0; j < nv; ++j) {
     dev.qpos[(size_t)j * n + e] = o[j];
-    dev.qvel[(size_t)j * n + e] = o[kNV + j];
-    dev.warm[(size_t)j * n + e] = o[2 * kNV + j];
+    dev.qvel[(size_t)j * n + e] = o[nv + j];
+    dev.warm[(size_t)j * n + e] = o[2 * nv + j];
   }
-  const double* t = o + 3 * kNV;
+  for (int j = nv; j < kNV; ++j) {  // ghost dofs stay at rest
+    dev.qpos[(size_t)j * n + e] = 0.0;
+    dev.qvel[(size_t)j * n + e] = 0.0;
+    dev.warm[(size_t)j * n + e] = 0.0;
+  }
+  const double* t = o + 3 * nv;
   cm.done[e] = t[3] != 0.0;
   cm.cur_step[e] = (int)t[4];
   dev.nsaved[e] = t[5];
   dev.navail[e] = t[6] != 0.0;
 }
 
-std::vector<KeySpec> CheetahKeys(const Config& cfg, bool walker = false) {
+std::vector<KeySpec> CheetahKeys(const Config& cfg, bool walker = false, bool hopper = false) {
   int no_pos = cfg.Get("exclude_current_positions_from_observation", 1) != 0;
   int fs = (int)cfg.Get("frame_stack", 1);
-  // half_cheetah.h:44-62 (non-ENVPOOL_TEST build); StackSpec, frame_stack.h:42-71
-  std::vector<int> oshape = {no_pos ? 17 : 18};
+  // half_cheetah.h:44-62, hopper.h:51-63 (non-ENVPOOL_TEST build); StackSpec, frame_stack.h:42-71
+  std::vector<int> oshape = {(hopper ? 12 : 18) - (no_pos ? 1 : 0)};
   if (fs > 1) oshape.insert(oshape.begin(), fs);
   if (walker) {  // walker2d.h:49-62
     return {{"obs", EPA_F64, oshape},
@@ -284,13 +310,14 @@ std::vector<KeySpec> CheetahKeys(const Config& cfg, bool walker = false) {
 
 class CheetahPool : public Pool {
  public:
-  // model: mj::kPlanarCheetah / kPlanarWalker / kPlanarWalkerV5
+  // model: mj::kPlanarCheetah / kPlanarWalker / kPlanarWalkerV5 / kPlanarHopper
   CheetahPool(const Config& cfg, int model)
-      : Pool(cfg, CheetahKeys(cfg, model != mj::kPlanarCheetah),
-             KeySpec{"action", EPA_F64, {kNU}},
+      : Pool(cfg, CheetahKeys(cfg, model != mj::kPlanarCheetah, model == mj::kPlanarHopper),
+             KeySpec{"action", EPA_F64, {model == mj::kPlanarHopper ? 3 : kNU}},
              /*needs_rng=*/true),
         model_id_(model) {
-    const bool walker = model != mj::kPlanarCheetah;
+    const bool walker = model != mj::kPlanarCheetah;  // Walker2d or Hopper
+    const bool hopper = model == mj::kPlanarHopper;
     task_.frame_stack = (int)cfg.Get("frame_stack", 1);
     if (task_.frame_stack < 1) {
       throw std::invalid_argument("frame_stack must be greater than 0");
@@ -308,10 +335,12 @@ class CheetahPool : public Pool {
     task_.dt = task_.frame_skip * (walker ? kWalkerModelConst.timestep
                                           : kCheetahModelConst.timestep);
     task_.healthy_reward = cfg.Get("healthy_reward", 1.0);
-    task_.healthy_z_min = cfg.Get("healthy_z_min", 0.8);
+    task_.healthy_z_min = cfg.Get("healthy_z_min", hopper ? 0.7 : 0.8);
     task_.healthy_z_max = cfg.Get("healthy_z_max", 2.0);
-    task_.healthy_angle_min = cfg.Get("healthy_angle_min", -1.0);
-    task_.healthy_angle_max = cfg.Get("healthy_angle_max", 1.0);
+    task_.healthy_angle_min = cfg.Get("healthy_angle_min", hopper ? -0.2 : -1.0);
+    task_.healthy_angle_max = cfg.Get("healthy_angle_max", hopper ? 0.2 : 1.0);
+    task_.healthy_state_min = cfg.Get("healthy_state_min", -100.0);
+    task_.healthy_state_max = cfg.Get("healthy_state_max", 100.0);
     task_.velocity_min = cfg.Get("velocity_min", -10.0);
     task_.velocity_max = cfg.Get("velocity_max", 10.0);
     task_.terminate_when_unhealthy = cfg.Get("terminate_when_unhealthy", 1) != 0;
@@ -345,14 +374,15 @@ class CheetahPool : public Pool {
     (void)hipFree(dev_.iters);
     if (dev_.stack) (void)hipFree(dev_.stack);
   }
-  int StateDim() const override { return kCheetahStateDim; }
+  int ModelNv() const { return model_id_ == mj::kPlanarHopper ? 6 : kNV; }
+  int StateDim() const override { return 3 * ModelNv() + 7; }
   void GetState(const int* d_ids, int k, double* d_out) override {
     hipLaunchKernelGGL(CheetahGetState, dim3((k + 255) / 256), dim3(256), 0,
-                       stream_, dev_, common_, d_ids, k, d_out);
+                       stream_, dev_, common_, d_ids, k, d_out, ModelNv());
   }
   void SetState(const int* d_ids, int k, const double* d_in) override {
     hipLaunchKernelGGL(CheetahSetState, dim3((k + 255) / 256), dim3(256), 0,
-                       stream_, dev_, common_, d_ids, k, d_in);
+                       stream_, dev_, common_, d_ids, k, d_in, ModelNv());
   }
 
  protected:
@@ -373,7 +403,9 @@ class CheetahPool : public Pool {
       case 3: EPA_LAUNCH_PLANAR(double, mj::kPlanarWalker, sd); break;
       case 2: EPA_LAUNCH_PLANAR(float, mj::kPlanarWalker, sf); break;
       case 5: EPA_LAUNCH_PLANAR(double, mj::kPlanarWalkerV5, sd); break;
-      default: EPA_LAUNCH_PLANAR(float, mj::kPlanarWalkerV5, sf); break;
+      case 4: EPA_LAUNCH_PLANAR(float, mj::kPlanarWalkerV5, sf); break;
+      case 7: EPA_LAUNCH_PLANAR(double, mj::kPlanarHopper, sd); break;
+      default: EPA_LAUNCH_PLANAR(float, mj::kPlanarHopper, sf); break;
     }
 #undef EPA_LAUNCH_PLANAR
   }
@@ -396,9 +428,9 @@ Pool* MakePendulum(const std::string& family, const Config& cfg);
 
 bool DescribeMujoco(const std::string& family, const Config& cfg,
                     std::vector<KeySpec>* state, KeySpec* action) {
-  if (family == "HalfCheetah" || family == "Walker2d") {
-    *state = CheetahKeys(cfg, family == "Walker2d");
-    *action = KeySpec{"action", EPA_F64, {kNU}};
+  if (family == "HalfCheetah" || family == "Walker2d" || family == "Hopper") {
+    *state = CheetahKeys(cfg, family != "HalfCheetah", family == "Hopper");
+    *action = KeySpec{"action", EPA_F64, {family == "Hopper" ? 3 : kNU}};
     return true;
   }
   if (DescribePendulum(family, cfg, state, action)) return true;
@@ -407,6 +439,7 @@ bool DescribeMujoco(const std::string& family, const Config& cfg,
 
 Pool* MakeMujoco(const std::string& family, const Config& cfg) {
   if (family == "HalfCheetah") return new CheetahPool(cfg, mj::kPlanarCheetah);
+  if (family == "Hopper") return new CheetahPool(cfg, mj::kPlanarHopper);
   if (family == "Walker2d") {
     // "xml_v5" = 1: walker2d_v5.xml (gym/registration.py:79-83)
     return new CheetahPool(cfg, cfg.Get("xml_v5", 0) != 0 ? mj::kPlanarWalkerV5

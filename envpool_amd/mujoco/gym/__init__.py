@@ -4,7 +4,7 @@ Spec tables restate `HalfCheetahEnvFns` (half_cheetah.h:31-62), `AntEnvFns`
 (ant.h:31-75; v3/v5 add 6 contact-force numbers per body) and `Walker2dEnvFns`
 (walker2d.h:30-67), `InvertedPendulumEnvFns` (inverted_pendulum.h:30-60) and
 `InvertedDoublePendulumEnvFns` (inverted_double_pendulum.h:30-62) and
-`ReacherEnvFns` (reacher.h:30-65), `SwimmerEnvFns` (swimmer.h:30-66); the pixel
+`ReacherEnvFns` (reacher.h:30-65), `SwimmerEnvFns` (swimmer.h:30-66), `HopperEnvFns` (hopper.h:30-70); the pixel
 variants are out of scope.  `precision` is an extension key: 64 (default, the
 reference's mjtNum=double) or 32 (fp32 arithmetic, fp64 state and I/O).
 """
@@ -287,7 +287,54 @@ _Swimmer = FamilyDef(
     unsupported={"xml_file": "swimmer.xml", "frame_stack": 1},
 )
 
+_Hopper = FamilyDef(
+    name="GymHopper", native="Hopper",
+    # hopper.h:32-49
+    default_config=[
+        ("reward_threshold", 6000.0), ("frame_skip", 4), ("frame_stack", 1),
+        ("post_constraint", True), ("terminate_when_unhealthy", True),
+        ("legacy_healthy_reward", True),
+        ("exclude_current_positions_from_observation", True),
+        ("xml_file", "hopper.xml"), ("gymnasium_v5_render_camera", False),
+        ("ctrl_cost_weight", 1e-3), ("forward_reward_weight", 1.0),
+        ("healthy_reward", 1.0), ("velocity_min", -10.0), ("velocity_max", 10.0),
+        ("healthy_state_min", -100.0), ("healthy_state_max", 100.0),
+        ("healthy_angle_min", -0.2), ("healthy_angle_max", 0.2),
+        ("healthy_z_min", 0.7), ("reset_noise_scale", 5e-3), ("precision", 64),
+    ],
+    state_spec=lambda c: [
+        ("obs", spec(np.float64,
+                     _stack([11 if c["exclude_current_positions_from_observation"] else 12], c),
+                     (-_inf, _inf))),
+        ("info:x_position", spec(np.float64, [-1])),
+        ("info:x_velocity", spec(np.float64, [-1])),
+    ],
+    action_spec=lambda c: [("action", spec(np.float64, [-1, 3], (-1.0, 1.0)))],
+    native_params=lambda c: {
+        "frame_skip": c["frame_skip"], "frame_stack": c["frame_stack"],
+        "exclude_current_positions_from_observation":
+            c["exclude_current_positions_from_observation"],
+        "terminate_when_unhealthy": c["terminate_when_unhealthy"],
+        "legacy_healthy_reward": c["legacy_healthy_reward"],
+        "ctrl_cost_weight": c["ctrl_cost_weight"],
+        "forward_reward_weight": c["forward_reward_weight"],
+        "healthy_reward": c["healthy_reward"],
+        "velocity_min": c["velocity_min"], "velocity_max": c["velocity_max"],
+        "healthy_state_min": c["healthy_state_min"],
+        "healthy_state_max": c["healthy_state_max"],
+        "healthy_angle_min": c["healthy_angle_min"],
+        "healthy_angle_max": c["healthy_angle_max"],
+        "healthy_z_min": c["healthy_z_min"],
+        "reset_noise_scale": c["reset_noise_scale"],
+        "precision": _precision(c),
+    },
+    unsupported={"xml_file": "hopper.xml"},
+)
+
 _GymHalfCheetahEnvSpec, _GymHalfCheetahEnvPool = make_native_classes(_HalfCheetah)
+_GymHopperEnvSpec, _GymHopperEnvPool = make_native_classes(_Hopper)
+(GymHopperEnvSpec, GymHopperDMEnvPool,
+ GymHopperGymnasiumEnvPool) = py_env(_GymHopperEnvSpec, _GymHopperEnvPool)
 _GymSwimmerEnvSpec, _GymSwimmerEnvPool = make_native_classes(_Swimmer)
 (GymSwimmerEnvSpec, GymSwimmerDMEnvPool,
  GymSwimmerGymnasiumEnvPool) = py_env(_GymSwimmerEnvSpec, _GymSwimmerEnvPool)
@@ -319,4 +366,5 @@ __all__ = ["GymHalfCheetahEnvSpec", "GymHalfCheetahDMEnvPool",
            "GymInvertedDoublePendulumEnvSpec", "GymInvertedDoublePendulumDMEnvPool",
            "GymInvertedDoublePendulumGymnasiumEnvPool", "GymReacherEnvSpec",
            "GymReacherDMEnvPool", "GymReacherGymnasiumEnvPool", "GymSwimmerEnvSpec",
-           "GymSwimmerDMEnvPool", "GymSwimmerGymnasiumEnvPool"]
+           "GymSwimmerDMEnvPool", "GymSwimmerGymnasiumEnvPool", "GymHopperEnvSpec",
+           "GymHopperDMEnvPool", "GymHopperGymnasiumEnvPool"]

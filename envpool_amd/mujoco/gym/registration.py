@@ -4,6 +4,7 @@ from envpool_amd.registration import register
 gym_mujoco_envs = [
     ("Ant", ("v3", "v4", "v5"), 1000),
     ("HalfCheetah", ("v3", "v4", "v5"), 1000),
+    ("Hopper", ("v3", "v4", "v5"), 1000),
     ("InvertedDoublePendulum", ("v2", "v4", "v5"), 1000),
     ("InvertedPendulum", ("v2", "v4", "v5"), 1000),
     ("Reacher", ("v2", "v4", "v5"), 50),
@@ -24,6 +25,8 @@ for task, versions, max_episode_steps in gym_mujoco_envs:
                 "legacy_healthy_reward": False,
                 "exclude_worldbody_contact_forces": True,
             })
+        if task == "Hopper" and version == "v5":  # gym/registration.py:47-48
+            extra_args["legacy_healthy_reward"] = False
         if task == "InvertedDoublePendulum" and version == "v5":  # gym/registration.py:61-65
             extra_args.update({
                 "constraint_obs_dim": 1,

@@ -225,7 +225,7 @@ void mjc_jac(const mjc_model* m, const mjc_data* d, double jacp[3][MJC_MAXV],
   }
 }
 
-/* ---- M3: mj_collision (plane-sphere, plane-capsule) ----------------------------- */
+/* ---- M3: mj_collision (plane-sphere, plane-capsule, capsule-capsule) -------------- */
 static void make_frame(double* frame) { /* mju_makeFrame */
   double* x = frame;
   double* y = frame + 3;
@@ -240,6 +240,105 @@ static void make_frame(double* frame) { /* mju_makeFrame */
   v3_addscl(y, x, -t);
   v3_normalize(y);
   v3_cross(frame + 6, x, y);
+}
+
+/* mj_contactParam for a geom pair: condim max, friction max, solref / solimp
+ * mixed with solmix 1:1 */
+static void contact_params(const mjc_model* m, mjc_contact* c, int g1, int g2, double margin) {
+  c->geom1 = g1;
+  c->geom2 = g2;
+  c->includemargin = margin;
+  c->dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+  c->friction = fmax(m->geom_friction[g1][0], m->geom_friction[g2][0]);
+  for (int i = 0; i < 2; ++i) {
+    c->solref[i] = 0.5 * (m->geom_solref[g1][i] + m->geom_solref[g2][i]);
+  }
+  for (int i = 0; i < 5; ++i) {
+    c->solimp[i] = 0.5 * (m->geom_solimp[g1][i] + m->geom_solimp[g2][i]);
+  }
+}
+
+/* mjraw_SphereSphere on two points of the capsule axes */
+static void add_sphere_sphere(const mjc_model* m, mjc_data* d, int g1, int g2, const double* p1,
+                              double r1, const double* p2, double r2, double margin) {
+  double dif[3];
+  v3_sub(dif, p2, p1);
+  double cdist = v3_norm(dif);
+  if (cdist > margin + r1 + r2) return;
+  if (d->ncon >= MJC_MAXCON) return;
+  mjc_contact* c = &d->contact[d->ncon++];
+  c->dist = cdist - r1 - r2;
+  if (cdist < 1e-15) { /* coincident centres: MuJoCo picks +x */
+    c->frame[0] = 1;
+    c->frame[1] = c->frame[2] = 0;
+  } else {
+    for (int k = 0; k < 3; ++k) c->frame[k] = dif[k] / cdist;
+  }
+  for (int k = 0; k < 3; ++k) c->pos[k] = p1[k] + c->frame[k] * (r1 + 0.5 * c->dist);
+  make_frame(c->frame);
+  contact_params(m, c, g1, g2, margin);
+}
+
+/* mjraw_CapsuleCapsule: closest points of the two axis segments, then sphere-sphere.
+ * Exactly parallel axes (|det| < mjMINVAL) make MuJoCo emit up to two contacts from the
+ * end-point projections; here the overlap midpoint is used (one contact) -- a
+ * measure-zero configuration for the hopper, flagged in DESIGN.md. */
+static void add_capsule_capsule(const mjc_model* m, mjc_data* d, int g1, int g2, double margin) {
+  const double *m1 = d->geom_xmat[g1], *m2 = d->geom_xmat[g2];
+  double h1 = m->geom_size[g1][1], h2 = m->geom_size[g2][1];
+  double a1[3] = {m1[2] * h1, m1[5] * h1, m1[8] * h1}; /* axes scaled by the half lengths */
+  double a2[3] = {m2[2] * h2, m2[5] * h2, m2[8] * h2};
+  double dif[3];
+  v3_sub(dif, d->geom_xpos[g1], d->geom_xpos[g2]);
+  double ma = v3_dot(a1, a1), mb = -v3_dot(a1, a2), mc = v3_dot(a2, a2);
+  double u = -v3_dot(a1, dif), v = v3_dot(a2, dif);
+  double det = ma * mc - mb * mb;
+  double x1, x2;
+  if (fabs(det) >= MINVAL) {
+    x1 = (mc * u - mb * v) / det;
+    x2 = (ma * v - mb * u) / det;
+    if (x1 > 1) {
+      x1 = 1;
+      x2 = (v - mb) / mc;
+    } else if (x1 < -1) {
+      x1 = -1;
+      x2 = (v + mb) / mc;
+    }
+    if (x2 > 1) {
+      x2 = 1;
+      x1 = (u - mb) / ma;
+      x1 = x1 > 1 ? 1 : (x1 < -1 ? -1 : x1);
+    } else if (x2 < -1) {
+      x2 = -1;
+      x1 = (u + mb) / ma;
+      x1 = x1 > 1 ? 1 : (x1 < -1 ? -1 : x1);
+    }
+  } else { /* parallel: midpoint of the overlap of segment 2 projected on axis 1 */
+    double lo = fmax(-1.0, (-v3_dot(a1, dif) - fabs(mb)) / ma);
+    double hi = fmin(1.0, (-v3_dot(a1, dif) + fabs(mb)) / ma);
+    x1 = lo <= hi ? 0.5 * (lo + hi) : (lo > 1 ? 1 : -1);
+    x2 = (v - mb * x1) / mc;
+    x2 = x2 > 1 ? 1 : (x2 < -1 ? -1 : x2);
+  }
+  double p1[3], p2[3];
+  for (int k = 0; k < 3; ++k) {
+    p1[k] = d->geom_xpos[g1][k] + a1[k] * x1;
+    p2[k] = d->geom_xpos[g2][k] + a2[k] * x2;
+  }
+  add_sphere_sphere(m, d, g1, g2, p1, m->geom_size[g1][0], p2, m->geom_size[g2][0], margin);
+}
+
+static int geoms_can_collide(const mjc_model* m, int g1, int g2) {
+  int b1 = m->geom_body[g1], b2 = m->geom_body[g2];
+  if (b1 == b2) return 0;
+  if (!((m->geom_contype[g1] & m->geom_conaffinity[g2]) ||
+        (m->geom_contype[g2] & m->geom_conaffinity[g1]))) {
+    return 0;
+  }
+  /* filterparent: no collisions between a body and its parent, unless the parent is
+   * the (static) world body */
+  if (b1 != 0 && b2 != 0 && (m->body_parent[b1] == b2 || m->body_parent[b2] == b1)) return 0;
+  return 1;
 }
 
 static void add_plane_sphere(const mjc_model* m, mjc_data* d, int g1, int g2,
@@ -257,17 +356,7 @@ static void add_plane_sphere(const mjc_model* m, mjc_data* d, int g1, int g2,
   v3_addscl(c->pos, normal, -c->dist / 2 - radius);
   v3_copy(c->frame, normal);
   make_frame(c->frame);
-  c->geom1 = g1;
-  c->geom2 = g2;
-  c->includemargin = margin;
-  /* mj_contactParam: friction max, solref/solimp mixed with solmix 1:1 */
-  c->friction = fmax(m->geom_friction[g1][0], m->geom_friction[g2][0]);
-  for (int i = 0; i < 2; ++i) {
-    c->solref[i] = 0.5 * (m->geom_solref[g1][i] + m->geom_solref[g2][i]);
-  }
-  for (int i = 0; i < 5; ++i) {
-    c->solimp[i] = 0.5 * (m->geom_solimp[g1][i] + m->geom_solimp[g2][i]);
-  }
+  contact_params(m, c, g1, g2, margin);
 }
 
 static void collision(const mjc_model* m, mjc_data* d) {
@@ -277,10 +366,7 @@ static void collision(const mjc_model* m, mjc_data* d) {
     if (m->geom_type[g1] != MJC_GEOM_PLANE) continue;
     for (int g2 = 0; g2 < m->ngeom; ++g2) {
       if (g2 == g1 || m->geom_type[g2] == MJC_GEOM_PLANE) continue;
-      if (m->geom_body[g1] == m->geom_body[g2]) continue;
-      int ok = (m->geom_contype[g1] & m->geom_conaffinity[g2]) ||
-               (m->geom_contype[g2] & m->geom_conaffinity[g1]);
-      if (!ok) continue;
+      if (!geoms_can_collide(m, g1, g2)) continue;
       double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
       if (m->geom_type[g2] == MJC_GEOM_SPHERE) {
         add_plane_sphere(m, d, g1, g2, d->geom_xpos[g2], m->geom_size[g2][0],
@@ -296,6 +382,14 @@ static void collision(const mjc_model* m, mjc_data* d) {
         v3_addscl(p, axis, -hl);
         add_plane_sphere(m, d, g1, g2, p, m->geom_size[g2][0], margin);
       }
+    }
+  }
+  /* body-body pairs: capsule-capsule only (the hopper's self collisions) */
+  for (int g1 = 0; g1 < m->ngeom && !m->disable_selfcollide; ++g1) {
+    if (m->geom_type[g1] != MJC_GEOM_CAPSULE) continue;
+    for (int g2 = g1 + 1; g2 < m->ngeom; ++g2) {
+      if (m->geom_type[g2] != MJC_GEOM_CAPSULE || !geoms_can_collide(m, g1, g2)) continue;
+      add_capsule_capsule(m, d, g1, g2, fmax(m->geom_margin[g1], m->geom_margin[g2]));
     }
   }
 }
@@ -408,6 +502,10 @@ static void make_constraint(const mjc_model* m, mjc_data* d) {
       }
     }
     double tran = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
+    if (con->dim == 1) { /* frictionless: the normal row alone, diagApprox = tran */
+      add_row(m, d, Jc[0], con->dist, con->includemargin, tran, con->solref, con->solimp);
+      continue;
+    }
     double mu = con->friction;
     double diag = tran + mu * mu * tran; /* mj_diagApprox, pyramidal */
     int first = d->nefc;
@@ -820,8 +918,12 @@ void mjc_rne_post_constraint(const mjc_model* m, mjc_data* d) {
     const mjc_contact* con = &d->contact[c];
     if (con->efc_address < 0) continue;
     const double* f = d->efc_force + con->efc_address;
-    double lf[3] = {f[0] + f[1] + f[2] + f[3], (f[0] - f[1]) * con->friction,
-                    (f[2] - f[3]) * con->friction};
+    double lf[3] = {f[0], 0, 0};
+    if (con->dim != 1) {
+      lf[0] = f[0] + f[1] + f[2] + f[3];
+      lf[1] = (f[0] - f[1]) * con->friction;
+      lf[2] = (f[2] - f[3]) * con->friction;
+    }
     double F[3]; /* world frame: frame^T lf (frame rows: normal, t1, t2) */
     for (int k = 0; k < 3; ++k) {
       F[k] = con->frame[k] * lf[0] + con->frame[3 + k] * lf[1] + con->frame[6 + k] * lf[2];

@@ -48,6 +48,7 @@ typedef struct {
   double opt_density, opt_viscosity; /* <option density viscosity>: medium for the fluid forces */
   int integrator;
   int disable_contact, disable_limit, disable_actuation; /* invariant tests */
+  int disable_selfcollide; /* tests: drop body-body (capsule-capsule) pairs */
   /* bodies */
   int body_parent[MJC_MAXBODY], body_rootid[MJC_MAXBODY];
   int body_jntadr[MJC_MAXBODY], body_jntnum[MJC_MAXBODY];
@@ -91,7 +92,8 @@ typedef struct {
   int geom1, geom2;
   double friction, includemargin;
   double solref[2], solimp[5];
-  int efc_address; /* first of its 4 pyramid rows, -1 if outside the margin */
+  int dim;         /* condim: 1 frictionless (1 row), 3 pyramidal (4 rows) */
+  int efc_address; /* first of its rows, -1 if outside the margin */
 } mjc_contact;
 
 typedef struct {
@@ -149,6 +151,7 @@ void mjc_build_inverted_pendulum(mjc_model* m);
 void mjc_build_inverted_double_pendulum(mjc_model* m);
 void mjc_build_reacher(mjc_model* m);
 void mjc_build_swimmer(mjc_model* m);
+void mjc_build_hopper(mjc_model* m);
 
 /* engine.c */
 void mjc_reset_data(const mjc_model* m, mjc_data* d);

@@ -7,7 +7,8 @@
  *   third_party/mujoco_gym_xml_patches/walker2d_envpool.xml (v3/v4),
  *   walker2d_v5_envpool.xml (v5: right foot friction 1.9 instead of 0.9, :47)
  *   third_party/mujoco_gym_xml_patches/inverted_pendulum_envpool.xml,
- *   inverted_double_pendulum_envpool.xml, reacher_envpool.xml, swimmer_envpool.xml
+ *   inverted_double_pendulum_envpool.xml, reacher_envpool.xml, swimmer_envpool.xml,
+ *   hopper_envpool.xml
  * Numbers are cited by XML line (":NN").
  */
 #include <math.h>
@@ -474,5 +475,79 @@ void mjc_build_swimmer(mjc_model* m) {
   int j2 = mjc_add_joint(m, back, MJC_JNT_HINGE, kZero3, zaxis, 1, -100 * deg, 100 * deg, 0, 0, 0.1);
   mjc_add_motor(m, j1, 150); /* :50-51 */
   mjc_add_motor(m, j2, 150);
+  mjc_compile(m);
+}
+
+/* ---- Hopper --------------------------------------------------------------------------- */
+static int hopper_geom(mjc_model* m, int g, double friction) {
+  /* <geom conaffinity="1" condim="1" contype="1" margin="0.001" solimp=".8 .8 .01"
+   *  solref=".02 1"/> :26; body geoms set friction[0] only (the rest stays at
+   *  MuJoCo's 0.005 0.0001) */
+  m->geom_conaffinity[g] = 1;
+  m->geom_contype[g] = 1;
+  m->geom_condim[g] = 1;
+  m->geom_margin[g] = 0.001;
+  m->geom_solimp[g][0] = 0.8;
+  m->geom_solimp[g][1] = 0.8;
+  m->geom_solimp[g][2] = 0.01;
+  m->geom_solref[g][0] = 0.02;
+  m->geom_solref[g][1] = 1;
+  m->geom_friction[g][0] = friction;
+  return g;
+}
+
+void mjc_build_hopper(mjc_model* m) {
+  const double deg = 3.14159265358979323846 / 180.0; /* angle="degree" :23 */
+  const double yaxis[3] = {0, 1, 0}, xaxis[3] = {1, 0, 0}, zaxis[3] = {0, 0, 1};
+  const double naxis[3] = {0, -1, 0};
+  const double quat_id[4] = {1, 0, 0, 0};
+  mjc_model_init(m);
+  m->timestep = 0.002;         /* :29 */
+  m->integrator = MJC_INT_RK4; /* :29 */
+  m->gravity[2] = -9.81;
+  { /* floor :35: class defaults + condim 3, friction MuJoCo default 1 */
+    const double size[3] = {20, 20, 0.125};
+    int g = hopper_geom(m, mjc_add_geom(m, 0, MJC_GEOM_PLANE, size, kZero3, quat_id), 1.0);
+    m->geom_condim[g] = 3;
+  }
+  /* <joint armature="1" damping="1" limited="true"/> :25 */
+  const double torso_pos[3] = {0, 0, 1.25};
+  int torso = mjc_add_body(m, 0, torso_pos); /* :36 */
+  const double root_pos[3] = {0, 0, -1.25};
+  mjc_add_joint(m, torso, MJC_JNT_SLIDE, root_pos, xaxis, 0, 0, 0, 0, 0, 0); /* :38 */
+  int rootz = mjc_add_joint(m, torso, MJC_JNT_SLIDE, root_pos, zaxis, 0, 0, 0, 0, 0, 0);
+  m->jnt_ref[rootz] = 1.25; /* :39 */
+  mjc_add_joint(m, torso, MJC_JNT_HINGE, kZero3, yaxis, 0, 0, 0, 0, 0, 0); /* :40 */
+  {
+    const double size[3] = {0.05, 0.19999999999999996, 0}; /* :41 */
+    hopper_geom(m, mjc_add_geom(m, torso, MJC_GEOM_CAPSULE, size, kZero3, quat_id), 0.9);
+  }
+  const double thigh_pos[3] = {0, 0, -0.19999999999999996};
+  int thigh = mjc_add_body(m, torso, thigh_pos); /* :42 */
+  int j_thigh = mjc_add_joint(m, thigh, MJC_JNT_HINGE, kZero3, naxis, 1, -150 * deg, 0, 0, 1, 1);
+  {
+    const double size[3] = {0.05, 0.22500000000000003, 0}, pos[3] = {0, 0, -0.22500000000000009};
+    hopper_geom(m, mjc_add_geom(m, thigh, MJC_GEOM_CAPSULE, size, pos, quat_id), 0.9); /* :44 */
+  }
+  const double leg_pos[3] = {0, 0, -0.70000000000000007};
+  int leg = mjc_add_body(m, thigh, leg_pos); /* :45 */
+  const double leg_jpos[3] = {0, 0, 0.25};
+  int j_leg = mjc_add_joint(m, leg, MJC_JNT_HINGE, leg_jpos, naxis, 1, -150 * deg, 0, 0, 1, 1);
+  {
+    const double size[3] = {0.04, 0.25, 0};
+    hopper_geom(m, mjc_add_geom(m, leg, MJC_GEOM_CAPSULE, size, kZero3, quat_id), 0.9); /* :47 */
+  }
+  const double foot_pos[3] = {0.13, 0, -0.35};
+  int foot = mjc_add_body(m, leg, foot_pos); /* :48 */
+  const double foot_jpos[3] = {-0.13, 0, 0.1};
+  int j_foot = mjc_add_joint(m, foot, MJC_JNT_HINGE, foot_jpos, naxis, 1, -45 * deg, 45 * deg, 0, 1, 1);
+  {
+    const double size[3] = {0.06, 0.195, 0}, pos[3] = {-0.065, 0, 0.1};
+    const double quat[4] = {0.70710678118654757, 0, -0.70710678118654746, 0};
+    hopper_geom(m, mjc_add_geom(m, foot, MJC_GEOM_CAPSULE, size, pos, quat), 2.0); /* :50 */
+  }
+  mjc_add_motor(m, j_thigh, 200); /* :56-58 */
+  mjc_add_motor(m, j_leg, 200);
+  mjc_add_motor(m, j_foot, 200);
   mjc_compile(m);
 }

@@ -32,7 +32,7 @@ typedef struct {
   int current_step, done, elapsed_step;
 } mj_env;
 
-enum { TASK_CHEETAH = 0, TASK_ANT = 1, TASK_WALKER = 2, TASK_IPEND = 3, TASK_IDPEND = 4, TASK_REACHER = 5, TASK_SWIMMER = 6 };
+enum { TASK_CHEETAH = 0, TASK_ANT = 1, TASK_WALKER = 2, TASK_IPEND = 3, TASK_IDPEND = 4, TASK_REACHER = 5, TASK_SWIMMER = 6, TASK_HOPPER = 7 };
 
 typedef struct {
   int is_ant;
@@ -88,6 +88,8 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
     kind = TASK_REACHER;
   } else if (strcmp(task, "Swimmer") == 0) {
     kind = TASK_SWIMMER;
+  } else if (strcmp(task, "Hopper") == 0) {
+    kind = TASK_HOPPER;
   } else {
     return NULL;
   }
@@ -108,6 +110,8 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
     mjc_build_reacher(&p->m);
   } else if (kind == TASK_SWIMMER) {
     mjc_build_swimmer(&p->m);
+  } else if (kind == TASK_HOPPER) {
+    mjc_build_hopper(&p->m);
   } else {
     mjc_build_half_cheetah(&p->m);
   }
@@ -115,12 +119,16 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   p->max_episode_steps = max_episode_steps > 0 ? max_episode_steps : INT_MAX;
   const int pend = kind == TASK_IPEND || kind == TASK_IDPEND;
   const int reacher = kind == TASK_REACHER, swimmer = kind == TASK_SWIMMER;
+  const int hopper = kind == TASK_HOPPER;
   p->frame_skip = (int)extra_or(
-      extra, n_extra, 0, (walker || swimmer) ? 4 : ((kind == TASK_IPEND || reacher) ? 2 : 5));
+      extra, n_extra, 0,
+      (walker || swimmer || hopper) ? 4 : ((kind == TASK_IPEND || reacher) ? 2 : 5));
   /* half_cheetah.h:33-43 / ant.h:33-50 / walker2d.h:32-47 defaults */
   p->ctrl_cost_weight =
       extra_or(extra, n_extra, 1,
-               is_ant ? 0.5 : (walker ? 0.001 : (reacher ? 1.0 : (swimmer ? 1e-4 : 0.1))));
+               is_ant ? 0.5
+               : (walker || hopper) ? 0.001
+                                    : (reacher ? 1.0 : (swimmer ? 1e-4 : 0.1)));
   p->reward_after_step = extra_or(extra, n_extra, 16, 0) != 0; /* Reacher-v5 */
   p->obs_include_z = extra_or(extra, n_extra, 17, 1) != 0;
   p->dist_cost_weight = 1.0;
@@ -130,7 +138,7 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   p->forward_reward_weight = extra_or(extra, n_extra, 2, 1.0);
   /* inverted_pendulum.h:32-41 (noise 0.01), inverted_double_pendulum.h:32-44 (0.1) */
   p->reset_noise_scale =
-      extra_or(extra, n_extra, 3, walker ? 0.005 : (kind == TASK_IPEND ? 0.01 : 0.1));
+      extra_or(extra, n_extra, 3, (walker || hopper) ? 0.005 : (kind == TASK_IPEND ? 0.01 : 0.1));
   p->reward_if_not_terminated = extra_or(extra, n_extra, 10, 0) != 0;
   p->constraint_obs_dim = (int)extra_or(extra, n_extra, 11, 3);
   p->observation_min = -10.0;
@@ -144,6 +152,7 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   p->m.disable_contact = extra_or(extra, n_extra, 4, 0) != 0;
   p->m.disable_limit = extra_or(extra, n_extra, 5, 0) != 0;
   p->m.disable_actuation = extra_or(extra, n_extra, 6, 0) != 0;
+  p->m.disable_selfcollide = extra_or(extra, n_extra, 18, 0) != 0;
   if (extra_or(extra, n_extra, 7, 0) != 0) { /* invariant tests: no passive */
     for (int i = 0; i < p->m.nv; ++i) p->m.dof_damping[i] = 0;
     for (int j = 0; j < p->m.njnt; ++j) p->m.jnt_stiffness[j] = 0;
@@ -151,10 +160,10 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   if (extra_or(extra, n_extra, 8, -1) >= 0) p->m.integrator = (int)extra[8];
   if (extra_or(extra, n_extra, 9, 0) > 0) p->m.timestep = extra[9];
   p->healthy_reward = kind == TASK_IDPEND ? 10.0 : 1.0;
-  p->healthy_z_min = walker ? 0.8 : (kind == TASK_IPEND ? -0.2 : 0.2);
+  p->healthy_z_min = walker ? 0.8 : (hopper ? 0.7 : (kind == TASK_IPEND ? -0.2 : 0.2));
   p->healthy_z_max = walker ? 2.0 : (kind == TASK_IPEND ? 0.2 : 1.0);
-  p->healthy_angle_min = -1.0;
-  p->healthy_angle_max = 1.0;
+  p->healthy_angle_min = hopper ? -0.2 : -1.0; /* hopper.h:44-46 */
+  p->healthy_angle_max = hopper ? 0.2 : 1.0;
   p->velocity_min = -10.0;
   p->velocity_max = 10.0;
   p->terminate_when_unhealthy = 1;
@@ -180,6 +189,7 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
                       : kind == TASK_IDPEND ? 8 + p->constraint_obs_dim
                       : reacher ? (p->obs_include_z ? 11 : 10)
                       : swimmer ? 8
+                      : hopper ? 11
                                             : 17;
   static const char* cheetah_info[4] = {"info:reward_run", "info:reward_ctrl",
                                         "info:x_position", "info:x_velocity"};
@@ -193,12 +203,12 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   static const char* swimmer_info[7] = {"info:reward_fwd", "info:reward_ctrl", "info:x_position",
                                         "info:y_position", "info:distance_from_origin",
                                         "info:x_velocity", "info:y_velocity"};
-  int ninfo = is_ant ? 9 : (swimmer ? 7 : (walker || reacher ? 2 : (pend ? 0 : 4)));
+  int ninfo = is_ant ? 9 : (swimmer ? 7 : (walker || reacher || hopper ? 2 : (pend ? 0 : 4)));
   for (int i = 0; i < ninfo; ++i) {
     p->key_names[k] = is_ant ? ant_info[i]
                       : swimmer ? swimmer_info[i]
                       : reacher ? reacher_info[i]
-                                : cheetah_info[(walker ? 2 : 0) + i];
+                                : cheetah_info[((walker || hopper) ? 2 : 0) + i];
     p->key_dtype[k] = DT_F64;
     p->key_elems[k++] = 1;
   }
@@ -305,12 +315,12 @@ static void write_obs(mj_pool* p, mj_env* e, void** out, int row) {
     return;
   }
   int skip = (p->is_ant || p->task == TASK_SWIMMER) ? 2 : 1; /* exclude_current_positions... */
-  int n = (p->is_ant || p->task == TASK_SWIMMER) ? p->key_elems[8] : 17;
+  int n = (p->is_ant || p->task == TASK_SWIMMER || p->task == TASK_HOPPER) ? p->key_elems[8] : 17;
   double* obs = (double*)out[8] + (size_t)row * n;
   for (int i = skip; i < p->m.nq; ++i) *(obs++) = e->d.qpos[i];
   for (int i = 0; i < p->m.nv; ++i) {
     double x = e->d.qvel[i];
-    if (p->task == TASK_WALKER) { /* walker2d.h:196-201: clip(qvel, vmin, vmax) */
+    if (p->task == TASK_WALKER || p->task == TASK_HOPPER) { /* walker2d.h:196-201, hopper.h */
       x = x < p->velocity_min ? p->velocity_min : x;
       x = x > p->velocity_max ? p->velocity_max : x;
     }
@@ -361,7 +371,8 @@ static void mujoco_reset(mj_pool* p, mj_env* e) {
                                     p->reset_noise_scale);
   }
   for (int i = 0; i < p->m.nv; ++i) {
-    if (p->task == TASK_WALKER || p->task == TASK_IPEND || p->task == TASK_SWIMMER) {
+    if (p->task == TASK_WALKER || p->task == TASK_IPEND || p->task == TASK_SWIMMER ||
+        p->task == TASK_HOPPER) {
       /* walker2d.h:119-126, inverted_pendulum.h:100-107: uniform for qvel too */
       e->d.qvel[i] = 0.0 + orc_uniform_real(&e->gen, -p->reset_noise_scale,
                                             p->reset_noise_scale);
@@ -390,7 +401,7 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
   float reward = 0.0f;
   int ninfo = p->is_ant ? 9
               : p->task == TASK_SWIMMER ? 7
-              : (p->task == TASK_WALKER || p->task == TASK_REACHER) ? 2
+              : (p->task == TASK_WALKER || p->task == TASK_REACHER || p->task == TASK_HOPPER) ? 2
               : (p->task >= TASK_IPEND ? 0 : 4);
   double info[9] = {0};
   if (reset) {
@@ -405,7 +416,30 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
     double dt = p->frame_skip * p->m.timestep;
     double ctrl_cost = 0;
     for (int i = 0; i < p->m.nu; ++i) ctrl_cost += p->ctrl_cost_weight * act[i] * act[i];
-    if (p->task == TASK_SWIMMER) { /* swimmer.h:131-152 */
+    if (p->task == TASK_HOPPER) { /* hopper.h:158-203 */
+      double x_before = e->d.qpos[0];
+      for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
+      for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
+      double x_after = e->d.qpos[0];
+      double xv = (x_after - x_before) / dt;
+      int healthy = !(e->d.qpos[2] <= p->healthy_angle_min || e->d.qpos[2] >= p->healthy_angle_max ||
+                      e->d.qpos[1] <= p->healthy_z_min);
+      for (int i = 2; i < p->m.nq; ++i) {
+        if (e->d.qpos[i] <= -100.0 || e->d.qpos[i] >= 100.0) healthy = 0;
+      }
+      for (int i = 0; i < p->m.nv; ++i) {
+        if (e->d.qvel[i] <= -100.0 || e->d.qvel[i] >= 100.0) healthy = 0;
+      }
+      int give = healthy;
+      if (p->legacy_healthy_reward) give = p->terminate_when_unhealthy || healthy;
+      double healthy_reward = give ? p->healthy_reward : 0.0;
+      reward = (float)(xv * p->forward_reward_weight + healthy_reward - ctrl_cost);
+      ++e->elapsed_step;
+      e->done = (p->terminate_when_unhealthy ? !healthy : 0) ||
+                (e->elapsed_step >= p->max_episode_steps);
+      info[0] = x_after;
+      info[1] = xv;
+    } else if (p->task == TASK_SWIMMER) { /* swimmer.h:131-152 */
       double x_before = e->d.qpos[0], y_before = e->d.qpos[1];
       for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
       for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
@@ -675,4 +709,22 @@ void mjcpu_raw_get(void* h, int env, double* qpos, double* qvel, double* misc) {
   double fsum = 0;
   for (int r = 0; r < tmp.nefc; ++r) fsum += tmp.efc_force[r];
   misc[10] = fsum;
+}
+
+/* debug hook (tests): contacts of the last forward evaluation of env `env`:
+ * out[10 * c + ...] = geom1 geom2 dist pos[3] normal[3] efc_address; returns ncon */
+int mjcpu_raw_contacts(void* h, int env, double* out) {
+  mj_pool* p = (mj_pool*)h;
+  const mjc_data* d = &p->envs[env].d;
+  for (int c = 0; c < d->ncon; ++c) {
+    const mjc_contact* k = &d->contact[c];
+    double* o = out + 10 * c;
+    o[0] = k->geom1;
+    o[1] = k->geom2;
+    o[2] = k->dist;
+    for (int i = 0; i < 3; ++i) o[3 + i] = k->pos[i];
+    for (int i = 0; i < 3; ++i) o[6 + i] = k->frame[i];
+    o[9] = k->efc_address;
+  }
+  return d->ncon;
 }

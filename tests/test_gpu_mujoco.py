@@ -451,3 +451,108 @@ def test_swimmer_matches_oracle():
         worst = max(worst, float(np.abs(a["obs"] - b["obs"]).max()))
     print(f"Swimmer: worst teacher-forced |d obs| = {worst:.3e}")
     assert hit  # the hinge limit rows were exercised
+
+
+# ---- Hopper (planar kernel, ghost second leg, margin 0.001, body-body capsule contacts) ----
+def make_hopper_pair(n, seed, precision, max_steps=1000):
+    pool = DevicePool("Hopper", n, seed=seed, max_episode_steps=max_steps,
+                      params={"precision": precision})
+    orc = Oracle("Hopper", n, seed=seed, max_episode_steps=max_steps)
+    return pool, orc
+
+
+def _deep_self_penetration(orc, n, depth=-0.03):
+    """Envs whose last forward evaluation holds a body-body contact deeper than `depth`.
+    The random folded states below teleport the leg INTO the torso; once two capsule
+    axes (which all lie in the y = 0 plane) cross, the segment distance is 0, the
+    contact normal is numerical noise (MuJoCo falls back to +x below 1e-15) and the
+    outcome is arbitrary in the reference as well.  Real trajectories never get there:
+    the contact engages at the 1 mm margin."""
+    import ctypes
+
+    from mj_util import _H
+
+    L = orc.lib
+    L.mjcpu_raw_contacts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    inner = ctypes.cast(orc.h, ctypes.POINTER(_H)).contents.h
+    out, deep = np.zeros(320), np.zeros(n, bool)
+    for e in range(n):
+        k = L.mjcpu_raw_contacts(inner, e, out.ctypes.data)
+        c = out[:10 * k].reshape(k, 10)
+        deep[e] = bool(((c[:, 0] >= 1) & (c[:, 2] < depth)).any())
+    return deep
+
+
+def test_hopper_matches_oracle():
+    """Reset bit-exact (uniform draws); teacher-forced env-steps (4 RK4 mj_steps) incl.
+    folded configurations where the torso-leg / torso-foot / thigh-foot capsule pairs
+    touch: obs rtol 1e-9 / atol 1e-10, bookkeeping exact."""
+    n = 256
+    pool, orc = make_hopper_pair(n, 5, 1)
+    a, b = hip_reset(pool), orc.reset()
+    assert list(a.keys()) == list(b.keys()) and a["obs"].shape == (n, 11)
+    np.testing.assert_array_equal(a["obs"], b["obs"])
+    # a second oracle without self collisions tells which steps exercised the pair contacts
+    ref_noself = Oracle("Hopper", n, seed=5, max_episode_steps=1000,
+                        extra=(4, 1e-3, 1, 5e-3, 0, 0, 0, 0, -1, 0, 0, 3, 0, 0, 0, -1, 0, 1, 1))
+    ref_noself.reset()
+    rng = np.random.default_rng(3)
+    worst, seen_term, self_hits, compared = 0.0, False, 0, 0
+    for t in range(100):
+        st = orc.get_state()
+        if t % 4 == 3:  # fold the leg: thigh / knee deep into their range, random height
+            st[:, 1] = rng.uniform(0.9, 1.4, n)
+            st[:, 2] = rng.uniform(-0.5, 0.5, n)
+            st[:, 3] = rng.uniform(-2.6, 0, n)
+            st[:, 4] = rng.uniform(-2.6, 0, n)
+            st[:, 5] = rng.uniform(-0.78, 0.78, n)
+            st[:, 6:12] = rng.uniform(-2, 2, (n, 6))
+            st[:, 12:18] = 0
+            st[:, 21] = 0  # not done
+            orc.set_state(st)
+        pool.set_state(st)
+        ref_noself.set_state(st)
+        act = rng.uniform(-1.2, 1.2, size=(n, 3))
+        a, b, c = hip_step(pool, act), orc.step(act), ref_noself.step(act)
+        ok = ~_deep_self_penetration(orc, n)
+        compared += int(ok.sum())
+        np.testing.assert_allclose(a["obs"][ok], b["obs"][ok], rtol=1e-9, atol=1e-10,
+                                   err_msg=f"step {t}")
+        np.testing.assert_allclose(a["reward"].ravel()[ok], b["reward"].ravel()[ok],
+                                   rtol=1e-6, atol=1e-6)
+        for k in ("info:x_position", "info:x_velocity"):
+            np.testing.assert_allclose(a[k].ravel()[ok], b[k].ravel()[ok], rtol=1e-9, atol=2e-9)
+        for k in ("done", "trunc", "elapsed_step", "step_type", "discount"):
+            np.testing.assert_array_equal(a[k].ravel()[ok], b[k].ravel()[ok], err_msg=f"{k}@{t}")
+        seen_term |= bool((b["done"] & ~b["trunc"]).any())
+        self_hits += int((np.abs(b["obs"] - c["obs"]).max(axis=1)[ok] > 1e-9).sum())
+        worst = max(worst, float(np.abs(a["obs"] - b["obs"])[ok].max()))
+    print(f"Hopper fp64: worst teacher-forced |d obs| = {worst:.3e}; env-steps with active "
+          f"body-body contacts: {self_hits}")
+    assert seen_term and self_hits > 100 and compared > 0.8 * n * 100
+
+
+def test_hopper_fp32_distribution_and_determinism():
+    n, steps = 256, 60
+    pool, orc = make_hopper_pair(n, 9, 0)
+    hip_reset(pool), orc.reset()
+    rng = np.random.default_rng(3)
+    errs = []
+    for t in range(steps):
+        pool.set_state(orc.get_state())
+        act = rng.uniform(-1.2, 1.2, size=(n, 3))
+        a, b = hip_step(pool, act), orc.step(act)
+        errs.append((np.abs(a["obs"] - b["obs"]) / (1.0 + np.abs(b["obs"]))).max(axis=1))
+    errs = np.concatenate(errs)
+    med, p99 = np.median(errs), np.percentile(errs, 99)
+    print(f"Hopper fp32 teacher-forced rel |d obs|: median {med:.2e} p99 {p99:.2e} max {errs.max():.2e}")
+    assert med <= 5e-5 and p99 <= 2e-3
+    outs = []
+    for _ in range(2):
+        p2 = DevicePool("Hopper", 512, seed=3, max_episode_steps=1000, params={"precision": 1})
+        hip_reset(p2)
+        r2 = np.random.default_rng(5)
+        for t in range(30):
+            a = hip_step(p2, r2.uniform(-1, 1, size=(512, 3)))
+        outs.append(a["obs"].copy())
+    np.testing.assert_array_equal(outs[0], outs[1])

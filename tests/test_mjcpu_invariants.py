@@ -275,3 +275,60 @@ def test_product_swimmer_code_matches_oracle_on_cpu():
                                 ctypes.byref(it))
             worst = max(worst, np.abs(sg * qo - st1[e, 0:5]).max(), np.abs(sg * vo - st1[e, 5:10]).max())
     assert worst < 1e-10, worst
+
+
+def test_product_hopper_code_matches_oracle_on_cpu():
+    """Host instantiation of the planar tree with the Hopper model (ghost second leg,
+    contact margin, capsule-capsule body pairs) vs the generic 3-D oracle, on random
+    rollouts and on folded configurations where the body pairs collide."""
+    from mj_util import RawMj
+    from oracle.orc import Oracle
+
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    so, src = os.path.join(h, "libcheetah_host.so"), os.path.join(h, "cheetah_host.cpp")
+    hdr = os.path.join(ROOT, "envpool_amd", "csrc", "mj_cheetah.cuh")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(so)
+    L.hopper_host_step.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4
+
+    def host(q, v, w, a):
+        qo, vo, wo, it = np.zeros(6), np.zeros(6), np.zeros(6), ctypes.c_int(0)
+        q, v, w, a = (np.ascontiguousarray(x, dtype=np.float64) for x in (q, v, w, a))
+        L.hopper_host_step(q.ctypes.data, v.ctypes.data, w.ctypes.data, a.ctypes.data, 4, 0,
+                           qo.ctypes.data, vo.ctypes.data, wo.ctypes.data, ctypes.byref(it))
+        assert it.value >= 0  # the ghost leg stayed at rest
+        return qo, vo
+
+    rng = np.random.default_rng(3)
+    n = 8
+    orc = Oracle("Hopper", n, seed=9, max_episode_steps=1000)
+    orc.reset()
+    worst = 0.0
+    for t in range(40):
+        st = orc.get_state()
+        act = rng.uniform(-1.2, 1.2, (n, 3))
+        b = orc.step(act)
+        st1 = orc.get_state()
+        for e in range(n):
+            if b["elapsed_step"][e, 0] == 0:
+                continue
+            qo, vo = host(st[e, 0:6], st[e, 6:12], st[e, 12:18], act[e])
+            worst = max(worst, np.abs(qo - st1[e, 0:6]).max(), np.abs(vo - st1[e, 6:12]).max())
+    raw = RawMj("Hopper")
+    noself = RawMj("Hopper", extra=[4, 1e-3, 1, 5e-3, 0, 0, 0, 0, -1, 0, 0, 3, 0, 0, 0, -1, 0, 1, 1])
+    hits = 0
+    for trial in range(120):
+        q = np.array([0, rng.uniform(0.9, 1.4), rng.uniform(-0.5, 0.5), rng.uniform(-2.6, 0),
+                      rng.uniform(-2.6, 0), rng.uniform(-0.78, 0.78)])
+        v, a = rng.uniform(-2, 2, 6), rng.uniform(-1, 1, 3)
+        raw.set(q, v, a)
+        raw.step(4)
+        noself.set(q, v, a)
+        noself.step(4)
+        q1, v1, _ = raw.get()
+        hits += int(np.abs(q1 - noself.get()[0]).max() > 1e-9)
+        qo, vo = host(q, v, np.zeros(6), a)
+        worst = max(worst, np.abs(qo - q1).max(), np.abs(vo - v1).max())
+    assert worst < 1e-9, worst
+    assert hits >= 5  # body-body contacts were really exercised

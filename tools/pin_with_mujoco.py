@@ -35,7 +35,8 @@ def main(xml_dir: str) -> None:
             ("inverted_pendulum", "inverted_pendulum_envpool.xml", 2, 3.0, 25),
             ("inverted_double_pendulum", "inverted_double_pendulum_envpool.xml", 5, 1.0, 25),
             ("reacher", "reacher_envpool.xml", 2, 1.0, 50),
-            ("swimmer", "swimmer_envpool.xml", 4, 1.0, 200)):
+            ("swimmer", "swimmer_envpool.xml", 4, 1.0, 200),
+            ("hopper", "hopper_envpool.xml", 4, 1.0, 25)):
         m = mujoco.MjModel.from_xml_path(os.path.join(xml_dir, xml))
         d = mujoco.MjData(m)
         rec = {k: [] for k in ("qpos0", "qvel0", "warm0", "ctrl", "qpos1", "qvel1", "xpos1",
