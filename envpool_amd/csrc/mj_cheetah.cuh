@@ -1,31 +1,35 @@
-// K3 — HalfCheetah `mj_step` restated as a planar, tree-specialised, fully
-// unrolled per-thread routine (one env per thread).
+// K3 — `mj_step` of the planar gym robots (HalfCheetah, Walker2d, Hopper)
+// restated as a tree-specialised, fully unrolled per-thread routine (one env
+// per thread).  Tree: torso (x / z slides + y hinge) with two 3-link legs.
 //
-// What it replaces: the arithmetic MuJoCo 3.6.0's mj_step performs for the gym
-// HalfCheetah model each time the reference calls it
+// What it replaces: the arithmetic MuJoCo 3.6.0's mj_step performs for these
+// models each time the reference calls it
 // (envpool/mujoco/gym/mujoco_env.h:137-148, `frame_skip x mj_step`), i.e.
 // SURVEY.md §8a stages M1-M9: kinematics, comPos, crb(+factor), collision
-// (plane-capsule), makeConstraint (joint limits + pyramidal frictional
-// contacts), comVel/passive/rne, actuation, Newton solve of the convex
-// constraint objective, Euler with implicit joint damping.
+// (plane-capsule; Hopper also capsule-capsule), makeConstraint (joint limits +
+// pyramidal frictional contacts), comVel/passive/rne, actuation, Newton solve of
+// the convex constraint objective, Euler with implicit joint damping
+// (HalfCheetah) or RK4 (Walker2d, Hopper).
 //
 // MI355X-first design (not a translation of MuJoCo's generic engine):
-//  * the model (third_party/mujoco_gym_xml_patches/half_cheetah_envpool.xml:
-//    2 slides + 7 y-hinges) moves in the x-z plane, so every spatial quantity
-//    is a 3-vector (w_y, v_x, v_z) and every inertia 4 numbers; the y-tangent
-//    friction rows have identically zero tangential Jacobian and fold into the
-//    normal row with weight 2D;
+//  * the models (third_party/mujoco_gym_xml_patches/{half_cheetah,walker2d,
+//    walker2d_v5,hopper}_envpool.xml: 2 slides + y-hinges) move in the x-z
+//    plane, so every spatial quantity is a 3-vector (w_y, v_x, v_z) and every
+//    inertia 4 numbers; the y-tangent friction rows have identically zero
+//    tangential Jacobian and fold into the normal row with weight 2D;
 //  * all tree loops are unrolled at compile time (static_for) so the 9x9
 //    inertia/Hessian, body poses and Jacobian columns live in VGPRs with static
 //    indices; the leg/leg zero blocks of M and H are never materialised;
 //  * M/H are factored as U U^T from the last dof upwards (tree order), which
-//    has no fill between the two legs;
+//    has no fill between the two legs; the diagonal is kept inverted;
 //  * per-contact constants (contact point, reference accelerations, D) are
 //    staged through LDS, laid out [slot][lane] so a wave's accesses are
 //    bank-conflict free; Jacobian rows are rebuilt from the contact point
-//    instead of being stored;
-//  * model constants arrive as a by-value kernel argument (scalar loads ->
-//    SGPRs), not per-env copies of mjModel.
+//    instead of being stored; the solver passes run a scalar loop over the
+//    wave-uniform set of touching end spheres;
+//  * no lane-divergent control flow in the solver (see WaveAny);
+//  * the model is a compile-time constant (gen_mj_consts.cpp), so per-model
+//    features (contact margin, Hopper's body pairs) fold away elsewhere.
 // The same source compiles for the host (EPA_HD) so tests can run it in fp64
 // on the CPU against oracle/mjcpu.
 #ifndef ENVPOOL_AMD_CSRC_MJ_CHEETAH_CUH_

@@ -1,9 +1,12 @@
-// K3 — gym-MuJoCo batched step kernels (one env per thread, one wave per block).
+// K3 — gym-MuJoCo batched step kernels for the planar robots (HalfCheetah,
+// Walker2d, Hopper; one env per thread, one wave per block).
 //
 // Replaces, for the whole batch in one launch:
 //   MujocoEnv::{MujocoReset,MujocoStep}     envpool/mujoco/gym/mujoco_env.h:126-148
 //   HalfCheetahEnvBase::{MujocoResetModel,Reset,Step,WriteState}
 //                                           envpool/mujoco/gym/half_cheetah.h:105-185
+//   Walker2dEnvBase::{...}                  envpool/mujoco/gym/walker2d.h:119-219
+//   HopperEnvBase::{...}                    envpool/mujoco/gym/hopper.h:121-230
 // including the `frame_skip x mj_step` physics (mj_cheetah.cuh) and the
 // runtime around it (async_envpool.h:118-132, env.h:184-256).
 //
