@@ -150,6 +150,12 @@ class Pool {
   virtual void Launch(const int* d_ids, int k, const void* d_action,
                       bool force_reset, const OutPtrs& out) = 0;
   void InitCommon();  // allocates + initialises CommonDev (after derived ctor)
+  // Generic TypedFrameStackBuffer (envpool/mujoco/frame_stack.h:74-146) for families
+  // whose step kernel writes one un-stacked float64 observation per row: the first
+  // env key must be "obs" declared with shape [S, nobs] (StackedObsShape).  The
+  // kernel then writes into a scratch [k, nobs] block and a second small kernel
+  // maintains a per-env ring and emits the stacked rows.  No-op for S == 1.
+  void EnableObsStack();
 
   Config cfg_;
   std::vector<KeySpec> keys_;
@@ -178,6 +184,11 @@ class Pool {
   Staging& NextStaging(size_t bytes);
   void CheckIds(const int32_t* ids, int k) const;
 
+  // generic observation frame stack (EnableObsStack)
+  int stack_s_{1}, stack_nobs_{0};
+  double* stack_ring_{nullptr};  // [N][S][nobs]
+  int* stack_head_{nullptr};     // [N] slot holding the oldest frame
+  double* stack_tmp_{nullptr};   // [N][nobs] un-stacked obs of the current launch
   std::mutex mu_;
   std::deque<Batch*> pending_;
   std::vector<Batch*> free_;
@@ -192,6 +203,10 @@ class Pool {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timers_;
   std::vector<hipEvent_t> timer_pool_;
 };
+
+// obs key shape with the optional leading frame_stack dimension (StackSpec,
+// envpool/mujoco/frame_stack.h:42-71); throws like the reference on frame_stack < 1
+std::vector<int> StackedObsShape(const Config& cfg, int nobs);
 
 // family factories (defined next to the kernels)
 Pool* MakeClassicControl(const std::string& family, const Config& cfg);

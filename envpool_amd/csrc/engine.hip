@@ -151,11 +151,71 @@ Pool::~Pool() {
   if (recv_stage_) (void)hipHostFree(recv_stage_);
   if (common_.cur_step) (void)hipFree(common_.cur_step);
   if (common_.done) (void)hipFree(common_.done);
+  if (stack_ring_) (void)hipFree(stack_ring_);
+  if (stack_head_) (void)hipFree(stack_head_);
+  if (stack_tmp_) (void)hipFree(stack_tmp_);
   if (common_.mt) (void)hipFree(common_.mt);
   if (common_.mti) (void)hipFree(common_.mti);
   if (stream_) (void)hipStreamDestroy(stream_);
   if (h2d_stream_) (void)hipStreamDestroy(h2d_stream_);
   if (d2h_stream_) (void)hipStreamDestroy(d2h_stream_);
+}
+
+// ---- generic observation frame stack ---------------------------------------------
+std::vector<int> StackedObsShape(const Config& cfg, int nobs) {
+  int s = (int)cfg.Get("frame_stack", 1);
+  if (s < 1) throw std::invalid_argument("frame_stack must be greater than 0");
+  if (s == 1) return {nobs};
+  return {s, nobs};
+}
+
+// FrameStackBuffer::Commit (frame_stack.h:109-135) as a ring: a reset fills every
+// slot with the new frame, a step overwrites the oldest one.
+__global__ void ObsStackKernel(const double* __restrict__ tmp, double* __restrict__ out,
+                               const int* __restrict__ elapsed, const int* __restrict__ ids,
+                               int id_offset, int k, int nobs, int S, double* ring,
+                               const int* __restrict__ head) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k * nobs) return;
+  const int row = t / nobs, i = t - row * nobs;
+  const int e = ids ? ids[row] - id_offset : row;
+  const double x = tmp[t];
+  double* r = ring + (size_t)e * S * nobs;
+  double* o = out + (size_t)row * S * nobs;
+  if (elapsed[row] == 0) {  // first observation of an episode
+    for (int f = 0; f < S; ++f) {
+      r[f * nobs + i] = x;
+      o[f * nobs + i] = x;
+    }
+  } else {
+    const int h = head[e];
+    r[h * nobs + i] = x;
+    for (int f = 0; f < S - 1; ++f) o[f * nobs + i] = r[((h + 1 + f) % S) * nobs + i];
+    o[(S - 1) * nobs + i] = x;
+  }
+}
+__global__ void ObsStackAdvanceKernel(const int* __restrict__ elapsed, const int* __restrict__ ids,
+                                      int id_offset, int k, int S, int* head) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= k) return;
+  const int e = ids ? ids[row] - id_offset : row;
+  head[e] = elapsed[row] == 0 ? 0 : (head[e] + 1) % S;
+}
+
+void Pool::EnableObsStack() {
+  const KeySpec& obs = keys_[kNumCommonKeys];
+  if (obs.name != "obs" || obs.dtype != EPA_F64) {
+    throw std::runtime_error("EnableObsStack: first env key must be a float64 `obs`");
+  }
+  if (obs.shape.size() != 2) return;  // frame_stack == 1: nothing to do
+  stack_s_ = obs.shape[0];
+  stack_nobs_ = obs.shape[1];
+  size_t n = cfg_.num_envs;
+  EPA_HIP(hipMalloc(&stack_ring_, sizeof(double) * n * stack_s_ * stack_nobs_));
+  EPA_HIP(hipMemsetAsync(stack_ring_, 0, sizeof(double) * n * stack_s_ * stack_nobs_, stream_));
+  EPA_HIP(hipMalloc(&stack_head_, sizeof(int) * n));
+  EPA_HIP(hipMemsetAsync(stack_head_, 0, sizeof(int) * n, stream_));
+  EPA_HIP(hipMalloc(&stack_tmp_, sizeof(double) * n * stack_nobs_));
 }
 
 Batch* Pool::AcquireBatch(int k) {
@@ -209,8 +269,21 @@ void Pool::Enqueue(const int* d_ids, int k, const void* d_action, bool force) {
     t1 = get();
     EPA_HIP(hipEventRecord(t0, stream_));
   }
-  Launch(d_ids, k, d_action, force, PtrsOf(*b));
+  OutPtrs out = PtrsOf(*b);
+  void* stacked_obs = out.p[kNumCommonKeys];
+  if (stack_s_ > 1) out.p[kNumCommonKeys] = stack_tmp_;  // the kernel writes one frame per row
+  Launch(d_ids, k, d_action, force, out);
   EPA_HIP(hipGetLastError());
+  if (stack_s_ > 1) {
+    const int* elapsed = static_cast<const int*>(out.p[2]);  // "elapsed_step": 0 on a reset
+    const int total = k * stack_nobs_;
+    hipLaunchKernelGGL(ObsStackKernel, dim3((total + 255) / 256), dim3(256), 0, stream_,
+                       stack_tmp_, static_cast<double*>(stacked_obs), elapsed, d_ids,
+                       cfg_.env_id_offset, k, stack_nobs_, stack_s_, stack_ring_, stack_head_);
+    hipLaunchKernelGGL(ObsStackAdvanceKernel, dim3((k + 255) / 256), dim3(256), 0, stream_,
+                       elapsed, d_ids, cfg_.env_id_offset, k, stack_s_, stack_head_);
+    EPA_HIP(hipGetLastError());
+  }
   if (timing_) {
     EPA_HIP(hipEventRecord(t1, stream_));
     timers_.emplace_back(t0, t1);

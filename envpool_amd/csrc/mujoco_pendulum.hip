@@ -337,7 +337,7 @@ __global__ void ReacherSetState(ReacherDev dev, CommonDev cm, const int* ids, in
 
 std::vector<KeySpec> ReacherKeys(const Config& cfg) {  // reacher.h:44-60
   int nobs = cfg.Get("obs_include_z_distance", 1) != 0 ? 11 : 10;
-  return {{"obs", EPA_F64, {nobs}},
+  return {{"obs", EPA_F64, StackedObsShape(cfg, nobs)},
           {"info:reward_dist", EPA_F64, {}},
           {"info:reward_ctrl", EPA_F64, {}}};
 }
@@ -346,9 +346,7 @@ class ReacherPool : public Pool {
  public:
   explicit ReacherPool(const Config& cfg)
       : Pool(cfg, ReacherKeys(cfg), KeySpec{"action", EPA_F64, {2}}, /*needs_rng=*/true) {
-    if ((int)cfg.Get("frame_stack", 1) != 1) {
-      throw std::invalid_argument("frame_stack > 1 is not supported for Reacher yet");
-    }
+    EnableObsStack();
     model_ = P::BuildReacher();
     // defaults: reacher.h:32-43
     task_.frame_skip = (int)cfg.Get("frame_skip", 2);
@@ -485,7 +483,7 @@ __global__ __launch_bounds__(kPendBlock) void SwimmerStepKernel(
 
 std::vector<KeySpec> SwimmerKeys(const Config& cfg) {  // swimmer.h:44-61
   int no_pos = cfg.Get("exclude_current_positions_from_observation", 1) != 0;
-  std::vector<KeySpec> k = {{"obs", EPA_F64, {no_pos ? 8 : 10}}};
+  std::vector<KeySpec> k = {{"obs", EPA_F64, StackedObsShape(cfg, no_pos ? 8 : 10)}};
   for (const char* name : {"info:reward_fwd", "info:reward_ctrl", "info:x_position",
                            "info:y_position", "info:distance_from_origin", "info:x_velocity",
                            "info:y_velocity"}) {
@@ -506,11 +504,9 @@ class PendPool : public Pool {
  public:
   static constexpr int NV = NL + 1;
   explicit PendPool(const Config& cfg)
-      : Pool(cfg, {{"obs", EPA_F64, {PendObsDim(cfg, NL)}}}, KeySpec{"action", EPA_F64, {1}},
-             /*needs_rng=*/true) {
-    if ((int)cfg.Get("frame_stack", 1) != 1) {
-      throw std::invalid_argument("frame_stack > 1 is not supported for the inverted pendulums yet");
-    }
+      : Pool(cfg, {{"obs", EPA_F64, StackedObsShape(cfg, PendObsDim(cfg, NL))}},
+             KeySpec{"action", EPA_F64, {1}}, /*needs_rng=*/true) {
+    EnableObsStack();
     if constexpr (NL == 1) {
       model1_ = P::BuildInvertedPendulum();
     } else {
@@ -583,9 +579,7 @@ class SwimmerPool : public Pool {
   static constexpr int NV = 5;
   explicit SwimmerPool(const Config& cfg)
       : Pool(cfg, SwimmerKeys(cfg), KeySpec{"action", EPA_F64, {2}}, /*needs_rng=*/true) {
-    if ((int)cfg.Get("frame_stack", 1) != 1) {
-      throw std::invalid_argument("frame_stack > 1 is not supported for Swimmer yet");
-    }
+    EnableObsStack();
     model_ = P::BuildSwimmer();
     // defaults: swimmer.h:32-42
     task_.frame_skip = (int)cfg.Get("frame_skip", 4);
@@ -649,7 +643,7 @@ bool DescribePendulum(const std::string& family, const Config& cfg,
   }
   int nl = family == "InvertedPendulum" ? 1 : (family == "InvertedDoublePendulum" ? 2 : 0);
   if (nl == 0) return false;
-  *state = {{"obs", EPA_F64, {PendObsDim(cfg, nl)}}};
+  *state = {{"obs", EPA_F64, StackedObsShape(cfg, PendObsDim(cfg, nl))}};
   *action = KeySpec{"action", EPA_F64, {1}};
   return true;
 }

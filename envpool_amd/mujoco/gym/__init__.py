@@ -189,7 +189,7 @@ _InvertedPendulum = FamilyDef(
         "healthy_z_min": c["healthy_z_min"], "healthy_z_max": c["healthy_z_max"],
         "reset_noise_scale": c["reset_noise_scale"],
     },
-    unsupported={"xml_file": "inverted_pendulum.xml", "frame_stack": 1},
+    unsupported={"xml_file": "inverted_pendulum.xml"},
 )
 
 
@@ -223,7 +223,7 @@ _InvertedDoublePendulum = FamilyDef(
         "observation_min": c["observation_min"], "observation_max": c["observation_max"],
         "reset_noise_scale": c["reset_noise_scale"],
     },
-    unsupported={"xml_file": "inverted_double_pendulum.xml", "frame_stack": 1},
+    unsupported={"xml_file": "inverted_double_pendulum.xml"},
 )
 
 _Reacher = FamilyDef(
@@ -254,7 +254,7 @@ _Reacher = FamilyDef(
         "reset_qvel_scale": c["reset_qvel_scale"],
         "reset_goal_scale": c["reset_goal_scale"],
     },
-    unsupported={"xml_file": "reacher.xml", "frame_stack": 1},
+    unsupported={"xml_file": "reacher.xml"},
 )
 
 _Swimmer = FamilyDef(
@@ -284,7 +284,7 @@ _Swimmer = FamilyDef(
         "ctrl_cost_weight": c["ctrl_cost_weight"],
         "reset_noise_scale": c["reset_noise_scale"],
     },
-    unsupported={"xml_file": "swimmer.xml", "frame_stack": 1},
+    unsupported={"xml_file": "swimmer.xml"},
 )
 
 _Hopper = FamilyDef(

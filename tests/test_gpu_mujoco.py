@@ -556,3 +556,43 @@ def test_hopper_fp32_distribution_and_determinism():
             a = hip_step(p2, r2.uniform(-1, 1, size=(512, 3)))
         outs.append(a["obs"].copy())
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+# ---- generic observation frame stack (engine-level TypedFrameStackBuffer) ----
+@pytest.mark.parametrize("task,adim,amax,S", [("InvertedPendulum", 1, 3.0, 3), ("Swimmer", 2, 1.0, 2),
+                                              ("Reacher", 2, 1.0, 4)])
+def test_chain_families_frame_stack(task, adim, amax, S):
+    """frame_stack = S: obs[:, -1] is the newest frame, older frames shift towards 0,
+    a reset fills all S slots (envpool/mujoco/frame_stack.h:109-135).  Checked against
+    the oracle's un-stacked observations stacked in numpy, across auto-resets."""
+    n, max_steps = 256, 12
+    pool = DevicePool(task, n, seed=2, max_episode_steps=max_steps, params={"frame_stack": S})
+    orc = Oracle(task, n, seed=2, max_episode_steps=max_steps)
+    a, b = hip_reset(pool), orc.reset()
+    nobs = b["obs"].shape[1]
+    assert a["obs"].shape == (n, S, nobs)
+    ring = np.repeat(b["obs"][:, None, :], S, axis=1)
+    np.testing.assert_allclose(a["obs"], ring, rtol=1e-12, atol=1e-14)
+    rng = np.random.default_rng(4)
+    for t in range(40):
+        pool.set_state(orc.get_state())
+        act = rng.uniform(-amax, amax, size=(n, adim))
+        a, b = hip_step(pool, act), orc.step(act)
+        first = b["elapsed_step"].ravel() == 0
+        ring = np.concatenate([ring[:, 1:], b["obs"][:, None, :]], axis=1)
+        ring[first] = b["obs"][first][:, None, :]
+        np.testing.assert_allclose(a["obs"], ring, rtol=1e-9, atol=1e-10, err_msg=f"step {t}")
+    # partial / permuted env_id batches keep per-env rings
+    ids = rng.permutation(n)[:37].astype(np.int32)
+    st = orc.get_state()
+    pool.set_state(st)
+    act = rng.uniform(-amax, amax, size=(37, adim))
+    pool.send(ids, act)
+    a = pool.recv_dict()
+    full = np.zeros((n, adim))
+    full[ids] = act
+    b = orc.step(full)
+    first = b["elapsed_step"].ravel() == 0
+    ring = np.concatenate([ring[:, 1:], b["obs"][:, None, :]], axis=1)
+    ring[first] = b["obs"][first][:, None, :]
+    np.testing.assert_allclose(a["obs"], ring[ids], rtol=1e-9, atol=1e-10)
