@@ -15,10 +15,18 @@ def short(name):
                      ("CheetahStepKernel<float, 1>", "[Walker2d]"),
                      ("CheetahStepKernel<double, 1>", "[Walker2d]"),
                      ("CheetahStepKernel<float, 2>", "[Walker2d-v5]"),
-                     ("CheetahStepKernel<double, 2>", "[Walker2d-v5]")):
+                     ("CheetahStepKernel<double, 2>", "[Walker2d-v5]"),
+                     ("CheetahStepKernel<float, 3>", "[Hopper]"),
+                     ("CheetahStepKernel<double, 3>", "[Hopper]")):
         if k in name:  # planar kernel, second template argument = PlanarModelId
             return k.split(",")[0] + ">" + model
-    for k in ("AntStepKernel<float>", "AntStepKernel<double>", "ClassicStepKernel",
+    for k, v in (("AntStepKernel<float, false>", "AntStepKernel<float>"),
+                 ("AntStepKernel<double, false>", "AntStepKernel<double>"),
+                 ("AntStepKernel<float, true>", "AntStepKernel<float>[v5 cfrc_ext]"),
+                 ("AntStepKernel<double, true>", "AntStepKernel<double>[v5 cfrc_ext]")):
+        if k in name:
+            return v
+    for k in ("PendStepKernel", "ReacherStepKernel", "SwimmerStepKernel", "ClassicStepKernel",
               "ToyStepKernel", "AtariPostKernel"):
         if k in name:
             return k
