@@ -1224,9 +1224,11 @@ EPA_HD int AntStep(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, T* v, T*
                    const T* ctrl, T* lagx, T* lagy, Lds&& lds, bool wrench = false,
                    Sink&& sink = Sink()) {
   const T h = m.timestep;
+  // q0, v0: state at the start; qs, vs: state of the current stage; dq, dv: running
+  // B-weighted sums.  The previous stage's velocity / acceleration are vs / F
+  // themselves, read before they are overwritten.
   T q0[kNQ], v0[kNV], qs[kNQ], vs[kNV];
-  T F[kNV], dq[kNV], dv[kNV];     // running B-weighted sums
-  T Xv_prev[kNV], F_prev[kNV];
+  T F[kNV], dq[kNV], dv[kNV];
   int it = 0;
   static_for<0, kNQ>([&](auto ic) { q0[decltype(ic)::value] = q[decltype(ic)::value]; });
   static_for<0, kNV>([&](auto ic) { v0[decltype(ic)::value] = v[decltype(ic)::value]; });
@@ -1237,8 +1239,7 @@ EPA_HD int AntStep(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, T* v, T*
     constexpr int i = decltype(ic)::value;
     dq[i] = v0[i] * T(1.0 / 6.0);
     dv[i] = F[i] * T(1.0 / 6.0);
-    Xv_prev[i] = v0[i];
-    F_prev[i] = F[i];
+    vs[i] = v0[i];
   });
   // stages 2..4: X_i = X_0 + h * a_i * (Xv_{i-1}, F_{i-1}), a = 1/2, 1/2, 1
   for (int stage = 1; stage < 4; ++stage) {
@@ -1247,8 +1248,8 @@ EPA_HD int AntStep(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, T* v, T*
     T step_dq[kNV];
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      step_dq[i] = a * Xv_prev[i];
-      vs[i] = v0[i] + h * a * F_prev[i];
+      step_dq[i] = a * vs[i];  // vs, F: previous stage
+      vs[i] = v0[i] + h * a * F[i];
     });
     static_for<0, kNQ>([&](auto ic) { qs[decltype(ic)::value] = q0[decltype(ic)::value]; });
     AntIntegratePos(qs, step_dq, h);
@@ -1257,8 +1258,6 @@ EPA_HD int AntStep(const AntModel<T>& m, const SolverCfg<T>& cfg, T* q, T* v, T*
       constexpr int i = decltype(ic)::value;
       dq[i] += bw * vs[i];
       dv[i] += bw * F[i];
-      Xv_prev[i] = vs[i];
-      F_prev[i] = F[i];
     });
     if (stage == 3) {
       *lagx = qs[0];

@@ -987,18 +987,19 @@ template <typename T, typename Lds>
 EPA_HD int PlanarStepRK4(const CheetahModel<T>& m, const SolverCfg<T>& cfg, T* q, T* v,
                          T* warm, const T* ctrl, Lds&& lds) {
   const T h = m.timestep;
-  T q0[kNV], v0[kNV], qs[kNV], vs[kNV];
-  T F[kNV], dq[kNV], dv[kNV];  // running B-weighted sums
-  T Xv_prev[kNV], F_prev[kNV];
+  // q0, v0: state at the start; qs, vs: state of the current stage; dq, dv: running
+  // B-weighted sums.  The previous stage's velocity / acceleration are vs / F
+  // themselves (read before they are overwritten), so no extra copies stay live
+  // across the forward evaluations.
+  T q0[kNV], v0[kNV], qs[kNV], vs[kNV], F[kNV], dq[kNV], dv[kNV];
   int it = PlanarForward(m, cfg, q, v, warm, ctrl, lds, F);  // stage 1 at (q0, v0)
   static_for<0, kNV>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     q0[i] = q[i];
     v0[i] = v[i];
+    vs[i] = v[i];
     dq[i] = v0[i] * T(1.0 / 6.0);
     dv[i] = F[i] * T(1.0 / 6.0);
-    Xv_prev[i] = v0[i];
-    F_prev[i] = F[i];
   });
   // stages 2..4: X_i = X_0 + h * a_i * (Xv_{i-1}, F_{i-1}), a = 1/2, 1/2, 1
   for (int stage = 1; stage < 4; ++stage) {
@@ -1006,16 +1007,14 @@ EPA_HD int PlanarStepRK4(const CheetahModel<T>& m, const SolverCfg<T>& cfg, T* q
     const T bw = stage == 3 ? T(1.0 / 6.0) : T(1.0 / 3.0);
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      qs[i] = q0[i] + h * (a * Xv_prev[i]);
-      vs[i] = v0[i] + h * a * F_prev[i];
+      qs[i] = q0[i] + h * (a * vs[i]);  // vs, F: previous stage
+      vs[i] = v0[i] + h * a * F[i];
     });
     it += PlanarForward(m, cfg, qs, vs, warm, ctrl, lds, F);
     static_for<0, kNV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       dq[i] += bw * vs[i];
       dv[i] += bw * F[i];
-      Xv_prev[i] = vs[i];
-      F_prev[i] = F[i];
     });
   }
   static_for<0, kNV>([&](auto ic) {

@@ -381,7 +381,7 @@ EPA_HD int PendStepRK4(const PendModel<T, NL, kBase>& m, const SolverCfg<T>& cfg
                        T* warm, const T* ctrl, PendAux<T, NL>& aux) {
   constexpr int NV = NL + kBase;
   const T h = m.timestep;
-  T q0[NV], v0[NV], qs[NV], vs[NV], F[NV], dq[NV], dv[NV], Xv[NV], Fp[NV];
+  T q0[NV], v0[NV], qs[NV], vs[NV], F[NV], dq[NV], dv[NV];  // vs / F double as the previous stage's
   int it = PendForward(m, cfg, q, v, ctrl, warm, F, aux);
   static_for<0, NV>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -389,24 +389,21 @@ EPA_HD int PendStepRK4(const PendModel<T, NL, kBase>& m, const SolverCfg<T>& cfg
     v0[i] = v[i];
     dq[i] = v0[i] * T(1.0 / 6.0);
     dv[i] = F[i] * T(1.0 / 6.0);
-    Xv[i] = v0[i];
-    Fp[i] = F[i];
+    vs[i] = v0[i];
   });
   for (int stage = 1; stage < 4; ++stage) {
     const T a = stage == 3 ? T(1) : T(0.5);
     const T bw = stage == 3 ? T(1.0 / 6.0) : T(1.0 / 3.0);
     static_for<0, NV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      qs[i] = q0[i] + h * (a * Xv[i]);
-      vs[i] = v0[i] + h * a * Fp[i];
+      qs[i] = q0[i] + h * (a * vs[i]);
+      vs[i] = v0[i] + h * a * F[i];
     });
     it += PendForward(m, cfg, qs, vs, ctrl, warm, F, aux);
     static_for<0, NV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       dq[i] += bw * vs[i];
       dv[i] += bw * F[i];
-      Xv[i] = vs[i];
-      Fp[i] = F[i];
     });
   }
   static_for<0, NV>([&](auto ic) {
