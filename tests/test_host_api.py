@@ -23,7 +23,11 @@ def test_list_all_envs_and_registry():
               "FrozenLake-v1", "FrozenLake8x8-v1", "Taxi-v3", "NChain-v0",
               "CliffWalking-v0", "CliffWalking-v1", "CliffWalkingSlippery-v1",
               "Blackjack-v1", "HalfCheetah-v3", "HalfCheetah-v4", "HalfCheetah-v5",
-              "Ant-v4"]:
+              "Ant-v3", "Ant-v4", "Ant-v5", "Walker2d-v3", "Walker2d-v4", "Walker2d-v5",
+              "Hopper-v3", "Hopper-v4", "Hopper-v5", "Swimmer-v3", "Swimmer-v4", "Swimmer-v5",
+              "Reacher-v2", "Reacher-v4", "Reacher-v5", "InvertedPendulum-v2",
+              "InvertedPendulum-v4", "InvertedPendulum-v5", "InvertedDoublePendulum-v2",
+              "InvertedDoublePendulum-v4", "InvertedDoublePendulum-v5"]:
         assert t in ids, t
     with pytest.raises(AssertionError):
         envpool.make("NoSuchEnv-v0", "gym", num_envs=1)
@@ -53,6 +57,25 @@ def test_spec_config_defaults_and_key_order():
     hc = envpool.make_spec("HalfCheetah-v4").config
     assert (hc.frame_skip, hc.post_constraint, hc.max_episode_steps) == (5, False, 1000)
     assert envpool.make_spec("HalfCheetah-v5").config.post_constraint is True
+    # version-specific registrations (envpool/mujoco/gym/registration.py:36-83)
+    a3, a5 = envpool.make_spec("Ant-v3").config, envpool.make_spec("Ant-v5").config
+    assert (a3.use_contact_force, a3.post_constraint) == (True, False)
+    assert (a5.use_contact_force, a5.exclude_worldbody_contact_forces,
+            a5.legacy_healthy_reward, a5.post_constraint) == (True, True, False, True)
+    assert envpool.make_spec("Ant-v3").observation_space.shape == (111,)
+    assert envpool.make_spec("Ant-v5").observation_space.shape == (105,)
+    w5 = envpool.make_spec("Walker2d-v5").config
+    assert (w5.xml_file, w5.legacy_healthy_reward) == ("walker2d_v5.xml", False)
+    assert envpool.make_spec("Hopper-v5").config.legacy_healthy_reward is False
+    r5 = envpool.make_spec("Reacher-v5")
+    assert r5.config.reward_after_step is True and r5.observation_space.shape == (10,)
+    assert envpool.make_spec("Reacher-v4").config.max_episode_steps == 50
+    d5 = envpool.make_spec("InvertedDoublePendulum-v5")
+    assert d5.config.constraint_obs_dim == 1 and d5.observation_space.shape == (9,)
+    assert envpool.make_spec("InvertedPendulum-v5").config.reward_if_not_terminated is True
+    assert envpool.make_spec("Swimmer-v4", frame_stack=3).observation_space.shape == (3, 8)
+    with pytest.raises(ValueError):
+        envpool.make_spec("Walker2d-v4", xml_file="walker2d_custom.xml")
 
 
 def test_spaces_and_dm_specs():
@@ -119,12 +142,23 @@ FAMILY_PARAMS = {
     "FrozenLake8x8-v1": {"size": 8}, "Taxi-v3": {}, "NChain-v0": {},
     "CliffWalkingSlippery-v1": {"is_slippery": 1}, "Blackjack-v1": {}, "HalfCheetah-v4": {},
     "Ant-v4": {},
+    "Ant-v3": {"use_contact_force": 1},
+    "Ant-v5": {"use_contact_force": 1, "exclude_worldbody_contact_forces": 1, "post_constraint": 1},
+    "Walker2d-v4": {}, "Walker2d-v5": {"xml_v5": 1}, "Hopper-v4": {}, "Swimmer-v4": {},
+    "Reacher-v4": {}, "Reacher-v5": {"obs_include_z_distance": 0},
+    "InvertedPendulum-v4": {}, "InvertedDoublePendulum-v4": {},
+    "InvertedDoublePendulum-v5": {"constraint_obs_dim": 1},
 }
 NATIVE = {"CartPole-v1": "CartPole", "Pendulum-v1": "Pendulum", "MountainCar-v0": "MountainCar",
           "MountainCarContinuous-v0": "MountainCarContinuous", "Acrobot-v1": "Acrobot",
           "Catch-v0": "Catch", "FrozenLake8x8-v1": "FrozenLake", "Taxi-v3": "Taxi",
           "NChain-v0": "NChain", "CliffWalkingSlippery-v1": "CliffWalking",
-          "Blackjack-v1": "Blackjack", "HalfCheetah-v4": "HalfCheetah", "Ant-v4": "Ant"}
+          "Blackjack-v1": "Blackjack", "HalfCheetah-v4": "HalfCheetah", "Ant-v4": "Ant",
+          "Ant-v3": "Ant", "Ant-v5": "Ant", "Walker2d-v4": "Walker2d", "Walker2d-v5": "Walker2d",
+          "Hopper-v4": "Hopper", "Swimmer-v4": "Swimmer", "Reacher-v4": "Reacher",
+          "Reacher-v5": "Reacher", "InvertedPendulum-v4": "InvertedPendulum",
+          "InvertedDoublePendulum-v4": "InvertedDoublePendulum",
+          "InvertedDoublePendulum-v5": "InvertedDoublePendulum"}
 
 
 @pytest.mark.parametrize("task", sorted(FAMILY_PARAMS))
