@@ -34,6 +34,25 @@ class AtariPostProcess:
             num_envs, stack_num, raw_height, raw_width, img_height, img_width,
             1 if use_inter_area_resize else 0, device, ctypes.byref(h)))
         self._h = h
+        self._frames = None  # pinned frame buffer handed to the emulator loop
+        from envpool_amd.core.device_pool import _PinnedBlocks
+
+        self._blocks = _PinnedBlocks(self._lib)
+
+    def frame_buffer(self) -> np.ndarray:
+        """Pinned host array [num_envs, 2, raw_h, raw_w] u8 for the emulator loop to write
+        `maxpool_buf_[0/1]` into (atari_env.h:230-237): `push` then uploads straight from it
+        with `hipMemcpyAsync`, chunk by chunk, overlapped with the kernel and the download of
+        the previous chunk.  (Pageable arrays work too, at about 2/3 of the rate.)"""
+        if self._frames is None:
+            nb = self.num_envs * 2 * self.raw_hw[0] * self.raw_hw[1]
+            ptr = self._lib.epa_host_alloc(nb)
+            if not ptr:
+                raise MemoryError(f"epa_host_alloc({nb}) failed")
+            self._frames_ptr = ptr
+            self._frames = np.ctypeslib.as_array((ctypes.c_ubyte * nb).from_address(ptr)).reshape(
+                self.num_envs, 2, *self.raw_hw)
+        return self._frames
 
     def push(self, frames: np.ndarray, env_id: np.ndarray | None = None,
              reset_mask: np.ndarray | None = None) -> np.ndarray:
@@ -45,7 +64,10 @@ class AtariPostProcess:
         mask = None
         if reset_mask is not None:
             mask = np.ascontiguousarray(reset_mask, dtype=np.uint8)
-        obs = np.empty((k, self.stack_num, *self.out_hw), dtype=np.uint8)
+        # observations land in a pinned block that the returned array owns (recycled when it
+        # is garbage collected), like DevicePool.recv
+        nb = k * self.stack_num * self.out_hw[0] * self.out_hw[1]
+        obs = self._blocks.take(max(nb, 1))[:nb].reshape(k, self.stack_num, *self.out_hw)
         native.check(self._lib.epa_atari_post_push(
             self._h, ids.ctypes.data, k, frames.ctypes.data,
             mask.ctypes.data if mask is not None else None, obs.ctypes.data))
@@ -64,8 +86,13 @@ class AtariPostProcess:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
-            self._lib.epa_atari_post_destroy(self._h)
+            self._lib.epa_atari_post_destroy(self._h)  # drains the streams first
             self._h = None
+        if getattr(self, "_frames", None) is not None:
+            self._frames = None
+            self._lib.epa_host_free(self._frames_ptr)
+        if getattr(self, "_blocks", None) is not None:
+            self._blocks.close()
 
     def __del__(self) -> None:
         try:

@@ -252,6 +252,12 @@ struct epa_atari_post {
   int* d_ids{nullptr};
   int cap{0};
   int max_xtap{epa::kMaxTap}, max_ytap{epa::kMaxTap};
+  // host path pipeline: frames go up, kernels run and observations come down on
+  // three streams, in chunks linked by events, so the two PCIe directions and the
+  // kernel overlap
+  static constexpr int kChunks = 4;
+  hipStream_t h2d{nullptr}, d2h{nullptr};
+  hipEvent_t up[kChunks]{}, done[kChunks]{};
 };
 
 namespace {
@@ -335,6 +341,12 @@ int epa_atari_post_create(int32_t num_envs, int32_t stack_num, int32_t in_h,
     p->device = device;
     EPA_HIP(hipSetDevice(device));
     EPA_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    EPA_HIP(hipStreamCreateWithFlags(&p->h2d, hipStreamNonBlocking));
+    EPA_HIP(hipStreamCreateWithFlags(&p->d2h, hipStreamNonBlocking));
+    for (int c = 0; c < epa_atari_post::kChunks; ++c) {
+      EPA_HIP(hipEventCreateWithFlags(&p->up[c], hipEventDisableTiming));
+      EPA_HIP(hipEventCreateWithFlags(&p->done[c], hipEventDisableTiming));
+    }
     p->d.n = num_envs;
     p->d.s = stack_num;
     p->d.sh = in_h;
@@ -371,6 +383,12 @@ int epa_atari_post_destroy(epa_atari_post* p) {
     if (p->d_mask) (void)hipFree(p->d_mask);
     if (p->d_ids) (void)hipFree(p->d_ids);
     (void)hipStreamDestroy(p->stream);
+    if (p->h2d) (void)hipStreamDestroy(p->h2d);
+    if (p->d2h) (void)hipStreamDestroy(p->d2h);
+    for (int c = 0; c < epa_atari_post::kChunks; ++c) {
+      if (p->up[c]) (void)hipEventDestroy(p->up[c]);
+      if (p->done[c]) (void)hipEventDestroy(p->done[c]);
+    }
     delete p;
   });
 }
@@ -398,14 +416,28 @@ int epa_atari_post_push(epa_atari_post* p, const int32_t* env_id, int32_t k,
       EPA_HIP(hipMalloc(&p->d_ids, sizeof(int) * p->d.n));
       p->cap = p->d.n;
     }
-    EPA_HIP(hipMemcpyAsync(p->d_frames, frames, fsz * k, hipMemcpyHostToDevice, p->stream));
-    EPA_HIP(hipMemcpyAsync(p->d_ids, env_id, sizeof(int) * k, hipMemcpyHostToDevice, p->stream));
-    if (reset_mask) {
-      EPA_HIP(hipMemcpyAsync(p->d_mask, reset_mask, k, hipMemcpyHostToDevice, p->stream));
-    }
-    LaunchPost(p, p->d_ids, k, p->d_frames, reset_mask ? p->d_mask : nullptr, p->d_obs);
-    EPA_HIP(hipMemcpyAsync(obs_out, p->d_obs, osz * k, hipMemcpyDeviceToHost, p->stream));
+    // the kernel stream may still hold device-path work of the caller
     EPA_HIP(hipStreamSynchronize(p->stream));
+    EPA_HIP(hipMemcpyAsync(p->d_ids, env_id, sizeof(int) * k, hipMemcpyHostToDevice, p->h2d));
+    if (reset_mask) {
+      EPA_HIP(hipMemcpyAsync(p->d_mask, reset_mask, k, hipMemcpyHostToDevice, p->h2d));
+    }
+    const int nchunk = k >= 64 ? epa_atari_post::kChunks : 1;
+    for (int c = 0; c < nchunk; ++c) {
+      const int r0 = (int)((long long)k * c / nchunk), r1 = (int)((long long)k * (c + 1) / nchunk);
+      if (r1 == r0) continue;
+      EPA_HIP(hipMemcpyAsync(p->d_frames + fsz * r0, frames + fsz * r0, fsz * (r1 - r0),
+                             hipMemcpyHostToDevice, p->h2d));
+      EPA_HIP(hipEventRecord(p->up[c], p->h2d));
+      EPA_HIP(hipStreamWaitEvent(p->stream, p->up[c], 0));
+      LaunchPost(p, p->d_ids + r0, r1 - r0, p->d_frames + fsz * r0,
+                 reset_mask ? p->d_mask + r0 : nullptr, p->d_obs + osz * r0);
+      EPA_HIP(hipEventRecord(p->done[c], p->stream));
+      EPA_HIP(hipStreamWaitEvent(p->d2h, p->done[c], 0));
+      EPA_HIP(hipMemcpyAsync(obs_out + osz * r0, p->d_obs + osz * r0, osz * (r1 - r0),
+                             hipMemcpyDeviceToHost, p->d2h));
+    }
+    EPA_HIP(hipStreamSynchronize(p->d2h));
   });
 }
 
