@@ -1,56 +1,53 @@
-"""Task ids of envpool/mujoco/gym/registration.py:21-93 (hot-path tasks only)."""
+"""Task ids of the gym-MuJoCo families that have a HIP kernel.
+
+The ids, `max_episode_steps` and the per-version overrides restate
+envpool/mujoco/gym/registration.py:21-93; they are kept here as one table so the
+version differences can be read at a glance.  `post_constraint` is True for v5 only
+(mj_rnePostConstraint after the frame_skip loop, mujoco_env.h:145-147).
+"""
 from envpool_amd.registration import register
 
-gym_mujoco_envs = [
-    ("Ant", ("v3", "v4", "v5"), 1000),
-    ("HalfCheetah", ("v3", "v4", "v5"), 1000),
-    ("Hopper", ("v3", "v4", "v5"), 1000),
-    ("InvertedDoublePendulum", ("v2", "v4", "v5"), 1000),
-    ("InvertedPendulum", ("v2", "v4", "v5"), 1000),
-    ("Reacher", ("v2", "v4", "v5"), 50),
-    ("Swimmer", ("v3", "v4", "v5"), 1000),
-    ("Walker2d", ("v3", "v4", "v5"), 1000),
-]
+_V5_CAMERA = {"gymnasium_v5_render_camera": True}
 
-for task, versions, max_episode_steps in gym_mujoco_envs:
-    for version in versions:
-        extra_args = {}
-        if version == "v5":
-            extra_args["gymnasium_v5_render_camera"] = True
-        if task == "Ant" and version == "v3":  # gym/registration.py:39-40
-            extra_args["use_contact_force"] = True
-        if task == "Ant" and version == "v5":  # gym/registration.py:41-46
-            extra_args.update({
-                "use_contact_force": True,
-                "legacy_healthy_reward": False,
-                "exclude_worldbody_contact_forces": True,
-            })
-        if task == "Hopper" and version == "v5":  # gym/registration.py:47-48
-            extra_args["legacy_healthy_reward"] = False
-        if task == "InvertedDoublePendulum" and version == "v5":  # gym/registration.py:61-65
-            extra_args.update({
-                "constraint_obs_dim": 1,
-                "reward_if_not_terminated": True,
-            })
-        if task == "InvertedPendulum" and version == "v5":  # gym/registration.py:66-67
-            extra_args["reward_if_not_terminated"] = True
-        if task == "Reacher" and version == "v5":  # gym/registration.py:74-78
-            extra_args.update({
-                "reward_after_step": True,
-                "obs_include_z_distance": False,
-            })
-        if task == "Walker2d" and version == "v5":  # gym/registration.py:79-83
-            extra_args.update({
-                "xml_file": "walker2d_v5.xml",
-                "legacy_healthy_reward": False,
-            })
+# task -> (max_episode_steps, {version: extra config})
+_TASKS = {
+    "Ant": (1000, {
+        "v3": {"use_contact_force": True},
+        "v4": {},
+        "v5": {"use_contact_force": True, "legacy_healthy_reward": False,
+               "exclude_worldbody_contact_forces": True},
+    }),
+    "HalfCheetah": (1000, {"v3": {}, "v4": {}, "v5": {}}),
+    "Hopper": (1000, {"v3": {}, "v4": {}, "v5": {"legacy_healthy_reward": False}}),
+    "InvertedDoublePendulum": (1000, {
+        "v2": {}, "v4": {},
+        "v5": {"constraint_obs_dim": 1, "reward_if_not_terminated": True},
+    }),
+    "InvertedPendulum": (1000, {"v2": {}, "v4": {}, "v5": {"reward_if_not_terminated": True}}),
+    "Reacher": (50, {
+        "v2": {}, "v4": {},
+        "v5": {"reward_after_step": True, "obs_include_z_distance": False},
+    }),
+    "Swimmer": (1000, {"v3": {}, "v4": {}, "v5": {}}),
+    "Walker2d": (1000, {
+        "v3": {}, "v4": {},
+        "v5": {"xml_file": "walker2d_v5.xml", "legacy_healthy_reward": False},
+    }),
+}
+# Humanoid, HumanoidStandup (PGS solver, self collisions, tendons) and Pusher have no
+# kernel yet and are not registered.
+
+for _task, (_steps, _versions) in _TASKS.items():
+    for _version, _extra in _versions.items():
+        _cfg = dict(_V5_CAMERA) if _version == "v5" else {}
+        _cfg.update(_extra)
         register(
-            task_id=f"{task}-{version}",
+            task_id=f"{_task}-{_version}",
             import_path="envpool_amd.mujoco.gym",
-            spec_cls=f"Gym{task}EnvSpec",
-            dm_cls=f"Gym{task}DMEnvPool",
-            gymnasium_cls=f"Gym{task}GymnasiumEnvPool",
-            post_constraint=(version == "v5"),
-            max_episode_steps=max_episode_steps,
-            **extra_args,
+            spec_cls=f"Gym{_task}EnvSpec",
+            dm_cls=f"Gym{_task}DMEnvPool",
+            gymnasium_cls=f"Gym{_task}GymnasiumEnvPool",
+            post_constraint=_version == "v5",
+            max_episode_steps=_steps,
+            **_cfg,
         )
