@@ -197,3 +197,44 @@ def test_recv_arrays_own_their_memory_zero_copy():
     pool.send(ids, rng.integers(0, 2, n).astype(np.int32))
     a = pool.recv()
     assert a[0].__array_interface__["data"][0] in addrs
+
+
+@pytest.mark.parametrize("task,adim", [("HalfCheetah", 6), ("Walker2d", 6), ("Ant", 8)])
+def test_results_independent_of_batch_composition(task, adim):
+    """An env's trajectory must not depend on which other envs share its batch / wave
+    (the reference's envs are independent objects): the sync pool (all envs per step)
+    and an async pool (batch_size = n / 4, several batches in flight, rows arriving in
+    shuffled groups) produce bit-identical observations for every (env, step)."""
+    from envpool_amd.core.device_pool import DevicePool
+
+    n, T = 256, 12
+    acts = np.random.default_rng(5).uniform(-1, 1, size=(T + 8, n, adim))  # [step, env]
+    ids = np.arange(n, dtype=np.int32)
+    sync = DevicePool(task, n, seed=11, max_episode_steps=1000)
+    sync.reset(ids)
+    first = sync.recv_dict()
+    ref, ref_el = [first["obs"].copy()], [first["elapsed_step"].ravel().copy()]
+    for t in range(T):
+        sync.send(ids, acts[t])
+        out = sync.recv_dict()
+        ref.append(out["obs"].copy())
+        ref_el.append(out["elapsed_step"].ravel().copy())  # episodes may end and auto-reset
+    ref, ref_el = np.stack(ref), np.stack(ref_el)  # [T + 1, n, ...]
+
+    apool = DevicePool(task, n, batch_size=n // 4, seed=11, max_episode_steps=1000)
+    perm = np.random.default_rng(0).permutation(n).astype(np.int32)
+    for c in range(4):  # resets submitted in shuffled groups: 4 batches in flight
+        apool.reset(perm[c * (n // 4):(c + 1) * (n // 4)])
+    count = np.zeros(n, dtype=np.int64)  # rows received so far per env = index of its next row
+    checked = 0
+    while count.min() <= T:
+        out = apool.recv_dict()
+        eid = out["info:env_id"].ravel()
+        t = count[eid]
+        ok = t <= T
+        np.testing.assert_array_equal(out["obs"][ok], ref[t[ok], eid[ok]])
+        np.testing.assert_array_equal(out["elapsed_step"].ravel()[ok], ref_el[t[ok], eid[ok]])
+        checked += int(ok.sum())
+        count[eid] += 1
+        apool.send(eid, acts[np.minimum(t, T + 7), eid])  # every row goes straight back in
+    assert checked == n * (T + 1)
