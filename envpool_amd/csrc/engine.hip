@@ -15,6 +15,8 @@ namespace {
 thread_local std::string g_last_error;
 
 size_t Align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+// host-path transfers below this size stay on the kernel stream (see Pool::Send)
+constexpr size_t kSplitStreamBytes = 256 * 1024;
 
 __global__ void InitCommonKernel(CommonDev c, int seed, const int* env_seed,
                                  int id_offset, int with_rng) {
@@ -355,12 +357,18 @@ void Pool::Send(const int32_t* env_id, int k, const void* action) {
   if (!identity) std::memcpy(s.h, env_id, (size_t)k * 4);
   std::memcpy(s.h + id_bytes, action, act_bytes);
   // upload on its own stream: it overlaps the kernel of the previous batch; the
-  // step kernel only waits for this slot's upload
-  EPA_HIP(hipMemcpyAsync(s.d + copy_from, s.h + copy_from,
-                         id_bytes + act_bytes - copy_from,
-                         hipMemcpyHostToDevice, h2d_stream_));
-  EPA_HIP(hipEventRecord(s.h2d_ev, h2d_stream_));
-  EPA_HIP(hipStreamWaitEvent(stream_, s.h2d_ev, 0));
+  // step kernel only waits for this slot's upload.  Tiny batches stay on the kernel
+  // stream: there the extra event round trip costs more than the overlap gains.
+  const size_t up_bytes = id_bytes + act_bytes - copy_from;
+  if (up_bytes >= kSplitStreamBytes) {
+    EPA_HIP(hipMemcpyAsync(s.d + copy_from, s.h + copy_from, up_bytes, hipMemcpyHostToDevice,
+                           h2d_stream_));
+    EPA_HIP(hipEventRecord(s.h2d_ev, h2d_stream_));
+    EPA_HIP(hipStreamWaitEvent(stream_, s.h2d_ev, 0));
+  } else {
+    EPA_HIP(hipMemcpyAsync(s.d + copy_from, s.h + copy_from, up_bytes, hipMemcpyHostToDevice,
+                           stream_));
+  }
   Enqueue(identity ? nullptr : reinterpret_cast<const int*>(s.d), k,
           s.d + id_bytes, false);
   EPA_HIP(hipEventRecord(s.free_ev, stream_));
@@ -381,10 +389,7 @@ void Pool::Reset(const int32_t* env_ids, int k) {
   size_t id_bytes = Align((size_t)k * 4);
   Staging& s = NextStaging(id_bytes);
   std::memcpy(s.h, env_ids, (size_t)k * 4);
-  EPA_HIP(hipMemcpyAsync(s.d, s.h, (size_t)k * 4, hipMemcpyHostToDevice,
-                         h2d_stream_));
-  EPA_HIP(hipEventRecord(s.h2d_ev, h2d_stream_));
-  EPA_HIP(hipStreamWaitEvent(stream_, s.h2d_ev, 0));
+  EPA_HIP(hipMemcpyAsync(s.d, s.h, (size_t)k * 4, hipMemcpyHostToDevice, stream_));
   Enqueue(reinterpret_cast<const int*>(s.d), k, nullptr, true);
   EPA_HIP(hipEventRecord(s.free_ev, stream_));
   s.in_use = true;
@@ -440,23 +445,24 @@ size_t Pool::RecvLayout(int rows, size_t* offsets, int n_keys) const {
 // RecvLayout(want); waits for completion.
 void Pool::CopyRowsToHost(char* dst, const std::vector<size_t>& off, int want) {
   size_t total = off.back() + Align((size_t)want * keys_.back().row_bytes());
+  // small batches: copy on the kernel stream itself (no event round trip)
+  hipStream_t cs = total >= kSplitStreamBytes ? d2h_stream_ : stream_;
   int got = 0;
   while (got < want) {
     Batch* b = pending_.front();
     int take = std::min(want - got, b->k - b->consumed);
     // the copies go on the download stream, behind the kernel that produced the
     // rows (its `done` event) but NOT behind kernels enqueued after it
-    EPA_HIP(hipStreamWaitEvent(d2h_stream_, b->done, 0));
+    if (cs != stream_) EPA_HIP(hipStreamWaitEvent(cs, b->done, 0));
     if (got == 0 && take == want && b->consumed == 0 && take == b->k) {
       // whole batch: one D2H of the packed block (offsets coincide)
-      EPA_HIP(hipMemcpyAsync(dst, b->dbuf, total, hipMemcpyDeviceToHost, d2h_stream_));
+      EPA_HIP(hipMemcpyAsync(dst, b->dbuf, total, hipMemcpyDeviceToHost, cs));
     } else {
       for (size_t i = 0; i < keys_.size(); ++i) {
         size_t rb = keys_[i].row_bytes();
         EPA_HIP(hipMemcpyAsync(dst + off[i] + (size_t)got * rb,
                                b->dbuf + b->offsets[i] + (size_t)b->consumed * rb,
-                               (size_t)take * rb, hipMemcpyDeviceToHost,
-                               d2h_stream_));
+                               (size_t)take * rb, hipMemcpyDeviceToHost, cs));
       }
     }
     b->consumed += take;
@@ -467,7 +473,7 @@ void Pool::CopyRowsToHost(char* dst, const std::vector<size_t>& off, int want) {
                         // later Send can hand the buffer to another kernel (mu_ is held)
     }
   }
-  EPA_HIP(hipStreamSynchronize(d2h_stream_));
+  EPA_HIP(hipStreamSynchronize(cs));
 }
 
 int Pool::Recv(void* const* out_ptrs, int n_ptrs, int cap_rows) {
