@@ -281,3 +281,62 @@ def test_dm_adaptor_contract(fake_pool):
     assert ts.reward.dtype == np.float32 and ts.discount.shape == (2,)
     assert env.action_spec().num_values == 3
     assert env.observation_spec().obs.shape == (6,)
+
+
+def test_default_config_tables_match_reference_headers():
+    """tests/golden/spec_defaults.json was extracted from the reference's C++
+    `DefaultConfig()` tables (tests/golden/make_spec_golden.py): every family's Python
+    table must list the same keys, in the same order, with the same defaults; the only
+    additions allowed are this engine's extension keys at the end."""
+    import importlib
+    import json
+    import os
+
+    from envpool_amd.core.binding import FamilyDef
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "spec_defaults.json")))
+    fams = {}
+    for mod in ("envpool_amd.classic_control", "envpool_amd.toy_text", "envpool_amd.mujoco.gym"):
+        m = importlib.import_module(mod)
+        for v in vars(m).values():
+            if isinstance(v, FamilyDef):
+                fams[v.name] = v
+    assert set(gold) <= set(fams), set(gold) - set(fams)
+    extensions = {"precision"}
+    for name, g in gold.items():
+        mine = [(k, v) for k, v in fams[name].default_config]
+        ref = [tuple(kv) for kv in g["default_config"]]
+        assert mine[:len(ref)] == ref, (name, g["source"], mine[:len(ref)], ref)
+        assert {k for k, _ in mine[len(ref):]} <= extensions, (name, mine[len(ref):])
+
+
+def test_registry_matches_reference_registration_modules():
+    """tests/golden/registry.json records what the reference's own registration modules
+    pass to `register` (tests/golden/make_registry_golden.py).  Every id this engine
+    registers must carry the same class names and keyword arguments (aliases included);
+    the reference ids it does not register are the families without a kernel."""
+    import json
+    import os
+
+    from envpool_amd.registration import registry
+
+    envpool.list_all_envs()  # imports every registration module
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "registry.json")))
+    missing = sorted(set(gold) - set(registry.specs))
+    assert all(m.split("-")[0] in ("Humanoid", "HumanoidStandup", "Pusher") for m in missing), missing
+    checked = 0
+    for task_id, g in gold.items():
+        if task_id not in registry.specs:
+            continue
+        import_path, spec_cls, kwargs = registry.specs[task_id]
+        assert import_path == g["import_path"].replace("envpool.", "envpool_amd.", 1)
+        assert spec_cls == g["spec_cls"]
+        assert registry.envpools[task_id]["dm"][1] == g["dm_cls"]
+        assert registry.envpools[task_id]["gymnasium"][1] == g["gymnasium_cls"]
+        want = dict(g["kwargs"])
+        for alias in want.pop("aliases", []):
+            assert registry.specs[alias][1] == spec_cls, alias
+        mine = {k: v for k, v in kwargs.items() if k != "base_path"}
+        assert mine == want, (task_id, mine, want)
+        checked += 1
+    assert checked >= 40
