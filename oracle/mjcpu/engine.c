@@ -335,9 +335,13 @@ static int geoms_can_collide(const mjc_model* m, int g1, int g2) {
         (m->geom_contype[g2] & m->geom_conaffinity[g1]))) {
     return 0;
   }
-  /* filterparent: no collisions between a body and its parent, unless the parent is
-   * the (static) world body */
-  if (b1 != 0 && b2 != 0 && (m->body_parent[b1] == b2 || m->body_parent[b2] == b1)) return 0;
+  /* bodies without joints are welded to their parent and filtered as one body
+   * (body_weldid); filterparent: no collisions between a (weld) body and its parent,
+   * unless the parent is the (static) world body */
+  int w1 = m->body_weldid[b1], w2 = m->body_weldid[b2];
+  if (w1 == w2) return 0;
+  int p1 = m->body_weldid[m->body_parent[w1]], p2 = m->body_weldid[m->body_parent[w2]];
+  if (w1 != 0 && w2 != 0 && (w1 == p2 || w2 == p1)) return 0;
   return 1;
 }
 
@@ -384,12 +388,36 @@ static void collision(const mjc_model* m, mjc_data* d) {
       }
     }
   }
-  /* body-body pairs: capsule-capsule only (the hopper's self collisions) */
-  for (int g1 = 0; g1 < m->ngeom && !m->disable_selfcollide; ++g1) {
-    if (m->geom_type[g1] != MJC_GEOM_CAPSULE) continue;
-    for (int g2 = g1 + 1; g2 < m->ngeom; ++g2) {
-      if (m->geom_type[g2] != MJC_GEOM_CAPSULE || !geoms_can_collide(m, g1, g2)) continue;
-      add_capsule_capsule(m, d, g1, g2, fmax(m->geom_margin[g1], m->geom_margin[g2]));
+  /* body-body pairs (hopper, humanoid self collisions): sphere / capsule primitives.
+   * Pairs are visited in (geom1 < geom2) order, which is body-pair order because geoms are
+   * numbered body by body; mj_collideGeoms puts the lower geom TYPE first, so a capsule
+   * vs a later sphere is reported as (sphere, capsule) with the normal from the sphere. */
+  for (int ga = 0; ga < m->ngeom && !m->disable_selfcollide; ++ga) {
+    if (m->geom_type[ga] == MJC_GEOM_PLANE) continue;
+    for (int gb = ga + 1; gb < m->ngeom; ++gb) {
+      if (m->geom_type[gb] == MJC_GEOM_PLANE || !geoms_can_collide(m, ga, gb)) continue;
+      int g1 = ga, g2 = gb;
+      if (m->geom_type[g1] > m->geom_type[g2]) {
+        g1 = gb;
+        g2 = ga;
+      }
+      double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
+      if (m->geom_type[g1] == MJC_GEOM_CAPSULE) { /* both capsules */
+        add_capsule_capsule(m, d, g1, g2, margin);
+      } else if (m->geom_type[g2] == MJC_GEOM_SPHERE) { /* both spheres */
+        add_sphere_sphere(m, d, g1, g2, d->geom_xpos[g1], m->geom_size[g1][0], d->geom_xpos[g2],
+                          m->geom_size[g2][0], margin);
+      } else { /* mjraw_SphereCapsule: closest point of the capsule axis to the centre */
+        const double* cm = d->geom_xmat[g2];
+        double axis[3] = {cm[2], cm[5], cm[8]}, dif[3], p[3];
+        v3_sub(dif, d->geom_xpos[g1], d->geom_xpos[g2]);
+        double x = v3_dot(axis, dif), hl = m->geom_size[g2][1];
+        x = x > hl ? hl : (x < -hl ? -hl : x);
+        v3_copy(p, d->geom_xpos[g2]);
+        v3_addscl(p, axis, x);
+        add_sphere_sphere(m, d, g1, g2, d->geom_xpos[g1], m->geom_size[g1][0], p,
+                          m->geom_size[g2][0], margin);
+      }
     }
   }
 }
@@ -681,6 +709,82 @@ static double constraint_cost(const mjc_data* d, int nefc, const double* jar) {
   return c;
 }
 
+/* mj_solPGS on the dual problem  min_f 1/2 f'(A+R)f + f'b,  f >= 0  with
+ * A = J M^-1 J' (mj_projectConstraint) and b = J qacc_smooth - aref.  Unlike Newton
+ * this is NOT run to convergence (humanoid.xml: iterations=50), so sweep order, the
+ * warm start and the stopping rule are part of the result:
+ *  - warm start: forces of qacc_warmstart through the primal law f = -D min(0, J a - aref);
+ *    kept only if their dual cost is below the cost of f = 0 (which is 0);
+ *  - one sweep: rows in order, f_i <- max(0, f_i - res_i / AR_ii), res_i = AR_i. f + b_i;
+ *    a row update that raises the cost by more than 1e-10 is reverted;
+ *  - stop when scale * (cost decrease of the sweep) < tolerance (1e-8). */
+static _Thread_local double pgs_AR[MJC_MAXEFC * MJC_MAXEFC];
+static _Thread_local double pgs_W[MJC_MAXEFC][MJC_MAXV];
+
+static void fwd_constraint_pgs(const mjc_model* m, mjc_data* d) {
+  int nv = m->nv, nefc = d->nefc;
+  double L[MJC_MAXV * MJC_MAXV], b[MJC_MAXEFC];
+  double* f = d->efc_force;
+  for (int i = 0; i < nv; ++i) {
+    for (int j = 0; j < nv; ++j) L[i * nv + j] = d->M[i][j];
+  }
+  chol_factor(L, nv);
+  for (int r = 0; r < nefc; ++r) {
+    memcpy(pgs_W[r], d->efc_J[r], sizeof(double) * nv);
+    chol_solve(L, nv, pgs_W[r]);
+  }
+  for (int r = 0; r < nefc; ++r) {
+    for (int c = 0; c < nefc; ++c) {
+      double s = 0;
+      for (int i = 0; i < nv; ++i) s += d->efc_J[r][i] * pgs_W[c][i];
+      pgs_AR[r * nefc + c] = s;
+    }
+    pgs_AR[r * nefc + r] += d->efc_R[r];
+    double s = 0, w = 0;
+    for (int i = 0; i < nv; ++i) {
+      s += d->efc_J[r][i] * d->qacc_smooth[i];
+      w += d->efc_J[r][i] * d->qacc_warmstart[i];
+    }
+    b[r] = s - d->efc_aref[r];
+    double jar = w - d->efc_aref[r];
+    f[r] = jar < 0 ? -d->efc_D[r] * jar : 0;
+  }
+  double cost = 0;
+  for (int r = 0; r < nefc; ++r) {
+    double s = 0;
+    for (int c = 0; c < nefc; ++c) s += pgs_AR[r * nefc + c] * f[c];
+    cost += 0.5 * f[r] * s + f[r] * b[r];
+  }
+  if (cost > 0) memset(f, 0, sizeof(double) * nefc);
+  double scale = 1 / (m->meaninertia * (nv > 1 ? nv : 1));
+  for (int iter = 0; iter < m->iterations; ++iter) {
+    double improvement = 0;
+    for (int r = 0; r < nefc; ++r) {
+      double res = b[r];
+      for (int c = 0; c < nefc; ++c) res += pgs_AR[r * nefc + c] * f[c];
+      double old = f[r], Arr = pgs_AR[r * nefc + r];
+      f[r] -= res / Arr;
+      if (f[r] < 0) f[r] = 0;
+      double delta = f[r] - old;
+      double change = 0.5 * delta * delta * Arr + delta * res;
+      if (change > 1e-10) {
+        f[r] = old;
+        change = 0;
+      }
+      improvement -= change;
+    }
+    d->solver_iter = iter + 1;
+    if (improvement * scale < 1e-8) break;
+  }
+  for (int r = 0; r < nefc; ++r) {
+    for (int i = 0; i < nv; ++i) d->qfrc_constraint[i] += d->efc_J[r][i] * f[r];
+  }
+  memcpy(d->qacc, d->qfrc_constraint, sizeof(double) * nv);
+  chol_solve(L, nv, d->qacc);
+  for (int i = 0; i < nv; ++i) d->qacc[i] += d->qacc_smooth[i];
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+}
+
 static void fwd_constraint(const mjc_model* m, mjc_data* d) {
   int nv = m->nv, nefc = d->nefc;
   d->solver_iter = 0;
@@ -688,6 +792,10 @@ static void fwd_constraint(const mjc_model* m, mjc_data* d) {
   if (nefc == 0) {
     memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
     memcpy(d->qacc_warmstart, d->qacc_smooth, sizeof(double) * nv);
+    return;
+  }
+  if (m->solver == MJC_SOL_PGS) {
+    fwd_constraint_pgs(m, d);
     return;
   }
   /* efc_vel / aref were built in make_constraint with the current qvel */

@@ -2,8 +2,8 @@
  *
  * oracle/mjcpu: float64 CPU restatement of the part of the MuJoCo 3.6.0
  * pipeline that `mj_step` / `mj_forward` execute for the gym HalfCheetah, Ant,
- * Walker2d, InvertedPendulum and InvertedDoublePendulum models, plus the task
- * logic around it.
+ * Walker2d, Hopper, Swimmer, Reacher, InvertedPendulum, InvertedDoublePendulum,
+ * Humanoid and HumanoidStandup models, plus the task logic around it.
  *
  * PARITY UNPINNED for the engine part: the arithmetic lives in the third-party
  * dependency google-deepmind/mujoco tag 3.6.0 (pinned in the reference at
@@ -29,17 +29,18 @@
 #define ORACLE_MJCPU_H_
 
 #define MJC_MAXBODY 16
-#define MJC_MAXJNT 16
-#define MJC_MAXQ 16
-#define MJC_MAXV 16
-#define MJC_MAXGEOM 16
-#define MJC_MAXU 8
-#define MJC_MAXCON 32
-#define MJC_MAXEFC 160
+#define MJC_MAXJNT 20
+#define MJC_MAXQ 24
+#define MJC_MAXV 24
+#define MJC_MAXGEOM 24
+#define MJC_MAXU 20
+#define MJC_MAXCON 64
+#define MJC_MAXEFC 256
 
 enum { MJC_JNT_FREE = 0, MJC_JNT_SLIDE = 2, MJC_JNT_HINGE = 3 };
 enum { MJC_GEOM_PLANE = 0, MJC_GEOM_SPHERE = 2, MJC_GEOM_CAPSULE = 3 };
 enum { MJC_INT_EULER = 0, MJC_INT_RK4 = 1 };
+enum { MJC_SOL_NEWTON = 0, MJC_SOL_PGS = 1 };
 
 typedef struct {
   int nq, nv, nu, nbody, njnt, ngeom;
@@ -47,10 +48,11 @@ typedef struct {
   double timestep, gravity[3];
   double opt_density, opt_viscosity; /* <option density viscosity>: medium for the fluid forces */
   int integrator;
+  int solver, iterations; /* <option solver iterations>: Newton / 100 unless the XML says otherwise */
   int disable_contact, disable_limit, disable_actuation; /* invariant tests */
   int disable_selfcollide; /* tests: drop body-body (capsule-capsule) pairs */
   /* bodies */
-  int body_parent[MJC_MAXBODY], body_rootid[MJC_MAXBODY];
+  int body_parent[MJC_MAXBODY], body_rootid[MJC_MAXBODY], body_weldid[MJC_MAXBODY];
   int body_jntadr[MJC_MAXBODY], body_jntnum[MJC_MAXBODY];
   int body_dofadr[MJC_MAXBODY], body_dofnum[MJC_MAXBODY];
   double body_pos[MJC_MAXBODY][3], body_quat[MJC_MAXBODY][4];
@@ -152,6 +154,7 @@ void mjc_build_inverted_double_pendulum(mjc_model* m);
 void mjc_build_reacher(mjc_model* m);
 void mjc_build_swimmer(mjc_model* m);
 void mjc_build_hopper(mjc_model* m);
+void mjc_build_humanoid(mjc_model* m, int standup);
 
 /* engine.c */
 void mjc_reset_data(const mjc_model* m, mjc_data* d);

@@ -17,6 +17,8 @@ void mjc_model_init(mjc_model* m) {
   m->timestep = 0.002;
   m->gravity[2] = -9.81;
   m->integrator = MJC_INT_EULER;
+  m->solver = MJC_SOL_NEWTON;
+  m->iterations = 100;
   /* world body */
   m->nbody = 1;
   m->body_parent[0] = 0;
@@ -239,6 +241,10 @@ void mjc_compile(mjc_model* m) {
     int r = b;
     while (r > 0 && m->body_parent[r] > 0) r = m->body_parent[r];
     m->body_rootid[b] = r;
+    /* body_weldid: the nearest ancestor-or-self that moves relative to its parent */
+    int w = b;
+    while (w > 0 && m->body_dofnum[w] == 0) w = m->body_parent[w];
+    m->body_weldid[b] = w;
   }
   for (int d = 0; d < m->nv; ++d) {
     int b = m->dof_body[d];

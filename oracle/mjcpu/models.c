@@ -551,3 +551,156 @@ void mjc_build_hopper(mjc_model* m) {
   mjc_add_motor(m, j_foot, 200);
   mjc_compile(m);
 }
+
+/* ---- Humanoid / HumanoidStandup ------------------------------------------------
+ * humanoid_envpool.xml (line numbers below) and humanoidstandup_envpool.xml, which is
+ * the same kinematic tree laid on its back: only body / geom placements along the spine
+ * and the legs differ (and left_hip_y's lower range, :72), the diff is spelled out at
+ * each use of `su`.
+ *   <compiler angle="degree" inertiafromgeom="true"/>                             :18
+ *   <joint armature="1" damping="1" limited="true"/>                              :20
+ *   <geom conaffinity="1" condim="1" contype="1" margin="0.001" .../>             :21
+ *   <motor ctrllimited="true" ctrlrange="-.4 .4"/>                                :22
+ *   <option integrator="RK4" iterations="50" solver="PGS" timestep="0.003">       :24
+ * The two fixed tendons (:107-116) have no limit, spring or actuator: no effect. */
+static int hum_geom(mjc_model* m, int g) {
+  m->geom_conaffinity[g] = 1;
+  m->geom_contype[g] = 1;
+  m->geom_condim[g] = 1;
+  m->geom_margin[g] = 0.001;
+  return g;
+}
+static int hum_capsule(mjc_model* m, int body, double x0, double y0, double z0, double x1,
+                       double y1, double z1, double radius) {
+  const double from[3] = {x0, y0, z0}, to[3] = {x1, y1, z1};
+  return hum_geom(m, mjc_add_capsule_fromto(m, body, from, to, radius));
+}
+static int hum_sphere(mjc_model* m, int body, double x, double y, double z, double radius) {
+  const double size[3] = {radius, 0, 0}, pos[3] = {x, y, z}, quat[4] = {1, 0, 0, 0};
+  return hum_geom(m, mjc_add_geom(m, body, MJC_GEOM_SPHERE, size, pos, quat));
+}
+static int hum_hinge(mjc_model* m, int body, double px, double py, double pz, double ax,
+                     double ay, double az, double lo_deg, double hi_deg, double stiffness,
+                     double damping, double armature) {
+  const double pos[3] = {px, py, pz}, axis[3] = {ax, ay, az};
+  const double d2r = 3.14159265358979323846 / 180.0;
+  return mjc_add_joint(m, body, MJC_JNT_HINGE, pos, axis, 1, lo_deg * d2r, hi_deg * d2r,
+                       stiffness, damping, armature);
+}
+static int hum_body(mjc_model* m, int parent, double x, double y, double z) {
+  const double pos[3] = {x, y, z};
+  return mjc_add_body(m, parent, pos);
+}
+static void hum_quat(mjc_model* m, int b) { /* quat="1.000 0 -0.002 0", normalised :50,:54 */
+  double n = sqrt(1.0 + 0.002 * 0.002);
+  m->body_quat[b][0] = 1.0 / n;
+  m->body_quat[b][1] = 0;
+  m->body_quat[b][2] = -0.002 / n;
+  m->body_quat[b][3] = 0;
+}
+
+void mjc_build_humanoid(mjc_model* m, int su) {
+  const double size0[3] = {20, 20, 0.125}, quat0[4] = {1, 0, 0, 0};
+  mjc_model_init(m);
+  m->timestep = 0.003;          /* :24 */
+  m->integrator = MJC_INT_RK4;  /* :24 */
+  m->solver = MJC_SOL_PGS;      /* :24 */
+  m->iterations = 50;           /* :24 */
+  /* floor :41 (condim 3, friction 1 .1 .1; the class default gives it margin 0.001) */
+  int floor = hum_geom(m, mjc_add_geom(m, 0, MJC_GEOM_PLANE, size0, kZero3, quat0));
+  m->geom_condim[floor] = 3;
+  m->geom_friction[floor][0] = 1;
+  m->geom_friction[floor][1] = 0.1;
+  m->geom_friction[floor][2] = 0.1;
+  /* torso :43-48 (standup: pos 0 0 .105, head at -.15 0 0, uwaist at x=.11) */
+  int torso = hum_body(m, 0, 0, 0, su ? 0.105 : 1.4);
+  {
+    const double axis[3] = {0, 0, 1};
+    mjc_add_joint(m, torso, MJC_JNT_FREE, kZero3, axis, 0, 0, 0, 0, 0, 0); /* :45 */
+  }
+  hum_capsule(m, torso, 0, -.07, 0, 0, .07, 0, 0.07); /* torso1 :46 */
+  if (su) {
+    hum_sphere(m, torso, -.15, 0, 0, .09);                   /* head */
+    hum_capsule(m, torso, .11, -.06, 0, .11, .06, 0, 0.06);  /* uwaist */
+  } else {
+    hum_sphere(m, torso, 0, 0, .19, .09);                       /* head :47 */
+    hum_capsule(m, torso, -.01, -.06, -.12, -.01, .06, -.12, 0.06); /* uwaist :48 */
+  }
+  /* lwaist :49-52 */
+  int lwaist = su ? hum_body(m, torso, .21, 0, 0) : hum_body(m, torso, -.01, 0, -0.260);
+  hum_quat(m, lwaist);
+  hum_capsule(m, lwaist, 0, -.06, 0, 0, .06, 0, 0.06);
+  hum_hinge(m, lwaist, 0, 0, 0.065, 0, 0, 1, -45, 45, 20, 5, 0.02); /* abdomen_z :51 */
+  hum_hinge(m, lwaist, 0, 0, 0.065, 0, 1, 0, -75, 30, 10, 5, 0.02); /* abdomen_y :52 */
+  /* pelvis :53-55 */
+  int pelvis = su ? hum_body(m, lwaist, 0.165, 0, 0) : hum_body(m, lwaist, 0, 0, -0.165);
+  hum_quat(m, pelvis);
+  hum_hinge(m, pelvis, 0, 0, 0.1, 1, 0, 0, -35, 35, 10, 5, 0.02); /* abdomen_x :54 */
+  hum_capsule(m, pelvis, -.02, -.07, 0, -.02, .07, 0, 0.09);      /* butt :55 */
+  /* legs: right :56-68, left :69-81 */
+  for (int side = 0; side < 2; ++side) {
+    double s = side == 0 ? -1.0 : 1.0; /* right leg is at y = -0.1 */
+    int thigh = hum_body(m, pelvis, 0, s * 0.1, su ? 0 : -0.04);
+    if (side == 0) {
+      hum_hinge(m, thigh, 0, 0, 0, 1, 0, 0, -25, 5, 10, 5, 0.01);    /* right_hip_x :57 */
+      hum_hinge(m, thigh, 0, 0, 0, 0, 0, 1, -60, 35, 10, 5, 0.01);   /* right_hip_z :58 */
+      hum_hinge(m, thigh, 0, 0, 0, 0, 1, 0, -110, 20, 20, 5, 0.008); /* right_hip_y :59 */
+    } else {
+      hum_hinge(m, thigh, 0, 0, 0, -1, 0, 0, -25, 5, 10, 5, 0.01);  /* left_hip_x :70 */
+      hum_hinge(m, thigh, 0, 0, 0, 0, 0, -1, -60, 35, 10, 5, 0.01); /* left_hip_z :71 */
+      hum_hinge(m, thigh, 0, 0, 0, 0, 1, 0, su ? -120 : -110, 20, 20, 5, 0.01); /* left_hip_y :72 */
+    }
+    int shin;
+    if (su) {
+      hum_capsule(m, thigh, 0, 0, 0, 0.34, -s * 0.01, 0, 0.06);
+      shin = hum_body(m, thigh, 0.403, -s * 0.01, 0);
+    } else {
+      hum_capsule(m, thigh, 0, 0, 0, 0, -s * 0.01, -.34, 0.06); /* thigh1 :60 / :73 */
+      shin = hum_body(m, thigh, 0, -s * 0.01, -0.403);          /* :61 / :74 */
+    }
+    /* knee :62 (right: no stiffness) / :75 (left: stiffness 1); damping is the class default 1 */
+    hum_hinge(m, shin, 0, 0, .02, 0, -1, 0, -160, -2, side == 0 ? 0 : 1, 1, 0.006);
+    int foot;
+    if (su) {
+      hum_capsule(m, shin, 0, 0, 0, 0.3, 0, 0, 0.049);
+      foot = hum_body(m, shin, 0.35, 0, -.10);
+    } else {
+      hum_capsule(m, shin, 0, 0, 0, 0, 0, -.3, 0.049); /* shin1 :63 */
+      foot = hum_body(m, shin, 0, 0, -0.45);           /* :64 */
+    }
+    hum_sphere(m, foot, 0, 0, 0.1, 0.075); /* :65 */
+  }
+  /* arms: right :84-94, left :95-104 */
+  for (int side = 0; side < 2; ++side) {
+    double s = side == 0 ? -1.0 : 1.0;
+    int uarm = hum_body(m, torso, 0, s * 0.17, 0.06);
+    if (side == 0) {
+      hum_hinge(m, uarm, 0, 0, 0, 2, 1, 1, -85, 60, 1, 1, 0.0068);  /* right_shoulder1 :85 */
+      hum_hinge(m, uarm, 0, 0, 0, 0, -1, 1, -85, 60, 1, 1, 0.0051); /* right_shoulder2 :86 */
+    } else {
+      hum_hinge(m, uarm, 0, 0, 0, 2, -1, 1, -60, 85, 1, 1, 0.0068); /* left_shoulder1 :96 */
+      hum_hinge(m, uarm, 0, 0, 0, 0, 1, 1, -60, 85, 1, 1, 0.0051);  /* left_shoulder2 :97 */
+    }
+    hum_capsule(m, uarm, 0, 0, 0, .16, s * .16, -.16, 0.04); /* uarm1 :87 / :98 */
+    int larm = hum_body(m, uarm, .18, s * .18, -.18);        /* :88 / :99 */
+    if (side == 0) {
+      hum_hinge(m, larm, 0, 0, 0, 0, -1, 1, -90, 50, 0, 1, 0.0028); /* right_elbow :89 */
+    } else {
+      hum_hinge(m, larm, 0, 0, 0, 0, -1, -1, -90, 50, 0, 1, 0.0028); /* left_elbow :100 */
+    }
+    hum_capsule(m, larm, 0.01, -s * 0.01, 0.01, .17, -s * .17, .17, 0.031); /* larm :90 / :101 */
+    hum_sphere(m, larm, .18, -s * .18, .18, 0.04);                          /* hand :91 / :102 */
+  }
+  /* actuators :118-136: joint ids are 0 root, 1 abdomen_z, 2 abdomen_y, 3 abdomen_x,
+   * 4-6 right hip x z y, 7 right knee, 8-10 left hip x z y, 11 left knee,
+   * 12-14 right shoulder1 shoulder2 elbow, 15-17 left */
+  static const int jnt[17] = {2, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17};
+  static const double gear[17] = {100, 100, 100, 100, 100, 300, 200, 100, 100,
+                                  300, 200, 25,  25,  25,  25,  25,  25};
+  for (int u = 0; u < 17; ++u) {
+    int a = mjc_add_motor(m, jnt[u], gear[u]);
+    m->act_ctrlrange[a][0] = -0.4;
+    m->act_ctrlrange[a][1] = 0.4;
+  }
+  mjc_compile(m);
+}

@@ -30,9 +30,11 @@ typedef struct {
   orc_mt19937 gen;
   orc_normal_state nstate; /* dist_qvel_ member: persists across resets */
   int current_step, done, elapsed_step;
+  int lag_set;       /* set_state gave the lagged mass centre (humanoid tasks) */
+  double lag_mc[2];
 } mj_env;
 
-enum { TASK_CHEETAH = 0, TASK_ANT = 1, TASK_WALKER = 2, TASK_IPEND = 3, TASK_IDPEND = 4, TASK_REACHER = 5, TASK_SWIMMER = 6, TASK_HOPPER = 7 };
+enum { TASK_CHEETAH = 0, TASK_ANT = 1, TASK_WALKER = 2, TASK_IPEND = 3, TASK_IDPEND = 4, TASK_REACHER = 5, TASK_SWIMMER = 6, TASK_HOPPER = 7, TASK_HUMANOID = 8, TASK_STANDUP = 9 };
 
 typedef struct {
   int is_ant;
@@ -46,6 +48,8 @@ typedef struct {
   int reward_if_not_terminated, constraint_obs_dim; /* inverted pendulums */
   /* Ant-v3 / v5 (gym/registration.py:39-46) */
   int use_contact_force, post_constraint, exclude_worldbody;
+  int exclude_root_actuator; /* Humanoid-v5: humanoid.h:37-38 */
+  double contact_cost_max;
   /* Reacher (reacher.h:32-43) */
   int reward_after_step, obs_include_z, target;
   double dist_cost_weight, reset_qpos_scale, reset_qvel_scale, reset_goal_scale;
@@ -54,8 +58,8 @@ typedef struct {
   int torso;
   mj_env* envs;
   int nkeys;
-  const char* key_names[20];
-  int key_dtype[20], key_elems[20];
+  const char* key_names[24];
+  int key_dtype[24], key_elems[24];
 } mj_pool;
 
 static const char* kCommonNames[8] = {
@@ -90,6 +94,10 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
     kind = TASK_SWIMMER;
   } else if (strcmp(task, "Hopper") == 0) {
     kind = TASK_HOPPER;
+  } else if (strcmp(task, "Humanoid") == 0) {
+    kind = TASK_HUMANOID;
+  } else if (strcmp(task, "HumanoidStandup") == 0) {
+    kind = TASK_STANDUP;
   } else {
     return NULL;
   }
@@ -112,6 +120,8 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
     mjc_build_swimmer(&p->m);
   } else if (kind == TASK_HOPPER) {
     mjc_build_hopper(&p->m);
+  } else if (kind == TASK_HUMANOID || kind == TASK_STANDUP) {
+    mjc_build_humanoid(&p->m, kind == TASK_STANDUP);
   } else {
     mjc_build_half_cheetah(&p->m);
   }
@@ -120,6 +130,7 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   const int pend = kind == TASK_IPEND || kind == TASK_IDPEND;
   const int reacher = kind == TASK_REACHER, swimmer = kind == TASK_SWIMMER;
   const int hopper = kind == TASK_HOPPER;
+  const int humanoid = kind == TASK_HUMANOID || kind == TASK_STANDUP;
   p->frame_skip = (int)extra_or(
       extra, n_extra, 0,
       (walker || swimmer || hopper) ? 4 : ((kind == TASK_IPEND || reacher) ? 2 : 5));
@@ -135,10 +146,11 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   p->reset_qpos_scale = 0.1;
   p->reset_qvel_scale = 0.005;
   p->reset_goal_scale = 0.2;
-  p->forward_reward_weight = extra_or(extra, n_extra, 2, 1.0);
+  /* humanoid.h:39 (1.25), humanoid_standup.h:35 (1.0) */
+  p->forward_reward_weight = extra_or(extra, n_extra, 2, kind == TASK_HUMANOID ? 1.25 : 1.0);
   /* inverted_pendulum.h:32-41 (noise 0.01), inverted_double_pendulum.h:32-44 (0.1) */
   p->reset_noise_scale =
-      extra_or(extra, n_extra, 3, (walker || hopper) ? 0.005 : (kind == TASK_IPEND ? 0.01 : 0.1));
+      extra_or(extra, n_extra, 3, (walker || hopper) ? 0.005 : ((kind == TASK_IPEND || humanoid) ? 0.01 : 0.1));
   p->reward_if_not_terminated = extra_or(extra, n_extra, 10, 0) != 0;
   p->constraint_obs_dim = (int)extra_or(extra, n_extra, 11, 3);
   p->observation_min = -10.0;
@@ -146,7 +158,9 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   p->use_contact_force = extra_or(extra, n_extra, 12, 0) != 0;
   p->post_constraint = extra_or(extra, n_extra, 13, 0) != 0;
   p->exclude_worldbody = extra_or(extra, n_extra, 14, 0) != 0;
-  p->contact_cost_weight = 5e-4; /* ant.h:44-47 */
+  p->exclude_root_actuator = extra_or(extra, n_extra, 19, 0) != 0;
+  p->contact_cost_weight = humanoid ? 5e-7 : 5e-4; /* ant.h:44-47, humanoid.h:45-46 */
+  p->contact_cost_max = 10.0;
   p->contact_force_min = -1.0;
   p->contact_force_max = 1.0;
   p->m.disable_contact = extra_or(extra, n_extra, 4, 0) != 0;
@@ -159,9 +173,9 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   }
   if (extra_or(extra, n_extra, 8, -1) >= 0) p->m.integrator = (int)extra[8];
   if (extra_or(extra, n_extra, 9, 0) > 0) p->m.timestep = extra[9];
-  p->healthy_reward = kind == TASK_IDPEND ? 10.0 : 1.0;
-  p->healthy_z_min = walker ? 0.8 : (hopper ? 0.7 : (kind == TASK_IPEND ? -0.2 : 0.2));
-  p->healthy_z_max = walker ? 2.0 : (kind == TASK_IPEND ? 0.2 : 1.0);
+  p->healthy_reward = kind == TASK_IDPEND ? 10.0 : (kind == TASK_HUMANOID ? 5.0 : 1.0);
+  p->healthy_z_min = walker ? 0.8 : (hopper ? 0.7 : (kind == TASK_IPEND ? -0.2 : (humanoid ? 1.0 : 0.2)));
+  p->healthy_z_max = (walker || humanoid) ? 2.0 : (kind == TASK_IPEND ? 0.2 : 1.0);
   p->healthy_angle_min = hopper ? -0.2 : -1.0; /* hopper.h:44-46 */
   p->healthy_angle_max = hopper ? 0.2 : 1.0;
   p->velocity_min = -10.0;
@@ -190,6 +204,8 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
                       : reacher ? (p->obs_include_z ? 11 : 10)
                       : swimmer ? 8
                       : hopper ? 11
+                      : humanoid ? 376 - (p->exclude_worldbody ? 22 : 0) -
+                                       (p->exclude_root_actuator ? 6 : 0)
                                             : 17;
   static const char* cheetah_info[4] = {"info:reward_run", "info:reward_ctrl",
                                         "info:x_position", "info:x_velocity"};
@@ -203,9 +219,19 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   static const char* swimmer_info[7] = {"info:reward_fwd", "info:reward_ctrl", "info:x_position",
                                         "info:y_position", "info:distance_from_origin",
                                         "info:x_velocity", "info:y_velocity"};
+  /* humanoid.h:66-74, humanoid_standup.h:62-65 */
+  static const char* humanoid_info[9] = {
+      "info:reward_linvel", "info:reward_quadctrl", "info:reward_alive",
+      "info:reward_impact", "info:x_position",      "info:y_position",
+      "info:distance_from_origin", "info:x_velocity", "info:y_velocity"};
+  static const char* standup_info[4] = {"info:reward_linup", "info:reward_quadctrl",
+                                        "info:reward_alive", "info:reward_impact"};
   int ninfo = is_ant ? 9 : (swimmer ? 7 : (walker || reacher || hopper ? 2 : (pend ? 0 : 4)));
+  if (humanoid) ninfo = kind == TASK_HUMANOID ? 9 : 4;
   for (int i = 0; i < ninfo; ++i) {
-    p->key_names[k] = is_ant ? ant_info[i]
+    p->key_names[k] = kind == TASK_HUMANOID ? humanoid_info[i]
+                      : kind == TASK_STANDUP ? standup_info[i]
+                      : is_ant ? ant_info[i]
                       : swimmer ? swimmer_info[i]
                       : reacher ? reacher_info[i]
                                 : cheetah_info[((walker || hopper) ? 2 : 0) + i];
@@ -297,6 +323,23 @@ static void write_obs(mj_pool* p, mj_env* e, void** out, int row) {
     if (p->obs_include_z) *(obs++) = dist[2];
     return;
   }
+  if (p->task == TASK_HUMANOID || p->task == TASK_STANDUP) { /* humanoid.h:229-257 */
+    double* obs = (double*)out[8] + (size_t)row * p->key_elems[8];
+    int b0 = p->exclude_worldbody ? 1 : 0;
+    for (int i = 2; i < p->m.nq; ++i) *(obs++) = e->d.qpos[i];
+    for (int i = 0; i < p->m.nv; ++i) *(obs++) = e->d.qvel[i];
+    for (int b = b0; b < p->m.nbody; ++b) {
+      for (int j = 0; j < 10; ++j) *(obs++) = e->d.cinert[b][j];
+    }
+    for (int b = b0; b < p->m.nbody; ++b) {
+      for (int j = 0; j < 6; ++j) *(obs++) = e->d.cvel[b][j];
+    }
+    for (int i = p->exclude_root_actuator ? 6 : 0; i < p->m.nv; ++i) *(obs++) = e->d.qfrc_actuator[i];
+    for (int b = b0; b < p->m.nbody; ++b) {
+      for (int j = 0; j < 6; ++j) *(obs++) = e->d.cfrc_ext[b][j];
+    }
+    return;
+  }
   if (p->task == TASK_IPEND) { /* inverted_pendulum.h:172-178 */
     double* obs = (double*)out[8] + (size_t)row * 4;
     for (int i = 0; i < 2; ++i) obs[i] = e->d.qpos[i];
@@ -372,7 +415,7 @@ static void mujoco_reset(mj_pool* p, mj_env* e) {
   }
   for (int i = 0; i < p->m.nv; ++i) {
     if (p->task == TASK_WALKER || p->task == TASK_IPEND || p->task == TASK_SWIMMER ||
-        p->task == TASK_HOPPER) {
+        p->task == TASK_HOPPER || p->task == TASK_HUMANOID || p->task == TASK_STANDUP) {
       /* walker2d.h:119-126, inverted_pendulum.h:100-107: uniform for qvel too */
       e->d.qvel[i] = 0.0 + orc_uniform_real(&e->gen, -p->reset_noise_scale,
                                             p->reset_noise_scale);
@@ -381,6 +424,20 @@ static void mujoco_reset(mj_pool* p, mj_env* e) {
     }
   }
   mjc_forward(&p->m, &e->d); /* mj_forward */
+}
+
+/* HumanoidEnvBase::GetMassCenter, humanoid.h:212-223: from the xipos of the LAST forward
+ * evaluation */
+static void mass_center(const mj_pool* p, const mj_env* e, double* mc) {
+  double sum = 0, x = 0, y = 0;
+  for (int b = 0; b < p->m.nbody; ++b) {
+    double mass = p->m.body_mass[b];
+    sum += mass;
+    x += mass * e->d.xipos[b][0];
+    y += mass * e->d.xipos[b][1];
+  }
+  mc[0] = x / sum;
+  mc[1] = y / sum;
 }
 
 static int ant_is_healthy(mj_pool* p, mj_env* e) { /* ant.h:214-229 */
@@ -399,7 +456,8 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
   mj_env* e = &p->envs[eid];
   int reset = force_reset || e->done; /* async_envpool.h:127 */
   float reward = 0.0f;
-  int ninfo = p->is_ant ? 9
+  int ninfo = (p->is_ant || p->task == TASK_HUMANOID) ? 9
+              : p->task == TASK_STANDUP ? 4
               : p->task == TASK_SWIMMER ? 7
               : (p->task == TASK_WALKER || p->task == TASK_REACHER || p->task == TASK_HOPPER) ? 2
               : (p->task >= TASK_IPEND ? 0 : 4);
@@ -411,12 +469,64 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
     mujoco_reset(p, e);
     /* WriteState(0.0, 0, ...) on reset: ant.h:160-164 passes zeros */
     if (p->is_ant) info[6] = sqrt(0.0);
+    e->lag_set = 0;
   } else {
     ++e->current_step;
     double dt = p->frame_skip * p->m.timestep;
     double ctrl_cost = 0;
     for (int i = 0; i < p->m.nu; ++i) ctrl_cost += p->ctrl_cost_weight * act[i] * act[i];
-    if (p->task == TASK_HOPPER) { /* hopper.h:158-203 */
+    if (p->task == TASK_HUMANOID || p->task == TASK_STANDUP) {
+      /* humanoid.h:164-205, humanoid_standup.h:160-185 */
+      double before[2], after[2];
+      mass_center(p, e, before);
+      if (e->lag_set) {
+        before[0] = e->lag_mc[0];
+        before[1] = e->lag_mc[1];
+        e->lag_set = 0;
+      }
+      for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
+      for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
+      if (p->post_constraint) mjc_rne_post_constraint(&p->m, &e->d);
+      mass_center(p, e, after);
+      double contact_cost = 0.0;
+      if (p->use_contact_force || p->task == TASK_STANDUP) {
+        for (int b = 0; b < p->m.nbody; ++b) {
+          for (int j = 0; j < 6; ++j) {
+            double x = e->d.cfrc_ext[b][j];
+            contact_cost += p->contact_cost_weight * x * x;
+          }
+        }
+        contact_cost = fmin(contact_cost, p->contact_cost_max);
+      }
+      if (p->task == TASK_STANDUP) {
+        double xv = e->d.qpos[2] / p->m.timestep;
+        reward = (float)(xv * p->forward_reward_weight + p->healthy_reward - ctrl_cost - contact_cost);
+        e->done = (++e->elapsed_step >= p->max_episode_steps);
+        info[0] = xv * p->forward_reward_weight;
+        info[1] = -ctrl_cost;
+        info[2] = p->healthy_reward;
+        info[3] = -contact_cost;
+      } else {
+        double xv = (after[0] - before[0]) / dt, yv = (after[1] - before[1]) / dt;
+        int healthy = p->healthy_z_min < e->d.qpos[2] && e->d.qpos[2] < p->healthy_z_max;
+        int give = healthy;
+        if (p->legacy_healthy_reward) give = p->terminate_when_unhealthy || healthy;
+        double healthy_reward = give ? p->healthy_reward : 0.0;
+        reward = (float)(xv * p->forward_reward_weight + healthy_reward - ctrl_cost - contact_cost);
+        ++e->elapsed_step;
+        e->done = (p->terminate_when_unhealthy ? !healthy : 0) ||
+                  (e->elapsed_step >= p->max_episode_steps);
+        info[0] = xv * p->forward_reward_weight;
+        info[1] = -ctrl_cost;
+        info[2] = healthy_reward;
+        info[3] = -contact_cost;
+        info[4] = after[0];
+        info[5] = after[1];
+        info[6] = sqrt(after[0] * after[0] + after[1] * after[1]);
+        info[7] = xv;
+        info[8] = yv;
+      }
+    } else if (p->task == TASK_HOPPER) { /* hopper.h:158-203 */
       double x_before = e->d.qpos[0];
       for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
       for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
@@ -612,6 +722,7 @@ void mjcpu_get_state(void* h, const int* ids, int k, double* out) {
     t[0] = e->d.time;
     t[1] = e->d.xpos[p->torso][0];
     t[2] = e->d.xpos[p->torso][1];
+    if (p->task == TASK_HUMANOID || p->task == TASK_STANDUP) mass_center(p, e, t + 1);
     t[3] = e->done;
     t[4] = e->current_step;
     t[5] = e->nstate.saved;
@@ -631,6 +742,9 @@ void mjcpu_set_state(void* h, const int* ids, int k, const double* in) {
     e->d.time = t[0];
     e->d.xpos[p->torso][0] = t[1];
     e->d.xpos[p->torso][1] = t[2];
+    e->lag_set = 1;
+    e->lag_mc[0] = t[1];
+    e->lag_mc[1] = t[2];
     e->done = t[3] != 0;
     e->current_step = (int)t[4];
     e->elapsed_step = e->current_step;
