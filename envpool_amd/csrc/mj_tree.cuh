@@ -1,0 +1,1155 @@
+// K3c -- `mj_step` for a general 3-D kinematic tree with a floating base (gym Humanoid /
+// HumanoidStandup: 13 bodies, free joint + 17 hinges, nv = 23, sphere / capsule geoms that
+// also collide with each other, PGS solver, RK4).
+//
+// What it replaces: the arithmetic MuJoCo 3.6.0 performs each time the reference calls
+// mj_forward / mj_step / mj_rnePostConstraint for these models
+// (envpool/mujoco/gym/mujoco_env.h:126-148; task code envpool/mujoco/gym/humanoid.h,
+// humanoid_standup.h).  The engine itself is un-vendored third-party code: see
+// oracle/mjcpu/mjcpu.h (PARITY UNPINNED) for what the restatement is anchored on.
+//
+// MI355X-first design.  One env per lane, one wave per workgroup.  A 23-dof tree does not
+// fit a lane's registers (M alone is 185 numbers, a constraint row 23, up to ~150 rows), so
+// unlike the planar / Ant kernels the per-env data lives in an HBM workspace:
+//  * layout [wave][slot][lane]: a wave's 64 columns of one slot are one 512 B line (fully
+//    coalesced), a wave's whole workspace is one contiguous block (TLB / DRAM page
+//    locality), and every slot index is wave-uniform, so an address is an SGPR base plus
+//    the lane offset.  The block belongs to the launch's wave, not to an env: the few
+//    values that persist between steps (qpos, qvel, warm start, lagged mass centre) are
+//    copied in from / out to a per-env SoA by the step kernel;
+//  * the tree is a compile-time constant (gen_mj_consts.cpp): kinematics, CRB, the sparse
+//    L'DL factorisation, the M^-1 solves and RNE are fully unrolled over the tree with
+//    static slot numbers, intermediate vectors in VGPRs;
+//  * constraints use STATIC row slots: one per limited joint, four per potential floor
+//    contact (pyramid edges), one per geom pair that may collide.  Static order is MuJoCo's
+//    row order restricted to the active rows (limits by joint, contacts by body pair), so
+//    the order-dependent PGS sweep needs no compaction.  Each lane keeps a bitmask of its
+//    active groups; the wave-uniform union mask drives scalar loops (ctz) over rows that at
+//    least one lane needs, and lanes that do not have the row apply a zero update;
+//  * PGS works on  a = qacc_smooth + M^-1 J' f  instead of the nefc x nefc matrix A+R:
+//    res_r = J_r . a - aref_r + R_r f_r  and  a += delta W_r  with  W_r = M^-1 J_r'
+//    (2 x 23 loads per row visit instead of nefc, no O(nefc^2) memory);
+//  * no lane-divergent control flow anywhere: per-lane differences are selects, finished
+//    lanes run with frozen iterates (WaveAny, see mj_cheetah.cuh).
+// The same source compiles for the host (EPA_HD, lane stride 1) so tests run it on the CPU
+// against oracle/mjcpu.
+#ifndef ENVPOOL_AMD_CSRC_MJ_TREE_CUH_
+#define ENVPOOL_AMD_CSRC_MJ_TREE_CUH_
+
+#include "mj_cheetah.cuh"  // EPA_HD, static_for, WaveAny, WaveUniform, SinCos
+
+namespace epa {
+namespace mj {
+namespace tree {
+
+constexpr int kMaxBody = 16, kMaxJnt = 20, kMaxV = 24, kMaxQ = 24, kMaxGeom = 20, kMaxU = 20;
+constexpr int kMaxFloor = 32, kMaxPair = 128, kMaxGroup = 192;
+enum { kJntFree = 0, kJntHinge = 3 };
+enum { kGeomPlane = 0, kGeomSphere = 2, kGeomCapsule = 3 };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+constexpr int kLaneStride = 64;
+#else
+constexpr int kLaneStride = 1;
+#endif
+
+// The compiled model (mj_tree_model.h builds it on the host; the kernels see it as a
+// compile-time constant).  Single tree: body 1 carries the free joint, every other joint
+// is a hinge; geom 0 is the floor plane z = 0.
+struct TreeModel {
+  int nbody, njnt, nq, nv, ngeom, nu;
+  int nlimit, nfloor, npair;  // constraint groups: limited joints, floor spheres, geom pairs
+  int iterations;             // <option iterations>
+  double timestep, gravity;   // gravity: magnitude along -z
+  double margin, floor_mu;    // contact margin of every pair; sliding friction on the floor
+  double sol_K, sol_B, sol_d0, sol_dmax, sol_width;  // default solref / solimp everywhere
+  double meaninertia, total_mass;
+  int body_parent[kMaxBody], body_jntadr[kMaxBody], body_jntnum[kMaxBody];
+  int body_dofadr[kMaxBody], body_dofnum[kMaxBody];
+  unsigned body_dofmask[kMaxBody];  // dofs on the path world -> body
+  double body_pos[kMaxBody][3], body_quat[kMaxBody][4], body_ipos[kMaxBody][3];
+  double body_mass[kMaxBody], body_inertia[kMaxBody][6];  // xx yy zz xy xz yz about ipos
+  double body_invw[kMaxBody];                             // body_invweight0, translational
+  int jnt_type[kMaxJnt], jnt_body[kMaxJnt], jnt_qadr[kMaxJnt], jnt_dadr[kMaxJnt];
+  int jnt_limited[kMaxJnt];
+  double jnt_pos[kMaxJnt][3], jnt_axis[kMaxJnt][3], jnt_lo[kMaxJnt], jnt_hi[kMaxJnt];
+  double jnt_stiff[kMaxJnt];
+  int dof_parent[kMaxV], dof_body[kMaxV];
+  double dof_arm[kMaxV], dof_damp[kMaxV], dof_invw[kMaxV];
+  int geom_type[kMaxGeom], geom_body[kMaxGeom];
+  double geom_pos[kMaxGeom][3], geom_axis[kMaxGeom][3], geom_rad[kMaxGeom], geom_hl[kMaxGeom];
+  int act_dof[kMaxU];
+  double act_gear[kMaxU], ctrl_lo, ctrl_hi;
+  int limit_jnt[kMaxJnt];                              // limit group -> joint
+  int floor_geom[kMaxFloor]; double floor_sign[kMaxFloor];  // sphere = gpos + sign * hl * axis
+  int pair_g1[kMaxPair], pair_g2[kMaxPair];            // lower geom TYPE first (mj_collideGeoms)
+  double qpos0[kMaxQ];
+};
+
+// ---- workspace ------------------------------------------------------------------------
+struct Layout {
+  int qpos, qvel, warm, lag, npersist;               // slots [0, npersist) persist between steps
+  int ctrl;
+  int xpos, xquat, xmat, xipos, anchor, axis, gpos, gaxis, com;
+  int cinert, cdof, cvel, crb, cacc, cfrc;
+  int M, dinv;                                       // M (lower, tree-sparse) -> L'DL in place
+  int passive, bias, act, smooth, accs, qacc;
+  int limd, lims, condist, conpos, connrm;           // detection results per group
+  int rowJ, rowW, rowR, rowAref, rowArr, rowF;
+  int x0q, x0v, accq, accv;                          // RK4
+  int cext;                                          // cfrc_ext [nbody][6]
+  int total;
+};
+constexpr Layout MakeLayout(const TreeModel& m) {
+  Layout L{};
+  int s = 0;
+  auto take = [&s](int n) { int at = s; s += n; return at; };
+  const int ncon = m.nfloor + m.npair, nrow = m.nlimit + 4 * m.nfloor + m.npair;
+  L.qpos = take(m.nq); L.qvel = take(m.nv); L.warm = take(m.nv); L.lag = take(2);
+  L.npersist = s;
+  L.ctrl = take(m.nu);
+  L.xpos = take(3 * m.nbody); L.xquat = take(4 * m.nbody); L.xmat = take(9 * m.nbody);
+  L.xipos = take(3 * m.nbody); L.anchor = take(3 * m.njnt); L.axis = take(3 * m.njnt);
+  L.gpos = take(3 * m.ngeom); L.gaxis = take(3 * m.ngeom); L.com = take(3);
+  L.cinert = take(10 * m.nbody); L.cdof = take(6 * m.nv); L.cvel = take(6 * m.nbody);
+  L.crb = take(10 * m.nbody); L.cacc = take(6 * m.nbody); L.cfrc = take(6 * m.nbody);
+  L.M = take(m.nv * m.nv); L.dinv = take(m.nv);
+  L.passive = take(m.nv); L.bias = take(m.nv); L.act = take(m.nv); L.smooth = take(m.nv);
+  L.accs = take(m.nv); L.qacc = take(m.nv);
+  L.limd = take(m.nlimit); L.lims = take(m.nlimit);
+  L.condist = take(ncon); L.conpos = take(3 * ncon); L.connrm = take(3 * ncon);
+  L.rowJ = take(nrow * m.nv); L.rowW = take(nrow * m.nv);
+  L.rowR = take(nrow); L.rowAref = take(nrow); L.rowArr = take(nrow); L.rowF = take(nrow);
+  L.x0q = take(m.nq); L.x0v = take(m.nv); L.accq = take(m.nv); L.accv = take(m.nv);
+  L.cext = take(6 * m.nbody);
+  L.total = s;
+  return L;
+}
+
+// `base` is the wave's block (wave-uniform: it lives in SGPRs and slot offsets are scalar
+// arithmetic), `lane` the column inside it.
+struct Ws {
+  double* base;
+  unsigned lane;
+  // byte offset in 32 bits: the access becomes `global_load v, v_off, s[base]` (SGPR base +
+  // 32-bit lane offset) instead of a 64-bit per-lane address per slot
+  EPA_HD double& operator()(int slot) const {
+    const unsigned off = ((unsigned)slot * (unsigned)kLaneStride + lane) * 8u;
+    return *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off);
+  }
+  // A fresh copy whose lane offset is opaque to the optimiser: used at the top of loop bodies
+  // so that the (hundreds of) slot addresses are recomputed where needed instead of being
+  // hoisted out of the loop and spilled.
+  EPA_HD Ws Fresh() const {
+    Ws r = *this;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(r.lane));
+#endif
+    return r;
+  }
+};
+
+// per-group tables indexed at run time by a wave-uniform group number
+struct GroupTab {
+  int b1[kMaxGroup], b2[kMaxGroup];           // bodies of a contact group (b1 = 0: floor)
+  unsigned mask1[kMaxGroup], mask2[kMaxGroup];
+  int dof[kMaxGroup];                         // limit group: its dof
+  double diag[kMaxGroup];                     // mj_diagApprox of the (first) row
+};
+constexpr GroupTab MakeGroupTab(const TreeModel& m) {
+  GroupTab t{};
+  for (int g = 0; g < m.nlimit; ++g) {
+    t.dof[g] = m.jnt_dadr[m.limit_jnt[g]];
+    t.diag[g] = m.dof_invw[t.dof[g]];
+  }
+  for (int c = 0; c < m.nfloor; ++c) {
+    const int g = m.nlimit + c, b = m.geom_body[m.floor_geom[c]];
+    t.b1[g] = 0;
+    t.b2[g] = b;
+    t.mask1[g] = 0;
+    t.mask2[g] = m.body_dofmask[b];
+    t.diag[g] = m.body_invw[b] * (1.0 + m.floor_mu * m.floor_mu);
+  }
+  for (int p = 0; p < m.npair; ++p) {
+    const int g = m.nlimit + m.nfloor + p;
+    const int b1 = m.geom_body[m.pair_g1[p]], b2 = m.geom_body[m.pair_g2[p]];
+    t.b1[g] = b1;
+    t.b2[g] = b2;
+    t.mask1[g] = m.body_dofmask[b1];
+    t.mask2[g] = m.body_dofmask[b2];
+    t.diag[g] = m.body_invw[b1] + m.body_invw[b2];
+  }
+  return t;
+}
+
+constexpr int kGW = kMaxGroup / 64;
+struct GMask {
+  unsigned long long w[kGW];
+};
+
+// ---- small algebra ------------------------------------------------------------------------
+struct Vec3 {
+  double x, y, z;
+};
+struct Quat {
+  double w, x, y, z;
+};
+EPA_HD Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+EPA_HD Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+EPA_HD Vec3 operator*(Vec3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+EPA_HD double Dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+EPA_HD Vec3 Cross(Vec3 a, Vec3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+EPA_HD Quat QMul(Quat a, Quat b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
+          a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+          a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+EPA_HD Quat QNormalize(Quat q) {
+  const double inv = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  return {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
+}
+EPA_HD void QMat(Quat q, double* M) {  // row-major 3x3
+  const double w = q.w, x = q.x, y = q.y, z = q.z;
+  M[0] = w * w + x * x - y * y - z * z;
+  M[4] = w * w - x * x + y * y - z * z;
+  M[8] = w * w - x * x - y * y + z * z;
+  M[1] = 2 * (x * y - w * z);
+  M[2] = 2 * (x * z + w * y);
+  M[3] = 2 * (x * y + w * z);
+  M[5] = 2 * (y * z - w * x);
+  M[6] = 2 * (x * z - w * y);
+  M[7] = 2 * (y * z + w * x);
+}
+EPA_HD Vec3 MulV(const double* M, Vec3 v) {
+  return {M[0] * v.x + M[1] * v.y + M[2] * v.z, M[3] * v.x + M[4] * v.y + M[5] * v.z,
+          M[6] * v.x + M[7] * v.y + M[8] * v.z};
+}
+// spatial inertia (10-vector about the c-frame origin) times a motion vector [ang; lin]
+EPA_HD void MulInertVec(double* r, const double* i, const double* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+EPA_HD double Dot6(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+EPA_HD void CrossMotion(double* r, const double* vel, const double* v) {  // mju_crossMotion
+  r[0] = vel[1] * v[2] - vel[2] * v[1];
+  r[1] = vel[2] * v[0] - vel[0] * v[2];
+  r[2] = vel[0] * v[1] - vel[1] * v[0];
+  r[3] = vel[1] * v[5] - vel[2] * v[4] + vel[4] * v[2] - vel[5] * v[1];
+  r[4] = vel[2] * v[3] - vel[0] * v[5] + vel[5] * v[0] - vel[3] * v[2];
+  r[5] = vel[0] * v[4] - vel[1] * v[3] + vel[3] * v[1] - vel[4] * v[0];
+}
+EPA_HD void CrossForce(double* r, const double* vel, const double* f) {  // mju_crossForce
+  r[0] = vel[1] * f[2] - vel[2] * f[1] + vel[4] * f[5] - vel[5] * f[4];
+  r[1] = vel[2] * f[0] - vel[0] * f[2] + vel[5] * f[3] - vel[3] * f[5];
+  r[2] = vel[0] * f[1] - vel[1] * f[0] + vel[3] * f[4] - vel[4] * f[3];
+  r[3] = vel[1] * f[5] - vel[2] * f[4];
+  r[4] = vel[2] * f[3] - vel[0] * f[5];
+  r[5] = vel[0] * f[4] - vel[1] * f[3];
+}
+EPA_HD double Sel(bool c, double a, double b) { return c ? a : b; }
+EPA_HD double Clamp(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+EPA_HD int Ctz64(unsigned long long x) {
+  return __builtin_ctzll(x);
+}
+
+constexpr double kMinVal = 1e-15;
+
+// Keeps the instruction scheduler from hoisting a whole unrolled stage's loads in front of its
+// arithmetic (hundreds of live VGPRs -> spills): nothing moves across this point.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EPA_TREE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define EPA_TREE_FENCE() ((void)0)
+#endif
+
+// MP::kM is the constexpr TreeModel
+template <class MP>
+struct Tree {
+  static constexpr TreeModel kM = MP::kM;
+  static constexpr Layout kL = MakeLayout(MP::kM);
+  static constexpr int NB = kM.nbody, NV = kM.nv, NQ = kM.nq, NJ = kM.njnt, NG = kM.ngeom,
+                       NU = kM.nu;
+  static constexpr int kNLimit = kM.nlimit, kNFloor = kM.nfloor, kNPair = kM.npair;
+  static constexpr int kNGroup = kNLimit + kNFloor + kNPair;
+  static constexpr int kNRow = kNLimit + 4 * kNFloor + kNPair;
+  static_assert(kNGroup <= kMaxGroup, "raise kMaxGroup");
+  static constexpr int MIdx(int i, int j) { return kL.M + i * NV + j; }  // i >= j
+
+  // f(IC<j>) for j = I, parent(I), ... (the dofs on the path from dof I to the root)
+  template <int I, typename F>
+  static EPA_HD void Chain(F&& f) {
+    if constexpr (I >= 0) {
+      f(IC<I>{});
+      Chain<MP::kM.dof_parent[I]>(static_cast<F&&>(f));
+    }
+  }
+
+  // ---- mj_kinematics ---------------------------------------------------------------------
+  static EPA_HD void Kinematics(Ws w) {
+    constexpr TreeModel m = MP::kM;
+    static_for<1, NB>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      constexpr int p = m.body_parent[b];
+      constexpr int ja = m.body_jntadr[b], jn = m.body_jntnum[b];
+      Vec3 xpos;
+      Quat q;
+      double R[9];
+      if constexpr (jn == 1 && m.jnt_type[ja < 0 ? 0 : ja] == kJntFree) {
+        constexpr int qa = m.jnt_qadr[ja];
+        xpos = {w(kL.qpos + qa), w(kL.qpos + qa + 1), w(kL.qpos + qa + 2)};
+        // mj_kinematics normalises the quaternion in qpos itself
+        q = QNormalize({w(kL.qpos + qa + 3), w(kL.qpos + qa + 4), w(kL.qpos + qa + 5),
+                        w(kL.qpos + qa + 6)});
+        w(kL.qpos + qa + 3) = q.w;
+        w(kL.qpos + qa + 4) = q.x;
+        w(kL.qpos + qa + 5) = q.y;
+        w(kL.qpos + qa + 6) = q.z;
+      } else {
+        double Rp[9];
+        static_for<0, 9>([&](auto kc) { Rp[decltype(kc)::value] = w(kL.xmat + 9 * p + decltype(kc)::value); });
+        const Vec3 pp = {w(kL.xpos + 3 * p), w(kL.xpos + 3 * p + 1), w(kL.xpos + 3 * p + 2)};
+        const Quat pq = {w(kL.xquat + 4 * p), w(kL.xquat + 4 * p + 1), w(kL.xquat + 4 * p + 2),
+                         w(kL.xquat + 4 * p + 3)};
+        xpos = pp + MulV(Rp, Vec3{m.body_pos[b][0], m.body_pos[b][1], m.body_pos[b][2]});
+        q = QMul(pq, Quat{m.body_quat[b][0], m.body_quat[b][1], m.body_quat[b][2],
+                          m.body_quat[b][3]});
+        static_for<0, jn>([&](auto jc) {
+          constexpr int j = ja + decltype(jc)::value;
+          static_assert(m.jnt_type[j] == kJntHinge, "free root + hinges only");
+          QMat(q, R);
+          const Vec3 jp = {m.jnt_pos[j][0], m.jnt_pos[j][1], m.jnt_pos[j][2]};
+          const Vec3 anchor = MulV(R, jp) + xpos;
+          const Vec3 axis = MulV(R, Vec3{m.jnt_axis[j][0], m.jnt_axis[j][1], m.jnt_axis[j][2]});
+          w(kL.anchor + 3 * j) = anchor.x;
+          w(kL.anchor + 3 * j + 1) = anchor.y;
+          w(kL.anchor + 3 * j + 2) = anchor.z;
+          w(kL.axis + 3 * j) = axis.x;
+          w(kL.axis + 3 * j + 1) = axis.y;
+          w(kL.axis + 3 * j + 2) = axis.z;
+          double sn, cs;
+          SinCos(0.5 * (w(kL.qpos + m.jnt_qadr[j]) - m.qpos0[m.jnt_qadr[j]]), &sn, &cs);
+          q = QMul(q, Quat{cs, m.jnt_axis[j][0] * sn, m.jnt_axis[j][1] * sn, m.jnt_axis[j][2] * sn});
+          QMat(q, R);
+          xpos = anchor - MulV(R, jp);
+        });
+        q = QNormalize(q);
+      }
+      QMat(q, R);
+      w(kL.xpos + 3 * b) = xpos.x;
+      w(kL.xpos + 3 * b + 1) = xpos.y;
+      w(kL.xpos + 3 * b + 2) = xpos.z;
+      w(kL.xquat + 4 * b) = q.w;
+      w(kL.xquat + 4 * b + 1) = q.x;
+      w(kL.xquat + 4 * b + 2) = q.y;
+      w(kL.xquat + 4 * b + 3) = q.z;
+      static_for<0, 9>([&](auto kc) { w(kL.xmat + 9 * b + decltype(kc)::value) = R[decltype(kc)::value]; });
+      const Vec3 ip = xpos + MulV(R, Vec3{m.body_ipos[b][0], m.body_ipos[b][1], m.body_ipos[b][2]});
+      w(kL.xipos + 3 * b) = ip.x;
+      w(kL.xipos + 3 * b + 1) = ip.y;
+      w(kL.xipos + 3 * b + 2) = ip.z;
+      // geoms of this body: centre and (capsules) axis
+      static_for<1, NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (m.geom_body[g] == b) {
+          const Vec3 gp = xpos + MulV(R, Vec3{m.geom_pos[g][0], m.geom_pos[g][1], m.geom_pos[g][2]});
+          w(kL.gpos + 3 * g) = gp.x;
+          w(kL.gpos + 3 * g + 1) = gp.y;
+          w(kL.gpos + 3 * g + 2) = gp.z;
+          if constexpr (m.geom_type[g] == kGeomCapsule) {
+            const Vec3 ga = MulV(R, Vec3{m.geom_axis[g][0], m.geom_axis[g][1], m.geom_axis[g][2]});
+            w(kL.gaxis + 3 * g) = ga.x;
+            w(kL.gaxis + 3 * g + 1) = ga.y;
+            w(kL.gaxis + 3 * g + 2) = ga.z;
+          }
+        }
+      });
+    });
+  }
+
+  // ---- mj_comPos: system COM (origin of the c-frame), cinert, cdof ---------------------------
+  static EPA_HD void ComPos(Ws w) {
+    constexpr TreeModel m = MP::kM;
+    Vec3 c = {0, 0, 0};
+    static_for<1, NB>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      c = c + Vec3{w(kL.xipos + 3 * b), w(kL.xipos + 3 * b + 1), w(kL.xipos + 3 * b + 2)} *
+                  m.body_mass[b];
+    });
+    c = c * (1.0 / m.total_mass);
+    w(kL.com) = c.x;
+    w(kL.com + 1) = c.y;
+    w(kL.com + 2) = c.z;
+    static_for<1, NB>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      double R[9];
+      static_for<0, 9>([&](auto kc) { R[decltype(kc)::value] = w(kL.xmat + 9 * b + decltype(kc)::value); });
+      // Iw = R I R^T, I symmetric (xx yy zz xy xz yz)
+      constexpr double Ixx = m.body_inertia[b][0], Iyy = m.body_inertia[b][1],
+                       Izz = m.body_inertia[b][2], Ixy = m.body_inertia[b][3],
+                       Ixz = m.body_inertia[b][4], Iyz = m.body_inertia[b][5];
+      double RI[9];
+      static_for<0, 3>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        RI[3 * r + 0] = R[3 * r] * Ixx + R[3 * r + 1] * Ixy + R[3 * r + 2] * Ixz;
+        RI[3 * r + 1] = R[3 * r] * Ixy + R[3 * r + 1] * Iyy + R[3 * r + 2] * Iyz;
+        RI[3 * r + 2] = R[3 * r] * Ixz + R[3 * r + 1] * Iyz + R[3 * r + 2] * Izz;
+      });
+      auto iw = [&](int r, int cidx) {
+        return RI[3 * r] * R[3 * cidx] + RI[3 * r + 1] * R[3 * cidx + 1] + RI[3 * r + 2] * R[3 * cidx + 2];
+      };
+      const Vec3 off = Vec3{w(kL.xipos + 3 * b), w(kL.xipos + 3 * b + 1), w(kL.xipos + 3 * b + 2)} - c;
+      constexpr double mass = m.body_mass[b];
+      const double o2 = Dot(off, off);
+      const int ci = kL.cinert + 10 * b;
+      w(ci + 0) = iw(0, 0) + mass * (o2 - off.x * off.x);
+      w(ci + 1) = iw(1, 1) + mass * (o2 - off.y * off.y);
+      w(ci + 2) = iw(2, 2) + mass * (o2 - off.z * off.z);
+      w(ci + 3) = iw(0, 1) - mass * off.x * off.y;
+      w(ci + 4) = iw(0, 2) - mass * off.x * off.z;
+      w(ci + 5) = iw(1, 2) - mass * off.y * off.z;
+      w(ci + 6) = mass * off.x;
+      w(ci + 7) = mass * off.y;
+      w(ci + 8) = mass * off.z;
+      w(ci + 9) = mass;
+    });
+    static_for<0, NJ>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int a = m.jnt_dadr[j], b = m.jnt_body[j];
+      if constexpr (m.jnt_type[j] == kJntHinge) {
+        const Vec3 ax = {w(kL.axis + 3 * j), w(kL.axis + 3 * j + 1), w(kL.axis + 3 * j + 2)};
+        const Vec3 off = c - Vec3{w(kL.anchor + 3 * j), w(kL.anchor + 3 * j + 1), w(kL.anchor + 3 * j + 2)};
+        const Vec3 lin = Cross(ax, off);
+        w(kL.cdof + 6 * a) = ax.x;
+        w(kL.cdof + 6 * a + 1) = ax.y;
+        w(kL.cdof + 6 * a + 2) = ax.z;
+        w(kL.cdof + 6 * a + 3) = lin.x;
+        w(kL.cdof + 6 * a + 4) = lin.y;
+        w(kL.cdof + 6 * a + 5) = lin.z;
+      } else {  // free: 3 world translations, then rotations about the body axes
+        const Vec3 off = c - Vec3{w(kL.xpos + 3 * b), w(kL.xpos + 3 * b + 1), w(kL.xpos + 3 * b + 2)};
+        static_for<0, 3>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          static_for<0, 6>([&](auto rc) {
+            w(kL.cdof + 6 * (a + k) + decltype(rc)::value) = decltype(rc)::value == 3 + k ? 1.0 : 0.0;
+          });
+          const Vec3 ax = {w(kL.xmat + 9 * b + k), w(kL.xmat + 9 * b + 3 + k), w(kL.xmat + 9 * b + 6 + k)};
+          const Vec3 lin = Cross(ax, off);
+          w(kL.cdof + 6 * (a + 3 + k)) = ax.x;
+          w(kL.cdof + 6 * (a + 3 + k) + 1) = ax.y;
+          w(kL.cdof + 6 * (a + 3 + k) + 2) = ax.z;
+          w(kL.cdof + 6 * (a + 3 + k) + 3) = lin.x;
+          w(kL.cdof + 6 * (a + 3 + k) + 4) = lin.y;
+          w(kL.cdof + 6 * (a + 3 + k) + 5) = lin.z;
+        });
+      }
+    });
+  }
+
+  // ---- mj_crb (+ armature), then mj_factorM in place ----------------------------------------
+  static EPA_HD void CrbFactor(Ws w) {
+    constexpr TreeModel m = MP::kM;
+    static_for<1, NB>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      static_for<0, 10>([&](auto kc) {
+        w(kL.crb + 10 * b + decltype(kc)::value) = w(kL.cinert + 10 * b + decltype(kc)::value);
+      });
+    });
+    static_for_down<NB, 2>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      constexpr int p = m.body_parent[b];
+      if constexpr (p > 0) {
+        static_for<0, 10>([&](auto kc) {
+          w(kL.crb + 10 * p + decltype(kc)::value) += w(kL.crb + 10 * b + decltype(kc)::value);
+        });
+      }
+    });
+    {
+      double cd[NV][6];
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<0, 6>([&](auto rc) { cd[i][decltype(rc)::value] = w(kL.cdof + 6 * i + decltype(rc)::value); });
+      });
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        double in[10], buf[6];
+        static_for<0, 10>([&](auto kc) { in[decltype(kc)::value] = w(kL.crb + 10 * m.dof_body[i] + decltype(kc)::value); });
+        MulInertVec(buf, in, cd[i]);
+        Chain<i>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          double v = Dot6(cd[j], buf);
+          if constexpr (i == j) v += m.dof_arm[i];
+          w(MIdx(i, j)) = v;
+        });
+      });
+    }
+    // L'DL: M = L' D L, L unit lower with the tree's sparsity (MuJoCo mj_factorM)
+    static_for_down<NV, 0>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      double rk[NV];
+      Chain<k>([&](auto jc) { rk[decltype(jc)::value] = w(MIdx(k, decltype(jc)::value)); });
+      const double inv = 1.0 / rk[k];
+      w(kL.dinv + k) = inv;
+      Chain<m.dof_parent[k]>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const double tmp = rk[i] * inv;
+        Chain<i>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          w(MIdx(i, j)) -= tmp * rk[j];
+        });
+        w(MIdx(k, i)) = tmp;
+      });
+    });
+  }
+
+  // x <- M^-1 x (mj_solveM), x in registers
+  static EPA_HD void SolveM(Ws w, double* x) {
+    constexpr TreeModel m = MP::kM;
+    static_for_down<NV, 0>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      Chain<m.dof_parent[i]>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        x[j] -= w(MIdx(i, j)) * x[i];
+      });
+      if constexpr (i % 2 == 0) EPA_TREE_FENCE();
+    });
+    static_for<0, NV>([&](auto ic) { x[decltype(ic)::value] *= w(kL.dinv + decltype(ic)::value); });
+    EPA_TREE_FENCE();
+    static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      Chain<m.dof_parent[i]>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        x[i] -= w(MIdx(i, j)) * x[j];
+      });
+      if constexpr (i % 2 == 0) EPA_TREE_FENCE();
+    });
+  }
+
+  // ---- mj_fwdVelocity + mj_fwdActuation + mj_fwdAcceleration ---------------------------------
+  static EPA_HD void Velocity(Ws w) {
+    constexpr TreeModel m = MP::kM;
+    static_for<0, 6>([&](auto rc) {
+      w(kL.cvel + decltype(rc)::value) = 0.0;
+      w(kL.cacc + decltype(rc)::value) = decltype(rc)::value == 5 ? m.gravity : 0.0;
+    });
+    static_for<1, NB>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      constexpr int p = m.body_parent[b];
+      constexpr int a = m.body_dofadr[b], n = m.body_dofnum[b];
+      double cvel[6], cacc[6];
+      static_for<0, 6>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        cvel[r] = w(kL.cvel + 6 * p + r);
+        cacc[r] = w(kL.cacc + 6 * p + r);
+      });
+      if constexpr (n == 6) {  // free joint: translations first, their cdof_dot is zero
+        static_for<0, 3>([&](auto kc) { cvel[3 + decltype(kc)::value] += w(kL.qvel + a + decltype(kc)::value); });
+        double cd[3][6], dot[6];
+        static_for<0, 3>([&](auto kc) {
+          static_for<0, 6>([&](auto rc) {
+            cd[decltype(kc)::value][decltype(rc)::value] = w(kL.cdof + 6 * (a + 3 + decltype(kc)::value) + decltype(rc)::value);
+          });
+        });
+        static_for<0, 3>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          CrossMotion(dot, cvel, cd[k]);  // all three with the velocity before the rotations
+          const double qv = w(kL.qvel + a + 3 + k);
+          static_for<0, 6>([&](auto rc) { cacc[decltype(rc)::value] += dot[decltype(rc)::value] * qv; });
+        });
+        static_for<0, 3>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          const double qv = w(kL.qvel + a + 3 + k);
+          static_for<0, 6>([&](auto rc) { cvel[decltype(rc)::value] += cd[k][decltype(rc)::value] * qv; });
+        });
+      } else {
+        static_for<0, n>([&](auto jc) {
+          constexpr int i = a + decltype(jc)::value;
+          double cd[6], dot[6];
+          static_for<0, 6>([&](auto rc) { cd[decltype(rc)::value] = w(kL.cdof + 6 * i + decltype(rc)::value); });
+          CrossMotion(dot, cvel, cd);
+          const double qv = w(kL.qvel + i);
+          static_for<0, 6>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            cacc[r] += dot[r] * qv;
+            cvel[r] += cd[r] * qv;
+          });
+        });
+      }
+      double in[10], t1[6], t2[6], t3[6];
+      static_for<0, 10>([&](auto kc) { in[decltype(kc)::value] = w(kL.cinert + 10 * b + decltype(kc)::value); });
+      MulInertVec(t1, in, cacc);
+      MulInertVec(t2, in, cvel);
+      CrossForce(t3, cvel, t2);
+      static_for<0, 6>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        w(kL.cvel + 6 * b + r) = cvel[r];
+        w(kL.cacc + 6 * b + r) = cacc[r];
+        w(kL.cfrc + 6 * b + r) = t1[r] + t3[r];
+      });
+    });
+    static_for_down<NB, 2>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      constexpr int p = m.body_parent[b];
+      if constexpr (p > 0) {
+        static_for<0, 6>([&](auto rc) {
+          w(kL.cfrc + 6 * p + decltype(rc)::value) += w(kL.cfrc + 6 * b + decltype(rc)::value);
+        });
+      }
+    });
+    double x[NV];
+    static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      double cd[6], f[6];
+      static_for<0, 6>([&](auto rc) {
+        cd[decltype(rc)::value] = w(kL.cdof + 6 * i + decltype(rc)::value);
+        f[decltype(rc)::value] = w(kL.cfrc + 6 * m.dof_body[i] + decltype(rc)::value);
+      });
+      const double bias = Dot6(cd, f);
+      double passive = -m.dof_damp[i] * w(kL.qvel + i);
+      w(kL.bias + i) = bias;
+      x[i] = -bias;
+      w(kL.act + i) = 0.0;
+      w(kL.passive + i) = passive;
+    });
+    static_for<1, NJ>([&](auto jc) {  // joint springs (hinges; joint 0 is the free root)
+      constexpr int j = decltype(jc)::value;
+      if constexpr (m.jnt_stiff[j] != 0.0) {
+        w(kL.passive + m.jnt_dadr[j]) -= m.jnt_stiff[j] * (w(kL.qpos + m.jnt_qadr[j]) - m.qpos0[m.jnt_qadr[j]]);
+      }
+    });
+    static_for<0, NU>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      w(kL.act + m.act_dof[u]) += m.act_gear[u] * Clamp(w(kL.ctrl + u), m.ctrl_lo, m.ctrl_hi);
+    });
+    static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      x[i] += w(kL.passive + i) + w(kL.act + i);
+      w(kL.smooth + i) = x[i];
+    });
+    SolveM(w, x);
+    static_for<0, NV>([&](auto ic) { w(kL.accs + decltype(ic)::value) = x[decltype(ic)::value]; });
+  }
+
+  // ---- mj_collision + joint-limit detection (phase A) ---------------------------------------
+  // Scalar loops over the static candidate lists (tables in constant memory, slot numbers
+  // wave-uniform).  Results per group in the workspace; `act` = this lane's active groups,
+  // `uni` = the wave-uniform union.
+  struct DetTab {
+    int lim_qadr[kMaxJnt];
+    double lim_lo[kMaxJnt], lim_hi[kMaxJnt];
+    int floor_geom[kMaxFloor], floor_caps[kMaxFloor];
+    double floor_off[kMaxFloor], floor_rad[kMaxFloor];  // off = sign * half length
+    int pair_g1[kMaxPair], pair_g2[kMaxPair], pair_kind[kMaxPair];  // 0 ss, 1 sphere-capsule, 2 cc
+    double pair_r1[kMaxPair], pair_r2[kMaxPair], pair_h1[kMaxPair], pair_h2[kMaxPair];
+    double pair_bound2[kMaxPair];
+  };
+  static constexpr DetTab MakeDetTab() {
+    constexpr TreeModel m = MP::kM;
+    DetTab t{};
+    for (int g = 0; g < m.nlimit; ++g) {
+      t.lim_qadr[g] = m.jnt_qadr[m.limit_jnt[g]];
+      t.lim_lo[g] = m.jnt_lo[m.limit_jnt[g]];
+      t.lim_hi[g] = m.jnt_hi[m.limit_jnt[g]];
+    }
+    for (int c = 0; c < m.nfloor; ++c) {
+      const int g = m.floor_geom[c];
+      t.floor_geom[c] = g;
+      t.floor_caps[c] = m.geom_type[g] == kGeomCapsule;
+      t.floor_off[c] = m.floor_sign[c] * m.geom_hl[g];
+      t.floor_rad[c] = m.geom_rad[g];
+    }
+    for (int p = 0; p < m.npair; ++p) {
+      const int g1 = m.pair_g1[p], g2 = m.pair_g2[p];
+      t.pair_g1[p] = g1;
+      t.pair_g2[p] = g2;
+      t.pair_kind[p] = m.geom_type[g1] == kGeomCapsule ? 2 : (m.geom_type[g2] == kGeomCapsule ? 1 : 0);
+      t.pair_r1[p] = m.geom_rad[g1];
+      t.pair_r2[p] = m.geom_rad[g2];
+      t.pair_h1[p] = m.geom_hl[g1];
+      t.pair_h2[p] = m.geom_hl[g2];
+      const double bound = m.geom_rad[g1] + m.geom_hl[g1] + m.geom_rad[g2] + m.geom_hl[g2] + m.margin;
+      t.pair_bound2[p] = bound * bound;
+    }
+    return t;
+  }
+  static EPA_HD void SetBit(GMask& act, GMask& uni, int g, bool on) {
+    const unsigned long long bit = 1ull << (g & 63);
+    const bool wany = WaveAny(on);
+    static_for<0, kGW>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const bool here = (g >> 6) == k;
+      act.w[k] |= (here && on) ? bit : 0ull;
+      uni.w[k] |= (here && wany) ? bit : 0ull;
+    });
+  }
+  // sphere-sphere: returns dist; n from 1 to 2; pos midway
+  static EPA_HD double SphereSphere(Vec3 p1, double r1, Vec3 p2, double r2, Vec3* n, Vec3* pos) {
+    const Vec3 dif = p2 - p1;
+    const double cd = sqrt(Dot(dif, dif));
+    const bool far = cd >= kMinVal;
+    const double inv = 1.0 / Sel(far, cd, 1.0);
+    *n = {Sel(far, dif.x * inv, 1.0), Sel(far, dif.y * inv, 0.0), Sel(far, dif.z * inv, 0.0)};
+    const double dist = cd - r1 - r2;
+    *pos = p1 + *n * (r1 + 0.5 * dist);
+    return dist;
+  }
+  static EPA_HD Vec3 Load3(Ws w, int slot) { return {w(slot), w(slot + 1), w(slot + 2)}; }
+  static EPA_HD void Detect(Ws w, GMask& act, GMask& uni) {
+    constexpr TreeModel m = MP::kM;
+    static constexpr DetTab dt = MakeDetTab();
+    static_for<0, kGW>([&](auto kc) { act.w[decltype(kc)::value] = uni.w[decltype(kc)::value] = 0ull; });
+    // joint limits (mj_instantiateLimit): dist = q - lo (J = +1) or hi - q (J = -1); margin 0
+    for (int g = 0; g < kNLimit; ++g) {
+      const double q = w(kL.qpos + dt.lim_qadr[g]);
+      const double dlo = q - dt.lim_lo[g], dhi = dt.lim_hi[g] - q;
+      const bool lo = dlo < 0.0, on = lo || dhi < 0.0;
+      SetBit(act, uni, g, on);
+      if (WaveAny(on)) {
+        w(kL.limd + g) = Sel(lo, dlo, dhi);
+        w(kL.lims + g) = Sel(lo, 1.0, -1.0);
+      }
+    }
+    // floor (plane z = 0, normal +z): mjc_PlaneSphere on spheres and capsule end spheres
+    for (int c = 0; c < kNFloor; ++c) {
+      const int g = dt.floor_geom[c];
+      Vec3 ctr = Load3(w, kL.gpos + 3 * g);
+      if (dt.floor_caps[c]) ctr = ctr + Load3(w, kL.gaxis + 3 * g) * dt.floor_off[c];
+      const double dist = ctr.z - dt.floor_rad[c];
+      const bool on = dist < m.margin;
+      SetBit(act, uni, kNLimit + c, on);
+      if (WaveAny(on)) {
+        w(kL.condist + c) = dist;
+        w(kL.conpos + 3 * c) = ctr.x;
+        w(kL.conpos + 3 * c + 1) = ctr.y;
+        w(kL.conpos + 3 * c + 2) = 0.5 * dist;  // centre - n (r + dist / 2)
+      }
+    }
+    // geom pairs: sphere / capsule primitives (mjraw_SphereSphere / SphereCapsule / CapsuleCapsule)
+    for (int p = 0; p < kNPair; ++p) {
+      const int g1 = dt.pair_g1[p], g2 = dt.pair_g2[p], kind = dt.pair_kind[p];
+      const int c = kNFloor + p;
+      const double r1 = dt.pair_r1[p], r2 = dt.pair_r2[p];
+      const Vec3 p1 = Load3(w, kL.gpos + 3 * g1), p2 = Load3(w, kL.gpos + 3 * g2);
+      // wave-level cull on bounding spheres
+      const Vec3 dc = p2 - p1;
+      const bool near = Dot(dc, dc) < dt.pair_bound2[p];
+      bool on = false;
+      if (WaveAny(near)) {
+        Vec3 q1 = p1, q2 = p2;
+        if (kind == 2) {
+          const Vec3 a1 = Load3(w, kL.gaxis + 3 * g1) * dt.pair_h1[p];
+          const Vec3 a2 = Load3(w, kL.gaxis + 3 * g2) * dt.pair_h2[p];
+          const Vec3 dif = p1 - p2;
+          const double ma = Dot(a1, a1), mb = -Dot(a1, a2), mc = Dot(a2, a2);
+          const double u = -Dot(a1, dif), v = Dot(a2, dif);
+          const double det = ma * mc - mb * mb;
+          const bool reg = fabs(det) >= kMinVal;
+          const double idet = 1.0 / Sel(reg, det, 1.0);
+          double x1 = (mc * u - mb * v) * idet, x2 = (ma * v - mb * u) * idet;
+          {  // clamp x1, recompute x2; then clamp x2, recompute x1
+            const bool hi1 = x1 > 1.0, lo1 = x1 < -1.0;
+            x2 = Sel(hi1, (v - mb) / mc, Sel(lo1, (v + mb) / mc, x2));
+            x1 = Sel(hi1, 1.0, Sel(lo1, -1.0, x1));
+            const bool hi2 = x2 > 1.0, lo2 = x2 < -1.0;
+            const double y1 = Clamp(Sel(hi2, (u - mb) / ma, (u + mb) / ma), -1.0, 1.0);
+            x1 = Sel(hi2 || lo2, y1, x1);
+            x2 = Sel(hi2, 1.0, Sel(lo2, -1.0, x2));
+          }
+          {  // exactly parallel axes: midpoint of the overlap (see oracle/mjcpu/engine.c)
+            const double lo = fmax(-1.0, (u - fabs(mb)) / ma), hi = fmin(1.0, (u + fabs(mb)) / ma);
+            const double px1 = Sel(lo <= hi, 0.5 * (lo + hi), Sel(lo > 1.0, 1.0, -1.0));
+            const double px2 = Clamp((v - mb * px1) / mc, -1.0, 1.0);
+            x1 = Sel(reg, x1, px1);
+            x2 = Sel(reg, x2, px2);
+          }
+          q1 = p1 + a1 * x1;
+          q2 = p2 + a2 * x2;
+        } else if (kind == 1) {
+          const Vec3 ax = Load3(w, kL.gaxis + 3 * g2);
+          const double h2 = dt.pair_h2[p];
+          q2 = p2 + ax * Clamp(Dot(ax, p1 - p2), -h2, h2);
+        }
+        Vec3 n, pos;
+        const double dist = SphereSphere(q1, r1, q2, r2, &n, &pos);
+        on = near && dist < m.margin;
+        if (WaveAny(on)) {
+          w(kL.condist + c) = dist;
+          w(kL.conpos + 3 * c) = pos.x;
+          w(kL.conpos + 3 * c + 1) = pos.y;
+          w(kL.conpos + 3 * c + 2) = pos.z;
+          w(kL.connrm + 3 * c) = n.x;
+          w(kL.connrm + 3 * c + 1) = n.y;
+          w(kL.connrm + 3 * c + 2) = n.z;
+        }
+      }
+      SetBit(act, uni, kNLimit + c, on);
+    }
+  }
+
+  // scalar iteration over the set bits of a wave-uniform group mask
+  static EPA_HD int NextGroup(const GMask& uni, int from) {
+    int found = -1;
+    static_for_down<kGW, 0>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const int lo = from - 64 * k;  // first candidate bit inside word k
+      const unsigned long long keep = lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
+      const unsigned long long mw = uni.w[k] & keep;
+      if (mw != 0ull) found = 64 * k + Ctz64(mw);
+    });
+    return found;
+  }
+  static EPA_HD bool LaneHas(const GMask& act, int g) {
+    unsigned long long word = 0ull;
+    static_for<0, kGW>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      word = (g >> 6) == k ? act.w[k] : word;
+    });
+    return (word >> (g & 63)) & 1ull;
+  }
+
+  static EPA_HD double Impedance(double x_abs) {  // solimp (d0, dmax, width, 0.5, 2)
+    constexpr TreeModel m = MP::kM;
+    const double x = x_abs * (1.0 / m.sol_width);
+    const double y = Sel(x <= 0.5, 2.0 * x * x, 1.0 - 2.0 * (1.0 - x) * (1.0 - x));
+    return Sel(x >= 1.0, m.sol_dmax, m.sol_d0 + y * (m.sol_dmax - m.sol_d0));
+  }
+
+  // ---- mj_makeConstraint + mj_projectConstraint rows (phase B: one code instance, scalar loop
+  // over the groups some lane needs).  Also the warm-start forces f = -D min(0, J a_warm - aref).
+  static EPA_HD void MakeRows(Ws w0, const GMask& act, const GMask& uni) {
+    constexpr TreeModel m = MP::kM;
+    static constexpr GroupTab gt = MakeGroupTab(MP::kM);
+    const Vec3 com = {w0(kL.com), w0(kL.com + 1), w0(kL.com + 2)};
+    {
+      for (int g = NextGroup(uni, 0); g >= 0; g = NextGroup(uni, g + 1)) {
+        const Ws w = w0.Fresh();
+        const bool on = LaneHas(act, g);
+        const bool is_limit = g < kNLimit, is_floor = !is_limit && g < kNLimit + kNFloor;
+        const int c = g - kNLimit;  // contact index (floor, then pairs)
+        double jn[NV], jt1[NV], jt2[NV];
+        double pos;
+        if (is_limit) {
+          const int d = gt.dof[g];
+          const double s = w(kL.lims + g);
+          pos = w(kL.limd + g);
+          static_for<0, NV>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            jn[i] = i == d ? s : 0.0;
+            jt1[i] = jt2[i] = 0.0;
+          });
+        } else {
+          pos = w(kL.condist + c) - m.margin;  // r = dist - includemargin
+          const Vec3 off = Vec3{w(kL.conpos + 3 * c), w(kL.conpos + 3 * c + 1), w(kL.conpos + 3 * c + 2)} - com;
+          // floor frame (mju_makeFrame of +z): n = z, t1 = y, t2 = -x
+          Vec3 n = {0, 0, 1};
+          if (!is_floor) n = {w(kL.connrm + 3 * c), w(kL.connrm + 3 * c + 1), w(kL.connrm + 3 * c + 2)};
+          const Vec3 mn = Cross(off, n);
+          const Vec3 mt1 = Cross(off, Vec3{0, 1, 0}), mt2 = Cross(off, Vec3{-1, 0, 0});
+          const unsigned m1 = gt.mask1[g], m2 = gt.mask2[g];
+          static_for<0, NV>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int coef = (int)((m2 >> i) & 1u) - (int)((m1 >> i) & 1u);
+            jn[i] = jt1[i] = jt2[i] = 0.0;
+            if (coef != 0) {  // scalar: the masks are per group
+              const Vec3 ang = {w(kL.cdof + 6 * i), w(kL.cdof + 6 * i + 1), w(kL.cdof + 6 * i + 2)};
+              const Vec3 lin = {w(kL.cdof + 6 * i + 3), w(kL.cdof + 6 * i + 4), w(kL.cdof + 6 * i + 5)};
+              const double sg = (double)coef;
+              jn[i] = sg * (Dot(n, lin) + Dot(mn, ang));
+              if (is_floor) {
+                jt1[i] = sg * (lin.y + Dot(mt1, ang));
+                jt2[i] = sg * (-lin.x + Dot(mt2, ang));
+              }
+            }
+          });
+        }
+        // impedance / regulariser of the group (mj_makeImpedance); pyramid rows share 2 mu^2 R
+        const double imp = Impedance(fabs(pos));
+        double R = fmax(kMinVal, (1.0 - imp) * gt.diag[g] / imp);
+        if (is_floor) R *= 2.0 * m.floor_mu * m.floor_mu;
+        const double kimp = m.sol_K * imp * pos;
+        const int nsub = is_floor ? 4 : 1;
+        const int row0 = is_limit ? g : (is_floor ? kNLimit + 4 * c : kNLimit + 4 * kNFloor + (c - kNFloor));
+#pragma nounroll
+        for (int k = 0; k < nsub; ++k) {
+          const Ws w = w0.Fresh();
+          const double c1 = is_floor ? (k == 0 ? m.floor_mu : (k == 1 ? -m.floor_mu : 0.0)) : 0.0;
+          const double c2 = is_floor ? (k == 2 ? m.floor_mu : (k == 3 ? -m.floor_mu : 0.0)) : 0.0;
+          const int r = row0 + k;
+          double x[NV];
+          double vel = 0.0, jw = 0.0;
+          static_for<0, NV>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            x[i] = jn[i] + c1 * jt1[i] + c2 * jt2[i];
+            vel += x[i] * w(kL.qvel + i);
+            jw += x[i] * w(kL.warm + i);
+            w(kL.rowJ + r * NV + i) = x[i];
+          });
+          SolveM(w, x);
+          double arr = R;
+          static_for<0, NV>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            arr += (jn[i] + c1 * jt1[i] + c2 * jt2[i]) * x[i];
+            w(kL.rowW + r * NV + i) = x[i];
+          });
+          const double aref = -m.sol_B * vel - kimp;
+          const double jar = jw - aref;
+          w(kL.rowR + r) = R;
+          w(kL.rowAref + r) = aref;
+          w(kL.rowArr + r) = arr;
+          w(kL.rowF + r) = (on && jar < 0.0) ? -jar / R : 0.0;
+        }
+      }
+    }
+  }
+
+  // visit the rows of the union mask in order: f(row, lane_has_row)
+  template <typename F>
+  static EPA_HD void ForRows(const GMask& act, const GMask& uni, F&& f) {
+    for (int g = NextGroup(uni, 0); g >= 0; g = NextGroup(uni, g + 1)) {
+      const bool on = LaneHas(act, g);
+      const bool is_limit = g < kNLimit, is_floor = !is_limit && g < kNLimit + kNFloor;
+      const int row0 = is_limit ? g : (is_floor ? kNLimit + 4 * (g - kNLimit) : g + 3 * kNFloor);
+      const int nsub = is_floor ? 4 : 1;
+#pragma nounroll
+      for (int k = 0; k < nsub; ++k) f(row0 + k, on);
+    }
+  }
+
+  // ---- mj_fwdConstraint with mj_solPGS ----------------------------------------------------------
+  // `commit`: lanes that are only kept busy must not disturb their warm start.
+  static EPA_HD void SolvePgs(Ws w, const GMask& act, const GMask& uni, bool commit) {
+    constexpr TreeModel m = MP::kM;
+    double a[NV], u[NV];
+    bool any = false;
+    static_for<0, kGW>([&](auto kc) { any = any || uni.w[decltype(kc)::value] != 0ull; });
+    if (any) {
+      // dual cost of the warm-start forces: 1/2 f'(A+R)f + f'b, b = J qacc_smooth - aref;
+      // keep them only if it is below the cost of f = 0
+      static_for<0, NV>([&](auto ic) { a[decltype(ic)::value] = u[decltype(ic)::value] = 0.0; });
+      double cost = 0.0;
+      ForRows(act, uni, [&](int r, bool on) {
+        (void)on;
+        const double f = w(kL.rowF + r);
+        double jb = 0.0;
+        static_for<0, NV>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          const double J = w(kL.rowJ + r * NV + i);
+          u[i] += f * J;
+          a[i] += f * w(kL.rowW + r * NV + i);
+          jb += J * w(kL.accs + i);
+        });
+        cost += f * (0.5 * w(kL.rowR + r) * f + jb - w(kL.rowAref + r));
+      });
+      static_for<0, NV>([&](auto ic) { cost += 0.5 * u[decltype(ic)::value] * a[decltype(ic)::value]; });
+      const bool cold = cost > 0.0;
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        a[i] = w(kL.accs + i) + Sel(cold, 0.0, a[i]);
+      });
+      if (WaveAny(cold)) {
+        ForRows(act, uni, [&](int r, bool on) {
+          (void)on;
+          if (cold) w(kL.rowF + r) = 0.0;
+        });
+      }
+      const double scale = 1.0 / (m.meaninertia * (double)NV);
+      bool done = false;
+      for (int iter = 0; iter < m.iterations; ++iter) {
+        double improvement = 0.0;
+        ForRows(act, uni, [&](int r, bool on) {
+          const double f = w(kL.rowF + r), arr = w(kL.rowArr + r);
+          double res = w(kL.rowR + r) * f - w(kL.rowAref + r);
+          static_for<0, NV>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            res += w(kL.rowJ + r * NV + i) * a[i];
+          });
+          double fn = fmax(0.0, f - res / arr);
+          double delta = fn - f;
+          double change = 0.5 * delta * delta * arr + delta * res;
+          const bool keep = on && !done && !(change > 1e-10);
+          delta = Sel(keep, delta, 0.0);
+          improvement -= Sel(keep, change, 0.0);
+          w(kL.rowF + r) = f + delta;
+          static_for<0, NV>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            a[i] += delta * w(kL.rowW + r * NV + i);
+          });
+        });
+        done = done || improvement * scale < 1e-8;
+        if (!WaveAny(!done)) break;
+      }
+      // dual finish: qfrc_constraint = J' f, qacc = qacc_smooth + M^-1 qfrc_constraint
+      static_for<0, NV>([&](auto ic) { u[decltype(ic)::value] = 0.0; });
+      ForRows(act, uni, [&](int r, bool on) {
+        (void)on;
+        const double f = w(kL.rowF + r);
+        static_for<0, NV>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          u[i] += f * w(kL.rowJ + r * NV + i);
+        });
+      });
+      SolveM(w, u);
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        a[i] = w(kL.accs + i) + u[i];
+      });
+    } else {
+      static_for<0, NV>([&](auto ic) { a[decltype(ic)::value] = w(kL.accs + decltype(ic)::value); });
+    }
+    static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      w(kL.qacc + i) = a[i];
+      if (commit) w(kL.warm + i) = a[i];
+    });
+  }
+
+  // mj_forward
+  static EPA_HD void Forward(Ws w, GMask& act, GMask& uni, bool commit) {
+    // Fresh(): every stage recomputes its slot addresses locally (see Ws::Fresh)
+    Kinematics(w.Fresh());
+    EPA_TREE_FENCE();
+    ComPos(w.Fresh());
+    EPA_TREE_FENCE();
+    CrbFactor(w.Fresh());
+    EPA_TREE_FENCE();
+    Detect(w.Fresh(), act, uni);
+    EPA_TREE_FENCE();
+    Velocity(w.Fresh());
+    EPA_TREE_FENCE();
+    MakeRows(w.Fresh(), act, uni);
+    EPA_TREE_FENCE();
+    SolvePgs(w.Fresh(), act, uni, commit);
+    EPA_TREE_FENCE();
+  }
+
+  // mj_integratePos from the saved q0 with velocity slot `vel` scaled by `h`; result -> qpos
+  static EPA_HD void IntegratePos(Ws w, int vel, double h, bool commit) {
+    constexpr TreeModel m = MP::kM;
+    static_for<0, NJ>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int qa = m.jnt_qadr[j], da = m.jnt_dadr[j];
+      if constexpr (m.jnt_type[j] == kJntFree) {
+        static_for<0, 3>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          const double v = w(kL.x0q + qa + k) + h * w(vel + da + k);
+          if (commit) w(kL.qpos + qa + k) = v;
+        });
+        const Vec3 om = {w(vel + da + 3), w(vel + da + 4), w(vel + da + 5)};
+        const double nrm = sqrt(Dot(om, om));
+        const bool rot = nrm * h > 0.0;
+        const double inv = 1.0 / Sel(rot, nrm, 1.0);
+        double sn, cs;
+        SinCos(0.5 * nrm * h, &sn, &cs);
+        const Quat q0 = {w(kL.x0q + qa + 3), w(kL.x0q + qa + 4), w(kL.x0q + qa + 5), w(kL.x0q + qa + 6)};
+        const Quat q1 = QNormalize(QMul(q0, Quat{cs, om.x * inv * sn, om.y * inv * sn, om.z * inv * sn}));
+        if (commit) {
+          w(kL.qpos + qa + 3) = Sel(rot, q1.w, q0.w);
+          w(kL.qpos + qa + 4) = Sel(rot, q1.x, q0.x);
+          w(kL.qpos + qa + 5) = Sel(rot, q1.y, q0.y);
+          w(kL.qpos + qa + 6) = Sel(rot, q1.z, q0.z);
+        }
+      } else {
+        const double v = w(kL.x0q + qa) + h * w(vel + da);
+        if (commit) w(kL.qpos + qa) = v;
+      }
+    });
+  }
+
+  // One stage boundary of mj_RungeKutta(4).  Called after the forward evaluation of stage
+  // `stage` (0: the evaluation at the start state).  Stages 0..2 move the state to the next
+  // stage point, stage 3 finishes the step.  `live`: lanes that really integrate.
+  static EPA_HD void RkAdvance(Ws w, int stage, bool live) {
+    constexpr TreeModel m = MP::kM;
+    const double h = m.timestep;
+    const double B = stage == 0 || stage == 3 ? 1.0 / 6.0 : 1.0 / 3.0;
+    const double A = stage == 2 ? 1.0 : 0.5;
+    if (stage == 0) {
+      static_for<0, NQ>([&](auto ic) {
+        if (live) w(kL.x0q + decltype(ic)::value) = w(kL.qpos + decltype(ic)::value);
+      });
+    }
+    static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const double v = w(kL.qvel + i), acc = w(kL.qacc + i);
+      if (stage == 0) {
+        if (live) {
+          w(kL.x0v + i) = v;
+          w(kL.accq + i) = B * v;
+          w(kL.accv + i) = B * acc;
+        }
+      } else if (live) {
+        w(kL.accq + i) += B * v;
+        w(kL.accv + i) += B * acc;
+      }
+    });
+    if (stage < 3) {
+      // X[i+1] = X0 + h A (Xv[i], F[i]); qvel (the stage velocity) is still in place
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (live) w(kL.accs + i) = A * w(kL.qvel + i);  // scratch: dq
+      });
+      IntegratePos(w, kL.accs, h, live);
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (live) w(kL.qvel + i) = w(kL.x0v + i) + h * A * w(kL.qacc + i);
+      });
+    } else {
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (live) w(kL.qvel + i) = w(kL.x0v + i) + h * w(kL.accv + i);
+      });
+      IntegratePos(w, kL.accq, h, live);
+    }
+  }
+
+  // mj_rnePostConstraint, cfrc_ext part: contact forces of the LAST forward evaluation as
+  // spatial forces [torque; force] about the c-frame origin (mju_decodePyramid for the floor).
+  static EPA_HD void ContactWrench(Ws w, const GMask& act, const GMask& uni) {
+    constexpr TreeModel m = MP::kM;
+    static constexpr GroupTab gt = MakeGroupTab(MP::kM);
+    static_for<0, 6 * NB>([&](auto kc) { w(kL.cext + decltype(kc)::value) = 0.0; });
+    const Vec3 com = {w(kL.com), w(kL.com + 1), w(kL.com + 2)};
+    {
+      for (int g = NextGroup(uni, kNLimit); g >= 0; g = NextGroup(uni, g + 1)) {
+        const bool on = LaneHas(act, g);
+        const int c = g - kNLimit;
+        const bool is_floor = c < kNFloor;
+        Vec3 F;
+        if (is_floor) {
+          const int r = kNLimit + 4 * c;
+          const double f0 = w(kL.rowF + r), f1 = w(kL.rowF + r + 1), f2 = w(kL.rowF + r + 2),
+                       f3 = w(kL.rowF + r + 3);
+          // frame rows n = z, t1 = y, t2 = -x
+          F = {-(f2 - f3) * m.floor_mu, (f0 - f1) * m.floor_mu, f0 + f1 + f2 + f3};
+        } else {
+          const double f = w(kL.rowF + kNLimit + 4 * kNFloor + (c - kNFloor));
+          F = Vec3{w(kL.connrm + 3 * c), w(kL.connrm + 3 * c + 1), w(kL.connrm + 3 * c + 2)} * f;
+        }
+        F = F * Sel(on, 1.0, 0.0);
+        const Vec3 off = Vec3{w(kL.conpos + 3 * c), w(kL.conpos + 3 * c + 1), w(kL.conpos + 3 * c + 2)} - com;
+        const Vec3 tq = Cross(off, F);
+        const double w6[6] = {Sel(on, tq.x, 0.0), Sel(on, tq.y, 0.0), Sel(on, tq.z, 0.0), F.x, F.y, F.z};
+        const int s1 = kL.cext + 6 * gt.b1[g], s2 = kL.cext + 6 * gt.b2[g];
+        static_for<0, 6>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          w(s1 + r) -= w6[r];
+          w(s2 + r) += w6[r];
+        });
+      }
+    }
+  }
+};
+
+}  // namespace tree
+}  // namespace mj
+}  // namespace epa
+
+#endif  // ENVPOOL_AMD_CSRC_MJ_TREE_CUH_

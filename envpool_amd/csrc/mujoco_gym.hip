@@ -428,6 +428,9 @@ Pool* MakeAnt(const std::string& family, const Config& cfg);
 bool DescribePendulum(const std::string& family, const Config& cfg,
                       std::vector<KeySpec>* state, KeySpec* action);
 Pool* MakePendulum(const std::string& family, const Config& cfg);
+bool DescribeHumanoid(const std::string& family, const Config& cfg,
+                      std::vector<KeySpec>* state, KeySpec* action);
+Pool* MakeHumanoid(const std::string& family, const Config& cfg);
 
 bool DescribeMujoco(const std::string& family, const Config& cfg,
                     std::vector<KeySpec>* state, KeySpec* action) {
@@ -437,6 +440,7 @@ bool DescribeMujoco(const std::string& family, const Config& cfg,
     return true;
   }
   if (DescribePendulum(family, cfg, state, action)) return true;
+  if (DescribeHumanoid(family, cfg, state, action)) return true;
   return DescribeAnt(family, cfg, state, action);
 }
 
@@ -449,6 +453,7 @@ Pool* MakeMujoco(const std::string& family, const Config& cfg) {
                                                          : mj::kPlanarWalker);
   }
   if (Pool* p = MakePendulum(family, cfg)) return p;
+  if (Pool* p = MakeHumanoid(family, cfg)) return p;
   return MakeAnt(family, cfg);
 }
 

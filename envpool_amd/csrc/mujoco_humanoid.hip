@@ -1,0 +1,346 @@
+// K3c — gym-MuJoCo Humanoid / HumanoidStandup batched step kernel (one env per lane, one
+// wave per workgroup, per-env workspace in HBM: see mj_tree.cuh).
+//
+// Replaces, for the whole batch in one launch:
+//   MujocoEnv::{MujocoReset,MujocoStep}   envpool/mujoco/gym/mujoco_env.h:126-148
+//   HumanoidEnvBase::{MujocoResetModel,Reset,Step,IsHealthy,GetMassCenter,WriteState}
+//                                         envpool/mujoco/gym/humanoid.h:129-268
+//   HumanoidStandupEnvBase::{...}         envpool/mujoco/gym/humanoid_standup.h:119-240
+// with `frame_skip x mj_step` (RK4: 4 forward passes each, PGS 50 iterations) and, for the
+// v5 ids, mj_rnePostConstraint's cfrc_ext.
+// v3 / v4 ids register post_constraint=False (gym/registration.py:95-124): MuJoCo 3 fills
+// cfrc_ext only in mj_rnePostConstraint, so their 84 cfrc_ext observations and the contact
+// cost stay zero, exactly as in the reference.
+//
+// The observation's cinert / cvel / qfrc_actuator / cfrc_ext and the mass centre belong to
+// the LAST forward evaluation (RK4 stage 4 of the last sub-step), like the mjData fields the
+// reference reads; the mass centre "before" a step is therefore the lagged one of the
+// previous step (persistent slot `lag`).
+#include "device_common.cuh"
+#include "engine.h"
+#include "mj_tree.cuh"
+#include "build/mj_humanoid_consts.inc"  // generated: kHumanoidModelConst, kHumanoidStandupModelConst
+
+namespace epa {
+namespace {
+
+namespace T = mj::tree;
+
+struct HumanoidMP {
+  static constexpr T::TreeModel kM = kHumanoidModelConst;
+};
+struct StandupMP {
+  static constexpr T::TreeModel kM = kHumanoidStandupModelConst;
+};
+
+struct HumDev {
+  double* ws;     // [ceil(N / 64)][Layout::total][64]: block b belongs to wave b of a launch
+  double* state;  // [Layout::npersist][N]: what persists between steps, per env
+};
+
+struct HumTask {
+  int frame_skip, obs_skip;
+  int terminate_when_unhealthy, legacy_healthy_reward;
+  int use_contact_force, post_constraint, exclude_worldbody, exclude_root_actuator;
+  double ctrl_cost_weight, forward_reward_weight, healthy_reward;
+  double healthy_z_min, healthy_z_max, reset_noise_scale, dt;
+  double contact_cost_weight, contact_cost_max;
+};
+
+constexpr int kHumBlock = 64;
+
+
+template <class MP, bool kStandup>
+__global__ __launch_bounds__(kHumBlock) void HumanoidStepKernel(
+    HumDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
+    HumTask task) {
+  using E = T::Tree<MP>;
+  constexpr T::TreeModel m = MP::kM;
+  constexpr T::Layout L = E::kL;
+  const int row = blockIdx.x * kHumBlock + threadIdx.x;
+  if (row >= a.k) return;
+  const int e = a.ids ? a.ids[row] - a.id_offset : row;
+  const int n = cm.n;
+  const T::Ws w{dev.ws + (size_t)blockIdx.x * L.total * 64, threadIdx.x};
+  bool done = cm.done[e] != 0;
+  int cur = cm.cur_step[e];
+  const bool reset = a.force_reset || done;
+  double ctrl_cost = 0.0;
+  for (int i = 0; i < L.npersist; ++i) w(i) = dev.state[(size_t)i * n + e];
+  if (reset) {
+    // MujocoReset (mujoco_env.h:126-131) + MujocoResetModel (humanoid.h:129-141): one
+    // uniform distribution for qpos and qvel; mj_resetData clears ctrl and the warm start
+    cur = 0;
+    done = false;
+    Mt19937 g(cm, e);
+    for (int i = 0; i < E::NQ; ++i) {
+      // (runtime loop: the table lookup is wave-uniform)
+      static constexpr T::TreeModel mm = MP::kM;
+      w(L.qpos + i) = mm.qpos0[i] + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
+    }
+    for (int i = 0; i < E::NV; ++i) {
+      w(L.qvel + i) = 0.0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
+      w(L.warm + i) = 0.0;
+    }
+    for (int i = 0; i < E::NU; ++i) w(L.ctrl + i) = 0.0;
+    g.Commit();
+  } else {
+    ++cur;
+    const double* act = action + (size_t)row * E::NU;
+    for (int i = 0; i < E::NU; ++i) {
+      const double ai = act[i];
+      ctrl_cost += task.ctrl_cost_weight * ai * ai;  // humanoid.h:171-174
+      w(L.ctrl + i) = ai;                            // clamped to ctrlrange in mj_fwdActuation
+    }
+  }
+  const double x_before = w(L.lag), y_before = w(L.lag + 1);
+  // reset lanes: mj_forward once; stepping lanes: frame_skip x (4 RK stages).  Every lane runs
+  // the wave's trip count with its own state writes predicated (no divergent control flow).
+  const int nfwd = reset ? 1 : 4 * task.frame_skip;
+  const int nmax = mj::WaveAny(!reset) ? 4 * task.frame_skip : 1;
+  T::GMask gact, guni;
+  for (int it = 0; it < nmax; ++it) {
+    const bool live = it < nfwd;
+    E::Forward(w, gact, guni, live);
+    E::RkAdvance(w.Fresh(), it & 3, live && !reset);
+  }
+  // mj_rnePostConstraint after the last mj_step (mujoco_env.h:145-147)
+  const bool wrench = task.post_constraint != 0;
+  if (wrench) E::ContactWrench(w, gact, guni);
+  double mx = 0.0, my = 0.0;  // GetMassCenter, humanoid.h:212-223
+  mj::static_for<1, E::NB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    mx += m.body_mass[b] * w(L.xipos + 3 * b);
+    my += m.body_mass[b] * w(L.xipos + 3 * b + 1);
+  });
+  mx /= m.total_mass;
+  my /= m.total_mass;
+  w(L.lag) = mx;
+  w(L.lag + 1) = my;
+  for (int i = 0; i < L.npersist; ++i) dev.state[(size_t)i * n + e] = w(i);
+  const bool have_cfrc = wrench && !reset;  // a reset leaves mj_resetData's zeros
+  float reward = 0.0f;
+  double info[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (!reset) {
+    double contact_cost = 0.0;
+    if ((kStandup || task.use_contact_force) && have_cfrc) {  // humanoid.h:180-187
+      for (int i = 0; i < 6 * E::NB; ++i) {
+        const double x = w(L.cext + i);
+        contact_cost += task.contact_cost_weight * x * x;
+      }
+      contact_cost = contact_cost < task.contact_cost_max ? contact_cost : task.contact_cost_max;
+    }
+    const double z = w(L.qpos + 2);
+    if constexpr (kStandup) {  // humanoid_standup.h:160-185
+      const double xv = z / m.timestep;
+      reward = static_cast<float>(xv * task.forward_reward_weight + task.healthy_reward -
+                                  ctrl_cost - contact_cost);
+      done = cur >= a.max_episode_steps;
+      info[0] = xv * task.forward_reward_weight;
+      info[1] = -ctrl_cost;
+      info[2] = task.healthy_reward;
+      info[3] = -contact_cost;
+    } else {
+      const double xv = (mx - x_before) / task.dt, yv = (my - y_before) / task.dt;
+      const bool healthy = task.healthy_z_min < z && z < task.healthy_z_max;
+      bool give = healthy;
+      if (task.legacy_healthy_reward) give = task.terminate_when_unhealthy || healthy;
+      const double healthy_reward = give ? task.healthy_reward : 0.0;
+      reward = static_cast<float>(xv * task.forward_reward_weight + healthy_reward - ctrl_cost -
+                                  contact_cost);
+      done = (task.terminate_when_unhealthy ? !healthy : false) || (cur >= a.max_episode_steps);
+      info[0] = xv * task.forward_reward_weight;
+      info[1] = -ctrl_cost;
+      info[2] = healthy_reward;
+      info[3] = -contact_cost;
+      info[4] = mx;
+      info[5] = my;
+      info[6] = sqrt(mx * mx + my * my);
+      info[7] = xv;
+      info[8] = yv;
+    }
+  } else if (kStandup) {
+    info[2] = task.healthy_reward;  // WriteState(0, 0, 0, 0): reward_alive is the constant
+  }
+  cm.done[e] = done ? 1 : 0;
+  cm.cur_step[e] = cur;
+  // WriteState, humanoid.h:225-268
+  const int b0 = task.exclude_worldbody ? 1 : 0;
+  const int a0 = task.exclude_root_actuator ? 6 : 0;
+  const int nobs = (E::NQ - task.obs_skip) + E::NV + 22 * (E::NB - b0) + (E::NV - a0);
+  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
+  for (int i = task.obs_skip; i < E::NQ; ++i) *(obs++) = w(L.qpos + i);
+  for (int i = 0; i < E::NV; ++i) *(obs++) = w(L.qvel + i);
+  for (int i = 10 * b0; i < 10 * E::NB; ++i) *(obs++) = i < 10 ? 0.0 : w(L.cinert + i);
+  for (int i = 6 * b0; i < 6 * E::NB; ++i) *(obs++) = w(L.cvel + i);
+  for (int i = a0; i < E::NV; ++i) *(obs++) = w(L.act + i);
+  for (int i = 6 * b0; i < 6 * E::NB; ++i) *(obs++) = have_cfrc ? w(L.cext + i) : 0.0;
+  constexpr int ninfo = kStandup ? 4 : 9;
+  for (int i = 0; i < ninfo; ++i) ((double*)out.p[kKeyEnv0 + 1 + i])[row] = info[i];
+  WriteCommon(out, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
+}
+
+// flat state like oracle/mjcpu: qpos[24] qvel[23] warm[23] time xlag ylag done cur_step
+// normal_saved normal_avail (the last two unused: uniform noise only; xlag / ylag: the lagged
+// mass centre)
+template <class MP>
+__global__ void HumGetState(HumDev dev, CommonDev cm, const int* ids, int k, double* out) {
+  using E = T::Tree<MP>;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  const int e = ids[i], n = cm.n;
+  constexpr int np = E::kL.npersist;  // qpos qvel warm lag[2], in this order
+  double* o = out + (size_t)i * (np + 5);
+  for (int j = 0; j < np - 2; ++j) o[j] = dev.state[(size_t)j * n + e];
+  double* t = o + np - 2;
+  t[0] = 0;
+  t[1] = dev.state[(size_t)(np - 2) * n + e];
+  t[2] = dev.state[(size_t)(np - 1) * n + e];
+  t[3] = cm.done[e];
+  t[4] = cm.cur_step[e];
+  t[5] = 0;
+  t[6] = 0;
+}
+template <class MP>
+__global__ void HumSetState(HumDev dev, CommonDev cm, const int* ids, int k, const double* in) {
+  using E = T::Tree<MP>;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  const int e = ids[i], n = cm.n;
+  constexpr int np = E::kL.npersist;
+  const double* o = in + (size_t)i * (np + 5);
+  for (int j = 0; j < np - 2; ++j) dev.state[(size_t)j * n + e] = o[j];
+  const double* t = o + np - 2;
+  dev.state[(size_t)(np - 2) * n + e] = t[1];
+  dev.state[(size_t)(np - 1) * n + e] = t[2];
+  cm.done[e] = t[3] != 0.0;
+  cm.cur_step[e] = (int)t[4];
+}
+
+int HumObsDim(const Config& cfg) {
+  // humanoid.h:50-60: 376 (378 with positions), minus the world body's cinert / cvel /
+  // cfrc_ext (22) and the free joint's qfrc_actuator (6) for the v5 ids
+  int n = cfg.Get("exclude_current_positions_from_observation", 1) != 0 ? 376 : 378;
+  if (cfg.Get("exclude_worldbody_observations", 0) != 0) n -= 22;
+  if (cfg.Get("exclude_root_actuator_forces", 0) != 0) n -= 6;
+  return n;
+}
+
+std::vector<KeySpec> HumKeys(const Config& cfg, bool standup) {
+  std::vector<KeySpec> k = {{"obs", EPA_F64, StackedObsShape(cfg, HumObsDim(cfg))}};
+  if (standup) {  // humanoid_standup.h:62-65
+    for (const char* name : {"info:reward_linup", "info:reward_quadctrl", "info:reward_alive",
+                             "info:reward_impact"}) {
+      k.push_back({name, EPA_F64, {}});
+    }
+  } else {  // humanoid.h:66-74
+    for (const char* name :
+         {"info:reward_linvel", "info:reward_quadctrl", "info:reward_alive", "info:reward_impact",
+          "info:x_position", "info:y_position", "info:distance_from_origin", "info:x_velocity",
+          "info:y_velocity"}) {
+      k.push_back({name, EPA_F64, {}});
+    }
+  }
+  return k;
+}
+
+class HumanoidPool : public Pool {
+ public:
+  HumanoidPool(const Config& cfg, bool standup)
+      : Pool(cfg, HumKeys(cfg, standup), KeySpec{"action", EPA_F64, {kHumanoidModelConst.nu}},
+             /*needs_rng=*/true),
+        standup_(standup) {
+    EnableObsStack();
+    // defaults: humanoid.h:32-48, humanoid_standup.h:32-45
+    task_.frame_skip = (int)cfg.Get("frame_skip", 5);
+    task_.obs_skip = cfg.Get("exclude_current_positions_from_observation", 1) != 0 ? 2 : 0;
+    task_.terminate_when_unhealthy = cfg.Get("terminate_when_unhealthy", 1) != 0;
+    task_.legacy_healthy_reward = cfg.Get("legacy_healthy_reward", 1) != 0;
+    task_.use_contact_force = cfg.Get("use_contact_force", 0) != 0;
+    task_.post_constraint = cfg.Get("post_constraint", 1) != 0;
+    task_.exclude_worldbody = cfg.Get("exclude_worldbody_observations", 0) != 0;
+    task_.exclude_root_actuator = cfg.Get("exclude_root_actuator_forces", 0) != 0;
+    task_.ctrl_cost_weight = cfg.Get("ctrl_cost_weight", 0.1);
+    task_.forward_reward_weight = cfg.Get("forward_reward_weight", standup ? 1.0 : 1.25);
+    task_.healthy_reward = cfg.Get("healthy_reward", standup ? 1.0 : 5.0);
+    task_.healthy_z_min = cfg.Get("healthy_z_min", 1.0);
+    task_.healthy_z_max = cfg.Get("healthy_z_max", 2.0);
+    task_.reset_noise_scale = cfg.Get("reset_noise_scale", 1e-2);
+    task_.contact_cost_weight = cfg.Get("contact_cost_weight", 5e-7);
+    task_.contact_cost_max = cfg.Get("contact_cost_max", 10.0);
+    task_.dt = task_.frame_skip * kHumanoidModelConst.timestep;
+    const size_t blocks = ((size_t)cfg.num_envs + 63) / 64;
+    ws_bytes_ = sizeof(double) * blocks * 64 * (size_t)Total();
+    EPA_HIP(hipMalloc(&dev_.ws, ws_bytes_));
+    EPA_HIP(hipMemsetAsync(dev_.ws, 0, ws_bytes_, stream_));
+    const size_t sb = sizeof(double) * (size_t)T::Tree<HumanoidMP>::kL.npersist * cfg.num_envs;
+    EPA_HIP(hipMalloc(&dev_.state, sb));
+    EPA_HIP(hipMemsetAsync(dev_.state, 0, sb, stream_));
+    InitCommon();
+  }
+  ~HumanoidPool() override {
+    (void)hipFree(dev_.ws);
+    (void)hipFree(dev_.state);
+  }
+  int StateDim() const override { return kHumanoidModelConst.nq + 2 * kHumanoidModelConst.nv + 7; }
+  void GetState(const int* d_ids, int k, double* d_out) override {
+    if (standup_) {
+      hipLaunchKernelGGL(HumGetState<StandupMP>, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
+                         common_, d_ids, k, d_out);
+    } else {
+      hipLaunchKernelGGL(HumGetState<HumanoidMP>, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
+                         common_, d_ids, k, d_out);
+    }
+  }
+  void SetState(const int* d_ids, int k, const double* d_in) override {
+    if (standup_) {
+      hipLaunchKernelGGL(HumSetState<StandupMP>, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
+                         common_, d_ids, k, d_in);
+    } else {
+      hipLaunchKernelGGL(HumSetState<HumanoidMP>, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
+                         common_, d_ids, k, d_in);
+    }
+  }
+
+ protected:
+  void Launch(const int* d_ids, int k, const void* d_action, bool force_reset,
+              const OutPtrs& out) override {
+    StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps, cfg_.env_id_offset};
+    const int blocks = (k + kHumBlock - 1) / kHumBlock;
+    const double* act = static_cast<const double*>(d_action);
+    if (standup_) {
+      hipLaunchKernelGGL((HumanoidStepKernel<StandupMP, true>), dim3(blocks), dim3(kHumBlock), 0,
+                         stream_, dev_, common_, a, act, out, task_);
+    } else {
+      hipLaunchKernelGGL((HumanoidStepKernel<HumanoidMP, false>), dim3(blocks), dim3(kHumBlock), 0,
+                         stream_, dev_, common_, a, act, out, task_);
+    }
+  }
+
+ private:
+  int Total() const {
+    return standup_ ? T::Tree<StandupMP>::kL.total : T::Tree<HumanoidMP>::kL.total;
+  }
+  HumDev dev_{};
+  HumTask task_{};
+  size_t ws_bytes_{0};
+  bool standup_;
+};
+
+}  // namespace
+
+bool DescribeHumanoid(const std::string& family, const Config& cfg, std::vector<KeySpec>* state,
+                      KeySpec* action) {
+  if (family != "Humanoid" && family != "HumanoidStandup") return false;
+  *state = HumKeys(cfg, family == "HumanoidStandup");
+  *action = KeySpec{"action", EPA_F64, {kHumanoidModelConst.nu}};
+  return true;
+}
+
+Pool* MakeHumanoid(const std::string& family, const Config& cfg) {
+  if (family == "Humanoid") return new HumanoidPool(cfg, false);
+  if (family == "HumanoidStandup") return new HumanoidPool(cfg, true);
+  return nullptr;
+}
+
+}  // namespace epa

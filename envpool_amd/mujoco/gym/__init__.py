@@ -4,7 +4,8 @@ Spec tables restate `HalfCheetahEnvFns` (half_cheetah.h:31-62), `AntEnvFns`
 (ant.h:31-75; v3/v5 add 6 contact-force numbers per body) and `Walker2dEnvFns`
 (walker2d.h:30-67), `InvertedPendulumEnvFns` (inverted_pendulum.h:30-60) and
 `InvertedDoublePendulumEnvFns` (inverted_double_pendulum.h:30-62) and
-`ReacherEnvFns` (reacher.h:30-65), `SwimmerEnvFns` (swimmer.h:30-66), `HopperEnvFns` (hopper.h:30-70); the pixel
+`ReacherEnvFns` (reacher.h:30-65), `SwimmerEnvFns` (swimmer.h:30-66), `HopperEnvFns` (hopper.h:30-70),
+`HumanoidEnvFns` (humanoid.h:30-82), `HumanoidStandupEnvFns` (humanoid_standup.h:30-73); the pixel
 variants are out of scope.  `precision` is an extension key: 64 (default, the
 reference's mjtNum=double) or 32 (fp32 arithmetic, fp64 state and I/O).
 """
@@ -331,7 +332,92 @@ _Hopper = FamilyDef(
     unsupported={"xml_file": "hopper.xml"},
 )
 
+def _humanoid_obs_dim(c):
+    """humanoid.h:50-60."""
+    n = 376 if c["exclude_current_positions_from_observation"] else 378
+    if c["exclude_worldbody_observations"]:
+        n -= 10 + 6 + 6
+    if c["exclude_root_actuator_forces"]:
+        n -= 6
+    return n
+
+
+def _humanoid_params(c, keys):
+    return {k: c[k] for k in keys}
+
+
+_HUMANOID_SHARED = ("frame_skip", "frame_stack", "post_constraint",
+                    "exclude_current_positions_from_observation",
+                    "exclude_worldbody_observations", "exclude_root_actuator_forces",
+                    "forward_reward_weight", "ctrl_cost_weight", "healthy_reward",
+                    "contact_cost_weight", "contact_cost_max", "reset_noise_scale")
+
+_Humanoid = FamilyDef(
+    name="GymHumanoid", native="Humanoid",
+    # humanoid.h:32-48
+    default_config=[
+        ("frame_skip", 5), ("frame_stack", 1), ("post_constraint", True),
+        ("legacy_healthy_reward", True), ("exclude_worldbody_observations", False),
+        ("exclude_root_actuator_forces", False), ("use_contact_force", False),
+        ("forward_reward_weight", 1.25), ("terminate_when_unhealthy", True),
+        ("exclude_current_positions_from_observation", True),
+        ("xml_file", "humanoid.xml"), ("gymnasium_v5_render_camera", False),
+        ("ctrl_cost_weight", 0.1), ("healthy_reward", 5.0), ("healthy_z_min", 1.0),
+        ("healthy_z_max", 2.0), ("contact_cost_weight", 5e-7), ("contact_cost_max", 10.0),
+        ("reset_noise_scale", 1e-2),
+    ],
+    state_spec=lambda c: [
+        ("obs", spec(np.float64, _stack([_humanoid_obs_dim(c)], c), (-_inf, _inf))),
+        ("info:reward_linvel", spec(np.float64, [-1])),
+        ("info:reward_quadctrl", spec(np.float64, [-1])),
+        ("info:reward_alive", spec(np.float64, [-1])),
+        ("info:reward_impact", spec(np.float64, [-1])),
+        ("info:x_position", spec(np.float64, [-1])),
+        ("info:y_position", spec(np.float64, [-1])),
+        ("info:distance_from_origin", spec(np.float64, [-1])),
+        ("info:x_velocity", spec(np.float64, [-1])),
+        ("info:y_velocity", spec(np.float64, [-1])),
+    ],
+    action_spec=lambda c: [("action", spec(np.float64, [-1, 17], (-0.4, 0.4)))],
+    native_params=lambda c: _humanoid_params(
+        c, _HUMANOID_SHARED + ("legacy_healthy_reward", "use_contact_force",
+                               "terminate_when_unhealthy", "healthy_z_min", "healthy_z_max")),
+    unsupported={"xml_file": "humanoid.xml"},
+)
+
+_HumanoidStandup = FamilyDef(
+    name="GymHumanoidStandup", native="HumanoidStandup",
+    # humanoid_standup.h:32-45
+    default_config=[
+        ("frame_skip", 5), ("frame_stack", 1), ("post_constraint", True),
+        ("forward_reward_weight", 1.0),
+        ("exclude_current_positions_from_observation", True),
+        ("exclude_worldbody_observations", False), ("exclude_root_actuator_forces", False),
+        ("xml_file", "humanoidstandup.xml"), ("gymnasium_v5_render_camera", False),
+        ("ctrl_cost_weight", 0.1), ("contact_cost_weight", 5e-7), ("contact_cost_max", 10.0),
+        ("healthy_reward", 1.0), ("reset_noise_scale", 1e-2),
+    ],
+    # humanoid_standup.h:47-66: `obs` first, then the four reward terms
+    state_spec=lambda c: [
+        ("obs", spec(np.float64, _stack([_humanoid_obs_dim(c)], c), (-_inf, _inf))),
+        ("info:reward_linup", spec(np.float64, [-1])),
+        ("info:reward_quadctrl", spec(np.float64, [-1])),
+        ("info:reward_alive", spec(np.float64, [-1])),
+        ("info:reward_impact", spec(np.float64, [-1])),
+    ],
+    action_spec=lambda c: [("action", spec(np.float64, [-1, 17], (-0.4, 0.4)))],
+    native_params=lambda c: _humanoid_params(c, _HUMANOID_SHARED),
+    unsupported={"xml_file": "humanoidstandup.xml"},
+)
+
 _GymHalfCheetahEnvSpec, _GymHalfCheetahEnvPool = make_native_classes(_HalfCheetah)
+_GymHumanoidEnvSpec, _GymHumanoidEnvPool = make_native_classes(_Humanoid)
+(GymHumanoidEnvSpec, GymHumanoidDMEnvPool,
+ GymHumanoidGymnasiumEnvPool) = py_env(_GymHumanoidEnvSpec, _GymHumanoidEnvPool)
+_GymHumanoidStandupEnvSpec, _GymHumanoidStandupEnvPool = make_native_classes(_HumanoidStandup)
+(GymHumanoidStandupEnvSpec, GymHumanoidStandupDMEnvPool,
+ GymHumanoidStandupGymnasiumEnvPool) = py_env(_GymHumanoidStandupEnvSpec,
+                                              _GymHumanoidStandupEnvPool)
 _GymHopperEnvSpec, _GymHopperEnvPool = make_native_classes(_Hopper)
 (GymHopperEnvSpec, GymHopperDMEnvPool,
  GymHopperGymnasiumEnvPool) = py_env(_GymHopperEnvSpec, _GymHopperEnvPool)
@@ -367,4 +453,7 @@ __all__ = ["GymHalfCheetahEnvSpec", "GymHalfCheetahDMEnvPool",
            "GymInvertedDoublePendulumGymnasiumEnvPool", "GymReacherEnvSpec",
            "GymReacherDMEnvPool", "GymReacherGymnasiumEnvPool", "GymSwimmerEnvSpec",
            "GymSwimmerDMEnvPool", "GymSwimmerGymnasiumEnvPool", "GymHopperEnvSpec",
-           "GymHopperDMEnvPool", "GymHopperGymnasiumEnvPool"]
+           "GymHopperDMEnvPool", "GymHopperGymnasiumEnvPool", "GymHumanoidEnvSpec",
+           "GymHumanoidDMEnvPool", "GymHumanoidGymnasiumEnvPool",
+           "GymHumanoidStandupEnvSpec", "GymHumanoidStandupDMEnvPool",
+           "GymHumanoidStandupGymnasiumEnvPool"]

@@ -19,6 +19,16 @@ _TASKS = {
     }),
     "HalfCheetah": (1000, {"v3": {}, "v4": {}, "v5": {}}),
     "Hopper": (1000, {"v3": {}, "v4": {}, "v5": {"legacy_healthy_reward": False}}),
+    "Humanoid": (1000, {
+        "v3": {"use_contact_force": True},
+        "v4": {},
+        "v5": {"use_contact_force": True, "legacy_healthy_reward": False,
+               "exclude_worldbody_observations": True, "exclude_root_actuator_forces": True},
+    }),
+    "HumanoidStandup": (1000, {
+        "v2": {}, "v4": {},
+        "v5": {"exclude_worldbody_observations": True, "exclude_root_actuator_forces": True},
+    }),
     "InvertedDoublePendulum": (1000, {
         "v2": {}, "v4": {},
         "v5": {"constraint_obs_dim": 1, "reward_if_not_terminated": True},
@@ -34,8 +44,8 @@ _TASKS = {
         "v5": {"xml_file": "walker2d_v5.xml", "legacy_healthy_reward": False},
     }),
 }
-# Humanoid, HumanoidStandup (PGS solver, self collisions, tendons) and Pusher have no
-# kernel yet and are not registered.
+# Pusher (capsule-cylinder contacts go through MuJoCo's general convex collider) has no
+# kernel and is not registered.
 
 for _task, (_steps, _versions) in _TASKS.items():
     for _version, _extra in _versions.items():

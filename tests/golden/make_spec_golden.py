@@ -33,6 +33,8 @@ FAMILIES = {
     "mujoco/gym/reacher.h": {"ReacherEnvFns": "GymReacher"},
     "mujoco/gym/inverted_pendulum.h": {"InvertedPendulumEnvFns": "GymInvertedPendulum"},
     "mujoco/gym/inverted_double_pendulum.h": {"InvertedDoublePendulumEnvFns": "GymInvertedDoublePendulum"},
+    "mujoco/gym/humanoid.h": {"HumanoidEnvFns": "GymHumanoid"},
+    "mujoco/gym/humanoid_standup.h": {"HumanoidStandupEnvFns": "GymHumanoidStandup"},
 }
 
 

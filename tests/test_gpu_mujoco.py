@@ -596,3 +596,105 @@ def test_chain_families_frame_stack(task, adim, amax, S):
     ring = np.concatenate([ring[:, 1:], b["obs"][:, None, :]], axis=1)
     ring[first] = b["obs"][first][:, None, :]
     np.testing.assert_allclose(a["obs"], ring[ids], rtol=1e-9, atol=1e-10)
+
+
+# ---- Humanoid / HumanoidStandup (mj_tree.cuh: HBM workspace, PGS, self collisions) ----
+# name, native family, native params, oracle extras (see oracle/mjcpu/tasks.c), obs dim
+_HUM_VARIANTS = [
+    ("Humanoid-v4", "Humanoid", {"post_constraint": 0}, {}, 376),
+    ("Humanoid-v5", "Humanoid",
+     {"post_constraint": 1, "use_contact_force": 1, "legacy_healthy_reward": 0,
+      "exclude_worldbody_observations": 1, "exclude_root_actuator_forces": 1},
+     {12: 1, 13: 1, 14: 1, 15: 0, 19: 1}, 348),
+    ("HumanoidStandup-v4", "HumanoidStandup", {"post_constraint": 0}, {}, 376),
+    ("HumanoidStandup-v5", "HumanoidStandup",
+     {"post_constraint": 1, "exclude_worldbody_observations": 1, "exclude_root_actuator_forces": 1},
+     {13: 1, 14: 1, 19: 1}, 348),
+]
+
+
+def _hum_extra(task, over):
+    e = [5, 0.1, 1.25 if task == "Humanoid" else 1.0, 0.01, 0, 0, 0, 0, -1, 0, 0, 3, 0, 0, 0, -1,
+         0, 1, 0, 0]
+    for k, v in over.items():
+        e[k] = v
+    return e
+
+
+@pytest.mark.parametrize("name,task,params,over,nobs", _HUM_VARIANTS)
+def test_humanoid_matches_oracle(name, task, params, over, nobs):
+    """Reset bit-exact (uniform draws only, then one mj_forward: cinert / cvel to rounding);
+    teacher-forced env-steps (5 RK4 mj_steps = 20 forward passes with PGS).  PGS is not run to
+    convergence, its stopping / revert tests are discontinuous, so two correct implementations
+    whose roundings differ can occasionally take one sweep more or less: the bulk must agree
+    to rtol 1e-9 / atol 1e-10 and every env-step to 1e-5 relative."""
+    n = 192  # three waves
+    steps = 60 if task == "Humanoid" else 40
+    pool = DevicePool(task, n, seed=5, max_episode_steps=1000, params=params)
+    orc = Oracle(task, n, seed=5, max_episode_steps=1000, extra=_hum_extra(task, over))
+    a, b = hip_reset(pool), orc.reset()
+    assert list(a.keys()) == list(b.keys()) and a["obs"].shape == (n, nobs)
+    # obs[1:5] is the root quaternion, normalised in place by mj_kinematics (rounding)
+    np.testing.assert_array_equal(a["obs"][:, 0], b["obs"][:, 0])
+    np.testing.assert_array_equal(a["obs"][:, 5:45], b["obs"][:, 5:45])
+    np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-11, atol=1e-12)
+    rng = np.random.default_rng(3)
+    rel_all, seen_term, contact_obs = [], False, 0.0
+    for t in range(steps):
+        pool.set_state(orc.get_state())
+        act = rng.uniform(-0.45, 0.45, size=(n, 17))
+        a, b = hip_step(pool, act), orc.step(act)
+        rel = (np.abs(a["obs"] - b["obs"]) / (1.0 + np.abs(b["obs"]))).max(axis=1)
+        rel_all.append(rel)
+        assert rel.max() < 1e-5, (name, t, rel.max())
+        np.testing.assert_allclose(a["reward"].ravel(), b["reward"].ravel(), rtol=1e-5, atol=1e-4)
+        for k in a:
+            if k.startswith("info:") and k not in ("info:env_id", "info:players.env_id"):
+                np.testing.assert_allclose(a[k].ravel(), b[k].ravel(), rtol=1e-5, atol=1e-5,
+                                           err_msg=f"{k}@{t}")
+        for k in ("done", "trunc", "elapsed_step", "step_type", "discount"):
+            np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k}@{t}")
+        seen_term |= bool((b["done"] & ~b["trunc"]).any())
+        contact_obs = max(contact_obs, float(np.abs(b["obs"][:, -78:]).max()))
+    rel_all = np.concatenate(rel_all)
+    tight = float((rel_all < 1e-9).mean())
+    print(f"{name}: teacher-forced rel |d obs| median {np.median(rel_all):.2e} "
+          f"max {rel_all.max():.2e}; within 1e-9: {100 * tight:.2f}%")
+    assert tight > 0.99
+    if task == "Humanoid":
+        assert seen_term  # falls below z = 1.0 under random actions, then auto-resets
+    if params.get("post_constraint"):
+        assert contact_obs > 1.0  # cfrc_ext is exercised
+    else:
+        assert contact_obs == 0.0
+
+
+def test_humanoid_deterministic_and_partial_batches():
+    """Same seed, same actions => bit-identical observations across pools; envs stepped
+    through a permuted partial batch get the same results as in a full batch (the workspace
+    block belongs to the launch's wave, the persistent state to the env)."""
+    n = 128
+    rng = np.random.default_rng(7)
+    acts = rng.uniform(-0.4, 0.4, size=(12, n, 17))
+    outs = []
+    for _ in range(2):
+        p = DevicePool("Humanoid", n, seed=11, max_episode_steps=1000, params={"post_constraint": 1})
+        hip_reset(p)
+        for t in range(12):
+            a = hip_step(p, acts[t])
+        outs.append(a["obs"].copy())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    full = DevicePool("Humanoid", n, seed=11, max_episode_steps=1000, params={"post_constraint": 1})
+    part = DevicePool("Humanoid", n, seed=11, max_episode_steps=1000, params={"post_constraint": 1})
+    hip_reset(full), hip_reset(part)
+    for t in range(6):
+        a = hip_step(full, acts[t])
+        perm = rng.permutation(n).astype(np.int32)
+        rows = {}
+        for ids in (perm[:37], perm[37:101], perm[101:]):
+            part.send(ids, acts[t][ids])
+            r = part.recv_dict()
+            for j, e in enumerate(r["info:env_id"].ravel()):
+                rows[int(e)] = r["obs"][j]
+        got = np.stack([rows[e] for e in range(n)])
+        np.testing.assert_array_equal(got, a["obs"], err_msg=f"step {t}")

@@ -323,7 +323,7 @@ def test_registry_matches_reference_registration_modules():
     envpool.list_all_envs()  # imports every registration module
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "registry.json")))
     missing = sorted(set(gold) - set(registry.specs))
-    assert all(m.split("-")[0] in ("Humanoid", "HumanoidStandup", "Pusher") for m in missing), missing
+    assert all(m.split("-")[0] == "Pusher" for m in missing), missing
     checked = 0
     for task_id, g in gold.items():
         if task_id not in registry.specs:

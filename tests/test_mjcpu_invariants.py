@@ -332,3 +332,60 @@ def test_product_hopper_code_matches_oracle_on_cpu():
         worst = max(worst, np.abs(qo - q1).max(), np.abs(vo - v1).max())
     assert worst < 1e-9, worst
     assert hits >= 5  # body-body contacts were really exercised
+
+
+def test_product_tree_code_matches_oracle_on_cpu():
+    """Host instantiation of mj_tree.cuh (the Humanoid / HumanoidStandup kernel source:
+    static-slot constraint rows, PGS on a = qacc_smooth + M^-1 J'f, sparse L'DL) vs the
+    oracle's dense generic engine, teacher forced per env-step (5 RK4 mj_steps), including
+    mj_rnePostConstraint's cfrc_ext.  The standup episode lies on the floor: dozens of
+    pyramidal floor contacts and frictionless self contacts per step."""
+    from oracle.orc import Oracle
+
+    csrc = os.path.join(ROOT, "envpool_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", csrc, "build/mj_humanoid_consts.inc"], check=True)
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    so, src = os.path.join(h, "libhumanoid_host.so"), os.path.join(h, "humanoid_host.cpp")
+    deps = [src, os.path.join(csrc, "mj_tree.cuh"), os.path.join(csrc, "mj_tree_model.h"),
+            os.path.join(csrc, "build", "mj_humanoid_consts.inc")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(so)
+    vp = ctypes.c_void_p
+    nq, nv, nu = 24, 23, 17
+    for su, task, steps in ((0, "Humanoid", 40), (1, "HumanoidStandup", 120)):
+        r = RawMj(task)
+        mo = np.zeros(64)
+        L.humanoid_host_model(su, mo.ctypes.data_as(vp))
+        assert abs(mo[0] - r.meaninertia) < 1e-12 * r.meaninertia
+        np.testing.assert_allclose(mo[2:16], r.body_mass, rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(mo[16:39], r.dof_invweight0, rtol=1e-11)
+        np.testing.assert_allclose(mo[39:53], r.body_invweight0[:, 0], rtol=1e-11, atol=1e-15)
+        n = 8
+        # extra[13] = post_constraint (v5), extra[12] = use_contact_force
+        extra = [5, 0.1, 1.0 if su else 1.25, 0.01, 0, 0, 0, 0, -1, 0, 0, 3, 1, 1]
+        orc = Oracle(task, n, seed=5, max_episode_steps=1000, extra=extra)
+        orc.reset()
+        rng = np.random.default_rng(1)
+        worst, most = 0.0, 0
+        for t in range(steps):
+            st = orc.get_state()
+            act = rng.uniform(-0.4, 0.4, size=(n, nu))
+            b = orc.step(act)
+            for e in range(n):
+                if b["elapsed_step"][e, 0] == 0:
+                    continue
+                q, v, w = (st[e, :nq].copy(), st[e, nq:nq + nv].copy(),
+                           st[e, nq + nv:nq + 2 * nv].copy())
+                o = np.zeros(512)
+                L.humanoid_host_step(q.ctypes.data_as(vp), v.ctypes.data_as(vp), w.ctypes.data_as(vp),
+                                     np.ascontiguousarray(act[e]).ctypes.data_as(vp), 5, su, 1,
+                                     o.ctypes.data_as(vp))
+                k = nq + 2 * nv
+                obs = np.concatenate([o[2:nq], o[nq:nq + nv], o[k:k + 140 + 84 + 23 + 84]])
+                ref = b["obs"][e]
+                worst = max(worst, float((np.abs(obs - ref) / (1.0 + np.abs(ref))).max()))
+                most = max(most, int(o[k + 331 + 2]))
+        print(f"{task}: worst teacher-forced rel |d obs| = {worst:.2e}; max active groups {most}")
+        assert worst < 1e-8, (task, worst)
+        assert most >= (10 if su else 3)
