@@ -95,7 +95,7 @@ struct Layout {
   int M, dinv;                                       // M (lower, tree-sparse) -> L'DL in place
   int passive, bias, act, smooth, accs, qacc;
   int limd, lims, condist, conpos, connrm;           // detection results per group
-  int rowJ, rowW, rowR, rowAref, rowArr, rowF;
+  int rowJ, rowW, rowR, rowAref, rowArr, rowArrInv, rowF;
   int x0q, x0v, accq, accv;                          // RK4
   int cext;                                          // cfrc_ext [nbody][6]
   int total;
@@ -119,7 +119,7 @@ constexpr Layout MakeLayout(const TreeModel& m) {
   L.limd = take(m.nlimit); L.lims = take(m.nlimit);
   L.condist = take(ncon); L.conpos = take(3 * ncon); L.connrm = take(3 * ncon);
   L.rowJ = take(nrow * m.nv); L.rowW = take(nrow * m.nv);
-  L.rowR = take(nrow); L.rowAref = take(nrow); L.rowArr = take(nrow); L.rowF = take(nrow);
+  L.rowR = take(nrow); L.rowAref = take(nrow); L.rowArr = take(nrow); L.rowArrInv = take(nrow); L.rowF = take(nrow);
   L.x0q = take(m.nq); L.x0v = take(m.nv); L.accq = take(m.nv); L.accv = take(m.nv);
   L.cext = take(6 * m.nbody);
   L.total = s;
@@ -133,8 +133,10 @@ struct Ws {
   unsigned lane;
   // byte offset in 32 bits: the access becomes `global_load v, v_off, s[base]` (SGPR base +
   // 32-bit lane offset) instead of a 64-bit per-lane address per slot
+  // (signed arithmetic: no-wrap lets alias analysis tell two slots apart, so loads are not
+  // pinned behind unrelated stores)
   EPA_HD double& operator()(int slot) const {
-    const unsigned off = ((unsigned)slot * (unsigned)kLaneStride + lane) * 8u;
+    const int off = (slot * kLaneStride + (int)lane) * 8;
     return *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off);
   }
   // A fresh copy whose lane offset is opaque to the optimiser: used at the top of loop bodies
@@ -144,6 +146,7 @@ struct Ws {
     Ws r = *this;
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(r.lane));
+    r.lane &= (unsigned)(kLaneStride - 1);  // keeps the known range [0, 64)
 #endif
     return r;
   }
@@ -293,105 +296,119 @@ struct Tree {
     }
   }
 
-  // ---- mj_kinematics ---------------------------------------------------------------------
-  static EPA_HD void Kinematics(Ws w) {
+  // Every stage below has the shape  [issue all loads] -> FENCE -> [arithmetic in VGPRs] ->
+  // [stores]:  a wave runs alone on its SIMD (512 VGPRs), so a dependent HBM round trip costs
+  // ~1 us with nothing to overlap it; batching turns the ~5000 dependent round trips of a naive
+  // body-by-body pipeline into ~100 per forward pass.
+
+  // ---- mj_kinematics: depth-first over the tree, the parent's frame stays in registers -------
+  struct Frame {
+    Vec3 pos;
+    Quat q;
+    double R[9];
+  };
+  template <int B>
+  static EPA_HD void KinBody(Ws w, const Frame& par, const double* qp, Vec3& msum) {
     constexpr TreeModel m = MP::kM;
-    static_for<1, NB>([&](auto bc) {
-      constexpr int b = decltype(bc)::value;
-      constexpr int p = m.body_parent[b];
-      constexpr int ja = m.body_jntadr[b], jn = m.body_jntnum[b];
-      Vec3 xpos;
-      Quat q;
-      double R[9];
-      if constexpr (jn == 1 && m.jnt_type[ja < 0 ? 0 : ja] == kJntFree) {
-        constexpr int qa = m.jnt_qadr[ja];
-        xpos = {w(kL.qpos + qa), w(kL.qpos + qa + 1), w(kL.qpos + qa + 2)};
-        // mj_kinematics normalises the quaternion in qpos itself
-        q = QNormalize({w(kL.qpos + qa + 3), w(kL.qpos + qa + 4), w(kL.qpos + qa + 5),
-                        w(kL.qpos + qa + 6)});
-        w(kL.qpos + qa + 3) = q.w;
-        w(kL.qpos + qa + 4) = q.x;
-        w(kL.qpos + qa + 5) = q.y;
-        w(kL.qpos + qa + 6) = q.z;
-      } else {
-        double Rp[9];
-        static_for<0, 9>([&](auto kc) { Rp[decltype(kc)::value] = w(kL.xmat + 9 * p + decltype(kc)::value); });
-        const Vec3 pp = {w(kL.xpos + 3 * p), w(kL.xpos + 3 * p + 1), w(kL.xpos + 3 * p + 2)};
-        const Quat pq = {w(kL.xquat + 4 * p), w(kL.xquat + 4 * p + 1), w(kL.xquat + 4 * p + 2),
-                         w(kL.xquat + 4 * p + 3)};
-        xpos = pp + MulV(Rp, Vec3{m.body_pos[b][0], m.body_pos[b][1], m.body_pos[b][2]});
-        q = QMul(pq, Quat{m.body_quat[b][0], m.body_quat[b][1], m.body_quat[b][2],
-                          m.body_quat[b][3]});
-        static_for<0, jn>([&](auto jc) {
-          constexpr int j = ja + decltype(jc)::value;
-          static_assert(m.jnt_type[j] == kJntHinge, "free root + hinges only");
-          QMat(q, R);
-          const Vec3 jp = {m.jnt_pos[j][0], m.jnt_pos[j][1], m.jnt_pos[j][2]};
-          const Vec3 anchor = MulV(R, jp) + xpos;
-          const Vec3 axis = MulV(R, Vec3{m.jnt_axis[j][0], m.jnt_axis[j][1], m.jnt_axis[j][2]});
-          w(kL.anchor + 3 * j) = anchor.x;
-          w(kL.anchor + 3 * j + 1) = anchor.y;
-          w(kL.anchor + 3 * j + 2) = anchor.z;
-          w(kL.axis + 3 * j) = axis.x;
-          w(kL.axis + 3 * j + 1) = axis.y;
-          w(kL.axis + 3 * j + 2) = axis.z;
-          double sn, cs;
-          SinCos(0.5 * (w(kL.qpos + m.jnt_qadr[j]) - m.qpos0[m.jnt_qadr[j]]), &sn, &cs);
-          q = QMul(q, Quat{cs, m.jnt_axis[j][0] * sn, m.jnt_axis[j][1] * sn, m.jnt_axis[j][2] * sn});
-          QMat(q, R);
-          xpos = anchor - MulV(R, jp);
-        });
-        q = QNormalize(q);
-      }
-      QMat(q, R);
-      w(kL.xpos + 3 * b) = xpos.x;
-      w(kL.xpos + 3 * b + 1) = xpos.y;
-      w(kL.xpos + 3 * b + 2) = xpos.z;
-      w(kL.xquat + 4 * b) = q.w;
-      w(kL.xquat + 4 * b + 1) = q.x;
-      w(kL.xquat + 4 * b + 2) = q.y;
-      w(kL.xquat + 4 * b + 3) = q.z;
-      static_for<0, 9>([&](auto kc) { w(kL.xmat + 9 * b + decltype(kc)::value) = R[decltype(kc)::value]; });
-      const Vec3 ip = xpos + MulV(R, Vec3{m.body_ipos[b][0], m.body_ipos[b][1], m.body_ipos[b][2]});
-      w(kL.xipos + 3 * b) = ip.x;
-      w(kL.xipos + 3 * b + 1) = ip.y;
-      w(kL.xipos + 3 * b + 2) = ip.z;
-      // geoms of this body: centre and (capsules) axis
-      static_for<1, NG>([&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-        if constexpr (m.geom_body[g] == b) {
-          const Vec3 gp = xpos + MulV(R, Vec3{m.geom_pos[g][0], m.geom_pos[g][1], m.geom_pos[g][2]});
-          w(kL.gpos + 3 * g) = gp.x;
-          w(kL.gpos + 3 * g + 1) = gp.y;
-          w(kL.gpos + 3 * g + 2) = gp.z;
-          if constexpr (m.geom_type[g] == kGeomCapsule) {
-            const Vec3 ga = MulV(R, Vec3{m.geom_axis[g][0], m.geom_axis[g][1], m.geom_axis[g][2]});
-            w(kL.gaxis + 3 * g) = ga.x;
-            w(kL.gaxis + 3 * g + 1) = ga.y;
-            w(kL.gaxis + 3 * g + 2) = ga.z;
-          }
-        }
+    constexpr int ja = m.body_jntadr[B], jn = m.body_jntnum[B];
+    Frame f;
+    if constexpr (jn == 1 && m.jnt_type[ja < 0 ? 0 : ja] == kJntFree) {
+      constexpr int qa = m.jnt_qadr[ja];
+      f.pos = {qp[qa], qp[qa + 1], qp[qa + 2]};
+      // mj_kinematics normalises the quaternion in qpos itself
+      f.q = QNormalize({qp[qa + 3], qp[qa + 4], qp[qa + 5], qp[qa + 6]});
+      w(kL.qpos + qa + 3) = f.q.w;
+      w(kL.qpos + qa + 4) = f.q.x;
+      w(kL.qpos + qa + 5) = f.q.y;
+      w(kL.qpos + qa + 6) = f.q.z;
+    } else {
+      f.pos = par.pos + MulV(par.R, Vec3{m.body_pos[B][0], m.body_pos[B][1], m.body_pos[B][2]});
+      f.q = QMul(par.q, Quat{m.body_quat[B][0], m.body_quat[B][1], m.body_quat[B][2],
+                             m.body_quat[B][3]});
+      static_for<0, jn>([&](auto jc) {
+        constexpr int j = ja + decltype(jc)::value;
+        static_assert(m.jnt_type[j] == kJntHinge, "free root + hinges only");
+        QMat(f.q, f.R);
+        const Vec3 jp = {m.jnt_pos[j][0], m.jnt_pos[j][1], m.jnt_pos[j][2]};
+        const Vec3 anchor = MulV(f.R, jp) + f.pos;
+        const Vec3 axis = MulV(f.R, Vec3{m.jnt_axis[j][0], m.jnt_axis[j][1], m.jnt_axis[j][2]});
+        w(kL.anchor + 3 * j) = anchor.x;
+        w(kL.anchor + 3 * j + 1) = anchor.y;
+        w(kL.anchor + 3 * j + 2) = anchor.z;
+        w(kL.axis + 3 * j) = axis.x;
+        w(kL.axis + 3 * j + 1) = axis.y;
+        w(kL.axis + 3 * j + 2) = axis.z;
+        double sn, cs;
+        SinCos(0.5 * (qp[m.jnt_qadr[j]] - m.qpos0[m.jnt_qadr[j]]), &sn, &cs);
+        f.q = QMul(f.q, Quat{cs, m.jnt_axis[j][0] * sn, m.jnt_axis[j][1] * sn, m.jnt_axis[j][2] * sn});
+        QMat(f.q, f.R);
+        f.pos = anchor - MulV(f.R, jp);
       });
+      f.q = QNormalize(f.q);
+    }
+    QMat(f.q, f.R);
+    w(kL.xpos + 3 * B) = f.pos.x;
+    w(kL.xpos + 3 * B + 1) = f.pos.y;
+    w(kL.xpos + 3 * B + 2) = f.pos.z;
+    static_for<0, 9>([&](auto kc) { w(kL.xmat + 9 * B + decltype(kc)::value) = f.R[decltype(kc)::value]; });
+    const Vec3 ip = f.pos + MulV(f.R, Vec3{m.body_ipos[B][0], m.body_ipos[B][1], m.body_ipos[B][2]});
+    w(kL.xipos + 3 * B) = ip.x;
+    w(kL.xipos + 3 * B + 1) = ip.y;
+    w(kL.xipos + 3 * B + 2) = ip.z;
+    msum = msum + ip * m.body_mass[B];
+    // geoms of this body: centre and (capsules) axis
+    static_for<1, NG>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (m.geom_body[g] == B) {
+        const Vec3 gp = f.pos + MulV(f.R, Vec3{m.geom_pos[g][0], m.geom_pos[g][1], m.geom_pos[g][2]});
+        w(kL.gpos + 3 * g) = gp.x;
+        w(kL.gpos + 3 * g + 1) = gp.y;
+        w(kL.gpos + 3 * g + 2) = gp.z;
+        if constexpr (m.geom_type[g] == kGeomCapsule) {
+          const Vec3 ga = MulV(f.R, Vec3{m.geom_axis[g][0], m.geom_axis[g][1], m.geom_axis[g][2]});
+          w(kL.gaxis + 3 * g) = ga.x;
+          w(kL.gaxis + 3 * g + 1) = ga.y;
+          w(kL.gaxis + 3 * g + 2) = ga.z;
+        }
+      }
+    });
+    static_for<B + 1, NB>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      if constexpr (m.body_parent[c] == B) KinBody<c>(w, f, qp, msum);
     });
   }
-
-  // ---- mj_comPos: system COM (origin of the c-frame), cinert, cdof ---------------------------
-  static EPA_HD void ComPos(Ws w) {
+  static EPA_HD void Kinematics(Ws w) {
     constexpr TreeModel m = MP::kM;
-    Vec3 c = {0, 0, 0};
-    static_for<1, NB>([&](auto bc) {
+    double qp[NQ];
+    static_for<0, NQ>([&](auto ic) { qp[decltype(ic)::value] = w(kL.qpos + decltype(ic)::value); });
+    EPA_TREE_FENCE();
+    Frame world;
+    world.pos = {0, 0, 0};
+    world.q = {1, 0, 0, 0};
+    QMat(world.q, world.R);
+    Vec3 msum = {0, 0, 0};
+    KinBody<1>(w, world, qp, msum);
+    // mj_comPos, first half: system COM = origin of the c-frame (single tree)
+    msum = msum * (1.0 / m.total_mass);
+    w(kL.com) = msum.x;
+    w(kL.com + 1) = msum.y;
+    w(kL.com + 2) = msum.z;
+  }
+
+  // ---- mj_comPos (cinert, cdof) + the composite inertias of mj_crb ----------------------------
+  template <int B0, int B1>
+  static EPA_HD void CinertBatch(Ws w, Vec3 c, double (*ci)[10]) {
+    constexpr TreeModel m = MP::kM;
+    double R[B1 - B0][9], xi[B1 - B0][3];
+    static_for<B0, B1>([&](auto bc) {
       constexpr int b = decltype(bc)::value;
-      c = c + Vec3{w(kL.xipos + 3 * b), w(kL.xipos + 3 * b + 1), w(kL.xipos + 3 * b + 2)} *
-                  m.body_mass[b];
+      static_for<0, 9>([&](auto kc) { R[b - B0][decltype(kc)::value] = w(kL.xmat + 9 * b + decltype(kc)::value); });
+      static_for<0, 3>([&](auto kc) { xi[b - B0][decltype(kc)::value] = w(kL.xipos + 3 * b + decltype(kc)::value); });
     });
-    c = c * (1.0 / m.total_mass);
-    w(kL.com) = c.x;
-    w(kL.com + 1) = c.y;
-    w(kL.com + 2) = c.z;
-    static_for<1, NB>([&](auto bc) {
+    EPA_TREE_FENCE();
+    static_for<B0, B1>([&](auto bc) {
       constexpr int b = decltype(bc)::value;
-      double R[9];
-      static_for<0, 9>([&](auto kc) { R[decltype(kc)::value] = w(kL.xmat + 9 * b + decltype(kc)::value); });
+      const double* Rb = R[b - B0];
       // Iw = R I R^T, I symmetric (xx yy zz xy xz yz)
       constexpr double Ixx = m.body_inertia[b][0], Iyy = m.body_inertia[b][1],
                        Izz = m.body_inertia[b][2], Ixy = m.body_inertia[b][3],
@@ -399,287 +416,340 @@ struct Tree {
       double RI[9];
       static_for<0, 3>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
-        RI[3 * r + 0] = R[3 * r] * Ixx + R[3 * r + 1] * Ixy + R[3 * r + 2] * Ixz;
-        RI[3 * r + 1] = R[3 * r] * Ixy + R[3 * r + 1] * Iyy + R[3 * r + 2] * Iyz;
-        RI[3 * r + 2] = R[3 * r] * Ixz + R[3 * r + 1] * Iyz + R[3 * r + 2] * Izz;
+        RI[3 * r + 0] = Rb[3 * r] * Ixx + Rb[3 * r + 1] * Ixy + Rb[3 * r + 2] * Ixz;
+        RI[3 * r + 1] = Rb[3 * r] * Ixy + Rb[3 * r + 1] * Iyy + Rb[3 * r + 2] * Iyz;
+        RI[3 * r + 2] = Rb[3 * r] * Ixz + Rb[3 * r + 1] * Iyz + Rb[3 * r + 2] * Izz;
       });
       auto iw = [&](int r, int cidx) {
-        return RI[3 * r] * R[3 * cidx] + RI[3 * r + 1] * R[3 * cidx + 1] + RI[3 * r + 2] * R[3 * cidx + 2];
+        return RI[3 * r] * Rb[3 * cidx] + RI[3 * r + 1] * Rb[3 * cidx + 1] + RI[3 * r + 2] * Rb[3 * cidx + 2];
       };
-      const Vec3 off = Vec3{w(kL.xipos + 3 * b), w(kL.xipos + 3 * b + 1), w(kL.xipos + 3 * b + 2)} - c;
+      const Vec3 off = Vec3{xi[b - B0][0], xi[b - B0][1], xi[b - B0][2]} - c;
       constexpr double mass = m.body_mass[b];
       const double o2 = Dot(off, off);
-      const int ci = kL.cinert + 10 * b;
-      w(ci + 0) = iw(0, 0) + mass * (o2 - off.x * off.x);
-      w(ci + 1) = iw(1, 1) + mass * (o2 - off.y * off.y);
-      w(ci + 2) = iw(2, 2) + mass * (o2 - off.z * off.z);
-      w(ci + 3) = iw(0, 1) - mass * off.x * off.y;
-      w(ci + 4) = iw(0, 2) - mass * off.x * off.z;
-      w(ci + 5) = iw(1, 2) - mass * off.y * off.z;
-      w(ci + 6) = mass * off.x;
-      w(ci + 7) = mass * off.y;
-      w(ci + 8) = mass * off.z;
-      w(ci + 9) = mass;
-    });
-    static_for<0, NJ>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      constexpr int a = m.jnt_dadr[j], b = m.jnt_body[j];
-      if constexpr (m.jnt_type[j] == kJntHinge) {
-        const Vec3 ax = {w(kL.axis + 3 * j), w(kL.axis + 3 * j + 1), w(kL.axis + 3 * j + 2)};
-        const Vec3 off = c - Vec3{w(kL.anchor + 3 * j), w(kL.anchor + 3 * j + 1), w(kL.anchor + 3 * j + 2)};
-        const Vec3 lin = Cross(ax, off);
-        w(kL.cdof + 6 * a) = ax.x;
-        w(kL.cdof + 6 * a + 1) = ax.y;
-        w(kL.cdof + 6 * a + 2) = ax.z;
-        w(kL.cdof + 6 * a + 3) = lin.x;
-        w(kL.cdof + 6 * a + 4) = lin.y;
-        w(kL.cdof + 6 * a + 5) = lin.z;
-      } else {  // free: 3 world translations, then rotations about the body axes
-        const Vec3 off = c - Vec3{w(kL.xpos + 3 * b), w(kL.xpos + 3 * b + 1), w(kL.xpos + 3 * b + 2)};
-        static_for<0, 3>([&](auto kc) {
-          constexpr int k = decltype(kc)::value;
-          static_for<0, 6>([&](auto rc) {
-            w(kL.cdof + 6 * (a + k) + decltype(rc)::value) = decltype(rc)::value == 3 + k ? 1.0 : 0.0;
-          });
-          const Vec3 ax = {w(kL.xmat + 9 * b + k), w(kL.xmat + 9 * b + 3 + k), w(kL.xmat + 9 * b + 6 + k)};
-          const Vec3 lin = Cross(ax, off);
-          w(kL.cdof + 6 * (a + 3 + k)) = ax.x;
-          w(kL.cdof + 6 * (a + 3 + k) + 1) = ax.y;
-          w(kL.cdof + 6 * (a + 3 + k) + 2) = ax.z;
-          w(kL.cdof + 6 * (a + 3 + k) + 3) = lin.x;
-          w(kL.cdof + 6 * (a + 3 + k) + 4) = lin.y;
-          w(kL.cdof + 6 * (a + 3 + k) + 5) = lin.z;
-        });
-      }
+      ci[b][0] = iw(0, 0) + mass * (o2 - off.x * off.x);
+      ci[b][1] = iw(1, 1) + mass * (o2 - off.y * off.y);
+      ci[b][2] = iw(2, 2) + mass * (o2 - off.z * off.z);
+      ci[b][3] = iw(0, 1) - mass * off.x * off.y;
+      ci[b][4] = iw(0, 2) - mass * off.x * off.z;
+      ci[b][5] = iw(1, 2) - mass * off.y * off.z;
+      ci[b][6] = mass * off.x;
+      ci[b][7] = mass * off.y;
+      ci[b][8] = mass * off.z;
+      ci[b][9] = mass;
+      static_for<0, 10>([&](auto kc) { w(kL.cinert + 10 * b + decltype(kc)::value) = ci[b][decltype(kc)::value]; });
     });
   }
-
-  // ---- mj_crb (+ armature), then mj_factorM in place ----------------------------------------
-  static EPA_HD void CrbFactor(Ws w) {
+  static EPA_HD void ComPos(Ws w) {
     constexpr TreeModel m = MP::kM;
-    static_for<1, NB>([&](auto bc) {
-      constexpr int b = decltype(bc)::value;
-      static_for<0, 10>([&](auto kc) {
-        w(kL.crb + 10 * b + decltype(kc)::value) = w(kL.cinert + 10 * b + decltype(kc)::value);
+    const Vec3 c = {w(kL.com), w(kL.com + 1), w(kL.com + 2)};
+    {  // cdof from the joint anchors / axes
+      double an[NJ][3], ax[NJ][3], rp[3], rR[9];
+      static_for<0, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (m.jnt_type[j] == kJntHinge) {
+          static_for<0, 3>([&](auto kc) {
+            an[j][decltype(kc)::value] = w(kL.anchor + 3 * j + decltype(kc)::value);
+            ax[j][decltype(kc)::value] = w(kL.axis + 3 * j + decltype(kc)::value);
+          });
+        } else {
+          constexpr int b = m.jnt_body[j];
+          static_for<0, 3>([&](auto kc) { rp[decltype(kc)::value] = w(kL.xpos + 3 * b + decltype(kc)::value); });
+          static_for<0, 9>([&](auto kc) { rR[decltype(kc)::value] = w(kL.xmat + 9 * b + decltype(kc)::value); });
+        }
       });
-    });
+      EPA_TREE_FENCE();
+      static_for<0, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int a = m.jnt_dadr[j];
+        if constexpr (m.jnt_type[j] == kJntHinge) {
+          const Vec3 axis = {ax[j][0], ax[j][1], ax[j][2]};
+          const Vec3 lin = Cross(axis, c - Vec3{an[j][0], an[j][1], an[j][2]});
+          w(kL.cdof + 6 * a) = axis.x;
+          w(kL.cdof + 6 * a + 1) = axis.y;
+          w(kL.cdof + 6 * a + 2) = axis.z;
+          w(kL.cdof + 6 * a + 3) = lin.x;
+          w(kL.cdof + 6 * a + 4) = lin.y;
+          w(kL.cdof + 6 * a + 5) = lin.z;
+        } else {  // free: 3 world translations, then rotations about the body axes
+          const Vec3 off = c - Vec3{rp[0], rp[1], rp[2]};
+          static_for<0, 3>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            static_for<0, 6>([&](auto rc) {
+              w(kL.cdof + 6 * (a + k) + decltype(rc)::value) = decltype(rc)::value == 3 + k ? 1.0 : 0.0;
+            });
+            const Vec3 axis = {rR[k], rR[3 + k], rR[6 + k]};
+            const Vec3 lin = Cross(axis, off);
+            w(kL.cdof + 6 * (a + 3 + k)) = axis.x;
+            w(kL.cdof + 6 * (a + 3 + k) + 1) = axis.y;
+            w(kL.cdof + 6 * (a + 3 + k) + 2) = axis.z;
+            w(kL.cdof + 6 * (a + 3 + k) + 3) = lin.x;
+            w(kL.cdof + 6 * (a + 3 + k) + 4) = lin.y;
+            w(kL.cdof + 6 * (a + 3 + k) + 5) = lin.z;
+          });
+        }
+      });
+    }
+    EPA_TREE_FENCE();
+    // cinert in two register batches, then the composite inertias (mj_crb, backward pass)
+    double ci[NB][10];
+    constexpr int kHalf = (NB + 1) / 2;
+    CinertBatch<1, kHalf>(w, c, ci);
+    EPA_TREE_FENCE();
+    CinertBatch<kHalf, NB>(w, c, ci);
     static_for_down<NB, 2>([&](auto bc) {
       constexpr int b = decltype(bc)::value;
       constexpr int p = m.body_parent[b];
       if constexpr (p > 0) {
-        static_for<0, 10>([&](auto kc) {
-          w(kL.crb + 10 * p + decltype(kc)::value) += w(kL.crb + 10 * b + decltype(kc)::value);
-        });
+        static_for<0, 10>([&](auto kc) { ci[p][decltype(kc)::value] += ci[b][decltype(kc)::value]; });
       }
     });
-    {
-      double cd[NV][6];
-      static_for<0, NV>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        static_for<0, 6>([&](auto rc) { cd[i][decltype(rc)::value] = w(kL.cdof + 6 * i + decltype(rc)::value); });
-      });
-      static_for<0, NV>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        double in[10], buf[6];
-        static_for<0, 10>([&](auto kc) { in[decltype(kc)::value] = w(kL.crb + 10 * m.dof_body[i] + decltype(kc)::value); });
-        MulInertVec(buf, in, cd[i]);
+    static_for<1, NB>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      static_for<0, 10>([&](auto kc) { w(kL.crb + 10 * b + decltype(kc)::value) = ci[b][decltype(kc)::value]; });
+    });
+  }
+
+  // ---- mj_crb (M, + armature), then mj_factorM, all of M in registers ----------------------------
+  template <int B0, int B1>
+  static EPA_HD void MassBatch(Ws w, const double (*cd)[6]) {
+    constexpr TreeModel m = MP::kM;
+    double in[B1 - B0][10];
+    static_for<B0, B1>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      static_for<0, 10>([&](auto kc) { in[b - B0][decltype(kc)::value] = w(kL.crb + 10 * b + decltype(kc)::value); });
+    });
+    EPA_TREE_FENCE();
+    static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int b = m.dof_body[i];
+      if constexpr (b >= B0 && b < B1) {
+        double buf[6];
+        MulInertVec(buf, in[b - B0], cd[i]);
         Chain<i>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           double v = Dot6(cd[j], buf);
           if constexpr (i == j) v += m.dof_arm[i];
           w(MIdx(i, j)) = v;
         });
+      }
+    });
+  }
+  static EPA_HD void CrbFactor(Ws w) {
+    constexpr TreeModel m = MP::kM;
+    {
+      double cd[NV][6];
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<0, 6>([&](auto rc) { cd[i][decltype(rc)::value] = w(kL.cdof + 6 * i + decltype(rc)::value); });
       });
+      constexpr int kHalf = (NB + 1) / 2;
+      MassBatch<1, kHalf>(w, cd);
+      EPA_TREE_FENCE();
+      MassBatch<kHalf, NB>(w, cd);
     }
+    EPA_TREE_FENCE();
     // L'DL: M = L' D L, L unit lower with the tree's sparsity (MuJoCo mj_factorM)
+    double L[NV * NV];  // only the tree-sparse entries are ever touched (static indices)
+    static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      Chain<i>([&](auto jc) { L[i * NV + decltype(jc)::value] = w(MIdx(i, decltype(jc)::value)); });
+    });
+    EPA_TREE_FENCE();
     static_for_down<NV, 0>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
-      double rk[NV];
-      Chain<k>([&](auto jc) { rk[decltype(jc)::value] = w(MIdx(k, decltype(jc)::value)); });
-      const double inv = 1.0 / rk[k];
+      const double inv = 1.0 / L[k * NV + k];
       w(kL.dinv + k) = inv;
       Chain<m.dof_parent[k]>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const double tmp = rk[i] * inv;
+        const double tmp = L[k * NV + i] * inv;
         Chain<i>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
-          w(MIdx(i, j)) -= tmp * rk[j];
+          L[i * NV + j] -= tmp * L[k * NV + j];
         });
+        L[k * NV + i] = tmp;
         w(MIdx(k, i)) = tmp;
       });
     });
   }
 
-  // x <- M^-1 x (mj_solveM), x in registers
-  static EPA_HD void SolveM(Ws w, double* x) {
+  // x <- M^-1 x (mj_solveM), x in registers; the factor is loaded in one batch.  Returns
+  // x0' M^-1 x0 = sum_i y_i^2 / D_i with y = L^-T x0 (the diagonal of A for a constraint row).
+  static EPA_HD double SolveM(Ws w, double* x) {
     constexpr TreeModel m = MP::kM;
+    double L[NV * NV], dinv[NV];
+    static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      dinv[i] = w(kL.dinv + i);
+      Chain<m.dof_parent[i]>([&](auto jc) { L[i * NV + decltype(jc)::value] = w(MIdx(i, decltype(jc)::value)); });
+    });
+    EPA_TREE_FENCE();
     static_for_down<NV, 0>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       Chain<m.dof_parent[i]>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        x[j] -= w(MIdx(i, j)) * x[i];
+        x[j] -= L[i * NV + j] * x[i];
       });
-      if constexpr (i % 2 == 0) EPA_TREE_FENCE();
     });
-    static_for<0, NV>([&](auto ic) { x[decltype(ic)::value] *= w(kL.dinv + decltype(ic)::value); });
-    EPA_TREE_FENCE();
+    double quad = 0.0;
+    static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const double y = x[i];
+      x[i] = y * dinv[i];
+      quad += y * x[i];
+    });
     static_for<0, NV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       Chain<m.dof_parent[i]>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        x[i] -= w(MIdx(i, j)) * x[j];
+        x[i] -= L[i * NV + j] * x[j];
       });
-      if constexpr (i % 2 == 0) EPA_TREE_FENCE();
     });
+    return quad;
   }
 
   // ---- mj_fwdVelocity + mj_fwdActuation + mj_fwdAcceleration ---------------------------------
+  // down the tree: cvel and the bias acceleration cacc (parent values in registers)
+  template <int B>
+  static EPA_HD void VelBody(Ws w, const double (*cd)[6], const double* qv, const double* pvel,
+                             const double* pacc) {
+    constexpr TreeModel m = MP::kM;
+    constexpr int a = m.body_dofadr[B], n = m.body_dofnum[B];
+    double cvel[6], cacc[6];
+    static_for<0, 6>([&](auto rc) {
+      cvel[decltype(rc)::value] = pvel[decltype(rc)::value];
+      cacc[decltype(rc)::value] = pacc[decltype(rc)::value];
+    });
+    if constexpr (n == 6) {  // free joint: translations first, their cdof_dot is zero
+      static_for<0, 3>([&](auto kc) { cvel[3 + decltype(kc)::value] += qv[a + decltype(kc)::value]; });
+      double dot[6];
+      static_for<0, 3>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        CrossMotion(dot, cvel, cd[a + 3 + k]);  // all three with the velocity before the rotations
+        static_for<0, 6>([&](auto rc) { cacc[decltype(rc)::value] += dot[decltype(rc)::value] * qv[a + 3 + k]; });
+      });
+      static_for<0, 3>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        static_for<0, 6>([&](auto rc) { cvel[decltype(rc)::value] += cd[a + 3 + k][decltype(rc)::value] * qv[a + 3 + k]; });
+      });
+    } else {
+      static_for<0, n>([&](auto jc) {
+        constexpr int i = a + decltype(jc)::value;
+        double dot[6];
+        CrossMotion(dot, cvel, cd[i]);
+        static_for<0, 6>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          cacc[r] += dot[r] * qv[i];
+          cvel[r] += cd[i][r] * qv[i];
+        });
+      });
+    }
+    static_for<0, 6>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      w(kL.cvel + 6 * B + r) = cvel[r];
+      w(kL.cacc + 6 * B + r) = cacc[r];
+    });
+    static_for<B + 1, NB>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      if constexpr (m.body_parent[c] == B) VelBody<c>(w, cd, qv, cvel, cacc);
+    });
+  }
+  // cfrc = I cacc + cvel x* (I cvel) for a batch of bodies
+  template <int B0, int B1>
+  static EPA_HD void RneBatch(Ws w, double (*cf)[6]) {
+    double in[B1 - B0][10], cv[B1 - B0][6], ca[B1 - B0][6];
+    static_for<B0, B1>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      static_for<0, 10>([&](auto kc) { in[b - B0][decltype(kc)::value] = w(kL.cinert + 10 * b + decltype(kc)::value); });
+      static_for<0, 6>([&](auto kc) {
+        cv[b - B0][decltype(kc)::value] = w(kL.cvel + 6 * b + decltype(kc)::value);
+        ca[b - B0][decltype(kc)::value] = w(kL.cacc + 6 * b + decltype(kc)::value);
+      });
+    });
+    EPA_TREE_FENCE();
+    static_for<B0, B1>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      double t1[6], t2[6], t3[6];
+      MulInertVec(t1, in[b - B0], ca[b - B0]);
+      MulInertVec(t2, in[b - B0], cv[b - B0]);
+      CrossForce(t3, cv[b - B0], t2);
+      static_for<0, 6>([&](auto rc) { cf[b][decltype(rc)::value] = t1[decltype(rc)::value] + t3[decltype(rc)::value]; });
+    });
+  }
   static EPA_HD void Velocity(Ws w) {
     constexpr TreeModel m = MP::kM;
-    static_for<0, 6>([&](auto rc) {
-      w(kL.cvel + decltype(rc)::value) = 0.0;
-      w(kL.cacc + decltype(rc)::value) = decltype(rc)::value == 5 ? m.gravity : 0.0;
-    });
-    static_for<1, NB>([&](auto bc) {
-      constexpr int b = decltype(bc)::value;
-      constexpr int p = m.body_parent[b];
-      constexpr int a = m.body_dofadr[b], n = m.body_dofnum[b];
-      double cvel[6], cacc[6];
-      static_for<0, 6>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        cvel[r] = w(kL.cvel + 6 * p + r);
-        cacc[r] = w(kL.cacc + 6 * p + r);
+    {
+      double cd[NV][6], qv[NV];
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        qv[i] = w(kL.qvel + i);
+        static_for<0, 6>([&](auto rc) { cd[i][decltype(rc)::value] = w(kL.cdof + 6 * i + decltype(rc)::value); });
       });
-      if constexpr (n == 6) {  // free joint: translations first, their cdof_dot is zero
-        static_for<0, 3>([&](auto kc) { cvel[3 + decltype(kc)::value] += w(kL.qvel + a + decltype(kc)::value); });
-        double cd[3][6], dot[6];
-        static_for<0, 3>([&](auto kc) {
-          static_for<0, 6>([&](auto rc) {
-            cd[decltype(kc)::value][decltype(rc)::value] = w(kL.cdof + 6 * (a + 3 + decltype(kc)::value) + decltype(rc)::value);
-          });
-        });
-        static_for<0, 3>([&](auto kc) {
-          constexpr int k = decltype(kc)::value;
-          CrossMotion(dot, cvel, cd[k]);  // all three with the velocity before the rotations
-          const double qv = w(kL.qvel + a + 3 + k);
-          static_for<0, 6>([&](auto rc) { cacc[decltype(rc)::value] += dot[decltype(rc)::value] * qv; });
-        });
-        static_for<0, 3>([&](auto kc) {
-          constexpr int k = decltype(kc)::value;
-          const double qv = w(kL.qvel + a + 3 + k);
-          static_for<0, 6>([&](auto rc) { cvel[decltype(rc)::value] += cd[k][decltype(rc)::value] * qv; });
-        });
-      } else {
-        static_for<0, n>([&](auto jc) {
-          constexpr int i = a + decltype(jc)::value;
-          double cd[6], dot[6];
-          static_for<0, 6>([&](auto rc) { cd[decltype(rc)::value] = w(kL.cdof + 6 * i + decltype(rc)::value); });
-          CrossMotion(dot, cvel, cd);
-          const double qv = w(kL.qvel + i);
-          static_for<0, 6>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            cacc[r] += dot[r] * qv;
-            cvel[r] += cd[r] * qv;
-          });
-        });
-      }
-      double in[10], t1[6], t2[6], t3[6];
-      static_for<0, 10>([&](auto kc) { in[decltype(kc)::value] = w(kL.cinert + 10 * b + decltype(kc)::value); });
-      MulInertVec(t1, in, cacc);
-      MulInertVec(t2, in, cvel);
-      CrossForce(t3, cvel, t2);
-      static_for<0, 6>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        w(kL.cvel + 6 * b + r) = cvel[r];
-        w(kL.cacc + 6 * b + r) = cacc[r];
-        w(kL.cfrc + 6 * b + r) = t1[r] + t3[r];
-      });
-    });
+      EPA_TREE_FENCE();
+      const double zero[6] = {0, 0, 0, 0, 0, 0};
+      const double grav[6] = {0, 0, 0, 0, 0, m.gravity};  // cacc[world] = -gravity
+      static_for<0, 6>([&](auto rc) { w(kL.cvel + decltype(rc)::value) = 0.0; });
+      VelBody<1>(w, cd, qv, zero, grav);
+    }
+    EPA_TREE_FENCE();
+    double cf[NB][6];
+    constexpr int kHalf = (NB + 1) / 2;
+    RneBatch<1, kHalf>(w, cf);
+    EPA_TREE_FENCE();
+    RneBatch<kHalf, NB>(w, cf);
     static_for_down<NB, 2>([&](auto bc) {
       constexpr int b = decltype(bc)::value;
       constexpr int p = m.body_parent[b];
       if constexpr (p > 0) {
-        static_for<0, 6>([&](auto rc) {
-          w(kL.cfrc + 6 * p + decltype(rc)::value) += w(kL.cfrc + 6 * b + decltype(rc)::value);
-        });
+        static_for<0, 6>([&](auto rc) { cf[p][decltype(rc)::value] += cf[b][decltype(rc)::value]; });
       }
     });
+    EPA_TREE_FENCE();
     double x[NV];
-    static_for<0, NV>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      double cd[6], f[6];
-      static_for<0, 6>([&](auto rc) {
-        cd[decltype(rc)::value] = w(kL.cdof + 6 * i + decltype(rc)::value);
-        f[decltype(rc)::value] = w(kL.cfrc + 6 * m.dof_body[i] + decltype(rc)::value);
+    {
+      double cd[NV][6], qv[NV], qs[NJ], ct[NU];
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        qv[i] = w(kL.qvel + i);
+        static_for<0, 6>([&](auto rc) { cd[i][decltype(rc)::value] = w(kL.cdof + 6 * i + decltype(rc)::value); });
       });
-      const double bias = Dot6(cd, f);
-      double passive = -m.dof_damp[i] * w(kL.qvel + i);
-      w(kL.bias + i) = bias;
-      x[i] = -bias;
-      w(kL.act + i) = 0.0;
-      w(kL.passive + i) = passive;
-    });
-    static_for<1, NJ>([&](auto jc) {  // joint springs (hinges; joint 0 is the free root)
-      constexpr int j = decltype(jc)::value;
-      if constexpr (m.jnt_stiff[j] != 0.0) {
-        w(kL.passive + m.jnt_dadr[j]) -= m.jnt_stiff[j] * (w(kL.qpos + m.jnt_qadr[j]) - m.qpos0[m.jnt_qadr[j]]);
-      }
-    });
-    static_for<0, NU>([&](auto uc) {
-      constexpr int u = decltype(uc)::value;
-      w(kL.act + m.act_dof[u]) += m.act_gear[u] * Clamp(w(kL.ctrl + u), m.ctrl_lo, m.ctrl_hi);
-    });
-    static_for<0, NV>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      x[i] += w(kL.passive + i) + w(kL.act + i);
-      w(kL.smooth + i) = x[i];
-    });
+      static_for<1, NJ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (m.jnt_stiff[j] != 0.0) qs[j] = w(kL.qpos + m.jnt_qadr[j]);
+      });
+      static_for<0, NU>([&](auto uc) { ct[decltype(uc)::value] = w(kL.ctrl + decltype(uc)::value); });
+      EPA_TREE_FENCE();
+      double act[NV];
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        x[i] = -Dot6(cd[i], cf[m.dof_body[i]]) - m.dof_damp[i] * qv[i];  // -bias + damper
+        act[i] = 0.0;
+      });
+      static_for<1, NJ>([&](auto jc) {  // joint springs (hinges; joint 0 is the free root)
+        constexpr int j = decltype(jc)::value;
+        if constexpr (m.jnt_stiff[j] != 0.0) {
+          x[m.jnt_dadr[j]] -= m.jnt_stiff[j] * (qs[j] - m.qpos0[m.jnt_qadr[j]]);
+        }
+      });
+      static_for<0, NU>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        act[m.act_dof[u]] += m.act_gear[u] * Clamp(ct[u], m.ctrl_lo, m.ctrl_hi);
+      });
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        x[i] += act[i];
+        w(kL.act + i) = act[i];
+      });
+    }
+    EPA_TREE_FENCE();
     SolveM(w, x);
     static_for<0, NV>([&](auto ic) { w(kL.accs + decltype(ic)::value) = x[decltype(ic)::value]; });
   }
 
   // ---- mj_collision + joint-limit detection (phase A) ---------------------------------------
-  // Scalar loops over the static candidate lists (tables in constant memory, slot numbers
-  // wave-uniform).  Results per group in the workspace; `act` = this lane's active groups,
-  // `uni` = the wave-uniform union.
-  struct DetTab {
-    int lim_qadr[kMaxJnt];
-    double lim_lo[kMaxJnt], lim_hi[kMaxJnt];
-    int floor_geom[kMaxFloor], floor_caps[kMaxFloor];
-    double floor_off[kMaxFloor], floor_rad[kMaxFloor];  // off = sign * half length
-    int pair_g1[kMaxPair], pair_g2[kMaxPair], pair_kind[kMaxPair];  // 0 ss, 1 sphere-capsule, 2 cc
-    double pair_r1[kMaxPair], pair_r2[kMaxPair], pair_h1[kMaxPair], pair_h2[kMaxPair];
-    double pair_bound2[kMaxPair];
-  };
-  static constexpr DetTab MakeDetTab() {
-    constexpr TreeModel m = MP::kM;
-    DetTab t{};
-    for (int g = 0; g < m.nlimit; ++g) {
-      t.lim_qadr[g] = m.jnt_qadr[m.limit_jnt[g]];
-      t.lim_lo[g] = m.jnt_lo[m.limit_jnt[g]];
-      t.lim_hi[g] = m.jnt_hi[m.limit_jnt[g]];
-    }
-    for (int c = 0; c < m.nfloor; ++c) {
-      const int g = m.floor_geom[c];
-      t.floor_geom[c] = g;
-      t.floor_caps[c] = m.geom_type[g] == kGeomCapsule;
-      t.floor_off[c] = m.floor_sign[c] * m.geom_hl[g];
-      t.floor_rad[c] = m.geom_rad[g];
-    }
-    for (int p = 0; p < m.npair; ++p) {
-      const int g1 = m.pair_g1[p], g2 = m.pair_g2[p];
-      t.pair_g1[p] = g1;
-      t.pair_g2[p] = g2;
-      t.pair_kind[p] = m.geom_type[g1] == kGeomCapsule ? 2 : (m.geom_type[g2] == kGeomCapsule ? 1 : 0);
-      t.pair_r1[p] = m.geom_rad[g1];
-      t.pair_r2[p] = m.geom_rad[g2];
-      t.pair_h1[p] = m.geom_hl[g1];
-      t.pair_h2[p] = m.geom_hl[g2];
-      const double bound = m.geom_rad[g1] + m.geom_hl[g1] + m.geom_rad[g2] + m.geom_hl[g2] + m.margin;
-      t.pair_bound2[p] = bound * bound;
-    }
-    return t;
-  }
+  // All candidates are static: unrolled tests on geoms held in registers (one batch of loads);
+  // the narrow phase of a pair only runs if some lane passes the bounding-sphere cull.
+  // Results per group in the workspace; `act` = this lane's active groups, `uni` = the
+  // wave-uniform union.
   static EPA_HD void SetBit(GMask& act, GMask& uni, int g, bool on) {
     const unsigned long long bit = 1ull << (g & 63);
     const bool wany = WaveAny(on);
@@ -701,52 +771,71 @@ struct Tree {
     *pos = p1 + *n * (r1 + 0.5 * dist);
     return dist;
   }
-  static EPA_HD Vec3 Load3(Ws w, int slot) { return {w(slot), w(slot + 1), w(slot + 2)}; }
   static EPA_HD void Detect(Ws w, GMask& act, GMask& uni) {
     constexpr TreeModel m = MP::kM;
-    static constexpr DetTab dt = MakeDetTab();
     static_for<0, kGW>([&](auto kc) { act.w[decltype(kc)::value] = uni.w[decltype(kc)::value] = 0ull; });
+    double ql[kNLimit > 0 ? kNLimit : 1], gp[NG][3], ga[NG][3];
+    static_for<0, kNLimit>([&](auto gc) {
+      ql[decltype(gc)::value] = w(kL.qpos + m.jnt_qadr[m.limit_jnt[decltype(gc)::value]]);
+    });
+    static_for<1, NG>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      static_for<0, 3>([&](auto rc) {
+        gp[g][decltype(rc)::value] = w(kL.gpos + 3 * g + decltype(rc)::value);
+        if constexpr (m.geom_type[g] == kGeomCapsule) ga[g][decltype(rc)::value] = w(kL.gaxis + 3 * g + decltype(rc)::value);
+      });
+    });
+    EPA_TREE_FENCE();
     // joint limits (mj_instantiateLimit): dist = q - lo (J = +1) or hi - q (J = -1); margin 0
-    for (int g = 0; g < kNLimit; ++g) {
-      const double q = w(kL.qpos + dt.lim_qadr[g]);
-      const double dlo = q - dt.lim_lo[g], dhi = dt.lim_hi[g] - q;
+    static_for<0, kNLimit>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int j = m.limit_jnt[g];
+      const double dlo = ql[g] - m.jnt_lo[j], dhi = m.jnt_hi[j] - ql[g];
       const bool lo = dlo < 0.0, on = lo || dhi < 0.0;
       SetBit(act, uni, g, on);
       if (WaveAny(on)) {
         w(kL.limd + g) = Sel(lo, dlo, dhi);
         w(kL.lims + g) = Sel(lo, 1.0, -1.0);
       }
-    }
+    });
     // floor (plane z = 0, normal +z): mjc_PlaneSphere on spheres and capsule end spheres
-    for (int c = 0; c < kNFloor; ++c) {
-      const int g = dt.floor_geom[c];
-      Vec3 ctr = Load3(w, kL.gpos + 3 * g);
-      if (dt.floor_caps[c]) ctr = ctr + Load3(w, kL.gaxis + 3 * g) * dt.floor_off[c];
-      const double dist = ctr.z - dt.floor_rad[c];
+    static_for<0, kNFloor>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      constexpr int g = m.floor_geom[c];
+      constexpr double s = m.floor_sign[c] * m.geom_hl[g];
+      double cx = gp[g][0], cy = gp[g][1], cz = gp[g][2];
+      if constexpr (m.geom_type[g] == kGeomCapsule) {
+        cx += s * ga[g][0];
+        cy += s * ga[g][1];
+        cz += s * ga[g][2];
+      }
+      const double dist = cz - m.geom_rad[g];
       const bool on = dist < m.margin;
       SetBit(act, uni, kNLimit + c, on);
       if (WaveAny(on)) {
         w(kL.condist + c) = dist;
-        w(kL.conpos + 3 * c) = ctr.x;
-        w(kL.conpos + 3 * c + 1) = ctr.y;
+        w(kL.conpos + 3 * c) = cx;
+        w(kL.conpos + 3 * c + 1) = cy;
         w(kL.conpos + 3 * c + 2) = 0.5 * dist;  // centre - n (r + dist / 2)
       }
-    }
+    });
     // geom pairs: sphere / capsule primitives (mjraw_SphereSphere / SphereCapsule / CapsuleCapsule)
-    for (int p = 0; p < kNPair; ++p) {
-      const int g1 = dt.pair_g1[p], g2 = dt.pair_g2[p], kind = dt.pair_kind[p];
-      const int c = kNFloor + p;
-      const double r1 = dt.pair_r1[p], r2 = dt.pair_r2[p];
-      const Vec3 p1 = Load3(w, kL.gpos + 3 * g1), p2 = Load3(w, kL.gpos + 3 * g2);
+    static_for<0, kNPair>([&](auto pc) {
+      constexpr int p = decltype(pc)::value;
+      constexpr int g1 = m.pair_g1[p], g2 = m.pair_g2[p];
+      constexpr int c = kNFloor + p;
+      constexpr double r1 = m.geom_rad[g1], r2 = m.geom_rad[g2];
+      constexpr double h1 = m.geom_hl[g1], h2 = m.geom_hl[g2];
+      const Vec3 p1 = {gp[g1][0], gp[g1][1], gp[g1][2]}, p2 = {gp[g2][0], gp[g2][1], gp[g2][2]};
       // wave-level cull on bounding spheres
+      constexpr double bound = r1 + h1 + r2 + h2 + m.margin;
       const Vec3 dc = p2 - p1;
-      const bool near = Dot(dc, dc) < dt.pair_bound2[p];
-      bool on = false;
+      const bool near = Dot(dc, dc) < bound * bound;
       if (WaveAny(near)) {
         Vec3 q1 = p1, q2 = p2;
-        if (kind == 2) {
-          const Vec3 a1 = Load3(w, kL.gaxis + 3 * g1) * dt.pair_h1[p];
-          const Vec3 a2 = Load3(w, kL.gaxis + 3 * g2) * dt.pair_h2[p];
+        if constexpr (m.geom_type[g1] == kGeomCapsule) {  // both capsules
+          const Vec3 a1 = Vec3{ga[g1][0], ga[g1][1], ga[g1][2]} * h1;
+          const Vec3 a2 = Vec3{ga[g2][0], ga[g2][1], ga[g2][2]} * h2;
           const Vec3 dif = p1 - p2;
           const double ma = Dot(a1, a1), mb = -Dot(a1, a2), mc = Dot(a2, a2);
           const double u = -Dot(a1, dif), v = Dot(a2, dif);
@@ -772,14 +861,14 @@ struct Tree {
           }
           q1 = p1 + a1 * x1;
           q2 = p2 + a2 * x2;
-        } else if (kind == 1) {
-          const Vec3 ax = Load3(w, kL.gaxis + 3 * g2);
-          const double h2 = dt.pair_h2[p];
+        } else if constexpr (m.geom_type[g2] == kGeomCapsule) {  // sphere - capsule
+          const Vec3 ax = {ga[g2][0], ga[g2][1], ga[g2][2]};
           q2 = p2 + ax * Clamp(Dot(ax, p1 - p2), -h2, h2);
         }
         Vec3 n, pos;
         const double dist = SphereSphere(q1, r1, q2, r2, &n, &pos);
-        on = near && dist < m.margin;
+        const bool on = near && dist < m.margin;
+        SetBit(act, uni, kNLimit + c, on);
         if (WaveAny(on)) {
           w(kL.condist + c) = dist;
           w(kL.conpos + 3 * c) = pos.x;
@@ -790,8 +879,7 @@ struct Tree {
           w(kL.connrm + 3 * c + 2) = n.z;
         }
       }
-      SetBit(act, uni, kNLimit + c, on);
-    }
+    });
   }
 
   // scalar iteration over the set bits of a wave-uniform group mask
@@ -822,94 +910,6 @@ struct Tree {
     return Sel(x >= 1.0, m.sol_dmax, m.sol_d0 + y * (m.sol_dmax - m.sol_d0));
   }
 
-  // ---- mj_makeConstraint + mj_projectConstraint rows (phase B: one code instance, scalar loop
-  // over the groups some lane needs).  Also the warm-start forces f = -D min(0, J a_warm - aref).
-  static EPA_HD void MakeRows(Ws w0, const GMask& act, const GMask& uni) {
-    constexpr TreeModel m = MP::kM;
-    static constexpr GroupTab gt = MakeGroupTab(MP::kM);
-    const Vec3 com = {w0(kL.com), w0(kL.com + 1), w0(kL.com + 2)};
-    {
-      for (int g = NextGroup(uni, 0); g >= 0; g = NextGroup(uni, g + 1)) {
-        const Ws w = w0.Fresh();
-        const bool on = LaneHas(act, g);
-        const bool is_limit = g < kNLimit, is_floor = !is_limit && g < kNLimit + kNFloor;
-        const int c = g - kNLimit;  // contact index (floor, then pairs)
-        double jn[NV], jt1[NV], jt2[NV];
-        double pos;
-        if (is_limit) {
-          const int d = gt.dof[g];
-          const double s = w(kL.lims + g);
-          pos = w(kL.limd + g);
-          static_for<0, NV>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            jn[i] = i == d ? s : 0.0;
-            jt1[i] = jt2[i] = 0.0;
-          });
-        } else {
-          pos = w(kL.condist + c) - m.margin;  // r = dist - includemargin
-          const Vec3 off = Vec3{w(kL.conpos + 3 * c), w(kL.conpos + 3 * c + 1), w(kL.conpos + 3 * c + 2)} - com;
-          // floor frame (mju_makeFrame of +z): n = z, t1 = y, t2 = -x
-          Vec3 n = {0, 0, 1};
-          if (!is_floor) n = {w(kL.connrm + 3 * c), w(kL.connrm + 3 * c + 1), w(kL.connrm + 3 * c + 2)};
-          const Vec3 mn = Cross(off, n);
-          const Vec3 mt1 = Cross(off, Vec3{0, 1, 0}), mt2 = Cross(off, Vec3{-1, 0, 0});
-          const unsigned m1 = gt.mask1[g], m2 = gt.mask2[g];
-          static_for<0, NV>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const int coef = (int)((m2 >> i) & 1u) - (int)((m1 >> i) & 1u);
-            jn[i] = jt1[i] = jt2[i] = 0.0;
-            if (coef != 0) {  // scalar: the masks are per group
-              const Vec3 ang = {w(kL.cdof + 6 * i), w(kL.cdof + 6 * i + 1), w(kL.cdof + 6 * i + 2)};
-              const Vec3 lin = {w(kL.cdof + 6 * i + 3), w(kL.cdof + 6 * i + 4), w(kL.cdof + 6 * i + 5)};
-              const double sg = (double)coef;
-              jn[i] = sg * (Dot(n, lin) + Dot(mn, ang));
-              if (is_floor) {
-                jt1[i] = sg * (lin.y + Dot(mt1, ang));
-                jt2[i] = sg * (-lin.x + Dot(mt2, ang));
-              }
-            }
-          });
-        }
-        // impedance / regulariser of the group (mj_makeImpedance); pyramid rows share 2 mu^2 R
-        const double imp = Impedance(fabs(pos));
-        double R = fmax(kMinVal, (1.0 - imp) * gt.diag[g] / imp);
-        if (is_floor) R *= 2.0 * m.floor_mu * m.floor_mu;
-        const double kimp = m.sol_K * imp * pos;
-        const int nsub = is_floor ? 4 : 1;
-        const int row0 = is_limit ? g : (is_floor ? kNLimit + 4 * c : kNLimit + 4 * kNFloor + (c - kNFloor));
-#pragma nounroll
-        for (int k = 0; k < nsub; ++k) {
-          const Ws w = w0.Fresh();
-          const double c1 = is_floor ? (k == 0 ? m.floor_mu : (k == 1 ? -m.floor_mu : 0.0)) : 0.0;
-          const double c2 = is_floor ? (k == 2 ? m.floor_mu : (k == 3 ? -m.floor_mu : 0.0)) : 0.0;
-          const int r = row0 + k;
-          double x[NV];
-          double vel = 0.0, jw = 0.0;
-          static_for<0, NV>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            x[i] = jn[i] + c1 * jt1[i] + c2 * jt2[i];
-            vel += x[i] * w(kL.qvel + i);
-            jw += x[i] * w(kL.warm + i);
-            w(kL.rowJ + r * NV + i) = x[i];
-          });
-          SolveM(w, x);
-          double arr = R;
-          static_for<0, NV>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            arr += (jn[i] + c1 * jt1[i] + c2 * jt2[i]) * x[i];
-            w(kL.rowW + r * NV + i) = x[i];
-          });
-          const double aref = -m.sol_B * vel - kimp;
-          const double jar = jw - aref;
-          w(kL.rowR + r) = R;
-          w(kL.rowAref + r) = aref;
-          w(kL.rowArr + r) = arr;
-          w(kL.rowF + r) = (on && jar < 0.0) ? -jar / R : 0.0;
-        }
-      }
-    }
-  }
-
   // visit the rows of the union mask in order: f(row, lane_has_row)
   template <typename F>
   static EPA_HD void ForRows(const GMask& act, const GMask& uni, F&& f) {
@@ -923,91 +923,232 @@ struct Tree {
     }
   }
 
-  // ---- mj_fwdConstraint with mj_solPGS ----------------------------------------------------------
-  // `commit`: lanes that are only kept busy must not disturb their warm start.
-  static EPA_HD void SolvePgs(Ws w, const GMask& act, const GMask& uni, bool commit) {
+  // ---- mj_makeConstraint + mj_projectConstraint (phase B: one code instance, scalar loops over
+  // the groups / rows some lane needs).  Pass 1 builds the Jacobian rows from cdof held in
+  // registers, with aref, R and the warm-start force f = -D min(0, J a_warm - aref); pass 2 is
+  // one M^-1 solve per row: W_r = M^-1 J_r', A_rr + R_r.
+  static EPA_HD void MakeRows(Ws w0, const GMask& act, const GMask& uni, double* u, double* csum_out) {
     constexpr TreeModel m = MP::kM;
-    double a[NV], u[NV];
+    static constexpr GroupTab gt = MakeGroupTab(MP::kM);
+    {
+      double cd[NV][6], qv[NV], wm[NV];
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        qv[i] = w0(kL.qvel + i);
+        wm[i] = w0(kL.warm + i);
+        static_for<0, 6>([&](auto rc) { cd[i][decltype(rc)::value] = w0(kL.cdof + 6 * i + decltype(rc)::value); });
+      });
+      const Vec3 com = {w0(kL.com), w0(kL.com + 1), w0(kL.com + 2)};
+      EPA_TREE_FENCE();
+      double csum = 0.0;  // sum_r f_r (R_r f_r / 2 - aref_r) of the warm-start forces
+      static_for<0, NV>([&](auto ic) { u[decltype(ic)::value] = 0.0; });  // J' f_warm
+      for (int g = NextGroup(uni, 0); g >= 0; g = NextGroup(uni, g + 1)) {
+        const Ws w = w0.Fresh();
+        const bool on = LaneHas(act, g);
+        const bool is_limit = g < kNLimit, is_floor = !is_limit && g < kNLimit + kNFloor;
+        const int c = is_limit ? 0 : g - kNLimit;  // contact index (floor, then pairs)
+        // detection results of the group (harmless dummy slots for a limit / floor group)
+        const double lim_d = w(kL.limd + (is_limit ? g : 0)), lim_s = w(kL.lims + (is_limit ? g : 0));
+        const double cdist = w(kL.condist + c);
+        const Vec3 cpos = {w(kL.conpos + 3 * c), w(kL.conpos + 3 * c + 1), w(kL.conpos + 3 * c + 2)};
+        const Vec3 cn = {w(kL.connrm + 3 * c), w(kL.connrm + 3 * c + 1), w(kL.connrm + 3 * c + 2)};
+        EPA_TREE_FENCE();
+        const double pos = is_limit ? lim_d : cdist - m.margin;  // r = dist - includemargin
+        const Vec3 off = cpos - com;
+        // floor frame (mju_makeFrame of +z): n = z, t1 = y, t2 = -x
+        const Vec3 n = is_floor ? Vec3{0, 0, 1} : cn;
+        // impedance / regulariser of the group (mj_makeImpedance); pyramid rows share 2 mu^2 R
+        const double imp = Impedance(fabs(pos));
+        double R = fmax(kMinVal, (1.0 - imp) * gt.diag[g] / imp);
+        if (is_floor) R *= 2.0 * m.floor_mu * m.floor_mu;
+        const double kimp = m.sol_K * imp * pos;
+        const int nsub = is_floor ? 4 : 1;
+        const int row0 = is_limit ? g : (is_floor ? kNLimit + 4 * c : kNLimit + 4 * kNFloor + (c - kNFloor));
+        const unsigned m1 = is_limit ? 0u : gt.mask1[g], m2 = is_limit ? 0u : gt.mask2[g];
+        const int ld = is_limit ? gt.dof[g] : -1;
+#pragma nounroll
+        for (int k = 0; k < nsub; ++k) {
+          // row direction: n, or the pyramid edge n +- mu t
+          Vec3 dir = n;
+          if (is_floor) {
+            dir = k == 0 ? Vec3{0, m.floor_mu, 1} : (k == 1 ? Vec3{0, -m.floor_mu, 1}
+                         : (k == 2 ? Vec3{-m.floor_mu, 0, 1} : Vec3{m.floor_mu, 0, 1}));
+          }
+          const Vec3 mdir = Cross(off, dir);
+          const int r = row0 + k;
+          double vel = 0.0, jw = 0.0, J[NV];
+          static_for<0, NV>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int coef = (int)((m2 >> i) & 1u) - (int)((m1 >> i) & 1u);
+            J[i] = i == ld ? lim_s : 0.0;
+            if (coef != 0) {  // scalar: the masks are per group
+              J[i] = (double)coef * (dir.x * cd[i][3] + dir.y * cd[i][4] + dir.z * cd[i][5] +
+                                     mdir.x * cd[i][0] + mdir.y * cd[i][1] + mdir.z * cd[i][2]);
+            }
+            vel += J[i] * qv[i];
+            jw += J[i] * wm[i];
+            w(kL.rowJ + r * NV + i) = J[i];
+          });
+          const double aref = -m.sol_B * vel - kimp;
+          const double jar = jw - aref;
+          const double f = (on && jar < 0.0) ? -jar / R : 0.0;
+          w(kL.rowR + r) = R;
+          w(kL.rowAref + r) = aref;
+          w(kL.rowF + r) = f;
+          csum += f * (0.5 * R * f - aref);
+          static_for<0, NV>([&](auto ic) { u[decltype(ic)::value] += f * J[decltype(ic)::value]; });
+        }
+      }
+      *csum_out = csum;
+    }
+    EPA_TREE_FENCE();
+    ForRows(act, uni, [&](int r, bool on) {
+      (void)on;
+      const Ws w = w0.Fresh();
+      double x[NV];
+      static_for<0, NV>([&](auto ic) { x[decltype(ic)::value] = w(kL.rowJ + r * NV + decltype(ic)::value); });
+      const double R = w(kL.rowR + r);
+      const double quad = SolveM(w, x);
+      static_for<0, NV>([&](auto ic) { w(kL.rowW + r * NV + decltype(ic)::value) = x[decltype(ic)::value]; });
+      w(kL.rowArr + r) = R + quad;
+      w(kL.rowArrInv + r) = 1.0 / (R + quad);
+    });
+  }
+
+  // ---- mj_fwdConstraint with mj_solPGS ----------------------------------------------------------
+  // (g, k) -> next row of the union mask; false at the end
+  static EPA_HD bool NextRow(const GMask& uni, int& g, int& k) {
+    const bool is_floor = g >= kNLimit && g < kNLimit + kNFloor;
+    if (is_floor && k < 3) {
+      ++k;
+      return true;
+    }
+    g = NextGroup(uni, g + 1);
+    k = 0;
+    return g >= 0;
+  }
+  static EPA_HD int RowOf(int g, int k) {
+    const bool is_limit = g < kNLimit, is_floor = !is_limit && g < kNLimit + kNFloor;
+    return (is_limit ? g : (is_floor ? kNLimit + 4 * (g - kNLimit) : g + 3 * kNFloor)) + k;
+  }
+  struct RowRegs {
+    double J[NV], W[NV], f, arrinv, arr, R, aref;
+  };
+  static EPA_HD void LoadRow(Ws w, int r, RowRegs& t) {
+    static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      t.J[i] = w(kL.rowJ + r * NV + i);
+      t.W[i] = w(kL.rowW + r * NV + i);
+    });
+    t.f = w(kL.rowF + r);
+    t.arr = w(kL.rowArr + r);
+    t.arrinv = w(kL.rowArrInv + r);
+    t.R = w(kL.rowR + r);
+    t.aref = w(kL.rowAref + r);
+  }
+  // one PGS row update (mj_solPGS, dim 1): returns the cost decrease
+  static EPA_HD double VisitRow(Ws w, int r, const RowRegs& t, bool live, double* a) {
+    double p0 = t.R * t.f - t.aref, p1 = 0.0, p2 = 0.0, p3 = 0.0;  // 4 chains: short latency
+    static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i % 4 == 0) p0 += t.J[i] * a[i];
+      if constexpr (i % 4 == 1) p1 += t.J[i] * a[i];
+      if constexpr (i % 4 == 2) p2 += t.J[i] * a[i];
+      if constexpr (i % 4 == 3) p3 += t.J[i] * a[i];
+    });
+    const double res = (p0 + p1) + (p2 + p3);
+    const double fn = fmax(0.0, t.f - res * t.arrinv);
+    double delta = fn - t.f;
+    const double change = 0.5 * delta * delta * t.arr + delta * res;
+    const bool keep = live && !(change > 1e-10);
+    delta = Sel(keep, delta, 0.0);
+    w(kL.rowF + r) = t.f + delta;
+    static_for<0, NV>([&](auto ic) { a[decltype(ic)::value] += delta * t.W[decltype(ic)::value]; });
+    return Sel(keep, -change, 0.0);
+  }
+  // `u` = J' f_warm and `csum` = sum_r f_r (R_r f_r / 2 - aref_r) come from MakeRows.
+  // `commit`: lanes that are only kept busy must not disturb their warm start.
+  static EPA_HD void SolvePgs(Ws w0, const GMask& act, const GMask& uni, bool commit, double* u,
+                              double csum) {
+    constexpr TreeModel m = MP::kM;
+    double a[NV];
     bool any = false;
     static_for<0, kGW>([&](auto kc) { any = any || uni.w[decltype(kc)::value] != 0ull; });
+    static_for<0, NV>([&](auto ic) { a[decltype(ic)::value] = w0(kL.accs + decltype(ic)::value); });
     if (any) {
-      // dual cost of the warm-start forces: 1/2 f'(A+R)f + f'b, b = J qacc_smooth - aref;
-      // keep them only if it is below the cost of f = 0
-      static_for<0, NV>([&](auto ic) { a[decltype(ic)::value] = u[decltype(ic)::value] = 0.0; });
-      double cost = 0.0;
-      ForRows(act, uni, [&](int r, bool on) {
-        (void)on;
-        const double f = w(kL.rowF + r);
-        double jb = 0.0;
-        static_for<0, NV>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          const double J = w(kL.rowJ + r * NV + i);
-          u[i] += f * J;
-          a[i] += f * w(kL.rowW + r * NV + i);
-          jb += J * w(kL.accs + i);
-        });
-        cost += f * (0.5 * w(kL.rowR + r) * f + jb - w(kL.rowAref + r));
+      // dual cost of the warm-start forces: 1/2 f'(A+R)f + f'b with A f = J M^-1 J'f and
+      // b = J qacc_smooth - aref; they are kept only if it is below the cost of f = 0
+      double v[NV];
+      double cost = csum;
+      static_for<0, NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        v[i] = u[i];
+        cost += u[i] * a[i];
       });
-      static_for<0, NV>([&](auto ic) { cost += 0.5 * u[decltype(ic)::value] * a[decltype(ic)::value]; });
+      SolveM(w0.Fresh(), v);
+      static_for<0, NV>([&](auto ic) { cost += 0.5 * u[decltype(ic)::value] * v[decltype(ic)::value]; });
       const bool cold = cost > 0.0;
       static_for<0, NV>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        a[i] = w(kL.accs + i) + Sel(cold, 0.0, a[i]);
+        a[i] += Sel(cold, 0.0, v[i]);
       });
       if (WaveAny(cold)) {
         ForRows(act, uni, [&](int r, bool on) {
           (void)on;
-          if (cold) w(kL.rowF + r) = 0.0;
+          if (cold) w0(kL.rowF + r) = 0.0;
         });
       }
+      EPA_TREE_FENCE();
       const double scale = 1.0 / (m.meaninertia * (double)NV);
       bool done = false;
       for (int iter = 0; iter < m.iterations; ++iter) {
+        // rows stream through a ring of kRing register buffers: a row is loaded kRing - 1 visits
+        // before it is used, so the HBM latency overlaps the arithmetic of the rows in between
+        constexpr int kRing = 3;
         double improvement = 0.0;
-        ForRows(act, uni, [&](int r, bool on) {
-          const double f = w(kL.rowF + r), arr = w(kL.rowArr + r);
-          double res = w(kL.rowR + r) * f - w(kL.rowAref + r);
-          static_for<0, NV>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            res += w(kL.rowJ + r * NV + i) * a[i];
-          });
-          double fn = fmax(0.0, f - res / arr);
-          double delta = fn - f;
-          double change = 0.5 * delta * delta * arr + delta * res;
-          const bool keep = on && !done && !(change > 1e-10);
-          delta = Sel(keep, delta, 0.0);
-          improvement -= Sel(keep, change, 0.0);
-          w(kL.rowF + r) = f + delta;
-          static_for<0, NV>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            a[i] += delta * w(kL.rowW + r * NV + i);
-          });
+        RowRegs buf[kRing];
+        int rg[kRing], rk[kRing];  // (group, sub-row) held by each buffer; group -1: none
+        int g = NextGroup(uni, 0), k = 0;
+        static_for<0, kRing - 1>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          rg[b] = g;
+          rk[b] = k;
+          if (g >= 0) {
+            LoadRow(w0.Fresh(), RowOf(g, k), buf[b]);
+            if (!NextRow(uni, g, k)) g = -1;
+          }
         });
+        for (bool more = true; more;) {
+          static_for<0, kRing>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            constexpr int pre = (b + kRing - 1) % kRing;
+            if (more) {
+              const Ws w = w0.Fresh();
+              rg[pre] = g;
+              rk[pre] = k;
+              if (g >= 0) {  // prefetch: independent of the updates in between
+                LoadRow(w, RowOf(g, k), buf[pre]);
+                if (!NextRow(uni, g, k)) g = -1;
+              }
+              EPA_TREE_FENCE();
+              if (rg[b] >= 0) {
+                improvement += VisitRow(w, RowOf(rg[b], rk[b]), buf[b], LaneHas(act, rg[b]) && !done, a);
+              } else {
+                more = false;
+              }
+              EPA_TREE_FENCE();
+            }
+          });
+        }
         done = done || improvement * scale < 1e-8;
         if (!WaveAny(!done)) break;
       }
-      // dual finish: qfrc_constraint = J' f, qacc = qacc_smooth + M^-1 qfrc_constraint
-      static_for<0, NV>([&](auto ic) { u[decltype(ic)::value] = 0.0; });
-      ForRows(act, uni, [&](int r, bool on) {
-        (void)on;
-        const double f = w(kL.rowF + r);
-        static_for<0, NV>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          u[i] += f * w(kL.rowJ + r * NV + i);
-        });
-      });
-      SolveM(w, u);
-      static_for<0, NV>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        a[i] = w(kL.accs + i) + u[i];
-      });
-    } else {
-      static_for<0, NV>([&](auto ic) { a[decltype(ic)::value] = w(kL.accs + decltype(ic)::value); });
+      // qacc = qacc_smooth + M^-1 J' f is `a` itself (accumulated row update by row update)
     }
     static_for<0, NV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      w(kL.qacc + i) = a[i];
-      if (commit) w(kL.warm + i) = a[i];
+      w0(kL.qacc + i) = a[i];
+      if (commit) w0(kL.warm + i) = a[i];
     });
   }
 
@@ -1024,9 +1165,10 @@ struct Tree {
     EPA_TREE_FENCE();
     Velocity(w.Fresh());
     EPA_TREE_FENCE();
-    MakeRows(w.Fresh(), act, uni);
+    double u[NV], csum;
+    MakeRows(w.Fresh(), act, uni, u, &csum);
     EPA_TREE_FENCE();
-    SolvePgs(w.Fresh(), act, uni, commit);
+    SolvePgs(w.Fresh(), act, uni, commit, u, csum);
     EPA_TREE_FENCE();
   }
 
