@@ -96,6 +96,7 @@ struct Layout {
   int passive, bias, act, smooth, accs, qacc;
   int limd, lims, condist, conpos, connrm;           // detection results per group
   int rowJ, rowW, rowR, rowAref, rowArr, rowArrInv, rowF;
+  int ccpos, ccnrm, ccbody;                          // compact contact records (floor, then pairs)
   int x0q, x0v, accq, accv;                          // RK4
   int cext;                                          // cfrc_ext [nbody][6]
   int total;
@@ -120,6 +121,7 @@ constexpr Layout MakeLayout(const TreeModel& m) {
   L.condist = take(ncon); L.conpos = take(3 * ncon); L.connrm = take(3 * ncon);
   L.rowJ = take(nrow * m.nv); L.rowW = take(nrow * m.nv);
   L.rowR = take(nrow); L.rowAref = take(nrow); L.rowArr = take(nrow); L.rowArrInv = take(nrow); L.rowF = take(nrow);
+  L.ccpos = take(3 * ncon); L.ccnrm = take(3 * ncon); L.ccbody = take(2 * ncon);
   L.x0q = take(m.nq); L.x0v = take(m.nv); L.accq = take(m.nv); L.accv = take(m.nv);
   L.cext = take(6 * m.nbody);
   L.total = s;
@@ -882,25 +884,36 @@ struct Tree {
     });
   }
 
-  // scalar iteration over the set bits of a wave-uniform group mask
-  static EPA_HD int NextGroup(const GMask& uni, int from) {
-    int found = -1;
-    static_for_down<kGW, 0>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      const int lo = from - 64 * k;  // first candidate bit inside word k
-      const unsigned long long keep = lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
-      const unsigned long long mw = uni.w[k] & keep;
-      if (mw != 0ull) found = 64 * k + Ctz64(mw);
-    });
-    return found;
+  // ---- per-lane compaction of the constraint rows ------------------------------------------------
+  // Which groups are active differs from lane to lane; visiting the wave's UNION of static rows
+  // would cost every lane the work of all 64 (the union is 2-3x a lane's own set).  Rows are
+  // therefore built into COMPACT slots: in iteration t of a phase (limits, floor contacts, geom
+  // pairs) every lane takes ITS t-th active group of that phase, so the wave needs
+  // max-over-lanes iterations.  Each lane still sees its own rows in MuJoCo's order (limits by
+  // joint, contacts by body pair), which is what the order-dependent PGS sweep requires.  A lane
+  // that has run out of groups writes an inert row (J = W = 0, f = 0).
+  struct RowCount {
+    int nl, nf, np;  // compact limit rows, floor contacts (4 rows each), pair rows: wave-uniform
+    EPA_HD int rows() const { return nl + 4 * nf + np; }
+  };
+  EPA_HD static double Gather(Ws w, int slot_lane) {  // slot differs per lane
+    return w.base[(size_t)slot_lane * kLaneStride + w.lane];
   }
-  static EPA_HD bool LaneHas(const GMask& act, int g) {
+  EPA_HD static double& GatherRef(Ws w, int slot_lane) {
+    return w.base[(size_t)slot_lane * kLaneStride + w.lane];
+  }
+  // bits of the groups [lo, hi) inside mask word `wi`
+  static EPA_HD unsigned long long RangeBits(int wi, int lo, int hi) {
+    const int a = lo - 64 * wi, b = hi - 64 * wi;
+    if (b <= 0 || a >= 64) return 0ull;
+    const unsigned long long upto = b >= 64 ? ~0ull : ((1ull << b) - 1ull);
+    const unsigned long long from = a <= 0 ? ~0ull : (~0ull << a);
+    return upto & from;
+  }
+  static EPA_HD unsigned long long WordOf(const GMask& act, int wi) {
     unsigned long long word = 0ull;
-    static_for<0, kGW>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      word = (g >> 6) == k ? act.w[k] : word;
-    });
-    return (word >> (g & 63)) & 1ull;
+    static_for<0, kGW>([&](auto kc) { word = wi == decltype(kc)::value ? act.w[decltype(kc)::value] : word; });
+    return word;
   }
 
   static EPA_HD double Impedance(double x_abs) {  // solimp (d0, dmax, width, 0.5, 2)
@@ -910,127 +923,138 @@ struct Tree {
     return Sel(x >= 1.0, m.sol_dmax, m.sol_d0 + y * (m.sol_dmax - m.sol_d0));
   }
 
-  // visit the rows of the union mask in order: f(row, lane_has_row)
-  template <typename F>
-  static EPA_HD void ForRows(const GMask& act, const GMask& uni, F&& f) {
-    for (int g = NextGroup(uni, 0); g >= 0; g = NextGroup(uni, g + 1)) {
-      const bool on = LaneHas(act, g);
-      const bool is_limit = g < kNLimit, is_floor = !is_limit && g < kNLimit + kNFloor;
-      const int row0 = is_limit ? g : (is_floor ? kNLimit + 4 * (g - kNLimit) : g + 3 * kNFloor);
-      const int nsub = is_floor ? 4 : 1;
-#pragma nounroll
-      for (int k = 0; k < nsub; ++k) f(row0 + k, on);
-    }
-  }
-
-  // ---- mj_makeConstraint + mj_projectConstraint (phase B: one code instance, scalar loops over
-  // the groups / rows some lane needs).  Pass 1 builds the Jacobian rows from cdof held in
-  // registers, with aref, R and the warm-start force f = -D min(0, J a_warm - aref); pass 2 is
-  // one M^-1 solve per row: W_r = M^-1 J_r', A_rr + R_r.
-  static EPA_HD void MakeRows(Ws w0, const GMask& act, const GMask& uni, double* u, double* csum_out) {
+  // ---- mj_makeConstraint + mj_projectConstraint ------------------------------------------------
+  // Pass 1 builds the Jacobian rows from cdof held in registers, with aref, R and the warm-start
+  // force f = -D min(0, J a_warm - aref); pass 2 is one M^-1 solve per row: W_r = M^-1 J_r',
+  // A_rr + R_r.  Also returns u = J' f_warm and csum = sum_r f_r (R_r f_r / 2 - aref_r).
+  static EPA_HD RowCount MakeRows(Ws w0, const GMask& act, double* u, double* csum_out) {
     constexpr TreeModel m = MP::kM;
     static constexpr GroupTab gt = MakeGroupTab(MP::kM);
+    RowCount rc{0, 0, 0};
     {
       double cd[NV][6], qv[NV], wm[NV];
       static_for<0, NV>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         qv[i] = w0(kL.qvel + i);
         wm[i] = w0(kL.warm + i);
-        static_for<0, 6>([&](auto rc) { cd[i][decltype(rc)::value] = w0(kL.cdof + 6 * i + decltype(rc)::value); });
+        static_for<0, 6>([&](auto rc6) { cd[i][decltype(rc6)::value] = w0(kL.cdof + 6 * i + decltype(rc6)::value); });
       });
       const Vec3 com = {w0(kL.com), w0(kL.com + 1), w0(kL.com + 2)};
       EPA_TREE_FENCE();
-      double csum = 0.0;  // sum_r f_r (R_r f_r / 2 - aref_r) of the warm-start forces
-      static_for<0, NV>([&](auto ic) { u[decltype(ic)::value] = 0.0; });  // J' f_warm
-      for (int g = NextGroup(uni, 0); g >= 0; g = NextGroup(uni, g + 1)) {
-        const Ws w = w0.Fresh();
-        const bool on = LaneHas(act, g);
-        const bool is_limit = g < kNLimit, is_floor = !is_limit && g < kNLimit + kNFloor;
-        const int c = is_limit ? 0 : g - kNLimit;  // contact index (floor, then pairs)
-        // detection results of the group (harmless dummy slots for a limit / floor group)
-        const double lim_d = w(kL.limd + (is_limit ? g : 0)), lim_s = w(kL.lims + (is_limit ? g : 0));
-        const double cdist = w(kL.condist + c);
-        const Vec3 cpos = {w(kL.conpos + 3 * c), w(kL.conpos + 3 * c + 1), w(kL.conpos + 3 * c + 2)};
-        const Vec3 cn = {w(kL.connrm + 3 * c), w(kL.connrm + 3 * c + 1), w(kL.connrm + 3 * c + 2)};
-        EPA_TREE_FENCE();
-        const double pos = is_limit ? lim_d : cdist - m.margin;  // r = dist - includemargin
-        const Vec3 off = cpos - com;
-        // floor frame (mju_makeFrame of +z): n = z, t1 = y, t2 = -x
-        const Vec3 n = is_floor ? Vec3{0, 0, 1} : cn;
-        // impedance / regulariser of the group (mj_makeImpedance); pyramid rows share 2 mu^2 R
-        const double imp = Impedance(fabs(pos));
-        double R = fmax(kMinVal, (1.0 - imp) * gt.diag[g] / imp);
-        if (is_floor) R *= 2.0 * m.floor_mu * m.floor_mu;
-        const double kimp = m.sol_K * imp * pos;
-        const int nsub = is_floor ? 4 : 1;
-        const int row0 = is_limit ? g : (is_floor ? kNLimit + 4 * c : kNLimit + 4 * kNFloor + (c - kNFloor));
-        const unsigned m1 = is_limit ? 0u : gt.mask1[g], m2 = is_limit ? 0u : gt.mask2[g];
-        const int ld = is_limit ? gt.dof[g] : -1;
+      double csum = 0.0;
+      static_for<0, NV>([&](auto ic) { u[decltype(ic)::value] = 0.0; });
+      int row = 0;  // next compact row slot (wave-uniform)
+      // phases: 0 limits, 1 floor contacts, 2 geom pairs
 #pragma nounroll
-        for (int k = 0; k < nsub; ++k) {
-          // row direction: n, or the pyramid edge n +- mu t
-          Vec3 dir = n;
-          if (is_floor) {
-            dir = k == 0 ? Vec3{0, m.floor_mu, 1} : (k == 1 ? Vec3{0, -m.floor_mu, 1}
-                         : (k == 2 ? Vec3{-m.floor_mu, 0, 1} : Vec3{m.floor_mu, 0, 1}));
-          }
-          const Vec3 mdir = Cross(off, dir);
-          const int r = row0 + k;
-          double vel = 0.0, jw = 0.0, J[NV];
-          static_for<0, NV>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const int coef = (int)((m2 >> i) & 1u) - (int)((m1 >> i) & 1u);
-            J[i] = i == ld ? lim_s : 0.0;
-            if (coef != 0) {  // scalar: the masks are per group
-              J[i] = (double)coef * (dir.x * cd[i][3] + dir.y * cd[i][4] + dir.z * cd[i][5] +
-                                     mdir.x * cd[i][0] + mdir.y * cd[i][1] + mdir.z * cd[i][2]);
+      for (int phase = 0; phase < 3; ++phase) {
+        const int glo = phase == 0 ? 0 : (phase == 1 ? kNLimit : kNLimit + kNFloor);
+        const int ghi = phase == 0 ? kNLimit : (phase == 1 ? kNLimit + kNFloor : kNGroup);
+        const int nsub = phase == 1 ? 4 : 1;
+        int count = 0;
+#pragma nounroll
+        for (int wi = 0; wi < kGW; ++wi) {
+          const unsigned long long bits = RangeBits(wi, glo, ghi);
+          if (bits == 0ull) continue;
+          unsigned long long rem = WordOf(act, wi) & bits;
+          while (WaveAny(rem != 0ull)) {
+            const Ws w = w0.Fresh();
+            const bool on = rem != 0ull;
+            const int g = on ? 64 * wi + Ctz64(rem) : glo;  // this lane's group (glo: inert dummy)
+            rem &= rem - 1ull;
+            const int c = phase == 0 ? 0 : g - kNLimit;  // contact index (floor, then pairs)
+            double pos, lim_s = 0.0;
+            Vec3 cpos = {0, 0, 0}, n = {0, 0, 1};
+            if (phase == 0) {
+              pos = Gather(w, kL.limd + g);
+              lim_s = Gather(w, kL.lims + g);
+            } else {
+              pos = Gather(w, kL.condist + c) - m.margin;  // r = dist - includemargin
+              cpos = {Gather(w, kL.conpos + 3 * c), Gather(w, kL.conpos + 3 * c + 1),
+                      Gather(w, kL.conpos + 3 * c + 2)};
+              if (phase == 2) {
+                n = {Gather(w, kL.connrm + 3 * c), Gather(w, kL.connrm + 3 * c + 1),
+                     Gather(w, kL.connrm + 3 * c + 2)};
+              }
             }
-            vel += J[i] * qv[i];
-            jw += J[i] * wm[i];
-            w(kL.rowJ + r * NV + i) = J[i];
-          });
-          const double aref = -m.sol_B * vel - kimp;
-          const double jar = jw - aref;
-          const double f = (on && jar < 0.0) ? -jar / R : 0.0;
-          w(kL.rowR + r) = R;
-          w(kL.rowAref + r) = aref;
-          w(kL.rowF + r) = f;
-          csum += f * (0.5 * R * f - aref);
-          static_for<0, NV>([&](auto ic) { u[decltype(ic)::value] += f * J[decltype(ic)::value]; });
+            const unsigned m1 = phase == 0 ? 0u : gt.mask1[g], m2 = phase == 0 ? 0u : gt.mask2[g];
+            const int ld = phase == 0 ? gt.dof[g] : -1;
+            const double diag = gt.diag[g];
+            EPA_TREE_FENCE();
+            const Vec3 off = cpos - com;
+            // impedance / regulariser of the group (mj_makeImpedance); pyramid rows share 2 mu^2 R
+            const double imp = Impedance(fabs(pos));
+            double R = fmax(kMinVal, (1.0 - imp) * diag / imp);
+            if (phase == 1) R *= 2.0 * m.floor_mu * m.floor_mu;
+            const double kimp = m.sol_K * imp * pos;
+            if (phase != 0) {  // compact contact record for mj_rnePostConstraint
+              const int t = phase == 1 ? count : kNFloor + count;
+              w(kL.ccpos + 3 * t) = cpos.x;
+              w(kL.ccpos + 3 * t + 1) = cpos.y;
+              w(kL.ccpos + 3 * t + 2) = cpos.z;
+              w(kL.ccnrm + 3 * t) = n.x;
+              w(kL.ccnrm + 3 * t + 1) = n.y;
+              w(kL.ccnrm + 3 * t + 2) = n.z;
+              w(kL.ccbody + 2 * t) = (double)gt.b1[g];
+              w(kL.ccbody + 2 * t + 1) = (double)gt.b2[g];
+            }
+#pragma nounroll
+            for (int k = 0; k < nsub; ++k) {
+              // row direction: n, or the pyramid edge n +- mu t (floor frame: n = z, t1 = y, t2 = -x)
+              Vec3 dir = n;
+              if (phase == 1) {
+                dir = k == 0 ? Vec3{0, m.floor_mu, 1} : (k == 1 ? Vec3{0, -m.floor_mu, 1}
+                             : (k == 2 ? Vec3{-m.floor_mu, 0, 1} : Vec3{m.floor_mu, 0, 1}));
+              }
+              const Vec3 mdir = Cross(off, dir);
+              const int r = row + k;
+              double vel = 0.0, jw = 0.0, J[NV];
+              static_for<0, NV>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const double coef = (double)((int)((m2 >> i) & 1u) - (int)((m1 >> i) & 1u));
+                const double jc = coef * (dir.x * cd[i][3] + dir.y * cd[i][4] + dir.z * cd[i][5] +
+                                          mdir.x * cd[i][0] + mdir.y * cd[i][1] + mdir.z * cd[i][2]);
+                J[i] = Sel(on, phase == 0 ? Sel(i == ld, lim_s, 0.0) : jc, 0.0);
+                vel += J[i] * qv[i];
+                jw += J[i] * wm[i];
+                w(kL.rowJ + r * NV + i) = J[i];
+              });
+              const double aref = -m.sol_B * vel - kimp;
+              const double jar = jw - aref;
+              const double f = (on && jar < 0.0) ? -jar / R : 0.0;
+              w(kL.rowR + r) = Sel(on, R, 0.0);
+              w(kL.rowAref + r) = Sel(on, aref, 0.0);
+              w(kL.rowF + r) = f;
+              csum += f * (0.5 * R * f - aref);
+              static_for<0, NV>([&](auto ic) { u[decltype(ic)::value] += f * J[decltype(ic)::value]; });
+            }
+            row += nsub;
+            ++count;
+          }
         }
+        if (phase == 0) rc.nl = count;
+        if (phase == 1) rc.nf = count;
+        if (phase == 2) rc.np = count;
       }
       *csum_out = csum;
     }
     EPA_TREE_FENCE();
-    ForRows(act, uni, [&](int r, bool on) {
-      (void)on;
+    const int nrow = rc.rows();
+#pragma nounroll
+    for (int r = 0; r < nrow; ++r) {
       const Ws w = w0.Fresh();
       double x[NV];
       static_for<0, NV>([&](auto ic) { x[decltype(ic)::value] = w(kL.rowJ + r * NV + decltype(ic)::value); });
       const double R = w(kL.rowR + r);
       const double quad = SolveM(w, x);
       static_for<0, NV>([&](auto ic) { w(kL.rowW + r * NV + decltype(ic)::value) = x[decltype(ic)::value]; });
-      w(kL.rowArr + r) = R + quad;
-      w(kL.rowArrInv + r) = 1.0 / (R + quad);
-    });
+      const double arr = R + quad;  // 0 for an inert row
+      w(kL.rowArr + r) = arr;
+      w(kL.rowArrInv + r) = arr > 0.0 ? 1.0 / arr : 0.0;
+    }
+    return rc;
   }
 
   // ---- mj_fwdConstraint with mj_solPGS ----------------------------------------------------------
-  // (g, k) -> next row of the union mask; false at the end
-  static EPA_HD bool NextRow(const GMask& uni, int& g, int& k) {
-    const bool is_floor = g >= kNLimit && g < kNLimit + kNFloor;
-    if (is_floor && k < 3) {
-      ++k;
-      return true;
-    }
-    g = NextGroup(uni, g + 1);
-    k = 0;
-    return g >= 0;
-  }
-  static EPA_HD int RowOf(int g, int k) {
-    const bool is_limit = g < kNLimit, is_floor = !is_limit && g < kNLimit + kNFloor;
-    return (is_limit ? g : (is_floor ? kNLimit + 4 * (g - kNLimit) : g + 3 * kNFloor)) + k;
-  }
   struct RowRegs {
     double J[NV], W[NV], f, arrinv, arr, R, aref;
   };
@@ -1046,7 +1070,8 @@ struct Tree {
     t.R = w(kL.rowR + r);
     t.aref = w(kL.rowAref + r);
   }
-  // one PGS row update (mj_solPGS, dim 1): returns the cost decrease
+  // one PGS row update (mj_solPGS, dim 1): returns the cost decrease.  An inert row (all zero)
+  // yields delta = 0 by itself.
   static EPA_HD double VisitRow(Ws w, int r, const RowRegs& t, bool live, double* a) {
     double p0 = t.R * t.f - t.aref, p1 = 0.0, p2 = 0.0, p3 = 0.0;  // 4 chains: short latency
     static_for<0, NV>([&](auto ic) {
@@ -1068,14 +1093,11 @@ struct Tree {
   }
   // `u` = J' f_warm and `csum` = sum_r f_r (R_r f_r / 2 - aref_r) come from MakeRows.
   // `commit`: lanes that are only kept busy must not disturb their warm start.
-  static EPA_HD void SolvePgs(Ws w0, const GMask& act, const GMask& uni, bool commit, double* u,
-                              double csum) {
+  static EPA_HD void SolvePgs(Ws w0, int nrow, bool commit, double* u, double csum) {
     constexpr TreeModel m = MP::kM;
     double a[NV];
-    bool any = false;
-    static_for<0, kGW>([&](auto kc) { any = any || uni.w[decltype(kc)::value] != 0ull; });
     static_for<0, NV>([&](auto ic) { a[decltype(ic)::value] = w0(kL.accs + decltype(ic)::value); });
-    if (any) {
+    if (nrow > 0) {
       // dual cost of the warm-start forces: 1/2 f'(A+R)f + f'b with A f = J M^-1 J'f and
       // b = J qacc_smooth - aref; they are kept only if it is below the cost of f = 0
       double v[NV];
@@ -1093,10 +1115,10 @@ struct Tree {
         a[i] += Sel(cold, 0.0, v[i]);
       });
       if (WaveAny(cold)) {
-        ForRows(act, uni, [&](int r, bool on) {
-          (void)on;
+#pragma nounroll
+        for (int r = 0; r < nrow; ++r) {
           if (cold) w0(kL.rowF + r) = 0.0;
-        });
+        }
       }
       EPA_TREE_FENCE();
       const double scale = 1.0 / (m.meaninertia * (double)NV);
@@ -1107,35 +1129,21 @@ struct Tree {
         constexpr int kRing = 3;
         double improvement = 0.0;
         RowRegs buf[kRing];
-        int rg[kRing], rk[kRing];  // (group, sub-row) held by each buffer; group -1: none
-        int g = NextGroup(uni, 0), k = 0;
         static_for<0, kRing - 1>([&](auto bc) {
           constexpr int b = decltype(bc)::value;
-          rg[b] = g;
-          rk[b] = k;
-          if (g >= 0) {
-            LoadRow(w0.Fresh(), RowOf(g, k), buf[b]);
-            if (!NextRow(uni, g, k)) g = -1;
-          }
+          if (b < nrow) LoadRow(w0.Fresh(), b, buf[b]);
         });
-        for (bool more = true; more;) {
+#pragma nounroll
+        for (int r0 = 0; r0 < nrow; r0 += kRing) {
           static_for<0, kRing>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             constexpr int pre = (b + kRing - 1) % kRing;
-            if (more) {
+            const int r = r0 + b;
+            if (r < nrow) {
               const Ws w = w0.Fresh();
-              rg[pre] = g;
-              rk[pre] = k;
-              if (g >= 0) {  // prefetch: independent of the updates in between
-                LoadRow(w, RowOf(g, k), buf[pre]);
-                if (!NextRow(uni, g, k)) g = -1;
-              }
+              if (r + kRing - 1 < nrow) LoadRow(w, r + kRing - 1, buf[pre]);  // prefetch
               EPA_TREE_FENCE();
-              if (rg[b] >= 0) {
-                improvement += VisitRow(w, RowOf(rg[b], rk[b]), buf[b], LaneHas(act, rg[b]) && !done, a);
-              } else {
-                more = false;
-              }
+              improvement += VisitRow(w, r, buf[b], !done, a);
               EPA_TREE_FENCE();
             }
           });
@@ -1153,8 +1161,9 @@ struct Tree {
   }
 
   // mj_forward
-  static EPA_HD void Forward(Ws w, GMask& act, GMask& uni, bool commit) {
+  static EPA_HD RowCount Forward(Ws w, bool commit) {
     // Fresh(): every stage recomputes its slot addresses locally (see Ws::Fresh)
+    GMask act, uni;
     Kinematics(w.Fresh());
     EPA_TREE_FENCE();
     ComPos(w.Fresh());
@@ -1166,10 +1175,11 @@ struct Tree {
     Velocity(w.Fresh());
     EPA_TREE_FENCE();
     double u[NV], csum;
-    MakeRows(w.Fresh(), act, uni, u, &csum);
+    const RowCount rc = MakeRows(w.Fresh(), act, u, &csum);
     EPA_TREE_FENCE();
-    SolvePgs(w.Fresh(), act, uni, commit, u, csum);
+    SolvePgs(w.Fresh(), rc.rows(), commit, u, csum);
     EPA_TREE_FENCE();
+    return rc;
   }
 
   // mj_integratePos from the saved q0 with velocity slot `vel` scaled by `h`; result -> qpos
@@ -1254,38 +1264,36 @@ struct Tree {
 
   // mj_rnePostConstraint, cfrc_ext part: contact forces of the LAST forward evaluation as
   // spatial forces [torque; force] about the c-frame origin (mju_decodePyramid for the floor).
-  static EPA_HD void ContactWrench(Ws w, const GMask& act, const GMask& uni) {
+  // Walks the compact contact records MakeRows left behind; the bodies differ per lane.
+  static EPA_HD void ContactWrench(Ws w, RowCount rc) {
     constexpr TreeModel m = MP::kM;
-    static constexpr GroupTab gt = MakeGroupTab(MP::kM);
     static_for<0, 6 * NB>([&](auto kc) { w(kL.cext + decltype(kc)::value) = 0.0; });
     const Vec3 com = {w(kL.com), w(kL.com + 1), w(kL.com + 2)};
-    {
-      for (int g = NextGroup(uni, kNLimit); g >= 0; g = NextGroup(uni, g + 1)) {
-        const bool on = LaneHas(act, g);
-        const int c = g - kNLimit;
-        const bool is_floor = c < kNFloor;
-        Vec3 F;
-        if (is_floor) {
-          const int r = kNLimit + 4 * c;
-          const double f0 = w(kL.rowF + r), f1 = w(kL.rowF + r + 1), f2 = w(kL.rowF + r + 2),
-                       f3 = w(kL.rowF + r + 3);
-          // frame rows n = z, t1 = y, t2 = -x
-          F = {-(f2 - f3) * m.floor_mu, (f0 - f1) * m.floor_mu, f0 + f1 + f2 + f3};
-        } else {
-          const double f = w(kL.rowF + kNLimit + 4 * kNFloor + (c - kNFloor));
-          F = Vec3{w(kL.connrm + 3 * c), w(kL.connrm + 3 * c + 1), w(kL.connrm + 3 * c + 2)} * f;
-        }
-        F = F * Sel(on, 1.0, 0.0);
-        const Vec3 off = Vec3{w(kL.conpos + 3 * c), w(kL.conpos + 3 * c + 1), w(kL.conpos + 3 * c + 2)} - com;
-        const Vec3 tq = Cross(off, F);
-        const double w6[6] = {Sel(on, tq.x, 0.0), Sel(on, tq.y, 0.0), Sel(on, tq.z, 0.0), F.x, F.y, F.z};
-        const int s1 = kL.cext + 6 * gt.b1[g], s2 = kL.cext + 6 * gt.b2[g];
-        static_for<0, 6>([&](auto rc) {
-          constexpr int r = decltype(rc)::value;
-          w(s1 + r) -= w6[r];
-          w(s2 + r) += w6[r];
-        });
+    const int ncon = rc.nf + rc.np;
+#pragma nounroll
+    for (int i = 0; i < ncon; ++i) {
+      const bool is_floor = i < rc.nf;
+      const int t = is_floor ? i : kNFloor + (i - rc.nf);
+      Vec3 F;
+      if (is_floor) {
+        const int r = rc.nl + 4 * i;
+        const double f0 = w(kL.rowF + r), f1 = w(kL.rowF + r + 1), f2 = w(kL.rowF + r + 2),
+                     f3 = w(kL.rowF + r + 3);
+        // frame rows n = z, t1 = y, t2 = -x
+        F = {-(f2 - f3) * m.floor_mu, (f0 - f1) * m.floor_mu, f0 + f1 + f2 + f3};
+      } else {
+        const double f = w(kL.rowF + rc.nl + 4 * rc.nf + (i - rc.nf));
+        F = Vec3{w(kL.ccnrm + 3 * t), w(kL.ccnrm + 3 * t + 1), w(kL.ccnrm + 3 * t + 2)} * f;
       }
+      const Vec3 off = Vec3{w(kL.ccpos + 3 * t), w(kL.ccpos + 3 * t + 1), w(kL.ccpos + 3 * t + 2)} - com;
+      const Vec3 tq = Cross(off, F);  // zero force (inert rows) => zero wrench
+      const double w6[6] = {tq.x, tq.y, tq.z, F.x, F.y, F.z};
+      const int b1 = (int)w(kL.ccbody + 2 * t), b2 = (int)w(kL.ccbody + 2 * t + 1);
+      static_for<0, 6>([&](auto rc6) {
+        constexpr int r = decltype(rc6)::value;
+        GatherRef(w, kL.cext + 6 * b1 + r) -= w6[r];
+        GatherRef(w, kL.cext + 6 * b2 + r) += w6[r];
+      });
     }
   }
 };

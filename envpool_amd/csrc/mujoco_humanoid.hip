@@ -98,15 +98,15 @@ __global__ __launch_bounds__(kHumBlock) void HumanoidStepKernel(
   // the wave's trip count with its own state writes predicated (no divergent control flow).
   const int nfwd = reset ? 1 : 4 * task.frame_skip;
   const int nmax = mj::WaveAny(!reset) ? 4 * task.frame_skip : 1;
-  T::GMask gact, guni;
+  typename E::RowCount rows{0, 0, 0};
   for (int it = 0; it < nmax; ++it) {
     const bool live = it < nfwd;
-    E::Forward(w, gact, guni, live);
+    rows = E::Forward(w, live);
     E::RkAdvance(w.Fresh(), it & 3, live && !reset);
   }
   // mj_rnePostConstraint after the last mj_step (mujoco_env.h:145-147)
   const bool wrench = task.post_constraint != 0;
-  if (wrench) E::ContactWrench(w, gact, guni);
+  if (wrench) E::ContactWrench(w, rows);
   double mx = 0.0, my = 0.0;  // GetMassCenter, humanoid.h:212-223
   mj::static_for<1, E::NB>([&](auto bc) {
     constexpr int b = decltype(bc)::value;

@@ -23,15 +23,15 @@ static void Run(const double* q, const double* v, const double* warm, const doub
     w(E::kL.warm + i) = warm[i];
   }
   for (int i = 0; i < E::NU; ++i) w(E::kL.ctrl + i) = ctrl[i];
-  T::GMask act{}, uni{};
-  if (nsub == 0) E::Forward(w, act, uni, true);  // mj_forward only (reset)
+  typename E::RowCount rc{0, 0, 0};
+  if (nsub == 0) rc = E::Forward(w, true);  // mj_forward only (reset)
   for (int s = 0; s < nsub; ++s) {
     for (int stage = 0; stage < 4; ++stage) {
-      E::Forward(w, act, uni, true);
+      rc = E::Forward(w, true);
       E::RkAdvance(w, stage, true);
     }
   }
-  if (post_constraint) E::ContactWrench(w, act, uni);
+  if (post_constraint) E::ContactWrench(w, rc);
   int k = 0;
   for (int i = 0; i < E::NQ; ++i) out[k++] = w(E::kL.qpos + i);
   for (int i = 0; i < E::NV; ++i) out[k++] = w(E::kL.qvel + i);
@@ -48,9 +48,7 @@ static void Run(const double* q, const double* v, const double* warm, const doub
   }
   out[k++] = mx / MP::kM.total_mass;
   out[k++] = my / MP::kM.total_mass;
-  int nact = 0;
-  for (int g = 0; g < E::kNGroup; ++g) nact += (act.w[g >> 6] >> (g & 63)) & 1ull;
-  out[k++] = nact;
+  out[k++] = rc.nl + rc.nf + rc.np;  // active groups of the last forward pass
 }
 
 extern "C" {
