@@ -95,7 +95,9 @@ struct Layout {
   int M, dinv;                                       // M (lower, tree-sparse) -> L'DL in place
   int passive, bias, act, smooth, accs, qacc;
   int limd, lims, condist, conpos, connrm;           // detection results per group
-  int rowJ, rowW, rowR, rowAref, rowArr, rowArrInv, rowF;
+  // constraint rows as 16-byte pairs per lane: rowJW pair r * nv + i = (J_i, W_i); rowS pairs
+  // 3 r .. 3 r + 2 = (f, 1 / A_rr), (A_rr, R), (aref, -).  Slot numbers are in doubles.
+  int rowJW, rowS;
   int ccpos, ccnrm, ccbody;                          // compact contact records (floor, then pairs)
   int x0q, x0v, accq, accv;                          // RK4
   int cext;                                          // cfrc_ext [nbody][6]
@@ -119,14 +121,18 @@ constexpr Layout MakeLayout(const TreeModel& m) {
   L.accs = take(m.nv); L.qacc = take(m.nv);
   L.limd = take(m.nlimit); L.lims = take(m.nlimit);
   L.condist = take(ncon); L.conpos = take(3 * ncon); L.connrm = take(3 * ncon);
-  L.rowJ = take(nrow * m.nv); L.rowW = take(nrow * m.nv);
-  L.rowR = take(nrow); L.rowAref = take(nrow); L.rowArr = take(nrow); L.rowArrInv = take(nrow); L.rowF = take(nrow);
+  s += s & 1;  // 16-byte alignment of the pair regions
+  L.rowJW = take(2 * nrow * m.nv); L.rowS = take(2 * 3 * nrow);
   L.ccpos = take(3 * ncon); L.ccnrm = take(3 * ncon); L.ccbody = take(2 * ncon);
   L.x0q = take(m.nq); L.x0v = take(m.nv); L.accq = take(m.nv); L.accv = take(m.nv);
   L.cext = take(6 * m.nbody);
   L.total = s;
   return L;
 }
+
+struct alignas(16) D2 {
+  double x, y;
+};
 
 // `base` is the wave's block (wave-uniform: it lives in SGPRs and slot offsets are scalar
 // arithmetic), `lane` the column inside it.
@@ -140,6 +146,11 @@ struct Ws {
   EPA_HD double& operator()(int slot) const {
     const int off = (slot * kLaneStride + (int)lane) * 8;
     return *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off);
+  }
+  // 16-byte element `pair` of a pair region starting at (even) slot `region`
+  EPA_HD D2& Pair(int region, int pair) const {
+    const int off = (region * kLaneStride + (pair * kLaneStride + (int)lane) * 2) * 8;
+    return *reinterpret_cast<D2*>(reinterpret_cast<char*>(base) + off);
   }
   // A fresh copy whose lane offset is opaque to the optimiser: used at the top of loop bodies
   // so that the (hundreds of) slot addresses are recomputed where needed instead of being
@@ -1016,14 +1027,14 @@ struct Tree {
                 J[i] = Sel(on, phase == 0 ? Sel(i == ld, lim_s, 0.0) : jc, 0.0);
                 vel += J[i] * qv[i];
                 jw += J[i] * wm[i];
-                w(kL.rowJ + r * NV + i) = J[i];
+                w.Pair(kL.rowJW, r * NV + i).x = J[i];
               });
               const double aref = -m.sol_B * vel - kimp;
               const double jar = jw - aref;
               const double f = (on && jar < 0.0) ? -jar / R : 0.0;
-              w(kL.rowR + r) = Sel(on, R, 0.0);
-              w(kL.rowAref + r) = Sel(on, aref, 0.0);
-              w(kL.rowF + r) = f;
+              w.Pair(kL.rowS, 3 * r).x = f;
+              w.Pair(kL.rowS, 3 * r + 1).y = Sel(on, R, 0.0);
+              w.Pair(kL.rowS, 3 * r + 2).x = Sel(on, aref, 0.0);
               csum += f * (0.5 * R * f - aref);
               static_for<0, NV>([&](auto ic) { u[decltype(ic)::value] += f * J[decltype(ic)::value]; });
             }
@@ -1043,13 +1054,13 @@ struct Tree {
     for (int r = 0; r < nrow; ++r) {
       const Ws w = w0.Fresh();
       double x[NV];
-      static_for<0, NV>([&](auto ic) { x[decltype(ic)::value] = w(kL.rowJ + r * NV + decltype(ic)::value); });
-      const double R = w(kL.rowR + r);
+      static_for<0, NV>([&](auto ic) { x[decltype(ic)::value] = w.Pair(kL.rowJW, r * NV + decltype(ic)::value).x; });
+      const double R = w.Pair(kL.rowS, 3 * r + 1).y;
       const double quad = SolveM(w, x);
-      static_for<0, NV>([&](auto ic) { w(kL.rowW + r * NV + decltype(ic)::value) = x[decltype(ic)::value]; });
+      static_for<0, NV>([&](auto ic) { w.Pair(kL.rowJW, r * NV + decltype(ic)::value).y = x[decltype(ic)::value]; });
       const double arr = R + quad;  // 0 for an inert row
-      w(kL.rowArr + r) = arr;
-      w(kL.rowArrInv + r) = arr > 0.0 ? 1.0 / arr : 0.0;
+      w.Pair(kL.rowS, 3 * r + 1).x = arr;
+      w.Pair(kL.rowS, 3 * r).y = arr > 0.0 ? 1.0 / arr : 0.0;
     }
     return rc;
   }
@@ -1061,14 +1072,16 @@ struct Tree {
   static EPA_HD void LoadRow(Ws w, int r, RowRegs& t) {
     static_for<0, NV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      t.J[i] = w(kL.rowJ + r * NV + i);
-      t.W[i] = w(kL.rowW + r * NV + i);
+      const D2 jw = w.Pair(kL.rowJW, r * NV + i);
+      t.J[i] = jw.x;
+      t.W[i] = jw.y;
     });
-    t.f = w(kL.rowF + r);
-    t.arr = w(kL.rowArr + r);
-    t.arrinv = w(kL.rowArrInv + r);
-    t.R = w(kL.rowR + r);
-    t.aref = w(kL.rowAref + r);
+    const D2 s0 = w.Pair(kL.rowS, 3 * r), s1 = w.Pair(kL.rowS, 3 * r + 1);
+    t.f = s0.x;
+    t.arrinv = s0.y;
+    t.arr = s1.x;
+    t.R = s1.y;
+    t.aref = w.Pair(kL.rowS, 3 * r + 2).x;
   }
   // one PGS row update (mj_solPGS, dim 1): returns the cost decrease.  An inert row (all zero)
   // yields delta = 0 by itself.
@@ -1087,7 +1100,7 @@ struct Tree {
     const double change = 0.5 * delta * delta * t.arr + delta * res;
     const bool keep = live && !(change > 1e-10);
     delta = Sel(keep, delta, 0.0);
-    w(kL.rowF + r) = t.f + delta;
+    w.Pair(kL.rowS, 3 * r).x = t.f + delta;
     static_for<0, NV>([&](auto ic) { a[decltype(ic)::value] += delta * t.W[decltype(ic)::value]; });
     return Sel(keep, -change, 0.0);
   }
@@ -1117,7 +1130,7 @@ struct Tree {
       if (WaveAny(cold)) {
 #pragma nounroll
         for (int r = 0; r < nrow; ++r) {
-          if (cold) w0(kL.rowF + r) = 0.0;
+          if (cold) w0.Pair(kL.rowS, 3 * r).x = 0.0;
         }
       }
       EPA_TREE_FENCE();
@@ -1129,24 +1142,31 @@ struct Tree {
         constexpr int kRing = 3;
         double improvement = 0.0;
         RowRegs buf[kRing];
-        static_for<0, kRing - 1>([&](auto bc) {
-          constexpr int b = decltype(bc)::value;
-          if (b < nrow) LoadRow(w0.Fresh(), b, buf[b]);
-        });
-#pragma nounroll
-        for (int r0 = 0; r0 < nrow; r0 += kRing) {
-          static_for<0, kRing>([&](auto bc) {
+        // Lanes whose solve has converged skip the row traffic altogether (the one place with
+        // lane-divergent control flow: per-env sweep counts are heavily skewed -- median 2, wave
+        // maximum ~45 -- so late sweeps would otherwise stream 64 columns for a few live lanes).
+        if (!done) {
+          static_for<0, kRing - 1>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
-            constexpr int pre = (b + kRing - 1) % kRing;
-            const int r = r0 + b;
-            if (r < nrow) {
-              const Ws w = w0.Fresh();
-              if (r + kRing - 1 < nrow) LoadRow(w, r + kRing - 1, buf[pre]);  // prefetch
-              EPA_TREE_FENCE();
-              improvement += VisitRow(w, r, buf[b], !done, a);
-              EPA_TREE_FENCE();
-            }
+            LoadRow(w0.Fresh(), b < nrow ? b : nrow - 1, buf[b]);
           });
+#pragma nounroll
+          for (int r0 = 0; r0 < nrow; r0 += kRing) {
+            static_for<0, kRing>([&](auto bc) {
+              constexpr int b = decltype(bc)::value;
+              constexpr int pre = (b + kRing - 1) % kRing;
+              const int r = r0 + b;
+              if (r < nrow) {
+                const Ws w = w0.Fresh();
+                // prefetch (always issued, clamped: the number of loads in flight is then the
+                // same on every path and the wait below can leave them outstanding)
+                LoadRow(w, r + kRing - 1 < nrow ? r + kRing - 1 : nrow - 1, buf[pre]);
+                EPA_TREE_FENCE();
+                improvement += VisitRow(w, r, buf[b], true, a);
+                EPA_TREE_FENCE();
+              }
+            });
+          }
         }
         done = done || improvement * scale < 1e-8;
         if (!WaveAny(!done)) break;
@@ -1277,12 +1297,12 @@ struct Tree {
       Vec3 F;
       if (is_floor) {
         const int r = rc.nl + 4 * i;
-        const double f0 = w(kL.rowF + r), f1 = w(kL.rowF + r + 1), f2 = w(kL.rowF + r + 2),
-                     f3 = w(kL.rowF + r + 3);
+        const double f0 = w.Pair(kL.rowS, 3 * r).x, f1 = w.Pair(kL.rowS, 3 * r + 3).x,
+                     f2 = w.Pair(kL.rowS, 3 * r + 6).x, f3 = w.Pair(kL.rowS, 3 * r + 9).x;
         // frame rows n = z, t1 = y, t2 = -x
         F = {-(f2 - f3) * m.floor_mu, (f0 - f1) * m.floor_mu, f0 + f1 + f2 + f3};
       } else {
-        const double f = w(kL.rowF + rc.nl + 4 * rc.nf + (i - rc.nf));
+        const double f = w.Pair(kL.rowS, 3 * (rc.nl + 4 * rc.nf + (i - rc.nf))).x;
         F = Vec3{w(kL.ccnrm + 3 * t), w(kL.ccnrm + 3 * t + 1), w(kL.ccnrm + 3 * t + 2)} * f;
       }
       const Vec3 off = Vec3{w(kL.ccpos + 3 * t), w(kL.ccpos + 3 * t + 1), w(kL.ccpos + 3 * t + 2)} - com;
