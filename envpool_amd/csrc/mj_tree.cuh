@@ -1180,6 +1180,124 @@ struct Tree {
     });
   }
 
+  // ---- mj_solPGS, register-resident variant -----------------------------------------------------
+  // When the wave's compact row count fits kRegRows, the dual problem's matrix A + R (symmetric,
+  // kRegRows (kRegRows + 1) / 2 numbers per lane), b and f live in VGPRs and the sweeps touch no
+  // memory at all (MuJoCo's own formulation: res_r = b_r + sum_c AR_rc f_c).  Streaming the
+  // (J, W) rows instead re-reads ~50 numbers per row visit, ~45 sweeps deep for the slowest lane
+  // of a wave: 10x the HBM traffic of everything else in a forward pass.
+  static constexpr int kRegRows = 16;
+  static EPA_HD constexpr int TriAR(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
+  static EPA_HD void SolvePgsReg(Ws w0, int nrow, bool commit) {
+    constexpr TreeModel m = MP::kM;
+    constexpr int R = kRegRows;
+    double AR[R * (R + 1) / 2], b[R], f[R], ainv[R];
+    {
+      double accs[NV];
+      static_for<0, NV>([&](auto ic) { accs[decltype(ic)::value] = w0(kL.accs + decltype(ic)::value); });
+      static_for<0, R>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        static_for<c, R>([&](auto rc) { AR[TriAR(decltype(rc)::value, c)] = 0.0; });
+        b[c] = f[c] = ainv[c] = 0.0;
+        if (c < nrow) {  // scalar
+          const Ws w = w0.Fresh();
+          double Jc[NV], Wc[NV];
+          static_for<0, NV>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const D2 jw = w.Pair(kL.rowJW, c * NV + i);
+            Jc[i] = jw.x;
+            Wc[i] = jw.y;
+          });
+          const D2 s0 = w.Pair(kL.rowS, 3 * c), s1 = w.Pair(kL.rowS, 3 * c + 1);
+          const double aref = w.Pair(kL.rowS, 3 * c + 2).x;
+          EPA_TREE_FENCE();
+          double jb = 0.0;
+          static_for<0, NV>([&](auto ic) { jb += Jc[decltype(ic)::value] * accs[decltype(ic)::value]; });
+          b[c] = jb - aref;
+          f[c] = s0.x;
+          ainv[c] = s0.y;
+          AR[TriAR(c, c)] = s1.x;  // A_cc + R_c
+          static_for<c + 1, R>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            if (r < nrow) {  // scalar
+              double Jr[NV];
+              static_for<0, NV>([&](auto ic) { Jr[decltype(ic)::value] = w.Pair(kL.rowJW, r * NV + decltype(ic)::value).x; });
+              EPA_TREE_FENCE();
+              double p0 = 0.0, p1 = 0.0;
+              static_for<0, NV>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i % 2 == 0) p0 += Jr[i] * Wc[i];
+                else p1 += Jr[i] * Wc[i];
+              });
+              AR[TriAR(r, c)] = p0 + p1;
+            }
+          });
+        }
+      });
+    }
+    EPA_TREE_FENCE();
+    // dual cost of the warm-start forces 1/2 f'(A+R)f + f'b: kept only if below the cost of f = 0
+    {
+      double cost = 0.0;
+      static_for<0, R>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        double s = 0.0;
+        static_for<0, R>([&](auto cc) { s += AR[TriAR(r, decltype(cc)::value)] * f[decltype(cc)::value]; });
+        cost += f[r] * (0.5 * s + b[r]);
+      });
+      const bool cold = cost > 0.0;
+      static_for<0, R>([&](auto rc) { f[decltype(rc)::value] = Sel(cold, 0.0, f[decltype(rc)::value]); });
+    }
+    const double scale = 1.0 / (m.meaninertia * (double)NV);
+    bool done = false;
+    for (int iter = 0; iter < m.iterations; ++iter) {
+      double improvement = 0.0;
+      static_for<0, R>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        if (r < nrow) {  // scalar
+          double p0 = b[r], p1 = 0.0, p2 = 0.0, p3 = 0.0;
+          static_for<0, R>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const double t = AR[TriAR(r, c)] * f[c];
+            if constexpr (c % 4 == 0) p0 += t;
+            if constexpr (c % 4 == 1) p1 += t;
+            if constexpr (c % 4 == 2) p2 += t;
+            if constexpr (c % 4 == 3) p3 += t;
+          });
+          const double res = (p0 + p1) + (p2 + p3);
+          const double fn = fmax(0.0, f[r] - res * ainv[r]);
+          double delta = fn - f[r];
+          const double change = 0.5 * delta * delta * AR[TriAR(r, r)] + delta * res;
+          const bool keep = !done && !(change > 1e-10);
+          f[r] += Sel(keep, delta, 0.0);
+          improvement -= Sel(keep, change, 0.0);
+        }
+      });
+      done = done || improvement * scale < 1e-8;
+      if (!WaveAny(!done)) break;
+    }
+    EPA_TREE_FENCE();
+    // dual finish: qacc = qacc_smooth + M^-1 J' f = qacc_smooth + sum_r f_r W_r
+    double a[NV];
+    static_for<0, NV>([&](auto ic) { a[decltype(ic)::value] = w0(kL.accs + decltype(ic)::value); });
+    static_for<0, R>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      if (r < nrow) {  // scalar
+        const Ws w = w0.Fresh();
+        w.Pair(kL.rowS, 3 * r).x = f[r];  // efc_force, for mj_rnePostConstraint
+        double Wr[NV];
+        static_for<0, NV>([&](auto ic) { Wr[decltype(ic)::value] = w.Pair(kL.rowJW, r * NV + decltype(ic)::value).y; });
+        EPA_TREE_FENCE();
+        static_for<0, NV>([&](auto ic) { a[decltype(ic)::value] += f[r] * Wr[decltype(ic)::value]; });
+      }
+    });
+    static_for<0, NV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      w0(kL.qacc + i) = a[i];
+      if (commit) w0(kL.warm + i) = a[i];
+    });
+  }
+
   // mj_forward
   static EPA_HD RowCount Forward(Ws w, bool commit) {
     // Fresh(): every stage recomputes its slot addresses locally (see Ws::Fresh)
@@ -1197,7 +1315,11 @@ struct Tree {
     double u[NV], csum;
     const RowCount rc = MakeRows(w.Fresh(), act, u, &csum);
     EPA_TREE_FENCE();
-    SolvePgs(w.Fresh(), rc.rows(), commit, u, csum);
+    if (rc.rows() <= kRegRows) {
+      SolvePgsReg(w.Fresh(), rc.rows(), commit);
+    } else {
+      SolvePgs(w.Fresh(), rc.rows(), commit, u, csum);
+    }
     EPA_TREE_FENCE();
     return rc;
   }

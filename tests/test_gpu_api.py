@@ -89,13 +89,15 @@ def test_send_recv_async_api():
 
 
 @pytest.mark.parametrize("task,adim,precision", [("HalfCheetah-v4", 6, 32), ("Ant-v4", 8, 64),
-                                                 ("Ant-v4", 8, 32)])
+                                                 ("Ant-v4", 8, 32), ("Humanoid-v5", 17, None),
+                                                 ("HumanoidStandup-v4", 17, None)])
 def test_mujoco_run_to_run_determinism(task, adim, precision):
     """Same seed, same actions => bit-identical rollouts (the reference's
     mujoco_gym_deterministic_test.py:70-123), for every kernel variant."""
     n = 256
-    e0 = envpool.make_gym(task, num_envs=n, seed=5, precision=precision)
-    e1 = envpool.make_gym(task, num_envs=n, seed=5, precision=precision)
+    kw = {} if precision is None else {"precision": precision}  # Humanoid: fp64 only
+    e0 = envpool.make_gym(task, num_envs=n, seed=5, **kw)
+    e1 = envpool.make_gym(task, num_envs=n, seed=5, **kw)
     np.testing.assert_array_equal(e0.reset()[0], e1.reset()[0])
     rng = np.random.default_rng(1)
     for _ in range(40):
@@ -136,7 +138,9 @@ def test_env_seed_list_matches_offset_seeds():
     np.testing.assert_array_equal(a.reset()[0], b.reset()[0])
 
 
-@pytest.mark.parametrize("task,obs_dim,adim", [("HalfCheetah-v4", 17, 6), ("Ant-v4", 27, 8)])
+@pytest.mark.parametrize("task,obs_dim,adim", [("HalfCheetah-v4", 17, 6), ("Ant-v4", 27, 8),
+                                               ("Humanoid-v4", 376, 17),
+                                               ("HumanoidStandup-v5", 348, 17)])
 def test_mujoco_frame_stack(task, obs_dim, adim):
     """frame_stack semantics of envpool/mujoco/frame_stack.h:109-135, checked the
     way the reference does (mujoco_gym_envpool_test.cc:58-112): reset replicates

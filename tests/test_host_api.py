@@ -27,7 +27,9 @@ def test_list_all_envs_and_registry():
               "Hopper-v3", "Hopper-v4", "Hopper-v5", "Swimmer-v3", "Swimmer-v4", "Swimmer-v5",
               "Reacher-v2", "Reacher-v4", "Reacher-v5", "InvertedPendulum-v2",
               "InvertedPendulum-v4", "InvertedPendulum-v5", "InvertedDoublePendulum-v2",
-              "InvertedDoublePendulum-v4", "InvertedDoublePendulum-v5"]:
+              "InvertedDoublePendulum-v4", "InvertedDoublePendulum-v5",
+              "Humanoid-v3", "Humanoid-v4", "Humanoid-v5", "HumanoidStandup-v2",
+              "HumanoidStandup-v4", "HumanoidStandup-v5"]:
         assert t in ids, t
     with pytest.raises(AssertionError):
         envpool.make("NoSuchEnv-v0", "gym", num_envs=1)
@@ -73,6 +75,16 @@ def test_spec_config_defaults_and_key_order():
     d5 = envpool.make_spec("InvertedDoublePendulum-v5")
     assert d5.config.constraint_obs_dim == 1 and d5.observation_space.shape == (9,)
     assert envpool.make_spec("InvertedPendulum-v5").config.reward_if_not_terminated is True
+    # humanoid.h:50-60: 376 observations, v5 drops the world body rows and the root actuator forces
+    h4, h5 = envpool.make_spec("Humanoid-v4"), envpool.make_spec("Humanoid-v5")
+    assert h4.observation_space.shape == (376,) and h5.observation_space.shape == (348,)
+    assert (h4.config.post_constraint, h5.config.post_constraint) == (False, True)
+    assert envpool.make_spec("Humanoid-v3").config.use_contact_force is True
+    assert h4.action_space.shape == (17,) and float(h4.action_space.high[0]) == 0.4
+    assert envpool.make_spec("HumanoidStandup-v5").observation_space.shape == (348,)
+    assert envpool.make_spec("HumanoidStandup-v4")._state_keys[8:] == [
+        "obs", "info:reward_linup", "info:reward_quadctrl", "info:reward_alive",
+        "info:reward_impact"]
     assert envpool.make_spec("Swimmer-v4", frame_stack=3).observation_space.shape == (3, 8)
     with pytest.raises(ValueError):
         envpool.make_spec("Walker2d-v4", xml_file="walker2d_custom.xml")
@@ -148,6 +160,8 @@ FAMILY_PARAMS = {
     "Reacher-v4": {}, "Reacher-v5": {"obs_include_z_distance": 0},
     "InvertedPendulum-v4": {}, "InvertedDoublePendulum-v4": {},
     "InvertedDoublePendulum-v5": {"constraint_obs_dim": 1},
+    "Humanoid-v4": {}, "HumanoidStandup-v4": {},
+    "Humanoid-v5": {"exclude_worldbody_observations": 1, "exclude_root_actuator_forces": 1},
 }
 NATIVE = {"CartPole-v1": "CartPole", "Pendulum-v1": "Pendulum", "MountainCar-v0": "MountainCar",
           "MountainCarContinuous-v0": "MountainCarContinuous", "Acrobot-v1": "Acrobot",
@@ -158,7 +172,9 @@ NATIVE = {"CartPole-v1": "CartPole", "Pendulum-v1": "Pendulum", "MountainCar-v0"
           "Hopper-v4": "Hopper", "Swimmer-v4": "Swimmer", "Reacher-v4": "Reacher",
           "Reacher-v5": "Reacher", "InvertedPendulum-v4": "InvertedPendulum",
           "InvertedDoublePendulum-v4": "InvertedDoublePendulum",
-          "InvertedDoublePendulum-v5": "InvertedDoublePendulum"}
+          "InvertedDoublePendulum-v5": "InvertedDoublePendulum",
+          "Humanoid-v4": "Humanoid", "Humanoid-v5": "Humanoid",
+          "HumanoidStandup-v4": "HumanoidStandup"}
 
 
 @pytest.mark.parametrize("task", sorted(FAMILY_PARAMS))

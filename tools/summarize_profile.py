@@ -26,6 +26,8 @@ def short(name):
                  ("AntStepKernel<double, true>", "AntStepKernel<double>[v5 cfrc_ext]")):
         if k in name:
             return v
+    if "HumanoidStepKernel" in name:
+        return "HumanoidStepKernel" + ("[Standup]" if "StandupMP" in name else "")
     for k in ("PendStepKernel", "ReacherStepKernel", "SwimmerStepKernel", "ClassicStepKernel",
               "ToyStepKernel", "AtariPostKernel"):
         if k in name:
