@@ -163,7 +163,8 @@ def main():
         # collection needs its own rocprofv3 runs and cannot happen inside the bench.
         kbase = ("AntStepKernel" if args.task == "Ant" else
                  "HumanoidStepKernel" if args.task.startswith("Humanoid") else "CheetahStepKernel")
-        kname = kbase + ("<double>" if args.precision == "fp64" else "<float>")
+        kname = kbase + ("<double>" if args.precision == "fp64" or args.task.startswith("Humanoid")
+                         else "<float>")
         if args.task in ("Walker2d", "Hopper"):
             kname += f"[{args.task}]"
         pmc = {}
@@ -213,8 +214,11 @@ def main():
                 "kernel_ms": kernel_ms,
                 "launches": launches,
                 "algorithmic_bytes_per_env_step": alg_bytes,
-                "note": "physics kernel is VALU/latency-bound, not HBM-bound "
-                        "(~65 flop/B counted); HBM fraction reported as BASELINE.md asks",
+                "note": ("per-env workspace streamed through HBM (a 23-dof tree does not fit a lane's "
+                         "registers): `traffic` is far above the algorithmic bytes by design, see "
+                         "DESIGN.md K3c") if args.task.startswith("Humanoid") else
+                        ("physics kernel is VALU/latency-bound, not HBM-bound "
+                         "(~65 flop/B counted); HBM fraction reported as BASELINE.md asks"),
             },
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
