@@ -1192,44 +1192,58 @@ struct Tree {
     constexpr TreeModel m = MP::kM;
     constexpr int R = kRegRows;
     double AR[R * (R + 1) / 2], b[R], f[R], ainv[R];
+    static_for<0, R>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      static_for<c, R>([&](auto rc) { AR[TriAR(decltype(rc)::value, c)] = 0.0; });
+      b[c] = f[c] = ainv[c] = 0.0;
+    });
     {
+      // A_rc = J_r . W_c, four columns per pass over the J rows (W_c in registers), so a J row is
+      // read nrow / 4 times instead of once per column
+      constexpr int kCols = 4;
       double accs[NV];
       static_for<0, NV>([&](auto ic) { accs[decltype(ic)::value] = w0(kL.accs + decltype(ic)::value); });
-      static_for<0, R>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        static_for<c, R>([&](auto rc) { AR[TriAR(decltype(rc)::value, c)] = 0.0; });
-        b[c] = f[c] = ainv[c] = 0.0;
-        if (c < nrow) {  // scalar
-          const Ws w = w0.Fresh();
-          double Jc[NV], Wc[NV];
-          static_for<0, NV>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const D2 jw = w.Pair(kL.rowJW, c * NV + i);
-            Jc[i] = jw.x;
-            Wc[i] = jw.y;
-          });
-          const D2 s0 = w.Pair(kL.rowS, 3 * c), s1 = w.Pair(kL.rowS, 3 * c + 1);
-          const double aref = w.Pair(kL.rowS, 3 * c + 2).x;
-          EPA_TREE_FENCE();
-          double jb = 0.0;
-          static_for<0, NV>([&](auto ic) { jb += Jc[decltype(ic)::value] * accs[decltype(ic)::value]; });
-          b[c] = jb - aref;
-          f[c] = s0.x;
-          ainv[c] = s0.y;
-          AR[TriAR(c, c)] = s1.x;  // A_cc + R_c
-          static_for<c + 1, R>([&](auto rc) {
+      static_for<0, R / kCols>([&](auto blk) {
+        constexpr int c0 = decltype(blk)::value * kCols;
+        if (c0 < nrow) {  // scalar
+          double Wc[kCols][NV];
+          {
+            const Ws w = w0.Fresh();
+            static_for<0, kCols>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              const int c = c0 + k < nrow ? c0 + k : nrow - 1;  // clamped: finite dummies past the end
+              static_for<0, NV>([&](auto ic) { Wc[k][decltype(ic)::value] = w.Pair(kL.rowJW, c * NV + decltype(ic)::value).y; });
+            });
+          }
+          static_for<c0, R>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
             if (r < nrow) {  // scalar
+              const Ws w = w0.Fresh();
               double Jr[NV];
               static_for<0, NV>([&](auto ic) { Jr[decltype(ic)::value] = w.Pair(kL.rowJW, r * NV + decltype(ic)::value).x; });
+              const D2 s0 = w.Pair(kL.rowS, 3 * r), s1 = w.Pair(kL.rowS, 3 * r + 1);
+              const double aref = w.Pair(kL.rowS, 3 * r + 2).x;
               EPA_TREE_FENCE();
-              double p0 = 0.0, p1 = 0.0;
-              static_for<0, NV>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                if constexpr (i % 2 == 0) p0 += Jr[i] * Wc[i];
-                else p1 += Jr[i] * Wc[i];
+              static_for<0, kCols>([&](auto kc) {
+                constexpr int c = c0 + decltype(kc)::value;
+                if constexpr (c <= r) {
+                  double p0 = 0.0, p1 = 0.0;
+                  static_for<0, NV>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr (i % 2 == 0) p0 += Jr[i] * Wc[c - c0][i];
+                    else p1 += Jr[i] * Wc[c - c0][i];
+                  });
+                  // the diagonal carries R_r: take the stored A_rr + R_r
+                  AR[TriAR(r, c)] = c == r ? s1.x : p0 + p1;
+                }
               });
-              AR[TriAR(r, c)] = p0 + p1;
+              if constexpr (r < c0 + kCols) {  // this row's own scalars, once
+                double jb = 0.0;
+                static_for<0, NV>([&](auto ic) { jb += Jr[decltype(ic)::value] * accs[decltype(ic)::value]; });
+                b[r] = jb - aref;
+                f[r] = s0.x;
+                ainv[r] = s0.y;
+              }
             }
           });
         }

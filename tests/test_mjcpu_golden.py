@@ -14,7 +14,8 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 @pytest.mark.parametrize("name,task", [
     ("half_cheetah", "HalfCheetah"), ("ant", "Ant"), ("walker2d", "Walker2d"),
     ("walker2d_v5", "Walker2dV5"), ("inverted_pendulum", "InvertedPendulum"),
-    ("inverted_double_pendulum", "InvertedDoublePendulum"), ("reacher", "Reacher"), ("swimmer", "Swimmer"), ("hopper", "Hopper")])
+    ("inverted_double_pendulum", "InvertedDoublePendulum"), ("reacher", "Reacher"), ("swimmer", "Swimmer"), ("hopper", "Hopper"),
+    ("humanoid", "Humanoid"), ("humanoidstandup", "HumanoidStandup")])
 def test_oracle_matches_real_mujoco(name, task):
     path = os.path.join(GOLD, f"mujoco_{name}.npz")
     if not os.path.exists(path):

@@ -8,7 +8,8 @@ that has `mujoco==3.6.0` and a checkout of the reference:
     python tools/pin_with_mujoco.py /path/to/envpool/third_party/mujoco_gym_xml_patches
 
 It writes tests/golden/mujoco_{half_cheetah,ant,walker2d,walker2d_v5,
-inverted_pendulum,inverted_double_pendulum}.npz; tests/test_mjcpu_golden.py
+inverted_pendulum,inverted_double_pendulum,reacher,swimmer,hopper,humanoid,
+humanoidstandup}.npz; tests/test_mjcpu_golden.py
 activates automatically when those files exist and checks oracle/mjcpu (and,
 with a GPU, the HIP kernels) against them with the reference's own tolerance
 (obs atol 1e-6, rtol 1e-7: envpool/mujoco/gym/mujoco_gym_align_test.py:38-80).
@@ -36,7 +37,9 @@ def main(xml_dir: str) -> None:
             ("inverted_double_pendulum", "inverted_double_pendulum_envpool.xml", 5, 1.0, 25),
             ("reacher", "reacher_envpool.xml", 2, 1.0, 50),
             ("swimmer", "swimmer_envpool.xml", 4, 1.0, 200),
-            ("hopper", "hopper_envpool.xml", 4, 1.0, 25)):
+            ("hopper", "hopper_envpool.xml", 4, 1.0, 25),
+            ("humanoid", "humanoid_envpool.xml", 5, 0.4, 25),
+            ("humanoidstandup", "humanoidstandup_envpool.xml", 5, 0.4, 100)):
         m = mujoco.MjModel.from_xml_path(os.path.join(xml_dir, xml))
         d = mujoco.MjData(m)
         rec = {k: [] for k in ("qpos0", "qvel0", "warm0", "ctrl", "qpos1", "qvel1", "xpos1",
