@@ -17,20 +17,24 @@
 //    the lane offset.  The block belongs to the launch's wave, not to an env: the few
 //    values that persist between steps (qpos, qvel, warm start, lagged mass centre) are
 //    copied in from / out to a per-env SoA by the step kernel;
-//  * the tree is a compile-time constant (gen_mj_consts.cpp): kinematics, CRB, the sparse
-//    L'DL factorisation, the M^-1 solves and RNE are fully unrolled over the tree with
-//    static slot numbers, intermediate vectors in VGPRs;
-//  * constraints use STATIC row slots: one per limited joint, four per potential floor
-//    contact (pyramid edges), one per geom pair that may collide.  Static order is MuJoCo's
-//    row order restricted to the active rows (limits by joint, contacts by body pair), so
-//    the order-dependent PGS sweep needs no compaction.  Each lane keeps a bitmask of its
-//    active groups; the wave-uniform union mask drives scalar loops (ctz) over rows that at
-//    least one lane needs, and lanes that do not have the row apply a zero update;
-//  * PGS works on  a = qacc_smooth + M^-1 J' f  instead of the nefc x nefc matrix A+R:
-//    res_r = J_r . a - aref_r + R_r f_r  and  a += delta W_r  with  W_r = M^-1 J_r'
-//    (2 x 23 loads per row visit instead of nefc, no O(nefc^2) memory);
-//  * no lane-divergent control flow anywhere: per-lane differences are selects, finished
-//    lanes run with frozen iterates (WaveAny, see mj_cheetah.cuh).
+//  * the tree is a compile-time constant (gen_mj_consts.cpp) and every stage has the shape
+//    [issue all loads] -> fence -> [arithmetic in VGPRs] -> [stores]: kinematics and the
+//    velocity pass are depth-first template recursions with the parent's frame in
+//    registers, M is built, loaded once and factored (tree-sparse L'DL) in registers, an
+//    M^-1 solve loads the factor in one batch.  A wave runs alone on its SIMD, so a
+//    dependent HBM round trip has nothing to overlap it: batching is what counts;
+//  * constraint candidates are STATIC lists (limited joints, floor spheres, geom pairs);
+//    detection leaves a per-lane bitmask of active groups, and rows are built into COMPACT
+//    slots, every lane taking ITS t-th active group in iteration t -- the wave pays
+//    max-over-lanes rows, each lane keeps MuJoCo's row order (which the unconverged,
+//    order-dependent PGS sweep needs);
+//  * PGS: with <= 16 compact rows A + R, b and f live in VGPRs and the sweeps touch no
+//    memory; otherwise the sweep works on  a = qacc_smooth + M^-1 J' f  (res_r = J_r . a -
+//    aref_r + R_r f_r,  a += delta W_r,  W_r = M^-1 J_r') and streams (J_r, W_r) pairs
+//    through a register ring prefetched two visits ahead;
+//  * no lane-divergent control flow except one branch: per-lane differences are selects,
+//    finished lanes run with frozen iterates (WaveAny, see mj_cheetah.cuh); only in the
+//    streaming sweep do converged lanes skip their row traffic.
 // The same source compiles for the host (EPA_HD, lane stride 1) so tests run it on the CPU
 // against oracle/mjcpu.
 #ifndef ENVPOOL_AMD_CSRC_MJ_TREE_CUH_
@@ -90,10 +94,10 @@ struct TreeModel {
 struct Layout {
   int qpos, qvel, warm, lag, npersist;               // slots [0, npersist) persist between steps
   int ctrl;
-  int xpos, xquat, xmat, xipos, anchor, axis, gpos, gaxis, com;
-  int cinert, cdof, cvel, crb, cacc, cfrc;
+  int xpos, xmat, xipos, anchor, axis, gpos, gaxis, com;
+  int cinert, cdof, cvel, crb, cacc;
   int M, dinv;                                       // M (lower, tree-sparse) -> L'DL in place
-  int passive, bias, act, smooth, accs, qacc;
+  int act, accs, qacc;                               // qfrc_actuator, qacc_smooth, qacc
   int limd, lims, condist, conpos, connrm;           // detection results per group
   // constraint rows as 16-byte pairs per lane: rowJW pair r * nv + i = (J_i, W_i); rowS pairs
   // 3 r .. 3 r + 2 = (f, 1 / A_rr), (A_rr, R), (aref, -).  Slot numbers are in doubles.
@@ -111,14 +115,13 @@ constexpr Layout MakeLayout(const TreeModel& m) {
   L.qpos = take(m.nq); L.qvel = take(m.nv); L.warm = take(m.nv); L.lag = take(2);
   L.npersist = s;
   L.ctrl = take(m.nu);
-  L.xpos = take(3 * m.nbody); L.xquat = take(4 * m.nbody); L.xmat = take(9 * m.nbody);
+  L.xpos = take(3 * m.nbody); L.xmat = take(9 * m.nbody);
   L.xipos = take(3 * m.nbody); L.anchor = take(3 * m.njnt); L.axis = take(3 * m.njnt);
   L.gpos = take(3 * m.ngeom); L.gaxis = take(3 * m.ngeom); L.com = take(3);
   L.cinert = take(10 * m.nbody); L.cdof = take(6 * m.nv); L.cvel = take(6 * m.nbody);
-  L.crb = take(10 * m.nbody); L.cacc = take(6 * m.nbody); L.cfrc = take(6 * m.nbody);
+  L.crb = take(10 * m.nbody); L.cacc = take(6 * m.nbody);
   L.M = take(m.nv * m.nv); L.dinv = take(m.nv);
-  L.passive = take(m.nv); L.bias = take(m.nv); L.act = take(m.nv); L.smooth = take(m.nv);
-  L.accs = take(m.nv); L.qacc = take(m.nv);
+  L.act = take(m.nv); L.accs = take(m.nv); L.qacc = take(m.nv);
   L.limd = take(m.nlimit); L.lims = take(m.nlimit);
   L.condist = take(ncon); L.conpos = take(3 * ncon); L.connrm = take(3 * ncon);
   s += s & 1;  // 16-byte alignment of the pair regions
