@@ -36,6 +36,9 @@ def run(task, n, steps, adim=None):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # e.g. Humanoid-v4 65536 20
+        print(json.dumps(run(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]))))
+        sys.exit(0)
     for task, n, steps in (("HalfCheetah-v4", 65536, 100), ("HalfCheetah-v4", 8192, 300),
                            ("Walker2d-v4", 65536, 100),
                            ("Ant-v4", 32768, 20), ("CartPole-v1", 65536, 200),
