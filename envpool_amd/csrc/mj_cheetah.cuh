@@ -92,13 +92,65 @@ EPA_HD T Rsqrt(T x) {
   return T(1) / std::sqrt(x);
 #endif
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// fp64 sin and cos together in ~50 VALU instructions (the device library's sincos is ~200 and
+// carries a large-argument branch; seven of them per forward pass are 10 % of the planar
+// kernels' code, which sits right at the 64 KB instruction cache): Cody-Waite reduction by
+// pi/2 in three pieces -- 1 ulp up to |x| ~ 1e6 rad, degrading smoothly beyond; joint angles
+// and the torso pitch stay orders of magnitude below that, NaN / inf give NaN like libm --
+// and the classic fdlibm kernel polynomials on [-pi/4, pi/4].
+__device__ __forceinline__ void FastSinCos(double x, double* s, double* c) {
+  const double n = rint(x * 6.36619772367581382433e-01);  // x * 2/pi
+  double r = fma(-n, 1.57079632673412561417e+00, x);    // pi/2, first 33 bits
+  r = fma(-n, 6.07710050630396597660e-11, r);           // next 33 bits
+  r = fma(-n, 2.02226624879595063154e-21, r);           // tail
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10,
+                                                   -2.50507602534068634195e-08),
+                                             2.75573137070700676789e-06),
+                                       -1.98412698298579493134e-04),
+                                 8.33333333332248946124e-03),
+                        -1.66666666666666324348e-01);
+  const double sr = fma(z * r, ps, r);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11,
+                                                   2.08757232129817482790e-09),
+                                             -2.75573143513906633035e-07),
+                                       2.48015872894767294178e-05),
+                                 -1.38888888888741095749e-03),
+                        4.16666666666666019037e-02);
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * z * pc);
+  const int q = (int)n & 3;
+  const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
+#endif
+// EPA_SINCOS_MODE (per translation unit, chosen by measurement -- these one-wave-per-SIMD
+// kernels react to code size and to how far the scheduler may hoist straight-line code):
+//   0 device library, 1 FastSinCos (default), 2 FastSinCos behind a wave-uniform range check
+//   with the library as the out-of-range path (the branch also stops hoisting across it).
+#ifndef EPA_SINCOS_MODE
+#define EPA_SINCOS_MODE 1
+#endif
+EPA_HD bool WaveAny(bool x);
 template <typename T>
 EPA_HD void SinCos(T x, T* s, T* c) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (std::is_same<T, float>::value) {
     sincosf(x, s, c);
   } else {
+#if EPA_SINCOS_MODE == 0
     sincos(x, s, c);
+#elif EPA_SINCOS_MODE == 2
+    if (WaveAny(!(fabs(x) < 1.0e5))) {  // also catches NaN / inf
+      sincos(x, s, c);
+    } else {
+      FastSinCos(x, s, c);
+    }
+#else
+    FastSinCos(x, s, c);
+#endif
   }
 #else
   *s = std::sin(x);

@@ -16,6 +16,7 @@
 // the LAST forward evaluation (RK4 stage 4 of the last sub-step), like the mjData fields the
 // reference reads; the mass centre "before" a step is therefore the lagged one of the
 // previous step (persistent slot `lag`).
+#define EPA_SINCOS_MODE 0  // see mj_cheetah.cuh; Humanoid: mode 1 lets the scheduler interleave 17 joints (2.3 k VGPR spills, 1.94 -> 1.77 M env-steps/s)
 #include "device_common.cuh"
 #include "engine.h"
 #include "mj_tree.cuh"

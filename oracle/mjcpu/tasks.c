@@ -469,6 +469,8 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
     mujoco_reset(p, e);
     /* WriteState(0.0, 0, ...) on reset: ant.h:160-164 passes zeros */
     if (p->is_ant) info[6] = sqrt(0.0);
+    /* humanoid_standup.h:226: WriteState stores the member healthy_reward_ on resets too */
+    if (p->task == TASK_STANDUP) info[2] = p->healthy_reward;
     e->lag_set = 0;
   } else {
     ++e->current_step;

@@ -638,6 +638,9 @@ def test_humanoid_matches_oracle(name, task, params, over, nobs):
     np.testing.assert_array_equal(a["obs"][:, 0], b["obs"][:, 0])
     np.testing.assert_array_equal(a["obs"][:, 5:45], b["obs"][:, 5:45])
     np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-11, atol=1e-12)
+    for k in a:  # reset rows: zeros, except HumanoidStandup's constant reward_alive
+        if k != "obs":
+            np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=k)
     rng = np.random.default_rng(3)
     rel_all, seen_term, contact_obs = [], False, 0.0
     for t in range(steps):
