@@ -203,7 +203,8 @@ def test_recv_arrays_own_their_memory_zero_copy():
     assert a[0].__array_interface__["data"][0] in addrs
 
 
-@pytest.mark.parametrize("task,adim", [("HalfCheetah", 6), ("Walker2d", 6), ("Ant", 8)])
+@pytest.mark.parametrize("task,adim", [("HalfCheetah", 6), ("Walker2d", 6), ("Ant", 8),
+                                       ("Humanoid", 17), ("HumanoidStandup", 17)])
 def test_results_independent_of_batch_composition(task, adim):
     """An env's trajectory must not depend on which other envs share its batch / wave
     (the reference's envs are independent objects): the sync pool (all envs per step)
