@@ -237,7 +237,13 @@ def test_results_independent_of_batch_composition(task, adim):
         eid = out["info:env_id"].ravel()
         t = count[eid]
         ok = t <= T
-        np.testing.assert_array_equal(out["obs"][ok], ref[t[ok], eid[ok]])
+        if task.startswith("Humanoid"):
+            # the PGS formulation (register-resident A + R vs streamed rows) is chosen per WAVE
+            # from its row count, so an env's result may differ in the last bits with the
+            # company it keeps (observed 1e-13); everything else about it is identical
+            np.testing.assert_allclose(out["obs"][ok], ref[t[ok], eid[ok]], rtol=1e-9, atol=1e-10)
+        else:
+            np.testing.assert_array_equal(out["obs"][ok], ref[t[ok], eid[ok]])
         np.testing.assert_array_equal(out["elapsed_step"].ravel()[ok], ref_el[t[ok], eid[ok]])
         checked += int(ok.sum())
         count[eid] += 1

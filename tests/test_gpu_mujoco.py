@@ -673,9 +673,10 @@ def test_humanoid_matches_oracle(name, task, params, over, nobs):
 
 
 def test_humanoid_deterministic_and_partial_batches():
-    """Same seed, same actions => bit-identical observations across pools; envs stepped
-    through a permuted partial batch get the same results as in a full batch (the workspace
-    block belongs to the launch's wave, the persistent state to the env)."""
+    """Same seed, same actions, same batches => bit-identical observations across pools; envs
+    stepped through permuted partial batches get the same results as in a full batch (the
+    workspace block belongs to the launch's wave, the persistent state to the env) up to
+    rounding: which PGS formulation runs is decided per wave."""
     n = 128
     rng = np.random.default_rng(7)
     acts = rng.uniform(-0.4, 0.4, size=(12, n, 17))
@@ -700,4 +701,4 @@ def test_humanoid_deterministic_and_partial_batches():
             for j, e in enumerate(r["info:env_id"].ravel()):
                 rows[int(e)] = r["obs"][j]
         got = np.stack([rows[e] for e in range(n)])
-        np.testing.assert_array_equal(got, a["obs"], err_msg=f"step {t}")
+        np.testing.assert_allclose(got, a["obs"], rtol=1e-9, atol=1e-10, err_msg=f"step {t}")
