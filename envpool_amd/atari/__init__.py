@@ -6,8 +6,8 @@ and pushes into a 4-deep frame stack (`PushStack`, atari_env.h:308-346).  ALE,
 its ROMs and OpenCV are not part of this repository; this module exposes the
 post-process as a batched HIP kernel behind the C ABI so that a host ALE loop
 can hand over `maxpool_buf_[0/1]` of every env and get the stacked observation
-back.  Gray-scale (the default `gray_scale=True`) and INTER_AREA (the default
-`use_inter_area_resize=True`) only.
+back.  Gray-scale (the default `gray_scale=True`) only; INTER_AREA (the default
+`use_inter_area_resize=True`) or INTER_LINEAR (`False`, the reference benchmark's setting).
 """
 
 from __future__ import annotations

@@ -1,5 +1,6 @@
 // K4 — Atari observation post-process: max-pool of the last two ALE frames,
-// INTER_AREA resize to img_height x img_width, push into the frame stack.
+// INTER_AREA (default) or INTER_LINEAR resize to img_height x img_width, push into the
+// frame stack.
 //
 // Replaces, for a whole batch of envs in one launch:
 //   AtariEnv::PushStack   envpool/atari/atari_env.h:308-346
@@ -21,6 +22,11 @@
 // cvRound saturate) — compiled with -ffp-contract=off, so the result equals
 // oracle/atari/atari_post.c exactly.  The frame stack is a per-env ring in HBM
 // (`head` = oldest slot): a push overwrites one slot instead of shifting three.
+// use_inter_area_resize=false (the reference's benchmark setting, benchmark/test_envpool.py:92)
+// selects cv::INTER_LINEAR: OpenCV's 8-bit fixed-point path, pure integer arithmetic -- 2x2
+// taps with short coefficients scaled by 2^11 and the vertical pass
+// ((b0 (S0 >> 4)) >> 16) + ((b1 (S1 >> 4)) >> 16) + 2) >> 2 (kernel instantiation <2, 2, true>;
+// the tables carry the coefficients as exactly representable floats).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -67,7 +73,7 @@ __device__ __forceinline__ unsigned int MaxU8x4(unsigned int a, unsigned int b) 
 // (3 / 4 for 210x160 -> 84x84); taps beyond a row's count carry weight 0, which
 // adds exactly +0.0f, so the result is bit-identical to OpenCV's variable loops
 // while every LDS read of a pixel can be issued before the first one is used.
-template <int XT, int YT>
+template <int XT, int YT, bool kLinear = false>
 __global__ __launch_bounds__(kPostBlock) void AtariPostKernel(
     PostDev d, const int* __restrict__ env_id, int k,
     const unsigned char* __restrict__ frames,
@@ -138,6 +144,15 @@ __global__ __launch_bounds__(kPostBlock) void AtariPostKernel(
   // vertical accumulation in tap order, then cvRound + saturate
   auto pixel = [&](const TabEntry& ty, int dx) -> unsigned int {
     const TabEntry tx = xtab[dx];
+    if constexpr (kLinear) {  // cv::INTER_LINEAR, 8UC1 fixed point
+      const int sy0 = ty.ofs * d.sw, sy1 = min(ty.ofs + 1, d.sh - 1) * d.sw;
+      const int sx0 = tx.ofs, sx1 = min(tx.ofs + 1, d.sw - 1);
+      const int a0 = (int)tx.alpha[0], a1 = (int)tx.alpha[1];
+      const int b0 = (int)ty.alpha[0], b1 = (int)ty.alpha[1];
+      const int S0 = pooled[sy0 + sx0] * a0 + pooled[sy0 + sx1] * a1;
+      const int S1 = pooled[sy1 + sx0] * a0 + pooled[sy1 + sx1] * a1;
+      return (unsigned int)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+    }
     unsigned char px[YT][XT];
 #pragma unroll
     for (int yi = 0; yi < YT; ++yi) {  // clamped: padded taps have weight 0
@@ -237,6 +252,32 @@ bool BuildAreaTab(int ssize, int dsize, std::vector<short>* ofs,
   return true;
 }
 
+// one axis of cv::resize's INTER_LINEAR tables (imgproc/src/resize.cpp): source index and the two
+// weights saturate_cast<short>(c * INTER_RESIZE_COEF_SCALE), c computed in float
+void BuildLinearTab(int ssize, int dsize, std::vector<short>* ofs, std::vector<short>* cnt,
+                    std::vector<float>* alpha) {
+  const double scale = (double)ssize / dsize;
+  ofs->assign(dsize, 0);
+  cnt->assign(dsize, 2);
+  alpha->assign((size_t)dsize * kMaxTap, 0.0f);
+  for (int dx = 0; dx < dsize; dx++) {
+    float fx = (float)((dx + 0.5) * scale - 0.5);
+    int sx = (int)std::floor(fx);
+    fx -= (float)sx;
+    if (sx < 0) {
+      fx = 0;
+      sx = 0;
+    }
+    if (sx >= ssize - 1) {
+      fx = 0;
+      sx = ssize - 1;
+    }
+    (*ofs)[dx] = (short)sx;
+    (*alpha)[(size_t)dx * kMaxTap] = (float)std::lrint((1.f - fx) * 2048.f);
+    (*alpha)[(size_t)dx * kMaxTap + 1] = (float)std::lrint(fx * 2048.f);
+  }
+}
+
 }  // namespace
 }  // namespace epa
 
@@ -252,6 +293,7 @@ struct epa_atari_post {
   int* d_ids{nullptr};
   int cap{0};
   int max_xtap{epa::kMaxTap}, max_ytap{epa::kMaxTap};
+  bool linear{false};  // use_inter_area_resize = false
   // host path pipeline: frames go up, kernels run and observations come down on
   // three streams, in chunks linked by events, so the two PCIe directions and the
   // kernel overlap
@@ -293,7 +335,10 @@ void LaunchPost(epa_atari_post* p, const int* d_ids, int k,
                 unsigned char* d_obs) {
   size_t lds = (size_t)p->d.sh * p->d.sw;
   lds = (lds + 15) / 16 * 16 + sizeof(epa::TabEntry) * (size_t)(p->d.dw + p->d.dh);
-  if (p->max_xtap <= 3 && p->max_ytap <= 4) {  // the Atari default 210x160 -> 84x84
+  if (p->linear) {
+    hipLaunchKernelGGL((epa::AtariPostKernel<2, 2, true>), dim3(k), dim3(epa::kPostBlock), lds,
+                       p->stream, p->d, d_ids, k, d_frames, d_mask, d_obs);
+  } else if (p->max_xtap <= 3 && p->max_ytap <= 4) {  // the Atari default 210x160 -> 84x84
     hipLaunchKernelGGL((epa::AtariPostKernel<3, 4>), dim3(k), dim3(epa::kPostBlock), lds,
                        p->stream, p->d, d_ids, k, d_frames, d_mask, d_obs);
   } else {
@@ -312,16 +357,16 @@ int epa_atari_post_create(int32_t num_envs, int32_t stack_num, int32_t in_h,
                           int32_t use_inter_area, int32_t device,
                           epa_atari_post** out) {
   return PostGuard([&] {
-    if (!use_inter_area) {
-      throw std::invalid_argument(
-          "use_inter_area_resize=false (cv::INTER_LINEAR) is not supported: its "
-          "u8 result depends on OpenCV's SIMD path");
-    }
     if (num_envs < 1 || stack_num < 1 || out_h > in_h || out_w > in_w ||
         out_h < 1 || out_w < 1 || (size_t)in_h * in_w > 60000) {
       throw std::invalid_argument("atari_post: bad dimensions");
     }
-    if (in_h % out_h == 0 && in_w % out_w == 0) {
+    if (!use_inter_area && in_h == 2 * out_h && in_w == 2 * out_w) {
+      throw std::invalid_argument(
+          "atari_post: cv::INTER_LINEAR with an exact 2x2 reduction takes OpenCV's area-fast "
+          "path, which is not restated");
+    }
+    if (use_inter_area && in_h % out_h == 0 && in_w % out_w == 0) {
       throw std::invalid_argument(
           "atari_post: integer scale factors take OpenCV's resizeAreaFast path, "
           "which is not restated");
@@ -333,11 +378,15 @@ int epa_atari_post_create(int32_t num_envs, int32_t stack_num, int32_t in_h,
     if (device < 0 || device >= ndev) throw std::invalid_argument("device out of range");
     std::vector<short> xo, xc, yo, yc;
     std::vector<float> xa, ya;
-    if (!epa::BuildAreaTab(in_w, out_w, &xo, &xc, &xa) ||
-        !epa::BuildAreaTab(in_h, out_h, &yo, &yc, &ya)) {
+    if (!use_inter_area) {
+      epa::BuildLinearTab(in_w, out_w, &xo, &xc, &xa);
+      epa::BuildLinearTab(in_h, out_h, &yo, &yc, &ya);
+    } else if (!epa::BuildAreaTab(in_w, out_w, &xo, &xc, &xa) ||
+               !epa::BuildAreaTab(in_h, out_h, &yo, &yc, &ya)) {
       throw std::invalid_argument("atari_post: scale factor too large");
     }
     auto* p = new epa_atari_post();
+    p->linear = !use_inter_area;
     p->device = device;
     EPA_HIP(hipSetDevice(device));
     EPA_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));

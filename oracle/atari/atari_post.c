@@ -16,6 +16,11 @@
  * ResizeArea_Invoker<uchar, float>): float taps, horizontal then vertical
  * accumulation in table order, saturate_cast<uchar> = round-half-even.
  * Compile with -ffp-contract=off (x86-64 OpenCV does not fuse).
+ * use_inter_area_resize=false (what the reference's benchmark/test_envpool.py:92 selects)
+ * is cv::INTER_LINEAR on 8UC1: OpenCV's fixed-point path -- coefficients as shorts scaled by
+ * 2^11 (saturate_cast<short>(c * 2048), c in float), horizontal pass into int, vertical pass
+ * ((b0 (S0 >> 4)) >> 16) + ((b1 (S1 >> 4)) >> 16) + 2) >> 2 (the uchar specialisation of
+ * VResizeLinear; its SIMD twin VResizeLinearVec_32s8u computes the same expression).
  */
 #include <math.h>
 #include <stdint.h>
@@ -97,9 +102,59 @@ void orc_resize_area_u8(const unsigned char* src, int sh, int sw,
   free(sum);
 }
 
+/* one axis of cv::resize's INTER_LINEAR tables: source index and the two fixed-point weights */
+static void linear_tab(int ssize, int dsize, int* ofs, short* coef) {
+  double scale = (double)ssize / dsize;
+  for (int dx = 0; dx < dsize; dx++) {
+    float fx = (float)((dx + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) {
+      fx = 0;
+      sx = 0;
+    }
+    if (sx >= ssize - 1) {
+      fx = 0;
+      sx = ssize - 1;
+    }
+    ofs[dx] = sx;
+    long c0 = lrintf((1.f - fx) * 2048.f), c1 = lrintf(fx * 2048.f); /* saturate_cast<short> */
+    coef[2 * dx] = (short)c0;
+    coef[2 * dx + 1] = (short)c1;
+  }
+}
+
+/* cv::resize(src[sh x sw] 8UC1, dst[dh x dw], INTER_LINEAR) */
+void orc_resize_linear_u8(const unsigned char* src, int sh, int sw, unsigned char* dst, int dh,
+                          int dw) {
+  int* xofs = (int*)malloc(sizeof(int) * dw);
+  int* yofs = (int*)malloc(sizeof(int) * dh);
+  short* xa = (short*)malloc(sizeof(short) * 2 * dw);
+  short* yb = (short*)malloc(sizeof(short) * 2 * dh);
+  linear_tab(sw, dw, xofs, xa);
+  linear_tab(sh, dh, yofs, yb);
+  for (int dy = 0; dy < dh; dy++) {
+    int sy0 = yofs[dy], sy1 = sy0 + 1 < sh ? sy0 + 1 : sh - 1;
+    const unsigned char *r0 = src + (size_t)sy0 * sw, *r1 = src + (size_t)sy1 * sw;
+    int b0 = yb[2 * dy], b1 = yb[2 * dy + 1];
+    for (int dx = 0; dx < dw; dx++) {
+      int sx0 = xofs[dx], sx1 = sx0 + 1 < sw ? sx0 + 1 : sw - 1;
+      int a0 = xa[2 * dx], a1 = xa[2 * dx + 1];
+      int S0 = r0[sx0] * a0 + r0[sx1] * a1, S1 = r1[sx0] * a0 + r1[sx1] * a1;
+      dst[(size_t)dy * dw + dx] =
+          (unsigned char)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+    }
+  }
+  free(xofs);
+  free(yofs);
+  free(xa);
+  free(yb);
+}
+
 /* Frame-stack pool: stacks[N][S][dh*dw], logical order oldest..newest. */
 typedef struct {
   int n, s, sh, sw, dh, dw;
+  int linear; /* use_inter_area_resize = false */
   unsigned char* stacks;
 } post_pool;
 
@@ -109,6 +164,7 @@ void* orc_atari_post_create(int n, int s, int sh, int sw, int dh, int dw) {
   p->stacks = (unsigned char*)calloc((size_t)n * s * dh * dw, 1);
   return p;
 }
+void orc_atari_post_set_linear(void* h, int linear) { ((post_pool*)h)->linear = linear; }
 void orc_atari_post_destroy(void* h) {
   post_pool* p = (post_pool*)h;
   free(p->stacks);
@@ -130,7 +186,11 @@ void orc_atari_post_push(void* h, const int* env_id, int k,
     for (size_t j = 0; j < fsz; ++j) {
       pooled[j] = rst ? f0[j] : (f0[j] > f1[j] ? f0[j] : f1[j]);
     }
-    orc_resize_area_u8(pooled, p->sh, p->sw, resized, p->dh, p->dw);
+    if (p->linear) {
+      orc_resize_linear_u8(pooled, p->sh, p->sw, resized, p->dh, p->dw);
+    } else {
+      orc_resize_area_u8(pooled, p->sh, p->sw, resized, p->dh, p->dw);
+    }
     unsigned char* st = p->stacks + (size_t)env_id[i] * p->s * osz;
     memmove(st, st + osz, (size_t)(p->s - 1) * osz);
     memcpy(st + (size_t)(p->s - 1) * osz, resized, osz);

@@ -13,11 +13,13 @@ pytestmark = pytest.mark.gpu
 
 
 class OraclePost:
-    def __init__(self, n, s=4, oh=84, ow=84):
+    def __init__(self, n, s=4, oh=84, ow=84, linear=False):
         self.L = ctypes.CDLL(PORT_LIB)
         self.L.orc_atari_post_create.restype = ctypes.c_void_p
         self.L.orc_atari_post_push.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 3
         self.h = ctypes.c_void_p(self.L.orc_atari_post_create(n, s, 210, 160, oh, ow))
+        self.L.orc_atari_post_set_linear.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.L.orc_atari_post_set_linear(self.h, int(linear))
         self.s, self.oh, self.ow = s, oh, ow
 
     def push(self, frames, ids, mask):
@@ -83,8 +85,37 @@ def test_post_process_other_sizes(oh, ow):
         np.testing.assert_array_equal(a, b, err_msg=f"push {t}")
 
 
+@pytest.mark.parametrize("oh,ow", [(84, 84), (64, 64), (96, 75), (40, 30)])
+def test_post_process_bilinear(oh, ow):
+    """use_inter_area_resize=False: cv::INTER_LINEAR's 8-bit fixed-point path (what the
+    reference's benchmark selects, benchmark/test_envpool.py:92), bit-exact vs the oracle,
+    incl. resets, partial ids and sizes off the 84x84 default."""
+    n = 32
+    gpu = AtariPostProcess(n, img_height=oh, img_width=ow, use_inter_area_resize=False)
+    orc = OraclePost(n, oh=oh, ow=ow, linear=True)
+    rng = np.random.default_rng(2)
+    ids = np.arange(n, dtype=np.int32)
+    for t in range(8):
+        if t % 3 == 2:
+            sub = rng.permutation(n)[:11].astype(np.int32)
+            frames = rng.integers(0, 256, (11, 2, 210, 160), dtype=np.uint8)
+            mask = (rng.random(11) < 0.3).astype(np.uint8)
+        else:
+            sub = ids
+            frames = pong_like(rng, n) if t % 2 else rng.integers(0, 256, (n, 2, 210, 160), dtype=np.uint8)
+            mask = np.ones(n, np.uint8) if t == 0 else None
+        a, b = gpu.push(frames, sub, mask), orc.push(frames, sub, mask)
+        np.testing.assert_array_equal(a, b, err_msg=f"push {t}")
+    # a constant image stays constant; a horizontal ramp stays monotone
+    flat = np.full((n, 2, 210, 160), 131, np.uint8)
+    assert (gpu.push(flat, ids, np.ones(n, np.uint8)) == 131).all()
+    ramp = np.broadcast_to(np.arange(160, dtype=np.uint8)[None, None, None, :], (n, 2, 210, 160))
+    out = gpu.push(np.ascontiguousarray(ramp), ids, np.ones(n, np.uint8))[:, -1].astype(int)
+    assert (np.diff(out, axis=2) >= 0).all()
+
+
 def test_post_process_errors():
     with pytest.raises(ValueError):
-        AtariPostProcess(4, use_inter_area_resize=False)
-    with pytest.raises(ValueError):
         AtariPostProcess(4, img_height=105, img_width=80)  # integer scale: fast path
+    with pytest.raises(ValueError):  # INTER_LINEAR with an exact 2x2 reduction: area-fast path
+        AtariPostProcess(4, img_height=105, img_width=80, use_inter_area_resize=False)
