@@ -1059,6 +1059,12 @@ struct Tree {
       double x[NV];
       static_for<0, NV>([&](auto ic) { x[decltype(ic)::value] = w.Pair(kL.rowJW, r * NV + decltype(ic)::value).x; });
       const double R = w.Pair(kL.rowS, 3 * r + 1).y;
+      {  // b_r = J_r qacc_smooth - aref_r, kept next to aref for the register-resident PGS
+        double jb = -w.Pair(kL.rowS, 3 * r + 2).x;
+        static_for<0, NV>([&](auto ic) { jb += x[decltype(ic)::value] * w(kL.accs + decltype(ic)::value); });
+        w.Pair(kL.rowS, 3 * r + 2).y = jb;
+      }
+      EPA_TREE_FENCE();
       const double quad = SolveM(w, x);
       static_for<0, NV>([&](auto ic) { w.Pair(kL.rowJW, r * NV + decltype(ic)::value).y = x[decltype(ic)::value]; });
       const double arr = R + quad;  // 0 for an inert row
@@ -1200,58 +1206,36 @@ struct Tree {
       static_for<c, R>([&](auto rc) { AR[TriAR(decltype(rc)::value, c)] = 0.0; });
       b[c] = f[c] = ainv[c] = 0.0;
     });
-    {
-      // A_rc = J_r . W_c, four columns per pass over the J rows (W_c in registers), so a J row is
-      // read nrow / 4 times instead of once per column
-      constexpr int kCols = 4;
-      double accs[NV];
-      static_for<0, NV>([&](auto ic) { accs[decltype(ic)::value] = w0(kL.accs + decltype(ic)::value); });
-      static_for<0, R / kCols>([&](auto blk) {
-        constexpr int c0 = decltype(blk)::value * kCols;
-        if (c0 < nrow) {  // scalar
-          double Wc[kCols][NV];
-          {
-            const Ws w = w0.Fresh();
-            static_for<0, kCols>([&](auto kc) {
-              constexpr int k = decltype(kc)::value;
-              const int c = c0 + k < nrow ? c0 + k : nrow - 1;  // clamped: finite dummies past the end
-              static_for<0, NV>([&](auto ic) { Wc[k][decltype(ic)::value] = w.Pair(kL.rowJW, c * NV + decltype(ic)::value).y; });
+    // A_rc = J_r . W_c column by column: W_c stays in registers while the J rows below it
+    // stream through (more columns at once would not fit next to the 136 numbers of A + R)
+    static_for<0, R>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      if (c < nrow) {  // scalar
+        const Ws w = w0.Fresh();
+        double Wc[NV];
+        static_for<0, NV>([&](auto ic) { Wc[decltype(ic)::value] = w.Pair(kL.rowJW, c * NV + decltype(ic)::value).y; });
+        const D2 s0 = w.Pair(kL.rowS, 3 * c), s1 = w.Pair(kL.rowS, 3 * c + 1);
+        b[c] = w.Pair(kL.rowS, 3 * c + 2).y;
+        f[c] = s0.x;
+        ainv[c] = s0.y;
+        AR[TriAR(c, c)] = s1.x;  // A_cc + R_c
+        static_for<c + 1, R>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          if (r < nrow) {  // scalar
+            double Jr[NV];
+            static_for<0, NV>([&](auto ic) { Jr[decltype(ic)::value] = w.Pair(kL.rowJW, r * NV + decltype(ic)::value).x; });
+            EPA_TREE_FENCE();
+            double p0 = 0.0, p1 = 0.0;
+            static_for<0, NV>([&](auto ic) {
+              constexpr int i = decltype(ic)::value;
+              if constexpr (i % 2 == 0) p0 += Jr[i] * Wc[i];
+              else p1 += Jr[i] * Wc[i];
             });
+            AR[TriAR(r, c)] = p0 + p1;
           }
-          static_for<c0, R>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            if (r < nrow) {  // scalar
-              const Ws w = w0.Fresh();
-              double Jr[NV];
-              static_for<0, NV>([&](auto ic) { Jr[decltype(ic)::value] = w.Pair(kL.rowJW, r * NV + decltype(ic)::value).x; });
-              const D2 s0 = w.Pair(kL.rowS, 3 * r), s1 = w.Pair(kL.rowS, 3 * r + 1);
-              const double aref = w.Pair(kL.rowS, 3 * r + 2).x;
-              EPA_TREE_FENCE();
-              static_for<0, kCols>([&](auto kc) {
-                constexpr int c = c0 + decltype(kc)::value;
-                if constexpr (c <= r) {
-                  double p0 = 0.0, p1 = 0.0;
-                  static_for<0, NV>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    if constexpr (i % 2 == 0) p0 += Jr[i] * Wc[c - c0][i];
-                    else p1 += Jr[i] * Wc[c - c0][i];
-                  });
-                  // the diagonal carries R_r: take the stored A_rr + R_r
-                  AR[TriAR(r, c)] = c == r ? s1.x : p0 + p1;
-                }
-              });
-              if constexpr (r < c0 + kCols) {  // this row's own scalars, once
-                double jb = 0.0;
-                static_for<0, NV>([&](auto ic) { jb += Jr[decltype(ic)::value] * accs[decltype(ic)::value]; });
-                b[r] = jb - aref;
-                f[r] = s0.x;
-                ainv[r] = s0.y;
-              }
-            }
-          });
-        }
-      });
-    }
+        });
+      }
+    });
     EPA_TREE_FENCE();
     // dual cost of the warm-start forces 1/2 f'(A+R)f + f'b: kept only if below the cost of f = 0
     {
