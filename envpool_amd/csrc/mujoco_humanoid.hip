@@ -23,17 +23,8 @@
 #include "build/mj_humanoid_consts.inc"  // generated: kHumanoidModelConst, kHumanoidStandupModelConst
 
 namespace epa {
-namespace {
 
-namespace T = mj::tree;
-
-struct HumanoidMP {
-  static constexpr T::TreeModel kM = kHumanoidModelConst;
-};
-struct StandupMP {
-  static constexpr T::TreeModel kM = kHumanoidStandupModelConst;
-};
-
+// shared by the two translation units built from this file (external linkage)
 struct HumDev {
   double* ws;     // [ceil(N / 64)][Layout::total][64]: block b belongs to wave b of a launch
   double* state;  // [Layout::npersist][N]: what persists between steps, per env
@@ -47,6 +38,20 @@ struct HumTask {
   double healthy_z_min, healthy_z_max, reset_noise_scale, dt;
   double contact_cost_weight, contact_cost_max;
 };
+
+namespace {
+
+namespace T = mj::tree;
+
+#ifdef EPA_HUM_STANDUP_TU  // see the launchers below: one model per translation unit
+struct StandupMP {
+  static constexpr T::TreeModel kM = kHumanoidStandupModelConst;
+};
+#else
+struct HumanoidMP {
+  static constexpr T::TreeModel kM = kHumanoidModelConst;
+};
+#endif
 
 constexpr int kHumBlock = 64;
 
@@ -218,6 +223,46 @@ __global__ void HumSetState(HumDev dev, CommonDev cm, const int* ids, int k, con
   cm.cur_step[e] = (int)t[4];
 }
 
+}  // namespace
+
+// The two models are compiled in separate translation units (the step kernel takes ~1.5 min
+// each): this file is built twice, EPA_HUM_STANDUP_TU selects which model's kernels and
+// launchers it emits; the pool class lives in the Humanoid unit.
+#ifdef EPA_HUM_STANDUP_TU
+using HumModelP = StandupMP;
+#define EPA_HUM_FN(name) name##Standup
+constexpr bool kThisStandup = true;
+#else
+using HumModelP = HumanoidMP;
+#define EPA_HUM_FN(name) name##Humanoid
+constexpr bool kThisStandup = false;
+#endif
+void EPA_HUM_FN(HumLaunchStep)(hipStream_t st, int blocks, HumDev dev, CommonDev cm, StepArgs a,
+                               const double* act, OutPtrs out, HumTask task) {
+  hipLaunchKernelGGL((HumanoidStepKernel<HumModelP, kThisStandup>), dim3(blocks), dim3(kHumBlock), 0,
+                     st, dev, cm, a, act, out, task);
+}
+void EPA_HUM_FN(HumLaunchGet)(hipStream_t st, int k, HumDev dev, CommonDev cm, const int* ids,
+                              double* out) {
+  hipLaunchKernelGGL(HumGetState<HumModelP>, dim3((k + 255) / 256), dim3(256), 0, st, dev, cm, ids,
+                     k, out);
+}
+void EPA_HUM_FN(HumLaunchSet)(hipStream_t st, int k, HumDev dev, CommonDev cm, const int* ids,
+                              const double* in) {
+  hipLaunchKernelGGL(HumSetState<HumModelP>, dim3((k + 255) / 256), dim3(256), 0, st, dev, cm, ids,
+                     k, in);
+}
+int EPA_HUM_FN(HumWorkspaceSlots)() { return T::Tree<HumModelP>::kL.total; }
+
+#ifndef EPA_HUM_STANDUP_TU
+void HumLaunchStepStandup(hipStream_t, int, HumDev, CommonDev, StepArgs, const double*, OutPtrs,
+                          HumTask);
+void HumLaunchGetStandup(hipStream_t, int, HumDev, CommonDev, const int*, double*);
+void HumLaunchSetStandup(hipStream_t, int, HumDev, CommonDev, const int*, const double*);
+int HumWorkspaceSlotsStandup();
+
+namespace {
+
 int HumObsDim(const Config& cfg) {
   // humanoid.h:50-60: 376 (378 with positions), minus the world body's cinert / cvel /
   // cfrc_ext (22) and the free joint's qfrc_actuator (6) for the v5 ids
@@ -274,7 +319,7 @@ class HumanoidPool : public Pool {
     ws_bytes_ = sizeof(double) * blocks * 64 * (size_t)Total();
     EPA_HIP(hipMalloc(&dev_.ws, ws_bytes_));
     EPA_HIP(hipMemsetAsync(dev_.ws, 0, ws_bytes_, stream_));
-    const size_t sb = sizeof(double) * (size_t)T::Tree<HumanoidMP>::kL.npersist * cfg.num_envs;
+    const size_t sb = sizeof(double) * (size_t)T::MakeLayout(kHumanoidModelConst).npersist * cfg.num_envs;
     EPA_HIP(hipMalloc(&dev_.state, sb));
     EPA_HIP(hipMemsetAsync(dev_.state, 0, sb, stream_));
     InitCommon();
@@ -285,22 +330,10 @@ class HumanoidPool : public Pool {
   }
   int StateDim() const override { return kHumanoidModelConst.nq + 2 * kHumanoidModelConst.nv + 7; }
   void GetState(const int* d_ids, int k, double* d_out) override {
-    if (standup_) {
-      hipLaunchKernelGGL(HumGetState<StandupMP>, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
-                         common_, d_ids, k, d_out);
-    } else {
-      hipLaunchKernelGGL(HumGetState<HumanoidMP>, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
-                         common_, d_ids, k, d_out);
-    }
+    (standup_ ? HumLaunchGetStandup : HumLaunchGetHumanoid)(stream_, k, dev_, common_, d_ids, d_out);
   }
   void SetState(const int* d_ids, int k, const double* d_in) override {
-    if (standup_) {
-      hipLaunchKernelGGL(HumSetState<StandupMP>, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
-                         common_, d_ids, k, d_in);
-    } else {
-      hipLaunchKernelGGL(HumSetState<HumanoidMP>, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_,
-                         common_, d_ids, k, d_in);
-    }
+    (standup_ ? HumLaunchSetStandup : HumLaunchSetHumanoid)(stream_, k, dev_, common_, d_ids, d_in);
   }
 
  protected:
@@ -308,19 +341,13 @@ class HumanoidPool : public Pool {
               const OutPtrs& out) override {
     StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps, cfg_.env_id_offset};
     const int blocks = (k + kHumBlock - 1) / kHumBlock;
-    const double* act = static_cast<const double*>(d_action);
-    if (standup_) {
-      hipLaunchKernelGGL((HumanoidStepKernel<StandupMP, true>), dim3(blocks), dim3(kHumBlock), 0,
-                         stream_, dev_, common_, a, act, out, task_);
-    } else {
-      hipLaunchKernelGGL((HumanoidStepKernel<HumanoidMP, false>), dim3(blocks), dim3(kHumBlock), 0,
-                         stream_, dev_, common_, a, act, out, task_);
-    }
+    (standup_ ? HumLaunchStepStandup : HumLaunchStepHumanoid)(
+        stream_, blocks, dev_, common_, a, static_cast<const double*>(d_action), out, task_);
   }
 
  private:
   int Total() const {
-    return standup_ ? T::Tree<StandupMP>::kL.total : T::Tree<HumanoidMP>::kL.total;
+    return standup_ ? HumWorkspaceSlotsStandup() : HumWorkspaceSlotsHumanoid();
   }
   HumDev dev_{};
   HumTask task_{};
@@ -343,5 +370,6 @@ Pool* MakeHumanoid(const std::string& family, const Config& cfg) {
   if (family == "HumanoidStandup") return new HumanoidPool(cfg, true);
   return nullptr;
 }
+#endif  // !EPA_HUM_STANDUP_TU
 
 }  // namespace epa
