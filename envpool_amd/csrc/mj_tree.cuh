@@ -1197,13 +1197,35 @@ struct Tree {
   // of a wave: 10x the HBM traffic of everything else in a forward pass.
   static constexpr int kRegRows = 16;
   static EPA_HD constexpr int TriAR(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
-  static EPA_HD void SolvePgsReg(Ws w0, int nrow, bool commit) {
+  // A + R is split: the first kArReg entries (packed lower triangle) in VGPRs, the rest in a
+  // lane-private LDS column.  All 136 in registers overflow the 256 architectural VGPRs into
+  // AGPRs, and every use then costs two v_accvgpr_read: 2/3 of the sweep's instructions.
+  static constexpr int kArAll = kRegRows * (kRegRows + 1) / 2;
+  static constexpr int kArReg = kArAll / 2;
+  static constexpr int kArLds = kArAll - kArReg;  // doubles per lane: 34 KB per wave
+  struct ArStore {
+    double reg[kArReg];
+    double* lds;  // this lane's column: element k at lds[k * kLaneStride]
+    template <int I>
+    EPA_HD double Get() const {
+      if constexpr (I < kArReg) return reg[I];
+      else return lds[(I - kArReg) * kLaneStride];
+    }
+    template <int I>
+    EPA_HD void Set(double v) {
+      if constexpr (I < kArReg) reg[I] = v;
+      else lds[(I - kArReg) * kLaneStride] = v;
+    }
+  };
+  static EPA_HD void SolvePgsReg(Ws w0, int nrow, bool commit, double* lds_col) {
     constexpr TreeModel m = MP::kM;
     constexpr int R = kRegRows;
-    double AR[R * (R + 1) / 2], b[R], f[R], ainv[R];
+    ArStore AR;
+    AR.lds = lds_col;
+    double b[R], f[R], ainv[R];
     static_for<0, R>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
-      static_for<c, R>([&](auto rc) { AR[TriAR(decltype(rc)::value, c)] = 0.0; });
+      static_for<c, R>([&](auto rc) { AR.template Set<TriAR(decltype(rc)::value, c)>(0.0); });
       b[c] = f[c] = ainv[c] = 0.0;
     });
     // A_rc = J_r . W_c column by column: W_c stays in registers while the J rows below it
@@ -1218,7 +1240,7 @@ struct Tree {
         b[c] = w.Pair(kL.rowS, 3 * c + 2).y;
         f[c] = s0.x;
         ainv[c] = s0.y;
-        AR[TriAR(c, c)] = s1.x;  // A_cc + R_c
+        AR.template Set<TriAR(c, c)>(s1.x);  // A_cc + R_c
         static_for<c + 1, R>([&](auto rc) {
           constexpr int r = decltype(rc)::value;
           if (r < nrow) {  // scalar
@@ -1231,7 +1253,7 @@ struct Tree {
               if constexpr (i % 2 == 0) p0 += Jr[i] * Wc[i];
               else p1 += Jr[i] * Wc[i];
             });
-            AR[TriAR(r, c)] = p0 + p1;
+            AR.template Set<TriAR(r, c)>(p0 + p1);
           }
         });
       }
@@ -1243,7 +1265,7 @@ struct Tree {
       static_for<0, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         double s = 0.0;
-        static_for<0, R>([&](auto cc) { s += AR[TriAR(r, decltype(cc)::value)] * f[decltype(cc)::value]; });
+        static_for<0, R>([&](auto cc) { s += AR.template Get<TriAR(r, decltype(cc)::value)>() * f[decltype(cc)::value]; });
         cost += f[r] * (0.5 * s + b[r]);
       });
       const bool cold = cost > 0.0;
@@ -1253,13 +1275,16 @@ struct Tree {
     bool done = false;
     for (int iter = 0; iter < m.iterations; ++iter) {
       double improvement = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" ::: "memory");  // keep the LDS half of A + R in LDS: no hoisting out of the loop
+#endif
       static_for<0, R>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         if (r < nrow) {  // scalar
           double p0 = b[r], p1 = 0.0, p2 = 0.0, p3 = 0.0;
           static_for<0, R>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            const double t = AR[TriAR(r, c)] * f[c];
+            const double t = AR.template Get<TriAR(r, c)>() * f[c];
             if constexpr (c % 4 == 0) p0 += t;
             if constexpr (c % 4 == 1) p1 += t;
             if constexpr (c % 4 == 2) p2 += t;
@@ -1268,7 +1293,7 @@ struct Tree {
           const double res = (p0 + p1) + (p2 + p3);
           const double fn = fmax(0.0, f[r] - res * ainv[r]);
           double delta = fn - f[r];
-          const double change = 0.5 * delta * delta * AR[TriAR(r, r)] + delta * res;
+          const double change = 0.5 * delta * delta * AR.template Get<TriAR(r, r)>() + delta * res;
           const bool keep = !done && !(change > 1e-10);
           f[r] += Sel(keep, delta, 0.0);
           improvement -= Sel(keep, change, 0.0);
@@ -1300,7 +1325,8 @@ struct Tree {
   }
 
   // mj_forward
-  static EPA_HD RowCount Forward(Ws w, bool commit) {
+  // `lds_col`: this lane's column of a [kArLds][lanes] LDS block (SolvePgsReg)
+  static EPA_HD RowCount Forward(Ws w, bool commit, double* lds_col) {
     // Fresh(): every stage recomputes its slot addresses locally (see Ws::Fresh)
     GMask act, uni;
     Kinematics(w.Fresh());
@@ -1317,7 +1343,7 @@ struct Tree {
     const RowCount rc = MakeRows(w.Fresh(), act, u, &csum);
     EPA_TREE_FENCE();
     if (rc.rows() <= kRegRows) {
-      SolvePgsReg(w.Fresh(), rc.rows(), commit);
+      SolvePgsReg(w.Fresh(), rc.rows(), commit, lds_col);
     } else {
       SolvePgs(w.Fresh(), rc.rows(), commit, u, csum);
     }

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(kHumBlock) void HumanoidStepKernel(
   using E = T::Tree<MP>;
   constexpr T::TreeModel m = MP::kM;
   constexpr T::Layout L = E::kL;
+  __shared__ double lds_ar[E::kArLds * kHumBlock];  // [entry][lane], see Tree::SolvePgsReg
   const int row = blockIdx.x * kHumBlock + threadIdx.x;
   if (row >= a.k) return;
   const int e = a.ids ? a.ids[row] - a.id_offset : row;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(kHumBlock) void HumanoidStepKernel(
   typename E::RowCount rows{0, 0, 0};
   for (int it = 0; it < nmax; ++it) {
     const bool live = it < nfwd;
-    rows = E::Forward(w, live);
+    rows = E::Forward(w, live, lds_ar + threadIdx.x);
     E::RkAdvance(w.Fresh(), it & 3, live && !reset);
   }
   // mj_rnePostConstraint after the last mj_step (mujoco_env.h:145-147)

@@ -24,10 +24,11 @@ static void Run(const double* q, const double* v, const double* warm, const doub
   }
   for (int i = 0; i < E::NU; ++i) w(E::kL.ctrl + i) = ctrl[i];
   typename E::RowCount rc{0, 0, 0};
-  if (nsub == 0) rc = E::Forward(w, true);  // mj_forward only (reset)
+  std::vector<double> lds(E::kArLds, 0.0);
+  if (nsub == 0) rc = E::Forward(w, true, lds.data());  // mj_forward only (reset)
   for (int s = 0; s < nsub; ++s) {
     for (int stage = 0; stage < 4; ++stage) {
-      rc = E::Forward(w, true);
+      rc = E::Forward(w, true, lds.data());
       E::RkAdvance(w, stage, true);
     }
   }
