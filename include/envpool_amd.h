@@ -193,7 +193,9 @@ int epa_set_state(epa_pool* pool, const int32_t* env_ids, int32_t k,
 /* ---- Atari post-process (K4): max-pool of the last two ALE frames, resize
  *      to 84x84, push into the frame stack (replaces AtariEnv::PushStack,
  *      envpool/atari/atari_env.h:308-346 + envpool/utils/image_process.h:27-36).
- *      See epa_atari_* in this header's companion section below. */
+ *      use_inter_area: the config key `use_inter_area_resize` (atari_env.h:61):
+ *      1 = cv::INTER_AREA (default), 0 = cv::INTER_LINEAR (what the reference's
+ *      benchmark/test_envpool.py:92 selects). */
 typedef struct epa_atari_post epa_atari_post;
 int epa_atari_post_create(int32_t num_envs, int32_t stack_num, int32_t in_h,
                           int32_t in_w, int32_t out_h, int32_t out_w,
