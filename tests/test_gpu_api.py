@@ -249,3 +249,33 @@ def test_results_independent_of_batch_composition(task, adim):
         count[eid] += 1
         apool.send(eid, acts[np.minimum(t, T + 7), eid])  # every row goes straight back in
     assert checked == n * (T + 1)
+
+
+@pytest.mark.parametrize("task,adim,horizon", [("HalfCheetah-v4", 6, 1000), ("Humanoid-v4", 17, 300)])
+def test_mujoco_full_episode_determinism_and_truncation(task, adim, horizon):
+    """The reference's determinism test runs whole episodes
+    (mujoco_gym_deterministic_test.py:70-123): same seed => identical rollout up to and
+    across the time limit; at elapsed_step == max_episode_steps every surviving env reports
+    truncated (not terminated) and the next step returns its reset row."""
+    n = 128
+    e0 = envpool.make_gym(task, num_envs=n, seed=13, max_episode_steps=horizon)
+    e1 = envpool.make_gym(task, num_envs=n, seed=13, max_episode_steps=horizon)
+    e2 = envpool.make_gym(task, num_envs=n, seed=14, max_episode_steps=horizon)
+    o0, o1, o2 = e0.reset()[0], e1.reset()[0], e2.reset()[0]
+    np.testing.assert_array_equal(o0, o1)
+    assert not np.array_equal(o0, o2)  # different seed => different rollout
+    rng = np.random.default_rng(2)
+    lo, hi = e0.action_space.low[0], e0.action_space.high[0]
+    for t in range(1, horizon + 2):
+        a = rng.uniform(lo, hi, (n, adim))
+        r0, r1 = e0.step(a), e1.step(a)
+        for x, y in zip(r0[:4], r1[:4]):
+            np.testing.assert_array_equal(x, y)
+        obs, rew, term, trunc, info = r0
+        assert np.isfinite(obs).all() and np.isfinite(rew).all()
+        el = info["elapsed_step"]
+        assert (trunc == ((el == horizon) & ~term)).all()
+        assert not (term & trunc).any()
+        if task.startswith("HalfCheetah"):  # never terminates early: one clock for all envs
+            assert (el == (t if t <= horizon else 0)).all()
+            assert trunc.all() == (t == horizon)
