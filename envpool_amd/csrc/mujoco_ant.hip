@@ -16,7 +16,7 @@
 // lag[2][N] = data_->xpos[torso].xy of the last forward pass (the reference
 // reads the *lagged* torso position, ant.h:169-173 / SURVEY §7 H3), and the
 // env's normal_distribution saved value.
-#define EPA_SINCOS_MODE 2  // see mj_cheetah.cuh; Ant: 6.7 -> 8.4 M env-steps/s (fp64, N=65536) over mode 1
+#define EPA_SINCOS_MODE 2  // see mj_cheetah.cuh; Ant fp64, N=65536, 200-step bench: mode 2 7.0 M, mode 1 6.7 M, library 6.8 M env-steps/s
 #include "device_common.cuh"
 #include "engine.h"
 #include "mj_ant.cuh"
