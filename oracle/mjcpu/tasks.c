@@ -788,6 +788,32 @@ void mjcpu_raw_set(void* h, int env, const double* qpos, const double* qvel,
   memcpy(d->ctrl, ctrl, sizeof(double) * p->m.nu);
   mjc_forward(&p->m, d);
 }
+/* as mjcpu_raw_set, but with the warm start of a running simulation and WITHOUT a forward
+ * pass: the state a golden vector of tools/pin_with_mujoco.py was recorded from (the PGS
+ * result depends on qacc_warmstart) */
+void mjcpu_raw_set_warm(void* h, int env, const double* qpos, const double* qvel,
+                        const double* ctrl, const double* warm) {
+  mj_pool* p = (mj_pool*)h;
+  mjc_data* d = &p->envs[env].d;
+  mjc_reset_data(&p->m, d);
+  memcpy(d->qpos, qpos, sizeof(double) * p->m.nq);
+  memcpy(d->qvel, qvel, sizeof(double) * p->m.nv);
+  memcpy(d->ctrl, ctrl, sizeof(double) * p->m.nu);
+  memcpy(d->qacc_warmstart, warm, sizeof(double) * p->m.nv);
+}
+/* fields of the LAST forward evaluation that the Humanoid tasks observe:
+ * out = cinert[nbody*10] cvel[nbody*6] qfrc_actuator[nv] cfrc_ext[nbody*6] (after
+ * mj_rnePostConstraint) */
+void mjcpu_raw_observed(void* h, int env, double* out) {
+  mj_pool* p = (mj_pool*)h;
+  mjc_data* d = &p->envs[env].d;
+  int k = 0;
+  for (int b = 0; b < p->m.nbody; ++b) for (int j = 0; j < 10; ++j) out[k++] = d->cinert[b][j];
+  for (int b = 0; b < p->m.nbody; ++b) for (int j = 0; j < 6; ++j) out[k++] = d->cvel[b][j];
+  for (int i = 0; i < p->m.nv; ++i) out[k++] = d->qfrc_actuator[i];
+  mjc_rne_post_constraint(&p->m, d);
+  for (int b = 0; b < p->m.nbody; ++b) for (int j = 0; j < 6; ++j) out[k++] = d->cfrc_ext[b][j];
+}
 void mjcpu_raw_step(void* h, int env, int n) {
   mj_pool* p = (mj_pool*)h;
   for (int i = 0; i < n; ++i) mjc_step(&p->m, &p->envs[env].d);

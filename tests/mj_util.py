@@ -38,6 +38,21 @@ class RawMj:
         ctrl = np.zeros(self.nu) if ctrl is None else np.ascontiguousarray(ctrl, dtype=np.float64)
         self.L.mjcpu_raw_set(self.inner, 0, qpos.ctypes.data, qvel.ctypes.data, ctrl.ctypes.data)
 
+    def set_warm(self, qpos, qvel, ctrl, warm):
+        """State of a running simulation incl. qacc_warmstart, no forward pass."""
+        arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (qpos, qvel, ctrl, warm)]
+        self.L.mjcpu_raw_set_warm.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+        self.L.mjcpu_raw_set_warm(self.inner, 0, *[a.ctypes.data for a in arrs])
+
+    def observed(self):
+        """cinert, cvel, qfrc_actuator, cfrc_ext of the last forward evaluation."""
+        nb, nv = self.nbody, self.nv
+        out = np.zeros(nb * 22 + nv)
+        self.L.mjcpu_raw_observed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        self.L.mjcpu_raw_observed(self.inner, 0, out.ctypes.data)
+        return (out[:nb * 10].reshape(nb, 10), out[nb * 10:nb * 16].reshape(nb, 6),
+                out[nb * 16:nb * 16 + nv], out[nb * 16 + nv:].reshape(nb, 6))
+
     def step(self, n=1):
         self.L.mjcpu_raw_step(self.inner, 0, n)
 

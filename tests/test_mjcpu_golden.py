@@ -25,9 +25,17 @@ def test_oracle_matches_real_mujoco(name, task):
     np.testing.assert_allclose(o.body_mass, g["body_mass"], rtol=1e-9)
     np.testing.assert_allclose(o.dof_invweight0, g["dof_invweight0"], rtol=1e-7)
     for i in range(0, len(g["qpos0"]), 7):
-        o.set(g["qpos0"][i], g["qvel0"][i], g["ctrl"][i])
+        # the recorded state includes qacc_warmstart (the unconverged PGS of the humanoids
+        # depends on it); no forward pass in between, like the recording
+        o.set_warm(g["qpos0"][i], g["qvel0"][i], g["ctrl"][i], g["warm0"][i])
         o.step(int(g["frame_skip"]) if "frame_skip" in g else 5)
         q, v, _ = o.get()
         # the reference's own alignment tolerance (mujoco_gym_align_test.py:38-80)
         np.testing.assert_allclose(q, g["qpos1"][i], atol=1e-6, rtol=1e-7)
         np.testing.assert_allclose(v, g["qvel1"][i], atol=1e-6, rtol=1e-7)
+        if "cinert1" in g:  # fields of the last forward evaluation that Humanoid observes
+            cinert, cvel, qfrc_act, cfrc = o.observed()
+            np.testing.assert_allclose(cinert, g["cinert1"][i], atol=1e-6, rtol=1e-7)
+            np.testing.assert_allclose(cvel, g["cvel1"][i], atol=1e-6, rtol=1e-7)
+            np.testing.assert_allclose(qfrc_act, g["qfrc_actuator1"][i], atol=1e-6, rtol=1e-7)
+            np.testing.assert_allclose(cfrc, g["cfrc_ext1"][i], atol=1e-5, rtol=1e-6)

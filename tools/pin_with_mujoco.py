@@ -43,7 +43,8 @@ def main(xml_dir: str) -> None:
         m = mujoco.MjModel.from_xml_path(os.path.join(xml_dir, xml))
         d = mujoco.MjData(m)
         rec = {k: [] for k in ("qpos0", "qvel0", "warm0", "ctrl", "qpos1", "qvel1", "xpos1",
-                               "qfrc_constraint1", "cfrc_ext1")}
+                               "qfrc_constraint1", "cfrc_ext1", "cinert1", "cvel1",
+                               "qfrc_actuator1", "xipos1", "solver_niter1", "nefc1")}
         for ep in range(8 * 200 // horizon):
             mujoco.mj_resetData(m, d)
             d.qpos[:] = m.qpos0 + rng.uniform(-0.1, 0.1, m.nq)
@@ -63,6 +64,13 @@ def main(xml_dir: str) -> None:
                 rec["xpos1"].append(d.xpos[1].copy())
                 # lagged mjData fields the tasks observe (last RK4 stage) and cfrc_ext
                 rec["qfrc_constraint1"].append(d.qfrc_constraint.copy())
+                # what the Humanoid tasks observe (humanoid.h:229-257) and the solver's trace
+                rec["cinert1"].append(d.cinert.copy())
+                rec["cvel1"].append(d.cvel.copy())
+                rec["qfrc_actuator1"].append(d.qfrc_actuator.copy())
+                rec["xipos1"].append(d.xipos.copy())
+                rec["solver_niter1"].append(int(d.solver_niter[0]))
+                rec["nefc1"].append(int(d.nefc))
                 mujoco.mj_rnePostConstraint(m, d)
                 rec["cfrc_ext1"].append(d.cfrc_ext.copy())
         extra = dict(frame_skip=frame_skip, body_mass=m.body_mass.copy(), dof_invweight0=m.dof_invweight0.copy(),
