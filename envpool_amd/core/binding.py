@@ -18,6 +18,7 @@ std::numeric_limits<T>::min()/max() (envpool/core/spec.h:71-72; note that
 from __future__ import annotations
 
 import collections
+import ctypes
 from dataclasses import dataclass, field
 from typing import Any, Callable, Sequence
 
@@ -103,11 +104,19 @@ class FamilyDef:
 
 class _ShardedPools:
     """num_envs split contiguously over several GPUs of one process:
-    shard s owns env ids [s*per, (s+1)*per).  Each shard is a DevicePool with
-    its own stream, so the step kernels of all GPUs run concurrently; there is
-    no inter-GPU traffic on the data path."""
+    shard s owns env ids [offset + s*per, offset + (s+1)*per).  Each shard is a
+    DevicePool with its own streams and its own host thread, so uploads, step
+    kernels and downloads of all GPUs run concurrently; there is no inter-GPU
+    traffic on the data path ("host gather").
+
+    recv: every shard copies its rows device->host DIRECTLY into its row range of
+    ONE pinned block (epa_recv_into) whenever the batch is grouped by shard (the
+    `step(action)` / `reset()` case, ids ascending) -- no host-side scatter.  Only
+    batches whose ids interleave shards fall back to a per-shard recv + scatter."""
 
     def __init__(self, family: str, devices: Sequence[int], num_envs: int, **kw: Any):
+        import concurrent.futures
+
         if num_envs % len(devices) != 0:
             raise ValueError("num_envs must be divisible by the number of devices")
         if kw.get("batch_size", 0) not in (0, num_envs):
@@ -124,39 +133,82 @@ class _ShardedPools:
         ]
         self.state_keys = self.pools[0].state_keys
         self._pending: collections.deque = collections.deque()
+        # one host thread per GPU: the C ABI calls release the GIL (ctypes)
+        self._exec = concurrent.futures.ThreadPoolExecutor(len(self.pools))
+        self._blocks = self.pools[0]._blocks
+        self._lib = self.pools[0]._lib
 
-    def _split(self, ids: np.ndarray) -> list[np.ndarray]:
+    def _split(self, ids: np.ndarray) -> tuple[list[Any], bool]:
+        """Rows of each shard; `grouped` when every shard's rows are one contiguous run
+        (then parts are slices)."""
         shard = (ids - self.offset) // self.per
-        return [np.flatnonzero(shard == s) for s in range(len(self.pools))]
+        if len(ids) and np.all(shard[1:] >= shard[:-1]):
+            bounds = np.searchsorted(shard, np.arange(len(self.pools) + 1))
+            return [slice(int(bounds[s]), int(bounds[s + 1])) for s in range(len(self.pools))], True
+        return [np.flatnonzero(shard == s) for s in range(len(self.pools))], False
+
+    @staticmethod
+    def _count(part: Any) -> int:
+        return part.stop - part.start if isinstance(part, slice) else len(part)
+
+    def _each(self, fn: Callable[[int, DevicePool, Any], Any], parts: list[Any]) -> None:
+        futs = [self._exec.submit(fn, s, p, part)
+                for s, (p, part) in enumerate(zip(self.pools, parts)) if self._count(part)]
+        for f in futs:
+            f.result()
 
     def send(self, env_id: np.ndarray, action: np.ndarray) -> None:
         env_id = np.ascontiguousarray(env_id, dtype=np.int32)
-        parts = self._split(env_id)
-        for p, idx in zip(self.pools, parts):
-            if len(idx):
-                p.send(env_id[idx], np.ascontiguousarray(action[idx]))
-        self._pending.append((len(env_id), parts))
+        action = np.asarray(action)
+        parts, grouped = self._split(env_id)
+        self._each(lambda s, p, part: p.send(env_id[part], action[part]), parts)
+        self._pending.append((len(env_id), parts, grouped))
 
     def reset(self, env_ids: np.ndarray) -> None:
         env_ids = np.ascontiguousarray(env_ids, dtype=np.int32)
-        parts = self._split(env_ids)
-        for p, idx in zip(self.pools, parts):
-            if len(idx):
-                p.reset(env_ids[idx])
-        self._pending.append((len(env_ids), parts))
+        parts, grouped = self._split(env_ids)
+        self._each(lambda s, p, part: p.reset(env_ids[part]), parts)
+        self._pending.append((len(env_ids), parts, grouped))
 
     def recv(self) -> list[np.ndarray]:
         if not self._pending:
             raise RuntimeError("recv: nothing pending")
-        k, parts = self._pending.popleft()
-        outs = [np.empty((k, *shape), dtype=dtype) for _, dtype, shape in self.state_keys]
-        for p, idx in zip(self.pools, parts):
-            if len(idx):
+        k, parts, grouped = self._pending.popleft()
+        if not grouped:
+            outs = [np.empty((k, *shape), dtype=dtype) for _, dtype, shape in self.state_keys]
+
+            def scatter(s: int, p: DevicePool, idx: Any) -> None:
                 for o, part in zip(outs, p.recv()):
                     o[idx] = part
-        return outs
+
+            self._each(scatter, parts)
+            return outs
+        # one pinned block for the whole batch, laid out like a DevicePool batch of k rows
+        row_bytes = [int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+                     for _, dtype, shape in self.state_keys]
+        offs, total = [], 0
+        for rb in row_bytes:
+            offs.append(total)
+            total += (k * rb + 255) // 256 * 256
+        block = self._blocks.take(max(total, 256))
+        base = block.ctypes.data
+        n = len(self.state_keys)
+
+        def land(s: int, p: DevicePool, part: slice) -> None:
+            ptrs = (ctypes.c_void_p * n)(*[base + o + part.start * rb
+                                           for o, rb in zip(offs, row_bytes)])
+            got = ctypes.c_int32(0)
+            native.check(self._lib.epa_recv_into(p._h, ptrs, n, part.stop - part.start,
+                                                 ctypes.byref(got)))
+            assert got.value == part.stop - part.start
+            p._pending.popleft()
+
+        self._each(land, parts)
+        return [block[o:o + k * rb].view(dtype).reshape((k, *shape))
+                for (_, dtype, shape), o, rb in zip(self.state_keys, offs, row_bytes)]
 
     def close(self) -> None:
+        self._exec.shutdown(wait=True)
         for p in self.pools:
             p.close()
 

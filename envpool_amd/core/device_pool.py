@@ -117,13 +117,15 @@ class DevicePool:
         native.check(
             self._lib.epa_send(self._h, env_id.ctypes.data, k, action.ctypes.data)
         )
-        self._pending.append(k)
+        if k > 0:  # an empty send enqueues nothing (Pool::Send returns early)
+            self._pending.append(k)
 
     def reset(self, env_ids: np.ndarray) -> None:
         env_ids = np.ascontiguousarray(env_ids, dtype=np.int32)
         k = int(env_ids.shape[0])
         native.check(self._lib.epa_reset(self._h, env_ids.ctypes.data, k))
-        self._pending.append(k)
+        if k > 0:
+            self._pending.append(k)
 
     def _layout(self, rows: int) -> tuple[list[int], int]:
         lay = self._layouts.get(rows)
@@ -186,14 +188,25 @@ class DevicePool:
 
     # -- device path ---------------------------------------------------------
     def send_device(self, d_action: int | None, k: int | None = None,
-                    d_env_id: int | None = None) -> None:
-        """`d_action` / `d_env_id` are raw device addresses (ints)."""
+                    d_env_id: int | None = None, wait_event: int | None = None) -> None:
+        """`d_action` / `d_env_id` are raw device addresses (ints); `wait_event` is a
+        hipEvent_t (int) the producer of those buffers recorded on its stream."""
         k = self.num_envs if k is None else int(k)
         native.check(
             self._lib.epa_send_device(
-                self._h, ctypes.c_void_p(d_env_id), k, ctypes.c_void_p(d_action)
+                self._h, ctypes.c_void_p(d_env_id), k, ctypes.c_void_p(d_action),
+                ctypes.c_void_p(wait_event),
             )
         )
+
+    def wait_stream(self, producer_stream: int | None) -> None:
+        """Order the pool's stream behind everything enqueued on `producer_stream`
+        (raw hipStream_t, e.g. torch.cuda.current_stream().cuda_stream)."""
+        native.check(self._lib.epa_wait_stream(self._h, ctypes.c_void_p(producer_stream)))
+
+    def consumer_wait(self, consumer_stream: int | None) -> None:
+        """`consumer_stream` waits for the batch the last recv_device handed out."""
+        native.check(self._lib.epa_consumer_wait(self._h, ctypes.c_void_p(consumer_stream)))
 
     def recv_device(self) -> tuple[list[int], int]:
         n = len(self.state_keys)

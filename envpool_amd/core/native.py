@@ -78,8 +78,11 @@ def lib() -> ctypes.CDLL:
         "epa_recv": (i32, [vp, P(vp), i32, i32, P(i32)]),
         "epa_recv_layout": (i32, [vp, i32, P(ctypes.c_size_t), i32, P(ctypes.c_size_t)]),
         "epa_recv_block": (i32, [vp, vp, ctypes.c_size_t, P(ctypes.c_size_t), i32, P(i32)]),
+        "epa_recv_into": (i32, [vp, P(vp), i32, i32, P(i32)]),
         "epa_pending_rows": (i32, [vp, P(i32)]),
-        "epa_send_device": (i32, [vp, vp, i32, vp]),
+        "epa_send_device": (i32, [vp, vp, i32, vp, vp]),
+        "epa_wait_stream": (i32, [vp, vp]),
+        "epa_consumer_wait": (i32, [vp, vp]),
         "epa_recv_device": (i32, [vp, P(vp), i32, P(i32)]),
         "epa_stream": (vp, [vp]),
         "epa_synchronize": (i32, [vp]),
@@ -110,8 +113,8 @@ def lib() -> ctypes.CDLL:
 EXPORTED_SYMBOLS = [
     "epa_num_families", "epa_family_name", "epa_describe_state",
     "epa_describe_action", "epa_create", "epa_destroy", "epa_send", "epa_reset",
-    "epa_recv", "epa_recv_layout", "epa_recv_block", "epa_pending_rows",
-    "epa_send_device", "epa_recv_device",
+    "epa_recv", "epa_recv_layout", "epa_recv_block", "epa_recv_into", "epa_pending_rows",
+    "epa_send_device", "epa_recv_device", "epa_wait_stream", "epa_consumer_wait",
     "epa_stream", "epa_synchronize", "epa_set_timing", "epa_kernel_time_ms",
     "epa_state_dim", "epa_get_state", "epa_set_state", "epa_atari_post_create",
     "epa_atari_post_destroy", "epa_atari_post_push",

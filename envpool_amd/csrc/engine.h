@@ -126,11 +126,17 @@ class Pool {
 
   void Send(const int32_t* env_id, int k, const void* action);
   void Reset(const int32_t* env_ids, int k);
-  void SendDevice(const int32_t* d_env_id, int k, const void* d_action);
+  void SendDevice(const int32_t* d_env_id, int k, const void* d_action,
+                  hipEvent_t wait_event = nullptr);
+  // stream_ waits for everything enqueued so far on `producer` (device path)
+  void WaitStream(hipStream_t producer);
+  // `consumer` waits for the kernel of the batch RecvDevice handed out last
+  void ConsumerWait(hipStream_t consumer);
   int Recv(void* const* out_ptrs, int n_ptrs, int cap_rows);
   // zero-copy host recv into a caller-owned block (see epa_recv_block)
   size_t RecvLayout(int rows, size_t* offsets, int n_keys) const;
   int RecvBlock(void* block, size_t block_bytes, size_t* offsets, int n_keys);
+  int RecvInto(void* const* out_ptrs, int n_ptrs, int cap_rows);
   int RecvDevice(void** d_out_ptrs, int n_ptrs);
   int PendingRows();
   void Synchronize();
@@ -198,6 +204,7 @@ class Pool {
   size_t staging_next_{0};
   char* recv_stage_{nullptr};  // pinned D2H landing block
   size_t recv_stage_bytes_{0};
+  hipEvent_t order_ev_{nullptr};  // WaitStream's producer marker
   // timing
   bool timing_{false};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timers_;

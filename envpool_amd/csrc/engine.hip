@@ -54,6 +54,7 @@ Config Config::From(const epa_config* c) {
   Config r;
   if (c == nullptr) throw std::invalid_argument("null config");
   r.num_envs = c->num_envs;
+  if (r.num_envs < 1) throw std::invalid_argument("num_envs must be >= 1");
   r.batch_size = c->batch_size;
   r.seed = c->seed;
   if (c->env_seed != nullptr) {
@@ -65,7 +66,6 @@ Config Config::From(const epa_config* c) {
   for (int i = 0; i < c->n_params; ++i) {
     r.params[c->param_keys[i]] = c->param_values[i];
   }
-  if (r.num_envs < 1) throw std::invalid_argument("num_envs must be >= 1");
   // EnvSpec ctor, envpool/core/env_spec.h:75-83
   if (r.batch_size > r.num_envs) {
     throw std::invalid_argument(
@@ -151,6 +151,7 @@ Pool::~Pool() {
   }
   for (auto& t : timer_pool_) (void)hipEventDestroy(t);
   if (recv_stage_) (void)hipHostFree(recv_stage_);
+  if (order_ev_) (void)hipEventDestroy(order_ev_);
   if (common_.cur_step) (void)hipFree(common_.cur_step);
   if (common_.done) (void)hipFree(common_.done);
   if (stack_ring_) (void)hipFree(stack_ring_);
@@ -395,12 +396,34 @@ void Pool::Reset(const int32_t* env_ids, int k) {
   s.in_use = true;
 }
 
-void Pool::SendDevice(const int32_t* d_env_id, int k, const void* d_action) {
+void Pool::SendDevice(const int32_t* d_env_id, int k, const void* d_action,
+                      hipEvent_t wait_event) {
   CheckIds(nullptr, k);
   if (k == 0) return;
   std::lock_guard<std::mutex> lk(mu_);
   EPA_HIP(hipSetDevice(cfg_.device));
+  // the producer of d_action / d_env_id (a learner on another stream) recorded
+  // `wait_event` after writing them: the step kernel is ordered behind it
+  // (the analogue of the XLA custom call's stream ordering, core/xla.h:151-169)
+  if (wait_event != nullptr) EPA_HIP(hipStreamWaitEvent(stream_, wait_event, 0));
   Enqueue(d_env_id, k, d_action, d_action == nullptr);
+}
+
+void Pool::WaitStream(hipStream_t producer) {
+  std::lock_guard<std::mutex> lk(mu_);
+  EPA_HIP(hipSetDevice(cfg_.device));
+  if (!order_ev_) EPA_HIP(hipEventCreateWithFlags(&order_ev_, hipEventDisableTiming));
+  EPA_HIP(hipEventRecord(order_ev_, producer));
+  EPA_HIP(hipStreamWaitEvent(stream_, order_ev_, 0));
+}
+
+void Pool::ConsumerWait(hipStream_t consumer) {
+  std::lock_guard<std::mutex> lk(mu_);
+  EPA_HIP(hipSetDevice(cfg_.device));
+  if (lent_[0] == nullptr) {
+    throw std::runtime_error("consumer_wait: no batch handed out by recv_device yet");
+  }
+  EPA_HIP(hipStreamWaitEvent(consumer, lent_[0]->done, 0));
 }
 
 int Pool::PendingRows() {
@@ -527,6 +550,41 @@ int Pool::RecvBlock(void* block, size_t block_bytes, size_t* offsets, int n_keys
   return want;
 }
 
+// Per-key device -> host copies straight into caller-owned buffers (no landing block, no
+// host memcpy): what a multi-GPU gather needs, where GPU g's rows land directly in ITS
+// slice of one host batch (SURVEY 8e "host gather").
+int Pool::RecvInto(void* const* out_ptrs, int n_ptrs, int cap_rows) {
+  std::lock_guard<std::mutex> lk(mu_);
+  EPA_HIP(hipSetDevice(cfg_.device));
+  if (n_ptrs < (int)keys_.size()) {
+    throw std::invalid_argument("recv_into: need one output pointer per state key");
+  }
+  int want = WantRows();
+  if (cap_rows < want) throw std::invalid_argument("recv_into: output buffers too small");
+  hipStream_t cs = d2h_stream_;
+  int got = 0;
+  while (got < want) {
+    Batch* b = pending_.front();
+    int take = std::min(want - got, b->k - b->consumed);
+    EPA_HIP(hipStreamWaitEvent(cs, b->done, 0));
+    for (size_t i = 0; i < keys_.size(); ++i) {
+      if (out_ptrs[i] == nullptr) continue;
+      size_t rb = keys_[i].row_bytes();
+      EPA_HIP(hipMemcpyAsync(static_cast<char*>(out_ptrs[i]) + (size_t)got * rb,
+                             b->dbuf + b->offsets[i] + (size_t)b->consumed * rb,
+                             (size_t)take * rb, hipMemcpyDeviceToHost, cs));
+    }
+    b->consumed += take;
+    got += take;
+    if (b->consumed == b->k) {
+      pending_.pop_front();
+      ReleaseBatch(b);
+    }
+  }
+  EPA_HIP(hipStreamSynchronize(cs));
+  return want;
+}
+
 int Pool::RecvDevice(void** d_out_ptrs, int n_ptrs) {
   std::lock_guard<std::mutex> lk(mu_);
   if (n_ptrs < (int)keys_.size()) {
@@ -577,7 +635,9 @@ void Pool::KernelTime(double* avg_ms, int* launches) {
 }
 
 void Pool::GetStateHost(const int32_t* ids, int k, double* out) {
+  if (ids == nullptr || out == nullptr) throw std::invalid_argument("get_state: null argument");
   CheckIds(ids, k);
+  if (k == 0) return;
   std::lock_guard<std::mutex> lk(mu_);
   EPA_HIP(hipSetDevice(cfg_.device));
   int dim = StateDim();
@@ -598,7 +658,9 @@ void Pool::GetStateHost(const int32_t* ids, int k, double* out) {
 }
 
 void Pool::SetStateHost(const int32_t* ids, int k, const double* in) {
+  if (ids == nullptr || in == nullptr) throw std::invalid_argument("set_state: null argument");
   CheckIds(ids, k);
+  if (k == 0) return;
   std::lock_guard<std::mutex> lk(mu_);
   EPA_HIP(hipSetDevice(cfg_.device));
   int dim = StateDim();
@@ -788,13 +850,28 @@ int epa_recv_block(epa_pool* pool, void* block, size_t block_bytes,
   return Guard([&] { *k_out = pool->impl->RecvBlock(block, block_bytes, offsets, n_keys); });
 }
 
+int epa_recv_into(epa_pool* pool, void* const* out_ptrs, int32_t n_ptrs,
+                  int32_t cap_rows, int32_t* k_out) {
+  return Guard([&] { *k_out = pool->impl->RecvInto(out_ptrs, n_ptrs, cap_rows); });
+}
+
 int epa_pending_rows(epa_pool* pool, int32_t* rows) {
   return Guard([&] { *rows = pool->impl->PendingRows(); });
 }
 
 int epa_send_device(epa_pool* pool, const int32_t* d_env_id, int32_t k,
-                    const void* d_action) {
-  return Guard([&] { pool->impl->SendDevice(d_env_id, k, d_action); });
+                    const void* d_action, void* wait_event) {
+  return Guard([&] {
+    pool->impl->SendDevice(d_env_id, k, d_action, static_cast<hipEvent_t>(wait_event));
+  });
+}
+
+int epa_wait_stream(epa_pool* pool, void* producer_stream) {
+  return Guard([&] { pool->impl->WaitStream(static_cast<hipStream_t>(producer_stream)); });
+}
+
+int epa_consumer_wait(epa_pool* pool, void* consumer_stream) {
+  return Guard([&] { pool->impl->ConsumerWait(static_cast<hipStream_t>(consumer_stream)); });
 }
 
 int epa_recv_device(epa_pool* pool, void** d_out_ptrs, int32_t n_ptrs,

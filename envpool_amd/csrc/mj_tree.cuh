@@ -331,12 +331,8 @@ struct Tree {
     if constexpr (jn == 1 && m.jnt_type[ja < 0 ? 0 : ja] == kJntFree) {
       constexpr int qa = m.jnt_qadr[ja];
       f.pos = {qp[qa], qp[qa + 1], qp[qa + 2]};
-      // mj_kinematics normalises the quaternion in qpos itself
+      // mj_kinematics (MuJoCo >= 3.1.4) normalises a local copy; qpos itself is left alone
       f.q = QNormalize({qp[qa + 3], qp[qa + 4], qp[qa + 5], qp[qa + 6]});
-      w(kL.qpos + qa + 3) = f.q.w;
-      w(kL.qpos + qa + 4) = f.q.x;
-      w(kL.qpos + qa + 5) = f.q.y;
-      w(kL.qpos + qa + 6) = f.q.z;
     } else {
       f.pos = par.pos + MulV(par.R, Vec3{m.body_pos[B][0], m.body_pos[B][1], m.body_pos[B][2]});
       f.q = QMul(par.q, Quat{m.body_quat[B][0], m.body_quat[B][1], m.body_quat[B][2],

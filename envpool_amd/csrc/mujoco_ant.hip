@@ -91,10 +91,11 @@ __global__ __launch_bounds__(kAntBlock) void AntStepKernel(
     g.Commit();
     dev.nsaved[e] = saved;
     dev.navail[e] = (unsigned char)avail;
-    // mj_forward: mj_kinematics normalises the free-joint quaternion in place
-    // and leaves xpos[torso] = qpos[0:3]; the warm start is re-derived by the
-    // solver (unique minimiser) so it is simply cleared.
-    A::NormalizeQuat(qpos + 3);
+    // mj_forward leaves xpos[torso] = qpos[0:3]; the warm start is re-derived by the
+    // solver (unique minimiser) so it is simply cleared.  MuJoCo >= 3.1.4 no longer
+    // normalises the free-joint quaternion of qpos in place (mj_kinematics works on a
+    // normalised copy), so the reset observation carries the raw init_qpos + noise
+    // quaternion; the first mj_step's mj_integratePos leaves a unit quaternion.
     for (int i = 0; i < A::kNQ; ++i) dev.qpos[(size_t)i * n + e] = qpos[i];
     for (int i = 0; i < A::kNV; ++i) {
       dev.qvel[(size_t)i * n + e] = qvel[i];

@@ -95,7 +95,10 @@ class EnvPoolMixin(ABC):
     @property
     def all_env_ids(self) -> np.ndarray:
         if not hasattr(self, "_all_env_ids"):
-            self._all_env_ids = np.arange(self.config["num_envs"], dtype=np.int32)
+            # `env_id_offset` (extension): this pool is one shard of a bigger pool and
+            # its env ids are the global ones [offset, offset + num_envs)
+            off = int(self.config.get("env_id_offset", 0))
+            self._all_env_ids = np.arange(off, off + self.config["num_envs"], dtype=np.int32)
         return self._all_env_ids
 
     @property

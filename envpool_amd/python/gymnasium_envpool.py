@@ -87,7 +87,8 @@ class GymnasiumEnvPoolMixin:
         if env_id is not None and option_env_id is not None:
             raise ValueError("Pass either env_id or options['reset_mask'], not both.")
         if option_env_id is not None:
-            env_id = option_env_id
+            # the mask is over this pool's envs; ids are global (env_id_offset extension)
+            env_id = option_env_id + np.int32(self.config.get("env_id_offset", 0))
         return super().reset(env_id)
 
     def close(self, **kwargs: Any) -> None:

@@ -23,14 +23,50 @@ class _DevArray:
         }
 
 
-def recv_device_tensors(pool: Any, device: Any = None) -> dict[str, Any]:
+def send_device_tensors(pool: Any, action: Any, env_id: Any = None) -> None:
+    """Step the envs with an action tensor that lives on the pool's device.  The step
+    kernel is ordered behind everything enqueued so far on torch's CURRENT stream
+    (the stream the learner produced `action` on) -- no host synchronisation.
+    `action=None` resets the listed envs."""
+    import torch
+
+    k = None
+    d_action = None
+    if action is not None:
+        if not action.is_contiguous() or action.dtype != _torch_dtype(pool.action_dtype):
+            raise RuntimeError(
+                f"send_device_tensors: action must be contiguous {np.dtype(pool.action_dtype)}")
+        d_action = action.data_ptr()
+        k = int(action.shape[0])
+    d_ids = None
+    if env_id is not None:
+        if env_id.dtype != torch.int32 or not env_id.is_contiguous():
+            raise RuntimeError("send_device_tensors: env_id must be contiguous int32")
+        d_ids = env_id.data_ptr()
+        k = int(env_id.shape[0])
+    pool.wait_stream(torch.cuda.current_stream(torch.device("cuda", pool.device)).cuda_stream)
+    pool.send_device(d_action, k, d_ids)
+
+
+def _torch_dtype(dt: Any) -> Any:
+    import torch
+
+    return {np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32,
+            np.dtype(np.float64): torch.float64}[np.dtype(dt)]
+
+
+def recv_device_tensors(pool: Any, device: Any = None, order_current_stream: bool = True
+                        ) -> dict[str, Any]:
     """pool.recv_device() -> {state key: torch tensor aliasing the batch}.
-    Valid until the second next recv_device on the pool; consume it on
-    `pool.stream` or after `pool.synchronize()`."""
+    Valid until the second next recv_device on the pool.  With
+    `order_current_stream` torch's current stream is made to wait for the step
+    kernel, so the tensors can be consumed right away without a host sync."""
     import torch
 
     ptrs, k = pool.recv_device()
     dev = torch.device("cuda", pool.device) if device is None else device
+    if order_current_stream:
+        pool.consumer_wait(torch.cuda.current_stream(dev).cuda_stream)
     out = {}
     for (name, dtype, shape), ptr in zip(pool.state_keys, ptrs):
         if k == 0:

@@ -150,6 +150,14 @@ int epa_recv_layout(epa_pool* pool, int32_t rows, size_t* offsets, int32_t n_key
 int epa_recv_block(epa_pool* pool, void* block, size_t block_bytes,
                    size_t* offsets, int32_t n_keys, int32_t* k_out);
 
+/* Same blocking / batching semantics as epa_recv, but every state key is copied
+ * device->host DIRECTLY into `out_ptrs[key]` (no landing block, no host memcpy;
+ * pinned destinations get the full PCIe rate, NULL skips a key).  This is the
+ * building block of the multi-GPU host gather: GPU g's rows land
+ * in ITS row range of one host batch shared by all GPUs. */
+int epa_recv_into(epa_pool* pool, void* const* out_ptrs, int32_t n_ptrs,
+                  int32_t cap_rows, int32_t* k_out);
+
 /* Rows currently computed-or-in-flight and not yet received. */
 int epa_pending_rows(epa_pool* pool, int32_t* rows);
 
@@ -157,10 +165,22 @@ int epa_pending_rows(epa_pool* pool, int32_t* rows);
  *      without the host staging the reference does there) ---------------- */
 
 /* Like epa_send but `d_env_id` (may be NULL = all envs in order) and
- * `d_action` are device pointers on the pool's device; the kernel is enqueued
- * on the pool's stream after `wait_event` (may be NULL). */
+ * `d_action` (NULL = forced reset of the listed envs) are device pointers on
+ * the pool's device.  The step kernel is enqueued on the pool's stream behind
+ * `wait_event` (a hipEvent_t as void*, may be NULL) -- the event the producer
+ * of the action buffer recorded on ITS stream after writing it.  This is the
+ * stream-ordering half of the reference's XLA custom call
+ * (envpool/core/xla.h:151-169), minus its host staging.  With NULL the caller
+ * must have made the buffers visible some other way (epa_wait_stream below, or
+ * a device synchronise). */
 int epa_send_device(epa_pool* pool, const int32_t* d_env_id, int32_t k,
-                    const void* d_action);
+                    const void* d_action, void* wait_event);
+
+/* Convenience for callers that have a stream rather than an event (e.g.
+ * torch.cuda.current_stream().cuda_stream): everything enqueued on
+ * `producer_stream` (hipStream_t as void*; NULL = the legacy default stream)
+ * so far happens-before every kernel the pool enqueues from now on. */
+int epa_wait_stream(epa_pool* pool, void* producer_stream);
 
 /* Hands out device pointers (one per state key) to the oldest pending batch.
  * The pointers stay valid until the second next epa_recv_device call on this
@@ -168,6 +188,12 @@ int epa_send_device(epa_pool* pool, const int32_t* d_env_id, int32_t k,
  * enqueued on epa_stream() after this call is ordered after the step kernel. */
 int epa_recv_device(epa_pool* pool, void** d_out_ptrs, int32_t n_ptrs,
                     int32_t* k_out);
+
+/* The mirror of epa_wait_stream for the outputs: `consumer_stream` waits for the
+ * step kernel of the batch the LAST epa_recv_device handed out (a consumer on
+ * epa_stream() itself needs no call).  The consumer must be done with a batch's
+ * buffers before the second next epa_recv_device, when they are recycled. */
+int epa_consumer_wait(epa_pool* pool, void* consumer_stream);
 
 /* hipStream_t of the pool, as void*. */
 void* epa_stream(epa_pool* pool);

@@ -25,13 +25,11 @@ void mjc_reset_data(const mjc_model* m, mjc_data* d) { /* mj_resetData */
 
 /* ---- M1: mj_kinematics --------------------------------------------------- */
 static void kinematics(const mjc_model* m, mjc_data* d) {
-  /* normalise quaternions in qpos (mj_normalizeQuat at the top of
-   * mj_kinematics) [M] */
-  for (int j = 0; j < m->njnt; ++j) {
-    if (m->jnt_type[j] == MJC_JNT_FREE) {
-      quat_normalize(d->qpos + m->jnt_qposadr[j] + 3);
-    }
-  }
+  /* MuJoCo >= 3.1.4 (changelog: "quaternions in mjData.qpos are no longer normalised
+   * in place by mj_kinematics; they are normalised when they are used") -- so qpos keeps
+   * whatever the task wrote (the reset observation of Ant / Humanoid shows the raw
+   * init_qpos + noise quaternion) and only the local copy below is normalised.  After the
+   * first mj_step qpos is unit again (mj_integratePos normalises its result). */
   memset(d->xpos[0], 0, sizeof(d->xpos[0]));
   d->xquat[0][0] = 1;
   d->xquat[0][1] = d->xquat[0][2] = d->xquat[0][3] = 0;

@@ -870,3 +870,83 @@ int mjcpu_raw_contacts(void* h, int env, double* out) {
   }
   return d->ncon;
 }
+
+/* Pinning hook (tests): one mj_forward at the state set by mjcpu_raw_set_warm, then the
+ * named per-stage field of mjData, flattened row-major into `out` (capacity `cap` doubles).
+ * Returns the number of doubles written, -1 for an unknown name.  The names are MuJoCo's
+ * (mjData / mjContact members), so tools/pin_with_mujoco.py can dump the same fields from
+ * real MuJoCo and a mismatch localises to one pipeline stage. */
+void mjcpu_raw_forward(void* h, int env) {
+  mj_pool* p = (mj_pool*)h;
+  mjc_forward(&p->m, &p->envs[env].d);
+}
+int mjcpu_raw_stage(void* h, int env, const char* name, double* out, int cap) {
+  mj_pool* p = (mj_pool*)h;
+  const mjc_model* m = &p->m;
+  const mjc_data* d = &p->envs[env].d;
+  int nv = m->nv, nb = m->nbody, k = 0;
+#define PUT(x) do { if (k < cap) out[k] = (x); ++k; } while (0)
+  if (!strcmp(name, "qM")) { /* dense nv x nv (mj_fullM) */
+    for (int i = 0; i < nv; ++i) for (int j = 0; j < nv; ++j) PUT(d->M[i][j]);
+  } else if (!strcmp(name, "xpos")) {
+    for (int b = 0; b < nb; ++b) for (int j = 0; j < 3; ++j) PUT(d->xpos[b][j]);
+  } else if (!strcmp(name, "xquat")) {
+    for (int b = 0; b < nb; ++b) for (int j = 0; j < 4; ++j) PUT(d->xquat[b][j]);
+  } else if (!strcmp(name, "xipos")) {
+    for (int b = 0; b < nb; ++b) for (int j = 0; j < 3; ++j) PUT(d->xipos[b][j]);
+  } else if (!strcmp(name, "subtree_com")) {
+    for (int b = 0; b < nb; ++b) for (int j = 0; j < 3; ++j) PUT(d->subtree_com[b][j]);
+  } else if (!strcmp(name, "cinert")) {
+    for (int b = 0; b < nb; ++b) for (int j = 0; j < 10; ++j) PUT(d->cinert[b][j]);
+  } else if (!strcmp(name, "cdof")) {
+    for (int i = 0; i < nv; ++i) for (int j = 0; j < 6; ++j) PUT(d->cdof[i][j]);
+  } else if (!strcmp(name, "cvel")) {
+    for (int b = 0; b < nb; ++b) for (int j = 0; j < 6; ++j) PUT(d->cvel[b][j]);
+  } else if (!strcmp(name, "qfrc_passive")) {
+    for (int i = 0; i < nv; ++i) PUT(d->qfrc_passive[i]);
+  } else if (!strcmp(name, "qfrc_bias")) {
+    for (int i = 0; i < nv; ++i) PUT(d->qfrc_bias[i]);
+  } else if (!strcmp(name, "qfrc_actuator")) {
+    for (int i = 0; i < nv; ++i) PUT(d->qfrc_actuator[i]);
+  } else if (!strcmp(name, "qacc_smooth")) {
+    for (int i = 0; i < nv; ++i) PUT(d->qacc_smooth[i]);
+  } else if (!strcmp(name, "qacc")) {
+    for (int i = 0; i < nv; ++i) PUT(d->qacc[i]);
+  } else if (!strcmp(name, "qfrc_constraint")) {
+    for (int i = 0; i < nv; ++i) PUT(d->qfrc_constraint[i]);
+  } else if (!strcmp(name, "efc_J")) { /* dense nefc x nv */
+    for (int r = 0; r < d->nefc; ++r) for (int j = 0; j < nv; ++j) PUT(d->efc_J[r][j]);
+  } else if (!strcmp(name, "efc_pos")) {
+    for (int r = 0; r < d->nefc; ++r) PUT(d->efc_pos[r]);
+  } else if (!strcmp(name, "efc_margin")) {
+    for (int r = 0; r < d->nefc; ++r) PUT(d->efc_margin[r]);
+  } else if (!strcmp(name, "efc_vel")) {
+    for (int r = 0; r < d->nefc; ++r) PUT(d->efc_vel[r]);
+  } else if (!strcmp(name, "efc_aref")) {
+    for (int r = 0; r < d->nefc; ++r) PUT(d->efc_aref[r]);
+  } else if (!strcmp(name, "efc_R")) {
+    for (int r = 0; r < d->nefc; ++r) PUT(d->efc_R[r]);
+  } else if (!strcmp(name, "efc_D")) {
+    for (int r = 0; r < d->nefc; ++r) PUT(d->efc_D[r]);
+  } else if (!strcmp(name, "efc_diagApprox")) {
+    for (int r = 0; r < d->nefc; ++r) PUT(d->efc_diagApprox[r]);
+  } else if (!strcmp(name, "efc_KBIP")) { /* K, B, I per row (MuJoCo stores K B I P) */
+    for (int r = 0; r < d->nefc; ++r) for (int j = 0; j < 3; ++j) PUT(d->efc_KBI[r][j]);
+  } else if (!strcmp(name, "efc_force")) {
+    for (int r = 0; r < d->nefc; ++r) PUT(d->efc_force[r]);
+  } else if (!strcmp(name, "contact")) { /* per contact: geom1 geom2 dist includemargin pos[3] frame[9] dim efc_address */
+    for (int c = 0; c < d->ncon; ++c) {
+      const mjc_contact* q = &d->contact[c];
+      PUT(q->geom1); PUT(q->geom2); PUT(q->dist); PUT(q->includemargin);
+      for (int j = 0; j < 3; ++j) PUT(q->pos[j]);
+      for (int j = 0; j < 9; ++j) PUT(q->frame[j]);
+      PUT(q->dim); PUT(q->efc_address);
+    }
+  } else if (!strcmp(name, "counts")) { /* ncon nefc solver_niter */
+    PUT(d->ncon); PUT(d->nefc); PUT(d->solver_iter);
+  } else {
+    return -1;
+  }
+#undef PUT
+  return k;
+}

@@ -11,13 +11,51 @@ It writes tests/golden/mujoco_{half_cheetah,ant,walker2d,walker2d_v5,
 inverted_pendulum,inverted_double_pendulum,reacher,swimmer,hopper,humanoid,
 humanoidstandup}.npz; tests/test_mjcpu_golden.py
 activates automatically when those files exist and checks oracle/mjcpu (and,
-with a GPU, the HIP kernels) against them with the reference's own tolerance
-(obs atol 1e-6, rtol 1e-7: envpool/mujoco/gym/mujoco_gym_align_test.py:38-80).
+with a GPU, the HIP kernels: test_hip_kernels_match_real_mujoco) against them
+with the reference's own tolerance (obs atol 1e-6, rtol 1e-7:
+envpool/mujoco/gym/mujoco_gym_align_test.py:38-80).
+
+Besides the (state, ctrl) -> next-state vectors it records, for the first
+samples of every episode, MuJoCo's per-stage fields of ONE mj_forward at the
+recorded state (qM, cinert, cdof, qfrc_bias, qfrc_passive, contacts, efc_J,
+efc_aref, efc_R, efc_D, efc_KBIP, qacc_smooth, qacc, efc_force ...): when a
+golden step does not match, test_oracle_stages_match_real_mujoco says which
+pipeline stage is off.  It also records what mj_forward
+leaves in qpos for an un-normalised free-joint quaternion (the reset frame of
+Ant / Humanoid: MuJoCo >= 3.1.4 does not normalise qpos in place).
 """
+import copy
 import os
 import sys
 
 import numpy as np
+
+
+STAGE_FIELDS = ("xpos", "xquat", "xipos", "subtree_com", "cinert", "cdof", "cvel", "qfrc_passive",
+                "qfrc_bias", "qfrc_actuator", "qacc_smooth", "qacc", "qfrc_constraint", "efc_pos",
+                "efc_margin", "efc_vel", "efc_aref", "efc_R", "efc_D", "efc_diagApprox", "efc_KBIP",
+                "efc_force")
+
+
+def dump_stages(mujoco, m, d) -> dict:
+    """One mj_forward on a COPY of `d` (the trajectory is not disturbed); every field as a
+    flat float64 array under MuJoCo's own member name."""
+    d2 = copy.copy(d)
+    mujoco.mj_forward(m, d2)
+    out = {}
+    full = np.zeros((m.nv, m.nv))
+    mujoco.mj_fullM(m, full, d2.qM)
+    out["qM"] = full.ravel()
+    for f in STAGE_FIELDS:
+        out[f] = np.asarray(getattr(d2, f), dtype=np.float64).ravel().copy()
+    assert not mujoco.mj_isSparse(m), "dense Jacobian expected (nv < 60)"
+    out["efc_J"] = np.asarray(d2.efc_J, dtype=np.float64).ravel()[: d2.nefc * m.nv].copy()
+    con = []
+    for c in d2.contact:
+        con += [c.geom[0], c.geom[1], c.dist, c.includemargin, *c.pos, *c.frame, c.dim, c.efc_address]
+    out["contact"] = np.asarray(con, dtype=np.float64)
+    out["counts"] = np.asarray([d2.ncon, d2.nefc, int(d2.solver_niter[0])], dtype=np.float64)
+    return out
 
 
 def main(xml_dir: str) -> None:
@@ -45,12 +83,22 @@ def main(xml_dir: str) -> None:
         rec = {k: [] for k in ("qpos0", "qvel0", "warm0", "ctrl", "qpos1", "qvel1", "xpos1",
                                "qfrc_constraint1", "cfrc_ext1", "cinert1", "cvel1",
                                "qfrc_actuator1", "xipos1", "solver_niter1", "nefc1")}
+        stages = {}
+        reset_in, reset_out = [], []
         for ep in range(8 * 200 // horizon):
             mujoco.mj_resetData(m, d)
             d.qpos[:] = m.qpos0 + rng.uniform(-0.1, 0.1, m.nq)
             d.qvel[:] = rng.normal(0, 0.1, m.nv)
+            if name == "reacher":
+                d.qvel[2:] = 0.0  # the target never moves (reacher.h:116-131)
+            reset_in.append(d.qpos.copy())
             mujoco.mj_forward(m, d)
+            reset_out.append(d.qpos.copy())  # == reset_in unless mj_forward normalises in place
             for t in range(horizon):
+                if t < 3 or t == horizon - 1:  # per-stage fields at this (state, warm start)
+                    d.ctrl[:] = 0.0
+                    for f, v in dump_stages(mujoco, m, d).items():
+                        stages[f"stage/{len(rec['qpos0'])}/{f}"] = v
                 rec["qpos0"].append(d.qpos.copy())
                 rec["qvel0"].append(d.qvel.copy())
                 rec["warm0"].append(d.qacc_warmstart.copy())
@@ -73,7 +121,9 @@ def main(xml_dir: str) -> None:
                 rec["nefc1"].append(int(d.nefc))
                 mujoco.mj_rnePostConstraint(m, d)
                 rec["cfrc_ext1"].append(d.cfrc_ext.copy())
-        extra = dict(frame_skip=frame_skip, body_mass=m.body_mass.copy(), dof_invweight0=m.dof_invweight0.copy(),
+        extra = dict(frame_skip=frame_skip, reset_qpos_in=np.array(reset_in),
+                     reset_qpos_out=np.array(reset_out), mujoco_version=np.array(mujoco.__version__),
+                     **stages, body_mass=m.body_mass.copy(), dof_invweight0=m.dof_invweight0.copy(),
                      body_invweight0=m.body_invweight0.copy())
         np.savez_compressed(os.path.join(out_dir, f"mujoco_{name}.npz"),
                             **{k: np.array(v) for k, v in rec.items()}, **extra)
