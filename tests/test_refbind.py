@@ -166,6 +166,15 @@ def test_pybind_shim_is_bit_identical_to_the_ctypes_path(stem, module, ours, tas
         rp._reset(np.array([n + 3], dtype=np.int32))
 
 
+def _same_tree(a, b, ctx):
+    if isinstance(a, dict):
+        assert set(a) == set(b), ctx
+        for k in a:
+            _same_tree(a[k], b[k], (ctx, k))
+    else:
+        assert np.array_equal(np.asarray(a), np.asarray(b)), ctx
+
+
 @pytest.mark.gpu
 def test_pybind_classes_slot_into_the_python_adaptors():
     """py_env(spec, pool) (envpool/python/api.py:22-41) over the pybind11 classes: the
@@ -189,8 +198,7 @@ def test_pybind_classes_slot_into_the_python_adaptors():
         r1, r2 = env.step(act), ours.step(act)
         for x, y in zip(r1[:4], r2[:4]):
             assert np.array_equal(x, y)
-        for k in r1[4]:
-            assert np.array_equal(r1[4][k], r2[4][k]), k
+        _same_tree(r1[4], r2[4], "info")
 
 
 @pytest.mark.gpu
