@@ -1,25 +1,27 @@
-// K3b — gym-MuJoCo Ant batched step kernel (one env per thread, one wave/block).
+// K3b — gym-MuJoCo Ant batched step kernel: ONE ENV PER LANE QUAD (one lane per
+// leg, 16 envs per wavefront, one wave per block), see mj_ant4.cuh.
 //
 // Replaces, for the whole batch in one launch:
 //   MujocoEnv::{MujocoReset,MujocoStep}   envpool/mujoco/gym/mujoco_env.h:126-148
 //   AntEnvBase::{MujocoResetModel,Reset,Step,IsHealthy,WriteState}
 //                                         envpool/mujoco/gym/ant.h:135-278
-// with `frame_skip x mj_step` (RK4: 4 forward passes each) from mj_ant.cuh.
+// with `frame_skip x mj_step` (RK4: 4 forward passes each) from mj_ant4.cuh.
 // Ant-v4: use_contact_force=false (no cfrc_ext in obs, contact cost 0).
 // Ant-v3: use_contact_force=true but post_constraint=false: MuJoCo 3 fills
 //   cfrc_ext only in mj_rnePostConstraint, which the reference then never calls
 //   (mujoco_env.h:145-147) => 84 zeros in the obs, contact cost 0.
 // Ant-v5: use_contact_force + post_constraint: cfrc_ext of the last forward
-//   evaluation (mj_ant.cuh, AntContactWrench), world body excluded.
+//   evaluation (mj_ant4.cuh, ContactWrench), world body excluded.
 //
 // Persistent state (SoA fp64): qpos[15][N], qvel[14][N], qacc_warmstart[14][N],
 // lag[2][N] = data_->xpos[torso].xy of the last forward pass (the reference
 // reads the *lagged* torso position, ant.h:169-173 / SURVEY §7 H3), and the
-// env's normal_distribution saved value.
-#define EPA_SINCOS_MODE 2  // see mj_cheetah.cuh; Ant fp64, N=65536, 200-step bench: mode 2 7.0 M, mode 1 6.7 M, library 6.8 M env-steps/s
+// env's normal_distribution saved value.  Lane l of a quad loads / stores the
+// torso part (replicated) and the two dofs of leg l; lane 0 writes what is per env.
+#define EPA_SINCOS_MODE 1
 #include "device_common.cuh"
 #include "engine.h"
-#include "mj_ant.cuh"
+#include "mj_ant4.cuh"
 #include "mj_ant_model.h"
 #include "build/mj_ant_consts.inc"  // generated: kAntModelConst (gen_mj_consts.cpp)
 
@@ -27,6 +29,10 @@ namespace epa {
 namespace {
 
 namespace A = mj::ant;
+namespace A4 = mj::ant4;
+
+static_assert(A4::CheckLegSymmetry(kAntModelConst),
+              "ant_envpool.xml no longer has the mirror structure mj_ant4.cuh relies on");
 
 struct AntDev {
   double* qpos;  // [15][N]
@@ -35,14 +41,13 @@ struct AntDev {
   double* lag;   // [2][N]
   double* nsaved;
   unsigned char* navail;
-  double* stack;  // [N][frame_stack * nobs] obs ring (frame_stack > 1 only)
-  double* cfrc;   // [N][14][6] cfrc_ext accumulator (use_contact_force + post_constraint only)
+  double* cost;  // [N] profiling: Newton iterations of the last step, see AntGetState
 };
 
 constexpr int kAntMjBodies = 14;  // world + torso + 4 x (stub, leg, ankle) MuJoCo bodies
 
 struct AntTask {
-  int frame_skip, obs_skip, frame_stack;
+  int frame_skip, obs_skip;
   int terminate_when_unhealthy, legacy_healthy_reward;
   int use_contact_force, post_constraint, exclude_worldbody;
   double ctrl_cost_weight, forward_reward_weight, healthy_reward;
@@ -50,33 +55,46 @@ struct AntTask {
   double contact_cost_weight, contact_force_min, contact_force_max;
 };
 
-constexpr int kAntBlock = 64;
+constexpr int kAntBlock = 64;                 // one wavefront
+constexpr int kAntEnvsPerBlock = kAntBlock / 4;
+
+// waves per SIMD the register allocator targets: fp64 needs the whole 512-entry file
+// (486 registers, no scratch); fp32 fits two waves (25 spilled registers) and gains 50 %
+// from the second wave (profiles/r2b: 1.94e7 -> 2.93e7 env-steps/s at N=32768)
+template <typename T>
+constexpr int kAntWavesPerEu = sizeof(T) == 4 ? 2 : 1;
 
 // kWrench: the Ant-v5 variant that also evaluates cfrc_ext (separate instantiation
 // so that Ant-v3/v4 do not pay registers for the extra pass)
 template <typename T, bool kWrench>
-__global__ __launch_bounds__(kAntBlock) void AntStepKernel(
+__global__ __launch_bounds__(kAntBlock)
+__attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void AntStepKernel(
     AntDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action,
     OutPtrs out, AntTask task, mj::SolverCfg<T> scfg) {
   constexpr A::AntModel<T> m = A::CastAntModel<T>(kAntModelConst);
-  // lane-private LDS block [slot][lane]: M and the contact geometry of the
-  // current forward pass (mj_ant.cuh, AntPublish)
-  __shared__ T lds_buf[A::kAntLdsSlots * kAntBlock];
+  // lane-private LDS block [slot][lane]: local M and the contact geometry of the
+  // current forward pass (mj_ant4.cuh, FrontEnd)
+  __shared__ T lds_buf[A4::kSlots * kAntBlock];
   const int lane = threadIdx.x;
+  const int l = lane & 3;  // the leg this lane owns
   const int n = cm.n;
-  const int row = blockIdx.x * kAntBlock + threadIdx.x;
-  if (row >= a.k) return;
+  const int row = blockIdx.x * kAntEnvsPerBlock + (lane >> 2);
+  if (row >= a.k) return;  // whole quads leave together
   const int e = a.ids ? a.ids[row] - a.id_offset : row;
   bool done = cm.done[e] != 0;
   int cur = cm.cur_step[e];
   const bool reset = a.force_reset || done;
-  double qpos[A::kNQ], qvel[A::kNV];
-  float reward = 0.0f;
-  double info[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // WriteState, ant.h:231-278: obs = qpos[skip:] ++ qvel ++ clamped cfrc_ext
+  const int cf0 = task.exclude_worldbody ? 6 : 0;
+  const int ncf = task.use_contact_force ? kAntMjBodies * 6 - cf0 : 0;
+  const int nobs = A::kNQ + A::kNV - task.obs_skip + ncf;
+  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
+  double* obs_v = obs + A::kNQ - task.obs_skip;
+  double* obs_c = obs_v + A::kNV;
   if (reset) {
+    if (l != 0) return;  // the RNG stream of an env is sequential: its first lane draws
     // MujocoReset (mujoco_env.h:126-131) + MujocoResetModel (ant.h:135-147)
-    cur = 0;
-    done = false;
+    double qpos[A::kNQ], qvel[A::kNV];
     Mt19937 g(cm, e);
     double saved = dev.nsaved[e];
     int avail = dev.navail[e];
@@ -103,134 +121,159 @@ __global__ __launch_bounds__(kAntBlock) void AntStepKernel(
     }
     dev.lag[e] = qpos[0];
     dev.lag[(size_t)n + e] = qpos[1];
-    info[6] = 0.0;  // sqrt(0)
-  } else {
-    ++cur;
-    T q[A::kNQ], v[A::kNV], w[A::kNV], ctrl[A::kNU];
-    mj::static_for<0, A::kNQ>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      q[i] = (T)dev.qpos[(size_t)i * n + e];
-    });
-    mj::static_for<0, A::kNV>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      v[i] = (T)dev.qvel[(size_t)i * n + e];
-      w[i] = (T)dev.warm[(size_t)i * n + e];
-    });
-    const double x_before = dev.lag[e], y_before = dev.lag[(size_t)n + e];
-    const double* act = action + (size_t)row * A::kNU;
-    double ctrl_cost = 0.0;
-    mj::static_for<0, A::kNU>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      double ai = act[i];
-      ctrl_cost += task.ctrl_cost_weight * ai * ai;  // ant.h:176-179
-      ctrl[i] = (T)(ai < -1.0 ? -1.0 : (ai > 1.0 ? 1.0 : ai));
-    });
-    T lagx = T(0), lagy = T(0);
-    auto lds = [&](int slot) -> T& { return lds_buf[slot * kAntBlock + lane]; };
-    // mj_rnePostConstraint after the last mj_step (mujoco_env.h:145-147)
-    const bool wrench = kWrench;
-    double* cf = wrench ? dev.cfrc + (size_t)e * kAntMjBodies * 6 : nullptr;
-    if (wrench) {
-      for (int i = 0; i < kAntMjBodies * 6; ++i) cf[i] = 0.0;
-    }
-    auto sink = [&](int g, A::Vec3<T> tq, A::Vec3<T> f) {
-      // MuJoCo body id of geom body g is 1 + g; the world body (0) gets -[tq; f]
-      const double w6[6] = {(double)tq.x, (double)tq.y, (double)tq.z,
-                            (double)f.x, (double)f.y, (double)f.z};
-      for (int j = 0; j < 6; ++j) {
-        cf[(1 + g) * 6 + j] += w6[j];
-        cf[j] -= w6[j];
-      }
-    };
-    for (int s = 0; s < task.frame_skip; ++s) {
-      A::AntStep<kWrench>(m, scfg, q, v, w, ctrl, &lagx, &lagy, lds,
-                          wrench && s == task.frame_skip - 1, sink);
-    }
-    const double x_after = (double)lagx, y_after = (double)lagy;
-    bool healthy = true;  // IsHealthy, ant.h:214-229
-    mj::static_for<0, A::kNQ>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      qpos[i] = (double)q[i];
-      healthy = healthy && isfinite(qpos[i]);
-      dev.qpos[(size_t)i * n + e] = qpos[i];
-    });
-    mj::static_for<0, A::kNV>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      qvel[i] = (double)v[i];
-      healthy = healthy && isfinite(qvel[i]);
-      dev.qvel[(size_t)i * n + e] = qvel[i];
-      dev.warm[(size_t)i * n + e] = (double)w[i];
-    });
-    if (qpos[2] < task.healthy_z_min || qpos[2] > task.healthy_z_max) healthy = false;
-    dev.lag[e] = x_after;
-    dev.lag[(size_t)n + e] = y_after;
-    const double xv = (x_after - x_before) / task.dt;
-    const double yv = (y_after - y_before) / task.dt;
-    double contact_cost = 0.0;
-    if (wrench) {  // ant.h:183-194 (without post_constraint cfrc_ext stays zero)
-      for (int i = task.exclude_worldbody ? 6 : 0; i < kAntMjBodies * 6; ++i) {
-        double x = cf[i];
-        x = task.contact_force_max < x ? task.contact_force_max : x;  // std::min(max_, x)
-        x = task.contact_force_min > x ? task.contact_force_min : x;  // std::max(min_, x)
-        contact_cost += task.contact_cost_weight * x * x;
-      }
-    }
-    bool give = healthy;
-    if (task.legacy_healthy_reward) give = task.terminate_when_unhealthy || healthy;
-    const double healthy_reward = give ? task.healthy_reward : 0.0;
-    reward = static_cast<float>(xv * task.forward_reward_weight + healthy_reward -
-                                ctrl_cost - contact_cost);
-    done = (task.terminate_when_unhealthy ? !healthy : false) ||
-           (cur >= a.max_episode_steps);
-    info[0] = xv * task.forward_reward_weight;
-    info[1] = -ctrl_cost;
-    info[2] = -contact_cost;
-    info[3] = healthy_reward;
-    info[4] = x_after;
-    info[5] = y_after;
-    info[6] = sqrt(x_after * x_after + y_after * y_after);
-    info[7] = xv;
-    info[8] = yv;
+    cm.done[e] = 0;
+    cm.cur_step[e] = 0;
+    for (int i = task.obs_skip; i < A::kNQ; ++i) obs[i - task.obs_skip] = qpos[i];
+    for (int i = 0; i < A::kNV; ++i) obs_v[i] = qvel[i];
+    // a reset (mj_resetData) leaves cfrc_ext at zero; ant.h:248-258 clamps it
+    double z = 0.0;
+    z = z > task.contact_force_min ? z : task.contact_force_min;
+    z = z < task.contact_force_max ? z : task.contact_force_max;
+    for (int i = 0; i < ncf; ++i) obs_c[i] = z;
+    for (int i = 0; i < 9; ++i) ((double*)out.p[kKeyEnv0 + 1 + i])[row] = 0.0;  // info[6] = sqrt(0)
+    WriteCommon(out, row, e + a.id_offset, 0, false, 0.0f, a.max_episode_steps);
+    return;
   }
+  ++cur;
+  // lane layout: q = torso pose (7) + hip, ankle of leg l; v, w likewise (6 + 2)
+  T q[9], v[A4::kL], w[A4::kL], ctrl[2];
+  mj::static_for<0, 7>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    q[i] = (T)dev.qpos[(size_t)i * n + e];
+  });
+  mj::static_for<0, 6>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    v[i] = (T)dev.qvel[(size_t)i * n + e];
+    w[i] = (T)dev.warm[(size_t)i * n + e];
+  });
+  mj::static_for<0, 2>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    q[7 + c] = (T)dev.qpos[(size_t)(7 + 2 * l + c) * n + e];
+    v[6 + c] = (T)dev.qvel[(size_t)(6 + 2 * l + c) * n + e];
+    w[6 + c] = (T)dev.warm[(size_t)(6 + 2 * l + c) * n + e];
+  });
+  const double x_before = dev.lag[e], y_before = dev.lag[(size_t)n + e];
+  const double* act = action + (size_t)row * A::kNU;
+  // ctrl[u] drives dof CtrlDof(u): hip_4 ankle_4 hip_1 ankle_1 hip_2 ... (ant_envpool.xml:85-94)
+  mj::static_for<0, 2>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    const double ai = act[(2 + 2 * l + c) & 7];
+    ctrl[c] = (T)(ai < -1.0 ? -1.0 : (ai > 1.0 ? 1.0 : ai));
+  });
+  A4::Leg<T, bool> lg;
+  lg.sx = (l == 0 || l == 3) ? T(1) : T(-1);
+  lg.sy = l < 2 ? T(1) : T(-1);
+  lg.sxy = lg.sx * lg.sy;
+  lg.axs = (l & 1) ? T(1) : T(-1);
+  lg.alo = (l == 0 || l == 3) ? m.lo[1] : m.lo[3];
+  lg.ahi = (l == 0 || l == 3) ? m.hi[1] : m.hi[3];
+  lg.first = l == 0;
+  T lagx = T(0), lagy = T(0);
+  auto lds = [&](int slot) -> T& { return lds_buf[slot * kAntBlock + lane]; };
+  // mj_rnePostConstraint after the last mj_step (mujoco_env.h:145-147): cfrc_ext of the
+  // lane's stub / leg / ankle bodies, and of the torso body on the first lane
+  T cf[3][6], cft[6];
+  if constexpr (kWrench) {
+    for (int j = 0; j < 6; ++j) cft[j] = cf[0][j] = cf[1][j] = cf[2][j] = T(0);
+  }
+  T n_env = T(0);
+  int n_wave = 0;
+  for (int s = 0; s < task.frame_skip; ++s) {
+    A4::Step<unsigned, kWrench>(m, lg, scfg, q, v, w, ctrl, &lagx, &lagy, lds,
+                                kWrench && s == task.frame_skip - 1, cf, cft, &n_env, &n_wave);
+  }
+  const double x_after = (double)lagx, y_after = (double)lagy;
+  // new state; IsHealthy, ant.h:214-229
+  bool healthy = true;
+  mj::static_for<0, 2>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    const double qq = (double)q[7 + c], vv = (double)v[6 + c];
+    healthy = healthy && isfinite(qq) && isfinite(vv);
+    dev.qpos[(size_t)(7 + 2 * l + c) * n + e] = qq;
+    dev.qvel[(size_t)(6 + 2 * l + c) * n + e] = vv;
+    dev.warm[(size_t)(6 + 2 * l + c) * n + e] = (double)w[6 + c];
+    if (7 + 2 * l + c >= task.obs_skip) obs[7 + 2 * l + c - task.obs_skip] = qq;
+    obs_v[6 + 2 * l + c] = vv;
+  });
+  mj::static_for<0, 7>([&](auto ic) { healthy = healthy && isfinite((double)q[decltype(ic)::value]); });
+  mj::static_for<0, 6>([&](auto ic) { healthy = healthy && isfinite((double)v[decltype(ic)::value]); });
+  healthy = mj::All4(healthy);
+  const double z = (double)q[2];
+  if (z < task.healthy_z_min || z > task.healthy_z_max) healthy = false;
+  double contact_cost = 0.0;
+  if constexpr (kWrench) {  // ant.h:183-194 and :248-258
+    auto clampc = [&](double x) {  // cost: std::max(min_, std::min(max_, x))
+      x = task.contact_force_max < x ? task.contact_force_max : x;
+      return task.contact_force_min > x ? task.contact_force_min : x;
+    };
+    auto clampo = [&](double x) {  // obs: std::min(std::max(x, min_), max_)
+      x = x > task.contact_force_min ? x : task.contact_force_min;
+      return x < task.contact_force_max ? x : task.contact_force_max;
+    };
+    double part = 0.0;
+    for (int j = 0; j < 6; ++j) {
+      // the world body receives the opposite of every contact wrench
+      const double mine = (double)cf[0][j] + (double)cf[1][j] + (double)cf[2][j] + (double)cft[j];
+      const double world = -mj::Sum4(mine);
+      for (int b = 0; b < 3; ++b) {
+        const double x = (double)cf[b][j];
+        part += clampc(x) * clampc(x);
+        obs_c[(2 + 3 * l + b) * 6 + j - cf0] = clampo(x);
+      }
+      if (l == 0) {
+        const double x = (double)cft[j];
+        part += clampc(x) * clampc(x);
+        obs_c[6 + j - cf0] = clampo(x);
+        if (!task.exclude_worldbody) {
+          part += clampc(world) * clampc(world);
+          obs_c[j] = clampo(world);
+        }
+      }
+    }
+    contact_cost = task.contact_cost_weight * mj::Sum4(part);
+  } else {
+    // Ant-v3 (use_contact_force without post_constraint): cfrc_ext stays zero
+    if (ncf > 0) {
+      double zz = 0.0;
+      zz = zz > task.contact_force_min ? zz : task.contact_force_min;
+      zz = zz < task.contact_force_max ? zz : task.contact_force_max;
+      for (int i = l; i < ncf; i += 4) obs_c[i] = zz;
+    }
+  }
+  if (l != 0) return;
+  // per-env outputs: the first lane of the quad
+  mj::static_for<0, 7>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const double qq = (double)q[i];
+    dev.qpos[(size_t)i * n + e] = qq;
+    if (i >= task.obs_skip) obs[i - task.obs_skip] = qq;
+  });
+  mj::static_for<0, 6>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const double vv = (double)v[i];
+    dev.qvel[(size_t)i * n + e] = vv;
+    dev.warm[(size_t)i * n + e] = (double)w[i];
+    obs_v[i] = vv;
+  });
+  dev.lag[e] = x_after;
+  dev.lag[(size_t)n + e] = y_after;
+  // this env's Newton iterations + 1e4 x (those its wave executed + 1e3 x sphere classes visited)
+  dev.cost[e] = (double)n_env + 1.0e4 * (double)n_wave;
+  double ctrl_cost = 0.0;
+  for (int i = 0; i < A::kNU; ++i) ctrl_cost += task.ctrl_cost_weight * act[i] * act[i];  // ant.h:176-179
+  const double xv = (x_after - x_before) / task.dt;
+  const double yv = (y_after - y_before) / task.dt;
+  bool give = healthy;
+  if (task.legacy_healthy_reward) give = task.terminate_when_unhealthy || healthy;
+  const double healthy_reward = give ? task.healthy_reward : 0.0;
+  const float reward = static_cast<float>(xv * task.forward_reward_weight + healthy_reward -
+                                          ctrl_cost - contact_cost);
+  done = (task.terminate_when_unhealthy ? !healthy : false) || (cur >= a.max_episode_steps);
+  const double info[9] = {xv * task.forward_reward_weight, -ctrl_cost, -contact_cost,
+                          healthy_reward, x_after, y_after,
+                          sqrt(x_after * x_after + y_after * y_after), xv, yv};
   cm.done[e] = done ? 1 : 0;
   cm.cur_step[e] = cur;
-  // WriteState, ant.h:231-278
-  const int cf0 = task.exclude_worldbody ? 6 : 0;
-  const int ncf = task.use_contact_force ? kAntMjBodies * 6 - cf0 : 0;
-  const int nobs = A::kNQ + A::kNV - task.obs_skip + ncf;
-  const int S = task.frame_stack;
-  double* obs0 = (double*)out.p[kKeyEnv0] + (size_t)row * nobs * S;
-  double* newest = obs0 + (size_t)(S - 1) * nobs;
-  {
-    double* obs = newest;
-    for (int i = task.obs_skip; i < A::kNQ; ++i) *(obs++) = qpos[i];
-    for (int i = 0; i < A::kNV; ++i) *(obs++) = qvel[i];
-    // ant.h:248-258; a reset (mj_resetData) and Ant-v3 leave cfrc_ext at zero
-    const bool have = !reset && kWrench;
-    const double* cfr = dev.cfrc + (size_t)e * kAntMjBodies * 6;
-    for (int i = 0; i < ncf; ++i) {
-      double x = have ? cfr[cf0 + i] : 0.0;
-      x = x > task.contact_force_min ? x : task.contact_force_min;  // std::max(x, min_)
-      x = x < task.contact_force_max ? x : task.contact_force_max;  // std::min(.., max_)
-      *(obs++) = x;
-    }
-  }
-  if (S > 1) {  // FrameStackBuffer::Commit, envpool/mujoco/frame_stack.h:109-135
-    double* st = dev.stack + (size_t)e * S * nobs;
-    if (reset) {
-      for (int f = 0; f < S - 1; ++f) {
-        for (int i = 0; i < nobs; ++i) obs0[f * nobs + i] = newest[i];
-      }
-      for (int j = 0; j < S * nobs; ++j) st[j] = obs0[j];
-    } else {
-      for (int j = 0; j < (S - 1) * nobs; ++j) {
-        double x = st[j + nobs];
-        st[j] = x;
-        obs0[j] = x;
-      }
-      for (int i = 0; i < nobs; ++i) st[(S - 1) * nobs + i] = newest[i];
-    }
-  }
   for (int i = 0; i < 9; ++i) ((double*)out.p[kKeyEnv0 + 1 + i])[row] = info[i];
   WriteCommon(out, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
 }
@@ -249,7 +292,7 @@ __global__ void AntGetState(AntDev dev, CommonDev cm, const int* ids, int k, dou
     o[A::kNQ + A::kNV + j] = dev.warm[(size_t)j * n + e];
   }
   double* t = o + A::kNQ + 2 * A::kNV;
-  t[0] = 0;
+  t[0] = dev.cost[e];  // (oracle: time) profiling counters of the last step
   t[1] = dev.lag[e];
   t[2] = dev.lag[(size_t)n + e];
   t[3] = cm.done[e];
@@ -278,15 +321,12 @@ __global__ void AntSetState(AntDev dev, CommonDev cm, const int* ids, int k, con
 
 std::vector<KeySpec> AntKeys(const Config& cfg) {
   int no_pos = cfg.Get("exclude_current_positions_from_observation", 1) != 0;
-  int fs = (int)cfg.Get("frame_stack", 1);
   // ant.h:51-75 (obs 27/29 + 6 per body with use_contact_force); StackSpec, frame_stack.h:42-71
   int ncf = 0;
   if (cfg.Get("use_contact_force", 0) != 0) {
     ncf = 6 * (kAntMjBodies - (cfg.Get("exclude_worldbody_contact_forces", 0) != 0 ? 1 : 0));
   }
-  std::vector<int> oshape = {(no_pos ? 27 : 29) + ncf};
-  if (fs > 1) oshape.insert(oshape.begin(), fs);
-  std::vector<KeySpec> k = {{"obs", EPA_F64, oshape}};
+  std::vector<KeySpec> k = {{"obs", EPA_F64, StackedObsShape(cfg, (no_pos ? 27 : 29) + ncf)}};
   for (const char* name :
        {"info:reward_forward", "info:reward_ctrl", "info:reward_contact",
         "info:reward_survive", "info:x_position", "info:y_position",
@@ -300,10 +340,6 @@ class AntPool : public Pool {
  public:
   explicit AntPool(const Config& cfg)
       : Pool(cfg, AntKeys(cfg), KeySpec{"action", EPA_F64, {A::kNU}}, true) {
-    task_.frame_stack = (int)cfg.Get("frame_stack", 1);
-    if (task_.frame_stack < 1) {
-      throw std::invalid_argument("frame_stack must be greater than 0");
-    }
     task_.use_contact_force = cfg.Get("use_contact_force", 0) != 0;
     task_.post_constraint = cfg.Get("post_constraint", 0) != 0;
     task_.exclude_worldbody = cfg.Get("exclude_worldbody_contact_forces", 0) != 0;
@@ -330,25 +366,16 @@ class AntPool : public Pool {
     EPA_HIP(hipMalloc(&dev_.lag, sizeof(double) * 2 * n));
     EPA_HIP(hipMalloc(&dev_.nsaved, sizeof(double) * n));
     EPA_HIP(hipMalloc(&dev_.navail, n));
+    EPA_HIP(hipMalloc(&dev_.cost, sizeof(double) * n));
+    EPA_HIP(hipMemsetAsync(dev_.cost, 0, sizeof(double) * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.qpos, 0, sizeof(double) * A::kNQ * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.qvel, 0, sizeof(double) * A::kNV * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.warm, 0, sizeof(double) * A::kNV * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.lag, 0, sizeof(double) * 2 * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.nsaved, 0, sizeof(double) * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.navail, 0, n, stream_));
-    if (task_.use_contact_force && task_.post_constraint) {
-      EPA_HIP(hipMalloc(&dev_.cfrc, sizeof(double) * kAntMjBodies * 6 * n));
-      EPA_HIP(hipMemsetAsync(dev_.cfrc, 0, sizeof(double) * kAntMjBodies * 6 * n, stream_));
-    }
-    if (task_.frame_stack > 1) {
-      const int ncf = task_.use_contact_force
-                          ? 6 * (kAntMjBodies - (task_.exclude_worldbody ? 1 : 0)) : 0;
-      size_t sb = sizeof(double) * n * task_.frame_stack *
-                  (A::kNQ + A::kNV - task_.obs_skip + ncf);
-      EPA_HIP(hipMalloc(&dev_.stack, sb));
-      EPA_HIP(hipMemsetAsync(dev_.stack, 0, sb, stream_));
-    }
     InitCommon();
+    EnableObsStack();  // frame_stack > 1: generic ring (envpool/mujoco/frame_stack.h:74-146)
   }
   ~AntPool() override {
     (void)hipFree(dev_.qpos);
@@ -357,8 +384,7 @@ class AntPool : public Pool {
     (void)hipFree(dev_.lag);
     (void)hipFree(dev_.nsaved);
     (void)hipFree(dev_.navail);
-    if (dev_.stack) (void)hipFree(dev_.stack);
-    if (dev_.cfrc) (void)hipFree(dev_.cfrc);
+    (void)hipFree(dev_.cost);
   }
   int StateDim() const override { return kAntStateDim; }
   void GetState(const int* d_ids, int k, double* d_out) override {
@@ -374,7 +400,7 @@ class AntPool : public Pool {
   void Launch(const int* d_ids, int k, const void* d_action, bool force_reset,
               const OutPtrs& out) override {
     StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps, cfg_.env_id_offset};
-    int blocks = (k + kAntBlock - 1) / kAntBlock;
+    int blocks = (k + kAntEnvsPerBlock - 1) / kAntEnvsPerBlock;
     const double* act = static_cast<const double*>(d_action);
     const mj::SolverCfg<double> sd{50, 1e-13};
     const mj::SolverCfg<float> sf{12, 1e-6f};
