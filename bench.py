@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--task", default="HalfCheetah")
     ap.add_argument("--precision", default="fp64", choices=["fp32", "fp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE",
+                    help="extra pool parameter (A/B switches such as sort_by_cost=0)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (nccl = RCCL; gloo only to exercise the "
                          "multi-process path on a box with fewer GPUs than ranks)")
@@ -95,6 +97,9 @@ def main():
 
     n = args.num_envs
     params = {"precision": 1 if args.precision == "fp64" else 0}
+    for kv in args.param:
+        key, val = kv.split("=", 1)
+        params[key] = float(val)
     pool = DevicePool(args.task, n, seed=0, max_episode_steps=1000, device=dev_index,
                       env_id_offset=rank * n, params=params)
     adim = int(np.prod(pool.action_shape))

@@ -537,9 +537,9 @@ EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned
 // mj_fwdActuation + limit rows (mj_ant.cuh, AntFrontEnd).  q = torso pose (7,
 // replicated) + hip, ankle angle of the lane's leg; v, qfrc likewise (6 + 2).
 // Returns the wave-uniform mask of sphere classes inside the contact margin.
-template <typename T, typename V, typename B, typename Lds>
+template <typename U, typename T, typename V, typename B, typename Lds>
 EPA_HD unsigned FrontEnd(const AntModel<T>& m, const Leg<V, B>& lg, V* q, const V* v,
-                         const V* ctrl, Lds&& lds, Rows<V>& rows, V* qfrc) {
+                         const V* ctrl, Lds&& lds, Rows<V>& rows, V* qfrc, U* own) {
   constexpr int A0 = ant::Aux(0), F0 = ant::Foot(0);  // leg 0 is the (+, +) prototype
   auto put = [&](int base, Vec3<V> x) {
     lds(base) = x.x;
@@ -547,8 +547,11 @@ EPA_HD unsigned FrontEnd(const AntModel<T>& m, const Leg<V, B>& lg, V* q, const 
     lds(base + 2) = x.z;
   };
   unsigned mask = 0;
+  U mine = MaskFill(U(), 0u);  // classes inside the margin on this lane
   auto probe = [&](int w, V z, T radius) {
-    if (AnyWave(z - V(radius) < V(m.margin))) mask |= 1u << w;
+    const auto in = z - V(radius) < V(m.margin);
+    MaskSet(mine, in, w);
+    if (AnyWave(in)) mask |= 1u << w;
   };
   NormalizeQuatV(q + 3);  // mj_kinematics
   const Vec3<V> pos0 = {q[0], q[1], q[2]};
@@ -733,6 +736,7 @@ EPA_HD unsigned FrontEnd(const AntModel<T>& m, const Leg<V, B>& lg, V* q, const 
     rows.D[j] = Sel(sgn != V(0), Dj, V(0));
     rows.aref[j] = -V(m.con_B) * (sgn * v[6 + j]) - V(m.con_K) * imp * dist;
   });
+  *own = mine;
   return WaveUniform(mask);
 }
 
@@ -783,10 +787,12 @@ EPA_HD void Forward(const AntModel<T>& m, const Leg<V, B>& lg, const SolverCfg<T
   V qfrc[kL];
   Rows<V> rows;
   EPA_LDS_FENCE();
-  const unsigned sph = FrontEnd(m, lg, q, v, ctrl, lds, rows, qfrc);
+  U own;
+  const unsigned sph = FrontEnd(m, lg, q, v, ctrl, lds, rows, qfrc, &own);
   EPA_LDS_FENCE();
   Solve<U>(m, lg, lds, sph, rows, v, qfrc, cfg, qacc, n_env, n_wave);
-  *n_wave += 1000 * __builtin_popcount(sph);  // + 1000 x sphere classes the wave visits
+  // profiling / scheduling: + 1e3 x sphere classes the wave visits + 1e6 x those of this env
+  *n_wave += 1000 * __builtin_popcount(sph) + 1000000 * MaskCount4(own);
   if constexpr (kWrench) {
     if (wrench) ContactWrench(m, lg, lds, sph, v, qacc, cf, cf0);  // wave-uniform flag
   }

@@ -116,6 +116,7 @@ inline B4 MaskSame(const U4& a, const U4& b) {
   return {{a.v[0] == b.v[0], a.v[1] == b.v[1], a.v[2] == b.v[2], a.v[3] == b.v[3]}};
 }
 inline U4 MaskFill(U4, unsigned x) { return {{x, x, x, x}}; }
+inline int MaskCount4(const U4& m) { return __builtin_popcount(m.v[0] | m.v[1] | m.v[2] | m.v[3]); }
 template <typename T>
 inline Q4<T> Rsq(const Q4<T>& x) {
   Q4<T> r;
@@ -169,6 +170,7 @@ __device__ __forceinline__ double DppMov(double x) {
 #define EPA_QUAD_ADD(a, b) ((a) + (b))
 #define EPA_QUAD_MAX(a, b) ((a) > (b) ? (a) : (b))
 #define EPA_QUAD_AND(a, b) ((a) & (b))
+#define EPA_QUAD_OR(a, b) ((a) | (b))
 EPA_HD float Sum4(float x) {
   EPA_QUAD_REDUCE(x, EPA_QUAD_ADD);
   return x;
@@ -189,6 +191,12 @@ EPA_HD bool All4(bool c) {
   int x = c ? 1 : 0;
   EPA_QUAD_REDUCE(x, EPA_QUAD_AND);
   return x != 0;
+}
+// number of bits set in the OR of the quad's masks
+EPA_HD int MaskCount4(unsigned m) {
+  int x = (int)m;
+  EPA_QUAD_REDUCE(x, EPA_QUAD_OR);
+  return __builtin_popcount((unsigned)x);
 }
 EPA_HD bool IsFinite(float x) { return x - x == 0.0f; }  // false for NaN and +-inf
 EPA_HD bool IsFinite(double x) { return x - x == 0.0; }

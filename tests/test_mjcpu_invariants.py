@@ -99,15 +99,19 @@ def test_cheetah_stays_planar_and_ant_mirror_symmetry():
 
 
 def test_product_planar_code_matches_oracle_on_cpu():
-    """Host instantiation of the exact kernel source (mj_cheetah.cuh /
-    mj_ant.cuh) vs the oracle, teacher forced: two independent formulations."""
+    """Host instantiation of the exact kernel source (mj_cheetah.cuh; mj_ant4.cuh with
+    its lane quad emulated by Q4<double>) vs the oracle, teacher forced: two independent
+    formulations."""
     from oracle.orc import Oracle
 
     h = os.path.join(ROOT, "tests", "cpu_harness")
     for name in ("cheetah", "ant"):
         so = os.path.join(h, f"lib{name}_host.so")
         src = os.path.join(h, f"{name}_host.cpp")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        hdrs = [os.path.join(ROOT, "envpool_amd", "csrc", f) for f in
+                ("mj_cheetah.cuh", "mj_ant.cuh", "mj_ant4.cuh", "mj_quad.cuh", "mj_ant_model.h")]
+        newest = max(os.path.getmtime(f) for f in [src] + hdrs)
+        if not os.path.exists(so) or os.path.getmtime(so) < newest:
             subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so],
                            check=True)
     rng = np.random.default_rng(3)
@@ -143,6 +147,52 @@ def test_product_planar_code_matches_oracle_on_cpu():
                     L.cheetah_host_step(*args, 5, 0, *outs, ctypes.byref(it))
                 worst = max(worst, np.abs(np.concatenate([qo[skip:], vo]) - b["obs"][e]).max())
         assert worst < 1e-9, (task, worst)
+
+
+def test_product_ant_quad_layout_on_cpu():
+    """mj_ant4.cuh (one env per lane quad, Q4 emulation): the mirror structure it relies
+    on holds exactly for the compiled model, fp32 instantiation stays close to fp64, and the
+    Ant-v5 contact wrench (cfrc_ext of the last forward evaluation, assembled per lane and
+    reduced over the quad) matches the oracle's mj_rnePostConstraint."""
+    from oracle.orc import Oracle
+
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    so, src = os.path.join(h, "libant_host.so"), os.path.join(h, "ant_host.cpp")
+    hdrs = [os.path.join(ROOT, "envpool_amd", "csrc", f) for f in
+            ("mj_ant.cuh", "mj_ant4.cuh", "mj_quad.cuh", "mj_ant_model.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(so)
+    assert L.ant_host_symmetric() == 1
+    vp = ctypes.c_void_p
+    n, nq, nv, nu = 8, 15, 14, 8
+    # Ant-v5: use_contact_force + post_constraint, world body excluded (tests/test_gpu_mujoco.py)
+    extra = (5, 0.5, 1.0, 0.1, 0, 0, 0, 0, -1, 0, 0, 3, 1, 1, 1, 0)
+    orc = Oracle("Ant", n, seed=4, max_episode_steps=1000, extra=extra)
+    orc.reset()
+    rng = np.random.default_rng(8)
+    worst, worst32, nz = 0.0, 0.0, 0
+    for t in range(60):
+        st = orc.get_state()
+        act = rng.uniform(-1, 1, size=(n, nu))
+        b = orc.step(act)
+        for e in range(n):
+            if b["elapsed_step"][e, 0] == 0:
+                continue
+            q, v, w = st[e, :nq].copy(), st[e, nq:nq + nv].copy(), st[e, nq + nv:nq + 2 * nv].copy()
+            qo, vo, wo, lag, cf = np.zeros(nq), np.zeros(nv), np.zeros(nv), np.zeros(2), np.zeros(84)
+            args = [x.ctypes.data_as(vp) for x in (q, v, w, np.ascontiguousarray(act[e]))]
+            L.ant_host_step_wrench(*args, 5, *[x.ctypes.data_as(vp) for x in (qo, vo, wo, lag, cf)])
+            obs = np.concatenate([qo[2:], vo, np.clip(cf[6:], -1.0, 1.0)])
+            worst = max(worst, float(np.abs(obs - b["obs"][e]).max()))
+            nz += int((np.abs(cf[6:]) > 0).sum())
+            q32, v32, w32, it = np.zeros(nq), np.zeros(nv), np.zeros(nv), ctypes.c_int(0)
+            L.ant_host_step(*args, 5, 1, *[x.ctypes.data_as(vp) for x in (q32, v32, w32, lag)],
+                            ctypes.byref(it))
+            worst32 = max(worst32, float(np.median(np.abs(np.concatenate([q32[2:], v32]) - b["obs"][e, :27]))))
+    assert nz > 100, nz          # contacts were really exercised
+    assert worst < 1e-9, worst
+    assert worst32 < 1e-4, worst32
 
 
 def test_product_pendulum_code_matches_oracle_on_cpu():

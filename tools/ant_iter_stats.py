@@ -17,11 +17,13 @@ for t in range(70):
     pool.send(ids, act); out = pool.recv_dict()
     if t >= 30:
         c = pool.get_state()[:, 43]
+        kc = np.floor(c / 1e10)
+        c = c - 1e10 * kc
         w = np.floor(c / 1e4)
         it_env = c - 1e4 * w
         cls = np.floor(w / 1e3)
         it_wave = w - 1e3 * cls
-        hist.append((it_env, it_wave, cls, out["elapsed_step"].ravel().copy()))
+        hist.append((it_env, it_wave, cls, out["elapsed_step"].ravel().copy(), kc))
 it_env = np.array([h[0] for h in hist]); it_wave = np.array([h[1] for h in hist]); cls = np.array([h[2] for h in hist])
 el = np.array([h[3] for h in hist])
 live = el > 0
@@ -39,3 +41,16 @@ order = np.argsort(a, axis=1, kind="stable")
 srt = np.take_along_axis(b, order, axis=1).reshape(len(b), -1, 16).max(axis=2)
 print(f"corr(iters[t], iters[t+1]) = {cc:.3f}; mean over waves of max-over-16-envs: now {now:.1f}, "
       f"grouped by last step's count {srt.mean():.1f} (max wave {srt.max():.0f}), env mean {b.mean():.1f}")
+
+kc = np.array([h[4] for h in hist]).reshape(len(hist), -1, 16)[:, :, 0]  # kilo-clocks per wave
+print(f"wave duration (kilo core clocks): mean {kc.mean():.0f} p10 {np.percentile(kc,10):.0f} p50 {np.median(kc):.0f} "
+      f"p90 {np.percentile(kc,90):.0f} p99 {np.percentile(kc,99):.0f} max {kc.max():.0f}")
+print(f"corr(duration, iterations executed) {np.corrcoef(kc.ravel(), wv.ravel())[0,1]:.3f}; "
+      f"corr(duration, classes visited) {np.corrcoef(kc.ravel(), cv.ravel())[0,1]:.3f}")
+A = np.stack([np.ones(kc.size), wv.ravel(), cv.ravel()], 1)
+coef, *_ = np.linalg.lstsq(A, kc.ravel(), rcond=None)
+print(f"fit: kclocks = {coef[0]:.0f} + {coef[1]:.2f} * iterations + {coef[2]:.2f} * class visits; residual rms {np.std(kc.ravel() - A @ coef):.0f}")
+print(f"wave persistence: corr(duration[t], duration[t+1]) {np.corrcoef(kc[:-1].ravel(), kc[1:].ravel())[0,1]:.3f}; "
+      f"corr(classes[t], classes[t+1]) {np.corrcoef(cv[:-1].ravel(), cv[1:].ravel())[0,1]:.3f}")
+tot = kc.sum(axis=1).mean()
+print(f"sum of wave durations / 1024 SIMDs = {tot/1024:.0f} kclocks; longest wave {kc.max(axis=1).mean():.0f} kclocks")

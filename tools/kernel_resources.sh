@@ -17,5 +17,5 @@ for l in sys.stdin:
     m=re.search(r"remark: +([A-Za-z \[\]/]+): (\d+)",l)
     if m and cur is not None: cur[m.group(1).strip()]=int(m.group(2))
 for r in rows:
-    print("%-92s V=%3d A=%3d sgprspill=%3d vgprspill=%4d scratch=%5d lds=%6d occ=%d"%(r["name"],r.get("VGPRs",0),r.get("AGPRs",0),r.get("SGPRs Spill",0),r.get("VGPRs Spill",0),r.get("ScratchSize [bytes/lane]",0),r.get("LDS Size [bytes/block]",0),r.get("Occupancy [waves/SIMD]",0)))
+    print("%-62s V=%3d A=%3d sgprspill=%3d vgprspill=%4d scratch=%5d lds=%6d occ=%d"%(r["name"][:60],r.get("VGPRs",0),r.get("AGPRs",0),r.get("SGPRs Spill",0),r.get("VGPRs Spill",0),r.get("ScratchSize [bytes/lane]",0),r.get("LDS Size [bytes/block]",0),r.get("Occupancy [waves/SIMD]",0)))
 '
