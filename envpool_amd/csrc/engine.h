@@ -211,6 +211,19 @@ class Pool {
   std::vector<hipEvent_t> timer_pool_;
 };
 
+// Diagnostic per-wave trace of a family's step kernel: when the environment variable
+// `env` names a file, `d` is a device buffer of 6 x int64 per wave that the kernel fills
+// (wall clock begin / end at 100 MHz, core clock begin / end, two family-specific words)
+// and the buffer of the LAST launch is written to that file when the pool is destroyed
+// (tools/ant_trace_stats.py, tools/planar_trace_stats.py).  Off (d == nullptr) otherwise.
+struct WaveTrace {
+  long long* d{nullptr};
+  size_t waves{0};
+  std::string file;
+  void Init(const char* env, size_t n_waves, hipStream_t s);
+  void DumpAndFree();
+};
+
 // obs key shape with the optional leading frame_stack dimension (StackSpec,
 // envpool/mujoco/frame_stack.h:42-71); throws like the reference on frame_stack < 1
 std::vector<int> StackedObsShape(const Config& cfg, int nobs);

@@ -164,6 +164,27 @@ Pool::~Pool() {
   if (d2h_stream_) (void)hipStreamDestroy(d2h_stream_);
 }
 
+void WaveTrace::Init(const char* env, size_t n_waves, hipStream_t s) {
+  const char* f = getenv(env);
+  if (!f || !*f) return;
+  file = f;
+  waves = n_waves;
+  EPA_HIP(hipMalloc(&d, sizeof(long long) * 6 * waves));
+  EPA_HIP(hipMemsetAsync(d, 0, sizeof(long long) * 6 * waves, s));
+}
+void WaveTrace::DumpAndFree() {
+  if (!d) return;
+  std::vector<long long> h(6 * waves);
+  if (hipMemcpy(h.data(), d, sizeof(long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+    if (FILE* f = fopen(file.c_str(), "wb")) {
+      fwrite(h.data(), sizeof(long long), h.size(), f);
+      fclose(f);
+    }
+  }
+  (void)hipFree(d);
+  d = nullptr;
+}
+
 // ---- generic observation frame stack ---------------------------------------------
 std::vector<int> StackedObsShape(const Config& cfg, int nobs) {
   int s = (int)cfg.Get("frame_stack", 1);

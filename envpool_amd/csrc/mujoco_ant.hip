@@ -406,12 +406,8 @@ class AntPool : public Pool {
     EPA_HIP(hipMemsetAsync(dev_.cost, 0, sizeof(double) * n, stream_));
     EPA_HIP(hipMalloc(&dev_.key, sizeof(unsigned) * n));
     EPA_HIP(hipMemsetAsync(dev_.key, 0, sizeof(unsigned) * n, stream_));
-    if (const char* tf = getenv("EPA_ANT_TRACE")) {
-      trace_file_ = tf;
-      trace_waves_ = (n + kAntEnvsPerBlock - 1) / kAntEnvsPerBlock;
-      EPA_HIP(hipMalloc(&dev_.trace, sizeof(long long) * 6 * trace_waves_));
-      EPA_HIP(hipMemsetAsync(dev_.trace, 0, sizeof(long long) * 6 * trace_waves_, stream_));
-    }
+    trace_.Init("EPA_ANT_TRACE", (n + kAntEnvsPerBlock - 1) / kAntEnvsPerBlock, stream_);
+    dev_.trace = trace_.d;
     // launch-order sort (see Launch): row keys in / out, row indices in / out
     sort_on_ = cfg.Get("sort_by_cost", 1) != 0;
     EPA_HIP(hipMalloc(&keys_in_, sizeof(unsigned) * n));
@@ -439,17 +435,7 @@ class AntPool : public Pool {
     (void)hipFree(dev_.lag);
     (void)hipFree(dev_.nsaved);
     (void)hipFree(dev_.navail);
-    if (dev_.trace) {
-      std::vector<long long> h(6 * trace_waves_);
-      if (hipMemcpy(h.data(), dev_.trace, sizeof(long long) * h.size(), hipMemcpyDeviceToHost) ==
-          hipSuccess) {
-        if (FILE* f = fopen(trace_file_.c_str(), "wb")) {
-          fwrite(h.data(), sizeof(long long), h.size(), f);
-          fclose(f);
-        }
-      }
-      (void)hipFree(dev_.trace);
-    }
+    trace_.DumpAndFree();
     (void)hipFree(dev_.cost);
     (void)hipFree(dev_.key);
     (void)hipFree(keys_in_);
@@ -512,8 +498,7 @@ class AntPool : public Pool {
  private:
   AntDev dev_{};
   bool sort_on_{true};
-  std::string trace_file_;
-  size_t trace_waves_{0};
+  WaveTrace trace_;
   unsigned *keys_in_{nullptr}, *keys_out_{nullptr};
   int *iota_{nullptr}, *order_{nullptr};
   void* sort_tmp_{nullptr};

@@ -42,6 +42,10 @@ struct CheetahDev {
   double* stack;           // [N][frame_stack * nobs] obs ring (frame_stack > 1 only)
   double* nsaved;          // normal_distribution::_M_saved
   unsigned char* navail;   // normal_distribution::_M_saved_available
+  // diagnostic (EPA_PLANAR_TRACE=<file>): per wave of the last launch {wall clock begin,
+  // end (100 MHz), core clock begin, end, Newton iterations the wave executed (sum over
+  // mj_steps of the slowest lane's count), HW_ID}; nullptr otherwise
+  long long* trace;
 };
 
 struct CheetahTask {
@@ -152,15 +156,34 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
       }
     });
     auto lds = [&](int slot) -> T& { return lds_buf[slot * kCheetahBlock + lane]; };
-    int iters = 0;
+    int iters = 0, wave_iters = 0;
+    const long long c_begin = dev.trace ? clock64() : 0, w_begin = dev.trace ? wall_clock64() : 0;
     for (int s = 0; s < task.frame_skip; ++s) {  // mujoco_env.h:142-144
+      int it;
       if constexpr (kWalker) {
-        iters += mj::PlanarStepRK4(m, scfg, q, v, w, ctrl, lds);
+        it = mj::PlanarStepRK4(m, scfg, q, v, w, ctrl, lds);
       } else {
-        iters += mj::CheetahStep(m, scfg, q, v, w, ctrl, lds);
+        it = mj::CheetahStep(m, scfg, q, v, w, ctrl, lds);
+      }
+      iters += it;
+      if (dev.trace) {
+        for (int d = 1; d < 64; d <<= 1) {
+          const int o = __shfl_xor(it, d);
+          it = o > it ? o : it;
+        }
+        wave_iters += it;
       }
     }
     dev.iters[e] = iters;
+    if (dev.trace && lane == 0) {
+      long long* tr = dev.trace + (size_t)blockIdx.x * 6;
+      tr[0] = w_begin;
+      tr[1] = wall_clock64();
+      tr[2] = c_begin;
+      tr[3] = clock64();
+      tr[4] = wave_iters;
+      tr[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+    }
     const double x_after = x_before + (double)q[0];
     xv = (x_after - x_before) / task.dt;  // half_cheetah.h:148-149
     qpos[0] = x_after;
@@ -355,6 +378,8 @@ class CheetahPool : public Pool {
     EPA_HIP(hipMalloc(&dev_.nsaved, sizeof(double) * n));
     EPA_HIP(hipMalloc(&dev_.navail, n));
     EPA_HIP(hipMalloc(&dev_.iters, sizeof(int) * n));
+    trace_.Init("EPA_PLANAR_TRACE", (n + kCheetahBlock - 1) / kCheetahBlock, stream_);
+    dev_.trace = trace_.d;
     if (task_.frame_stack > 1) {
       size_t sb = sizeof(double) * n * task_.frame_stack * (2 * kNV - task_.obs_skip);
       EPA_HIP(hipMalloc(&dev_.stack, sb));
@@ -369,6 +394,7 @@ class CheetahPool : public Pool {
     InitCommon();
   }
   ~CheetahPool() override {
+    trace_.DumpAndFree();
     (void)hipFree(dev_.qpos);
     (void)hipFree(dev_.qvel);
     (void)hipFree(dev_.warm);
@@ -415,6 +441,7 @@ class CheetahPool : public Pool {
 
  private:
   CheetahDev dev_{};
+  WaveTrace trace_;
   int model_id_;
   CheetahTask task_{};
   bool fp64_{false};
