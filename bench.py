@@ -151,6 +151,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    reset_ms = None
+    numpy_api = None
+    if world == 1:
+        # (a) one step in which EVERY env resets (mt19937 draws + state init + reset frame):
+        #     the spike an episode boundary costs, outside the steady-state figure above
+        pool.set_timing(True)
+        for _ in range(3):
+            pool.send_device(None)
+            pool.recv_device()
+        pool.synchronize()
+        reset_ms, _ = pool.kernel_time_ms()
+        pool.set_timing(False)
+        # (b) T_numpy_api: the reference-compatible host path -- numpy actions in
+        #     (H2D), every state key out as numpy (D2H) -- PCIe inclusive; never `value`
+        ids = np.arange(rank * n, rank * n + n, dtype=np.int32)
+        rng = np.random.default_rng(0)
+        hact = [rng.uniform(-1, 1, size=(n, adim)) for _ in range(4)]
+        for i in range(3):
+            pool.send(ids, hact[i % 4])
+            pool.recv()
+        k_np = max(5, min(args.steps, 50))
+        t1 = time.perf_counter()
+        for i in range(k_np):
+            pool.send(ids, hact[i % 4])
+            pool.recv()
+        dt_np = time.perf_counter() - t1
+        numpy_api = {"value": n * k_np / dt_np, "unit": "env-steps/s", "ms_per_step": 1e3 * dt_np / k_np,
+                     "steps": k_np, "note": "send(numpy) + recv() -> numpy, PCIe inclusive"}
+
     if rank == 0:
         total_env_steps = n * world * args.steps
         value = total_env_steps / elapsed
@@ -164,7 +193,7 @@ def main():
         # counted fp32 flops / env-step from the kernel's ISA
         achieved_gbs = alg_bytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # HBM traffic and flop counts come from the committed rocprofv3 PMC passes of
-        # this same command (tools/profile_bench.sh -> profiles/r1_pmc.json): PMC
+        # this same command (tools/profile_bench.sh -> profiles/pmc.json): PMC
         # collection needs its own rocprofv3 runs and cannot happen inside the bench.
         kbase = ("AntStepKernel" if args.task == "Ant" else
                  "HumanoidStepKernel" if args.task.startswith("Humanoid") else "CheetahStepKernel")
@@ -174,8 +203,8 @@ def main():
             kname += f"[{args.task}]"
         pmc = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc.json")) as f:
-                pmc = json.load(f).get(kname, {})
+            with open(os.path.join(ROOT, "profiles", "pmc.json")) as f:
+                pmc = json.load(f).get(f"{kname}@{n}", {})
         except OSError:
             pass
         traffic = None
@@ -186,7 +215,27 @@ def main():
             tf = pmc["flops_per_launch"] / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
             valu = {"achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf,
                     "flops_per_env_step": pmc["flops_per_env_step"],
-                    "note": "fp VALU issue is the roofline that binds this kernel"}
+                    "flops_source": pmc.get("source")}
+        hbm = {"achieved": achieved_gbs, "peak": 8000.0, "unit": "GB/s",
+               "frac": achieved_gbs / 8000.0,
+               "algorithmic_bytes_per_env_step": alg_bytes,
+               "note": "algorithmic bytes / kernel time, the fraction BASELINE.md asks for"}
+        humanoid = args.task.startswith("Humanoid")
+        if humanoid or valu is None:
+            # Humanoid streams its workspace through HBM: HBM binds.  Without
+            # PMC flop counts for this exact configuration only the HBM figure can be stated.
+            roof = {"bound": "hbm", **{k: hbm[k] for k in ("achieved", "peak", "unit", "frac")},
+                    "traffic": traffic, "valu": valu}
+        else:
+            # the mj_step kernels are fp VALU-issue bound (~65 flop per algorithmic byte, far
+            # above machine balance): that roofline is the headline object, HBM is secondary
+            roof = {"bound": "valu", **{k: valu[k] for k in ("achieved", "peak", "unit", "frac")},
+                    "flops_per_env_step": valu["flops_per_env_step"],
+                    "flops_source": valu["flops_source"], "traffic": traffic, "hbm": hbm}
+        roof.update({"kernel": kbase, "kernel_ms": kernel_ms, "launches": launches,
+                     "algorithmic_bytes_per_env_step": alg_bytes,
+                     "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC passes of "
+                                     "this command (profiles/pmc.json; FETCH_SIZE x2 + WRITE_SIZE)"})
         out = {
             "metric": f"env steps/sec (raw FPS) at num_envs={n}, {args.task}-v4",
             "value": value,
@@ -207,25 +256,11 @@ def main():
                 "frames_per_sec": value * frame_skip,
                 "sharding": f"env ids sharded over {world} GPU(s), no collective",
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved_gbs,
-                "peak": 8000.0,
-                "unit": "GB/s",
-                "frac": achieved_gbs / 8000.0,
-                "traffic": traffic,
-                "valu": valu,
-                "kernel": kbase,
-                "kernel_ms": kernel_ms,
-                "launches": launches,
-                "algorithmic_bytes_per_env_step": alg_bytes,
-                "note": ("per-env workspace streamed through HBM (a 23-dof tree does not fit a lane's "
-                         "registers): `traffic` is far above the algorithmic bytes by design, see "
-                         "DESIGN.md K3c") if args.task.startswith("Humanoid") else
-                        ("physics kernel is VALU/latency-bound, not HBM-bound "
-                         "(~65 flop/B counted); HBM fraction reported as BASELINE.md asks"),
-            },
+            "roofline": roof,
         }
+        if world == 1:
+            out["reset_step_ms"] = reset_ms
+            out["numpy_api"] = numpy_api
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.task)
         print(json.dumps(out))

@@ -791,7 +791,7 @@ EPA_HD void Forward(const AntModel<T>& m, const Leg<V, B>& lg, const SolverCfg<T
   const unsigned sph = FrontEnd(m, lg, q, v, ctrl, lds, rows, qfrc, &own);
   EPA_LDS_FENCE();
   Solve<U>(m, lg, lds, sph, rows, v, qfrc, cfg, qacc, n_env, n_wave);
-  // profiling / scheduling: + 1e3 x sphere classes the wave visits + 1e6 x those of this env
+  // profiling: + 1e3 x sphere classes the wave visits + 1e6 x those of this env
   *n_wave += 1000 * __builtin_popcount(sph) + 1000000 * MaskCount4(own);
   if constexpr (kWrench) {
     if (wrench) ContactWrench(m, lg, lds, sph, v, qacc, cf, cf0);  // wave-uniform flag

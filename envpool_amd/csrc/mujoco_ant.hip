@@ -19,8 +19,6 @@
 // env's normal_distribution saved value.  Lane l of a quad loads / stores the
 // torso part (replicated) and the two dofs of leg l; lane 0 writes what is per env.
 #define EPA_SINCOS_MODE 1
-#include <hipcub/hipcub.hpp>
-
 #include "device_common.cuh"
 #include "engine.h"
 #include "mj_ant4.cuh"
@@ -44,9 +42,6 @@ struct AntDev {
   double* nsaved;
   unsigned char* navail;
   double* cost;  // [N] profiling: Newton iterations of the last step, see AntGetState
-  // [N] scheduling key: (forward pass, sphere class) pairs in which the env had a sphere
-  // inside the contact margin during its last step -- what its next step will cost
-  unsigned* key;
   // diagnostic (EPA_ANT_TRACE=<file>): per wave of the last launch {wall clock begin, end
   // (100 MHz), core clock begin, end, slot, HW_ID}; nullptr otherwise
   long long* trace;
@@ -77,8 +72,8 @@ constexpr int kAntWavesPerEu = sizeof(T) == 4 ? 2 : 1;
 template <typename T, bool kWrench>
 __global__ __launch_bounds__(kAntBlock)
 __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void AntStepKernel(
-    AntDev dev, CommonDev cm, StepArgs a, const int* __restrict__ order,
-    const double* __restrict__ action, OutPtrs out, AntTask task, mj::SolverCfg<T> scfg) {
+    AntDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
+    AntTask task, mj::SolverCfg<T> scfg) {
   constexpr A::AntModel<T> m = A::CastAntModel<T>(kAntModelConst);
   // lane-private LDS block [slot][lane]: local M and the contact geometry of the
   // current forward pass (mj_ant4.cuh, FrontEnd)
@@ -86,10 +81,8 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
   const int lane = threadIdx.x;
   const int l = lane & 3;  // the leg this lane owns
   const int n = cm.n;
-  const int slot = blockIdx.x * kAntEnvsPerBlock + (lane >> 2);
-  if (slot >= a.k) return;  // whole quads leave together
-  // `order` (AntPool::Launch): batch rows sorted by predicted cost, most expensive first
-  const int row = order ? order[slot] : slot;
+  const int row = blockIdx.x * kAntEnvsPerBlock + (lane >> 2);
+  if (row >= a.k) return;  // whole quads leave together
   const int e = a.ids ? a.ids[row] - a.id_offset : row;
   bool done = cm.done[e] != 0;
   int cur = cm.cur_step[e];
@@ -133,7 +126,6 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
     dev.lag[(size_t)n + e] = qpos[1];
     cm.done[e] = 0;
     cm.cur_step[e] = 0;
-    dev.key[e] = 0;
     for (int i = task.obs_skip; i < A::kNQ; ++i) obs[i - task.obs_skip] = qpos[i];
     for (int i = 0; i < A::kNV; ++i) obs_v[i] = qvel[i];
     // a reset (mj_resetData) leaves cfrc_ext at zero; ant.h:248-258 clamps it
@@ -189,8 +181,10 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
   }
   T n_env = T(0);
   int n_wave = 0;
+#ifdef EPA_WAVE_TRACE  // diagnostic build only (tools/build_trace_lib.sh)
   const long long t_begin = clock64();
   const long long w_begin = wall_clock64();
+#endif
   for (int s = 0; s < task.frame_skip; ++s) {
     A4::Step<unsigned, kWrench>(m, lg, scfg, q, v, w, ctrl, &lagx, &lagy, lds,
                                 kWrench && s == task.frame_skip - 1, cf, cft, &n_env, &n_wave);
@@ -272,18 +266,19 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
   dev.lag[(size_t)n + e] = y_after;
   // this env's Newton iterations + 1e4 x (those its wave executed + 1e3 x sphere classes visited)
   // + 1e10 x thousands of core clocks the wave spent in the physics
-  dev.cost[e] = (double)n_env + 1.0e4 * (double)(n_wave % 1000000) +
-                1.0e10 * (double)((clock64() - t_begin) / 1000);
-  dev.key[e] = (unsigned)(n_wave / 1000000);
+  dev.cost[e] = (double)n_env + 1.0e4 * (double)(n_wave % 1000000);
+#ifdef EPA_WAVE_TRACE
+  dev.cost[e] += 1.0e10 * (double)((clock64() - t_begin) / 1000);
   if (dev.trace && lane == 0) {
     long long* tr = dev.trace + (size_t)blockIdx.x * 6;
     tr[0] = w_begin;
     tr[1] = wall_clock64();
     tr[2] = t_begin;
     tr[3] = clock64();
-    tr[4] = slot;
+    tr[4] = row;
     tr[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
   }
+#endif
   double ctrl_cost = 0.0;
   for (int i = 0; i < A::kNU; ++i) ctrl_cost += task.ctrl_cost_weight * act[i] * act[i];  // ant.h:176-179
   const double xv = (x_after - x_before) / task.dt;
@@ -301,17 +296,6 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
   cm.cur_step[e] = cur;
   for (int i = 0; i < 9; ++i) ((double*)out.p[kKeyEnv0 + 1 + i])[row] = info[i];
   WriteCommon(out, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
-}
-
-// scheduling keys of the batch rows (rows with explicit env ids)
-__global__ void AntGatherKeys(const unsigned* __restrict__ key, const int* __restrict__ ids,
-                              int id_offset, int k, unsigned* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < k) out[i] = key[ids[i] - id_offset];
-}
-__global__ void AntIota(int* p, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = i;
 }
 
 // flat state like oracle/mjcpu: qpos[15] qvel[14] warm[14] time xlag ylag done
@@ -404,27 +388,6 @@ class AntPool : public Pool {
     EPA_HIP(hipMalloc(&dev_.navail, n));
     EPA_HIP(hipMalloc(&dev_.cost, sizeof(double) * n));
     EPA_HIP(hipMemsetAsync(dev_.cost, 0, sizeof(double) * n, stream_));
-    EPA_HIP(hipMalloc(&dev_.key, sizeof(unsigned) * n));
-    EPA_HIP(hipMemsetAsync(dev_.key, 0, sizeof(unsigned) * n, stream_));
-    trace_.Init("EPA_ANT_TRACE", (n + kAntEnvsPerBlock - 1) / kAntEnvsPerBlock, stream_);
-    dev_.trace = trace_.d;
-    // launch-order sort (see Launch): row keys in / out, row indices in / out
-    sort_on_ = cfg.Get("sort_by_cost", 1) != 0;
-    EPA_HIP(hipMalloc(&keys_in_, sizeof(unsigned) * n));
-    EPA_HIP(hipMalloc(&keys_out_, sizeof(unsigned) * n));
-    EPA_HIP(hipMalloc(&iota_, sizeof(int) * n));
-    EPA_HIP(hipMalloc(&order_, sizeof(int) * n));
-    hipLaunchKernelGGL(AntIota, dim3((n + 255) / 256), dim3(256), 0, stream_, iota_, (int)n);
-    EPA_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, sort_tmp_bytes_, keys_in_,
-                                                         keys_out_, iota_, order_, (int)n, 0, 8,
-                                                         stream_));
-    EPA_HIP(hipMalloc(&sort_tmp_, sort_tmp_bytes_));
-    EPA_HIP(hipMemsetAsync(dev_.qpos, 0, sizeof(double) * A::kNQ * n, stream_));
-    EPA_HIP(hipMemsetAsync(dev_.qvel, 0, sizeof(double) * A::kNV * n, stream_));
-    EPA_HIP(hipMemsetAsync(dev_.warm, 0, sizeof(double) * A::kNV * n, stream_));
-    EPA_HIP(hipMemsetAsync(dev_.lag, 0, sizeof(double) * 2 * n, stream_));
-    EPA_HIP(hipMemsetAsync(dev_.nsaved, 0, sizeof(double) * n, stream_));
-    EPA_HIP(hipMemsetAsync(dev_.navail, 0, n, stream_));
     InitCommon();
     EnableObsStack();  // frame_stack > 1: generic ring (envpool/mujoco/frame_stack.h:74-146)
   }
@@ -437,12 +400,6 @@ class AntPool : public Pool {
     (void)hipFree(dev_.navail);
     trace_.DumpAndFree();
     (void)hipFree(dev_.cost);
-    (void)hipFree(dev_.key);
-    (void)hipFree(keys_in_);
-    (void)hipFree(keys_out_);
-    (void)hipFree(iota_);
-    (void)hipFree(order_);
-    (void)hipFree(sort_tmp_);
   }
   int StateDim() const override { return kAntStateDim; }
   void GetState(const int* d_ids, int k, double* d_out) override {
@@ -463,30 +420,9 @@ class AntPool : public Pool {
     const mj::SolverCfg<double> sd{50, 1e-13};
     const mj::SolverCfg<float> sf{12, 1e-6f};
     const bool wrench = task_.use_contact_force && task_.post_constraint;
-    // Launch order.  A wave's cost is set by the sphere classes ANY of its 16 envs has in
-    // contact (measured: duration = 16.5 kclk x Newton iterations + 20 kclk x class visits,
-    // class visits explain r = 0.94 of the spread; the slowest wave of a launch takes 2.1x
-    // the mean and the count persists from step to step, r = 0.64).  So the rows are
-    // visited in descending order of their envs' last count: envs with many contacts share
-    // waves (tighter unions), and the long waves start first instead of landing in the last
-    // round of the launch.  Stable 8-bit radix sort: deterministic, ~15 us on the stream.
-    // Results do not depend on the order (rows are written by row index).
-    const int* order = nullptr;
-    if (sort_on_ && !force_reset && k > 16 * kAntEnvsPerBlock) {
-      const unsigned* keys = dev_.key;
-      if (d_ids) {
-        hipLaunchKernelGGL(AntGatherKeys, dim3((k + 255) / 256), dim3(256), 0, stream_, dev_.key,
-                           d_ids, cfg_.env_id_offset, k, keys_in_);
-        keys = keys_in_;
-      }
-      size_t bytes = sort_tmp_bytes_;
-      EPA_HIP(hipcub::DeviceRadixSort::SortPairsDescending(sort_tmp_, bytes, keys, keys_out_, iota_,
-                                                           order_, k, 0, 8, stream_));
-      order = order_;
-    }
 #define EPA_LAUNCH_ANT(T, W, SC)                                                          \
   hipLaunchKernelGGL((AntStepKernel<T, W>), dim3(blocks), dim3(kAntBlock), 0, stream_, dev_, \
-                     common_, a, order, act, out, task_, SC)
+                     common_, a, act, out, task_, SC)
     if (fp64_) {
       if (wrench) EPA_LAUNCH_ANT(double, true, sd); else EPA_LAUNCH_ANT(double, false, sd);
     } else {
@@ -497,12 +433,7 @@ class AntPool : public Pool {
 
  private:
   AntDev dev_{};
-  bool sort_on_{true};
   WaveTrace trace_;
-  unsigned *keys_in_{nullptr}, *keys_out_{nullptr};
-  int *iota_{nullptr}, *order_{nullptr};
-  void* sort_tmp_{nullptr};
-  size_t sort_tmp_bytes_{0};
   A::AntModel<double> model_;
   AntTask task_{};
   bool fp64_{true};

@@ -156,8 +156,12 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
       }
     });
     auto lds = [&](int slot) -> T& { return lds_buf[slot * kCheetahBlock + lane]; };
-    int iters = 0, wave_iters = 0;
+    int iters = 0;
+#ifdef EPA_WAVE_TRACE  // diagnostic build only (tools/build_trace_lib.sh): the fp64 kernel sits
+    // at the 512-register limit and pays 4 % for carrying these values
+    int wave_iters = 0;
     const long long c_begin = dev.trace ? clock64() : 0, w_begin = dev.trace ? wall_clock64() : 0;
+#endif
     for (int s = 0; s < task.frame_skip; ++s) {  // mujoco_env.h:142-144
       int it;
       if constexpr (kWalker) {
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
         it = mj::CheetahStep(m, scfg, q, v, w, ctrl, lds);
       }
       iters += it;
+#ifdef EPA_WAVE_TRACE
       if (dev.trace) {
         for (int d = 1; d < 64; d <<= 1) {
           const int o = __shfl_xor(it, d);
@@ -173,8 +178,10 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
         }
         wave_iters += it;
       }
+#endif
     }
     dev.iters[e] = iters;
+#ifdef EPA_WAVE_TRACE
     if (dev.trace && lane == 0) {
       long long* tr = dev.trace + (size_t)blockIdx.x * 6;
       tr[0] = w_begin;
@@ -184,6 +191,7 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
       tr[4] = wave_iters;
       tr[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
     }
+#endif
     const double x_after = x_before + (double)q[0];
     xv = (x_after - x_before) / task.dt;  // half_cheetah.h:148-149
     qpos[0] = x_after;

@@ -7,7 +7,7 @@ sys.path.insert(0, ".")
 from envpool_amd.core.device_pool import DevicePool
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
-pool = DevicePool("Ant", n, seed=0, max_episode_steps=1000, params={"precision": 1})
+pool = DevicePool("Ant", n, seed=0, max_episode_steps=1000, params={"precision": 1})  # needs the EPA_WAVE_TRACE build for durations
 ids = np.arange(n, dtype=np.int32)
 pool.reset(ids); pool.recv()
 rng = np.random.default_rng(1234)

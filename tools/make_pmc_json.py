@@ -1,5 +1,5 @@
 """Collects the PMC passes of tools/profile_bench.sh (gpurun_out/prof_<tag>/summary.md)
-into profiles/r1_pmc.json, which bench.py reads for `roofline.traffic` and the
+into profiles/pmc.json, which bench.py reads for `roofline.traffic` and the
 VALU figures.  usage: python tools/make_pmc_json.py <round-tag-prefix> [num_envs]
 
 Conventions (MI355X_MICROARCH.md, HBM / rocprofv3 section):
@@ -29,8 +29,8 @@ for path in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}_*"
     sfx = "F64" if f64 else "F32"
     flops = 64.0 * (2 * ctr.get(f"SQ_INSTS_VALU_FMA_{sfx}", 0) + ctr.get(f"SQ_INSTS_VALU_ADD_{sfx}", 0) +
                     ctr.get(f"SQ_INSTS_VALU_MUL_{sfx}", 0) + ctr.get(f"SQ_INSTS_VALU_TRANS_{sfx}", 0))
-    waves = (num_envs + 63) // 64
-    out[kernel] = {
+    waves = (num_envs + 63) // 64 if "Ant" not in kernel else (num_envs + 15) // 16  # Ant: 16 envs per wave
+    out[f"{kernel}@{num_envs}"] = {
         "fetch_size_kb": ctr.get("FETCH_SIZE"),
         "write_size_kb": ctr.get("WRITE_SIZE"),
         "traffic_bytes_per_launch": 1024.0 * (2 * ctr.get("FETCH_SIZE", 0) + ctr.get("WRITE_SIZE", 0)),
@@ -44,5 +44,11 @@ for path in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}_*"
         "source": f"profiles/{os.path.basename(os.path.dirname(path)).replace('prof_', '')}_summary.md",
         "num_envs": num_envs,
     }
-json.dump(out, open(os.path.join(root, "profiles", "r1_pmc.json"), "w"), indent=1)
+dst = os.path.join(root, "profiles", "pmc.json")
+try:
+    merged = json.load(open(dst))
+except OSError:
+    merged = {}
+merged.update(out)  # entries of other kernels / configurations stay
+json.dump(merged, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))

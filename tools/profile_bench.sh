@@ -19,4 +19,7 @@ for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_AC
   rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc$i" -o p -- python bench.py $ARGS > "$OUT/pmc$i.log" 2>&1
 done
 python tools/summarize_profile.py "$OUT" > "$OUT/summary.md" 2>&1
+# raw per-dispatch tables are large (gpurun merges at most 64 MiB back): keep the summaries
+find "$OUT" -name '*counter_collection.csv' -delete
+find "$OUT" -name '*kernel_trace.csv' -delete
 cat "$OUT/summary.md"
