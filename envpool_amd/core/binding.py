@@ -100,6 +100,8 @@ class FamilyDef:
     native_params: Callable[[dict], dict[str, float]] = lambda conf: {}
     # config keys accepted for API compatibility but not supported when changed
     unsupported: dict[str, Any] = field(default_factory=dict)
+    # (conf, DevicePool kwargs) -> pool, for families with their own constructor (Atari)
+    pool_factory: Callable[[dict, dict], Any] | None = None
 
 
 class _ShardedPools:
@@ -213,15 +215,18 @@ class _ShardedPools:
             p.close()
 
 
-def make_native_classes(fd: FamilyDef) -> tuple[type, type]:
-    """Build `_<Name>EnvSpec` and `_<Name>EnvPool` for a family."""
+def make_native_classes(fd: FamilyDef, static_action_spec: list | None = None) -> tuple[type, type]:
+    """Build `_<Name>EnvSpec` and `_<Name>EnvPool` for a family.  `static_action_spec`: key
+    list to use for the class-level `_action_keys` when `fd.action_spec` cannot be evaluated
+    on the default config (Atari sizes its action set from the ROM)."""
     config_items = COMMON_CONFIG + list(fd.default_config) + EXTENSION_CONFIG
     config_keys = [k for k, _ in config_items]
     default_values = tuple(v for _, v in config_items)
     # key lists are static per class in the reference (py_envpool.h:163-171)
     default_conf = dict(config_items)
     state_keys = [k for k, _ in COMMON_STATE_SPEC] + [k for k, _ in fd.state_spec(default_conf)]
-    action_keys = [k for k, _ in COMMON_ACTION_SPEC] + [k for k, _ in fd.action_spec(default_conf)]
+    action_keys = [k for k, _ in COMMON_ACTION_SPEC] + [
+        k for k, _ in (static_action_spec or fd.action_spec(default_conf))]
 
     class _Spec:
         _config_keys = config_keys
@@ -286,7 +291,14 @@ def make_native_classes(fd: FamilyDef) -> tuple[type, type]:
                 params=params,
             )
             device = conf["device"]
-            if isinstance(device, (list, tuple)) and len(device) > 1:
+            if fd.pool_factory is not None:
+                if isinstance(device, (list, tuple)):
+                    if len(device) != 1:
+                        raise ValueError(f"{fd.name}: in-process sharding over several devices "
+                                         "is not available for this family")
+                    device = device[0]
+                self._pool = fd.pool_factory(conf, dict(kw, device=int(device)))
+            elif isinstance(device, (list, tuple)) and len(device) > 1:
                 self._pool: Any = _ShardedPools(fd.native, list(device), conf["num_envs"], **kw)
             else:
                 if isinstance(device, (list, tuple)):

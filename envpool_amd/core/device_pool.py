@@ -89,6 +89,16 @@ class DevicePool:
             num_envs, batch_size, seed, env_seed, max_episode_steps, device,
             env_id_offset, params,
         )
+        h = self._create(family, cfg, params)
+        del keep
+        self._h = h
+        self._pending: collections.deque[int] = collections.deque()
+        self._is_sync = self.batch_size == self.num_envs
+        self._blocks = _PinnedBlocks(self._lib)
+        self._layouts: dict[int, tuple[list[int], int]] = {}
+
+    def _create(self, family: str, cfg: Any, params: dict[str, float] | None) -> ctypes.c_void_p:
+        """epa_create + the key tables (overridden by families with their own constructor)."""
         self.state_keys = native.describe(family, params, "state")
         self.action_keys = native.describe(family, params, "action")
         self.action_dtype = self.action_keys[-1][1]
@@ -97,12 +107,7 @@ class DevicePool:
         native.check(
             self._lib.epa_create(family.encode(), ctypes.byref(cfg), ctypes.byref(h))
         )
-        del keep
-        self._h = h
-        self._pending: collections.deque[int] = collections.deque()
-        self._is_sync = self.batch_size == self.num_envs
-        self._blocks = _PinnedBlocks(self._lib)
-        self._layouts: dict[int, tuple[list[int], int]] = {}
+        return h
 
     # -- host path ---------------------------------------------------------
     def send(self, env_id: np.ndarray, action: np.ndarray) -> None:

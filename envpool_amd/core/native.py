@@ -38,6 +38,14 @@ class EpaConfig(ctypes.Structure):
     ]
 
 
+class EpaAtariConfig(ctypes.Structure):
+    _fields_ = [
+        ("base", EpaConfig),
+        ("rom_path", ctypes.c_char_p),
+        ("emulator_lib", ctypes.c_char_p),
+    ]
+
+
 class EpaKeyInfo(ctypes.Structure):
     _fields_ = [
         ("name", ctypes.c_char_p),
@@ -92,6 +100,11 @@ def lib() -> ctypes.CDLL:
         "epa_get_state": (i32, [vp, vp, i32, vp]),
         "epa_set_state": (i32, [vp, vp, i32, vp]),
         "epa_atari_post_create": (i32, [i32] * 8 + [P(vp)]),
+        "epa_atari_post_create_ex": (i32, [i32] * 8 + [vp, i32, P(vp)]),
+        "epa_atari_create": (i32, [P(EpaAtariConfig), P(vp)]),
+        "epa_atari_num_actions": (i32, [P(EpaAtariConfig), P(i32)]),
+        "epa_pool_state_keys": (i32, [vp, P(EpaKeyInfo), i32, P(i32)]),
+        "epa_pool_action_keys": (i32, [vp, P(EpaKeyInfo), i32, P(i32)]),
         "epa_atari_post_destroy": (i32, [vp]),
         "epa_atari_post_push": (i32, [vp, vp, i32, vp, vp, vp]),
         "epa_atari_post_push_device": (i32, [vp, vp, i32, vp, vp, vp]),
@@ -117,6 +130,8 @@ EXPORTED_SYMBOLS = [
     "epa_send_device", "epa_recv_device", "epa_wait_stream", "epa_consumer_wait",
     "epa_stream", "epa_synchronize", "epa_set_timing", "epa_kernel_time_ms",
     "epa_state_dim", "epa_get_state", "epa_set_state", "epa_atari_post_create",
+    "epa_atari_post_create_ex", "epa_atari_create", "epa_atari_num_actions",
+    "epa_pool_state_keys", "epa_pool_action_keys",
     "epa_atari_post_destroy", "epa_atari_post_push",
     "epa_atari_post_push_device", "epa_atari_post_stream", "epa_last_error",
     "epa_version", "epa_device_count", "epa_host_alloc", "epa_host_free",
@@ -172,6 +187,16 @@ def make_config(
         cfg.param_keys = ctypes.cast(keys, ctypes.POINTER(ctypes.c_char_p))
         cfg.param_values = ctypes.cast(vals, ctypes.POINTER(ctypes.c_double))
     return cfg, keep
+
+
+def pool_keys(handle: ctypes.c_void_p, which: str = "state"):
+    """[(name, np dtype, row shape tuple)] of an existing pool's state or action keys."""
+    keys = (EpaKeyInfo * 32)()
+    n = ctypes.c_int32(0)
+    fn = lib().epa_pool_state_keys if which == "state" else lib().epa_pool_action_keys
+    check(fn(handle, keys, 32, ctypes.byref(n)))
+    return [(keys[i].name.decode(), DTYPES[keys[i].dtype], tuple(keys[i].shape[: keys[i].ndim]))
+            for i in range(n.value)]
 
 
 def describe(family: str, params: dict[str, float] | None = None, which: str = "state"):

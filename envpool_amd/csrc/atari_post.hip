@@ -53,10 +53,12 @@ struct TabEntry {  // one destination index of an area table, as staged in LDS
 };
 
 struct PostDev {
-  unsigned char* ring;  // [N][S][dh*dw]
+  unsigned char* ring;  // [N][S][C][dh*dw]
   int* head;            // [N] oldest slot
   AreaTab xt, yt;
   int n, s, sh, sw, dh, dw;
+  int chan;                   // planes per frame: 1 (gray_scale) or 3 (RGB, atari_env.h:320-335)
+  const unsigned char* lut;   // [chan][256] colour palette, or nullptr: frames are pixel values
 };
 
 // per-byte unsigned max of two packed words (SWAR; no packed u8 max on CDNA)
@@ -73,7 +75,13 @@ __device__ __forceinline__ unsigned int MaxU8x4(unsigned int a, unsigned int b) 
 // (3 / 4 for 210x160 -> 84x84); taps beyond a row's count carry weight 0, which
 // adds exactly +0.0f, so the result is bit-identical to OpenCV's variable loops
 // while every LDS read of a pixel can be issued before the first one is used.
-template <int XT, int YT, bool kLinear = false>
+// kChan / d.lut: the frames may be ALE palette INDICES (what the emulator's screen holds):
+// the colour palette -- applyPaletteGrayscale / applyPaletteRGB of atari_env.h:189-194,
+// 213-219 -- is then applied here, per frame BEFORE the max (the max of two grey values is
+// not the grey value of the larger index), and for gray_scale=False the three colour planes
+// are produced one after the other from the same 1-byte-per-pixel upload (a third of the
+// PCIe bytes of shipping RGB) and stored already transposed to [3, h, w] (atari_env.h:320-335).
+template <int XT, int YT, bool kLinear = false, int kChan = 1>
 __global__ __launch_bounds__(kPostBlock) void AtariPostKernel(
     PostDev d, const int* __restrict__ env_id, int k,
     const unsigned char* __restrict__ frames,
@@ -83,10 +91,15 @@ __global__ __launch_bounds__(kPostBlock) void AtariPostKernel(
   if (row >= k) return;
   const int e = env_id ? env_id[row] : row;
   const int fsz = d.sh * d.sw, osz = d.dh * d.dw;
-  const bool rst = reset_mask != nullptr && reset_mask[row] != 0;
-  // 0. area tables -> LDS (behind the pooled frame)
+  // per-row flags (include/envpool_amd.h): 1 reset (single frame, shown in every stack slot),
+  // 2 single frame without replication, 4 repeat the newest stacked frame (no new screen)
+  const unsigned int flags = reset_mask != nullptr ? reset_mask[row] : 0u;
+  const bool push_all = (flags & 1u) != 0, rst = (flags & 3u) != 0, repeat = (flags & 4u) != 0;
+  // 0. area tables (and the palette) -> LDS, behind the pooled frame
   TabEntry* xtab = reinterpret_cast<TabEntry*>(pooled + (fsz + 15) / 16 * 16);
   TabEntry* ytab = xtab + d.dw;
+  unsigned char* lut = reinterpret_cast<unsigned char*>(ytab + d.dh);  // [kChan][256]
+  const bool indexed = d.lut != nullptr;
   for (int i = threadIdx.x; i < d.dw + d.dh; i += kPostBlock) {
     const bool isx = i < d.dw;
     const int j = isx ? i : i - d.dw;
@@ -98,127 +111,176 @@ __global__ __launch_bounds__(kPostBlock) void AtariPostKernel(
     for (int a = 0; a < kMaxTap; ++a) en.alpha[a] = t.alpha[j * kMaxTap + a];
     (isx ? xtab : ytab)[j] = en;
   }
-  // 1. max-pool the two frames into LDS (atari_env.h:310-315); on reset there
-  //    is only one observation (maxpool = false)
+  if (indexed) {
+    for (int i = threadIdx.x; i < kChan * 256; i += kPostBlock) lut[i] = d.lut[i];
+  }
   const unsigned char* f0 = frames + (size_t)row * 2 * fsz;
   const unsigned char* f1 = f0 + fsz;
-  const int nvec = fsz / 16;
-  constexpr int kBatch = 6;  // independent 16-B loads in flight per thread and frame
-  for (int base = 0; base < nvec; base += kBatch * kPostBlock) {
-    uint4 a[kBatch], b[kBatch];
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      const int i = base + u * kPostBlock + threadIdx.x;
-      if (i < nvec) {
-        a[u] = reinterpret_cast<const uint4*>(f0)[i];
-        if (!rst) b[u] = reinterpret_cast<const uint4*>(f1)[i];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      const int i = base + u * kPostBlock + threadIdx.x;
-      if (i < nvec) {
-        uint4 r = a[u];
-        if (!rst) {
-          r.x = MaxU8x4(r.x, b[u].x);
-          r.y = MaxU8x4(r.y, b[u].y);
-          r.z = MaxU8x4(r.z, b[u].z);
-          r.w = MaxU8x4(r.w, b[u].w);
-        }
-        reinterpret_cast<uint4*>(pooled)[i] = r;
-      }
-    }
-  }
-  for (int i = nvec * 16 + threadIdx.x; i < fsz; i += kPostBlock) {
-    unsigned char a = f0[i], b = f1[i];
-    pooled[i] = rst ? a : (a > b ? a : b);
-  }
-  __syncthreads();
-  // 2. area resize
   const int head = d.head[e];
-  unsigned char* ring_e = d.ring + (size_t)e * d.s * osz;
-  unsigned char* obs_e = obs + (size_t)row * d.s * osz;
-  unsigned char* slot = ring_e + (size_t)head * osz;
-  unsigned char* newest = obs_e + (size_t)(d.s - 1) * osz;
-  // OpenCV's order: per source row the horizontal sum in tap order, then the
-  // vertical accumulation in tap order, then cvRound + saturate
-  auto pixel = [&](const TabEntry& ty, int dx) -> unsigned int {
-    const TabEntry tx = xtab[dx];
-    if constexpr (kLinear) {  // cv::INTER_LINEAR, 8UC1 fixed point
-      const int sy0 = ty.ofs * d.sw, sy1 = min(ty.ofs + 1, d.sh - 1) * d.sw;
-      const int sx0 = tx.ofs, sx1 = min(tx.ofs + 1, d.sw - 1);
-      const int a0 = (int)tx.alpha[0], a1 = (int)tx.alpha[1];
-      const int b0 = (int)ty.alpha[0], b1 = (int)ty.alpha[1];
-      const int S0 = pooled[sy0 + sx0] * a0 + pooled[sy0 + sx1] * a1;
-      const int S1 = pooled[sy1 + sx0] * a0 + pooled[sy1 + sx1] * a1;
-      return (unsigned int)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+  const size_t fr = (size_t)kChan * osz;  // bytes of one stacked frame (kChan planes)
+  unsigned char* ring_e = d.ring + (size_t)e * d.s * fr;
+  unsigned char* obs_e = obs + (size_t)row * d.s * fr;
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < kChan; ++c) {
+    if (repeat) {
+      // AtariEnv::Step left the frame_skip loop before a screen was captured (game over in
+      // the first sub-frames, atari_env.h:208-221): PushStack resizes the unchanged
+      // maxpool_buf_[0] again, i.e. the newest stacked frame is pushed once more
+      const unsigned char* prev = ring_e + (size_t)((head + d.s - 1) % d.s) * fr + (size_t)c * osz;
+      unsigned char* slot = ring_e + (size_t)head * fr + (size_t)c * osz;
+      unsigned char* newest = obs_e + (size_t)(d.s - 1) * fr + (size_t)c * osz;
+      for (int i = threadIdx.x; i < osz; i += kPostBlock) {
+        const unsigned char v = prev[i];
+        newest[i] = v;
+        if (d.s > 1) slot[i] = v;
+      }
+      continue;
     }
-    unsigned char px[YT][XT];
+    // 1. max-pool the two frames into LDS (atari_env.h:310-315); on reset there
+    //    is only one observation (maxpool = false)
+    const unsigned char* lc = lut + c * 256;
+    auto look4 = [&](unsigned int w) -> unsigned int {  // palette lookup of 4 packed indices
+      return (unsigned int)lc[w & 255u] | ((unsigned int)lc[(w >> 8) & 255u] << 8) |
+             ((unsigned int)lc[(w >> 16) & 255u] << 16) | ((unsigned int)lc[w >> 24] << 24);
+    };
+    const int nvec = fsz / 16;
+    constexpr int kBatch = 6;  // independent 16-B loads in flight per thread and frame
+    for (int base = 0; base < nvec; base += kBatch * kPostBlock) {
+      uint4 a[kBatch], b[kBatch];
 #pragma unroll
-    for (int yi = 0; yi < YT; ++yi) {  // clamped: padded taps have weight 0
-      const int sy = min(ty.ofs + yi, d.sh - 1) * d.sw;
+      for (int u = 0; u < kBatch; ++u) {
+        const int i = base + u * kPostBlock + threadIdx.x;
+        if (i < nvec) {
+          a[u] = reinterpret_cast<const uint4*>(f0)[i];
+          if (!rst) b[u] = reinterpret_cast<const uint4*>(f1)[i];
+        }
+      }
 #pragma unroll
-      for (int xi = 0; xi < XT; ++xi) px[yi][xi] = pooled[sy + min(tx.ofs + xi, d.sw - 1)];
-    }
-    float sum = 0.0f;
-#pragma unroll
-    for (int yi = 0; yi < YT; ++yi) {
-      float buf = 0.0f;
-#pragma unroll
-      for (int xi = 0; xi < XT; ++xi) buf += (float)px[yi][xi] * tx.alpha[xi];
-      float t = ty.alpha[yi] * buf;
-      sum = yi == 0 ? t : sum + t;
-    }
-    int r = __float2int_rn(sum);  // cvRound
-    return (unsigned int)(r < 0 ? 0 : (r > 255 ? 255 : r));
-  };
-  if ((d.dw & 3) == 0) {  // 4 pixels of one row per thread, one 32-bit store
-    const int qw = d.dw >> 2, nq = osz >> 2;
-    for (int q = threadIdx.x; q < nq; q += kPostBlock) {
-      const int dy = q / qw, dx = (q - dy * qw) << 2;
-      const TabEntry ty = ytab[dy];
-      unsigned int w = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) w |= pixel(ty, dx + j) << (8 * j);
-      const int p = q << 2;
-      *reinterpret_cast<unsigned int*>(newest + p) = w;
-      if (rst) {
-        for (int s = 0; s < d.s; ++s) *reinterpret_cast<unsigned int*>(ring_e + (size_t)s * osz + p) = w;
-        for (int s = 0; s < d.s - 1; ++s) *reinterpret_cast<unsigned int*>(obs_e + (size_t)s * osz + p) = w;
-      } else {
-        *reinterpret_cast<unsigned int*>(slot + p) = w;
+      for (int u = 0; u < kBatch; ++u) {
+        const int i = base + u * kPostBlock + threadIdx.x;
+        if (i < nvec) {
+          uint4 r = a[u];
+          if (indexed) {
+            r.x = look4(r.x);
+            r.y = look4(r.y);
+            r.z = look4(r.z);
+            r.w = look4(r.w);
+          }
+          if (!rst) {
+            uint4 q = b[u];
+            if (indexed) {
+              q.x = look4(q.x);
+              q.y = look4(q.y);
+              q.z = look4(q.z);
+              q.w = look4(q.w);
+            }
+            r.x = MaxU8x4(r.x, q.x);
+            r.y = MaxU8x4(r.y, q.y);
+            r.z = MaxU8x4(r.z, q.z);
+            r.w = MaxU8x4(r.w, q.w);
+          }
+          reinterpret_cast<uint4*>(pooled)[i] = r;
+        }
       }
     }
-  } else {
-    for (int p = threadIdx.x; p < osz; p += kPostBlock) {
-      const int dy = p / d.dw, dx = p - dy * d.dw;
-      const unsigned char v = (unsigned char)pixel(ytab[dy], dx);
-      newest[p] = v;
-      if (rst) {
-        for (int s = 0; s < d.s; ++s) ring_e[(size_t)s * osz + p] = v;
-        for (int s = 0; s < d.s - 1; ++s) obs_e[(size_t)s * osz + p] = v;
-      } else {
-        slot[p] = v;
+    for (int i = nvec * 16 + threadIdx.x; i < fsz; i += kPostBlock) {
+      unsigned char a = f0[i], b = f1[i];
+      if (indexed) {
+        a = lc[a];
+        b = lc[b];
+      }
+      pooled[i] = rst ? a : (a > b ? a : b);
+    }
+    __syncthreads();
+    // 2. area resize of this plane
+    unsigned char* slot = ring_e + (size_t)head * fr + (size_t)c * osz;
+    unsigned char* newest = obs_e + (size_t)(d.s - 1) * fr + (size_t)c * osz;
+    // OpenCV's order: per source row the horizontal sum in tap order, then the
+    // vertical accumulation in tap order, then cvRound + saturate
+    auto pixel = [&](const TabEntry& ty, int dx) -> unsigned int {
+      const TabEntry tx = xtab[dx];
+      if constexpr (kLinear) {  // cv::INTER_LINEAR, 8UC1 fixed point
+        const int sy0 = ty.ofs * d.sw, sy1 = min(ty.ofs + 1, d.sh - 1) * d.sw;
+        const int sx0 = tx.ofs, sx1 = min(tx.ofs + 1, d.sw - 1);
+        const int a0 = (int)tx.alpha[0], a1 = (int)tx.alpha[1];
+        const int b0 = (int)ty.alpha[0], b1 = (int)ty.alpha[1];
+        const int S0 = pooled[sy0 + sx0] * a0 + pooled[sy0 + sx1] * a1;
+        const int S1 = pooled[sy1 + sx0] * a0 + pooled[sy1 + sx1] * a1;
+        return (unsigned int)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+      }
+      unsigned char px[YT][XT];
+#pragma unroll
+      for (int yi = 0; yi < YT; ++yi) {  // clamped: padded taps have weight 0
+        const int sy = min(ty.ofs + yi, d.sh - 1) * d.sw;
+#pragma unroll
+        for (int xi = 0; xi < XT; ++xi) px[yi][xi] = pooled[sy + min(tx.ofs + xi, d.sw - 1)];
+      }
+      float sum = 0.0f;
+#pragma unroll
+      for (int yi = 0; yi < YT; ++yi) {
+        float buf = 0.0f;
+#pragma unroll
+        for (int xi = 0; xi < XT; ++xi) buf += (float)px[yi][xi] * tx.alpha[xi];
+        float t = ty.alpha[yi] * buf;
+        sum = yi == 0 ? t : sum + t;
+      }
+      int r = __float2int_rn(sum);  // cvRound
+      return (unsigned int)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    };
+    if ((d.dw & 3) == 0) {  // 4 pixels of one row per thread, one 32-bit store
+      const int qw = d.dw >> 2, nq = osz >> 2;
+      for (int q = threadIdx.x; q < nq; q += kPostBlock) {
+        const int dy = q / qw, dx = (q - dy * qw) << 2;
+        const TabEntry ty = ytab[dy];
+        unsigned int w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w |= pixel(ty, dx + j) << (8 * j);
+        const int p = q << 2;
+        *reinterpret_cast<unsigned int*>(newest + p) = w;
+        if (push_all) {  // every stack slot shows the new frame (atari_env.h:338-345)
+          for (int s = 0; s < d.s; ++s) {
+            *reinterpret_cast<unsigned int*>(ring_e + (size_t)s * fr + (size_t)c * osz + p) = w;
+          }
+          for (int s = 0; s < d.s - 1; ++s) {
+            *reinterpret_cast<unsigned int*>(obs_e + (size_t)s * fr + (size_t)c * osz + p) = w;
+          }
+        } else {
+          *reinterpret_cast<unsigned int*>(slot + p) = w;
+        }
+      }
+    } else {
+      for (int p = threadIdx.x; p < osz; p += kPostBlock) {
+        const int dy = p / d.dw, dx = p - dy * d.dw;
+        const unsigned char v = (unsigned char)pixel(ytab[dy], dx);
+        newest[p] = v;
+        if (push_all) {
+          for (int s = 0; s < d.s; ++s) ring_e[(size_t)s * fr + (size_t)c * osz + p] = v;
+          for (int s = 0; s < d.s - 1; ++s) obs_e[(size_t)s * fr + (size_t)c * osz + p] = v;
+        } else {
+          slot[p] = v;
+        }
       }
     }
+    if (kChan > 1) __syncthreads();  // the next plane reuses the pooled frame
   }
   // 3. older frames: obs[j] = ring[(head + 1 + j) % S], j = 0..S-2
-  if (!rst) {
-    const int ovec = osz / 16;  // 84*84 = 441 * 16
+  if (!push_all) {
+    const size_t ovec = fr / 16;  // 84*84 = 441 * 16
     for (int j = 0; j < d.s - 1; ++j) {
-      const unsigned char* src = ring_e + (size_t)((head + 1 + j) % d.s) * osz;
-      unsigned char* dst = obs_e + (size_t)j * osz;
-      if ((osz & 15) == 0) {
-        for (int i = threadIdx.x; i < ovec; i += kPostBlock) {
+      const unsigned char* src = ring_e + (size_t)((head + 1 + j) % d.s) * fr;
+      unsigned char* dst = obs_e + (size_t)j * fr;
+      if ((fr & 15) == 0) {
+        for (size_t i = threadIdx.x; i < ovec; i += kPostBlock) {
           reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
         }
       } else {
-        for (int i = threadIdx.x; i < osz; i += kPostBlock) dst[i] = src[i];
+        for (size_t i = threadIdx.x; i < fr; i += kPostBlock) dst[i] = src[i];
       }
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) d.head[e] = rst ? 0 : (head + 1) % d.s;
+  if (threadIdx.x == 0) d.head[e] = push_all ? 0 : (head + 1) % d.s;
 }
 
 // cv::computeResizeAreaTab restated (opencv imgproc/src/resize.cpp)
@@ -294,6 +356,7 @@ struct epa_atari_post {
   int cap{0};
   int max_xtap{epa::kMaxTap}, max_ytap{epa::kMaxTap};
   bool linear{false};  // use_inter_area_resize = false
+  unsigned char* d_lut{nullptr};  // [chan][256] colour palette (frames are palette indices)
   // host path pipeline: frames go up, kernels run and observations come down on
   // three streams, in chunks linked by events, so the two PCIe directions and the
   // kernel overlap
@@ -334,18 +397,21 @@ void LaunchPost(epa_atari_post* p, const int* d_ids, int k,
                 const unsigned char* d_frames, const unsigned char* d_mask,
                 unsigned char* d_obs) {
   size_t lds = (size_t)p->d.sh * p->d.sw;
-  lds = (lds + 15) / 16 * 16 + sizeof(epa::TabEntry) * (size_t)(p->d.dw + p->d.dh);
+  lds = (lds + 15) / 16 * 16 + sizeof(epa::TabEntry) * (size_t)(p->d.dw + p->d.dh) +
+        (size_t)p->d.chan * 256;
+#define EPA_POST_LAUNCH(XT, YT, LIN, CH)                                                     \
+  hipLaunchKernelGGL((epa::AtariPostKernel<XT, YT, LIN, CH>), dim3(k), dim3(epa::kPostBlock), \
+                     lds, p->stream, p->d, d_ids, k, d_frames, d_mask, d_obs)
+  const bool rgb = p->d.chan == 3;
   if (p->linear) {
-    hipLaunchKernelGGL((epa::AtariPostKernel<2, 2, true>), dim3(k), dim3(epa::kPostBlock), lds,
-                       p->stream, p->d, d_ids, k, d_frames, d_mask, d_obs);
+    if (rgb) EPA_POST_LAUNCH(2, 2, true, 3); else EPA_POST_LAUNCH(2, 2, true, 1);
   } else if (p->max_xtap <= 3 && p->max_ytap <= 4) {  // the Atari default 210x160 -> 84x84
-    hipLaunchKernelGGL((epa::AtariPostKernel<3, 4>), dim3(k), dim3(epa::kPostBlock), lds,
-                       p->stream, p->d, d_ids, k, d_frames, d_mask, d_obs);
+    if (rgb) EPA_POST_LAUNCH(3, 4, false, 3); else EPA_POST_LAUNCH(3, 4, false, 1);
   } else {
-    hipLaunchKernelGGL((epa::AtariPostKernel<epa::kMaxTap, epa::kMaxTap>), dim3(k),
-                       dim3(epa::kPostBlock), lds, p->stream, p->d, d_ids, k, d_frames, d_mask,
-                       d_obs);
+    if (rgb) EPA_POST_LAUNCH(epa::kMaxTap, epa::kMaxTap, false, 3);
+    else EPA_POST_LAUNCH(epa::kMaxTap, epa::kMaxTap, false, 1);
   }
+#undef EPA_POST_LAUNCH
   EPA_HIP(hipGetLastError());
 }
 }  // namespace
@@ -356,7 +422,20 @@ int epa_atari_post_create(int32_t num_envs, int32_t stack_num, int32_t in_h,
                           int32_t in_w, int32_t out_h, int32_t out_w,
                           int32_t use_inter_area, int32_t device,
                           epa_atari_post** out) {
+  return epa_atari_post_create_ex(num_envs, stack_num, in_h, in_w, out_h, out_w, use_inter_area,
+                                  1, nullptr, device, out);
+}
+
+int epa_atari_post_create_ex(int32_t num_envs, int32_t stack_num, int32_t in_h,
+                             int32_t in_w, int32_t out_h, int32_t out_w,
+                             int32_t use_inter_area, int32_t gray_scale,
+                             const uint8_t* palette, int32_t device,
+                             epa_atari_post** out) {
   return PostGuard([&] {
+    if (!gray_scale && palette == nullptr) {
+      throw std::invalid_argument(
+          "atari_post: gray_scale = 0 needs the colour palette (frames are palette indices)");
+    }
     if (num_envs < 1 || stack_num < 1 || out_h > in_h || out_w > in_w ||
         out_h < 1 || out_w < 1 || (size_t)in_h * in_w > 60000) {
       throw std::invalid_argument("atari_post: bad dimensions");
@@ -402,7 +481,13 @@ int epa_atari_post_create(int32_t num_envs, int32_t stack_num, int32_t in_h,
     p->d.sw = in_w;
     p->d.dh = out_h;
     p->d.dw = out_w;
-    size_t ring = (size_t)num_envs * stack_num * out_h * out_w;
+    p->d.chan = gray_scale ? 1 : 3;
+    if (palette != nullptr) {
+      EPA_HIP(hipMalloc(&p->d_lut, (size_t)p->d.chan * 256));
+      EPA_HIP(hipMemcpy(p->d_lut, palette, (size_t)p->d.chan * 256, hipMemcpyHostToDevice));
+      p->d.lut = p->d_lut;
+    }
+    size_t ring = (size_t)num_envs * stack_num * p->d.chan * out_h * out_w;
     EPA_HIP(hipMalloc(&p->d.ring, ring));
     EPA_HIP(hipMemset(p->d.ring, 0, ring));
     EPA_HIP(hipMalloc(&p->d.head, sizeof(int) * num_envs));
@@ -427,6 +512,7 @@ int epa_atari_post_destroy(epa_atari_post* p) {
       (void)hipFree(t->cnt);
       (void)hipFree(t->alpha);
     }
+    if (p->d_lut) (void)hipFree(p->d_lut);
     if (p->d_frames) (void)hipFree(p->d_frames);
     if (p->d_obs) (void)hipFree(p->d_obs);
     if (p->d_mask) (void)hipFree(p->d_mask);
@@ -457,7 +543,8 @@ int epa_atari_post_push(epa_atari_post* p, const int32_t* env_id, int32_t k,
     if (k == 0) return;
     std::lock_guard<std::mutex> lk(p->mu);
     EPA_HIP(hipSetDevice(p->device));
-    size_t fsz = (size_t)2 * p->d.sh * p->d.sw, osz = (size_t)p->d.s * p->d.dh * p->d.dw;
+    size_t fsz = (size_t)2 * p->d.sh * p->d.sw;
+    size_t osz = (size_t)p->d.s * p->d.chan * p->d.dh * p->d.dw;
     if (p->cap < p->d.n) {
       EPA_HIP(hipMalloc(&p->d_frames, fsz * p->d.n));
       EPA_HIP(hipMalloc(&p->d_obs, osz * p->d.n));

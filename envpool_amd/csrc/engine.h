@@ -124,22 +124,25 @@ class Pool {
   const KeySpec& action_key() const { return action_; }
   hipStream_t stream() const { return stream_; }
 
-  void Send(const int32_t* env_id, int k, const void* action);
-  void Reset(const int32_t* env_ids, int k);
-  void SendDevice(const int32_t* d_env_id, int k, const void* d_action,
-                  hipEvent_t wait_event = nullptr);
+  // The host-facing entry points are virtual: a family whose env bodies run on the HOST
+  // (Atari: ALE stays on the CPU, north star) replaces the stream-ordered execution with
+  // its own executor and keeps the C ABI (atari_env.hip).
+  virtual void Send(const int32_t* env_id, int k, const void* action);
+  virtual void Reset(const int32_t* env_ids, int k);
+  virtual void SendDevice(const int32_t* d_env_id, int k, const void* d_action,
+                          hipEvent_t wait_event = nullptr);
   // stream_ waits for everything enqueued so far on `producer` (device path)
   void WaitStream(hipStream_t producer);
   // `consumer` waits for the kernel of the batch RecvDevice handed out last
   void ConsumerWait(hipStream_t consumer);
-  int Recv(void* const* out_ptrs, int n_ptrs, int cap_rows);
+  virtual int Recv(void* const* out_ptrs, int n_ptrs, int cap_rows);
   // zero-copy host recv into a caller-owned block (see epa_recv_block)
   size_t RecvLayout(int rows, size_t* offsets, int n_keys) const;
-  int RecvBlock(void* block, size_t block_bytes, size_t* offsets, int n_keys);
-  int RecvInto(void* const* out_ptrs, int n_ptrs, int cap_rows);
-  int RecvDevice(void** d_out_ptrs, int n_ptrs);
-  int PendingRows();
-  void Synchronize();
+  virtual int RecvBlock(void* block, size_t block_bytes, size_t* offsets, int n_keys);
+  virtual int RecvInto(void* const* out_ptrs, int n_ptrs, int cap_rows);
+  virtual int RecvDevice(void** d_out_ptrs, int n_ptrs);
+  virtual int PendingRows();
+  virtual void Synchronize();
   void SetTiming(bool on);
   void KernelTime(double* avg_ms, int* launches);
 
@@ -188,8 +191,11 @@ class Pool {
     bool in_use{false};
   };
   Staging& NextStaging(size_t bytes);
+
+ protected:
   void CheckIds(const int32_t* ids, int k) const;
 
+ private:
   // generic observation frame stack (EnableObsStack)
   int stack_s_{1}, stack_nobs_{0};
   double* stack_ring_{nullptr};  // [N][S][nobs]
@@ -238,6 +244,9 @@ bool DescribeToyText(const std::string& family, const Config& cfg,
 Pool* MakeMujoco(const std::string& family, const Config& cfg);
 bool DescribeMujoco(const std::string& family, const Config& cfg,
                     std::vector<KeySpec>* state, KeySpec* action);
+// Atari (atari_env.hip): needs two strings the numeric epa_config cannot carry
+Pool* MakeAtari(const Config& cfg, const std::string& rom_path, const std::string& emulator_lib);
+int AtariNumActions(const Config& cfg, const std::string& rom_path, const std::string& emulator_lib);
 
 const std::vector<std::string>& FamilyNames();
 void SetLastError(const std::string& msg);  // thread-local epa_last_error()

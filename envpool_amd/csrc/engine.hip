@@ -928,6 +928,40 @@ int epa_set_state(epa_pool* pool, const int32_t* env_ids, int32_t k,
   return Guard([&] { pool->impl->SetStateHost(env_ids, k, in); });
 }
 
+int epa_atari_create(const epa_atari_config* cfg, epa_pool** out) {
+  return Guard([&] {
+    if (cfg == nullptr || out == nullptr || cfg->rom_path == nullptr) {
+      throw std::invalid_argument("epa_atari_create: null argument");
+    }
+    epa::Config c = epa::Config::From(&cfg->base);
+    epa::Pool* p = epa::MakeAtari(c, cfg->rom_path, cfg->emulator_lib ? cfg->emulator_lib : "");
+    *out = new epa_pool{std::unique_ptr<epa::Pool>(p)};
+  });
+}
+
+int epa_atari_num_actions(const epa_atari_config* cfg, int32_t* n) {
+  return Guard([&] {
+    if (cfg == nullptr || n == nullptr || cfg->rom_path == nullptr) {
+      throw std::invalid_argument("epa_atari_num_actions: null argument");
+    }
+    *n = epa::AtariNumActions(LenientConfig(&cfg->base), cfg->rom_path,
+                              cfg->emulator_lib ? cfg->emulator_lib : "");
+  });
+}
+
+int epa_pool_state_keys(epa_pool* pool, epa_key_info* keys, int cap, int* n) {
+  return Guard([&] { FillKeyInfo(pool->impl->state_keys(), keys, cap, n); });
+}
+
+int epa_pool_action_keys(epa_pool* pool, epa_key_info* keys, int cap, int* n) {
+  return Guard([&] {
+    std::vector<epa::KeySpec> a = {{"env_id", EPA_I32, {}},
+                                   {"players.env_id", EPA_I32, {}},
+                                   pool->impl->action_key()};
+    FillKeyInfo(a, keys, cap, n);
+  });
+}
+
 const char* epa_last_error(void) { return epa::g_last_error.c_str(); }
 const char* epa_version(void) { return "envpool_amd 0.1 (gfx950)"; }
 

@@ -227,10 +227,28 @@ int epa_atari_post_create(int32_t num_envs, int32_t stack_num, int32_t in_h,
                           int32_t in_w, int32_t out_h, int32_t out_w,
                           int32_t use_inter_area, int32_t device,
                           epa_atari_post** out);
+/* As above, plus the colour handling of atari_env.h:189-194 / 213-219 / 320-335:
+ *   palette != NULL: the frames handed to push are ALE palette INDICES (the emulator's
+ *     screen, 1 byte per pixel) and `palette` is the table behind applyPaletteGrayscale
+ *     ([256], gray_scale = 1) or applyPaletteRGB ([3][256] planar, gray_scale = 0); it is
+ *     applied on the device, per frame before the max-pool.
+ *   gray_scale = 0 (needs the palette): a stacked frame is three planes [3, out_h, out_w]
+ *     (the transpose of atari_env.h:320-335), observations are
+ *     [k, stack_num * 3, out_h, out_w]. */
+int epa_atari_post_create_ex(int32_t num_envs, int32_t stack_num, int32_t in_h,
+                             int32_t in_w, int32_t out_h, int32_t out_w,
+                             int32_t use_inter_area, int32_t gray_scale,
+                             const uint8_t* palette, int32_t device,
+                             epa_atari_post** out);
 int epa_atari_post_destroy(epa_atari_post* p);
 /* frames: [k, 2, in_h, in_w] u8 (the two max-pool buffers, host memory);
- * reset_mask[k] u8: 1 => replicate the new frame into every stack slot
- * (atari_env.h:330-337).  obs_out: [k, stack_num, out_h, out_w] u8 host. */
+ * reset_mask[k] u8 (NULL = all 0), per-row flags of AtariEnv::PushStack (atari_env.h:308-346):
+ *   0  max-pool the two frames, push                       (Step, frame_skip loop completed)
+ *   1  frame 0 only, replicated into every stack slot      (Reset with push_all)
+ *   2  frame 0 only, pushed like a step                    (Reset of an episodic-life env,
+ *                                                           frame_skip = 1, early game over)
+ *   4  no new screen: push the newest stacked frame again  (game over before a capture)
+ * obs_out: [k, stack_num * (gray_scale ? 1 : 3), out_h, out_w] u8 host. */
 int epa_atari_post_push(epa_atari_post* p, const int32_t* env_id, int32_t k,
                         const uint8_t* frames, const uint8_t* reset_mask,
                         uint8_t* obs_out);
@@ -239,6 +257,28 @@ int epa_atari_post_push_device(epa_atari_post* p, const int32_t* d_env_id,
                                int32_t k, const uint8_t* d_frames,
                                const uint8_t* d_reset_mask, uint8_t* d_obs_out);
 void* epa_atari_post_stream(epa_atari_post* p);
+
+/* ---- Atari end to end --------------------------------------------------- *
+ * AtariEnvPool = AsyncEnvPool<AtariEnv> (envpool/atari/atari_env.h:348) as an epa_pool: the
+ * emulator runs on host worker threads behind the plugin table of
+ * include/envpool_amd_emulator.h, palette + max-pool + resize + frame stack run as one HIP
+ * kernel per batch.  The pool is driven with the generic epa_send / epa_recv / epa_recv_block
+ * / epa_reset / epa_destroy (the device-resident entry points raise: the emulator is on the
+ * host).  Numeric config keys of AtariEnvFns::DefaultConfig (atari_env.h:52-63) travel in
+ * base.param_*: stack_num frame_skip noop_max zero_discount_on_life_loss episodic_life
+ * reward_clip use_fire_reset img_height img_width mode difficulty full_action_space
+ * repeat_action_probability use_inter_area_resize gray_scale, plus num_threads. */
+typedef struct epa_atari_config {
+  epa_config base;
+  const char* rom_path;     /* GetRomPath(base_path, task), atari_env.h:43-48 */
+  const char* emulator_lib; /* emulator plugin, see envpool_amd_emulator.h */
+} epa_atari_config;
+int epa_atari_create(const epa_atari_config* cfg, epa_pool** out);
+/* size of the action set (AtariEnvFns::ActionSpec loads the ROM for it, atari_env.h:76-90) */
+int epa_atari_num_actions(const epa_atari_config* cfg, int32_t* n);
+/* state / action keys of an existing pool (same order and meaning as epa_describe_*) */
+int epa_pool_state_keys(epa_pool* pool, epa_key_info* keys, int cap, int* n);
+int epa_pool_action_keys(epa_pool* pool, epa_key_info* keys, int cap, int* n);
 
 /* ---- misc -------------------------------------------------------------- */
 const char* epa_last_error(void);

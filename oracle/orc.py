@@ -4,6 +4,8 @@ ctypes wrapper over the small `orc_*` C API that both oracles export:
 
 * ``oracle/_ref/libref_oracle.so``  — the reference's own C++ compiled in place
   from /root/reference (kind "reference"; exists only where it was built).
+* ``oracle/_ref/libref_atari.so``   — the reference's own atari_env.h compiled in place
+  over the synthetic console of tests/synth_ale (kind "reference_atari").
 * ``oracle/_build/liboracle.so``    — the plain-C restatement under
   ``oracle/restate`` and ``oracle/mjcpu`` (kind "port"; travels everywhere).
 
@@ -21,9 +23,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REF_LIB = os.path.join(_HERE, "_ref", "libref_oracle.so")
+REF_ATARI_LIB = os.path.join(_HERE, "_ref", "libref_atari.so")
 PORT_LIB = os.path.join(_HERE, "_build", "liboracle.so")
 
-_DTYPES = {0: np.int32, 1: np.float32, 2: np.float64, 3: np.bool_}
+_DTYPES = {0: np.int32, 1: np.float32, 2: np.float64, 3: np.bool_, 4: np.uint8}
 
 _libs: dict[str, ctypes.CDLL] = {}
 
@@ -86,12 +89,16 @@ def have_ref() -> bool:
     return os.path.exists(REF_LIB)
 
 
+def have_ref_atari() -> bool:
+    return os.path.exists(REF_ATARI_LIB)
+
+
 def have_port() -> bool:
     return os.path.exists(PORT_LIB)
 
 
 class Oracle:
-    """One oracle pool. ``kind`` is "reference" or "port"."""
+    """One oracle pool. ``kind`` is "reference", "reference_atari" or "port"."""
 
     def __init__(
         self,
@@ -103,7 +110,7 @@ class Oracle:
         kind: str = "port",
         num_threads: int = 1,
     ) -> None:
-        path = REF_LIB if kind == "reference" else PORT_LIB
+        path = {"reference": REF_LIB, "reference_atari": REF_ATARI_LIB}.get(kind, PORT_LIB)
         self.lib = _load(path)
         self.kind = self.lib.orc_kind().decode()
         ex = (ctypes.c_double * max(1, len(extra)))(*extra)

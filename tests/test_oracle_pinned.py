@@ -80,3 +80,31 @@ def test_partial_env_id_step_matches_reference():
         for k in ra:
             assert np.array_equal(ra[k], rb[k]), k
         assert np.array_equal(ra["info:env_id"].ravel(), ids)
+
+
+def test_atari_fixtures_come_from_the_reference_compiled_in_place():
+    """tests/golden/atari_*.npz must be what oracle/_ref/libref_atari.so -- the reference's own
+    atari_env.h over the synthetic console -- produces (regenerate with
+    tests/golden/make_atari_golden.py); also checks that the emulator plugin the product loads
+    and the reference's ALE shim wrap the same console."""
+    import zlib
+
+    import atari_cases as ac
+    from oracle import orc
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    if not orc.have_ref_atari():
+        pytest.skip("oracle/_ref/libref_atari.so not built (no /root/reference here)")
+    for name, (_, n, seed, max_steps, steps) in ac.CASES.items():
+        g = np.load(os.path.join(ROOT, "tests", "golden", f"atari_{name}.npz"))
+        c = ac.config(name)
+        o = orc.Oracle("Atari", n, seed=seed, max_episode_steps=max_steps, extra=ac.extra(c),
+                       kind="reference_atari", num_threads=2)
+        b = o.reset()
+        for t in range(min(steps, 40) + 1):
+            np.testing.assert_array_equal(ac.crc_rows(b["obs"]), g["obs_crc"][t])
+            np.testing.assert_array_equal(b["reward"].ravel(), g["reward"][t])
+            np.testing.assert_array_equal(b["elapsed_step"].ravel(), g["elapsed_step"][t])
+            b = o.step(g["actions"][t])
+        assert zlib.crc32(b["obs"].tobytes()) != 0
