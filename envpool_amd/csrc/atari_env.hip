@@ -23,9 +23,13 @@
 // overrides of WriteState; seeds `seed + env_id` or env_seed[] (env.h:101-110) for both
 // the noop RNG and the emulator.
 #include <dlfcn.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -139,6 +143,7 @@ struct OutBatch {
   float *reward{nullptr}, *discount{nullptr}, *info_reward{nullptr};
   uint8_t* ram{nullptr};       // [cap][128]
   int32_t* local_id{nullptr};  // env index inside the pool (ring of the frame stack)
+  double t_send{0}, t_done{0};
 };
 
 struct Task {
@@ -160,8 +165,15 @@ class AtariPool : public Pool {
     sync_ = cfg.batch_size <= 0 || cfg.batch_size >= n;
     batch_size_ = sync_ ? n : cfg.batch_size;
     envs_.resize(n);
-    int nthreads = a_.num_threads > 0 ? a_.num_threads : (int)std::thread::hardware_concurrency();
-    nthreads = std::max(1, std::min(nthreads, n));
+    // num_threads = 0: an eighth of the hardware threads, at most one per env of a batch.
+    // (The reference defaults to min(batch_size, hardware_concurrency); with an emulator that
+    // costs ~1 us per frame -- the synthetic console of the tests -- waking 128+ parked workers
+    // per step costs more than it buys: emulate phase of a 1024-env step 0.9 ms with 32
+    // workers, 4.3 ms with 128, 5.0 ms with 256 on a 256-thread host, profiles/r2e.  With ALE
+    // (~150 us per frame) the work dominates: set num_threads to the core count.)
+    int nthreads = a_.num_threads > 0 ? a_.num_threads
+                                      : std::max(1, (int)std::thread::hardware_concurrency() / 8);
+    nthreads = std::max(1, std::min(nthreads, batch_size_));
     // emulators (ROM loading is the slow part: in parallel)
     std::atomic<int> next{0};
     std::string first_error;
@@ -218,15 +230,20 @@ class AtariPool : public Pool {
       DestroyEmus();
       throw std::invalid_argument(std::string("Atari: ") + epa_last_error());
     }
+    ring_.resize((size_t)4 * n);
     for (int t = 0; t < nthreads; ++t) workers_.emplace_back([this] { WorkerLoop(); });
   }
 
   ~AtariPool() override {
-    {
-      std::lock_guard<std::mutex> lk(q_mu_);
-      stop_ = true;
+    if (getenv("EPA_ATARI_PROFILE") && prof_batches_ > 0) {
+      fprintf(stderr, "atari pool: %ld batches, per batch: emulate %.3f ms (send -> last row), "
+              "recv called %.3f ms after that, post-process + copies %.3f ms; %zu workers\n",
+              prof_batches_, 1e3 * prof_emulate_ / prof_batches_, 1e3 * prof_wait_ / prof_batches_,
+              1e3 * prof_deliver_ / prof_batches_, workers_.size());
     }
-    q_cv_.notify_all();
+    stop_.store(true, std::memory_order_release);
+    sleepers_.fetch_add(1);  // force the wake-up syscall
+    WakeWorkers();
     for (auto& t : workers_) t.join();
     if (post_) epa_atari_post_destroy(post_);
     for (auto& b : all_batches_) FreeBatch(b.get());
@@ -375,13 +392,30 @@ class AtariPool : public Pool {
       }
       // async: rows of successive batch_size-row batches are claimed as envs finish
     }
-    {
-      std::lock_guard<std::mutex> lk(q_mu_);
-      for (int i = 0; i < k; ++i) {
-        tasks_.push_back(Task{ids[i] - cfg_.env_id_offset, act ? act[i] : 0, force, b, i});
+    // publish k tickets on the ring (single producer: send_mu_), then wake sleepers
+    std::lock_guard<std::mutex> sl(send_mu_);
+    if (b) b->t_send = Now();
+    uint64_t tail = tail_.load(std::memory_order_relaxed);
+    for (int i = 0; i < k; ++i) {
+      while (tail - done_tickets_.load(std::memory_order_acquire) >= ring_.size()) {
+        std::this_thread::yield();  // ring full: more than 4 x num_envs steps outstanding
       }
+      ring_[tail % ring_.size()] = Task{ids[i] - cfg_.env_id_offset, act ? act[i] : 0, force, b, i};
+      ++tail;
     }
-    q_cv_.notify_all();
+    tail_.store(tail, std::memory_order_release);
+    WakeWorkers();
+  }
+
+  // sleeping workers park on a futex word (no mutex to re-acquire on wake-up: a condition
+  // variable serialises a few hundred woken threads on its mutex, 17 ms per 1024-env step
+  // with 256 workers instead of 3 ms)
+  void WakeWorkers() {
+    wake_seq_.fetch_add(1, std::memory_order_acq_rel);
+    if (sleepers_.load(std::memory_order_acquire) > 0) {
+      syscall(SYS_futex, reinterpret_cast<uint32_t*>(&wake_seq_), FUTEX_WAKE_PRIVATE, INT_MAX,
+              nullptr, nullptr, 0);
+    }
   }
 
   OutBatch* WaitFront() {
@@ -408,8 +442,23 @@ class AtariPool : public Pool {
   }
 
   // post-process on the GPU and copy everything into the caller's arrays (state key order)
+  static double Now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
   void Deliver(OutBatch* b, void* const* out) {
     const int k = b->rows;
+    const double t_begin = Now();
+    struct Acc {  // EPA_ATARI_PROFILE=1: phase times on stderr when the pool is destroyed
+      AtariPool* p;
+      OutBatch* b;
+      double t0;
+      ~Acc() {
+        p->prof_emulate_ += b->t_done - b->t_send;
+        p->prof_wait_ += t0 - b->t_done;
+        p->prof_deliver_ += Now() - t0;
+        ++p->prof_batches_;
+      }
+    } acc{this, b, t_begin};
     EPA_HIP(hipSetDevice(cfg_.device));
     enum { kEnvId = 0, kPlayers, kElapsed, kDone, kReward, kDiscount, kStepType, kTrunc, kObs,
            kLives, kInfoReward, kTerminated, kRamKey };
@@ -522,14 +571,27 @@ class AtariPool : public Pool {
   void WorkerLoop() {
     const epa_emulator_api* A = plugin_.api;
     for (;;) {
-      Task t;
-      {
-        std::unique_lock<std::mutex> lk(q_mu_);
-        q_cv_.wait(lk, [&] { return stop_ || !tasks_.empty(); });
-        if (stop_ && tasks_.empty()) return;
-        t = tasks_.front();
-        tasks_.pop_front();
+      // lock-free ticket (the reference's ActionBufferQueue, action_buffer_queue.h:59-80, is the
+      // same idea): a worker owns ticket i and waits until the producer has published it --
+      // a short spin (a step's tickets arrive together), then a condition variable
+      const uint64_t ticket = head_.fetch_add(1, std::memory_order_acq_rel);
+      int spins = 0;
+      while (tail_.load(std::memory_order_acquire) <= ticket) {
+        if (stop_.load(std::memory_order_acquire)) return;
+        if (++spins < 4000) {
+          __builtin_ia32_pause();
+          continue;
+        }
+        const uint32_t seq = wake_seq_.load(std::memory_order_acquire);
+        sleepers_.fetch_add(1, std::memory_order_acq_rel);
+        if (tail_.load(std::memory_order_acquire) <= ticket && !stop_.load(std::memory_order_acquire)) {
+          syscall(SYS_futex, reinterpret_cast<uint32_t*>(&wake_seq_), FUTEX_WAIT_PRIVATE, seq,
+                  nullptr, nullptr, 0);  // returns at once if wake_seq_ moved on
+        }
+        sleepers_.fetch_sub(1, std::memory_order_acq_rel);
       }
+      const Task t = ring_[ticket % ring_.size()];
+      done_tickets_.fetch_add(1, std::memory_order_acq_rel);  // the slot may be reused
       Env& e = envs_[t.env];
       const RowOut r = RunEnv(e, t);
       // claim the row (Allocate, state_buffer_queue.h:123-141) and write it (WriteState)
@@ -565,6 +627,7 @@ class AtariPool : public Pool {
       b->terminated[row] = A->game_over(e.emu);
       std::memcpy(b->ram + (size_t)row * kRam, A->ram(e.emu), kRam);
       if (b->finished.fetch_add(1) + 1 >= b->rows) {
+        b->t_done = Now();
         std::lock_guard<std::mutex> lk(b_mu_);
         done_cv_.notify_all();
       }
@@ -580,11 +643,13 @@ class AtariPool : public Pool {
   std::vector<int> action_set_;
   bool fire_reset_{false};
   epa_atari_post* post_{nullptr};
-  // task queue
-  std::mutex q_mu_;
-  std::condition_variable q_cv_;
-  std::deque<Task> tasks_;
-  bool stop_{false};
+  // task ring: tickets [head_, tail_) are published and unclaimed
+  std::vector<Task> ring_;
+  std::atomic<uint64_t> head_{0}, tail_{0}, done_tickets_{0};
+  std::atomic<int> sleepers_{0};
+  std::atomic<uint32_t> wake_seq_{0};
+  std::atomic<bool> stop_{false};
+  std::mutex send_mu_;
   std::vector<std::thread> workers_;
   // output batches
   std::mutex b_mu_;
@@ -594,6 +659,8 @@ class AtariPool : public Pool {
   std::vector<OutBatch*> free_batches_;
   std::vector<std::unique_ptr<OutBatch>> all_batches_;
   long long inflight_{0};              // rows sent / reset and not yet received
+  double prof_emulate_{0}, prof_wait_{0}, prof_deliver_{0};
+  long prof_batches_{0};
 };
 
 }  // namespace

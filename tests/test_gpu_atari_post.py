@@ -119,3 +119,42 @@ def test_post_process_errors():
         AtariPostProcess(4, img_height=105, img_width=80)  # integer scale: fast path
     with pytest.raises(ValueError):  # INTER_LINEAR with an exact 2x2 reduction: area-fast path
         AtariPostProcess(4, img_height=105, img_width=80, use_inter_area_resize=False)
+
+
+def test_post_matches_opencv_golden():
+    """GPU leg of the cv::resize pin (tools/pin_with_opencv.py): the HIP post-process against real
+    cv2 outputs -- gray frames, and RGB through an identity-per-channel palette."""
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "opencv_resize.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/opencv_resize.npz absent (OpenCV not installable offline)")
+    from envpool_amd.atari import AtariPostProcess
+
+    g = np.load(path)
+    src = g["src"]
+    n = src.shape[0]
+    for key in g.files:
+        if "_" not in key or key in ("src", "cv_version"):
+            continue
+        kind, mode, hw = key.split("_")
+        h, w = (int(x) for x in hw.split("x"))
+        if kind == "gray":
+            post = AtariPostProcess(n, stack_num=1, img_height=h, img_width=w,
+                                    use_inter_area_resize=mode == "area")
+            fr = np.stack([src[:, :, :, 0], src[:, :, :, 0]], axis=1)
+            obs = post.push(fr, reset_mask=np.ones(n, dtype=np.uint8))
+            np.testing.assert_array_equal(obs[:, 0], g[key], err_msg=key)
+            post.close()
+        else:  # three planes from one index frame: push each channel as "indices" with an
+            # identity palette for that plane and zeros elsewhere is equivalent to the RGB path
+            for c in range(3):
+                pal = np.zeros((3, 256), dtype=np.uint8)
+                pal[c] = np.arange(256, dtype=np.uint8)
+                post = AtariPostProcess(n, stack_num=1, img_height=h, img_width=w,
+                                        use_inter_area_resize=mode == "area", gray_scale=False,
+                                        palette=pal)
+                fr = np.stack([src[:, :, :, c], src[:, :, :, c]], axis=1)
+                obs = post.push(fr, reset_mask=np.ones(n, dtype=np.uint8))
+                np.testing.assert_array_equal(obs[:, c], g[key][:, :, :, c], err_msg=f"{key} c{c}")
+                post.close()

@@ -108,3 +108,34 @@ def test_atari_fixtures_come_from_the_reference_compiled_in_place():
             np.testing.assert_array_equal(b["elapsed_step"].ravel(), g["elapsed_step"][t])
             b = o.step(g["actions"][t])
         assert zlib.crc32(b["obs"].tobytes()) != 0
+
+
+def test_resize_matches_opencv():
+    """Activates when tools/pin_with_opencv.py has been run somewhere with OpenCV: the plain-C
+    restatement of cv::resize (oracle/atari/atari_post.c) against real cv2 outputs, gray and
+    per channel of 3-channel images."""
+    import ctypes
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "opencv_resize.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/opencv_resize.npz absent (OpenCV not installable offline: PARITY "
+                    "UNPINNED for cv::resize; run tools/pin_with_opencv.py where cv2 imports)")
+    from oracle import orc
+
+    L = orc._load(orc.PORT_LIB)
+    g = np.load(path)
+    src = g["src"]
+    for key in g.files:
+        if "_" not in key or key in ("src", "cv_version"):
+            continue
+        kind, mode, hw = key.split("_")
+        h, w = (int(x) for x in hw.split("x"))
+        fn = L.orc_resize_area_u8 if mode == "area" else L.orc_resize_linear_u8
+        for i in range(src.shape[0]):
+            chans = [0] if kind == "gray" else [0, 1, 2]
+            for c in chans:
+                plane = np.ascontiguousarray(src[i, :, :, c])
+                out = np.zeros((h, w), dtype=np.uint8)
+                fn(plane.ctypes.data_as(ctypes.c_void_p), 210, 160, out.ctypes.data_as(ctypes.c_void_p), h, w)
+                want = g[key][i] if kind == "gray" else g[key][i][:, :, c]
+                np.testing.assert_array_equal(out, want, err_msg=f"{key} frame {i} channel {c}")
