@@ -61,17 +61,31 @@ constexpr int kTTri = 21;                 // packed 6x6 torso block = entries 0.
 constexpr int kNW = 7;
 EPA_HD constexpr int LinkOf(int w) { return w == 6 ? 0 : w / 2; }  // 0 torso-fixed, 1 aux, 2 foot
 
-// per-lane LDS block [slot][lane]: local M (36), geometry (24), robot COM (3)
-constexpr int kSlotM = 0;
-constexpr int kSlotPos0 = 36, kSlotRot = 39, kSlotPosA = 48, kSlotPosF = 51, kSlotTip = 54,
-              kSlotAnk = 57, kSlotCom = 60;
-constexpr int kSlots = 63;
+// LDS block of a wave.  Slots [0, kQuadSlots) hold what is REPLICATED over a quad -- stored
+// once per quad, [slot][quad], read as a broadcast: the torso block of M (the first 21
+// entries of the packed 8x8), the torso origin, its axes, the robot COM.  The rest is
+// lane-private, [slot][lane]: the lane's columns of M (15), its leg geometry (12), and the
+// per-pass constants of its contact candidates (4 per sphere class, SetupContacts).
+// fp64: 36 x 16 x 8 B + 55 x 64 x 8 B = 32.8 KB per wave.
+constexpr int kQuadSlots = 36, kLaneSlots = 55;
+constexpr int kSlotPos0 = 21, kSlotRot = 24, kSlotCom = 33;                       // quad
+constexpr int kSlotPosA = 51, kSlotPosF = 54, kSlotTip = 57, kSlotAnk = 60;       // lane
+constexpr int kSlotCache = 63;                                                    // lane, 4 x kNW
+constexpr int kSlots = kQuadSlots + kLaneSlots;
+EPA_HD constexpr int MSlot(int packed) { return packed < kTTri ? packed : kQuadSlots + (packed - kTTri); }
 EPA_HD constexpr int CenterSlot(int w) {
   return w == 0 ? kSlotPosA
                 : w == 1 ? kSlotPos0
                          : w == 2 ? kSlotPosF
                                   : w == 3 ? kSlotPosA : w == 4 ? kSlotTip : w == 5 ? kSlotPosF : kSlotPos0;
 }
+// element offset of a slot inside the wave's LDS block (device accessor; the slot number is
+// a compile-time constant or wave uniform, so this is scalar arithmetic)
+EPA_HD constexpr int LdsOffset(int slot, int lane) {
+  return slot < kQuadSlots ? slot * 16 + (lane >> 2)
+                           : kQuadSlots * 16 + (slot - kQuadSlots) * 64 + lane;
+}
+constexpr int kLdsElems = kQuadSlots * 16 + kLaneSlots * 64;
 
 // the mirror signs of a lane's leg and the two constants that differ between legs
 template <typename V, typename B>
@@ -189,17 +203,25 @@ template <typename V>
 struct Contact {
   V an, ay, ax, D;
 };
-template <int K, typename T, typename V, typename B, typename G>
-EPA_HD void MakeContact(const AntModel<T>& m, const G& g, B active, const V* v, int w, T radius,
-                        T invw, Contact<V>& c, Vec3<V>* C) {
-  const Vec3<V> ctr = g.At(CenterSlot(w));  // w is wave uniform: a scalar base
-  const V dist = ctr.z - V(radius);
-  const B touch = active & (dist < V(m.margin));
-  const Vec3<V> cp = {ctr.x, ctr.y, V(0.5) * dist};
+// the non-trivial Jacobian columns of contact point cp on link K
+template <int K, typename V, typename G>
+EPA_HD void ContactCols(const G& g, Vec3<V> cp, Vec3<V>* C) {
   const Vec3<V> r0 = cp - g.Pos0();
   static_for<0, 3>([&](auto kc) { C[decltype(kc)::value] = Cross(g.Rot(decltype(kc)::value), r0); });
   if constexpr (K >= 1) C[3] = Cross(g.Rot(2), cp - g.PosA());  // hip axis = torso z
   if constexpr (K >= 2) C[4] = Cross(g.Ank(), cp - g.PosF());
+}
+// once per forward pass and touching class: impedance, regulariser and reference
+// accelerations (they depend on the pose and the velocity only) -> the lane's cache slots
+template <int K, typename T, typename V, typename B, typename G, typename Lds>
+EPA_HD void SetupContact(const AntModel<T>& m, const G& g, B active, const V* v, int w, T radius,
+                         T invw, Lds&& lds) {
+  const Vec3<V> ctr = g.At(CenterSlot(w));  // w is wave uniform: a scalar base
+  const V dist = ctr.z - V(radius);
+  const B touch = active & (dist < V(m.margin));
+  const Vec3<V> cp = {ctr.x, ctr.y, V(0.5) * dist};
+  Vec3<V> C[5];
+  ContactCols<K>(g, cp, C);
   Vec3<V> vel = {v[0], v[1], v[2]};
   static_for<0, 3 + K>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
@@ -209,10 +231,23 @@ EPA_HD void MakeContact(const AntModel<T>& m, const G& g, B active, const V* v, 
   const V imp = ImpedanceV(m.imp_d0, m.imp_dmax, m.imp_width, rr);
   const V num = (V(1) - imp) * V(invw * (T(1) + m.mu * m.mu));  // R = max(mjMINVAL, num / imp)
   const V invR = Sel(num < V(1e-15) * imp, V(1e15), imp / num);
-  c.D = Sel(touch, invR * V(T(1) / (T(2) * m.mu * m.mu)), V(0));  // D_py = 1 / (2 mu^2 R)
-  c.an = Sel(touch, -V(m.con_B) * vel.z - V(m.con_K) * imp * rr, V(0));
-  c.ay = Sel(touch, V(m.con_B * m.mu) * vel.y, V(0));
-  c.ax = Sel(touch, V(m.con_B * m.mu) * vel.x, V(0));
+  const int base = kSlotCache + 4 * w;
+  lds(base) = Sel(touch, -V(m.con_B) * vel.z - V(m.con_K) * imp * rr, V(0));      // an
+  lds(base + 1) = Sel(touch, V(m.con_B * m.mu) * vel.y, V(0));                   // ay
+  lds(base + 2) = Sel(touch, V(m.con_B * m.mu) * vel.x, V(0));                   // ax
+  lds(base + 3) = Sel(touch, invR * V(T(1) / (T(2) * m.mu * m.mu)), V(0));       // D_py = 1 / (2 mu^2 R)
+}
+// every solver pass: the cached constants + the Jacobian columns rebuilt from the pose
+template <int K, typename T, typename V, typename G, typename Lds>
+EPA_HD void LoadContact(const G& g, int w, T radius, Lds&& lds, Contact<V>& c, Vec3<V>* C) {
+  const Vec3<V> ctr = g.At(CenterSlot(w));
+  const Vec3<V> cp = {ctr.x, ctr.y, V(0.5) * (ctr.z - V(radius))};
+  ContactCols<K>(g, cp, C);
+  const int base = kSlotCache + 4 * w;
+  c.an = lds(base);
+  c.ay = lds(base + 1);
+  c.ax = lds(base + 2);
+  c.D = lds(base + 3);
 }
 template <int K, typename V>
 EPA_HD Vec3<V> JacMul(const Vec3<V>* C, const V* a) {  // J a
@@ -276,8 +311,7 @@ EPA_HD void RowsPass(const AntModel<T>& m, const Leg<V, B>& lg, const G& g, unsi
       constexpr int K = decltype(kc)::value;
       Contact<V> c;
       Vec3<V> C[5];
-      const B active = w == 6 ? lg.first : (lg.first | !lg.first);
-      MakeContact<K>(m, g, active, v, w, radius, invw, c, C);
+      LoadContact<K>(g, w, radius, g.lds, c, C);
       V jar[4], wt[4];
       ContactJar(m, JacMul<K>(C, a), c, jar);
       static_for<0, 4>([&](auto kk) {
@@ -346,8 +380,7 @@ EPA_HD void LineEval(const AntModel<T>& m, const Leg<V, B>& lg, const G& g, unsi
       constexpr int K = decltype(kc)::value;
       Contact<V> c;
       Vec3<V> C[5];
-      const B active = w == 6 ? lg.first : (lg.first | !lg.first);
-      MakeContact<K>(m, g, active, v, w, radius, invw, c, C);
+      LoadContact<K>(g, w, radius, g.lds, c, C);
       V jar[4];
       ContactJar(m, JacMul<K>(C, a), c, jar);
       const Vec3<V> js = JacMul<K>(C, s);
@@ -371,14 +404,14 @@ EPA_HD void MulM(Lds&& lds, const V* x, V* y) {
   V part[6];
   static_for<0, 6>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
-    part[i] = lds(kSlotM + Tri(i, 6)) * x[6] + lds(kSlotM + Tri(i, 7)) * x[7];
+    part[i] = lds(MSlot(Tri(i, 6))) * x[6] + lds(MSlot(Tri(i, 7))) * x[7];
   });
   static_for<0, 6>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     V s = Sum4(part[i]);
     static_for<0, 6>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      s += lds(kSlotM + (i <= j ? Tri(i, j) : Tri(j, i))) * x[j];
+      s += lds(MSlot(i <= j ? Tri(i, j) : Tri(j, i))) * x[j];
     });
     y[i] = s;
   });
@@ -387,7 +420,7 @@ EPA_HD void MulM(Lds&& lds, const V* x, V* y) {
     V s = V(0);
     static_for<0, 8>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      s += lds(kSlotM + (i <= c ? Tri(i, c) : Tri(c, i))) * x[i];
+      s += lds(MSlot(i <= c ? Tri(i, c) : Tri(c, i))) * x[i];
     });
     y[c] = s;
   });
@@ -420,7 +453,7 @@ EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned
     static_for<0, kTTri>([&](auto ic) { H[decltype(ic)::value] = V(0); });  // torso: partial
     static_for<kTTri, kLTri>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      H[i] = lds(kSlotM + i);
+      H[i] = lds(MSlot(i));
     });
     static_for<0, 6>([&](auto ic) { s[decltype(ic)::value] = V(0); });
     s[6] = res[6];
@@ -460,7 +493,7 @@ EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned
       static_for<0, j + 1>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         tt[Tri(i, j)] = Sum4(H[Tri(i, j)] - H[Tri(i, 6)] * H[Tri(j, 6)] - H[Tri(i, 7)] * H[Tri(j, 7)]) +
-                        lds(kSlotM + Tri(i, j));
+                        lds(MSlot(Tri(i, j)));
       });
       ct[j] = -s[j] - Sum4(H[Tri(j, 6)] * y6 + H[Tri(j, 7)] * y7);
     });
@@ -673,14 +706,14 @@ EPA_HD unsigned FrontEnd(const AntModel<T>& m, const Leg<V, B>& lg, V* q, const 
   });
   {
     const Sp6<V> buf = MulInert(ciF, da);  // ankle dof
-    static_for<0, 6>([&](auto kc) { lds(kSlotM + Tri(decltype(kc)::value, 7)) = root_dot(kc, buf); });
-    lds(kSlotM + Tri(6, 7)) = Dot(dh, buf);
-    lds(kSlotM + Tri(7, 7)) = Dot(da, buf) + V(m.arm[1]);
+    static_for<0, 6>([&](auto kc) { lds(MSlot(Tri(decltype(kc)::value, 7))) = root_dot(kc, buf); });
+    lds(MSlot(Tri(6, 7))) = Dot(dh, buf);
+    lds(MSlot(Tri(7, 7))) = Dot(da, buf) + V(m.arm[1]);
   }
   {
     const Sp6<V> buf = MulInert(crbA, dh);  // hip dof
-    static_for<0, 6>([&](auto kc) { lds(kSlotM + Tri(decltype(kc)::value, 6)) = root_dot(kc, buf); });
-    lds(kSlotM + Tri(6, 6)) = Dot(dh, buf) + V(m.arm[0]);
+    static_for<0, 6>([&](auto kc) { lds(MSlot(Tri(decltype(kc)::value, 6))) = root_dot(kc, buf); });
+    lds(MSlot(Tri(6, 6))) = Dot(dh, buf) + V(m.arm[0]);
   }
   // mj_comVel / mj_rne (flg_acc = 0) down the leg and back
   Sp6<V> cvA = cvel0, caA = cacc0;
@@ -718,7 +751,7 @@ EPA_HD unsigned FrontEnd(const AntModel<T>& m, const Leg<V, B>& lg, V* q, const 
       di = rdof[i - 3];
     }
     const Sp6<V> buf = MulInert(crb0, di);
-    static_for<0, i + 1>([&](auto jc) { lds(kSlotM + Tri(decltype(jc)::value, i)) = root_dot(jc, buf); });
+    static_for<0, i + 1>([&](auto jc) { lds(MSlot(Tri(decltype(jc)::value, i))) = root_dot(jc, buf); });
     qfrc[i] = -root_dot(ic, cfrc0);
   });
   // mj_instantiateLimit + mj_makeImpedance for the lane's two limited hinges
@@ -755,8 +788,7 @@ EPA_HD void ContactWrench(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, 
       constexpr int K = decltype(kc)::value;
       Contact<V> c;
       Vec3<V> C[5];
-      const B active = w == 6 ? lg.first : (lg.first | !lg.first);
-      MakeContact<K>(m, g, active, v, w, radius, invw, c, C);
+      LoadContact<K>(g, w, radius, g.lds, c, C);
       V jar[4], f[4];
       ContactJar(m, JacMul<K>(C, qacc), c, jar);
       static_for<0, 4>([&](auto kk) {
@@ -789,6 +821,18 @@ EPA_HD void Forward(const AntModel<T>& m, const Leg<V, B>& lg, const SolverCfg<T
   EPA_LDS_FENCE();
   U own;
   const unsigned sph = FrontEnd(m, lg, q, v, ctrl, lds, rows, qfrc, &own);
+  EPA_LDS_FENCE();
+  {
+    const Geo<V, typename std::remove_reference<Lds>::type> g{lds};
+    EPA_ANT4_NO_UNROLL
+    for (unsigned rem = sph; rem != 0; rem &= rem - 1) {
+      const int w = __builtin_ctz(rem);
+      DispatchSphere(m, w, [&](auto kc, T radius, T invw) {
+        const B active = w == 6 ? lg.first : (lg.first | !lg.first);
+        SetupContact<decltype(kc)::value>(m, g, active, v, w, radius, invw, lds);
+      });
+    }
+  }
   EPA_LDS_FENCE();
   Solve<U>(m, lg, lds, sph, rows, v, qfrc, cfg, qacc, n_env, n_wave);
   // profiling: + 1e3 x sphere classes the wave visits + 1e6 x those of this env

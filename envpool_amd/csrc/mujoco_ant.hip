@@ -75,9 +75,9 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
     AntDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
     AntTask task, mj::SolverCfg<T> scfg) {
   constexpr A::AntModel<T> m = A::CastAntModel<T>(kAntModelConst);
-  // lane-private LDS block [slot][lane]: local M and the contact geometry of the
-  // current forward pass (mj_ant4.cuh, FrontEnd)
-  __shared__ T lds_buf[A4::kSlots * kAntBlock];
+  // the wave's LDS block: quad-shared and lane-private slots (mj_ant4.cuh, LdsOffset): local M,
+  // the contact geometry and the contact constants of the current forward pass
+  __shared__ T lds_buf[A4::kLdsElems];
   const int lane = threadIdx.x;
   const int l = lane & 3;  // the leg this lane owns
   const int n = cm.n;
@@ -172,7 +172,7 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
   lg.ahi = (l == 0 || l == 3) ? m.hi[1] : m.hi[3];
   lg.first = l == 0;
   T lagx = T(0), lagy = T(0);
-  auto lds = [&](int slot) -> T& { return lds_buf[slot * kAntBlock + lane]; };
+  auto lds = [&](int slot) -> T& { return lds_buf[A4::LdsOffset(slot, lane)]; };
   // mj_rnePostConstraint after the last mj_step (mujoco_env.h:145-147): cfrc_ext of the
   // lane's stub / leg / ankle bodies, and of the torso body on the first lane
   T cf[3][6], cft[6];
@@ -388,6 +388,14 @@ class AntPool : public Pool {
     EPA_HIP(hipMalloc(&dev_.navail, n));
     EPA_HIP(hipMalloc(&dev_.cost, sizeof(double) * n));
     EPA_HIP(hipMemsetAsync(dev_.cost, 0, sizeof(double) * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.qpos, 0, sizeof(double) * A::kNQ * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.qvel, 0, sizeof(double) * A::kNV * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.warm, 0, sizeof(double) * A::kNV * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.lag, 0, sizeof(double) * 2 * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.nsaved, 0, sizeof(double) * n, stream_));
+    EPA_HIP(hipMemsetAsync(dev_.navail, 0, n, stream_));
+    trace_.Init("EPA_ANT_TRACE", (n + kAntEnvsPerBlock - 1) / kAntEnvsPerBlock, stream_);
+    dev_.trace = trace_.d;
     InitCommon();
     EnableObsStack();  // frame_stack > 1: generic ring (envpool/mujoco/frame_stack.h:74-146)
   }

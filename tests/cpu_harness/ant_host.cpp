@@ -43,7 +43,7 @@ static void Run(const double* q, const double* v, const double* warm, const doub
       tc[c].v[l] = (T)(a < -1 ? -1 : (a > 1 ? 1 : a));
     }
   }
-  V lds_block[A4::kSlots];
+  V lds_block[A4::kSlots];  // host: one "lane" holds the quad, every slot is private
   auto lds = [&](int slot) -> V& { return lds_block[slot]; };
   V cf[3][6], cf0[6], n_env = V(0);
   int n_wave = 0;
