@@ -28,6 +28,9 @@ def cpu_baseline(task="HalfCheetah", target_s=15.0):
     import ctypes
     import subprocess
 
+    # one OpenMP thread per core, pinned: unpinned teams gave 2.9e5 .. 5.5e5 run to run
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "port"], check=True)
     from oracle.orc import Oracle
 

@@ -19,7 +19,7 @@
 //
 // HBM-bound streaming kernel: algorithmic bytes per env-step:
 // CartPole 128, Pendulum 92, Acrobot 144.
-#include "device_common.cuh"
+#include "device_common.hip.h"
 #include "engine.h"
 
 namespace epa {

@@ -10,8 +10,8 @@
 //    even in translation units built with fast contraction (mujoco_gym.hip).
 //  * WriteCommon: the bookkeeping Env::Allocate does for every returned row
 //    (envpool/core/env.h:224-256).
-#ifndef ENVPOOL_AMD_CSRC_DEVICE_COMMON_CUH_
-#define ENVPOOL_AMD_CSRC_DEVICE_COMMON_CUH_
+#ifndef ENVPOOL_AMD_CSRC_DEVICE_COMMON_HIP_H_
+#define ENVPOOL_AMD_CSRC_DEVICE_COMMON_HIP_H_
 
 #include <hip/hip_runtime.h>
 
@@ -169,4 +169,4 @@ __device__ inline void WriteCommon(const OutPtrs& out, int row, int global_id,
 
 }  // namespace epa
 
-#endif  // ENVPOOL_AMD_CSRC_DEVICE_COMMON_CUH_
+#endif  // ENVPOOL_AMD_CSRC_DEVICE_COMMON_HIP_H_

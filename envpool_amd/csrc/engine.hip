@@ -7,7 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "device_common.cuh"
+#include "device_common.hip.h"
 
 namespace epa {
 

@@ -1,4 +1,4 @@
-// K3b — Ant model algebra shared by the step kernel (mj_ant4.cuh: one env per lane quad)
+// K3b — Ant model algebra shared by the step kernel (mj_ant4.hip.h: one env per lane quad)
 // and the host-side model compiler (mj_ant_model.h): topology constants, 3-D spatial
 // algebra in MuJoCo's c-frame, the whole-tree kinematics / CRB pass and the
 // arrow-structured 14 x 14 factorisation the compiler uses for dof_invweight0 /
@@ -21,10 +21,10 @@
 //    and the U U^T factorisation in tree order has no fill;
 //  * contacts are the 25 end spheres (torso sphere + 2 per capsule); every
 //    capsule end sits on a body origin except the four foot tips.
-#ifndef ENVPOOL_AMD_CSRC_MJ_ANT_CUH_
-#define ENVPOOL_AMD_CSRC_MJ_ANT_CUH_
+#ifndef ENVPOOL_AMD_CSRC_MJ_ANT_HIP_H_
+#define ENVPOOL_AMD_CSRC_MJ_ANT_HIP_H_
 
-#include "mj_cheetah.cuh"  // static_for, IC, Sqrt, SinCos, Impedance (generic part)
+#include "mj_cheetah.hip.h"  // static_for, IC, Sqrt, SinCos, Impedance (generic part)
 
 namespace epa {
 namespace mj {
@@ -426,4 +426,4 @@ EPA_HD void ForChainCols(const G& g, Vec3<T> cp, F&& f) {
 }  // namespace mj
 }  // namespace epa
 
-#endif  // ENVPOOL_AMD_CSRC_MJ_ANT_CUH_
+#endif  // ENVPOOL_AMD_CSRC_MJ_ANT_HIP_H_

@@ -1,6 +1,6 @@
 // K3b' — Ant `mj_step` with ONE ENV SPLIT OVER FOUR LANES (one lane per leg).
 //
-// Same arithmetic as mj_ant.cuh (MuJoCo 3.6.0's mj_step for
+// Same arithmetic as mj_ant.hip.h (MuJoCo 3.6.0's mj_step for
 // third_party/mujoco_gym_xml_patches/ant_envpool.xml, called from
 // envpool/mujoco/gym/mujoco_env.h:137-148), re-laid
 // out for the machine instead of for one thread per env:
@@ -16,11 +16,11 @@
 //    3 GB of spills per launch, profiles/r1g_ant_f64_summary.md);
 //  * the legs differ only by mirror signs (sx, sy, ankle-axis sign, ankle range),
 //    which are per-lane values: all four legs execute the SAME instructions, the
-//    9-way body switch of mj_ant.cuh becomes a 3-way switch on the sphere's link
+//    9-way body switch of mj_ant.hip.h becomes a 3-way switch on the sphere's link
 //    (stub / leg / ankle capsule) and the code is a third of the size;
 //  * leg elimination is local: U U^T from the last dof up eliminates ankle and
 //    hip inside the lane, the four Schur complements are summed over the quad
-//    (DPP butterflies, mj_quad.cuh) and every lane factors the same 6x6.
+//    (DPP butterflies, mj_quad.hip.h) and every lane factors the same 6x6.
 //    Reductions per Newton iteration: 7 + 27 + 8 numbers, + 2 per line-search
 //    evaluation;
 //  * a wave holds 16 envs: N=65536 is 4096 waves instead of 1024, which is what
@@ -29,11 +29,11 @@
 //    torso sphere), visited by a scalar loop; lanes whose sphere is outside the
 //    margin carry D = 0.  No lane-divergent control flow anywhere.
 // The same source runs on the host with V = Q4<T> (tests/cpu_harness).
-#ifndef ENVPOOL_AMD_CSRC_MJ_ANT4_CUH_
-#define ENVPOOL_AMD_CSRC_MJ_ANT4_CUH_
+#ifndef ENVPOOL_AMD_CSRC_MJ_ANT4_HIP_H_
+#define ENVPOOL_AMD_CSRC_MJ_ANT4_HIP_H_
 
-#include "mj_ant.cuh"
-#include "mj_quad.cuh"
+#include "mj_ant.hip.h"
+#include "mj_quad.hip.h"
 
 namespace epa {
 namespace mj {
@@ -55,7 +55,7 @@ EPA_HD constexpr int Tri(int i, int j) { return j * (j + 1) / 2 + i; }  // i <= 
 constexpr int kLTri = kL * (kL + 1) / 2;  // 36: [torso 21 | hip col 7 | ankle col 8]
 constexpr int kTTri = 21;                 // packed 6x6 torso block = entries 0..20
 
-// sphere classes of a lane: w = 0..5 the leg's capsule ends in mj_ant.cuh's order
+// sphere classes of a lane: w = 0..5 the leg's capsule ends in mj_ant.hip.h's order
 // (stub: aux origin, torso origin; leg capsule: foot origin, aux origin; ankle
 // capsule: tip, foot origin), w = 6 the torso sphere (first lane of the quad only)
 constexpr int kNW = 7;
@@ -196,7 +196,7 @@ struct Geo {
 
 // One contact candidate of the lane: sphere class w (wave uniform) on link K.
 // mj_collision (plane-sphere) + mj_instantiateContact + mj_makeImpedance, re-derived
-// from the body pose each time it is needed (as in mj_ant.cuh).  C[k] are the
+// from the body pose each time it is needed (as in mj_ant.hip.h).  C[k] are the
 // non-trivial columns of the 3 x 8 point Jacobian: rot 0..2, then hip, ankle for
 // K >= 1, 2 (the translational columns are the unit vectors).
 template <typename V>
@@ -258,7 +258,7 @@ EPA_HD Vec3<V> JacMul(const Vec3<V>* C, const V* a) {  // J a
   });
   return r;
 }
-// the four pyramidal rows in terms of (jx, jy, jz) = J a (mj_ant.cuh, ContactJar)
+// the four pyramidal rows in terms of (jx, jy, jz) = J a (mj_ant.hip.h, ContactJar)
 template <typename T, typename V>
 EPA_HD void ContactJar(const AntModel<T>& m, Vec3<V> ja, const Contact<V>& c, V* jar) {
   jar[0] = ja.z + V(m.mu) * ja.y - (c.an - c.ay);
@@ -426,7 +426,7 @@ EPA_HD void MulM(Lds&& lds, const V* x, V* y) {
   });
 }
 
-// mj_fwdConstraint: exact Newton on the primal objective (mj_ant.cuh, AntSolve), with
+// mj_fwdConstraint: exact Newton on the primal objective (mj_ant.hip.h, AntSolve), with
 // the leg blocks eliminated inside each lane.
 template <typename U, typename T, typename V, typename B, typename Lds>
 EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned sph,
@@ -567,7 +567,7 @@ EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned
 
 // ---- fused front end of one forward pass, one leg per lane ------------------------
 // mj_kinematics + mj_comPos + mj_crb + mj_comVel + mj_rne + mj_passive +
-// mj_fwdActuation + limit rows (mj_ant.cuh, AntFrontEnd).  q = torso pose (7,
+// mj_fwdActuation + limit rows (mj_ant.hip.h, AntFrontEnd).  q = torso pose (7,
 // replicated) + hip, ankle angle of the lane's leg; v, qfrc likewise (6 + 2).
 // Returns the wave-uniform mask of sphere classes inside the contact margin.
 template <typename U, typename T, typename V, typename B, typename Lds>
@@ -774,7 +774,7 @@ EPA_HD unsigned FrontEnd(const AntModel<T>& m, const Leg<V, B>& lg, V* q, const 
 }
 
 // mj_rnePostConstraint, cfrc_ext part, of the forward pass that just finished
-// (mj_ant.cuh, AntContactWrench): cf[3][6] = [torque about the robot COM; force] on the
+// (mj_ant.hip.h, AntContactWrench): cf[3][6] = [torque about the robot COM; force] on the
 // lane's stub / leg / ankle MuJoCo bodies, cf0[6] on the torso body (first lane).
 template <typename T, typename V, typename B, typename Lds>
 EPA_HD void ContactWrench(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned sph,
@@ -870,7 +870,7 @@ EPA_HD void IntegratePos(V* q, const V* dq, V h) {
   q[8] += h * dq[7];
 }
 
-// One mj_step with integrator RK4 (mj_ant.cuh, AntStep).  q[9], v[8], warm[8] in the
+// One mj_step with integrator RK4 (mj_ant.hip.h, AntStep).  q[9], v[8], warm[8] in the
 // lane layout (torso replicated); (lagx, lagy) = torso xpos of the LAST forward
 // evaluation, which is what data_->xpos holds afterwards (ant.h:169-173).
 // The four stages run through ONE instance of the forward pass (code size: these
@@ -969,4 +969,4 @@ constexpr bool CheckLegSymmetry(const AntModel<double>& m) {
 }  // namespace mj
 }  // namespace epa
 
-#endif  // ENVPOOL_AMD_CSRC_MJ_ANT4_CUH_
+#endif  // ENVPOOL_AMD_CSRC_MJ_ANT4_HIP_H_

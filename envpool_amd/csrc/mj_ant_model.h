@@ -1,6 +1,6 @@
 // Host-side "model compiler" for the gym Ant: MJCF numbers of
 // third_party/mujoco_gym_xml_patches/ant_envpool.xml (hand transcribed, cited by
-// XML line) -> the constants mj_ant.cuh needs, i.e. what MuJoCo's compiler +
+// XML line) -> the constants mj_ant.hip.h needs, i.e. what MuJoCo's compiler +
 // mj_setConst produce (inertiafromgeom with density 5, body_invweight0 /
 // dof_invweight0 at qpos0).  fp64; cast afterwards.
 #ifndef ENVPOOL_AMD_CSRC_MJ_ANT_MODEL_H_
@@ -8,7 +8,7 @@
 
 #include <cmath>
 
-#include "mj_ant.cuh"
+#include "mj_ant.hip.h"
 
 namespace epa {
 namespace mj {

@@ -32,8 +32,8 @@
 //    features (contact margin, Hopper's body pairs) fold away elsewhere.
 // The same source compiles for the host (EPA_HD) so tests can run it in fp64
 // on the CPU against oracle/mjcpu.
-#ifndef ENVPOOL_AMD_CSRC_MJ_CHEETAH_CUH_
-#define ENVPOOL_AMD_CSRC_MJ_CHEETAH_CUH_
+#ifndef ENVPOOL_AMD_CSRC_MJ_CHEETAH_HIP_H_
+#define ENVPOOL_AMD_CSRC_MJ_CHEETAH_HIP_H_
 
 #include <cmath>
 #include <type_traits>
@@ -1120,4 +1120,4 @@ EPA_HD int CheetahStep(const CheetahModel<T>& m, const SolverCfg<T>& cfg, T* q,
 }  // namespace mj
 }  // namespace epa
 
-#endif  // ENVPOOL_AMD_CSRC_MJ_CHEETAH_CUH_
+#endif  // ENVPOOL_AMD_CSRC_MJ_CHEETAH_HIP_H_

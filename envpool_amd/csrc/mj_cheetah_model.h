@@ -11,7 +11,7 @@
 
 #include <cmath>
 
-#include "mj_cheetah.cuh"
+#include "mj_cheetah.hip.h"
 
 namespace epa {
 namespace mj {
@@ -268,7 +268,7 @@ inline CheetahModel<double> BuildWalkerModel(bool v5) {
 // its three dofs stay at rest and never couple (M rows = diag(1)).  Frames are
 // re-centred on the hinge anchors and the -y hinges mirrored like BuildWalkerModel.
 // Unlike the other planar models the geoms collide with each other (contype =
-// conaffinity = 1, condim 1, margin 0.001 :26): see kPairBody* in mj_cheetah.cuh.
+// conaffinity = 1, condim 1, margin 0.001 :26): see kPairBody* in mj_cheetah.hip.h.
 inline CheetahModel<double> BuildHopperModel() {
   const double kPi = 3.14159265358979323846, deg = kPi / 180.0;  // angle="degree" :23
   CheetahModel<double> m{};

@@ -3,7 +3,7 @@
 // planar floating base = two slides + a hinge on the first link).  Reacher and
 // Swimmer move in the xy plane about +z, which is this file's (x, z) plane about
 // +y after z := -y.  The MuJoCo 3.6.0 forward pipeline restated for this chain, same scheme
-// as mj_cheetah.cuh (planar spatial algebra about the system COM, CRB, RNE,
+// as mj_cheetah.hip.h (planar spatial algebra about the system COM, CRB, RNE,
 // primal Newton on the constraint objective, RK4) -- without contacts: every
 // geom of inverted_pendulum_envpool.xml:21 / inverted_double_pendulum_envpool.xml:39 /
 // reacher_envpool.xml:21 / swimmer_envpool.xml:21 has contype=0, so joint limits
@@ -16,10 +16,10 @@
 //   kBaseFixed: hinge l = dof l, first anchor at the origin
 //   kBaseCart : dof 0 = cart slide x, hinge l = dof l + 1
 //   kBaseFree : dofs 0, 1 = slides x, z and dof 2 = hinge of link 0, hinge l = dof l + 2
-#ifndef ENVPOOL_AMD_CSRC_MJ_PENDULUM_CUH_
-#define ENVPOOL_AMD_CSRC_MJ_PENDULUM_CUH_
+#ifndef ENVPOOL_AMD_CSRC_MJ_PENDULUM_HIP_H_
+#define ENVPOOL_AMD_CSRC_MJ_PENDULUM_HIP_H_
 
-#include "mj_cheetah.cuh"  // static_for, V3, In4, MulInert, Dot, Cross*, Impedance, WaveAny, SolverCfg
+#include "mj_cheetah.hip.h"  // static_for, V3, In4, MulInert, Dot, Cross*, Impedance, WaveAny, SolverCfg
 
 namespace epa {
 namespace mj {
@@ -418,4 +418,4 @@ EPA_HD int PendStepRK4(const PendModel<T, NL, kBase>& m, const SolverCfg<T>& cfg
 }  // namespace mj
 }  // namespace epa
 
-#endif  // ENVPOOL_AMD_CSRC_MJ_PENDULUM_CUH_
+#endif  // ENVPOOL_AMD_CSRC_MJ_PENDULUM_HIP_H_

@@ -9,7 +9,7 @@
 
 #include <cmath>
 
-#include "mj_pendulum.cuh"
+#include "mj_pendulum.hip.h"
 
 namespace epa {
 namespace mj {
@@ -122,7 +122,7 @@ inline PendModel<double, 2, kBaseCart> BuildInvertedDoublePendulum() {
 }
 
 // reacher_envpool.xml: the two-link arm (hinges about +z in the xy plane; see the
-// header of mj_pendulum.cuh for the z := -y mapping).  The target body only has
+// header of mj_pendulum.hip.h for the z := -y mapping).  The target body only has
 // two undamped slides along x / y with zero velocity and no in-plane force (gravity
 // is along -z), so it never moves: its qpos are constants of an episode and are
 // handled by the step kernel, not by the dynamics.

@@ -1,5 +1,5 @@
 // Lane-group ("quad") execution layer for the MuJoCo kernels that split ONE env
-// over FOUR adjacent lanes of a wavefront (mj_ant4.cuh: one lane per leg).
+// over FOUR adjacent lanes of a wavefront (mj_ant4.hip.h: one lane per leg).
 //
 // The solver code is written once against a tiny vocabulary
 //   Sel(c, a, b)   per-lane select            Sum4(x) / Max4(x)  all-reduce over the quad
@@ -15,10 +15,10 @@
 //   * host (tests/cpu_harness): a value is Q4<T>, four lanes in a struct, with the
 //     same reduction order -- so the product source runs on a CPU box against
 //     oracle/mjcpu.
-#ifndef ENVPOOL_AMD_CSRC_MJ_QUAD_CUH_
-#define ENVPOOL_AMD_CSRC_MJ_QUAD_CUH_
+#ifndef ENVPOOL_AMD_CSRC_MJ_QUAD_HIP_H_
+#define ENVPOOL_AMD_CSRC_MJ_QUAD_HIP_H_
 
-#include "mj_cheetah.cuh"  // EPA_HD, static_for, WaveAny, SinCos, Rsqrt
+#include "mj_cheetah.hip.h"  // EPA_HD, static_for, WaveAny, SinCos, Rsqrt
 
 namespace epa {
 namespace mj {
@@ -204,4 +204,4 @@ EPA_HD bool IsFinite(double x) { return x - x == 0.0; }
 }  // namespace mj
 }  // namespace epa
 
-#endif  // ENVPOOL_AMD_CSRC_MJ_QUAD_CUH_
+#endif  // ENVPOOL_AMD_CSRC_MJ_QUAD_HIP_H_

@@ -33,14 +33,14 @@
 //    aref_r + R_r f_r,  a += delta W_r,  W_r = M^-1 J_r') and streams (J_r, W_r) pairs
 //    through a register ring prefetched two visits ahead;
 //  * no lane-divergent control flow except one branch: per-lane differences are selects,
-//    finished lanes run with frozen iterates (WaveAny, see mj_cheetah.cuh); only in the
+//    finished lanes run with frozen iterates (WaveAny, see mj_cheetah.hip.h); only in the
 //    streaming sweep do converged lanes skip their row traffic.
 // The same source compiles for the host (EPA_HD, lane stride 1) so tests run it on the CPU
 // against oracle/mjcpu.
-#ifndef ENVPOOL_AMD_CSRC_MJ_TREE_CUH_
-#define ENVPOOL_AMD_CSRC_MJ_TREE_CUH_
+#ifndef ENVPOOL_AMD_CSRC_MJ_TREE_HIP_H_
+#define ENVPOOL_AMD_CSRC_MJ_TREE_HIP_H_
 
-#include "mj_cheetah.cuh"  // EPA_HD, static_for, WaveAny, WaveUniform, SinCos
+#include "mj_cheetah.hip.h"  // EPA_HD, static_for, WaveAny, WaveUniform, SinCos
 
 namespace epa {
 namespace mj {
@@ -1467,4 +1467,4 @@ struct Tree {
 }  // namespace mj
 }  // namespace epa
 
-#endif  // ENVPOOL_AMD_CSRC_MJ_TREE_CUH_
+#endif  // ENVPOOL_AMD_CSRC_MJ_TREE_HIP_H_

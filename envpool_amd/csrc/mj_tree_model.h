@@ -1,4 +1,4 @@
-// Host-side model compiler for mj_tree.cuh: turns a hand-transcribed MJCF subset (free
+// Host-side model compiler for mj_tree.hip.h: turns a hand-transcribed MJCF subset (free
 // root body, hinge joints, sphere / capsule geoms, joint motors, a floor plane) into the
 // constants MuJoCo's compiler would produce -- inertiafromgeom, body frames, the dof tree,
 // qpos0, and dof_invweight0 / body_invweight0 / meaninertia evaluated at qpos0 -- plus the
@@ -15,7 +15,7 @@
 #include <stdexcept>
 #include <vector>
 
-#include "mj_tree.cuh"
+#include "mj_tree.hip.h"
 
 namespace epa {
 namespace mj {

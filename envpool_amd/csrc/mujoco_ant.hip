@@ -1,17 +1,17 @@
 // K3b — gym-MuJoCo Ant batched step kernel: ONE ENV PER LANE QUAD (one lane per
-// leg, 16 envs per wavefront, one wave per block), see mj_ant4.cuh.
+// leg, 16 envs per wavefront, one wave per block), see mj_ant4.hip.h.
 //
 // Replaces, for the whole batch in one launch:
 //   MujocoEnv::{MujocoReset,MujocoStep}   envpool/mujoco/gym/mujoco_env.h:126-148
 //   AntEnvBase::{MujocoResetModel,Reset,Step,IsHealthy,WriteState}
 //                                         envpool/mujoco/gym/ant.h:135-278
-// with `frame_skip x mj_step` (RK4: 4 forward passes each) from mj_ant4.cuh.
+// with `frame_skip x mj_step` (RK4: 4 forward passes each) from mj_ant4.hip.h.
 // Ant-v4: use_contact_force=false (no cfrc_ext in obs, contact cost 0).
 // Ant-v3: use_contact_force=true but post_constraint=false: MuJoCo 3 fills
 //   cfrc_ext only in mj_rnePostConstraint, which the reference then never calls
 //   (mujoco_env.h:145-147) => 84 zeros in the obs, contact cost 0.
 // Ant-v5: use_contact_force + post_constraint: cfrc_ext of the last forward
-//   evaluation (mj_ant4.cuh, ContactWrench), world body excluded.
+//   evaluation (mj_ant4.hip.h, ContactWrench), world body excluded.
 //
 // Persistent state (SoA fp64): qpos[15][N], qvel[14][N], qacc_warmstart[14][N],
 // lag[2][N] = data_->xpos[torso].xy of the last forward pass (the reference
@@ -19,9 +19,9 @@
 // env's normal_distribution saved value.  Lane l of a quad loads / stores the
 // torso part (replicated) and the two dofs of leg l; lane 0 writes what is per env.
 #define EPA_SINCOS_MODE 1
-#include "device_common.cuh"
+#include "device_common.hip.h"
 #include "engine.h"
-#include "mj_ant4.cuh"
+#include "mj_ant4.hip.h"
 #include "mj_ant_model.h"
 #include "build/mj_ant_consts.inc"  // generated: kAntModelConst (gen_mj_consts.cpp)
 
@@ -32,7 +32,7 @@ namespace A = mj::ant;
 namespace A4 = mj::ant4;
 
 static_assert(A4::CheckLegSymmetry(kAntModelConst),
-              "ant_envpool.xml no longer has the mirror structure mj_ant4.cuh relies on");
+              "ant_envpool.xml no longer has the mirror structure mj_ant4.hip.h relies on");
 
 struct AntDev {
   double* qpos;  // [15][N]
@@ -75,7 +75,7 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
     AntDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
     AntTask task, mj::SolverCfg<T> scfg) {
   constexpr A::AntModel<T> m = A::CastAntModel<T>(kAntModelConst);
-  // the wave's LDS block: quad-shared and lane-private slots (mj_ant4.cuh, LdsOffset): local M,
+  // the wave's LDS block: quad-shared and lane-private slots (mj_ant4.hip.h, LdsOffset): local M,
   // the contact geometry and the contact constants of the current forward pass
   __shared__ T lds_buf[A4::kLdsElems];
   const int lane = threadIdx.x;

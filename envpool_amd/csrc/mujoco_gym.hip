@@ -7,7 +7,7 @@
 //                                           envpool/mujoco/gym/half_cheetah.h:105-185
 //   Walker2dEnvBase::{...}                  envpool/mujoco/gym/walker2d.h:119-219
 //   HopperEnvBase::{...}                    envpool/mujoco/gym/hopper.h:121-230
-// including the `frame_skip x mj_step` physics (mj_cheetah.cuh) and the
+// including the `frame_skip x mj_step` physics (mj_cheetah.hip.h) and the
 // runtime around it (async_envpool.h:118-132, env.h:184-256).
 //
 // Data layout (HBM): persistent state is SoA float64 — qpos[9][N], qvel[9][N],
@@ -20,9 +20,9 @@
 //
 // Not HBM-bound: ~708 algorithmic bytes vs ~2e5 flops per env-step
 // => bound by fp32 VALU issue + wave divergence in the Newton iteration count.
-#include "device_common.cuh"
+#include "device_common.hip.h"
 #include "engine.h"
-#include "mj_cheetah.cuh"
+#include "mj_cheetah.hip.h"
 #include "mj_cheetah_model.h"
 #include "build/mj_cheetah_consts.inc"  // generated: kCheetahModelConst (gen_mj_consts.cpp)
 #include "build/mj_walker_consts.inc"   // generated: kWalkerModelConst, kWalkerV5ModelConst, kHopperModelConst
@@ -60,7 +60,7 @@ struct CheetahTask {
   int terminate_when_unhealthy, legacy_healthy_reward;
 };
 
-// compile-time model of the planar kernel instance (mj_cheetah.cuh, PlanarModelId)
+// compile-time model of the planar kernel instance (mj_cheetah.hip.h, PlanarModelId)
 template <typename T, int kModel>
 constexpr CheetahModel<T> PlanarModel() {
   if constexpr (kModel == mj::kPlanarCheetah) {

@@ -1,5 +1,5 @@
 // K3c — gym-MuJoCo Humanoid / HumanoidStandup batched step kernel (one env per lane, one
-// wave per workgroup, per-env workspace in HBM: see mj_tree.cuh).
+// wave per workgroup, per-env workspace in HBM: see mj_tree.hip.h).
 //
 // Replaces, for the whole batch in one launch:
 //   MujocoEnv::{MujocoReset,MujocoStep}   envpool/mujoco/gym/mujoco_env.h:126-148
@@ -16,10 +16,10 @@
 // the LAST forward evaluation (RK4 stage 4 of the last sub-step), like the mjData fields the
 // reference reads; the mass centre "before" a step is therefore the lagged one of the
 // previous step (persistent slot `lag`).
-#define EPA_SINCOS_MODE 0  // see mj_cheetah.cuh; Humanoid: mode 1 lets the scheduler interleave 17 joints (2.3 k VGPR spills, 1.94 -> 1.77 M env-steps/s)
-#include "device_common.cuh"
+#define EPA_SINCOS_MODE 0  // see mj_cheetah.hip.h; Humanoid: mode 1 lets the scheduler interleave 17 joints (2.3 k VGPR spills, 1.94 -> 1.77 M env-steps/s)
+#include "device_common.hip.h"
 #include "engine.h"
-#include "mj_tree.cuh"
+#include "mj_tree.hip.h"
 #include "build/mj_humanoid_consts.inc"  // generated: kHumanoidModelConst, kHumanoidStandupModelConst
 
 namespace epa {

@@ -6,13 +6,13 @@
 //   InvertedDoublePendulumEnvBase::{...}       envpool/mujoco/gym/inverted_double_pendulum.h:108-186
 //   ReacherEnvBase::{...}                      envpool/mujoco/gym/reacher.h:112-221
 //   SwimmerEnvBase::{...}                      envpool/mujoco/gym/swimmer.h:110-186
-// with the `frame_skip x mj_step` (RK4) physics of mj_pendulum.cuh.  No contacts
+// with the `frame_skip x mj_step` (RK4) physics of mj_pendulum.hip.h.  No contacts
 // (every geom has contype 0), joint limits only; state is 3 x nv doubles per env,
 // so unlike the legged robots this kernel is HBM-streaming: 2 (3) dofs, ~2e3
 // flops and ~250 algorithmic bytes per env-step.
-#include "device_common.cuh"
+#include "device_common.hip.h"
 #include "engine.h"
-#include "mj_pendulum.cuh"
+#include "mj_pendulum.hip.h"
 #include "mj_pendulum_model.h"
 
 namespace epa {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kPendBlock) void ReacherStepKernel(
     const double zero[2] = {0.0, 0.0};
     P::PendForward(m, scfg, q, v, zero, w, qacc, aux);  // mj_forward: xpos, warm start
     fx = aux.tip_x;
-    fy = -aux.tip_z;  // the kernel's z axis is -y of the model (mj_pendulum.cuh)
+    fy = -aux.tip_z;  // the kernel's z axis is -y of the model (mj_pendulum.hip.h)
     dev.qpos[(size_t)2 * n + e] = tx;
     dev.qpos[(size_t)3 * n + e] = ty;
     dev.qvel[(size_t)2 * n + e] = 0.0;

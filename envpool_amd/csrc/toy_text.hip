@@ -11,10 +11,10 @@
 //
 // Data layout (HBM): the whole discrete state of an env is packed into one
 // int32 word (two for Blackjack) kept SoA `w0[N]`, `w1[N]`; the per-env
-// std::mt19937 lives in CommonDev (device_common.cuh).  All integer work;
+// std::mt19937 lives in CommonDev (device_common.hip.h).  All integer work;
 // NChain's `uniform_real < 0.2` branch needs exact fp64 => -ffp-contract=off.
 // HBM-bound: ~72 algorithmic bytes per env-step.
-#include "device_common.cuh"
+#include "device_common.hip.h"
 #include "engine.h"
 
 namespace epa {

@@ -1,7 +1,7 @@
-// TEST HARNESS (not product): host instantiation of mj_ant4.cuh -- the product's
+// TEST HARNESS (not product): host instantiation of mj_ant4.hip.h -- the product's
 // four-lanes-per-env Ant kernel source with a lane quad emulated by Q4<T> -- for
 // diffing against oracle/mjcpu on a CPU box.  Not linked by envpool_amd/.
-#include "../../envpool_amd/csrc/mj_ant4.cuh"
+#include "../../envpool_amd/csrc/mj_ant4.hip.h"
 #include "../../envpool_amd/csrc/mj_ant_model.h"
 
 using epa::mj::B4;

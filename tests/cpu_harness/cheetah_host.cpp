@@ -1,5 +1,5 @@
 // TEST HARNESS (not product): compiles the host instantiation of the planar
-// HalfCheetah step template (envpool_amd/csrc/mj_cheetah.cuh, EPA_HD) with g++
+// HalfCheetah step template (envpool_amd/csrc/mj_cheetah.hip.h, EPA_HD) with g++
 // so the exact kernel source can be diffed against oracle/mjcpu on a CPU box.
 // Nothing in envpool_amd/ links or loads this.
 #include <cstring>

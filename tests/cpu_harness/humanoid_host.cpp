@@ -1,4 +1,4 @@
-// TEST HARNESS (not product): host instantiation of mj_tree.cuh (lane stride 1) for diffing
+// TEST HARNESS (not product): host instantiation of mj_tree.hip.h (lane stride 1) for diffing
 // against oracle/mjcpu on a CPU box.  Not linked by envpool_amd/.
 #include <vector>
 

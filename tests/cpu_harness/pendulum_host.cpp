@@ -1,4 +1,4 @@
-// TEST HARNESS (not product): host instantiation of mj_pendulum.cuh for diffing
+// TEST HARNESS (not product): host instantiation of mj_pendulum.hip.h for diffing
 // against oracle/mjcpu on a CPU box.  Not linked by envpool_amd/.
 #include "../../envpool_amd/csrc/mj_pendulum_model.h"
 

@@ -298,7 +298,7 @@ def test_walker_deterministic():
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
-# ---- InvertedPendulum / InvertedDoublePendulum (mj_pendulum.cuh: no contacts, RK4) ----
+# ---- InvertedPendulum / InvertedDoublePendulum (mj_pendulum.hip.h: no contacts, RK4) ----
 @pytest.mark.parametrize("task,nv,amax,params,extra", [
     ("InvertedPendulum", 2, 3.0, {}, ()),
     ("InvertedDoublePendulum", 3, 1.0, {}, ()),
@@ -598,7 +598,7 @@ def test_chain_families_frame_stack(task, adim, amax, S):
     np.testing.assert_allclose(a["obs"], ring[ids], rtol=1e-9, atol=1e-10)
 
 
-# ---- Humanoid / HumanoidStandup (mj_tree.cuh: HBM workspace, PGS, self collisions) ----
+# ---- Humanoid / HumanoidStandup (mj_tree.hip.h: HBM workspace, PGS, self collisions) ----
 # name, native family, native params, oracle extras (see oracle/mjcpu/tasks.c), obs dim
 _HUM_VARIANTS = [
     ("Humanoid-v4", "Humanoid", {"post_constraint": 0}, {}, 376),

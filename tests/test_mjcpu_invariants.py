@@ -99,7 +99,7 @@ def test_cheetah_stays_planar_and_ant_mirror_symmetry():
 
 
 def test_product_planar_code_matches_oracle_on_cpu():
-    """Host instantiation of the exact kernel source (mj_cheetah.cuh; mj_ant4.cuh with
+    """Host instantiation of the exact kernel source (mj_cheetah.hip.h; mj_ant4.hip.h with
     its lane quad emulated by Q4<double>) vs the oracle, teacher forced: two independent
     formulations."""
     from oracle.orc import Oracle
@@ -109,7 +109,7 @@ def test_product_planar_code_matches_oracle_on_cpu():
         so = os.path.join(h, f"lib{name}_host.so")
         src = os.path.join(h, f"{name}_host.cpp")
         hdrs = [os.path.join(ROOT, "envpool_amd", "csrc", f) for f in
-                ("mj_cheetah.cuh", "mj_ant.cuh", "mj_ant4.cuh", "mj_quad.cuh", "mj_ant_model.h")]
+                ("mj_cheetah.hip.h", "mj_ant.hip.h", "mj_ant4.hip.h", "mj_quad.hip.h", "mj_ant_model.h")]
         newest = max(os.path.getmtime(f) for f in [src] + hdrs)
         if not os.path.exists(so) or os.path.getmtime(so) < newest:
             subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so],
@@ -150,7 +150,7 @@ def test_product_planar_code_matches_oracle_on_cpu():
 
 
 def test_product_ant_quad_layout_on_cpu():
-    """mj_ant4.cuh (one env per lane quad, Q4 emulation): the mirror structure it relies
+    """mj_ant4.hip.h (one env per lane quad, Q4 emulation): the mirror structure it relies
     on holds exactly for the compiled model, fp32 instantiation stays close to fp64, and the
     Ant-v5 contact wrench (cfrc_ext of the last forward evaluation, assembled per lane and
     reduced over the quad) matches the oracle's mj_rnePostConstraint."""
@@ -159,7 +159,7 @@ def test_product_ant_quad_layout_on_cpu():
     h = os.path.join(ROOT, "tests", "cpu_harness")
     so, src = os.path.join(h, "libant_host.so"), os.path.join(h, "ant_host.cpp")
     hdrs = [os.path.join(ROOT, "envpool_amd", "csrc", f) for f in
-            ("mj_ant.cuh", "mj_ant4.cuh", "mj_quad.cuh", "mj_ant_model.h")]
+            ("mj_ant.hip.h", "mj_ant4.hip.h", "mj_quad.hip.h", "mj_ant_model.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
     L = ctypes.CDLL(so)
@@ -196,14 +196,14 @@ def test_product_ant_quad_layout_on_cpu():
 
 
 def test_product_pendulum_code_matches_oracle_on_cpu():
-    """Host instantiation of mj_pendulum.cuh (cart + 1 / 2 link chain, limit rows,
+    """Host instantiation of mj_pendulum.hip.h (cart + 1 / 2 link chain, limit rows,
     RK4) vs the generic oracle, teacher forced, including states pushed against
     the slider / hinge limits."""
     from oracle.orc import Oracle
 
     h = os.path.join(ROOT, "tests", "cpu_harness")
     so, src = os.path.join(h, "libpendulum_host.so"), os.path.join(h, "pendulum_host.cpp")
-    hdr = os.path.join(ROOT, "envpool_amd", "csrc", "mj_pendulum.cuh")
+    hdr = os.path.join(ROOT, "envpool_amd", "csrc", "mj_pendulum.hip.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
     L = ctypes.CDLL(so)
@@ -248,13 +248,13 @@ def test_product_pendulum_code_matches_oracle_on_cpu():
 
 
 def test_product_reacher_code_matches_oracle_on_cpu():
-    """Host instantiation of the cart-less chain (mj_pendulum.cuh, Reacher model) vs
+    """Host instantiation of the cart-less chain (mj_pendulum.hip.h, Reacher model) vs
     the generic oracle: arm state and the lagged fingertip position."""
     from oracle.orc import Oracle
 
     h = os.path.join(ROOT, "tests", "cpu_harness")
     so, src = os.path.join(h, "libpendulum_host.so"), os.path.join(h, "pendulum_host.cpp")
-    hdr = os.path.join(ROOT, "envpool_amd", "csrc", "mj_pendulum.cuh")
+    hdr = os.path.join(ROOT, "envpool_amd", "csrc", "mj_pendulum.hip.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
     L = ctypes.CDLL(so)
@@ -290,12 +290,12 @@ def test_product_reacher_code_matches_oracle_on_cpu():
 
 def test_product_swimmer_code_matches_oracle_on_cpu():
     """Host instantiation of the planar floating chain with the inertia-box fluid
-    forces (mj_pendulum.cuh, Swimmer model; y mirrored) vs the generic 3-D oracle."""
+    forces (mj_pendulum.hip.h, Swimmer model; y mirrored) vs the generic 3-D oracle."""
     from oracle.orc import Oracle
 
     h = os.path.join(ROOT, "tests", "cpu_harness")
     so, src = os.path.join(h, "libpendulum_host.so"), os.path.join(h, "pendulum_host.cpp")
-    hdr = os.path.join(ROOT, "envpool_amd", "csrc", "mj_pendulum.cuh")
+    hdr = os.path.join(ROOT, "envpool_amd", "csrc", "mj_pendulum.hip.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
     L = ctypes.CDLL(so)
@@ -336,7 +336,7 @@ def test_product_hopper_code_matches_oracle_on_cpu():
 
     h = os.path.join(ROOT, "tests", "cpu_harness")
     so, src = os.path.join(h, "libcheetah_host.so"), os.path.join(h, "cheetah_host.cpp")
-    hdr = os.path.join(ROOT, "envpool_amd", "csrc", "mj_cheetah.cuh")
+    hdr = os.path.join(ROOT, "envpool_amd", "csrc", "mj_cheetah.hip.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
     L = ctypes.CDLL(so)
@@ -385,7 +385,7 @@ def test_product_hopper_code_matches_oracle_on_cpu():
 
 
 def test_product_tree_code_matches_oracle_on_cpu():
-    """Host instantiation of mj_tree.cuh (the Humanoid / HumanoidStandup kernel source:
+    """Host instantiation of mj_tree.hip.h (the Humanoid / HumanoidStandup kernel source:
     static-slot constraint rows, PGS on a = qacc_smooth + M^-1 J'f, sparse L'DL) vs the
     oracle's dense generic engine, teacher forced per env-step (5 RK4 mj_steps), including
     mj_rnePostConstraint's cfrc_ext.  The standup episode lies on the floor: dozens of
@@ -396,7 +396,7 @@ def test_product_tree_code_matches_oracle_on_cpu():
     subprocess.run(["make", "-s", "-C", csrc, "build/mj_humanoid_consts.inc"], check=True)
     h = os.path.join(ROOT, "tests", "cpu_harness")
     so, src = os.path.join(h, "libhumanoid_host.so"), os.path.join(h, "humanoid_host.cpp")
-    deps = [src, os.path.join(csrc, "mj_tree.cuh"), os.path.join(csrc, "mj_tree_model.h"),
+    deps = [src, os.path.join(csrc, "mj_tree.hip.h"), os.path.join(csrc, "mj_tree_model.h"),
             os.path.join(csrc, "build", "mj_humanoid_consts.inc")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)

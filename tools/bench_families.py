@@ -29,7 +29,7 @@ FAMILIES = [
     ("NChain", {}, 1000, ("int", 2), 72),
     ("CliffWalking", {"is_slippery": 1}, 0, ("int", 4), 76),
     ("Blackjack", {}, 0, ("int", 2), 84),
-    # gym-MuJoCo pendulums (mj_pendulum.cuh): 16 in + 26 + obs out + 2 x (3 nv doubles + 5) state
+    # gym-MuJoCo pendulums (mj_pendulum.hip.h): 16 in + 26 + obs out + 2 x (3 nv doubles + 5) state
     ("InvertedPendulum", {}, 1000, ("float64", 3.0), 16 + 58 + 106),
     ("InvertedDoublePendulum", {}, 1000, ("float64", 1.0), 16 + 114 + 172),
     ("Reacher", {}, 50, ("float64x2", 1.0), 24 + 26 + 88 + 16 + 2 * (12 * 8 + 16 + 5)),
