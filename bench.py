@@ -189,18 +189,21 @@ def main():
         # algorithmic bytes / env-step: action+ids
         # in, every state key out, persistent fp64 state read + written
         # Humanoid: 8 + 136 in, 26 + 376 x 8 + 72 out, 2 x 72 persistent doubles
+        # Pusher: 8 + 56 in, 26 + 23 x 8 + 24 out, 2 x 34 persistent doubles (q 11, v 9, warm 9, lag 5)
         alg_bytes = {"HalfCheetah": 708, "Ant": 1132, "Walker2d": 692, "Hopper": 476,
-                     "Humanoid": 4402, "HumanoidStandup": 4362}[args.task]
+                     "Humanoid": 4402, "HumanoidStandup": 4362, "Pusher": 842}[args.task]
         frame_skip = {"HalfCheetah": 5, "Ant": 5, "Walker2d": 4, "Hopper": 4,
-                      "Humanoid": 5, "HumanoidStandup": 5}[args.task]
+                      "Humanoid": 5, "HumanoidStandup": 5, "Pusher": 5}[args.task]
         # counted fp32 flops / env-step from the kernel's ISA
         achieved_gbs = alg_bytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # HBM traffic and flop counts come from the committed rocprofv3 PMC passes of
         # this same command (tools/profile_bench.sh -> profiles/pmc.json): PMC
         # collection needs its own rocprofv3 runs and cannot happen inside the bench.
         kbase = ("AntStepKernel" if args.task == "Ant" else
-                 "HumanoidStepKernel" if args.task.startswith("Humanoid") else "CheetahStepKernel")
-        kname = kbase + ("<double>" if args.precision == "fp64" or args.task.startswith("Humanoid")
+                 "HumanoidStepKernel" if args.task.startswith("Humanoid") else
+                 "PusherStepKernel" if args.task == "Pusher" else "CheetahStepKernel")
+        kname = kbase + ("" if args.task == "Pusher" else
+                         "<double>" if args.precision == "fp64" or args.task.startswith("Humanoid")
                          else "<float>")
         if args.task in ("Walker2d", "Hopper"):
             kname += f"[{args.task}]"

@@ -708,7 +708,7 @@ const std::vector<std::string>& FamilyNames() {
   static const std::vector<std::string> names = {
       "CartPole", "Pendulum", "MountainCar", "MountainCarContinuous", "Acrobot",
       "Catch", "FrozenLake", "Taxi", "NChain", "CliffWalking", "Blackjack",
-      "HalfCheetah", "Ant", "Walker2d", "InvertedPendulum", "InvertedDoublePendulum", "Reacher", "Swimmer", "Hopper", "Humanoid", "HumanoidStandup"};
+      "HalfCheetah", "Ant", "Walker2d", "InvertedPendulum", "InvertedDoublePendulum", "Reacher", "Swimmer", "Hopper", "Humanoid", "HumanoidStandup", "Pusher"};
   return names;
 }
 

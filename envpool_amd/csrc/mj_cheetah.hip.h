@@ -168,6 +168,8 @@ EPA_HD void SinCos(T x, T* s, T* c) {
 EPA_HD bool WaveAny(bool x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_ballot_w64(x) != 0;
+#elif defined(EPA_HOST_WAVE_ANY)
+  return EPA_HOST_WAVE_ANY(x);  // tests/cpu_harness: emulate a wave whose other lanes are still busy
 #else
   return x;
 #endif

@@ -466,6 +466,9 @@ Pool* MakePendulum(const std::string& family, const Config& cfg);
 bool DescribeHumanoid(const std::string& family, const Config& cfg,
                       std::vector<KeySpec>* state, KeySpec* action);
 Pool* MakeHumanoid(const std::string& family, const Config& cfg);
+bool DescribePusher(const std::string& family, const Config& cfg,
+                    std::vector<KeySpec>* state, KeySpec* action);
+Pool* MakePusher(const std::string& family, const Config& cfg);
 
 bool DescribeMujoco(const std::string& family, const Config& cfg,
                     std::vector<KeySpec>* state, KeySpec* action) {
@@ -476,6 +479,7 @@ bool DescribeMujoco(const std::string& family, const Config& cfg,
   }
   if (DescribePendulum(family, cfg, state, action)) return true;
   if (DescribeHumanoid(family, cfg, state, action)) return true;
+  if (DescribePusher(family, cfg, state, action)) return true;
   return DescribeAnt(family, cfg, state, action);
 }
 
@@ -489,6 +493,7 @@ Pool* MakeMujoco(const std::string& family, const Config& cfg) {
   }
   if (Pool* p = MakePendulum(family, cfg)) return p;
   if (Pool* p = MakeHumanoid(family, cfg)) return p;
+  if (Pool* p = MakePusher(family, cfg)) return p;
   return MakeAnt(family, cfg);
 }
 

@@ -258,6 +258,48 @@ _Reacher = FamilyDef(
     unsupported={"xml_file": "reacher.xml"},
 )
 
+def _pusher_xml(c: dict) -> int:
+    # pusher_envpool.xml / pusher_v5_envpool.xml (mujoco_env.h:50-58 resolves them from these names)
+    if c["xml_file"] not in ("pusher.xml", "pusher_v5.xml"):
+        raise ValueError(
+            f"GymPusher: xml_file={c['xml_file']!r} is not supported by the MI355X "
+            "engine (only 'pusher.xml' and 'pusher_v5.xml')")
+    return 1 if c["xml_file"] == "pusher_v5.xml" else 0
+
+
+_Pusher = FamilyDef(
+    name="GymPusher", native="Pusher",
+    # pusher.h:33-46
+    default_config=[
+        ("reward_threshold", 0.0), ("frame_skip", 5), ("frame_stack", 1),
+        ("post_constraint", True), ("ctrl_cost_weight", 0.1), ("dist_cost_weight", 1.0),
+        ("near_cost_weight", 0.5), ("xml_file", "pusher.xml"),
+        ("gymnasium_v5_render_camera", False), ("reward_after_step", False),
+        ("weighted_reward_info", False), ("reset_qvel_scale", 0.005),
+        ("cylinder_x_min", -0.3), ("cylinder_x_max", 0.0), ("cylinder_y_min", -0.2),
+        ("cylinder_y_max", 0.2), ("cylinder_dist_min", 0.17),
+    ],
+    state_spec=lambda c: [
+        ("obs", spec(np.float64, _stack([23], c), (-_inf, _inf))),
+        ("info:reward_dist", spec(np.float64, [-1])),
+        ("info:reward_ctrl", spec(np.float64, [-1])),
+        ("info:reward_near", spec(np.float64, [-1])),
+    ],
+    action_spec=lambda c: [("action", spec(np.float64, [-1, 7], (-2.0, 2.0)))],
+    native_params=lambda c: {
+        "frame_skip": c["frame_skip"], "frame_stack": c["frame_stack"],
+        "ctrl_cost_weight": c["ctrl_cost_weight"], "dist_cost_weight": c["dist_cost_weight"],
+        "near_cost_weight": c["near_cost_weight"],
+        "reward_after_step": c["reward_after_step"],
+        "weighted_reward_info": c["weighted_reward_info"],
+        "reset_qvel_scale": c["reset_qvel_scale"],
+        "cylinder_x_min": c["cylinder_x_min"], "cylinder_x_max": c["cylinder_x_max"],
+        "cylinder_y_min": c["cylinder_y_min"], "cylinder_y_max": c["cylinder_y_max"],
+        "cylinder_dist_min": c["cylinder_dist_min"],
+        "xml_v5": _pusher_xml(c),
+    },
+)
+
 _Swimmer = FamilyDef(
     name="GymSwimmer", native="Swimmer",
     # swimmer.h:32-42
@@ -424,6 +466,9 @@ _GymHopperEnvSpec, _GymHopperEnvPool = make_native_classes(_Hopper)
 _GymSwimmerEnvSpec, _GymSwimmerEnvPool = make_native_classes(_Swimmer)
 (GymSwimmerEnvSpec, GymSwimmerDMEnvPool,
  GymSwimmerGymnasiumEnvPool) = py_env(_GymSwimmerEnvSpec, _GymSwimmerEnvPool)
+_GymPusherEnvSpec, _GymPusherEnvPool = make_native_classes(_Pusher)
+(GymPusherEnvSpec, GymPusherDMEnvPool,
+ GymPusherGymnasiumEnvPool) = py_env(_GymPusherEnvSpec, _GymPusherEnvPool)
 _GymReacherEnvSpec, _GymReacherEnvPool = make_native_classes(_Reacher)
 (GymReacherEnvSpec, GymReacherDMEnvPool,
  GymReacherGymnasiumEnvPool) = py_env(_GymReacherEnvSpec, _GymReacherEnvPool)
@@ -451,7 +496,8 @@ __all__ = ["GymHalfCheetahEnvSpec", "GymHalfCheetahDMEnvPool",
            "GymInvertedPendulumDMEnvPool", "GymInvertedPendulumGymnasiumEnvPool",
            "GymInvertedDoublePendulumEnvSpec", "GymInvertedDoublePendulumDMEnvPool",
            "GymInvertedDoublePendulumGymnasiumEnvPool", "GymReacherEnvSpec",
-           "GymReacherDMEnvPool", "GymReacherGymnasiumEnvPool", "GymSwimmerEnvSpec",
+           "GymReacherDMEnvPool", "GymReacherGymnasiumEnvPool", "GymPusherEnvSpec",
+           "GymPusherDMEnvPool", "GymPusherGymnasiumEnvPool", "GymSwimmerEnvSpec",
            "GymSwimmerDMEnvPool", "GymSwimmerGymnasiumEnvPool", "GymHopperEnvSpec",
            "GymHopperDMEnvPool", "GymHopperGymnasiumEnvPool", "GymHumanoidEnvSpec",
            "GymHumanoidDMEnvPool", "GymHumanoidGymnasiumEnvPool",

@@ -34,6 +34,11 @@ _TASKS = {
         "v5": {"constraint_obs_dim": 1, "reward_if_not_terminated": True},
     }),
     "InvertedPendulum": (1000, {"v2": {}, "v4": {}, "v5": {"reward_if_not_terminated": True}}),
+    "Pusher": (100, {
+        "v2": {}, "v4": {},
+        "v5": {"xml_file": "pusher_v5.xml", "reward_after_step": True,
+               "weighted_reward_info": True},
+    }),
     "Reacher": (50, {
         "v2": {}, "v4": {},
         "v5": {"reward_after_step": True, "obs_include_z_distance": False},
@@ -44,8 +49,6 @@ _TASKS = {
         "v5": {"xml_file": "walker2d_v5.xml", "legacy_healthy_reward": False},
     }),
 }
-# Pusher (capsule-cylinder contacts go through MuJoCo's general convex collider) has no
-# kernel and is not registered.
 
 for _task, (_steps, _versions) in _TASKS.items():
     for _version, _extra in _versions.items():

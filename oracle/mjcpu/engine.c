@@ -326,6 +326,107 @@ static void add_capsule_capsule(const mjc_model* m, mjc_data* d, int g1, int g2,
   add_sphere_sphere(m, d, g1, g2, p1, m->geom_size[g1][0], p2, m->geom_size[g2][0], margin);
 }
 
+/* Capsule (g1) vs cylinder (g2).  MuJoCo sends this pair through its general convex
+ * collider (mjc_Convex: GJK / EPA, tolerance 1e-6), which is not restated; this is the
+ * geometric quantity that collider converges to -- the closest points between the capsule's
+ * axis segment and the solid cylinder -- by a deterministic rule:
+ *   F(t) = dist^2(P(t), cylinder) is convex in the segment parameter t; g(t) = F'(t) / 2 is
+ *   monotone.  Two bisections bracket the minimiser set [ta, tb] = [last t with g < -eps,
+ *   first t with g > +eps] and the contact uses its midpoint (unique minimum: ta ~ tb; a
+ *   segment parallel to a face or the side: the middle of the closest stretch).
+ * One contact (multiccd is off by default), frame normal from the capsule to the cylinder.
+ * Agreement with MuJoCo itself is bounded by its collider's tolerance: 1e-6 m in dist. */
+static double capcyl_g(const double* p0, const double* dp, double t, const double* c,
+                       const double* u, double R, double H, double* Pout, double* Qout) {
+  double P[3], rel[3], rad[3];
+  for (int k = 0; k < 3; ++k) P[k] = p0[k] + t * dp[k];
+  v3_sub(rel, P, c);
+  double z = v3_dot(rel, u);
+  for (int k = 0; k < 3; ++k) rad[k] = rel[k] - z * u[k];
+  double rho = v3_norm(rad);
+  double zd = v3_dot(dp, u), rd[3];
+  for (int k = 0; k < 3; ++k) rd[k] = dp[k] - zd * u[k];
+  double g = 0;
+  double az = fabs(z);
+  if (az > H) g += (az - H) * (z > 0 ? zd : -zd);
+  if (rho > R) g += (rho - R) * v3_dot(rad, rd) / rho;
+  if (Pout) {
+    double zc = z > H ? H : (z < -H ? -H : z);
+    double sc = rho > R ? R / rho : 1.0;
+    for (int k = 0; k < 3; ++k) {
+      Pout[k] = P[k];
+      Qout[k] = c[k] + zc * u[k] + sc * rad[k];
+    }
+  }
+  return g;
+}
+static void add_capsule_cylinder(const mjc_model* m, mjc_data* d, int g1, int g2, double margin) {
+  const double* cm1 = d->geom_xmat[g1];
+  const double* cm2 = d->geom_xmat[g2];
+  double a1[3] = {cm1[2], cm1[5], cm1[8]}, u[3] = {cm2[2], cm2[5], cm2[8]};
+  double hl = m->geom_size[g1][1], rc = m->geom_size[g1][0];
+  double R = m->geom_size[g2][0], H = m->geom_size[g2][1];
+  double p0[3], dp[3];
+  for (int k = 0; k < 3; ++k) {
+    p0[k] = d->geom_xpos[g1][k] - hl * a1[k];
+    dp[k] = 2 * hl * a1[k];
+  }
+  const double eps = 1e-10 * 4 * hl * hl;
+  double lo = 0, hi = 1; /* ta: largest t with g < -eps */
+  if (capcyl_g(p0, dp, 0, d->geom_xpos[g2], u, R, H, NULL, NULL) >= -eps) {
+    hi = 0;
+  } else if (capcyl_g(p0, dp, 1, d->geom_xpos[g2], u, R, H, NULL, NULL) < -eps) {
+    lo = 1;
+  } else {
+    for (int it = 0; it < 48; ++it) {
+      double mid = 0.5 * (lo + hi);
+      if (capcyl_g(p0, dp, mid, d->geom_xpos[g2], u, R, H, NULL, NULL) < -eps) lo = mid; else hi = mid;
+    }
+  }
+  const double ta = lo <= 0 && hi <= 0 ? 0 : (lo >= 1 ? 1 : 0.5 * (lo + hi));
+  lo = 0;
+  hi = 1; /* tb: smallest t with g > +eps */
+  if (capcyl_g(p0, dp, 1, d->geom_xpos[g2], u, R, H, NULL, NULL) <= eps) {
+    lo = 1;
+  } else if (capcyl_g(p0, dp, 0, d->geom_xpos[g2], u, R, H, NULL, NULL) > eps) {
+    hi = 0;
+  } else {
+    for (int it = 0; it < 48; ++it) {
+      double mid = 0.5 * (lo + hi);
+      if (capcyl_g(p0, dp, mid, d->geom_xpos[g2], u, R, H, NULL, NULL) > eps) hi = mid; else lo = mid;
+    }
+  }
+  const double tb = hi <= 0 ? 0 : (lo >= 1 && hi >= 1 ? 1 : 0.5 * (lo + hi));
+  double t = 0.5 * (ta + tb), P[3], Q[3], n[3];
+  capcyl_g(p0, dp, t, d->geom_xpos[g2], u, R, H, P, Q);
+  v3_sub(n, Q, P);
+  double cd = v3_norm(n);
+  if (cd - rc > margin) return;
+  if (d->ncon >= MJC_MAXCON) return;
+  mjc_contact* c = &d->contact[d->ncon++];
+  if (cd < 1e-12) { /* the axis itself is inside the solid: push out radially */
+    double rel[3];
+    v3_sub(rel, P, d->geom_xpos[g2]);
+    double z = v3_dot(rel, u);
+    for (int k = 0; k < 3; ++k) n[k] = -(rel[k] - z * u[k]);
+    if (v3_norm(n) < 1e-12) {
+      n[0] = 1;
+      n[1] = n[2] = 0;
+    }
+    v3_normalize(n);
+    cd = 0;
+  } else {
+    for (int k = 0; k < 3; ++k) n[k] /= cd;
+  }
+  c->dist = cd - rc;
+  for (int k = 0; k < 3; ++k) {
+    c->frame[k] = n[k];
+    c->pos[k] = P[k] + n[k] * (rc + 0.5 * c->dist);
+  }
+  make_frame(c->frame);
+  contact_params(m, c, g1, g2, margin);
+}
+
 static int geoms_can_collide(const mjc_model* m, int g1, int g2) {
   int b1 = m->geom_body[g1], b2 = m->geom_body[g2];
   if (b1 == b2) return 0;
@@ -384,6 +485,9 @@ static void collision(const mjc_model* m, mjc_data* d) {
         v3_addscl(p, axis, -hl);
         add_plane_sphere(m, d, g1, g2, p, m->geom_size[g2][0], margin);
       }
+      /* MJC_GEOM_CYLINDER vs plane (the Pusher's object on the table): the object only slides
+       * in x and y, so every such contact has an identically zero Jacobian (normal = z) and no
+       * effect on qacc; the rows are not generated */
     }
   }
   /* body-body pairs (hopper, humanoid self collisions): sphere / capsule primitives.
@@ -400,6 +504,10 @@ static void collision(const mjc_model* m, mjc_data* d) {
         g2 = ga;
       }
       double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
+      if (m->geom_type[g2] == MJC_GEOM_CYLINDER) { /* Pusher: wrist capsules vs the object */
+        if (m->geom_type[g1] == MJC_GEOM_CAPSULE) add_capsule_cylinder(m, d, g1, g2, margin);
+        continue; /* sphere / cylinder - cylinder: not needed by any model here */
+      }
       if (m->geom_type[g1] == MJC_GEOM_CAPSULE) { /* both capsules */
         add_capsule_capsule(m, d, g1, g2, margin);
       } else if (m->geom_type[g2] == MJC_GEOM_SPHERE) { /* both spheres */

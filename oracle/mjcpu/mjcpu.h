@@ -38,7 +38,7 @@
 #define MJC_MAXEFC 256
 
 enum { MJC_JNT_FREE = 0, MJC_JNT_SLIDE = 2, MJC_JNT_HINGE = 3 };
-enum { MJC_GEOM_PLANE = 0, MJC_GEOM_SPHERE = 2, MJC_GEOM_CAPSULE = 3 };
+enum { MJC_GEOM_PLANE = 0, MJC_GEOM_SPHERE = 2, MJC_GEOM_CAPSULE = 3, MJC_GEOM_CYLINDER = 5 };
 enum { MJC_INT_EULER = 0, MJC_INT_RK4 = 1 };
 enum { MJC_SOL_NEWTON = 0, MJC_SOL_PGS = 1 };
 
@@ -155,6 +155,7 @@ void mjc_build_reacher(mjc_model* m);
 void mjc_build_swimmer(mjc_model* m);
 void mjc_build_hopper(mjc_model* m);
 void mjc_build_humanoid(mjc_model* m, int standup);
+void mjc_build_pusher(mjc_model* m, int v5);
 
 /* engine.c */
 void mjc_reset_data(const mjc_model* m, mjc_data* d);

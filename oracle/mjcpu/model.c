@@ -187,6 +187,11 @@ static void geom_inertia(const mjc_model* m, int g, double* mass,
     inertia[0] += sph + shift;
     inertia[1] += sph + shift;
     inertia[2] += sph;
+  } else if (m->geom_type[g] == MJC_GEOM_CYLINDER) { /* size = radius, half height */
+    double height = 2 * m->geom_size[g][1];
+    *mass = m->geom_density[g] * pi * r * r * height;
+    inertia[0] = inertia[1] = (*mass) * (3 * r * r + height * height) / 12;
+    inertia[2] = (*mass) * r * r / 2;
   }
 }
 

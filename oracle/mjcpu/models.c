@@ -704,3 +704,116 @@ void mjc_build_humanoid(mjc_model* m, int su) {
   }
   mjc_compile(m);
 }
+
+/* ---- Pusher ----------------------------------------------------------------------------
+ * third_party/mujoco_gym_xml_patches/pusher_envpool.xml (v2 / v4) and pusher_v5_envpool.xml
+ * (v5: the object's sphere geom is gone and its cylinder has density 0.01 instead of 1e-5),
+ * line numbers of the former.  <default>: joint armature 0.04 damping 1 limited; geom friction
+ * .8 .1 .1 density 300 margin 0.002 condim 1 contype 0 conaffinity 0 (:22-25).
+ * <option timestep 0.01 gravity 0 iterations 20 integrator Euler> (:20). */
+static int pusher_geom(mjc_model* m, int g, int con) {
+  m->geom_friction[g][0] = 0.8;
+  m->geom_friction[g][1] = 0.1;
+  m->geom_friction[g][2] = 0.1;
+  m->geom_density[g] = 300;
+  m->geom_margin[g] = 0.002;
+  m->geom_condim[g] = 1;
+  m->geom_contype[g] = con;
+  m->geom_conaffinity[g] = con;
+  return g;
+}
+static void pusher_sphere(mjc_model* m, int body, double x, double y, double z, double r) {
+  const double size[3] = {r, 0, 0}, pos[3] = {x, y, z}, quat[4] = {1, 0, 0, 0};
+  pusher_geom(m, mjc_add_geom(m, body, MJC_GEOM_SPHERE, size, pos, quat), 0);
+}
+static int pusher_capsule(mjc_model* m, int body, double x0, double y0, double z0, double x1,
+                          double y1, double z1, double r, int con) {
+  const double from[3] = {x0, y0, z0}, to[3] = {x1, y1, z1};
+  return pusher_geom(m, mjc_add_capsule_fromto(m, body, from, to, r), con);
+}
+void mjc_build_pusher(mjc_model* m, int v5) {
+  const double xaxis[3] = {1, 0, 0}, yaxis[3] = {0, 1, 0}, zaxis[3] = {0, 0, 1};
+  const double quat_id[4] = {1, 0, 0, 0};
+  const double arm = 0.04;
+  mjc_model_init(m);
+  m->timestep = 0.01; /* :20 */
+  m->integrator = MJC_INT_EULER;
+  m->gravity[0] = m->gravity[1] = m->gravity[2] = 0;
+  m->iterations = 20;
+  { /* table :29 */
+    const double size[3] = {1, 1, 0.1}, pos[3] = {0, 0.5, -0.325};
+    pusher_geom(m, mjc_add_geom(m, 0, MJC_GEOM_PLANE, size, pos, quat_id), 1);
+  }
+  const double p_pan[3] = {0, -0.6, 0};
+  int pan = mjc_add_body(m, 0, p_pan); /* r_shoulder_pan_link :31 */
+  pusher_sphere(m, pan, -0.06, 0.05, 0.2, 0.05); /* e1 :32 */
+  pusher_sphere(m, pan, 0.06, 0.05, 0.2, 0.05);  /* e2 */
+  pusher_sphere(m, pan, -0.06, 0.09, 0.2, 0.03); /* e1p */
+  pusher_sphere(m, pan, 0.06, 0.09, 0.2, 0.03);  /* e2p */
+  pusher_capsule(m, pan, 0, 0, -0.4, 0, 0, 0.2, 0.1, 0); /* sp :36 */
+  int j1 = mjc_add_joint(m, pan, MJC_JNT_HINGE, kZero3, zaxis, 1, -2.2854, 1.714602, 0, 1.0, arm); /* :37 */
+  const double p_lift[3] = {0.1, 0, 0};
+  int lift = mjc_add_body(m, pan, p_lift); /* :39 */
+  pusher_capsule(m, lift, 0, -0.1, 0, 0, 0.1, 0, 0.1, 0); /* sl */
+  int j2 = mjc_add_joint(m, lift, MJC_JNT_HINGE, kZero3, yaxis, 1, -0.5236, 1.3963, 0, 1.0, arm);
+  int uroll = mjc_add_body(m, lift, kZero3); /* r_upper_arm_roll_link :43 */
+  pusher_capsule(m, uroll, -0.1, 0, 0, 0.1, 0, 0, 0.02, 0); /* uar */
+  int j3 = mjc_add_joint(m, uroll, MJC_JNT_HINGE, kZero3, xaxis, 1, -1.5, 1.7, 0, 0.1, arm);
+  int ua = mjc_add_body(m, uroll, kZero3); /* r_upper_arm_link :47, no joint */
+  pusher_capsule(m, ua, 0, 0, 0, 0.4, 0, 0, 0.06, 0);
+  const double p_elbow[3] = {0.4, 0, 0};
+  int elbow = mjc_add_body(m, ua, p_elbow); /* :50 */
+  pusher_capsule(m, elbow, 0, -0.02, 0, 0, 0.02, 0, 0.06, 0); /* ef */
+  int j4 = mjc_add_joint(m, elbow, MJC_JNT_HINGE, kZero3, yaxis, 1, -2.3213, 0, 0, 0.1, arm);
+  int froll = mjc_add_body(m, elbow, kZero3); /* r_forearm_roll_link :54 */
+  pusher_capsule(m, froll, -0.1, 0, 0, 0.1, 0, 0, 0.02, 0); /* fr */
+  int j5 = mjc_add_joint(m, froll, MJC_JNT_HINGE, kZero3, xaxis, 1, -1.5, 1.5, 0, 0.1, arm);
+  int fa = mjc_add_body(m, froll, kZero3); /* r_forearm_link :58, no joint */
+  pusher_capsule(m, fa, 0, 0, 0, 0.291, 0, 0, 0.05, 0);
+  const double p_wrist[3] = {0.321, 0, 0};
+  int wflex = mjc_add_body(m, fa, p_wrist); /* :61 */
+  pusher_capsule(m, wflex, 0, -0.02, 0, 0, 0.02, 0, 0.01, 0); /* wf */
+  int j6 = mjc_add_joint(m, wflex, MJC_JNT_HINGE, kZero3, yaxis, 1, -1.094, 0, 0, 0.1, arm);
+  int wroll = mjc_add_body(m, wflex, kZero3); /* r_wrist_roll_link :65 */
+  int j7 = mjc_add_joint(m, wroll, MJC_JNT_HINGE, kZero3, xaxis, 1, -1.5, 1.5, 0, 0.1, arm);
+  /* geoms are numbered body by body: the three colliding capsules of the wrist (:71-73) come
+   * before the spheres of its child tips_arm (:67-70) */
+  pusher_capsule(m, wroll, 0, -0.1, 0, 0, 0.1, 0, 0.02, 1);
+  pusher_capsule(m, wroll, 0, -0.1, 0, 0.1, -0.1, 0, 0.02, 1);
+  pusher_capsule(m, wroll, 0, 0.1, 0, 0.1, 0.1, 0, 0.02, 1);
+  int tips = mjc_add_body(m, wroll, kZero3); /* tips_arm :67, no joint */
+  pusher_sphere(m, tips, 0.1, -0.1, 0, 0.01);
+  pusher_sphere(m, tips, 0.1, 0.1, 0, 0.01);
+  const double p_obj[3] = {0.45, -0.05, -0.275};
+  int obj = mjc_add_body(m, 0, p_obj); /* object :85 */
+  if (!v5) { /* :86 sphere, density 1e-5, conaffinity 0 (contype default 0) */
+    const double size[3] = {0.05, 0, 0};
+    int g = pusher_geom(m, mjc_add_geom(m, obj, MJC_GEOM_SPHERE, size, kZero3, quat_id), 0);
+    m->geom_density[g] = 0.00001;
+  }
+  { /* :87 cylinder size 0.05 0.05, contype 1 conaffinity 0 */
+    const double size[3] = {0.05, 0.05, 0};
+    int g = pusher_geom(m, mjc_add_geom(m, obj, MJC_GEOM_CYLINDER, size, kZero3, quat_id), 0);
+    m->geom_density[g] = v5 ? 0.01 : 0.00001;
+    m->geom_contype[g] = 1;
+    m->geom_conaffinity[g] = 0;
+  }
+  mjc_add_joint(m, obj, MJC_JNT_SLIDE, kZero3, yaxis, 1, -10.3213, 10.3, 0, 0.5, arm); /* obj_slidey :88 */
+  mjc_add_joint(m, obj, MJC_JNT_SLIDE, kZero3, xaxis, 1, -10.3213, 10.3, 0, 0.5, arm); /* obj_slidex :89 */
+  const double p_goal[3] = {0.45, -0.05, -0.3230};
+  int goal = mjc_add_body(m, 0, p_goal); /* :92 */
+  {
+    const double size[3] = {0.08, 0.001, 0};
+    int g = pusher_geom(m, mjc_add_geom(m, goal, MJC_GEOM_CYLINDER, size, kZero3, quat_id), 0);
+    m->geom_density[g] = 0.00001;
+  }
+  mjc_add_joint(m, goal, MJC_JNT_SLIDE, kZero3, yaxis, 1, -10.3213, 10.3, 0, 0.5, arm); /* :94 */
+  mjc_add_joint(m, goal, MJC_JNT_SLIDE, kZero3, xaxis, 1, -10.3213, 10.3, 0, 0.5, arm); /* :95 */
+  const int jj[7] = {j1, j2, j3, j4, j5, j6, j7}; /* motors :99-107: gear 1, ctrlrange -2 2 */
+  for (int i = 0; i < 7; ++i) {
+    int u = mjc_add_motor(m, jj[i], 1.0);
+    m->act_ctrlrange[u][0] = -2;
+    m->act_ctrlrange[u][1] = 2;
+  }
+  mjc_compile(m);
+}

@@ -32,9 +32,10 @@ typedef struct {
   int current_step, done, elapsed_step;
   int lag_set;       /* set_state gave the lagged mass centre (humanoid tasks) */
   double lag_mc[2];
+  double lag_push[5]; /* Pusher: set_state gave xpos of tips_arm (3) and object (x, y) */
 } mj_env;
 
-enum { TASK_CHEETAH = 0, TASK_ANT = 1, TASK_WALKER = 2, TASK_IPEND = 3, TASK_IDPEND = 4, TASK_REACHER = 5, TASK_SWIMMER = 6, TASK_HOPPER = 7, TASK_HUMANOID = 8, TASK_STANDUP = 9 };
+enum { TASK_CHEETAH = 0, TASK_ANT = 1, TASK_WALKER = 2, TASK_IPEND = 3, TASK_IDPEND = 4, TASK_REACHER = 5, TASK_SWIMMER = 6, TASK_HOPPER = 7, TASK_HUMANOID = 8, TASK_STANDUP = 9, TASK_PUSHER = 10 };
 
 typedef struct {
   int is_ant;
@@ -56,6 +57,9 @@ typedef struct {
   double contact_cost_weight, contact_force_min, contact_force_max;
   double observation_min, observation_max;
   int torso;
+  /* Pusher (pusher.h:33-46): bodies and the cylinder placement of MujocoResetModel */
+  int tips, object, goal, weighted_reward_info;
+  double near_cost_weight, cyl_x_min, cyl_x_max, cyl_y_min, cyl_y_max, cyl_dist_min;
   mj_env* envs;
   int nkeys;
   const char* key_names[24];
@@ -98,6 +102,8 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
     kind = TASK_HUMANOID;
   } else if (strcmp(task, "HumanoidStandup") == 0) {
     kind = TASK_STANDUP;
+  } else if (strcmp(task, "Pusher") == 0 || strcmp(task, "PusherV5") == 0) {
+    kind = TASK_PUSHER;
   } else {
     return NULL;
   }
@@ -122,6 +128,8 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
     mjc_build_hopper(&p->m);
   } else if (kind == TASK_HUMANOID || kind == TASK_STANDUP) {
     mjc_build_humanoid(&p->m, kind == TASK_STANDUP);
+  } else if (kind == TASK_PUSHER) {
+    mjc_build_pusher(&p->m, strcmp(task, "PusherV5") == 0);
   } else {
     mjc_build_half_cheetah(&p->m);
   }
@@ -188,6 +196,22 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
     p->torso = 3;
     p->target = 4;
   }
+  const int pusher = kind == TASK_PUSHER;
+  if (pusher) { /* pusher.h:33-46; extra: 0 frame_skip 1 ctrl_cost_weight 16 reward_after_step
+                 * 20 dist_cost_weight 21 near_cost_weight 22 weighted_reward_info */
+    p->dist_cost_weight = extra_or(extra, n_extra, 20, 1.0);
+    p->near_cost_weight = extra_or(extra, n_extra, 21, 0.5);
+    p->weighted_reward_info = extra_or(extra, n_extra, 22, 0) != 0;
+    p->cyl_x_min = -0.3;
+    p->cyl_x_max = 0.0;
+    p->cyl_y_min = -0.2;
+    p->cyl_y_max = 0.2;
+    p->cyl_dist_min = 0.17;
+    p->tips = 10;   /* mj_name2id(model, mjOBJ_XBODY, "tips_arm") */
+    p->object = 11;
+    p->goal = 12;
+    p->torso = p->tips;
+  }
   for (int i = 0; i < 8; ++i) {
     p->key_names[i] = kCommonNames[i];
     p->key_dtype[i] = kCommonDtype[i];
@@ -202,6 +226,7 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
                       : kind == TASK_IPEND ? 4
                       : kind == TASK_IDPEND ? 8 + p->constraint_obs_dim
                       : reacher ? (p->obs_include_z ? 11 : 10)
+                      : pusher ? 23
                       : swimmer ? 8
                       : hopper ? 11
                       : humanoid ? 376 - (p->exclude_worldbody ? 22 : 0) -
@@ -226,14 +251,17 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
       "info:distance_from_origin", "info:x_velocity", "info:y_velocity"};
   static const char* standup_info[4] = {"info:reward_linup", "info:reward_quadctrl",
                                         "info:reward_alive", "info:reward_impact"};
+  static const char* pusher_info[3] = {"info:reward_dist", "info:reward_ctrl", "info:reward_near"};
   int ninfo = is_ant ? 9 : (swimmer ? 7 : (walker || reacher || hopper ? 2 : (pend ? 0 : 4)));
   if (humanoid) ninfo = kind == TASK_HUMANOID ? 9 : 4;
+  if (pusher) ninfo = 3;
   for (int i = 0; i < ninfo; ++i) {
     p->key_names[k] = kind == TASK_HUMANOID ? humanoid_info[i]
                       : kind == TASK_STANDUP ? standup_info[i]
                       : is_ant ? ant_info[i]
                       : swimmer ? swimmer_info[i]
                       : reacher ? reacher_info[i]
+                      : pusher ? pusher_info[i]
                                 : cheetah_info[((walker || hopper) ? 2 : 0) + i];
     p->key_dtype[k] = DT_F64;
     p->key_elems[k++] = 1;
@@ -307,7 +335,23 @@ static void reacher_dist(const mj_pool* p, const mj_env* e, double* dist) {
   for (int k = 0; k < 3; ++k) dist[k] = e->d.xpos[p->torso][k] - e->d.xpos[p->target][k];
 }
 
+static double body_dist(const mj_env* e, int b0, int b1) { /* PusherEnvBase::GetDist, pusher.h:190-195 */
+  double x = e->d.xpos[b0][0] - e->d.xpos[b1][0];
+  double y = e->d.xpos[b0][1] - e->d.xpos[b1][1];
+  double z = e->d.xpos[b0][2] - e->d.xpos[b1][2];
+  return sqrt(x * x + y * y + z * z);
+}
+
 static void write_obs(mj_pool* p, mj_env* e, void** out, int row) {
+  if (p->task == TASK_PUSHER) { /* pusher.h:207-224: xpos of the LAST forward evaluation */
+    double* obs = (double*)out[8] + (size_t)row * 23;
+    for (int i = 0; i < 7; ++i) *(obs++) = e->d.qpos[i];
+    for (int i = 0; i < 7; ++i) *(obs++) = e->d.qvel[i];
+    for (int i = 0; i < 3; ++i) *(obs++) = e->d.xpos[p->tips][i];
+    for (int i = 0; i < 3; ++i) *(obs++) = e->d.xpos[p->object][i];
+    for (int i = 0; i < 3; ++i) *(obs++) = e->d.xpos[p->goal][i];
+    return;
+  }
   if (p->task == TASK_REACHER) { /* reacher.h:196-216 */
     int n = p->obs_include_z ? 11 : 10;
     double* obs = (double*)out[8] + (size_t)row * n, dist[3];
@@ -385,6 +429,28 @@ static void mujoco_reset(mj_pool* p, mj_env* e) {
   double warm[MJC_MAXV];
   (void)warm;
   mjc_reset_data(&p->m, &e->d); /* mj_resetData */
+  if (p->task == TASK_PUSHER) { /* pusher.h:115-136 */
+    int nq = p->m.nq, nv = p->m.nv;
+    for (int i = 0; i < nq - 4; ++i) e->d.qpos[i] = p->m.qpos0[i];
+    for (;;) {
+      double x = orc_uniform_real(&e->gen, p->cyl_x_min, p->cyl_x_max);
+      double y = orc_uniform_real(&e->gen, p->cyl_y_min, p->cyl_y_max);
+      if (sqrt(x * x + y * y) > p->cyl_dist_min) {
+        e->d.qpos[nq - 4] = x;
+        e->d.qpos[nq - 3] = y;
+        e->d.qpos[nq - 2] = 0.0;
+        e->d.qpos[nq - 1] = 0.0;
+        break;
+      }
+    }
+    for (int i = 0; i < nv; ++i) {
+      e->d.qvel[i] = i < nv - 4 ? 0.0 + orc_uniform_real(&e->gen, -p->reset_qvel_scale,
+                                                         p->reset_qvel_scale)
+                                : 0.0;
+    }
+    mjc_forward(&p->m, &e->d);
+    return;
+  }
   if (p->task == TASK_REACHER) { /* reacher.h:112-132 */
     int nq = p->m.nq, nv = p->m.nv;
     for (int i = 0; i < nq - 2; ++i) {
@@ -459,6 +525,7 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
   int ninfo = (p->is_ant || p->task == TASK_HUMANOID) ? 9
               : p->task == TASK_STANDUP ? 4
               : p->task == TASK_SWIMMER ? 7
+              : p->task == TASK_PUSHER ? 3
               : (p->task == TASK_WALKER || p->task == TASK_REACHER || p->task == TASK_HOPPER) ? 2
               : (p->task >= TASK_IPEND ? 0 : 4);
   double info[9] = {0};
@@ -578,6 +645,26 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
       e->done = (++e->elapsed_step >= p->max_episode_steps);
       info[0] = -dist_cost;
       info[1] = -ctrl_cost;
+    } else if (p->task == TASK_PUSHER) { /* pusher.h:156-186 */
+      double near_cost = 0, dist_cost = 0;
+      if (!p->reward_after_step) {
+        near_cost = body_dist(e, p->object, p->tips);
+        dist_cost = body_dist(e, p->object, p->goal);
+      }
+      for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
+      for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
+      if (p->reward_after_step) {
+        near_cost = body_dist(e, p->object, p->tips);
+        dist_cost = body_dist(e, p->object, p->goal);
+      }
+      double cc = 0;
+      for (int i = 0; i < p->m.nu; ++i) cc += act[i] * act[i];
+      reward = (float)(-cc * p->ctrl_cost_weight - dist_cost * p->dist_cost_weight -
+                       near_cost * p->near_cost_weight);
+      e->done = (++e->elapsed_step >= p->max_episode_steps);
+      info[0] = -dist_cost * (p->weighted_reward_info ? p->dist_cost_weight : 1.0);
+      info[1] = -cc * (p->weighted_reward_info ? p->ctrl_cost_weight : 1.0);
+      info[2] = -near_cost * p->near_cost_weight;
     } else if (p->task == TASK_IPEND) { /* inverted_pendulum.h:137-148 */
       for (int i = 0; i < p->m.nu; ++i) e->d.ctrl[i] = act[i];
       for (int i = 0; i < p->frame_skip; ++i) mjc_step(&p->m, &e->d);
@@ -709,7 +796,8 @@ void mjcpu_destroy(void* h) {
  * cur_step normal_saved normal_avail */
 int mjcpu_state_dim(void* h) {
   mj_pool* p = (mj_pool*)h;
-  return p->m.nq + 2 * p->m.nv + 7;
+  /* Pusher: + xpos of tips_arm (3) and of the object (x, y) of the last forward evaluation */
+  return p->m.nq + 2 * p->m.nv + 7 + (p->task == TASK_PUSHER ? 5 : 0);
 }
 void mjcpu_get_state(void* h, const int* ids, int k, double* out) {
   mj_pool* p = (mj_pool*)h;
@@ -729,6 +817,11 @@ void mjcpu_get_state(void* h, const int* ids, int k, double* out) {
     t[4] = e->current_step;
     t[5] = e->nstate.saved;
     t[6] = e->nstate.saved_available;
+    if (p->task == TASK_PUSHER) {
+      for (int c = 0; c < 3; ++c) t[7 + c] = e->d.xpos[p->tips][c];
+      t[10] = e->d.xpos[p->object][0];
+      t[11] = e->d.xpos[p->object][1];
+    }
   }
 }
 void mjcpu_set_state(void* h, const int* ids, int k, const double* in) {
@@ -752,6 +845,17 @@ void mjcpu_set_state(void* h, const int* ids, int k, const double* in) {
     e->elapsed_step = e->current_step;
     e->nstate.saved = t[5];
     e->nstate.saved_available = t[6] != 0;
+    if (p->task == TASK_PUSHER) { /* the lagged positions the next step's costs / obs read */
+      for (int c = 0; c < 3; ++c) e->d.xpos[p->tips][c] = t[7 + c];
+      e->d.xpos[p->object][0] = t[10];
+      e->d.xpos[p->object][1] = t[11];
+      e->d.xpos[p->object][2] = p->m.body_pos[p->object][2];
+      for (int c = 0; c < 3; ++c) {
+        e->d.xpos[p->goal][c] = p->m.body_pos[p->goal][c];
+      }
+      e->d.xpos[p->goal][1] += e->d.qpos[p->m.nq - 2]; /* goal_slidey, goal_slidex */
+      e->d.xpos[p->goal][0] += e->d.qpos[p->m.nq - 1];
+    }
   }
 }
 

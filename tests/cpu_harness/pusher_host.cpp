@@ -1,0 +1,50 @@
+// TEST HARNESS (not product): host instantiation of mj_pusher.hip.h for diffing against
+// oracle/mjcpu on a CPU box.  Not linked by envpool_amd/.
+// g_busy emulates the device situation "another lane of my wave still iterates / has a contact":
+// every WaveAny() is true, so this env runs all solver iterations with frozen iterates and takes
+// the contact-row code with all-inactive rows -- results must not change.
+static bool g_busy = false;
+#define EPA_HOST_WAVE_ANY(x) ((x) || g_busy)
+#include "../../envpool_amd/csrc/mj_pusher_model.h"
+
+using epa::mj::SolverCfg;
+using namespace epa::mj::pusher;
+
+extern "C" {
+void pusher_host_set_busy(int on) { g_busy = on != 0; }
+// q, v, warm: 9 (arm 7, obj_slidey, obj_slidex); ctrl 7; lag out: tips xyz, object xy
+void pusher_host_step(const double* q, const double* v, const double* warm, const double* ctrl,
+                      int nsub, int v5, double* qo, double* vo, double* wo, double* lag,
+                      int* iters) {
+  const PusherModel<double> m = BuildPusherModel(v5 != 0);
+  SolverCfg<double> cfg{50, 1e-13};
+  double tq[kNV], tv[kNV], tw[kNV];
+  for (int i = 0; i < kNV; ++i) {
+    tq[i] = q[i];
+    tv[i] = v[i];
+    tw[i] = warm[i];
+  }
+  PusherLag<double> lg{};
+  int it = 0;
+  for (int s = 0; s < nsub; ++s) it += PusherStep(m, cfg, tq, tv, tw, ctrl, &lg);
+  for (int i = 0; i < kNV; ++i) {
+    qo[i] = tq[i];
+    vo[i] = tv[i];
+    wo[i] = tw[i];
+  }
+  for (int k = 0; k < 3; ++k) lag[k] = lg.tips[k];
+  lag[3] = lg.obj[0];
+  lag[4] = lg.obj[1];
+  *iters = it;
+}
+// [mass(7) dof_invw(7) wrist_invw obj_invw obj_mass]
+void pusher_host_model(int v5, double* out) {
+  const PusherModel<double> m = BuildPusherModel(v5 != 0);
+  int k = 0;
+  for (int l = 0; l < kNL; ++l) out[k++] = m.mass[l];
+  for (int l = 0; l < kNL; ++l) out[k++] = m.dof_invw[l];
+  out[k++] = m.wrist_invw;
+  out[k++] = m.obj_invw;
+  out[k++] = m.obj_mass;
+}
+}

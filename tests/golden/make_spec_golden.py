@@ -31,6 +31,7 @@ FAMILIES = {
     "mujoco/gym/hopper.h": {"HopperEnvFns": "GymHopper"},
     "mujoco/gym/swimmer.h": {"SwimmerEnvFns": "GymSwimmer"},
     "mujoco/gym/reacher.h": {"ReacherEnvFns": "GymReacher"},
+    "mujoco/gym/pusher.h": {"PusherEnvFns": "GymPusher"},
     "mujoco/gym/inverted_pendulum.h": {"InvertedPendulumEnvFns": "GymInvertedPendulum"},
     "mujoco/gym/inverted_double_pendulum.h": {"InvertedDoublePendulumEnvFns": "GymInvertedDoublePendulum"},
     "mujoco/gym/humanoid.h": {"HumanoidEnvFns": "GymHumanoid"},

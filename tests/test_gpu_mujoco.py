@@ -419,6 +419,92 @@ def test_reacher_matches_oracle(name, params, extra, nobs):
     print(f"{name}: worst free-running |d obs| over 130 steps = {worst:.3e}")
 
 
+# ---- Pusher (7-dof arm + sliding cylinder; capsule/sphere-cylinder and table contacts) ----
+_PUSHER_LO = np.array([-2.2854, -0.5236, -1.5, -2.3213, -1.5, -1.094, -1.5])
+_PUSHER_HI = np.array([1.714602, 1.3963, 1.7, 0.0, 1.5, 0.0, 1.5])
+
+
+@pytest.mark.parametrize("name,task,params,extra", [
+    ("Pusher-v4", "Pusher", {}, ()),
+    ("Pusher-v5", "PusherV5", {"xml_v5": 1, "reward_after_step": 1, "weighted_reward_info": 1},
+     (5, 0.1, 0, 0, 0, 0, 0, 0, -1, 0, 0, 3, 0, 0, 0, -1, 1, 0, 0, 0, 1.0, 0.5, 1)),
+])
+def test_pusher_matches_oracle(name, task, params, extra):
+    n, nq, nv = 512, 11, 11
+    pool = DevicePool("Pusher", n, seed=4, max_episode_steps=100, params=params)
+    orc = Oracle(task, n, seed=4, max_episode_steps=100, extra=extra)
+    a, b = hip_reset(pool), orc.reset()
+    assert list(a.keys()) == list(b.keys()) and a["obs"].shape == (n, 23)
+    # reset: uniform draws only (cylinder rejection loop, qvel noise) => exact
+    np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-14, atol=1e-16)
+    rng = np.random.default_rng(8)
+    worst = pushed = 0
+
+    def compare(act, tag):
+        nonlocal worst
+        a, b = hip_step(pool, act), orc.step(act)
+        np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-9, atol=1e-10, err_msg=tag)
+        np.testing.assert_allclose(a["reward"].ravel(), b["reward"].ravel(), rtol=1e-6, atol=1e-6)
+        for k in ("info:reward_dist", "info:reward_ctrl", "info:reward_near"):
+            np.testing.assert_allclose(a[k].ravel(), b[k].ravel(), rtol=1e-9, atol=1e-10,
+                                       err_msg=f"{k} {tag}")
+        for k in ("done", "trunc", "elapsed_step", "step_type", "discount"):
+            np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k} {tag}")
+        worst = max(worst, float(np.abs(a["obs"] - b["obs"]).max()))
+        return b
+
+    for t in range(45):
+        # (1) teacher-forced arm pose low over the table (the wrist / forearm capsules reach
+        #     the table plane and the cylinder's height), some joints beyond their limits
+        st = orc.get_state()
+        q = rng.uniform(_PUSHER_LO * 0.6, _PUSHER_HI * 0.6, (n, 7))
+        q[:, 1] = rng.uniform(0.25, 0.75, n)
+        q[:, 3] = rng.uniform(-0.8, 0.0, n)
+        over = rng.random(n) < 0.15
+        q[over, 5] = rng.choice([-1.094 - 0.02, 0.02], int(over.sum()))
+        st[:, :7] = q
+        st[:, nq:nq + 7] = rng.normal(0, 0.5, (n, 7))
+        st[:, nq + 7:nq + 9] = 0
+        st[:, nq + nv:nq + 2 * nv] = 0
+        orc.set_state(st)
+        pool.set_state(st)
+        b = compare(rng.uniform(-2, 2, (n, 7)), f"pose step {t}")
+        # (2) put the cylinder within reach of where the fingertips now are, give it a small
+        #     velocity, and step: the arm pushes the cylinder / the cylinder slides on the table
+        st = orc.get_state()
+        live = b["elapsed_step"].ravel() > 0
+        ang, dist = rng.uniform(0, 2 * np.pi, n), rng.uniform(0.0, 0.2, n)
+        ox, oy = st[:, -5] + dist * np.cos(ang), st[:, -4] + dist * np.sin(ang)
+        st[:, 7], st[:, 8] = oy + 0.05, ox - 0.45    # obj_slidey, obj_slidex (body at 0.45 -0.05)
+        st[:, nq + 7:nq + 9] = rng.normal(0, 0.05, (n, 2))
+        st[:, -2], st[:, -1] = ox, oy
+        orc.set_state(st)
+        pool.set_state(st)
+        v0 = st[:, nq + 7:nq + 9].copy()
+        compare(rng.uniform(-2, 2, (n, 7)), f"push step {t}")
+        dv = np.abs(orc.get_state()[:, nq + 7:nq + 9] - v0).max(axis=1)
+        pushed += int((dv[live] > 1e-2).sum())
+    assert pushed > 200, pushed    # the contact-rich branch really ran
+    print(f"{name}: worst teacher-forced |d obs| = {worst:.3e}; steps where the cylinder was "
+          f"pushed: {pushed}")
+
+
+def test_pusher_free_running_episodes():
+    """Free-running v4 episodes across auto-resets (100-step truncation); fp64 is the only
+    Pusher build."""
+    n = 256
+    pool = DevicePool("Pusher", n, seed=11, max_episode_steps=100)
+    orc = Oracle("Pusher", n, seed=11, max_episode_steps=100)
+    hip_reset(pool), orc.reset()
+    rng = np.random.default_rng(2)
+    for t in range(230):
+        act = rng.uniform(-2, 2, (n, 7))
+        a, b = hip_step(pool, act), orc.step(act)
+        np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-7, atol=1e-8, err_msg=f"step {t}")
+        for k in ("done", "trunc", "elapsed_step"):
+            np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k}@{t}")
+
+
 # ---- Swimmer (planar floating chain + inertia-box fluid forces) ----
 def test_swimmer_matches_oracle():
     n = 512

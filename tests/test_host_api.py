@@ -25,7 +25,8 @@ def test_list_all_envs_and_registry():
               "Blackjack-v1", "HalfCheetah-v3", "HalfCheetah-v4", "HalfCheetah-v5",
               "Ant-v3", "Ant-v4", "Ant-v5", "Walker2d-v3", "Walker2d-v4", "Walker2d-v5",
               "Hopper-v3", "Hopper-v4", "Hopper-v5", "Swimmer-v3", "Swimmer-v4", "Swimmer-v5",
-              "Reacher-v2", "Reacher-v4", "Reacher-v5", "InvertedPendulum-v2",
+              "Reacher-v2", "Reacher-v4", "Reacher-v5", "Pusher-v2", "Pusher-v4", "Pusher-v5",
+              "InvertedPendulum-v2",
               "InvertedPendulum-v4", "InvertedPendulum-v5", "InvertedDoublePendulum-v2",
               "InvertedDoublePendulum-v4", "InvertedDoublePendulum-v5",
               "Humanoid-v3", "Humanoid-v4", "Humanoid-v5", "HumanoidStandup-v2",
@@ -72,6 +73,11 @@ def test_spec_config_defaults_and_key_order():
     r5 = envpool.make_spec("Reacher-v5")
     assert r5.config.reward_after_step is True and r5.observation_space.shape == (10,)
     assert envpool.make_spec("Reacher-v4").config.max_episode_steps == 50
+    p5 = envpool.make_spec("Pusher-v5")
+    assert (p5.config.xml_file, p5.config.reward_after_step, p5.config.weighted_reward_info,
+            p5.config.max_episode_steps) == ("pusher_v5.xml", True, True, 100)
+    assert p5.observation_space.shape == (23,) and p5.action_space.shape == (7,)
+    assert envpool.make_spec("Pusher-v4").config.xml_file == "pusher.xml"
     d5 = envpool.make_spec("InvertedDoublePendulum-v5")
     assert d5.config.constraint_obs_dim == 1 and d5.observation_space.shape == (9,)
     assert envpool.make_spec("InvertedPendulum-v5").config.reward_if_not_terminated is True
@@ -158,6 +164,7 @@ FAMILY_PARAMS = {
     "Ant-v5": {"use_contact_force": 1, "exclude_worldbody_contact_forces": 1, "post_constraint": 1},
     "Walker2d-v4": {}, "Walker2d-v5": {"xml_v5": 1}, "Hopper-v4": {}, "Swimmer-v4": {},
     "Reacher-v4": {}, "Reacher-v5": {"obs_include_z_distance": 0},
+    "Pusher-v4": {}, "Pusher-v5": {"xml_v5": 1, "reward_after_step": 1, "weighted_reward_info": 1},
     "InvertedPendulum-v4": {}, "InvertedDoublePendulum-v4": {},
     "InvertedDoublePendulum-v5": {"constraint_obs_dim": 1},
     "Humanoid-v4": {}, "HumanoidStandup-v4": {},
@@ -170,7 +177,8 @@ NATIVE = {"CartPole-v1": "CartPole", "Pendulum-v1": "Pendulum", "MountainCar-v0"
           "Blackjack-v1": "Blackjack", "HalfCheetah-v4": "HalfCheetah", "Ant-v4": "Ant",
           "Ant-v3": "Ant", "Ant-v5": "Ant", "Walker2d-v4": "Walker2d", "Walker2d-v5": "Walker2d",
           "Hopper-v4": "Hopper", "Swimmer-v4": "Swimmer", "Reacher-v4": "Reacher",
-          "Reacher-v5": "Reacher", "InvertedPendulum-v4": "InvertedPendulum",
+          "Reacher-v5": "Reacher", "Pusher-v4": "Pusher", "Pusher-v5": "Pusher",
+          "InvertedPendulum-v4": "InvertedPendulum",
           "InvertedDoublePendulum-v4": "InvertedDoublePendulum",
           "InvertedDoublePendulum-v5": "InvertedDoublePendulum",
           "Humanoid-v4": "Humanoid", "Humanoid-v5": "Humanoid",
@@ -330,7 +338,7 @@ def test_registry_matches_reference_registration_modules():
     """tests/golden/registry.json records what the reference's own registration modules
     pass to `register` (tests/golden/make_registry_golden.py).  Every id this engine
     registers must carry the same class names and keyword arguments (aliases included);
-    the reference ids it does not register are the families without a kernel."""
+    and every reference id must be registered."""
     import json
     import os
 
@@ -339,7 +347,7 @@ def test_registry_matches_reference_registration_modules():
     envpool.list_all_envs()  # imports every registration module
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "registry.json")))
     missing = sorted(set(gold) - set(registry.specs))
-    assert all(m.split("-")[0] == "Pusher" for m in missing), missing
+    assert missing == [], missing
     checked = 0
     for task_id, g in gold.items():
         if task_id not in registry.specs:

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from mj_util import RawMj
+from mj_util import _H, RawMj
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ANT_Q0 = np.array([0, 0, 0.75, 1, 0, 0, 0, 0, 0.9, 0, -0.9, 0, -0.9, 0, 0.9], float)
@@ -439,3 +439,89 @@ def test_product_tree_code_matches_oracle_on_cpu():
         print(f"{task}: worst teacher-forced rel |d obs| = {worst:.2e}; max active groups {most}")
         assert worst < 1e-8, (task, worst)
         assert most >= (10 if su else 3)
+
+
+def test_product_pusher_code_matches_oracle_on_cpu():
+    """Host instantiation of mj_pusher.hip.h (the Pusher kernel source: 7-dof arm with the
+    fixed bodies merged into their parents, sliding cylinder, capsule/sphere-vs-cylinder and
+    table-plane contacts) vs the oracle's generic engine on the full 13-body model: compiled
+    model constants, then teacher-forced env-steps (5 mj_steps) from states that put the
+    cylinder within reach of the fingertips so the contact branches run."""
+    from oracle.orc import Oracle
+
+    csrc = os.path.join(ROOT, "envpool_amd", "csrc")
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    so, src = os.path.join(h, "libpusher_host.so"), os.path.join(h, "pusher_host.cpp")
+    deps = [src, os.path.join(csrc, "mj_pusher.hip.h"), os.path.join(csrc, "mj_pusher_model.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(so)
+    vp = ctypes.c_void_p
+
+    def host(q, v, w, a, nsub, v5):
+        qo, vo, wo, lag = np.zeros(9), np.zeros(9), np.zeros(9), np.zeros(5)
+        it = ctypes.c_int(0)
+        L.pusher_host_step(*[vp(x.ctypes.data) for x in (q, v, w, a)], nsub, v5,
+                           *[vp(x.ctypes.data) for x in (qo, vo, wo, lag)], ctypes.byref(it))
+        return qo, vo, wo, lag
+
+    lo = np.array([-2.2854, -0.5236, -1.5, -2.3213, -1.5, -1.094, -1.5])
+    hi = np.array([1.714602, 1.3963, 1.7, 0.0, 1.5, 0.0, 1.5])
+    n, nq, nv = 16, 11, 11
+    for task, v5 in (("Pusher", 0), ("PusherV5", 1)):
+        r = RawMj(task)
+        mo = np.zeros(32)
+        L.pusher_host_model(v5, vp(mo.ctypes.data))
+        bm = r.body_mass
+        # fixed bodies merge into their parents: links = bodies [1, 2, 3+4, 5, 6+7, 8, 9+10]
+        want = [bm[1], bm[2], bm[3] + bm[4], bm[5], bm[6] + bm[7], bm[8], bm[9] + bm[10]]
+        np.testing.assert_allclose(mo[:7], want, rtol=1e-13)
+        np.testing.assert_allclose(mo[7:14], r.dof_invweight0[:7], rtol=1e-11)
+        np.testing.assert_allclose(mo[14:17], [r.body_invweight0[9, 0], r.body_invweight0[11, 0], bm[11]],
+                                   rtol=1e-11)
+        orc = Oracle(task, n, seed=9, max_episode_steps=1000)
+        orc.reset()
+        rng = np.random.default_rng(5)
+        worst = 0.0
+        ncyl = nplane = 0
+        buf = np.zeros(640)
+        orc.lib.mjcpu_raw_contacts.restype = ctypes.c_int
+        orc.lib.mjcpu_raw_contacts.argtypes = [vp, ctypes.c_int, vp]
+        inner = ctypes.cast(orc.h, ctypes.POINTER(_H)).contents.h
+        for t in range(12):
+            orc.step(rng.uniform(-2, 2, (n, 7)))
+            st = orc.get_state()
+            for e in range(n):
+                q = rng.uniform(lo * 0.6, hi * 0.6)
+                q[1], q[3] = rng.uniform(0.25, 0.75), rng.uniform(-0.8, 0.0)
+                v = rng.normal(0, 0.5, 7)
+                z2 = np.zeros(2)
+                lag = host(np.concatenate([q, z2]), np.concatenate([v, z2]), np.zeros(9),
+                           np.zeros(7), 1, v5)[3]    # fingertip position at ~q
+                ang, dist = rng.uniform(0, 2 * np.pi), rng.uniform(0.0, 0.2)
+                ox, oy = lag[0] + dist * np.cos(ang), lag[1] + dist * np.sin(ang)
+                st[e, :7], st[e, 7], st[e, 8] = q, oy + 0.05, ox - 0.45
+                st[e, nq:nq + 7], st[e, nq + 7:nq + 9] = v, rng.normal(0, 0.05, 2)
+                st[e, nq + nv:nq + 2 * nv] = 0
+                st[e, -5:-2], st[e, -2], st[e, -1] = lag[:3], ox, oy
+            orc.set_state(st)
+            act = rng.uniform(-2, 2, (n, 7))
+            b = orc.step(act)
+            st2 = orc.get_state()
+            for e in range(n):
+                if b["elapsed_step"][e, 0] == 0:
+                    continue
+                qo, vo, wo, lag = host(st[e, :9].copy(), st[e, nq:nq + 9].copy(),
+                                       st[e, nq + nv:nq + nv + 9].copy(),
+                                       np.ascontiguousarray(act[e]), 5, v5)
+                ob = np.concatenate([qo[:7], vo[:7], lag])
+                worst = max(worst, np.abs(ob - b["obs"][e, :19]).max(),
+                            np.abs(qo[7:9] - st2[e, 7:9]).max(),
+                            np.abs(vo[7:9] - st2[e, nq + 7:nq + 9]).max())
+                nc = orc.lib.mjcpu_raw_contacts(inner, e, vp(buf.ctypes.data))
+                for c in range(nc):
+                    if buf[10 * c + 9] >= 0:    # active row
+                        ncyl += int(buf[10 * c] != 0)
+                        nplane += int(buf[10 * c] == 0)
+        assert worst < 1e-9, (task, worst)
+        assert ncyl > 20 and nplane > 20, (task, ncyl, nplane)
