@@ -34,6 +34,30 @@ namespace envpool_amd_binding {
 
 using Params = std::vector<std::pair<std::string, double>>;
 
+// Every arithmetic entry of the reference Spec's config (bool / int / float / double), under
+// the reference's own key name: libenvpool_amd's kernels read their parameters under exactly
+// those names and ignore the keys they do not know (num_threads, reward_threshold, ...).
+// String / vector entries (base_path, xml_file, env_seed) are skipped; an adapter adds what it
+// derives from them (e.g. xml_v5 from xml_file).
+template <typename Config>
+Params NumericParams(const Config& config, Params extra = {}) {
+  Params out;
+  const std::vector<std::string> keys = Config::AllKeys();
+  std::size_t i = 0;
+  std::apply(
+      [&](const auto&... value) {
+        auto one = [&](const auto& v) {
+          using V = std::decay_t<decltype(v)>;
+          if constexpr (std::is_arithmetic_v<V>) out.emplace_back(keys[i], static_cast<double>(v));
+          ++i;
+        };
+        (one(value), ...);
+      },
+      config.AllValues());
+  for (auto& kv : extra) out.push_back(kv);
+  return out;
+}
+
 // pinned host blocks shared by the Arrays of one batch
 class BlockPool : public std::enable_shared_from_this<BlockPool> {
  public:

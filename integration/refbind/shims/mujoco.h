@@ -15,6 +15,7 @@ typedef struct mjModel_ {
   mjOption opt;
   mjStatistic stat;
   mjtNum* qpos0;
+  mjtNum* body_mass;
 } mjModel;
 typedef struct mjData_ {
   mjtNum time;

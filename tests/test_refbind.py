@@ -41,9 +41,28 @@ def _refbind():
 FAMILIES = [
     ("CartPole", "envpool_amd.classic_control", "CartPole", "CartPole-v1"),
     ("Pendulum", "envpool_amd.classic_control", "Pendulum", "Pendulum-v1"),
+    ("MountainCar", "envpool_amd.classic_control", "MountainCar", "MountainCar-v0"),
+    ("MountainCarContinuous", "envpool_amd.classic_control", "MountainCarContinuous",
+     "MountainCarContinuous-v0"),
+    ("Acrobot", "envpool_amd.classic_control", "Acrobot", "Acrobot-v1"),
+    ("Catch", "envpool_amd.toy_text", "Catch", "Catch-v0"),
     ("FrozenLake", "envpool_amd.toy_text", "FrozenLake", "FrozenLake-v1"),
+    ("Taxi", "envpool_amd.toy_text", "Taxi", "Taxi-v3"),
+    ("NChain", "envpool_amd.toy_text", "NChain", "NChain-v0"),
+    ("CliffWalking", "envpool_amd.toy_text", "CliffWalking", "CliffWalking-v0"),
+    ("Blackjack", "envpool_amd.toy_text", "Blackjack", "Blackjack-v1"),
     ("GymHalfCheetah", "envpool_amd.mujoco.gym", "GymHalfCheetah", "HalfCheetah-v4"),
     ("GymAnt", "envpool_amd.mujoco.gym", "GymAnt", "Ant-v4"),
+    ("GymWalker2d", "envpool_amd.mujoco.gym", "GymWalker2d", "Walker2d-v4"),
+    ("GymHopper", "envpool_amd.mujoco.gym", "GymHopper", "Hopper-v4"),
+    ("GymSwimmer", "envpool_amd.mujoco.gym", "GymSwimmer", "Swimmer-v4"),
+    ("GymReacher", "envpool_amd.mujoco.gym", "GymReacher", "Reacher-v4"),
+    ("GymPusher", "envpool_amd.mujoco.gym", "GymPusher", "Pusher-v4"),
+    ("GymInvertedPendulum", "envpool_amd.mujoco.gym", "GymInvertedPendulum", "InvertedPendulum-v4"),
+    ("GymInvertedDoublePendulum", "envpool_amd.mujoco.gym", "GymInvertedDoublePendulum",
+     "InvertedDoublePendulum-v4"),
+    ("GymHumanoid", "envpool_amd.mujoco.gym", "GymHumanoid", "Humanoid-v4"),
+    ("GymHumanoidStandup", "envpool_amd.mujoco.gym", "GymHumanoidStandup", "HumanoidStandup-v4"),
 ]
 
 
