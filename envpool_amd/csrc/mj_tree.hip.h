@@ -227,7 +227,7 @@ EPA_HD Quat QMul(Quat a, Quat b) {
           a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
 }
 EPA_HD Quat QNormalize(Quat q) {
-  const double inv = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  const double inv = 1.0 / ::sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
   return {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
 }
 EPA_HD void QMat(Quat q, double* M) {  // row-major 3x3
@@ -775,7 +775,7 @@ struct Tree {
   // sphere-sphere: returns dist; n from 1 to 2; pos midway
   static EPA_HD double SphereSphere(Vec3 p1, double r1, Vec3 p2, double r2, Vec3* n, Vec3* pos) {
     const Vec3 dif = p2 - p1;
-    const double cd = sqrt(Dot(dif, dif));
+    const double cd = ::sqrt(Dot(dif, dif));
     const bool far = cd >= kMinVal;
     const double inv = 1.0 / Sel(far, cd, 1.0);
     *n = {Sel(far, dif.x * inv, 1.0), Sel(far, dif.y * inv, 0.0), Sel(far, dif.z * inv, 0.0)};
@@ -1360,7 +1360,7 @@ struct Tree {
           if (commit) w(kL.qpos + qa + k) = v;
         });
         const Vec3 om = {w(vel + da + 3), w(vel + da + 4), w(vel + da + 5)};
-        const double nrm = sqrt(Dot(om, om));
+        const double nrm = ::sqrt(Dot(om, om));
         const bool rot = nrm * h > 0.0;
         const double inv = 1.0 / Sel(rot, nrm, 1.0);
         double sn, cs;

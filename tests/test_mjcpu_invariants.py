@@ -525,3 +525,67 @@ def test_product_pusher_code_matches_oracle_on_cpu():
                         nplane += int(buf[10 * c] == 0)
         assert worst < 1e-9, (task, worst)
         assert ncyl > 20 and nplane > 20, (task, ncyl, nplane)
+
+
+def test_product_humanoid_quad_code_matches_oracle_on_cpu():
+    """Host instantiation of mj_hum4.hip.h -- the Humanoid / HumanoidStandup kernel source with
+    one env split over a lane quad (trunk replicated, one limb per lane, arrow-structured L'DL,
+    rows kept as y = L^-T J', y-space PGS), the quad emulated by Q4<double> -- vs the oracle's
+    dense generic engine, teacher forced per env-step (5 RK4 mj_steps) incl. cfrc_ext; and the
+    smooth dynamics (qacc_smooth, cinert, cvel, geoms) vs the one-env-per-lane mj_tree.hip.h."""
+    from oracle.orc import Oracle
+
+    csrc = os.path.join(ROOT, "envpool_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", csrc, "build/mj_humanoid_consts.inc"], check=True)
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    so, src = os.path.join(h, "libhumanoid4_host.so"), os.path.join(h, "humanoid4_host.cpp")
+    deps = [src] + [os.path.join(csrc, f) for f in ("mj_hum4.hip.h", "mj_quad.hip.h", "mj_tree.hip.h",
+                                                     "mj_tree_model.h", "build/mj_humanoid_consts.inc")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(so)
+    vp = ctypes.c_void_p
+    nq, nv, nu = 24, 23, 17
+    rng = np.random.default_rng(0)
+    for su in (0, 1):
+        worst = 0.0
+        for _ in range(20):
+            q = np.zeros(nq)
+            q[:2], q[2], q[3:7] = rng.normal(0, 1, 2), (0.1 if su else 1.4), rng.normal(0, 1, 4)
+            q[7:] = rng.uniform(-0.8, 0.8, 17)
+            v, ctrl = rng.normal(0, 1.5, nv), rng.uniform(-0.6, 0.6, nu)
+            a, b = np.zeros(381), np.zeros(381)
+            for use_tree, o in ((0, a), (1, b)):
+                L.hum4_smooth(vp(q.ctypes.data), vp(v.ctypes.data), vp(ctrl.ctypes.data), su, use_tree,
+                              vp(o.ctypes.data))
+            a[273:].reshape(18, 6)[[2, 8, 11, 14, 17], 3:] = 0  # sphere "axes": unused
+            worst = max(worst, float((np.abs(a - b) / (1.0 + np.abs(b))).max()))
+        assert worst < 1e-12, (su, worst)
+    for su, task, steps in ((0, "Humanoid", 40), (1, "HumanoidStandup", 120)):
+        n = 8
+        extra = [5, 0.1, 1.0 if su else 1.25, 0.01, 0, 0, 0, 0, -1, 0, 0, 3, 1, 1]
+        orc = Oracle(task, n, seed=5, max_episode_steps=1000, extra=extra)
+        orc.reset()
+        rng = np.random.default_rng(1)
+        worst, most = 0.0, 0
+        for t in range(steps):
+            st = orc.get_state()
+            act = rng.uniform(-0.4, 0.4, size=(n, nu))
+            b = orc.step(act)
+            for e in range(n):
+                if b["elapsed_step"][e, 0] == 0:
+                    continue
+                q, v, w = (st[e, :nq].copy(), st[e, nq:nq + nv].copy(),
+                           st[e, nq + nv:nq + 2 * nv].copy())
+                o = np.zeros(512)
+                L.humanoid4_host_step(vp(q.ctypes.data), vp(v.ctypes.data), vp(w.ctypes.data),
+                                      vp(np.ascontiguousarray(act[e]).ctypes.data), 5, su, 1,
+                                      vp(o.ctypes.data))
+                k = nq + 2 * nv
+                obs = np.concatenate([o[2:nq], o[nq:nq + nv], o[k:k + 140 + 84 + 23 + 84]])
+                ref = b["obs"][e]
+                worst = max(worst, float((np.abs(obs - ref) / (1.0 + np.abs(ref))).max()))
+                most = max(most, int(o[k + 331 + 2]))
+        print(f"{task} (quad layout): worst teacher-forced rel |d obs| = {worst:.2e}; max active groups {most}")
+        assert worst < 1e-8, (task, worst)
+        assert most >= (10 if su else 3)
