@@ -348,14 +348,11 @@ template <typename X>
 EPA_HD X ClampX(X x, X lo, X hi) {
   return Sel(x < lo, lo, Sel(x > hi, hi, x));
 }
-inline double SqrtX(double x) { return std::sqrt(x); }
+EPA_HD double SqrtX(double x) { return ::sqrt(x); }
 template <typename T>
 inline Q4<T> SqrtX(const Q4<T>& x) {
   return sqrt(x);
 }
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ inline double SqrtX(double x, int) { return sqrt(x); }
-#endif
 
 template <typename X>
 struct Quat {

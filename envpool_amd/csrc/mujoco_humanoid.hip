@@ -17,27 +17,11 @@
 // reference reads; the mass centre "before" a step is therefore the lagged one of the
 // previous step (persistent slot `lag`).
 #define EPA_SINCOS_MODE 0  // see mj_cheetah.hip.h; Humanoid: mode 1 lets the scheduler interleave 17 joints (2.3 k VGPR spills, 1.94 -> 1.77 M env-steps/s)
-#include "device_common.hip.h"
-#include "engine.h"
+#include "mujoco_humanoid_common.h"
 #include "mj_tree.hip.h"
 #include "build/mj_humanoid_consts.inc"  // generated: kHumanoidModelConst, kHumanoidStandupModelConst
 
 namespace epa {
-
-// shared by the two translation units built from this file (external linkage)
-struct HumDev {
-  double* ws;     // [ceil(N / 64)][Layout::total][64]: block b belongs to wave b of a launch
-  double* state;  // [Layout::npersist][N]: what persists between steps, per env
-};
-
-struct HumTask {
-  int frame_skip, obs_skip;
-  int terminate_when_unhealthy, legacy_healthy_reward;
-  int use_contact_force, post_constraint, exclude_worldbody, exclude_root_actuator;
-  double ctrl_cost_weight, forward_reward_weight, healthy_reward;
-  double healthy_z_min, healthy_z_max, reset_noise_scale, dt;
-  double contact_cost_weight, contact_cost_max;
-};
 
 namespace {
 
@@ -316,8 +300,11 @@ class HumanoidPool : public Pool {
     task_.contact_cost_weight = cfg.Get("contact_cost_weight", 5e-7);
     task_.contact_cost_max = cfg.Get("contact_cost_max", 10.0);
     task_.dt = task_.frame_skip * kHumanoidModelConst.timestep;
+    // "hum_layout": 1 (default) one env per lane quad (mj_hum4.hip.h), 0 one env per lane with
+    // the HBM workspace (mj_tree.hip.h; kept for A/B runs)
+    quad_ = cfg.Get("hum_layout", 1) != 0;
     const size_t blocks = ((size_t)cfg.num_envs + 63) / 64;
-    ws_bytes_ = sizeof(double) * blocks * 64 * (size_t)Total();
+    ws_bytes_ = quad_ ? Hum4WorkspaceBytes(cfg.num_envs) : sizeof(double) * blocks * 64 * (size_t)Total();
     EPA_HIP(hipMalloc(&dev_.ws, ws_bytes_));
     EPA_HIP(hipMemsetAsync(dev_.ws, 0, ws_bytes_, stream_));
     const size_t sb = sizeof(double) * (size_t)T::MakeLayout(kHumanoidModelConst).npersist * cfg.num_envs;
@@ -341,6 +328,11 @@ class HumanoidPool : public Pool {
   void Launch(const int* d_ids, int k, const void* d_action, bool force_reset,
               const OutPtrs& out) override {
     StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps, cfg_.env_id_offset};
+    if (quad_) {
+      Hum4LaunchStep(stream_, standup_, (k + 15) / 16, dev_, common_, a, static_cast<const double*>(d_action),
+                     out, task_);
+      return;
+    }
     const int blocks = (k + kHumBlock - 1) / kHumBlock;
     (standup_ ? HumLaunchStepStandup : HumLaunchStepHumanoid)(
         stream_, blocks, dev_, common_, a, static_cast<const double*>(d_action), out, task_);
@@ -354,6 +346,7 @@ class HumanoidPool : public Pool {
   HumTask task_{};
   size_t ws_bytes_{0};
   bool standup_;
+  bool quad_{true};
 };
 
 }  // namespace

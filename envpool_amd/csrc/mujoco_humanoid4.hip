@@ -1,0 +1,384 @@
+// K3d — gym-MuJoCo Humanoid / HumanoidStandup batched step kernel, ONE ENV PER LANE QUAD
+// (mj_hum4.hip.h: trunk replicated, one limb per lane, everything of a forward pass on chip
+// except the constraint rows).
+//
+// Replaces, for the whole batch in one launch, the same reference code as mujoco_humanoid.hip:
+//   MujocoEnv::{MujocoReset,MujocoStep}   envpool/mujoco/gym/mujoco_env.h:126-148
+//   HumanoidEnvBase::{MujocoResetModel,Reset,Step,IsHealthy,GetMassCenter,WriteState}
+//                                         envpool/mujoco/gym/humanoid.h:129-268
+//   HumanoidStandupEnvBase::{...}         envpool/mujoco/gym/humanoid_standup.h:119-240
+//
+// A 64-thread block is one wavefront = 16 envs; lane l of a quad owns limb l (right leg, left
+// leg, right arm, left arm).  LDS per wave: the per-limb constant table (3.5 KB) and the envs'
+// geoms (13 KB).  HBM per wave: the constraint rows (y = L^-T J', 9 slots per lane and row:
+// the lane's four limb entries, its share of the nine trunk entries and of the row's five
+// scalars -- every lane reads back only what it wrote itself, the rest of the quad's values
+// arrive by DPP broadcast) and the compact contact records.  What persists between steps is
+// the same per-env SoA as in mujoco_humanoid.hip (qpos, qvel, warm start, lagged mass centre).
+#include "mujoco_humanoid_common.h"
+#include "mj_hum4.hip.h"
+#include "build/mj_humanoid_consts.inc"  // generated: kHumanoidModelConst, kHumanoidStandupModelConst
+
+namespace epa {
+namespace {
+
+namespace H = mj::hum4;
+namespace T = mj::tree;
+
+struct HumanoidMP {
+  static constexpr T::TreeModel kM = kHumanoidModelConst;
+};
+struct StandupMP {
+  static constexpr T::TreeModel kM = kHumanoidStandupModelConst;
+};
+
+constexpr int kBlock = 64, kEnvsPerBlock = 16;
+// rows: 17 limits + 4 x 29 floor contacts + 109 pairs; contacts: 29 + 109
+constexpr int kMaxRows = 17 + 4 * 29 + 128, kMaxCon = 29 + 128;
+constexpr int kRowSlots = 9, kRecSlots = 2;
+constexpr int kWsSlots = kMaxRows * kRowSlots + kMaxCon * kRecSlots;  // per lane
+constexpr int kLdsTab = 0, kLdsGeo = H::kNLC * 4;
+constexpr int kLdsElems = kLdsGeo + 102 * 16;
+
+template <int K>
+__device__ __forceinline__ double Bcast(double x) {  // lane K of the quad
+#if defined(__HIP_DEVICE_COMPILE__)
+  return mj::DppMov<K * 0x55>(x);
+#else
+  return x;
+#endif
+}
+
+template <class MP>
+struct DevCtx {
+  using V = double;
+  double* lds;
+  double* ws;  // the wave's block, [slot][64]
+  int lane, l, quad;
+
+  __device__ double LC(int idx) const { return lds[kLdsTab + idx * 4 + l]; }
+  // geoms 1..17, 6 slots each, [slot][quad]
+  __device__ void GeoPut(int slot, double v) { lds[kLdsGeo + (slot - 6) * 16 + quad] = v; }
+  __device__ double GeoGet(int slot) const { return lds[kLdsGeo + (slot - 6) * 16 + quad]; }
+  __device__ int LimbGeom(int which) const { return (l < 2 ? 6 + 3 * l : 12 + 3 * (l - 2)) + which; }
+  __device__ void GeoPutLimb(int which, H::Vec3<double> pos, H::Vec3<double> axis) {
+    const int s = 6 * LimbGeom(which);
+    GeoPut(s, pos.x);
+    GeoPut(s + 1, pos.y);
+    GeoPut(s + 2, pos.z);
+    GeoPut(s + 3, axis.x);
+    GeoPut(s + 4, axis.y);
+    GeoPut(s + 5, axis.z);
+  }
+  __device__ void GeoGetLimb(int which, H::Vec3<double>* pos, H::Vec3<double>* axis) const {
+    const int s = 6 * LimbGeom(which);
+    *pos = {GeoGet(s), GeoGet(s + 1), GeoGet(s + 2)};
+    *axis = {GeoGet(s + 3), GeoGet(s + 4), GeoGet(s + 5)};
+  }
+  __device__ double& Ws(int slot) const { return ws[(size_t)slot * 64 + lane]; }
+  // row r: slots 0..2 trunk entries j with (j & 3) == l (j = 4 slot + l), 3..6 the limb entries,
+  // 7..8 the scalars k with (k & 3) == l
+  __device__ void RowPut(int r, const double* yt, const double* yl) {
+    const int b = r * kRowSlots;
+    Ws(b) = l == 0 ? yt[0] : (l == 1 ? yt[1] : (l == 2 ? yt[2] : yt[3]));
+    Ws(b + 1) = l == 0 ? yt[4] : (l == 1 ? yt[5] : (l == 2 ? yt[6] : yt[7]));
+    if (l == 0) Ws(b + 2) = yt[8];
+    mj::static_for<0, H::kNS>([&](auto sc) { Ws(b + 3 + decltype(sc)::value) = yl[decltype(sc)::value]; });
+  }
+  __device__ void RowGet(int r, double* yt, double* yl) const {
+    const int b = r * kRowSlots;
+    const double o0 = Ws(b), o1 = Ws(b + 1), o2 = Ws(b + 2);
+    mj::static_for<0, H::kNS>([&](auto sc) { yl[decltype(sc)::value] = Ws(b + 3 + decltype(sc)::value); });
+    yt[0] = Bcast<0>(o0);
+    yt[1] = Bcast<1>(o0);
+    yt[2] = Bcast<2>(o0);
+    yt[3] = Bcast<3>(o0);
+    yt[4] = Bcast<0>(o1);
+    yt[5] = Bcast<1>(o1);
+    yt[6] = Bcast<2>(o1);
+    yt[7] = Bcast<3>(o1);
+    yt[8] = Bcast<0>(o2);
+  }
+  __device__ void RsPut(int r, int k, double v) {
+    if ((k & 3) == l) Ws(r * kRowSlots + 7 + (k >> 2)) = v;
+  }
+  __device__ double RsGet(int r, int k) const {
+    const double own = Ws(r * kRowSlots + 7 + (k >> 2));
+    return mj::hum4::BcastQ(own, k & 3);
+  }
+  __device__ void RecPut(int t, int k, double v) {
+    if ((k & 3) == l) Ws(kMaxRows * kRowSlots + t * kRecSlots + (k >> 2)) = v;
+  }
+  __device__ double RecGet(int t, int k) const {
+    const double own = Ws(kMaxRows * kRowSlots + t * kRecSlots + (k >> 2));
+    return mj::hum4::BcastQ(own, k & 3);
+  }
+};
+
+// act u <-> dof: u0 -> 7, u1 -> 6, u2 -> 8, u >= 3 -> u + 6 (humanoid.xml's actuator order)
+__device__ __forceinline__ int CtrlOfDof(int d) { return d == 6 ? 1 : (d == 7 ? 0 : d - 6); }
+
+template <class MP, bool kStandup>
+__global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, CommonDev cm, StepArgs a,
+                                                              const double* __restrict__ action,
+                                                              OutPtrs out, HumTask task) {
+  using Ctx = DevCtx<MP>;
+  using Eng = H::Hum4<MP, Ctx>;
+  constexpr T::TreeModel m = MP::kM;
+  static_assert(m.act_dof[0] == 7 && m.act_dof[1] == 6 && m.act_dof[2] == 8 && m.act_dof[3] == 9 &&
+                    m.act_dof[16] == 22,
+                "CtrlOfDof");
+  static constexpr H::LimbTab kTab = H::MakeLimbTab(MP::kM);
+  __shared__ double lds[kLdsElems];
+  const int lane = threadIdx.x, l = lane & 3, quad = lane >> 2;
+  for (int i = lane; i < H::kNLC * 4; i += kBlock) lds[kLdsTab + i] = kTab.c[i >> 2][i & 3];
+  const int row = blockIdx.x * kEnvsPerBlock + quad;
+  const bool valid = row < a.k;
+  const int e = valid ? (a.ids ? a.ids[row] - a.id_offset : row) : 0;
+  const int n = cm.n;
+  bool done = valid && cm.done[e] != 0;
+  int cur = valid ? cm.cur_step[e] : 0;
+  const bool reset = valid && (a.force_reset || done);
+  // MujocoReset (mujoco_env.h:126-131) + MujocoResetModel (humanoid.h:129-141): one uniform
+  // distribution for qpos and qvel.  The env's RNG stream is sequential: the quad's first lane
+  // draws and hands the values to the other three through LDS.
+  double* xch = lds + kLdsGeo;  // [slot][quad]; the geoms are written later
+  if (reset && l == 0) {
+    Mt19937 g(cm, e);
+    for (int i = 0; i < m.nq; ++i) {
+      static constexpr T::TreeModel mm = MP::kM;
+      xch[i * 16 + quad] = mm.qpos0[i] + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
+    }
+    for (int i = 0; i < m.nv; ++i) {
+      xch[(m.nq + i) * 16 + quad] = 0.0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
+    }
+    g.Commit();
+  }
+  __syncthreads();
+  if (!valid) return;  // whole quads leave together
+  Ctx c{lds, dev.ws + (size_t)blockIdx.x * kWsSlots * 64, lane, l, quad};
+  // persistent state: qpos[24] qvel[23] warm[23] lag[2], SoA [slot][n]
+  constexpr int kQ = 0, kV = 24, kW = 47, kLag = 70;
+  auto get = [&](int slot) -> double {
+    return reset ? (slot < kW ? xch[slot * 16 + quad] : 0.0) : dev.state[(size_t)slot * n + e];
+  };
+  int dof[H::kNS];  // this lane's global dofs (-1: the arms' dummy slot)
+  mj::static_for<0, H::kNS>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int tab[4] = {H::LimbDof(0, s), H::LimbDof(1, s), H::LimbDof(2, s), H::LimbDof(3, s)};
+    dof[s] = H::LaneInt(tab);
+  });
+  typename Eng::State s;
+  mj::static_for<0, 10>([&](auto ic) { s.qt[decltype(ic)::value] = get(kQ + decltype(ic)::value); });
+  mj::static_for<0, H::kNT>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    s.vt[j] = get(kV + j);
+    s.wt[j] = get(kW + j);
+  });
+  mj::static_for<0, H::kNS>([&](auto sc) {
+    constexpr int k = decltype(sc)::value;
+    const bool real = dof[k] >= 0;
+    const int d = real ? dof[k] : 9;
+    s.ql[k] = real ? get(kQ + 1 + d) : 0.0;
+    s.vl[k] = real ? get(kV + d) : 0.0;
+    s.wl[k] = real ? get(kW + d) : 0.0;
+  });
+  const double x_before = get(kLag), y_before = get(kLag + 1);
+  __syncthreads();  // xch is about to be overwritten by the geoms
+  double ctrl_cost = 0.0;
+  if (reset) {
+    cur = 0;
+    done = false;
+    s.ut[0] = s.ut[1] = s.ut[2] = 0.0;
+    mj::static_for<0, H::kNS>([&](auto sc) { s.ul[decltype(sc)::value] = 0.0; });
+  } else {
+    ++cur;
+    const double* act = action + (size_t)row * m.nu;
+    for (int i = 0; i < m.nu; ++i) {
+      const double ai = act[i];
+      ctrl_cost += task.ctrl_cost_weight * ai * ai;  // humanoid.h:171-174
+    }
+    s.ut[0] = act[CtrlOfDof(6)];  // clamped in mj_fwdActuation
+    s.ut[1] = act[CtrlOfDof(7)];
+    s.ut[2] = act[CtrlOfDof(8)];
+    mj::static_for<0, H::kNS>([&](auto sc) {
+      constexpr int k = decltype(sc)::value;
+      s.ul[k] = dof[k] >= 0 ? act[CtrlOfDof(dof[k] >= 0 ? dof[k] : 9)] : 0.0;
+    });
+  }
+  // reset envs: mj_forward once; stepping envs: frame_skip x (4 RK stages).  Every env runs the
+  // wave's trip count with its own state updates predicated (no divergent control flow).
+  const int nfwd = reset ? 1 : 4 * task.frame_skip;
+  const int nmax = mj::WaveAny(!reset) ? 4 * task.frame_skip : 1;
+  H::Fwd<double> f;
+  typename Eng::Rk rk;
+  typename Eng::RowCount rows{0, 0, 0};
+  double at[H::kNT], al[H::kNS];
+  for (int it = 0; it < nmax; ++it) {
+    const bool live = it < nfwd;
+    rows = Eng::Forward(c, s, f, live, at, al);
+    Eng::RkAdvance(s, rk, it & 3, live && !reset, at, al);
+  }
+  // mj_rnePostConstraint after the last mj_step (mujoco_env.h:145-147)
+  const bool wrench = task.post_constraint != 0;
+  H::Sp6<double> ext_t[H::kNTB + 1], ext_l[3];
+  if (wrench) {
+    Eng::ContactWrench(c, f, rows, ext_t, ext_l);
+  } else {
+    mj::static_for<0, H::kNTB + 1>([&](auto bc) { ext_t[decltype(bc)::value] = {{0, 0, 0}, {0, 0, 0}}; });
+    mj::static_for<0, 3>([&](auto bc) { ext_l[decltype(bc)::value] = {{0, 0, 0}, {0, 0, 0}}; });
+  }
+  const double mx = f.com.x, my = f.com.y;  // GetMassCenter, humanoid.h:212-223
+  // what persists
+  auto put = [&](int slot, double v) { dev.state[(size_t)slot * n + e] = v; };
+  if (l == 0) {
+    mj::static_for<0, 10>([&](auto ic) { put(kQ + decltype(ic)::value, s.qt[decltype(ic)::value]); });
+    mj::static_for<0, H::kNT>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      put(kV + j, s.vt[j]);
+      put(kW + j, s.wt[j]);
+    });
+    put(kLag, mx);
+    put(kLag + 1, my);
+  }
+  mj::static_for<0, H::kNS>([&](auto sc) {
+    constexpr int k = decltype(sc)::value;
+    if (dof[k] >= 0) {
+      put(kQ + 1 + dof[k], s.ql[k]);
+      put(kV + dof[k], s.vl[k]);
+      put(kW + dof[k], s.wl[k]);
+    }
+  });
+  const bool have_cfrc = wrench && !reset;  // a reset leaves mj_resetData's zeros
+  auto sq6 = [](const H::Sp6<double>& x) {
+    return x.a.x * x.a.x + x.a.y * x.a.y + x.a.z * x.a.z + x.l.x * x.l.x + x.l.y * x.l.y + x.l.z * x.l.z;
+  };
+  float reward = 0.0f;
+  double info[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (!reset) {
+    double contact_cost = 0.0;
+    if ((kStandup || task.use_contact_force) && have_cfrc) {  // humanoid.h:180-187
+      double cc = 0.0;
+      mj::static_for<0, H::kNTB + 1>([&](auto bc) { cc += sq6(ext_t[decltype(bc)::value]); });
+      cc += H::SumQ(sq6(ext_l[0]) + sq6(ext_l[1]) + sq6(ext_l[2]));
+      contact_cost = task.contact_cost_weight * cc;
+      contact_cost = contact_cost < task.contact_cost_max ? contact_cost : task.contact_cost_max;
+    }
+    const double z = s.qt[2];
+    if constexpr (kStandup) {  // humanoid_standup.h:160-185
+      const double xv = z / m.timestep;
+      reward = static_cast<float>(xv * task.forward_reward_weight + task.healthy_reward - ctrl_cost -
+                                  contact_cost);
+      done = cur >= a.max_episode_steps;
+      info[0] = xv * task.forward_reward_weight;
+      info[1] = -ctrl_cost;
+      info[2] = task.healthy_reward;
+      info[3] = -contact_cost;
+    } else {
+      const double xv = (mx - x_before) / task.dt, yv = (my - y_before) / task.dt;
+      const bool healthy = task.healthy_z_min < z && z < task.healthy_z_max;
+      bool give = healthy;
+      if (task.legacy_healthy_reward) give = task.terminate_when_unhealthy || healthy;
+      const double healthy_reward = give ? task.healthy_reward : 0.0;
+      reward = static_cast<float>(xv * task.forward_reward_weight + healthy_reward - ctrl_cost -
+                                  contact_cost);
+      done = (task.terminate_when_unhealthy ? !healthy : false) || (cur >= a.max_episode_steps);
+      info[0] = xv * task.forward_reward_weight;
+      info[1] = -ctrl_cost;
+      info[2] = healthy_reward;
+      info[3] = -contact_cost;
+      info[4] = mx;
+      info[5] = my;
+      info[6] = sqrt(mx * mx + my * my);
+      info[7] = xv;
+      info[8] = yv;
+    }
+  } else if (kStandup) {
+    info[2] = task.healthy_reward;  // WriteState(0, 0, 0, 0): reward_alive is the constant
+  }
+  // WriteState, humanoid.h:225-268: qpos[skip:] qvel cinert cvel qfrc_actuator cfrc_ext
+  const int b0 = task.exclude_worldbody ? 1 : 0;
+  const int a0 = task.exclude_root_actuator ? 6 : 0;
+  const int nb = m.nbody - b0;
+  const int nobs = (m.nq - task.obs_skip) + m.nv + 22 * nb + (m.nv - a0);
+  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
+  double* o_q = obs - task.obs_skip;
+  double* o_v = obs + (m.nq - task.obs_skip);
+  double* o_ci = o_v + m.nv - 10 * b0;   // + 10 * body
+  double* o_cv = o_v + m.nv + 10 * nb - 6 * b0;  // + 6 * body
+  double* o_act = o_v + m.nv + 16 * nb - a0;     // + dof
+  double* o_ce = o_v + m.nv + 16 * nb + (m.nv - a0) - 6 * b0;  // + 6 * body
+  auto put6 = [](double* p, const H::Sp6<double>& x, bool on) {
+    p[0] = on ? x.a.x : 0.0;
+    p[1] = on ? x.a.y : 0.0;
+    p[2] = on ? x.a.z : 0.0;
+    p[3] = on ? x.l.x : 0.0;
+    p[4] = on ? x.l.y : 0.0;
+    p[5] = on ? x.l.z : 0.0;
+  };
+  if (l == 0) {
+    mj::static_for<0, 10>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if (i >= task.obs_skip) o_q[i] = s.qt[i];
+    });
+    mj::static_for<0, H::kNT>([&](auto jc) { o_v[decltype(jc)::value] = s.vt[decltype(jc)::value]; });
+    if (b0 == 0) {
+      for (int i = 0; i < 10; ++i) o_ci[i] = 0.0;
+      for (int i = 0; i < 6; ++i) o_cv[i] = 0.0;
+      put6(o_ce, ext_t[0], have_cfrc);
+    }
+    mj::static_for<1, H::kNTB + 1>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      mj::static_for<0, 10>([&](auto ic) { o_ci[10 * b + decltype(ic)::value] = f.tci[b - 1].v[decltype(ic)::value]; });
+      put6(o_cv + 6 * b, f.tcv[b - 1], true);
+      put6(o_ce + 6 * b, ext_t[b], have_cfrc);
+    });
+    mj::static_for<0, H::kNT>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (j >= a0) o_act[j] = f.act_t[j];
+    });
+    constexpr int ninfo = kStandup ? 4 : 9;
+    for (int i = 0; i < ninfo; ++i) ((double*)out.p[kKeyEnv0 + 1 + i])[row] = info[i];
+    cm.done[e] = done ? 1 : 0;
+    cm.cur_step[e] = cur;
+    WriteCommon(out, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
+  }
+  mj::static_for<0, H::kNS>([&](auto sc) {
+    constexpr int k = decltype(sc)::value;
+    if (dof[k] >= 0) {
+      o_q[1 + dof[k]] = s.ql[k];
+      o_v[dof[k]] = s.vl[k];
+      o_act[dof[k]] = f.act_l[k];
+    }
+  });
+  const int bodyA = l == 0 ? 4 : (l == 1 ? 7 : (l == 2 ? 10 : 12));
+  const int nlb = l < 2 ? 3 : 2;
+  mj::static_for<0, 3>([&](auto wc) {
+    constexpr int w = decltype(wc)::value;
+    if (w < nlb) {
+      const int b = bodyA + w;
+      mj::static_for<0, 10>([&](auto ic) { o_ci[10 * b + decltype(ic)::value] = f.lci[w].v[decltype(ic)::value]; });
+      put6(o_cv + 6 * b, f.lcv[w > 1 ? 1 : w], true);
+      put6(o_ce + 6 * b, ext_l[w], have_cfrc);
+    }
+  });
+}
+
+}  // namespace
+
+void Hum4LaunchStep(hipStream_t st, bool standup, int blocks, HumDev dev, CommonDev cm, StepArgs a,
+                    const double* act, OutPtrs out, HumTask task) {
+  if (standup) {
+    hipLaunchKernelGGL((Humanoid4StepKernel<StandupMP, true>), dim3(blocks), dim3(kBlock), 0, st, dev, cm,
+                       a, act, out, task);
+  } else {
+    hipLaunchKernelGGL((Humanoid4StepKernel<HumanoidMP, false>), dim3(blocks), dim3(kBlock), 0, st, dev, cm,
+                       a, act, out, task);
+  }
+}
+size_t Hum4WorkspaceBytes(int num_envs) {
+  const size_t blocks = ((size_t)num_envs + kEnvsPerBlock - 1) / kEnvsPerBlock;
+  return sizeof(double) * blocks * 64 * (size_t)kWsSlots;
+}
+
+}  // namespace epa
