@@ -311,6 +311,21 @@ inline T BcastQ(const Q4<T>& x, int k) {
 }
 EPA_HD double BcastQ(double x, int k) { return SumQ(Sel(LaneOps<double>::Is(k), x, 0.0)); }
 
+// entries base + 0..3 of an env-level array, one per lane of the quad
+EPA_HD double LanePick4(const double* x, int base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int l = (int)(threadIdx.x & 3u);
+  return l == 0 ? x[base] : (l == 1 ? x[base + 1] : (l == 2 ? x[base + 2] : x[base + 3]));
+#else
+  return x[base];
+#endif
+}
+template <typename T>
+inline Q4<T> LanePick4(const T* x, int base, Q4<T> = Q4<T>()) {
+  Q4<T> r;
+  for (int i = 0; i < 4; ++i) r.v[i] = x[base + i];
+  return r;
+}
 // entry `slot` of limb `limb`'s part of a distributed vector, as an env-level value
 template <typename T>
 inline T LimbPick(const Q4<T>* xl, int limb, int slot) {
@@ -447,15 +462,13 @@ EPA_HD constexpr int TrunkBodyOfDof(int j) { return j < 6 ? 0 : (j < 8 ? 1 : 2);
 template <typename V>
 struct Fwd {
   using E = typename EnvOf<V>::type;
-  Sp6<E> tcd[kNT];   // cdof, trunk
-  Sp6<V> lcd[kNS];   // cdof, limb
+  Sp6<V> lcd[kNS];   // cdof, limb (the trunk's: Ctx::TcdGet)
   In10<E> tci[kNTB];  // cinert of bodies 1 2 3
   In10<V> lci[3];     // cinert of A B C
   Sp6<E> tcv[kNTB];   // cvel of bodies 1 2 3
   Sp6<V> lcv[2];      // cvel of A, B (C moves with B)
   Vec3<E> com;
-  // L'DL of M: L strictly lower (unit diagonal implied), D^-1
-  E Ltt[kNTT], dinv_t[kNT];
+  // L'DL of M: L strictly lower (unit diagonal implied), D^-1; the trunk block: Ctx::LttGet, DtGet
   V Llt[kNS][kNT], Lll[kNLL], dinv_l[kNS];
   E act_t[kNT];  // qfrc_actuator
   V act_l[kNS];
@@ -496,6 +509,21 @@ struct Hum4 {
     c.GeoPut(GeoSlot(g), pos.x);
     c.GeoPut(GeoSlot(g) + 1, pos.y);
     c.GeoPut(GeoSlot(g) + 2, pos.z);
+  }
+
+  // trunk cdof and the trunk block of the L'DL factor are env-level data kept by the Ctx (LDS):
+  // replicated in every lane's registers they cost 200 VGPRs through the whole constraint stage
+  static EPA_HD void TcdPut(Ctx& c, int j, const Sp6<E>& x) {
+    c.TcdPut(6 * j, x.a.x);
+    c.TcdPut(6 * j + 1, x.a.y);
+    c.TcdPut(6 * j + 2, x.a.z);
+    c.TcdPut(6 * j + 3, x.l.x);
+    c.TcdPut(6 * j + 4, x.l.y);
+    c.TcdPut(6 * j + 5, x.l.z);
+  }
+  static EPA_HD Sp6<E> Tcd(Ctx& c, int j) {
+    return {{c.TcdGet(6 * j), c.TcdGet(6 * j + 1), c.TcdGet(6 * j + 2)},
+            {c.TcdGet(6 * j + 3), c.TcdGet(6 * j + 4), c.TcdGet(6 * j + 5)}};
   }
 
   // ---- mj_kinematics + mj_comPos + mj_crb + mj_factorM ------------------------------------------
@@ -623,10 +651,10 @@ struct Hum4 {
     static_for<0, 3>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       Vec3<E> e = {E(k == 0), E(k == 1), E(k == 2)};
-      f.tcd[k] = {{E(0), E(0), E(0)}, e};
+      TcdPut(c, k, Sp6<E>{{E(0), E(0), E(0)}, e});
       const Vec3<E> axis = {tf[0].R.m[k], tf[0].R.m[3 + k], tf[0].R.m[6 + k]};
-      f.tcd[3 + k] = {axis, Cross(axis, f.com - tf[0].pos)};
-      f.tcd[6 + k] = {t_axis[k], Cross(t_axis[k], f.com - t_anchor[k])};
+      TcdPut(c, 3 + k, Sp6<E>{axis, Cross(axis, f.com - tf[0].pos)});
+      TcdPut(c, 6 + k, Sp6<E>{t_axis[k], Cross(t_axis[k], f.com - t_anchor[k])});
     });
     static_for<0, kNS>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
@@ -664,10 +692,10 @@ struct Hum4 {
     V Mlt[kNS][kNT], Mll[kNLL];
     static_for<0, kNT>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      const Sp6<E> buf = MulInert(tcrb[TrunkBodyOfDof(i)], f.tcd[i]);
+      const Sp6<E> buf = MulInert(tcrb[TrunkBodyOfDof(i)], Tcd(c, i));
       static_for<0, i + 1>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        E v = Dot(f.tcd[j], buf);
+        E v = Dot(Tcd(c, j), buf);
         if constexpr (i == j) v = v + E(m.dof_arm[i]);
         Mtt[TT(i, j)] = v;
       });
@@ -683,7 +711,7 @@ struct Hum4 {
       });
       static_for<0, kNT>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        const V v = Dot(LiftS(f.tcd[j]), buf);
+        const V v = Dot(LiftS(Tcd(c, j)), buf);
         // dofs 6 7 8 (abdomen) are ancestors of the legs only
         if constexpr (j >= 6) Mlt[s][j] = Sel(leg, v, V(0));
         else Mlt[s][j] = v;
@@ -691,10 +719,10 @@ struct Hum4 {
     });
     // mj_factorM: M = L' D L from the last dof up.  Limb dofs are leaves of the arrow: they are
     // eliminated inside their lane; their updates of the trunk block are summed over the quad.
-    V dT[kNTT];
-    static_for<0, kNTT>([&](auto kc) { dT[decltype(kc)::value] = V(0); });
+    V dl[kNS];  // D of the limb dofs
     static_for_down<kNS, 0>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
+      dl[k] = Mll[LL(k, k)];
       const V inv = V(1) / Mll[LL(k, k)];
       f.dinv_l[k] = inv;
       // ancestors of k: limb slots < k, then the trunk dofs (in decreasing dof order: limb slots
@@ -712,21 +740,28 @@ struct Hum4 {
         });
         f.Lll[LL(k, i)] = tmp;
       });
-      static_for_down<kNT, 0>([&](auto ic) {
+      static_for<0, kNT>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const V tmp = Mlt[k][i] * inv;
-        static_for<0, i + 1>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          dT[TT(i, j)] += tmp * Mlt[k][j];
-        });
-        f.Llt[k][i] = tmp;
+        f.Llt[k][i] = Mlt[k][i] * inv;
       });
     });
-    static_for<0, kNTT>([&](auto kc) { Mtt[decltype(kc)::value] -= SumQ(dT[decltype(kc)::value]); });
+    // the limbs' update of the trunk block, sum_k L_ki L_kj D_k, summed over the quad
+    static_for<0, kNT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      static_for<0, i + 1>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        V v = V(0);
+        static_for<0, kNS>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          v += f.Llt[k][i] * (f.Llt[k][j] * dl[k]);
+        });
+        Mtt[TT(i, j)] -= SumQ(v);
+      });
+    });
     static_for_down<kNT, 0>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       const E inv = E(1) / Mtt[TT(k, k)];
-      f.dinv_t[k] = inv;
+      c.DtPut(k, inv);
       static_for_down<k, 0>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const E tmp = Mtt[TT(k, i)] * inv;
@@ -734,13 +769,13 @@ struct Hum4 {
           constexpr int j = decltype(jc)::value;
           Mtt[TT(i, j)] -= tmp * Mtt[TT(k, j)];
         });
-        f.Ltt[TT(k, i)] = tmp;
+        c.LttPut(TT(k, i), tmp);
       });
     });
   }
 
   // y = L^-T x (in place): the first half of mj_solveM.  Returns sum_i y_i^2 / D_i.
-  static EPA_HD E HalfSolve(const Fwd<V>& f, E* xt, V* xl) {
+  static EPA_HD E HalfSolve(Ctx& c, const Fwd<V>& f, E* xt, V* xl) {
     V ct[kNT];
     static_for<0, kNT>([&](auto jc) { ct[decltype(jc)::value] = V(0); });
     static_for_down<kNS, 0>([&](auto kc) {
@@ -759,7 +794,7 @@ struct Hum4 {
       constexpr int k = decltype(kc)::value;
       static_for<0, k>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        xt[i] -= f.Ltt[TT(k, i)] * xt[k];
+        xt[i] -= c.LttGet(TT(k, i)) * xt[k];
       });
     });
     V ql = V(0);
@@ -770,23 +805,23 @@ struct Hum4 {
     E qt = E(0);
     static_for<0, kNT>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      qt += xt[j] * xt[j] * f.dinv_t[j];
+      qt += xt[j] * xt[j] * c.DtGet(j);
     });
     return qt + SumQ(ql);
   }
   // x <- L^-1 D^-1 x: the second half
-  static EPA_HD void BackSolve(const Fwd<V>& f, E* xt, V* xl) {
-    static_for<0, kNT>([&](auto jc) { xt[decltype(jc)::value] *= f.dinv_t[decltype(jc)::value]; });
+  static EPA_HD void BackSolve(Ctx& c, const Fwd<V>& f, E* xt, V* xl) {
+    static_for<0, kNT>([&](auto jc) { xt[decltype(jc)::value] *= c.DtGet(decltype(jc)::value); });
     static_for<0, kNS>([&](auto sc) { xl[decltype(sc)::value] *= f.dinv_l[decltype(sc)::value]; });
-    ForwardSub(f, xt, xl);
+    ForwardSub(c, f, xt, xl);
   }
   // x <- L^-1 x
-  static EPA_HD void ForwardSub(const Fwd<V>& f, E* xt, V* xl) {
+  static EPA_HD void ForwardSub(Ctx& c, const Fwd<V>& f, E* xt, V* xl) {
     static_for<0, kNT>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       static_for<0, i>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        xt[i] -= f.Ltt[TT(i, j)] * xt[j];
+        xt[i] -= c.LttGet(TT(i, j)) * xt[j];
       });
     });
     static_for<0, kNS>([&](auto sc) {
@@ -818,20 +853,20 @@ struct Hum4 {
       cvel.l = cvel.l + Vec3<E>{vt[0], vt[1], vt[2]};
       static_for<0, 3>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        AxpySp(cacc, CrossMotion(cvel, f.tcd[3 + k]), vt[3 + k]);
+        AxpySp(cacc, CrossMotion(cvel, Tcd(c, 3 + k)), vt[3 + k]);
       });
-      static_for<0, 3>([&](auto kc) { AxpySp(cvel, f.tcd[3 + decltype(kc)::value], vt[3 + decltype(kc)::value]); });
+      static_for<0, 3>([&](auto kc) { AxpySp(cvel, Tcd(c, 3 + decltype(kc)::value), vt[3 + decltype(kc)::value]); });
       f.tcv[0] = cvel;
       tca[0] = cacc;
       static_for<6, 8>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        AxpySp(cacc, CrossMotion(cvel, f.tcd[i]), vt[i]);
-        AxpySp(cvel, f.tcd[i], vt[i]);
+        AxpySp(cacc, CrossMotion(cvel, Tcd(c, i)), vt[i]);
+        AxpySp(cvel, Tcd(c, i), vt[i]);
       });
       f.tcv[1] = cvel;
       tca[1] = cacc;
-      AxpySp(cacc, CrossMotion(cvel, f.tcd[8]), vt[8]);
-      AxpySp(cvel, f.tcd[8], vt[8]);
+      AxpySp(cacc, CrossMotion(cvel, Tcd(c, 8)), vt[8]);
+      AxpySp(cvel, Tcd(c, 8), vt[8]);
       f.tcv[2] = cvel;
       tca[2] = cacc;
     }
@@ -871,7 +906,7 @@ struct Hum4 {
     V xl[kNS];
     static_for<0, kNT>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      E x = -Dot(f.tcd[i], tf[TrunkBodyOfDof(i)]) - E(m.dof_damp[i]) * vt[i];
+      E x = -Dot(Tcd(c, i), tf[TrunkBodyOfDof(i)]) - E(m.dof_damp[i]) * vt[i];
       E act = E(0);
       if constexpr (i >= 6) {
         constexpr int j = i - 5;  // joint of the dof
@@ -890,8 +925,8 @@ struct Hum4 {
       f.act_l[s] = act;
       xl[s] = x + act;
     });
-    HalfSolve(f, xt, xl);
-    BackSolve(f, xt, xl);
+    HalfSolve(c, f, xt, xl);
+    BackSolve(c, f, xt, xl);
     static_for<0, kNT>([&](auto ic) { f.accs_t[decltype(ic)::value] = xt[decltype(ic)::value]; });
     static_for<0, kNS>([&](auto sc) { f.accs_l[decltype(sc)::value] = xl[decltype(sc)::value]; });
   }
@@ -1084,7 +1119,42 @@ struct Hum4 {
   }
 
   // ---- mj_makeConstraint + the y rows ------------------------------------------------------------
-  // Row storage (Ctx): RowPut / RowGet(r, yt, yl) the row's y = L^-T J'; RsPut / RsGet(r, k) its
+  // A 23-vector in DISTRIBUTED form: kND = 7 numbers per lane -- trunk entries l, 4 + l and (lane 0)
+  // 8, then the lane's four limb entries -- so that a dot product is 7 multiply-adds and ONE quad
+  // reduction, with no trunk entry touched twice.  The rows y_r, z and 1 / D are kept like this.
+  static constexpr int kND = 3 + kNS;
+  static EPA_HD void Distribute(const E* xt, const V* xl, V* xd) {
+    E pad[12];
+    static_for<0, kNT>([&](auto jc) { pad[decltype(jc)::value] = xt[decltype(jc)::value]; });
+    pad[9] = pad[10] = pad[11] = E(0);
+    xd[0] = LanePickV(pad, 0);
+    xd[1] = LanePickV(pad, 4);
+    xd[2] = LanePickV(pad, 8);
+    static_for<0, kNS>([&](auto sc) { xd[3 + decltype(sc)::value] = xl[decltype(sc)::value]; });
+  }
+  static EPA_HD V LanePickV(const E* x, int base) {
+    if constexpr (std::is_same<V, E>::value) return LanePick4(x, base);
+    else return LanePick4(x, base, V());
+  }
+  static EPA_HD void Gather(const V* xd, E* xt, V* xl) {
+    static_for<0, kNT>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      xt[j] = BcastQ(xd[j >> 2], j & 3);
+    });
+    static_for<0, kNS>([&](auto sc) { xl[decltype(sc)::value] = xd[3 + decltype(sc)::value]; });
+  }
+  static EPA_HD E DotD(const V* a, const V* b) {
+    V p = a[0] * b[0];
+    static_for<1, kND>([&](auto ic) { p += a[decltype(ic)::value] * b[decltype(ic)::value]; });
+    return SumQ(p);
+  }
+  // 1 / D in distributed form
+  static EPA_HD void DinvD(Ctx& c, const Fwd<V>& f, V* dd) {
+    E dt[kNT];
+    static_for<0, kNT>([&](auto jc) { dt[decltype(jc)::value] = c.DtGet(decltype(jc)::value); });
+    Distribute(dt, f.dinv_l, dd);
+  }
+  // Row storage (Ctx): RowPut / RowGet(r, yd) the row's y = L^-T J' (distributed); RsPut / RsGet(r, k) its
   // scalars k = 0 f, 1 A_rr + R_r, 2 R_r, 3 b_r = J_r qacc_smooth - aref_r, 4 1 / (A_rr + R_r);
   // RecPut / RecGet(t, k) the contact records (position 3, normal 3, bodies 2) in compact order.
   enum { kRsF = 0, kRsArr = 1, kRsR = 2, kRsB = 3, kRsAinv = 4 };
@@ -1102,13 +1172,11 @@ struct Hum4 {
   // vt / vl: qvel, wt / wl: qacc_warmstart.  Leaves zs = sum_r f_r y_r (f: the warm-start forces)
   // and cost = sum_r f_r (R_r f_r / 2 + b_r).
   static EPA_HD RowCount MakeRows(Ctx& c, const Fwd<V>& f, const EMask& act, const E* qt, const V* ql,
-                                  const E* vt, const V* vl, const E* wt, const V* wl, E* zst, V* zsl,
-                                  E* cost_out) {
+                                  const E* vt, const V* vl, const E* wt, const V* wl, V* zsd, E* cost_out) {
     constexpr TreeModel m = MP::kM;
     RowCount rc{0, 0, 0};
     E cost = E(0);
-    static_for<0, kNT>([&](auto jc) { zst[decltype(jc)::value] = E(0); });
-    static_for<0, kNS>([&](auto sc) { zsl[decltype(sc)::value] = V(0); });
+    static_for<0, kND>([&](auto ic) { zsd[decltype(ic)::value] = V(0); });
     int row = 0;
     for (int phase = 0; phase < 3; ++phase) {
       const int glo = phase == 0 ? 0 : (phase == 1 ? kG0Floor : kG0Pair);
@@ -1194,7 +1262,8 @@ struct Hum4 {
               static_for<0, kNT>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 const E coef = E((int)((m2 >> j) & 1u) - (int)((m1 >> j) & 1u));
-                const E jc0 = coef * (Dot(dir, f.tcd[j].l) + Dot(mdir, f.tcd[j].a));
+                const Sp6<E> cd = Tcd(c, j);
+                const E jc0 = coef * (Dot(dir, cd.l) + Dot(mdir, cd.a));
                 Jt[j] = on ? jc0 : E(0);
               });
               const Vec3<V> dv = LiftV(dir), mv = LiftV(mdir);
@@ -1228,8 +1297,10 @@ struct Hum4 {
             const E fw = (on && jar < E(0)) ? -jar / R : E(0);
             const E b = on ? ja - aref : E(0);
             const E Rr = on ? R : E(0);
-            const E quad = HalfSolve(f, Jt, Jl);  // J -> y in place
-            c.RowPut(r, Jt, Jl);
+            const E quad = HalfSolve(c, f, Jt, Jl);  // J -> y in place
+            V yd[kND];
+            Distribute(Jt, Jl, yd);
+            c.RowPut(r, yd);
             const E arr = Rr + quad;  // 0 for an inert row
             c.RsPut(r, kRsF, fw);
             c.RsPut(r, kRsArr, arr);
@@ -1237,8 +1308,7 @@ struct Hum4 {
             c.RsPut(r, kRsB, b);
             c.RsPut(r, kRsAinv, arr > E(0) ? E(1) / arr : E(0));
             cost += fw * (E(0.5) * Rr * fw + b);
-            static_for<0, kNT>([&](auto jc) { zst[decltype(jc)::value] += fw * Jt[decltype(jc)::value]; });
-            static_for<0, kNS>([&](auto sc) { zsl[decltype(sc)::value] += V(fw) * Jl[decltype(sc)::value]; });
+            static_for<0, kND>([&](auto ic) { zsd[decltype(ic)::value] += V(fw) * yd[decltype(ic)::value]; });
           }
           row += nsub;
           ++count;
@@ -1252,77 +1322,172 @@ struct Hum4 {
     return rc;
   }
 
-  // ---- mj_fwdConstraint with mj_solPGS, y-space streaming form ---------------------------------
-  //   z = sum_c f_c y_c / D;  res_r = b_r + R_r f_r + y_r . z  (= b_r + sum_c (A + R)_rc f_c)
-  // `commit`: envs that are only kept busy must not disturb their warm start.
-  static EPA_HD void SolvePgs(Ctx& c, const Fwd<V>& f, int nrow, E* zst, V* zsl, E cost, E* at, V* al) {
-    constexpr TreeModel m = MP::kM;
+  struct RowBuf {
+    V yd[kND];
+    E f, arr, R, b, ainv;
+  };
+  static EPA_HD void LoadRowBuf(Ctx& c, int r, RowBuf& t) {
+    c.RowGet(r, t.yd);
+    t.f = c.RsGet(r, kRsF);
+    t.arr = c.RsGet(r, kRsArr);
+    t.R = c.RsGet(r, kRsR);
+    t.b = c.RsGet(r, kRsB);
+    t.ainv = c.RsGet(r, kRsAinv);
+  }
+  // the warm start is kept only if its dual cost 1/2 f'(A+R)f + f'b is below the cost of f = 0
+  static EPA_HD bool ColdStart(const V* zsd, const V* dd, E cost) {
+    V q = V(0);
+    static_for<0, kND>([&](auto ic) { q += zsd[decltype(ic)::value] * zsd[decltype(ic)::value] * dd[decltype(ic)::value]; });
+    return cost + E(0.5) * SumQ(q) > E(0);
+  }
+  // qacc = qacc_smooth + L^-1 z,  z = D^-1 sum_r f_r y_r (distributed)
+  static EPA_HD void Finish(Ctx& c, const Fwd<V>& f, const V* zd, E* at, V* al) {
     E zt[kNT];
     V zl[kNS];
-    if (nrow > 0) {
-      // dual cost of the warm-start forces 1/2 f'(A+R)f + f'b: kept only if below the cost of f = 0
-      E qt = E(0);
-      V ql = V(0);
-      static_for<0, kNT>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        zt[j] = zst[j] * f.dinv_t[j];
-        qt += zst[j] * zt[j];
-      });
-      static_for<0, kNS>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        zl[s] = zsl[s] * f.dinv_l[s];
-        ql += zsl[s] * zl[s];
-      });
-      const bool cold = cost + E(0.5) * (qt + SumQ(ql)) > E(0);
-      static_for<0, kNT>([&](auto jc) { zt[decltype(jc)::value] = cold ? E(0) : zt[decltype(jc)::value]; });
-      static_for<0, kNS>([&](auto sc) { zl[decltype(sc)::value] = Sel(cold, V(0), zl[decltype(sc)::value]); });
-      if (AnyWave(cold)) {
-        for (int r = 0; r < nrow; ++r) {
-          if (cold) c.RsPut(r, kRsF, E(0));
-        }
-      }
-      const E scale = E(1.0 / (m.meaninertia * 23.0));
-      bool done = false;
-      for (int iter = 0; iter < m.iterations; ++iter) {
-        E improvement = E(0);
-        for (int r = 0; r < nrow; ++r) {
-          E yt[kNT];
-          V yl[kNS];
-          c.RowGet(r, yt, yl);
-          const E fr = c.RsGet(r, kRsF), arr = c.RsGet(r, kRsArr), Rr = c.RsGet(r, kRsR), b = c.RsGet(r, kRsB),
-                  ainv = c.RsGet(r, kRsAinv);
-          E p0 = b + Rr * fr;
-          V pl = V(0);
-          static_for<0, kNT>([&](auto jc) { p0 += yt[decltype(jc)::value] * zt[decltype(jc)::value]; });
-          static_for<0, kNS>([&](auto sc) { pl += yl[decltype(sc)::value] * zl[decltype(sc)::value]; });
-          const E res = p0 + SumQ(pl);
-          const E fn = MaxX(E(0), fr - res * ainv);
-          E delta = fn - fr;
-          const E change = E(0.5) * delta * delta * arr + delta * res;
-          const bool keep = !done && !(change > E(1e-10));
-          delta = keep ? delta : E(0);
-          c.RsPut(r, kRsF, fr + delta);
-          static_for<0, kNT>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            zt[j] += delta * yt[j] * f.dinv_t[j];
-          });
-          static_for<0, kNS>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            zl[s] += V(delta) * yl[s] * f.dinv_l[s];
-          });
-          improvement -= keep ? change : E(0);
-        }
-        done = done || improvement * scale < E(1e-8);
-        if (!AnyWave(!done)) break;
-      }
-    } else {
-      static_for<0, kNT>([&](auto jc) { zt[decltype(jc)::value] = E(0); });
-      static_for<0, kNS>([&](auto sc) { zl[decltype(sc)::value] = V(0); });
-    }
-    // qacc = qacc_smooth + M^-1 J' f = qacc_smooth + L^-1 z
-    ForwardSub(f, zt, zl);
+    Gather(zd, zt, zl);
+    ForwardSub(c, f, zt, zl);
     static_for<0, kNT>([&](auto jc) { at[decltype(jc)::value] = f.accs_t[decltype(jc)::value] + zt[decltype(jc)::value]; });
     static_for<0, kNS>([&](auto sc) { al[decltype(sc)::value] = f.accs_l[decltype(sc)::value] + zl[decltype(sc)::value]; });
+  }
+  // ---- mj_fwdConstraint with mj_solPGS, y-space streaming form ---------------------------------
+  //   z = sum_c f_c y_c / D;  res_r = b_r + R_r f_r + y_r . z  (= b_r + sum_c (A + R)_rc f_c)
+  static EPA_HD void SolvePgs(Ctx& c, const Fwd<V>& f, int nrow, const V* zsd, E cost, E* at, V* al) {
+    constexpr TreeModel m = MP::kM;
+    V dd[kND], zd[kND];
+    DinvD(c, f, dd);
+    const bool cold = ColdStart(zsd, dd, cost);
+    static_for<0, kND>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      zd[i] = Sel(cold, V(0), zsd[i] * dd[i]);
+    });
+    if (AnyWave(cold)) {
+      for (int r = 0; r < nrow; ++r) {
+        if (cold) c.RsPut(r, kRsF, E(0));
+      }
+    }
+    const E scale = E(1.0 / (m.meaninertia * 23.0));
+    bool done = false;
+    for (int iter = 0; iter < m.iterations; ++iter) {
+      E improvement = E(0);
+      // one row of lookahead: the next row's loads are in flight while this one is visited
+      RowBuf nx;
+      LoadRowBuf(c, 0, nx);
+      for (int r = 0; r < nrow; ++r) {
+        const RowBuf cu = nx;
+        LoadRowBuf(c, r + 1 < nrow ? r + 1 : 0, nx);
+        const E res = cu.b + cu.R * cu.f + DotD(cu.yd, zd);
+        const E fn = MaxX(E(0), cu.f - res * cu.ainv);
+        E delta = fn - cu.f;
+        const E change = E(0.5) * delta * delta * cu.arr + delta * res;
+        const bool keep = !done && !(change > E(1e-10));
+        delta = keep ? delta : E(0);
+        c.RsPut(r, kRsF, cu.f + delta);
+        if (nrow == 1) nx.f = cu.f + delta;  // the lookahead read the row that was just updated
+        static_for<0, kND>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          zd[i] += V(delta) * cu.yd[i] * dd[i];
+        });
+        improvement -= keep ? change : E(0);
+      }
+      done = done || improvement * scale < E(1e-8);
+      if (!AnyWave(!done)) break;
+    }
+    Finish(c, f, zd, at, al);
+  }
+
+  // ---- mj_solPGS on the dual matrix, on chip ------------------------------------------------------
+  // With <= kRegRows rows A + R (packed lower triangle), b, f and 1 / (A_rr + R_r) live in the
+  // env's shared block (Ctx::ShGet / ShPut: LDS) and the sweeps touch no memory: MuJoCo's own
+  // formulation res_r = b_r + sum_c (A + R)_rc f_c.  Lane l of the quad sums the columns c = l,
+  // l + 4, ... (Ctx::ArGetLane / FGetLane), one quad reduction per row visit.
+  enum { kShA = 0, kShB = kRegRows * (kRegRows + 1) / 2, kShF = kShB + kRegRows, kShAinv = kShF + kRegRows,
+         kShSlots = kShAinv + kRegRows };
+  static EPA_HD constexpr int Tri(int r, int cc) { return r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r; }
+  static EPA_HD void SolvePgsA(Ctx& c, const Fwd<V>& f, int nrow, const V* zsd, E cost, E* at, V* al) {
+    constexpr TreeModel m = MP::kM;
+    V dd[kND];
+    DinvD(c, f, dd);
+    const bool cold = ColdStart(zsd, dd, cost);
+    // A_rc = sum_i y_r[i] y_c[i] / D_i: four columns (scaled by 1 / D) stay in registers while the
+    // rows below them stream past, with one row of lookahead
+    for (int c0 = 0; c0 < nrow; c0 += 4) {
+      V w[4][kND];
+      static_for<0, 4>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const int cc = c0 + k < nrow ? c0 + k : c0;
+        c.RowGet(cc, w[k]);
+        if (c0 + k < nrow) {  // wave uniform
+          c.ShPut(kShB + cc, c.RsGet(cc, kRsB));
+          c.ShPut(kShF + cc, cold ? E(0) : c.RsGet(cc, kRsF));
+          c.ShPut(kShAinv + cc, c.RsGet(cc, kRsAinv));
+          c.ShPut(kShA + Tri(cc, cc), c.RsGet(cc, kRsArr));
+        }
+      });
+      static_for<0, 4>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        // entries inside the block: row c0 + r (unscaled, r > k) . column c0 + k (scaled below)
+        V wk[kND];
+        static_for<0, kND>([&](auto ic) { wk[decltype(ic)::value] = w[k][decltype(ic)::value] * dd[decltype(ic)::value]; });
+        static_for<k + 1, 4>([&](auto rc4) {
+          constexpr int r = decltype(rc4)::value;
+          const E a = DotD(w[r], wk);
+          if (c0 + r < nrow) c.ShPut(kShA + Tri(c0 + r, c0 + k), a);
+        });
+        static_for<0, kND>([&](auto ic) { w[k][decltype(ic)::value] = wk[decltype(ic)::value]; });
+      });
+      if (c0 + 4 < nrow) {
+        V nx[kND];
+        c.RowGet(c0 + 4, nx);
+        for (int r = c0 + 4; r < nrow; ++r) {
+          V y[kND];
+          static_for<0, kND>([&](auto ic) { y[decltype(ic)::value] = nx[decltype(ic)::value]; });
+          c.RowGet(r + 1 < nrow ? r + 1 : r, nx);
+          static_for<0, 4>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const E a = DotD(y, w[k]);
+            if (c0 + k < nrow) c.ShPut(kShA + Tri(r, c0 + k), a);
+          });
+        }
+      }
+    }
+    for (int r = nrow; r < kRegRows; ++r) c.ShPut(kShF + r, E(0));  // stale columns of A count for nothing
+    const E scale = E(1.0 / (m.meaninertia * 23.0));
+    bool done = false;
+    for (int iter = 0; iter < m.iterations; ++iter) {
+      E improvement = E(0);
+      for (int r = 0; r < nrow; ++r) {
+        V part = V(0);
+        static_for<0, kRegRows / 4>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          part += c.ArGetLane(kShA, r, k) * c.ShGetLane(kShF, k);
+        });
+        const E fr = c.ShGet(kShF + r), arr = c.ShGet(kShA + Tri(r, r)), ainv = c.ShGet(kShAinv + r);
+        const E res = c.ShGet(kShB + r) + SumQ(part);
+        const E fn = MaxX(E(0), fr - res * ainv);
+        E delta = fn - fr;
+        const E change = E(0.5) * delta * delta * arr + delta * res;
+        const bool keep = !done && !(change > E(1e-10));
+        delta = keep ? delta : E(0);
+        c.ShPut(kShF + r, fr + delta);
+        improvement -= keep ? change : E(0);
+      }
+      done = done || improvement * scale < E(1e-8);
+      if (!AnyWave(!done)) break;
+    }
+    // z = D^-1 sum_r f_r y_r; efc_force goes back to the rows (mj_rnePostConstraint)
+    V zd[kND], nx[kND];
+    static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] = V(0); });
+    if (nrow > 0) c.RowGet(0, nx);
+    for (int r = 0; r < nrow; ++r) {
+      V y[kND];
+      static_for<0, kND>([&](auto ic) { y[decltype(ic)::value] = nx[decltype(ic)::value]; });
+      c.RowGet(r + 1 < nrow ? r + 1 : r, nx);
+      const E fr = c.ShGet(kShF + r);
+      c.RsPut(r, kRsF, fr);
+      static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] += V(fr) * y[decltype(ic)::value]; });
+    }
+    static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] *= dd[decltype(ic)::value]; });
+    Finish(c, f, zd, at, al);
   }
 
   // the env's state, distributed: trunk (env level) + this lane's limb
@@ -1333,15 +1498,32 @@ struct Hum4 {
     V ul[kNS];
   };
   // mj_forward: qacc (at, al); `commit`: store it as the warm start
-  static EPA_HD RowCount Forward(Ctx& c, State& s, Fwd<V>& f, bool commit, E* at, V* al) {
+  // `dbg` (timing builds only, wave uniform): 1 no constraint solve, 2 no rows, 4 no detection
+  // `after_velocity(f)`: hook right after the smooth dynamics, while cinert / cvel / qfrc_actuator
+  // are at hand (the kernel writes its observation there on the last pass; nothing of them has to
+  // stay live through the constraint solve)
+  template <typename Hook>
+  static EPA_HD RowCount Forward(Ctx& c, State& s, Fwd<V>& f, bool commit, E* at, V* al, int dbg,
+                                 Hook&& after_velocity) {
     Position(c, s.qt, s.ql, f);
     EMask act;
-    Detect(c, s.qt, s.ql, act);
+    if (dbg & 4) {
+      act.w[0] = act.w[1] = act.w[2] = 0ull;
+    } else {
+      Detect(c, s.qt, s.ql, act);
+    }
+    if (dbg & 2) act.w[0] = act.w[1] = act.w[2] = 0ull;
     Velocity(c, s.qt, s.ql, s.vt, s.vl, s.ut, s.ul, f);
-    E zst[kNT], cost;
-    V zsl[kNS];
-    const RowCount rc = MakeRows(c, f, act, s.qt, s.ql, s.vt, s.vl, s.wt, s.wl, zst, zsl, &cost);
-    SolvePgs(c, f, rc.rows(), zst, zsl, cost, at, al);
+    after_velocity(f);
+    E cost;
+    V zsd[kND];
+    RowCount rc = MakeRows(c, f, act, s.qt, s.ql, s.vt, s.vl, s.wt, s.wl, zsd, &cost);
+    if (dbg & 1) rc = RowCount{0, 0, 0};
+    if (rc.rows() <= kRegRows) {  // wave uniform
+      SolvePgsA(c, f, rc.rows(), zsd, cost, at, al);
+    } else {
+      SolvePgs(c, f, rc.rows(), zsd, cost, at, al);
+    }
     static_for<0, kNT>([&](auto jc) { s.wt[decltype(jc)::value] = commit ? at[decltype(jc)::value] : s.wt[decltype(jc)::value]; });
     static_for<0, kNS>([&](auto sc) { s.wl[decltype(sc)::value] = Sel(commit, al[decltype(sc)::value], s.wl[decltype(sc)::value]); });
     return rc;

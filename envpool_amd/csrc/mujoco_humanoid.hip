@@ -300,6 +300,7 @@ class HumanoidPool : public Pool {
     task_.contact_cost_weight = cfg.Get("contact_cost_weight", 5e-7);
     task_.contact_cost_max = cfg.Get("contact_cost_max", 10.0);
     task_.dt = task_.frame_skip * kHumanoidModelConst.timestep;
+    task_.debug = (int)cfg.Get("hum_debug", 0);
     // "hum_layout": 1 (default) one env per lane quad (mj_hum4.hip.h), 0 one env per lane with
     // the HBM workspace (mj_tree.hip.h; kept for A/B runs)
     quad_ = cfg.Get("hum_layout", 1) != 0;

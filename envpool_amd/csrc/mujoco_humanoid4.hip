@@ -9,8 +9,9 @@
 //   HumanoidStandupEnvBase::{...}         envpool/mujoco/gym/humanoid_standup.h:119-240
 //
 // A 64-thread block is one wavefront = 16 envs; lane l of a quad owns limb l (right leg, left
-// leg, right arm, left arm).  LDS per wave: the per-limb constant table (3.5 KB) and the envs'
-// geoms (13 KB).  HBM per wave: the constraint rows (y = L^-T J', 9 slots per lane and row:
+// leg, right arm, left arm).  LDS per wave: the per-limb constant table (3.5 KB), the envs'
+// geoms + trunk cdof (20 KB), sharing their block with the dual problem of the PGS solve (A + R,
+// b, f for <= 16 rows: 23 KB), and the trunk block of the L'DL factor (7 KB).  HBM per wave: the constraint rows (y = L^-T J', 9 slots per lane and row:
 // the lane's four limb entries, its share of the nine trunk entries and of the row's five
 // scalars -- every lane reads back only what it wrote itself, the rest of the quad's values
 // arrive by DPP broadcast) and the compact contact records.  What persists between steps is
@@ -35,10 +36,18 @@ struct StandupMP {
 constexpr int kBlock = 64, kEnvsPerBlock = 16;
 // rows: 17 limits + 4 x 29 floor contacts + 109 pairs; contacts: 29 + 109
 constexpr int kMaxRows = 17 + 4 * 29 + 128, kMaxCon = 29 + 128;
-constexpr int kRowSlots = 9, kRecSlots = 2;
-constexpr int kWsSlots = kMaxRows * kRowSlots + kMaxCon * kRecSlots;  // per lane
-constexpr int kLdsTab = 0, kLdsGeo = H::kNLC * 4;
-constexpr int kLdsElems = kLdsGeo + 102 * 16;
+constexpr int kRowSlots = 12, kRecSlots = 2;
+constexpr int kRkSlots = 10 + 3 * H::kNT + 4 * H::kNS;  // RK4 bookkeeping of the running mj_step
+constexpr int kWsRk = kMaxRows * kRowSlots + kMaxCon * kRecSlots;
+constexpr int kWsSlots = kWsRk + kRkSlots;  // per lane
+// LDS of a wave, in doubles.  Env-level slots are [slot][quad].  The geoms + trunk cdof (Position
+// .. MakeRows) and the dual problem of the PGS solve (SolvePgsA, after MakeRows) share region U.
+constexpr int kShSlots = 16 * 17 / 2 + 3 * 16;  // Hum4::kShSlots: A + R (packed), b, f, 1 / (A_rr + R_r)
+constexpr int kGeoSlots = 102, kTcdSlots = 54, kLttSlots = 45 + 9;
+constexpr int kUSlots = kShSlots > kGeoSlots + kTcdSlots ? kShSlots : kGeoSlots + kTcdSlots;
+constexpr int kLdsTab = 0, kLdsU = H::kNLC * 4, kLdsGeo = kLdsU, kLdsTcd = kLdsU + kGeoSlots * 16, kLdsSh = kLdsU;
+constexpr int kLdsLtt = kLdsU + kUSlots * 16;
+constexpr int kLdsElems = kLdsLtt + kLttSlots * 16;  // 34 KB
 
 template <int K>
 __device__ __forceinline__ double Bcast(double x) {  // lane K of the quad
@@ -75,37 +84,31 @@ struct DevCtx {
     *pos = {GeoGet(s), GeoGet(s + 1), GeoGet(s + 2)};
     *axis = {GeoGet(s + 3), GeoGet(s + 4), GeoGet(s + 5)};
   }
+  __device__ void TcdPut(int i, double v) { lds[kLdsTcd + i * 16 + quad] = v; }
+  __device__ double TcdGet(int i) const { return lds[kLdsTcd + i * 16 + quad]; }
+  __device__ void LttPut(int i, double v) { lds[kLdsLtt + i * 16 + quad] = v; }
+  __device__ double LttGet(int i) const { return lds[kLdsLtt + i * 16 + quad]; }
+  __device__ void DtPut(int i, double v) { lds[kLdsLtt + (45 + i) * 16 + quad] = v; }
+  __device__ double DtGet(int i) const { return lds[kLdsLtt + (45 + i) * 16 + quad]; }
+  // the env's shared block [slot][quad] (PGS on the dual matrix)
+  __device__ void ShPut(int slot, double v) { lds[kLdsSh + slot * 16 + quad] = v; }
+  __device__ double ShGet(int slot) const { return lds[kLdsSh + slot * 16 + quad]; }
+  __device__ double ShGetLane(int base, int k) const { return ShGet(base + 4 * k + l); }
+  __device__ double ArGetLane(int base, int r, int k) const {
+    const int cc = 4 * k + l;
+    return ShGet(base + (r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r));
+  }
   __device__ double& Ws(int slot) const { return ws[(size_t)slot * 64 + lane]; }
-  // row r: slots 0..2 trunk entries j with (j & 3) == l (j = 4 slot + l), 3..6 the limb entries,
-  // 7..8 the scalars k with (k & 3) == l
-  __device__ void RowPut(int r, const double* yt, const double* yl) {
-    const int b = r * kRowSlots;
-    Ws(b) = l == 0 ? yt[0] : (l == 1 ? yt[1] : (l == 2 ? yt[2] : yt[3]));
-    Ws(b + 1) = l == 0 ? yt[4] : (l == 1 ? yt[5] : (l == 2 ? yt[6] : yt[7]));
-    if (l == 0) Ws(b + 2) = yt[8];
-    mj::static_for<0, H::kNS>([&](auto sc) { Ws(b + 3 + decltype(sc)::value) = yl[decltype(sc)::value]; });
+  // row r: slots 0..6 the lane's share of y (Hum4::kND), 7..11 the row's five scalars (every lane
+  // keeps its own copy: a lane only ever reads back what it wrote itself)
+  __device__ void RowPut(int r, const double* yd) {
+    mj::static_for<0, 7>([&](auto ic) { Ws(r * kRowSlots + decltype(ic)::value) = yd[decltype(ic)::value]; });
   }
-  __device__ void RowGet(int r, double* yt, double* yl) const {
-    const int b = r * kRowSlots;
-    const double o0 = Ws(b), o1 = Ws(b + 1), o2 = Ws(b + 2);
-    mj::static_for<0, H::kNS>([&](auto sc) { yl[decltype(sc)::value] = Ws(b + 3 + decltype(sc)::value); });
-    yt[0] = Bcast<0>(o0);
-    yt[1] = Bcast<1>(o0);
-    yt[2] = Bcast<2>(o0);
-    yt[3] = Bcast<3>(o0);
-    yt[4] = Bcast<0>(o1);
-    yt[5] = Bcast<1>(o1);
-    yt[6] = Bcast<2>(o1);
-    yt[7] = Bcast<3>(o1);
-    yt[8] = Bcast<0>(o2);
+  __device__ void RowGet(int r, double* yd) const {
+    mj::static_for<0, 7>([&](auto ic) { yd[decltype(ic)::value] = Ws(r * kRowSlots + decltype(ic)::value); });
   }
-  __device__ void RsPut(int r, int k, double v) {
-    if ((k & 3) == l) Ws(r * kRowSlots + 7 + (k >> 2)) = v;
-  }
-  __device__ double RsGet(int r, int k) const {
-    const double own = Ws(r * kRowSlots + 7 + (k >> 2));
-    return mj::hum4::BcastQ(own, k & 3);
-  }
+  __device__ void RsPut(int r, int k, double v) { Ws(r * kRowSlots + 7 + k) = v; }
+  __device__ double RsGet(int r, int k) const { return Ws(r * kRowSlots + 7 + k); }
   __device__ void RecPut(int t, int k, double v) {
     if ((k & 3) == l) Ws(kMaxRows * kRowSlots + t * kRecSlots + (k >> 2)) = v;
   }
@@ -131,7 +134,9 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
   static constexpr H::LimbTab kTab = H::MakeLimbTab(MP::kM);
   __shared__ double lds[kLdsElems];
   const int lane = threadIdx.x, l = lane & 3, quad = lane >> 2;
+  static_assert(kShSlots == Eng::kShSlots, "LDS layout");
   for (int i = lane; i < H::kNLC * 4; i += kBlock) lds[kLdsTab + i] = kTab.c[i >> 2][i & 3];
+  for (int i = lane; i < kUSlots * 16; i += kBlock) lds[kLdsU + i] = 0.0;  // stale A entries must be finite
   const int row = blockIdx.x * kEnvsPerBlock + quad;
   const bool valid = row < a.k;
   const int e = valid ? (a.ids ? a.ids[row] - a.id_offset : row) : 0;
@@ -211,13 +216,105 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
   const int nfwd = reset ? 1 : 4 * task.frame_skip;
   const int nmax = mj::WaveAny(!reset) ? 4 * task.frame_skip : 1;
   H::Fwd<double> f;
-  typename Eng::Rk rk;
   typename Eng::RowCount rows{0, 0, 0};
   double at[H::kNT], al[H::kNS];
+  // WriteState, humanoid.h:225-268: qpos[skip:] qvel cinert cvel qfrc_actuator cfrc_ext
+  const int b0 = task.exclude_worldbody ? 1 : 0;
+  const int a0 = task.exclude_root_actuator ? 6 : 0;
+  const int nb = m.nbody - b0;
+  const int nobs = (m.nq - task.obs_skip) + m.nv + 22 * nb + (m.nv - a0);
+  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
+  double* o_q = obs - task.obs_skip;
+  double* o_v = obs + (m.nq - task.obs_skip);
+  double* o_ci = o_v + m.nv - 10 * b0;   // + 10 * body
+  double* o_cv = o_v + m.nv + 10 * nb - 6 * b0;  // + 6 * body
+  double* o_act = o_v + m.nv + 16 * nb - a0;     // + dof
+  double* o_ce = o_v + m.nv + 16 * nb + (m.nv - a0) - 6 * b0;  // + 6 * body
+  auto put6 = [](double* p, const H::Sp6<double>& x, bool on) {
+    p[0] = on ? x.a.x : 0.0;
+    p[1] = on ? x.a.y : 0.0;
+    p[2] = on ? x.a.z : 0.0;
+    p[3] = on ? x.l.x : 0.0;
+    p[4] = on ? x.l.y : 0.0;
+    p[5] = on ? x.l.z : 0.0;
+  };
+  const int bodyA = l == 0 ? 4 : (l == 1 ? 7 : (l == 2 ? 10 : 12));
+  const int nlb = l < 2 ? 3 : 2;
+  double mx = 0.0, my = 0.0;
   for (int it = 0; it < nmax; ++it) {
     const bool live = it < nfwd;
-    rows = Eng::Forward(c, s, f, live, at, al);
+    const bool last = it == nmax - 1;
+    // cinert / cvel / qfrc_actuator of the LAST forward evaluation go straight to the observation
+    // (an env that is only kept busy re-evaluates the same state: its values do not change)
+    rows = Eng::Forward(c, s, f, live, at, al, task.debug, [&](const H::Fwd<double>& ff) {
+      if (!last) return;  // wave uniform
+      mx = ff.com.x;  // GetMassCenter, humanoid.h:212-223
+      my = ff.com.y;
+      if (l == 0) {
+        if (b0 == 0) {
+          for (int i = 0; i < 10; ++i) o_ci[i] = 0.0;
+          for (int i = 0; i < 6; ++i) o_cv[i] = 0.0;
+        }
+        mj::static_for<1, H::kNTB + 1>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          mj::static_for<0, 10>([&](auto ic) { o_ci[10 * b + decltype(ic)::value] = ff.tci[b - 1].v[decltype(ic)::value]; });
+          put6(o_cv + 6 * b, ff.tcv[b - 1], true);
+        });
+        mj::static_for<0, H::kNT>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if (j >= a0) o_act[j] = ff.act_t[j];
+        });
+      }
+      mj::static_for<0, H::kNS>([&](auto sc) {
+        constexpr int k = decltype(sc)::value;
+        if (dof[k] >= 0) o_act[dof[k]] = ff.act_l[k];
+      });
+      mj::static_for<0, 3>([&](auto wc) {
+        constexpr int w = decltype(wc)::value;
+        if (w < nlb) {
+          const int b = bodyA + w;
+          mj::static_for<0, 10>([&](auto ic) { o_ci[10 * b + decltype(ic)::value] = ff.lci[w].v[decltype(ic)::value]; });
+          put6(o_cv + 6 * b, ff.lcv[w > 1 ? 1 : w], true);
+        }
+      });
+    });
+    // RK4 bookkeeping lives in the wave's HBM block between the stages (53 numbers per lane)
+    typename Eng::Rk rk;
+    if ((it & 3) != 0) {
+      int k = kWsRk;
+      mj::static_for<0, 10>([&](auto ic) { rk.x0q[decltype(ic)::value] = c.Ws(k++); });
+      mj::static_for<0, H::kNT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        rk.x0v[j] = c.Ws(k++);
+        rk.accq[j] = c.Ws(k++);
+        rk.accv[j] = c.Ws(k++);
+      });
+      mj::static_for<0, H::kNS>([&](auto sc) {
+        constexpr int j = decltype(sc)::value;
+        rk.x0ql[j] = c.Ws(k++);
+        rk.x0vl[j] = c.Ws(k++);
+        rk.accql[j] = c.Ws(k++);
+        rk.accvl[j] = c.Ws(k++);
+      });
+    }
     Eng::RkAdvance(s, rk, it & 3, live && !reset, at, al);
+    if ((it & 3) != 3) {
+      int k = kWsRk;
+      mj::static_for<0, 10>([&](auto ic) { c.Ws(k++) = rk.x0q[decltype(ic)::value]; });
+      mj::static_for<0, H::kNT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        c.Ws(k++) = rk.x0v[j];
+        c.Ws(k++) = rk.accq[j];
+        c.Ws(k++) = rk.accv[j];
+      });
+      mj::static_for<0, H::kNS>([&](auto sc) {
+        constexpr int j = decltype(sc)::value;
+        c.Ws(k++) = rk.x0ql[j];
+        c.Ws(k++) = rk.x0vl[j];
+        c.Ws(k++) = rk.accql[j];
+        c.Ws(k++) = rk.accvl[j];
+      });
+    }
   }
   // mj_rnePostConstraint after the last mj_step (mujoco_env.h:145-147)
   const bool wrench = task.post_constraint != 0;
@@ -228,7 +325,6 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
     mj::static_for<0, H::kNTB + 1>([&](auto bc) { ext_t[decltype(bc)::value] = {{0, 0, 0}, {0, 0, 0}}; });
     mj::static_for<0, 3>([&](auto bc) { ext_l[decltype(bc)::value] = {{0, 0, 0}, {0, 0, 0}}; });
   }
-  const double mx = f.com.x, my = f.com.y;  // GetMassCenter, humanoid.h:212-223
   // what persists
   auto put = [&](int slot, double v) { dev.state[(size_t)slot * n + e] = v; };
   if (l == 0) {
@@ -296,46 +392,16 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
   } else if (kStandup) {
     info[2] = task.healthy_reward;  // WriteState(0, 0, 0, 0): reward_alive is the constant
   }
-  // WriteState, humanoid.h:225-268: qpos[skip:] qvel cinert cvel qfrc_actuator cfrc_ext
-  const int b0 = task.exclude_worldbody ? 1 : 0;
-  const int a0 = task.exclude_root_actuator ? 6 : 0;
-  const int nb = m.nbody - b0;
-  const int nobs = (m.nq - task.obs_skip) + m.nv + 22 * nb + (m.nv - a0);
-  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
-  double* o_q = obs - task.obs_skip;
-  double* o_v = obs + (m.nq - task.obs_skip);
-  double* o_ci = o_v + m.nv - 10 * b0;   // + 10 * body
-  double* o_cv = o_v + m.nv + 10 * nb - 6 * b0;  // + 6 * body
-  double* o_act = o_v + m.nv + 16 * nb - a0;     // + dof
-  double* o_ce = o_v + m.nv + 16 * nb + (m.nv - a0) - 6 * b0;  // + 6 * body
-  auto put6 = [](double* p, const H::Sp6<double>& x, bool on) {
-    p[0] = on ? x.a.x : 0.0;
-    p[1] = on ? x.a.y : 0.0;
-    p[2] = on ? x.a.z : 0.0;
-    p[3] = on ? x.l.x : 0.0;
-    p[4] = on ? x.l.y : 0.0;
-    p[5] = on ? x.l.z : 0.0;
-  };
   if (l == 0) {
     mj::static_for<0, 10>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       if (i >= task.obs_skip) o_q[i] = s.qt[i];
     });
     mj::static_for<0, H::kNT>([&](auto jc) { o_v[decltype(jc)::value] = s.vt[decltype(jc)::value]; });
-    if (b0 == 0) {
-      for (int i = 0; i < 10; ++i) o_ci[i] = 0.0;
-      for (int i = 0; i < 6; ++i) o_cv[i] = 0.0;
-      put6(o_ce, ext_t[0], have_cfrc);
-    }
+    if (b0 == 0) put6(o_ce, ext_t[0], have_cfrc);
     mj::static_for<1, H::kNTB + 1>([&](auto bc) {
       constexpr int b = decltype(bc)::value;
-      mj::static_for<0, 10>([&](auto ic) { o_ci[10 * b + decltype(ic)::value] = f.tci[b - 1].v[decltype(ic)::value]; });
-      put6(o_cv + 6 * b, f.tcv[b - 1], true);
       put6(o_ce + 6 * b, ext_t[b], have_cfrc);
-    });
-    mj::static_for<0, H::kNT>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      if (j >= a0) o_act[j] = f.act_t[j];
     });
     constexpr int ninfo = kStandup ? 4 : 9;
     for (int i = 0; i < ninfo; ++i) ((double*)out.p[kKeyEnv0 + 1 + i])[row] = info[i];
@@ -348,19 +414,11 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
     if (dof[k] >= 0) {
       o_q[1 + dof[k]] = s.ql[k];
       o_v[dof[k]] = s.vl[k];
-      o_act[dof[k]] = f.act_l[k];
     }
   });
-  const int bodyA = l == 0 ? 4 : (l == 1 ? 7 : (l == 2 ? 10 : 12));
-  const int nlb = l < 2 ? 3 : 2;
   mj::static_for<0, 3>([&](auto wc) {
     constexpr int w = decltype(wc)::value;
-    if (w < nlb) {
-      const int b = bodyA + w;
-      mj::static_for<0, 10>([&](auto ic) { o_ci[10 * b + decltype(ic)::value] = f.lci[w].v[decltype(ic)::value]; });
-      put6(o_cv + 6 * b, f.lcv[w > 1 ? 1 : w], true);
-      put6(o_ce + 6 * b, ext_l[w], have_cfrc);
-    }
+    if (w < nlb) put6(o_ce + 6 * (bodyA + w), ext_l[w], have_cfrc);
   });
 }
 

@@ -19,6 +19,7 @@ struct HumTask {
   double ctrl_cost_weight, forward_reward_weight, healthy_reward;
   double healthy_z_min, healthy_z_max, reset_noise_scale, dt;
   double contact_cost_weight, contact_cost_max;
+  int debug;  // timing builds only ("hum_debug"): stages of the quad kernel switched off
 };
 
 

@@ -20,17 +20,37 @@ struct HostCtx {
   using E = double;
   static constexpr H::LimbTab kTab = H::MakeLimbTab(MP::kM);
   double geo[6 * 18];
-  double rows_t[192][9];
-  Q4<double> rows_l[192][4];
-  double rs[192][5];
+  Q4<double> rows[320][7];
+  double rs[320][5];
   double rec[160][8];
-  void RowPut(int r, const double* yt, const V* yl) {
-    for (int j = 0; j < 9; ++j) rows_t[r][j] = yt[j];
-    for (int s = 0; s < 4; ++s) rows_l[r][s] = yl[s];
+  void RowPut(int r, const V* yd) {
+    for (int i = 0; i < 7; ++i) rows[r][i] = yd[i];
   }
-  void RowGet(int r, double* yt, V* yl) const {
-    for (int j = 0; j < 9; ++j) yt[j] = rows_t[r][j];
-    for (int s = 0; s < 4; ++s) yl[s] = rows_l[r][s];
+  void RowGet(int r, V* yd) const {
+    for (int i = 0; i < 7; ++i) yd[i] = rows[r][i];
+  }
+  double tcd[54], ltt[45], dt[9];
+  void TcdPut(int i, double v) { tcd[i] = v; }
+  double TcdGet(int i) const { return tcd[i]; }
+  void LttPut(int i, double v) { ltt[i] = v; }
+  double LttGet(int i) const { return ltt[i]; }
+  void DtPut(int i, double v) { dt[i] = v; }
+  double DtGet(int i) const { return dt[i]; }
+  double sh[256];
+  void ShPut(int slot, double v) { sh[slot] = v; }
+  double ShGet(int slot) const { return sh[slot]; }
+  V ShGetLane(int base, int k) const {
+    V r;
+    for (int l = 0; l < 4; ++l) r.v[l] = sh[base + 4 * k + l];
+    return r;
+  }
+  V ArGetLane(int base, int r, int k) const {
+    V x;
+    for (int l = 0; l < 4; ++l) {
+      const int cc = 4 * k + l;
+      x.v[l] = sh[base + (r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r)];
+    }
+    return x;
   }
   void RsPut(int r, int k, double v) { rs[r][k] = v; }
   double RsGet(int r, int k) const { return rs[r][k]; }
@@ -91,7 +111,7 @@ template <class MP>
 static void Smooth(const double* q, const double* v, const double* ctrl, double* out) {
   using C = HostCtx<MP>;
   using Eng = H::Hum4<MP, C>;
-  C c{};
+  static C c;
   H::Fwd<Q4<double>> f;
   double qt[10], vt[9], ut[3];
   Q4<double> ql[4], vl[4], ul[4];
@@ -192,10 +212,10 @@ static void Step4(const double* q, const double* v, const double* warm, const do
   double at[9];
   Q4<double> al[4];
   typename Eng::RowCount rc{0, 0, 0};
-  if (nsub == 0) rc = Eng::Forward(c, s, f, true, at, al);
+  if (nsub == 0) rc = Eng::Forward(c, s, f, true, at, al, 0, [](const H::Fwd<Q4<double>>&) {});
   for (int k = 0; k < nsub; ++k) {
     for (int stage = 0; stage < 4; ++stage) {
-      rc = Eng::Forward(c, s, f, true, at, al);
+      rc = Eng::Forward(c, s, f, true, at, al, 0, [](const H::Fwd<Q4<double>>&) {});
       Eng::RkAdvance(s, rk, stage, true, at, al);
     }
   }
