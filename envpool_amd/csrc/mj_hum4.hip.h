@@ -60,7 +60,7 @@ using mj::Sum4;
 constexpr int kNT = 9;        // trunk dofs 0..8 (free joint 0..5, abdomen z, y, x)
 constexpr int kNS = 4;        // limb dof slots of a lane: A0 A1 A2 (first limb body), B (second)
 constexpr int kNLimb = 4;
-constexpr int kRegRows = 16;  // rows whose A + R fits the LDS block
+constexpr int kRegRows = 12;  // rows (per env) that the register-resident PGS holds
 constexpr int kNTB = 3;       // trunk bodies 1, 2, 3
 
 // ---- the model, re-indexed by limb ----------------------------------------------------------
@@ -347,6 +347,20 @@ EPA_HD void LimbUnit(double* xl, int limb, int slot, double val) {
   for (int s = 0; s < kNS; ++s) xl[s] = (mine && s == slot) ? val : 0.0;
 }
 
+// lane K (compile time) of the quad as an env-level value
+template <int K, typename T>
+inline T BcastQS(const Q4<T>& x) {
+  return x.v[K];
+}
+template <int K>
+EPA_HD double BcastQS(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return DppMov<K * 0x55>(x);  // quad_perm:[K,K,K,K]
+#else
+  return x;
+#endif
+}
+
 template <typename X>
 EPA_HD X AbsX(X x) {
   return Sel(x < X(0), -x, x);
@@ -472,7 +486,7 @@ struct Fwd {
   V Llt[kNS][kNT], Lll[kNLL], dinv_l[kNS];
   E act_t[kNT];  // qfrc_actuator
   V act_l[kNS];
-  E accs_t[kNT];  // qacc_smooth
+  E accs_t[kNT];  // qfrc_smooth, then qacc_smooth
   V accs_l[kNS];
 };
 
@@ -676,6 +690,12 @@ struct Hum4 {
       static_for<0, 6>([&](auto kc) { I[decltype(kc)::value] = c.LC(kLcCin + decltype(kc)::value); });
       f.lci[2] = CinertOf<V>(I, c.LC(kLcCmass), RB, l_xipos[2] - comv);
     }
+  }
+
+  // ---- mj_crb + mj_factorM (after the velocity pass: cinert dies here, M is born here) --------
+  static EPA_HD void MassFactor(Ctx& c, Fwd<V>& f) {
+    constexpr TreeModel m = MP::kM;
+    const BV leg = IsLeg(c);
     // mj_crb: composite inertias, then M
     const In10<V> cB = AddIn(f.lci[1], f.lci[2]), cA = AddIn(f.lci[0], cB);
     In10<E> legs, arms;
@@ -925,10 +945,13 @@ struct Hum4 {
       f.act_l[s] = act;
       xl[s] = x + act;
     });
-    HalfSolve(c, f, xt, xl);
-    BackSolve(c, f, xt, xl);
     static_for<0, kNT>([&](auto ic) { f.accs_t[decltype(ic)::value] = xt[decltype(ic)::value]; });
     static_for<0, kNS>([&](auto sc) { f.accs_l[decltype(sc)::value] = xl[decltype(sc)::value]; });
+  }
+  // qacc_smooth = M^-1 qfrc_smooth (in place in f.accs)
+  static EPA_HD void SmoothAcc(Ctx& c, Fwd<V>& f) {
+    HalfSolve(c, f, f.accs_t, f.accs_l);
+    BackSolve(c, f, f.accs_t, f.accs_l);
   }
   // ---- static candidate tables (indexed at run time by an env- or lane-level group number) -----
   // groups: limits 0..16 (dof 6 + g), floor spheres 17..45, geom pairs 46..154 (TreeModel order)
@@ -1143,10 +1166,13 @@ struct Hum4 {
     });
     static_for<0, kNS>([&](auto sc) { xl[decltype(sc)::value] = xd[3 + decltype(sc)::value]; });
   }
-  static EPA_HD E DotD(const V* a, const V* b) {
-    V p = a[0] * b[0];
-    static_for<1, kND>([&](auto ic) { p += a[decltype(ic)::value] * b[decltype(ic)::value]; });
-    return SumQ(p);
+  static EPA_HD E DotD(const V* a, const V* b) {  // three short chains: this sits on the PGS critical path
+    V p0 = a[0] * b[0], p1 = a[1] * b[1], p2 = a[2] * b[2];
+    p0 += a[3] * b[3];
+    p1 += a[4] * b[4];
+    p2 += a[5] * b[5];
+    p0 += a[6] * b[6];
+    return SumQ((p0 + p1) + p2);
   }
   // 1 / D in distributed form
   static EPA_HD void DinvD(Ctx& c, const Fwd<V>& f, V* dd) {
@@ -1159,7 +1185,7 @@ struct Hum4 {
   // RecPut / RecGet(t, k) the contact records (position 3, normal 3, bodies 2) in compact order.
   enum { kRsF = 0, kRsArr = 1, kRsR = 2, kRsB = 3, kRsAinv = 4 };
   struct RowCount {
-    int nl, nf, np;  // compact limit rows, floor contacts (4 rows each), pair rows: wave uniform
+    int nl, nf, np;  // THIS ENV's limit rows, floor contacts (4 rows each), pair rows (env level)
     EPA_HD int rows() const { return nl + 4 * nf + np; }
   };
   static EPA_HD unsigned long long RangeBits(int wi, int lo, int hi) {
@@ -1174,6 +1200,8 @@ struct Hum4 {
   static EPA_HD RowCount MakeRows(Ctx& c, const Fwd<V>& f, const EMask& act, const E* qt, const V* ql,
                                   const E* vt, const V* vl, const E* wt, const V* wl, V* zsd, E* cost_out) {
     constexpr TreeModel m = MP::kM;
+    // Rows and contact records are compact PER ENV: env e's t-th active group goes to its own
+    // next slot, so a wave's solve works on max-over-envs rows, not on a per-phase padded union.
     RowCount rc{0, 0, 0};
     E cost = E(0);
     static_for<0, kND>([&](auto ic) { zsd[decltype(ic)::value] = V(0); });
@@ -1182,7 +1210,6 @@ struct Hum4 {
       const int glo = phase == 0 ? 0 : (phase == 1 ? kG0Floor : kG0Pair);
       const int ghi = phase == 0 ? kNLimit : (phase == 1 ? kG0Pair : kNGroup);
       const int nsub = phase == 1 ? 4 : 1;
-      int count = 0;
       for (int wi = 0; wi < 3; ++wi) {
         const unsigned long long bits = RangeBits(wi, glo, ghi);
         if (bits == 0ull) continue;
@@ -1229,8 +1256,8 @@ struct Hum4 {
           E R = MaxX(E(tree::kMinVal), (E(1) - imp) * diag / imp);
           if (phase == 1) R = R * E(2.0 * m.floor_mu * m.floor_mu);
           const E kimp = E(m.sol_K) * imp * pos;
-          if (phase != 0) {  // compact contact record for mj_rnePostConstraint
-            const int t = phase == 1 ? count : kNFloor + count;
+          if (phase != 0 && AnyWave(on)) {  // compact contact record for mj_rnePostConstraint
+            const int t = rc.nf + rc.np;  // this env's next record
             c.RecPut(t, 0, cpos.x);
             c.RecPut(t, 1, cpos.y);
             c.RecPut(t, 2, cpos.z);
@@ -1239,7 +1266,7 @@ struct Hum4 {
             c.RecPut(t, 5, n.z);
             c.RecPut(t, 6, E(b1));
             c.RecPut(t, 7, E(b2));
-          }
+          }  // (an env without this group rewrites its next record later, or never reads it)
           for (int k = 0; k < nsub; ++k) {
             // row direction: n, or the pyramid edge n +- mu t (floor frame: n = z, t1 = y, t2 = -x)
             Vec3<E> dir = n;
@@ -1249,7 +1276,7 @@ struct Hum4 {
                            : (k == 2 ? Vec3<E>{-mu, E(0), E(1)} : Vec3<E>{mu, E(0), E(1)}));
             }
             const Vec3<E> mdir = Cross(off, dir);
-            const int r = row + k;
+            const int r = row + k;  // env level
             E Jt[kNT];
             V Jl[kNS];
             if (phase == 0) {
@@ -1300,40 +1327,29 @@ struct Hum4 {
             const E quad = HalfSolve(c, f, Jt, Jl);  // J -> y in place
             V yd[kND];
             Distribute(Jt, Jl, yd);
-            c.RowPut(r, yd);
-            const E arr = Rr + quad;  // 0 for an inert row
-            c.RsPut(r, kRsF, fw);
-            c.RsPut(r, kRsArr, arr);
-            c.RsPut(r, kRsR, Rr);
-            c.RsPut(r, kRsB, b);
-            c.RsPut(r, kRsAinv, arr > E(0) ? E(1) / arr : E(0));
+            const E arr = Rr + quad;
+            if (on) {  // (the one lane-divergent branch of this stage: a handful of stores)
+              c.RowPut(r, yd);
+              c.RsPut(r, kRsF, fw);
+              c.RsPut(r, kRsArr, arr);
+              c.RsPut(r, kRsR, Rr);
+              c.RsPut(r, kRsB, b);
+              c.RsPut(r, kRsAinv, E(1) / arr);
+            }
             cost += fw * (E(0.5) * Rr * fw + b);
             static_for<0, kND>([&](auto ic) { zsd[decltype(ic)::value] += V(fw) * yd[decltype(ic)::value]; });
           }
-          row += nsub;
-          ++count;
+          row += on ? nsub : 0;
+          if (phase == 0) rc.nl += on ? 1 : 0;
+          if (phase == 1) rc.nf += on ? 1 : 0;
+          if (phase == 2) rc.np += on ? 1 : 0;
         }
       }
-      if (phase == 0) rc.nl = count;
-      if (phase == 1) rc.nf = count;
-      if (phase == 2) rc.np = count;
     }
     *cost_out = cost;
     return rc;
   }
 
-  struct RowBuf {
-    V yd[kND];
-    E f, arr, R, b, ainv;
-  };
-  static EPA_HD void LoadRowBuf(Ctx& c, int r, RowBuf& t) {
-    c.RowGet(r, t.yd);
-    t.f = c.RsGet(r, kRsF);
-    t.arr = c.RsGet(r, kRsArr);
-    t.R = c.RsGet(r, kRsR);
-    t.b = c.RsGet(r, kRsB);
-    t.ainv = c.RsGet(r, kRsAinv);
-  }
   // the warm start is kept only if its dual cost 1/2 f'(A+R)f + f'b is below the cost of f = 0
   static EPA_HD bool ColdStart(const V* zsd, const V* dd, E cost) {
     V q = V(0);
@@ -1351,8 +1367,37 @@ struct Hum4 {
   }
   // ---- mj_fwdConstraint with mj_solPGS, y-space streaming form ---------------------------------
   //   z = sum_c f_c y_c / D;  res_r = b_r + R_r f_r + y_r . z  (= b_r + sum_c (A + R)_rc f_c)
-  static EPA_HD void SolvePgs(Ctx& c, const Fwd<V>& f, int nrow, const V* zsd, E cost, E* at, V* al) {
+  // A row visit is a ~200-cycle dependent chain and an HBM round trip is ten times that, so the
+  // rows' constant part (y, A_rr + R_r, R_r, b_r, 1 / (A_rr + R_r)) streams through a ring of
+  // kRing register buffers, each loaded kRing visits before it is used -- across sweep
+  // boundaries too -- while the forces f, the only thing a visit changes, stay in the env's
+  // shared block (Ctx::ShGet / ShPut: the LDS that holds A in SolvePgsA).
+  static constexpr int kRing = 8;
+  // max over the wave of an env-level count < 256
+  static EPA_HD int WaveMax(int x) {
+    int mx = 0;
+    for (int b = 7; b >= 0; --b) {
+      const int cand = mx | (1 << b);
+      if (AnyWave(x >= cand)) mx = cand;
+    }
+    return mx;
+  }
+  struct RowConst {
+    V yd[kND];
+    E arr, R, b, ainv;
+  };
+  static EPA_HD void LoadRowConst(Ctx& c, int r, RowConst& t) {
+    c.RowGet(r, t.yd);
+    t.arr = c.RsGet(r, kRsArr);
+    t.R = c.RsGet(r, kRsR);
+    t.b = c.RsGet(r, kRsB);
+    t.ainv = c.RsGet(r, kRsAinv);
+  }
+  // nrow_e: this env's rows (0 .. nrow_e - 1, compact); the wave walks max-over-envs rows, an env
+  // treats the rows beyond its own as absent (its slots there hold stale data)
+  static EPA_HD void SolvePgs(Ctx& c, const Fwd<V>& f, int nrow_e, const V* zsd, E cost, E* at, V* al, int max_iter) {
     constexpr TreeModel m = MP::kM;
+    const int nrow = WaveMax(nrow_e);
     V dd[kND], zd[kND];
     DinvD(c, f, dd);
     const bool cold = ColdStart(zsd, dd, cost);
@@ -1360,132 +1405,169 @@ struct Hum4 {
       constexpr int i = decltype(ic)::value;
       zd[i] = Sel(cold, V(0), zsd[i] * dd[i]);
     });
-    if (AnyWave(cold)) {
-      for (int r = 0; r < nrow; ++r) {
-        if (cold) c.RsPut(r, kRsF, E(0));
-      }
-    }
+    // (rows beyond the shared block's capacity keep their force in HBM: never seen in practice)
+    auto fget = [&](int r) { return r < kFSlots ? c.ShGet(r) : c.RsGet(r, kRsF); };
+    auto fput = [&](int r, E v) {
+      if (r < kFSlots) c.ShPut(r, v);
+      else c.RsPut(r, kRsF, v);
+    };
+    for (int r = 0; r < nrow; ++r) fput(r, (cold || r >= nrow_e) ? E(0) : c.RsGet(r, kRsF));
     const E scale = E(1.0 / (m.meaninertia * 23.0));
-    bool done = false;
-    for (int iter = 0; iter < m.iterations; ++iter) {
-      E improvement = E(0);
-      // one row of lookahead: the next row's loads are in flight while this one is visited
-      RowBuf nx;
-      LoadRowBuf(c, 0, nx);
-      for (int r = 0; r < nrow; ++r) {
-        const RowBuf cu = nx;
-        LoadRowBuf(c, r + 1 < nrow ? r + 1 : 0, nx);
-        const E res = cu.b + cu.R * cu.f + DotD(cu.yd, zd);
-        const E fn = MaxX(E(0), cu.f - res * cu.ainv);
-        E delta = fn - cu.f;
-        const E change = E(0.5) * delta * delta * cu.arr + delta * res;
-        const bool keep = !done && !(change > E(1e-10));
-        delta = keep ? delta : E(0);
-        c.RsPut(r, kRsF, cu.f + delta);
-        if (nrow == 1) nx.f = cu.f + delta;  // the lookahead read the row that was just updated
-        static_for<0, kND>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          zd[i] += V(delta) * cu.yd[i] * dd[i];
-        });
-        improvement -= keep ? change : E(0);
-      }
-      done = done || improvement * scale < E(1e-8);
-      if (!AnyWave(!done)) break;
+    bool done = nrow_e == 0;
+    E improvement = E(0);
+    RowConst ring[kRing];
+    int pre = 0;  // next row to prefetch
+    static_for<0, kRing>([&](auto bc) {
+      LoadRowConst(c, pre, ring[decltype(bc)::value]);
+      pre = pre + 1 < nrow ? pre + 1 : 0;
+    });
+    int r = 0, iter = 0;
+    bool more = nrow > 0 && max_iter > 0;
+    while (more) {
+      static_for<0, kRing>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if (more) {  // wave uniform
+          RowConst cu = ring[b];
+          LoadRowConst(c, pre, ring[b]);
+          pre = pre + 1 < nrow ? pre + 1 : 0;
+          const bool valid = r < nrow_e;
+          static_for<0, kND>([&](auto ic) { cu.yd[decltype(ic)::value] = Sel(valid, cu.yd[decltype(ic)::value], V(0)); });
+          const E fr = fget(r);
+          const E res = cu.b + cu.R * fr + DotD(cu.yd, zd);
+          const E fn = MaxX(E(0), fr - res * cu.ainv);
+          E delta = fn - fr;
+          const E change = E(0.5) * delta * delta * cu.arr + delta * res;
+          const bool keep = valid && !done && !(change > E(1e-10));
+          delta = keep ? delta : E(0);
+          fput(r, fr + delta);
+          static_for<0, kND>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            zd[i] += V(delta) * cu.yd[i] * dd[i];
+          });
+          improvement -= keep ? change : E(0);
+          if (++r == nrow) {  // end of a sweep
+            r = 0;
+            done = done || improvement * scale < E(1e-8);
+            improvement = E(0);
+            more = ++iter < max_iter && AnyWave(!done);
+          }
+        }
+      });
+    }
+    for (int k = 0; k < nrow && k < kFSlots; ++k) {
+      if (k < nrow_e) c.RsPut(k, kRsF, c.ShGet(k));  // efc_force, for mj_rnePostConstraint
     }
     Finish(c, f, zd, at, al);
   }
 
-  // ---- mj_solPGS on the dual matrix, on chip ------------------------------------------------------
-  // With <= kRegRows rows A + R (packed lower triangle), b, f and 1 / (A_rr + R_r) live in the
-  // env's shared block (Ctx::ShGet / ShPut: LDS) and the sweeps touch no memory: MuJoCo's own
-  // formulation res_r = b_r + sum_c (A + R)_rc f_c.  Lane l of the quad sums the columns c = l,
-  // l + 4, ... (Ctx::ArGetLane / FGetLane), one quad reduction per row visit.
-  enum { kShA = 0, kShB = kRegRows * (kRegRows + 1) / 2, kShF = kShB + kRegRows, kShAinv = kShF + kRegRows,
-         kShSlots = kShAinv + kRegRows };
-  static EPA_HD constexpr int Tri(int r, int cc) { return r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r; }
-  static EPA_HD void SolvePgsA(Ctx& c, const Fwd<V>& f, int nrow, const V* zsd, E cost, E* at, V* al) {
+  // ---- mj_solPGS on the dual matrix, in registers ----------------------------------------------------
+  // Up to kRegRows rows per env.  A PGS row visit is ONE dependent chain (residual -> clamped force ->
+  // cost change -> accept) and a wave runs alone on its SIMD, so the chain length is the cost of a
+  // visit.  Working on  z = sum f y / D  puts a 7-term dot product, a quad reduction and an LDS
+  // round trip on it (~60 instructions, ~900 cycles measured).  Instead the rows are loaded once,
+  // A + R = Y D^-1 Y' + diag(R) is formed in registers -- lane l of the quad owns the rows r with
+  // (r & 3) == l: 3 x 12 entries -- and the residuals S_r = b_r + sum_c (A + R)_rc f_c are kept UP TO
+  // DATE: a visit reads S_r, decides, broadcasts the accepted change (DPP) and every lane adds
+  // (A + R)_{its rows, r} * change to its three residuals.  ~15 dependent operations per visit.
+  static constexpr int kFSlots = 156;  // capacity of the shared block (Ctx::ShGet / ShPut)
+  static constexpr int kOwn = kRegRows / 4;
+  static EPA_HD void SolvePgsR(Ctx& c, const Fwd<V>& f, int nrow_e, const V* zsd, E cost, E* at, V* al, int max_iter,
+                               int* stat) {
     constexpr TreeModel m = MP::kM;
     V dd[kND];
     DinvD(c, f, dd);
     const bool cold = ColdStart(zsd, dd, cost);
-    // A_rc = sum_i y_r[i] y_c[i] / D_i: four columns (scaled by 1 / D) stay in registers while the
-    // rows below them stream past, with one row of lookahead
-    for (int c0 = 0; c0 < nrow; c0 += 4) {
-      V w[4][kND];
-      static_for<0, 4>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        const int cc = c0 + k < nrow ? c0 + k : c0;
-        c.RowGet(cc, w[k]);
-        if (c0 + k < nrow) {  // wave uniform
-          c.ShPut(kShB + cc, c.RsGet(cc, kRsB));
-          c.ShPut(kShF + cc, cold ? E(0) : c.RsGet(cc, kRsF));
-          c.ShPut(kShAinv + cc, c.RsGet(cc, kRsAinv));
-          c.ShPut(kShA + Tri(cc, cc), c.RsGet(cc, kRsArr));
-        }
-      });
-      static_for<0, 4>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        // entries inside the block: row c0 + r (unscaled, r > k) . column c0 + k (scaled below)
-        V wk[kND];
-        static_for<0, kND>([&](auto ic) { wk[decltype(ic)::value] = w[k][decltype(ic)::value] * dd[decltype(ic)::value]; });
-        static_for<k + 1, 4>([&](auto rc4) {
-          constexpr int r = decltype(rc4)::value;
-          const E a = DotD(w[r], wk);
-          if (c0 + r < nrow) c.ShPut(kShA + Tri(c0 + r, c0 + k), a);
-        });
-        static_for<0, kND>([&](auto ic) { w[k][decltype(ic)::value] = wk[decltype(ic)::value]; });
-      });
-      if (c0 + 4 < nrow) {
-        V nx[kND];
-        c.RowGet(c0 + 4, nx);
-        for (int r = c0 + 4; r < nrow; ++r) {
-          V y[kND];
-          static_for<0, kND>([&](auto ic) { y[decltype(ic)::value] = nx[decltype(ic)::value]; });
-          c.RowGet(r + 1 < nrow ? r + 1 : r, nx);
-          static_for<0, 4>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const E a = DotD(y, w[k]);
-            if (c0 + k < nrow) c.ShPut(kShA + Tri(r, c0 + k), a);
-          });
-        }
+    V y[kRegRows][kND];
+    static_for<0, kRegRows>([&](auto rc0) {
+      constexpr int r = decltype(rc0)::value;
+      const bool valid = r < nrow_e;
+      if (AnyWave(valid)) {
+        c.RowGet(r, y[r]);
+        static_for<0, kND>([&](auto ic) { y[r][decltype(ic)::value] = Sel(valid, y[r][decltype(ic)::value], V(0)); });
+      } else {
+        static_for<0, kND>([&](auto ic) { y[r][decltype(ic)::value] = V(0); });
       }
-    }
-    for (int r = nrow; r < kRegRows; ++r) c.ShPut(kShF + r, E(0));  // stale columns of A count for nothing
+    });
+    // the scalars of the lane's own rows r = 4 k + l (lane level), absent rows: inert
+    V fo[kOwn], ainv[kOwn], arr[kOwn], S[kOwn], AR[kOwn][kRegRows];
+    static_for<0, kOwn>([&](auto kc) {
+      static_for<0, kRegRows>([&](auto cc) { AR[decltype(kc)::value][decltype(cc)::value] = V(0); });
+    });
+    static_for<0, kOwn>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const BV have = c.RowIndexLane(4 * k) < V(nrow_e);  // 4 k + lane < nrow_e
+      fo[k] = Sel(have, Sel(cold, V(0), c.RsGetLane(4 * k, kRsF)), V(0));
+      ainv[k] = Sel(have, c.RsGetLane(4 * k, kRsAinv), V(0));
+      arr[k] = Sel(have, c.RsGetLane(4 * k, kRsArr), V(0));
+      S[k] = Sel(have, c.RsGetLane(4 * k, kRsB), V(0));
+    });
+    // A_rc = y_r . (y_c / D); the owner lanes of r and of c keep it
+    static_for<0, kRegRows>([&](auto cc) {
+      constexpr int cidx = decltype(cc)::value;
+      if (AnyWave(cidx < nrow_e)) {
+        V w[kND];
+        static_for<0, kND>([&](auto ic) { w[decltype(ic)::value] = y[cidx][decltype(ic)::value] * dd[decltype(ic)::value]; });
+        static_for<cidx + 1, kRegRows>([&](auto rc0) {
+          constexpr int r = decltype(rc0)::value;
+          if (AnyWave(r < nrow_e)) {
+            const E a = DotD(y[r], w);
+            AR[r >> 2][cidx] = Sel(LaneOps<V>::Is(r & 3), V(a), AR[r >> 2][cidx]);
+            AR[cidx >> 2][r] = Sel(LaneOps<V>::Is(cidx & 3), V(a), AR[cidx >> 2][r]);
+          } else {
+            AR[r >> 2][cidx] = Sel(LaneOps<V>::Is(r & 3), V(0), AR[r >> 2][cidx]);
+            AR[cidx >> 2][r] = Sel(LaneOps<V>::Is(cidx & 3), V(0), AR[cidx >> 2][r]);
+          }
+        });
+      } else {
+        static_for<cidx + 1, kRegRows>([&](auto rc0) {
+          constexpr int r = decltype(rc0)::value;
+          AR[r >> 2][cidx] = Sel(LaneOps<V>::Is(r & 3), V(0), AR[r >> 2][cidx]);
+          AR[cidx >> 2][r] = Sel(LaneOps<V>::Is(cidx & 3), V(0), AR[cidx >> 2][r]);
+        });
+      }
+      AR[cidx >> 2][cidx] = Sel(LaneOps<V>::Is(cidx & 3), arr[cidx >> 2], AR[cidx >> 2][cidx]);  // A_rr + R_r
+    });
+    // S_r = b_r + sum_c (A + R)_rc f_c at the start forces
+    static_for<0, kRegRows>([&](auto cc) {
+      constexpr int cidx = decltype(cc)::value;
+      const E fc = BcastQS<cidx & 3>(fo[cidx >> 2]);
+      static_for<0, kOwn>([&](auto kc) { S[decltype(kc)::value] += AR[decltype(kc)::value][cidx] * V(fc); });
+    });
     const E scale = E(1.0 / (m.meaninertia * 23.0));
-    bool done = false;
-    for (int iter = 0; iter < m.iterations; ++iter) {
+    bool done = nrow_e == 0;
+    for (int iter = 0; iter < max_iter; ++iter) {
       E improvement = E(0);
-      for (int r = 0; r < nrow; ++r) {
-        V part = V(0);
-        static_for<0, kRegRows / 4>([&](auto kc) {
-          constexpr int k = decltype(kc)::value;
-          part += c.ArGetLane(kShA, r, k) * c.ShGetLane(kShF, k);
-        });
-        const E fr = c.ShGet(kShF + r), arr = c.ShGet(kShA + Tri(r, r)), ainv = c.ShGet(kShAinv + r);
-        const E res = c.ShGet(kShB + r) + SumQ(part);
-        const E fn = MaxX(E(0), fr - res * ainv);
-        E delta = fn - fr;
-        const E change = E(0.5) * delta * delta * arr + delta * res;
-        const bool keep = !done && !(change > E(1e-10));
-        delta = keep ? delta : E(0);
-        c.ShPut(kShF + r, fr + delta);
-        improvement -= keep ? change : E(0);
-      }
+      static_for<0, kRegRows>([&](auto rc0) {
+        constexpr int r = decltype(rc0)::value;
+        constexpr int k = r >> 2, o = r & 3;
+        const bool valid = r < nrow_e;
+        if (AnyWave(valid && !done)) {
+          ++stat[0];
+          // (only lane o's numbers mean row r; the others are never looked at)
+          const V fn = MaxX(V(0), fo[k] - S[k] * ainv[k]);
+          const V dv = fn - fo[k];
+          const V cv = V(0.5) * dv * dv * arr[k] + dv * S[k];
+          const E change = BcastQS<o>(cv);
+          const bool keep = valid && !done && !(change > E(1e-10));
+          const E delta = keep ? BcastQS<o>(dv) : E(0);
+          fo[k] += Sel(LaneOps<V>::Is(o), V(delta), V(0));
+          static_for<0, kOwn>([&](auto kc) { S[decltype(kc)::value] += AR[decltype(kc)::value][r] * V(delta); });
+          improvement -= keep ? change : E(0);
+        }
+      });
+      ++stat[1];
       done = done || improvement * scale < E(1e-8);
       if (!AnyWave(!done)) break;
     }
     // z = D^-1 sum_r f_r y_r; efc_force goes back to the rows (mj_rnePostConstraint)
-    V zd[kND], nx[kND];
+    V zd[kND];
     static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] = V(0); });
-    if (nrow > 0) c.RowGet(0, nx);
-    for (int r = 0; r < nrow; ++r) {
-      V y[kND];
-      static_for<0, kND>([&](auto ic) { y[decltype(ic)::value] = nx[decltype(ic)::value]; });
-      c.RowGet(r + 1 < nrow ? r + 1 : r, nx);
-      const E fr = c.ShGet(kShF + r);
-      c.RsPut(r, kRsF, fr);
-      static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] += V(fr) * y[decltype(ic)::value]; });
-    }
+    static_for<0, kRegRows>([&](auto rc0) {
+      constexpr int r = decltype(rc0)::value;
+      const E fr = BcastQS<r & 3>(fo[r >> 2]);
+      if (r < nrow_e) c.RsPut(r, kRsF, fr);
+      static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] += V(fr) * y[r][decltype(ic)::value]; });
+    });
     static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] *= dd[decltype(ic)::value]; });
     Finish(c, f, zd, at, al);
   }
@@ -1498,13 +1580,14 @@ struct Hum4 {
     V ul[kNS];
   };
   // mj_forward: qacc (at, al); `commit`: store it as the warm start
-  // `dbg` (timing builds only, wave uniform): 1 no constraint solve, 2 no rows, 4 no detection
+  // `dbg` (timing runs only, wave uniform): 1 no constraint solve, 2 no rows, 4 no detection, 8 no sweeps;
+  // stat[0..3] += row visits, sweeps, the wave's rows (register path), streaming solves
   // `after_velocity(f)`: hook right after the smooth dynamics, while cinert / cvel / qfrc_actuator
   // are at hand (the kernel writes its observation there on the last pass; nothing of them has to
   // stay live through the constraint solve)
   template <typename Hook>
   static EPA_HD RowCount Forward(Ctx& c, State& s, Fwd<V>& f, bool commit, E* at, V* al, int dbg,
-                                 Hook&& after_velocity) {
+                                 Hook&& after_velocity, int* stat) {
     Position(c, s.qt, s.ql, f);
     EMask act;
     if (dbg & 4) {
@@ -1515,14 +1598,18 @@ struct Hum4 {
     if (dbg & 2) act.w[0] = act.w[1] = act.w[2] = 0ull;
     Velocity(c, s.qt, s.ql, s.vt, s.vl, s.ut, s.ul, f);
     after_velocity(f);
+    MassFactor(c, f);
+    SmoothAcc(c, f);
     E cost;
     V zsd[kND];
     RowCount rc = MakeRows(c, f, act, s.qt, s.ql, s.vt, s.vl, s.wt, s.wl, zsd, &cost);
     if (dbg & 1) rc = RowCount{0, 0, 0};
-    if (rc.rows() <= kRegRows) {  // wave uniform
-      SolvePgsA(c, f, rc.rows(), zsd, cost, at, al);
+    if (!AnyWave(rc.rows() > kRegRows)) {
+      SolvePgsR(c, f, rc.rows(), zsd, cost, at, al, (dbg & 8) ? 0 : MP::kM.iterations, stat);
+      stat[2] += WaveMax(rc.rows());
     } else {
-      SolvePgs(c, f, rc.rows(), zsd, cost, at, al);
+      SolvePgs(c, f, rc.rows(), zsd, cost, at, al, (dbg & 8) ? 0 : MP::kM.iterations);
+      ++stat[3];
     }
     static_for<0, kNT>([&](auto jc) { s.wt[decltype(jc)::value] = commit ? at[decltype(jc)::value] : s.wt[decltype(jc)::value]; });
     static_for<0, kNS>([&](auto sc) { s.wl[decltype(sc)::value] = Sel(commit, al[decltype(sc)::value], s.wl[decltype(sc)::value]); });
@@ -1636,10 +1723,11 @@ struct Hum4 {
     constexpr TreeModel m = MP::kM;
     static_for<0, kNTB + 1>([&](auto bc) { ext_t[decltype(bc)::value] = {{E(0), E(0), E(0)}, {E(0), E(0), E(0)}}; });
     static_for<0, 3>([&](auto bc) { ext_l[decltype(bc)::value] = {{V(0), V(0), V(0)}, {V(0), V(0), V(0)}}; });
-    const int ncon = rc.nf + rc.np;
-    for (int i = 0; i < ncon; ++i) {
+    const int ncon = rc.nf + rc.np;  // this env's contacts: floor first, then pairs
+    for (int i = 0; AnyWave(i < ncon); ++i) {
+      const bool have = i < ncon;
       const bool is_floor = i < rc.nf;
-      const int t = is_floor ? i : kNFloor + (i - rc.nf);
+      const int t = have ? i : 0;
       Vec3<E> F;
       if (is_floor) {
         const int r = rc.nl + 4 * i;
@@ -1647,12 +1735,14 @@ struct Hum4 {
         // frame rows n = z, t1 = y, t2 = -x
         F = {-(f2 - f3) * E(m.floor_mu), (f0 - f1) * E(m.floor_mu), f0 + f1 + f2 + f3};
       } else {
-        const E fr = c.RsGet(rc.nl + 4 * rc.nf + (i - rc.nf), kRsF);
+        const E fr = c.RsGet(have ? rc.nl + 4 * rc.nf + (i - rc.nf) : 0, kRsF);
         F = Vec3<E>{c.RecGet(t, 3), c.RecGet(t, 4), c.RecGet(t, 5)} * fr;
       }
-      const Vec3<E> off = Vec3<E>{c.RecGet(t, 0), c.RecGet(t, 1), c.RecGet(t, 2)} - f.com;
-      const Vec3<E> tq = Cross(off, F);  // zero force (inert rows) => zero wrench
-      const int b1 = (int)c.RecGet(t, 6), b2 = (int)c.RecGet(t, 7);
+      F = {have ? F.x : E(0), have ? F.y : E(0), have ? F.z : E(0)};
+      Vec3<E> off = Vec3<E>{c.RecGet(t, 0), c.RecGet(t, 1), c.RecGet(t, 2)} - f.com;
+      off = {have ? off.x : E(0), have ? off.y : E(0), have ? off.z : E(0)};
+      const Vec3<E> tq = Cross(off, F);
+      const int b1 = have ? (int)c.RecGet(t, 6) : 0, b2 = have ? (int)c.RecGet(t, 7) : 0;
       static_for<0, kNTB + 1>([&](auto bc) {
         constexpr int b = decltype(bc)::value;
         const E sg = E((b2 == b ? 1 : 0) - (b1 == b ? 1 : 0));

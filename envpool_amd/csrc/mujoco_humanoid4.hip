@@ -10,8 +10,8 @@
 //
 // A 64-thread block is one wavefront = 16 envs; lane l of a quad owns limb l (right leg, left
 // leg, right arm, left arm).  LDS per wave: the per-limb constant table (3.5 KB), the envs'
-// geoms + trunk cdof (20 KB), sharing their block with the dual problem of the PGS solve (A + R,
-// b, f for <= 16 rows: 23 KB), and the trunk block of the L'DL factor (7 KB).  HBM per wave: the constraint rows (y = L^-T J', 9 slots per lane and row:
+// geoms + trunk cdof (20 KB), sharing their block with the PGS stage's per-row scalars, and the
+// trunk block of the L'DL factor (7 KB).  HBM per wave: the constraint rows (y = L^-T J', 9 slots per lane and row:
 // the lane's four limb entries, its share of the nine trunk entries and of the row's five
 // scalars -- every lane reads back only what it wrote itself, the rest of the quad's values
 // arrive by DPP broadcast) and the compact contact records.  What persists between steps is
@@ -42,12 +42,11 @@ constexpr int kWsRk = kMaxRows * kRowSlots + kMaxCon * kRecSlots;
 constexpr int kWsSlots = kWsRk + kRkSlots;  // per lane
 // LDS of a wave, in doubles.  Env-level slots are [slot][quad].  The geoms + trunk cdof (Position
 // .. MakeRows) and the dual problem of the PGS solve (SolvePgsA, after MakeRows) share region U.
-constexpr int kShSlots = 16 * 17 / 2 + 3 * 16;  // Hum4::kShSlots: A + R (packed), b, f, 1 / (A_rr + R_r)
 constexpr int kGeoSlots = 102, kTcdSlots = 54, kLttSlots = 45 + 9;
-constexpr int kUSlots = kShSlots > kGeoSlots + kTcdSlots ? kShSlots : kGeoSlots + kTcdSlots;
+constexpr int kUSlots = kGeoSlots + kTcdSlots;  // = Hum4::kFSlots: the PGS stage's shared block
 constexpr int kLdsTab = 0, kLdsU = H::kNLC * 4, kLdsGeo = kLdsU, kLdsTcd = kLdsU + kGeoSlots * 16, kLdsSh = kLdsU;
 constexpr int kLdsLtt = kLdsU + kUSlots * 16;
-constexpr int kLdsElems = kLdsLtt + kLttSlots * 16;  // 34 KB
+constexpr int kLdsElems = kLdsLtt + kLttSlots * 16;  // 30 KB
 
 template <int K>
 __device__ __forceinline__ double Bcast(double x) {  // lane K of the quad
@@ -93,11 +92,6 @@ struct DevCtx {
   // the env's shared block [slot][quad] (PGS on the dual matrix)
   __device__ void ShPut(int slot, double v) { lds[kLdsSh + slot * 16 + quad] = v; }
   __device__ double ShGet(int slot) const { return lds[kLdsSh + slot * 16 + quad]; }
-  __device__ double ShGetLane(int base, int k) const { return ShGet(base + 4 * k + l); }
-  __device__ double ArGetLane(int base, int r, int k) const {
-    const int cc = 4 * k + l;
-    return ShGet(base + (r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r));
-  }
   __device__ double& Ws(int slot) const { return ws[(size_t)slot * 64 + lane]; }
   // row r: slots 0..6 the lane's share of y (Hum4::kND), 7..11 the row's five scalars (every lane
   // keeps its own copy: a lane only ever reads back what it wrote itself)
@@ -109,6 +103,8 @@ struct DevCtx {
   }
   __device__ void RsPut(int r, int k, double v) { Ws(r * kRowSlots + 7 + k) = v; }
   __device__ double RsGet(int r, int k) const { return Ws(r * kRowSlots + 7 + k); }
+  __device__ double RsGetLane(int r0, int k) const { return Ws((r0 + l) * kRowSlots + 7 + k); }  // row r0 + lane
+  __device__ double RowIndexLane(int r0) const { return (double)(r0 + l); }
   __device__ void RecPut(int t, int k, double v) {
     if ((k & 3) == l) Ws(kMaxRows * kRowSlots + t * kRecSlots + (k >> 2)) = v;
   }
@@ -134,9 +130,8 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
   static constexpr H::LimbTab kTab = H::MakeLimbTab(MP::kM);
   __shared__ double lds[kLdsElems];
   const int lane = threadIdx.x, l = lane & 3, quad = lane >> 2;
-  static_assert(kShSlots == Eng::kShSlots, "LDS layout");
+  static_assert(kUSlots == Eng::kFSlots, "LDS layout");
   for (int i = lane; i < H::kNLC * 4; i += kBlock) lds[kLdsTab + i] = kTab.c[i >> 2][i & 3];
-  for (int i = lane; i < kUSlots * 16; i += kBlock) lds[kLdsU + i] = 0.0;  // stale A entries must be finite
   const int row = blockIdx.x * kEnvsPerBlock + quad;
   const bool valid = row < a.k;
   const int e = valid ? (a.ids ? a.ids[row] - a.id_offset : row) : 0;
@@ -241,6 +236,7 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
   const int bodyA = l == 0 ? 4 : (l == 1 ? 7 : (l == 2 ? 10 : 12));
   const int nlb = l < 2 ? 3 : 2;
   double mx = 0.0, my = 0.0;
+  int stat[4] = {0, 0, 0, 0};  // solver statistics of this env-step ("hum_debug" & 16: into info)
   for (int it = 0; it < nmax; ++it) {
     const bool live = it < nfwd;
     const bool last = it == nmax - 1;
@@ -277,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
           put6(o_cv + 6 * b, ff.lcv[w > 1 ? 1 : w], true);
         }
       });
-    });
+    }, stat);
     // RK4 bookkeeping lives in the wave's HBM block between the stages (53 numbers per lane)
     typename Eng::Rk rk;
     if ((it & 3) != 0) {
@@ -388,6 +384,12 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
       info[6] = sqrt(mx * mx + my * my);
       info[7] = xv;
       info[8] = yv;
+      if (task.debug & 16) {
+        info[4] = stat[0];
+        info[5] = stat[1];
+        info[6] = stat[2];
+        info[7] = stat[3];
+      }
     }
   } else if (kStandup) {
     info[2] = task.healthy_reward;  // WriteState(0, 0, 0, 0): reward_alive is the constant

@@ -36,23 +36,20 @@ struct HostCtx {
   double LttGet(int i) const { return ltt[i]; }
   void DtPut(int i, double v) { dt[i] = v; }
   double DtGet(int i) const { return dt[i]; }
-  double sh[256];
+  double sh[512];
   void ShPut(int slot, double v) { sh[slot] = v; }
   double ShGet(int slot) const { return sh[slot]; }
-  V ShGetLane(int base, int k) const {
-    V r;
-    for (int l = 0; l < 4; ++l) r.v[l] = sh[base + 4 * k + l];
-    return r;
-  }
-  V ArGetLane(int base, int r, int k) const {
+  void RsPut(int r, int k, double v) { rs[r][k] = v; }
+  V RsGetLane(int r0, int k) const {  // scalar k of row r0 + lane
     V x;
-    for (int l = 0; l < 4; ++l) {
-      const int cc = 4 * k + l;
-      x.v[l] = sh[base + (r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r)];
-    }
+    for (int l = 0; l < 4; ++l) x.v[l] = rs[r0 + l][k];
     return x;
   }
-  void RsPut(int r, int k, double v) { rs[r][k] = v; }
+  V RowIndexLane(int r0) const {
+    V x;
+    for (int l = 0; l < 4; ++l) x.v[l] = r0 + l;
+    return x;
+  }
   double RsGet(int r, int k) const { return rs[r][k]; }
   void RecPut(int t, int k, double v) { rec[t][k] = v; }
   double RecGet(int t, int k) const { return rec[t][k]; }
@@ -126,6 +123,8 @@ static void Smooth(const double* q, const double* v, const double* ctrl, double*
   for (int i = 0; i < 3; ++i) ut[i] = ud[6 + i];
   Eng::Position(c, qt, ql, f);
   Eng::Velocity(c, qt, ql, vt, vl, ut, ul, f);
+  Eng::MassFactor(c, f);
+  Eng::SmoothAcc(c, f);
   int k = 0;
   double a[23];
   JoinV(f.accs_t, f.accs_l, a);
@@ -212,10 +211,11 @@ static void Step4(const double* q, const double* v, const double* warm, const do
   double at[9];
   Q4<double> al[4];
   typename Eng::RowCount rc{0, 0, 0};
-  if (nsub == 0) rc = Eng::Forward(c, s, f, true, at, al, 0, [](const H::Fwd<Q4<double>>&) {});
+  int stat[4] = {0, 0, 0, 0};
+  if (nsub == 0) rc = Eng::Forward(c, s, f, true, at, al, 0, [](const H::Fwd<Q4<double>>&) {}, stat);
   for (int k = 0; k < nsub; ++k) {
     for (int stage = 0; stage < 4; ++stage) {
-      rc = Eng::Forward(c, s, f, true, at, al, 0, [](const H::Fwd<Q4<double>>&) {});
+      rc = Eng::Forward(c, s, f, true, at, al, 0, [](const H::Fwd<Q4<double>>&) {}, stat);
       Eng::RkAdvance(s, rk, stage, true, at, al);
     }
   }
