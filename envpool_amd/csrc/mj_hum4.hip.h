@@ -967,6 +967,7 @@ struct Hum4 {
     double body_invw[16];
     int floor_geom[32];
     double floor_sign[32];
+    double lim_lo[kNLimit], lim_hi[kNLimit], lim_invw[kNLimit];  // limit group g: joint g + 1, dof 6 + g
   };
   static constexpr Tabs MakeTabs() {
     constexpr TreeModel m = MP::kM;
@@ -985,6 +986,11 @@ struct Hum4 {
       t.floor_geom[c] = m.floor_geom[c];
       t.floor_sign[c] = m.floor_sign[c];
     }
+    for (int g = 0; g < kNLimit; ++g) {
+      t.lim_lo[g] = m.jnt_lo[g + 1];
+      t.lim_hi[g] = m.jnt_hi[g + 1];
+      t.lim_invw[g] = m.dof_invw[6 + g];
+    }
     for (int p = 0; p < m.npair; ++p) {
       const int g1 = m.pair_g1[p], g2 = m.pair_g2[p];
       t.pair_g1[p] = g1;
@@ -994,7 +1000,7 @@ struct Hum4 {
     }
     return t;
   }
-  static constexpr Tabs kT = MakeTabs();
+  static constexpr Tabs kT = MakeTabs();  // Ctx::T(): the device keeps a copy in LDS (run-time indexed)
 
   struct EMask {
     unsigned long long w[3];
@@ -1018,17 +1024,17 @@ struct Hum4 {
   }
   // bounding-sphere cull of pair p (p: any lane- or env-level index)
   static EPA_HD bool PairNear(Ctx& c, int p) {
-    const Vec3<E> dc = GeoPos(c, kT.pair_g2[p]) - GeoPos(c, kT.pair_g1[p]);
-    const E bound = kT.pair_bound[p];
+    const Vec3<E> dc = GeoPos(c, c.T().pair_g2[p]) - GeoPos(c, c.T().pair_g1[p]);
+    const E bound = c.T().pair_bound[p];
     return Dot(dc, dc) < bound * bound;
   }
   // narrow phase of pair p: sphere / capsule primitives (mjraw_SphereSphere / SphereCapsule /
   // CapsuleCapsule; pair_g1 has the lower geom TYPE: sphere before capsule).  Select-only: the
   // pair differs from lane to lane (Detect) or from env to env (MakeRows).
   static EPA_HD E PairNarrow(Ctx& c, int p, Vec3<E>* n, Vec3<E>* pos) {
-    const int g1 = kT.pair_g1[p], g2 = kT.pair_g2[p];
-    const bool cap1 = kT.geom_cap[g1] != 0, cap2 = kT.geom_cap[g2] != 0;
-    const E r1 = kT.geom_rad[g1], r2 = kT.geom_rad[g2], h1 = kT.geom_hl[g1], h2 = kT.geom_hl[g2];
+    const int g1 = c.T().pair_g1[p], g2 = c.T().pair_g2[p];
+    const bool cap1 = c.T().geom_cap[g1] != 0, cap2 = c.T().geom_cap[g2] != 0;
+    const E r1 = c.T().geom_rad[g1], r2 = c.T().geom_rad[g2], h1 = c.T().geom_hl[g1], h2 = c.T().geom_hl[g2];
     const Vec3<E> p1 = GeoPos(c, g1), p2 = GeoPos(c, g2);
     const Vec3<E> ax1 = GeoAxis(c, g1), ax2 = GeoAxis(c, g2);
     // both capsules
@@ -1225,31 +1231,30 @@ struct Hum4 {
           if (phase == 0) {
             ld = 6 + g;
             const E q = ld < kNT ? qt[1 + ld] : LimbPick(ql, LimbOfDof(ld), SlotOfDof(ld));
-            const int j = ld - 5;
-            const E dlo = q - E(m.jnt_lo[j]), dhi = E(m.jnt_hi[j]) - q;
+            const E dlo = q - E(c.T().lim_lo[g]), dhi = E(c.T().lim_hi[g]) - q;
             const bool lo = dlo < E(0);
             pos = Sel(lo, dlo, dhi);
             lim_s = Sel(lo, E(1), E(-1));
-            diag = E(m.dof_invw[ld]);
+            diag = E(c.T().lim_invw[g]);
           } else if (phase == 1) {
             const int cand = g - kG0Floor;
-            const int gg = kT.floor_geom[cand];
-            const Vec3<E> ctr = GeoPos(c, gg) + GeoAxis(c, gg) * E(kT.floor_sign[cand] * kT.geom_hl[gg]);
-            const E dist = ctr.z - E(kT.geom_rad[gg]);
+            const int gg = c.T().floor_geom[cand];
+            const Vec3<E> ctr = GeoPos(c, gg) + GeoAxis(c, gg) * E(c.T().floor_sign[cand] * c.T().geom_hl[gg]);
+            const E dist = ctr.z - E(c.T().geom_rad[gg]);
             pos = dist - E(m.margin);
             cpos = {ctr.x, ctr.y, E(0.5) * dist};
-            b2 = kT.geom_body[gg];
-            m2 = kT.body_mask[b2];
-            diag = E(kT.body_invw[b2] * (1.0 + m.floor_mu * m.floor_mu));
+            b2 = c.T().geom_body[gg];
+            m2 = c.T().body_mask[b2];
+            diag = E(c.T().body_invw[b2] * (1.0 + m.floor_mu * m.floor_mu));
           } else {
             const int p = g - kG0Pair;
             const E dist = PairNarrow(c, p, &n, &cpos);
             pos = dist - E(m.margin);
-            b1 = kT.geom_body[kT.pair_g1[p]];
-            b2 = kT.geom_body[kT.pair_g2[p]];
-            m1 = kT.body_mask[b1];
-            m2 = kT.body_mask[b2];
-            diag = E(kT.pair_diag[p]);
+            b1 = c.T().geom_body[c.T().pair_g1[p]];
+            b2 = c.T().geom_body[c.T().pair_g2[p]];
+            m1 = c.T().body_mask[b1];
+            m2 = c.T().body_mask[b2];
+            diag = E(c.T().pair_diag[p]);
           }
           const Vec3<E> off = cpos - f.com;
           const E imp = Impedance(AbsX(pos));
@@ -1395,7 +1400,8 @@ struct Hum4 {
   }
   // nrow_e: this env's rows (0 .. nrow_e - 1, compact); the wave walks max-over-envs rows, an env
   // treats the rows beyond its own as absent (its slots there hold stale data)
-  static EPA_HD void SolvePgs(Ctx& c, const Fwd<V>& f, int nrow_e, const V* zsd, E cost, E* at, V* al, int max_iter) {
+  static EPA_HD void SolvePgs(Ctx& c, const Fwd<V>& f, int nrow_e, const V* zsd, E cost, E* at, V* al, int max_iter,
+                              int* stat) {
     constexpr TreeModel m = MP::kM;
     const int nrow = WaveMax(nrow_e);
     V dd[kND], zd[kND];
@@ -1447,6 +1453,7 @@ struct Hum4 {
           improvement -= keep ? change : E(0);
           if (++r == nrow) {  // end of a sweep
             r = 0;
+            stat[4] += done ? 0 : 1;
             done = done || improvement * scale < E(1e-8);
             improvement = E(0);
             more = ++iter < max_iter && AnyWave(!done);
@@ -1556,6 +1563,7 @@ struct Hum4 {
         }
       });
       ++stat[1];
+      stat[4] += done ? 0 : 1;  // this env's own sweeps: the key of the cost-sorted scheduling
       done = done || improvement * scale < E(1e-8);
       if (!AnyWave(!done)) break;
     }
@@ -1581,7 +1589,7 @@ struct Hum4 {
   };
   // mj_forward: qacc (at, al); `commit`: store it as the warm start
   // `dbg` (timing runs only, wave uniform): 1 no constraint solve, 2 no rows, 4 no detection, 8 no sweeps;
-  // stat[0..3] += row visits, sweeps, the wave's rows (register path), streaming solves
+  // stat[0..4] += row visits, sweeps, the wave's rows (register path), streaming solves, this env's own sweeps
   // `after_velocity(f)`: hook right after the smooth dynamics, while cinert / cvel / qfrc_actuator
   // are at hand (the kernel writes its observation there on the last pass; nothing of them has to
   // stay live through the constraint solve)
@@ -1608,7 +1616,7 @@ struct Hum4 {
       SolvePgsR(c, f, rc.rows(), zsd, cost, at, al, (dbg & 8) ? 0 : MP::kM.iterations, stat);
       stat[2] += WaveMax(rc.rows());
     } else {
-      SolvePgs(c, f, rc.rows(), zsd, cost, at, al, (dbg & 8) ? 0 : MP::kM.iterations);
+      SolvePgs(c, f, rc.rows(), zsd, cost, at, al, (dbg & 8) ? 0 : MP::kM.iterations, stat);
       ++stat[3];
     }
     static_for<0, kNT>([&](auto jc) { s.wt[decltype(jc)::value] = commit ? at[decltype(jc)::value] : s.wt[decltype(jc)::value]; });

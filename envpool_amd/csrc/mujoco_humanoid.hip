@@ -304,6 +304,11 @@ class HumanoidPool : public Pool {
     // "hum_layout": 1 (default) one env per lane quad (mj_hum4.hip.h), 0 one env per lane with
     // the HBM workspace (mj_tree.hip.h; kept for A/B runs)
     quad_ = cfg.Get("hum_layout", 1) != 0;
+    // "hum_sort": 1 (default) waves are formed from envs of similar solver cost (Hum4SortKernel)
+    sort_ = quad_ && cfg.Get("hum_sort", 1) != 0;
+    EPA_HIP(hipMalloc(&dev_.cost, sizeof(int) * (size_t)cfg.num_envs));
+    EPA_HIP(hipMemsetAsync(dev_.cost, 0, sizeof(int) * (size_t)cfg.num_envs, stream_));
+    EPA_HIP(hipMalloc(&perm_, sizeof(int) * (size_t)cfg.num_envs));
     const size_t blocks = ((size_t)cfg.num_envs + 63) / 64;
     ws_bytes_ = quad_ ? Hum4WorkspaceBytes(cfg.num_envs) : sizeof(double) * blocks * 64 * (size_t)Total();
     EPA_HIP(hipMalloc(&dev_.ws, ws_bytes_));
@@ -316,6 +321,8 @@ class HumanoidPool : public Pool {
   ~HumanoidPool() override {
     (void)hipFree(dev_.ws);
     (void)hipFree(dev_.state);
+    (void)hipFree(dev_.cost);
+    (void)hipFree(perm_);
   }
   int StateDim() const override { return kHumanoidModelConst.nq + 2 * kHumanoidModelConst.nv + 7; }
   void GetState(const int* d_ids, int k, double* d_out) override {
@@ -330,6 +337,11 @@ class HumanoidPool : public Pool {
               const OutPtrs& out) override {
     StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps, cfg_.env_id_offset};
     if (quad_) {
+      dev_.perm = nullptr;
+      if (sort_ && k > 16) {
+        dev_.perm = perm_;
+        Hum4LaunchSort(stream_, dev_, a);
+      }
       Hum4LaunchStep(stream_, standup_, (k + 15) / 16, dev_, common_, a, static_cast<const double*>(d_action),
                      out, task_);
       return;
@@ -347,7 +359,8 @@ class HumanoidPool : public Pool {
   HumTask task_{};
   size_t ws_bytes_{0};
   bool standup_;
-  bool quad_{true};
+  bool quad_{true}, sort_{true};
+  int* perm_{nullptr};
 };
 
 }  // namespace

@@ -60,6 +60,9 @@ __device__ __forceinline__ double Bcast(double x) {  // lane K of the quad
 template <class MP>
 struct DevCtx {
   using V = double;
+  using Tabs = typename H::Hum4<MP, DevCtx<MP>>::Tabs;
+  const Tabs* tabs;  // the wave's LDS copy of the candidate tables
+  __device__ const Tabs& T() const { return *tabs; }
   double* lds;
   double* ws;  // the wave's block, [slot][64]
   int lane, l, quad;
@@ -129,11 +132,19 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
                 "CtrlOfDof");
   static constexpr H::LimbTab kTab = H::MakeLimbTab(MP::kM);
   __shared__ double lds[kLdsElems];
+  __shared__ typename Ctx::Tabs lds_tabs;  // 3.6 KB: pair / geom / body / limit tables, indexed at run time
   const int lane = threadIdx.x, l = lane & 3, quad = lane >> 2;
+  {
+    static_assert(sizeof(typename Ctx::Tabs) % 4 == 0, "word copy");
+    const int* src = reinterpret_cast<const int*>(&Eng::kT);
+    int* dst = reinterpret_cast<int*>(&lds_tabs);
+    for (int i = lane; i < (int)(sizeof(typename Ctx::Tabs) / 4); i += kBlock) dst[i] = src[i];
+  }
   static_assert(kUSlots == Eng::kFSlots, "LDS layout");
   for (int i = lane; i < H::kNLC * 4; i += kBlock) lds[kLdsTab + i] = kTab.c[i >> 2][i & 3];
-  const int row = blockIdx.x * kEnvsPerBlock + quad;
-  const bool valid = row < a.k;
+  const int slot = blockIdx.x * kEnvsPerBlock + quad;
+  const bool valid = slot < a.k;
+  const int row = valid && dev.perm ? dev.perm[slot] : slot;  // cost-sorted scheduling
   const int e = valid ? (a.ids ? a.ids[row] - a.id_offset : row) : 0;
   const int n = cm.n;
   bool done = valid && cm.done[e] != 0;
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
   }
   __syncthreads();
   if (!valid) return;  // whole quads leave together
-  Ctx c{lds, dev.ws + (size_t)blockIdx.x * kWsSlots * 64, lane, l, quad};
+  Ctx c{&lds_tabs, lds, dev.ws + (size_t)blockIdx.x * kWsSlots * 64, lane, l, quad};
   // persistent state: qpos[24] qvel[23] warm[23] lag[2], SoA [slot][n]
   constexpr int kQ = 0, kV = 24, kW = 47, kLag = 70;
   auto get = [&](int slot) -> double {
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
   const int bodyA = l == 0 ? 4 : (l == 1 ? 7 : (l == 2 ? 10 : 12));
   const int nlb = l < 2 ? 3 : 2;
   double mx = 0.0, my = 0.0;
-  int stat[4] = {0, 0, 0, 0};  // solver statistics of this env-step ("hum_debug" & 16: into info)
+  int stat[5] = {0, 0, 0, 0, 0};  // solver statistics of this env-step ("hum_debug" & 16: into info)
   for (int it = 0; it < nmax; ++it) {
     const bool live = it < nfwd;
     const bool last = it == nmax - 1;
@@ -409,6 +420,7 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
     for (int i = 0; i < ninfo; ++i) ((double*)out.p[kKeyEnv0 + 1 + i])[row] = info[i];
     cm.done[e] = done ? 1 : 0;
     cm.cur_step[e] = cur;
+    dev.cost[e] = reset ? 0 : stat[4];
     WriteCommon(out, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
   }
   mj::static_for<0, H::kNS>([&](auto sc) {
@@ -436,6 +448,66 @@ void Hum4LaunchStep(hipStream_t st, bool standup, int blocks, HumDev dev, Common
                        a, act, out, task);
   }
 }
+namespace {
+// Stable counting sort of the launch's rows by their env's cost, one workgroup: thread t owns the
+// contiguous chunk of rows [t C, (t + 1) C), counts its rows per bucket, a scan over (bucket major,
+// thread minor) gives every thread its start offset per bucket, and it then places its rows in
+// order.  Deterministic (no atomics): the same costs always give the same waves.
+constexpr int kSortThreads = 512, kSortBuckets = 16;
+__device__ __forceinline__ int CostBucket(int cost) {
+  const int b = cost >> 5;  // own sweeps of the last env-step (20 forward passes, <= 50 each)
+  return b < kSortBuckets - 1 ? b : kSortBuckets - 1;
+}
+__global__ __launch_bounds__(kSortThreads) void Hum4SortKernel(HumDev dev, StepArgs a) {
+  __shared__ int cnt[kSortBuckets][kSortThreads];
+  __shared__ int base[kSortBuckets + 1];
+  const int t = threadIdx.x;
+  const int chunk = (a.k + kSortThreads - 1) / kSortThreads;
+  const int lo = t * chunk, hi = lo + chunk < a.k ? lo + chunk : a.k;
+  int mine[kSortBuckets];
+  for (int b = 0; b < kSortBuckets; ++b) mine[b] = 0;
+  for (int r = lo; r < hi; ++r) {
+    const int e = a.ids ? a.ids[r] - a.id_offset : r;
+    const int b = CostBucket(dev.cost[e]);
+    for (int q = 0; q < kSortBuckets; ++q) mine[q] += q == b ? 1 : 0;
+  }
+  for (int b = 0; b < kSortBuckets; ++b) cnt[b][t] = mine[b];
+  __syncthreads();
+  // exclusive scan over threads, per bucket (thread b < 16 scans bucket b: 1024 adds)
+  if (t < kSortBuckets) {
+    int run = 0;
+    for (int i = 0; i < kSortThreads; ++i) {
+      const int v = cnt[t][i];
+      cnt[t][i] = run;
+      run += v;
+    }
+    base[t + 1] = run;
+  }
+  __syncthreads();
+  if (t == 0) {
+    base[0] = 0;
+    for (int b = 0; b < kSortBuckets; ++b) base[b + 1] += base[b];
+  }
+  __syncthreads();
+  // most expensive bucket first: the long waves start early, the short ones fill the tail
+  int at[kSortBuckets];
+  for (int b = 0; b < kSortBuckets; ++b) at[b] = (a.k - base[b + 1]) + cnt[b][t];
+  for (int r = lo; r < hi; ++r) {
+    const int e = a.ids ? a.ids[r] - a.id_offset : r;
+    const int b = CostBucket(dev.cost[e]);
+    int pos = 0;
+    for (int q = 0; q < kSortBuckets; ++q) {
+      if (q == b) pos = at[q]++;
+    }
+    dev.perm[pos] = r;
+  }
+}
+}  // namespace
+
+void Hum4LaunchSort(hipStream_t st, HumDev dev, StepArgs a) {
+  hipLaunchKernelGGL(Hum4SortKernel, dim3(1), dim3(kSortThreads), 0, st, dev, a);
+}
+
 size_t Hum4WorkspaceBytes(int num_envs) {
   const size_t blocks = ((size_t)num_envs + kEnvsPerBlock - 1) / kEnvsPerBlock;
   return sizeof(double) * blocks * 64 * (size_t)kWsSlots;

@@ -10,6 +10,10 @@ namespace epa {
 struct HumDev {
   double* ws;     // [ceil(N / 64)][Layout::total][64]: block b belongs to wave b of a launch
   double* state;  // [Layout::npersist][N]: what persists between steps, per env
+  // quad kernel, cost-sorted scheduling: an env's PGS sweeps of its last step, and the launch's
+  // row order (slot -> row) that puts envs of similar cost into the same wave
+  int* cost;  // [N]
+  int* perm;  // [N], nullptr: rows in order
 };
 
 struct HumTask {
@@ -27,6 +31,8 @@ struct HumTask {
 void Hum4LaunchStep(hipStream_t st, bool standup, int blocks, HumDev dev, CommonDev cm, StepArgs a,
                     const double* act, OutPtrs out, HumTask task);
 size_t Hum4WorkspaceBytes(int num_envs);
+// fills dev.perm[0..k) with the rows 0..k-1 ordered by dev.cost of their envs (stable, deterministic)
+void Hum4LaunchSort(hipStream_t st, HumDev dev, StepArgs a);
 
 }  // namespace epa
 

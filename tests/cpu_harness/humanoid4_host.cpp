@@ -29,6 +29,7 @@ struct HostCtx {
   void RowGet(int r, V* yd) const {
     for (int i = 0; i < 7; ++i) yd[i] = rows[r][i];
   }
+  const typename H::Hum4<MP, HostCtx<MP>>::Tabs& T() const { return H::Hum4<MP, HostCtx<MP>>::kT; }
   double tcd[54], ltt[45], dt[9];
   void TcdPut(int i, double v) { tcd[i] = v; }
   double TcdGet(int i) const { return tcd[i]; }
@@ -211,7 +212,7 @@ static void Step4(const double* q, const double* v, const double* warm, const do
   double at[9];
   Q4<double> al[4];
   typename Eng::RowCount rc{0, 0, 0};
-  int stat[4] = {0, 0, 0, 0};
+  int stat[5] = {0, 0, 0, 0, 0};
   if (nsub == 0) rc = Eng::Forward(c, s, f, true, at, al, 0, [](const H::Fwd<Q4<double>>&) {}, stat);
   for (int k = 0; k < nsub; ++k) {
     for (int stage = 0; stage < 4; ++stage) {
