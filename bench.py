@@ -199,14 +199,17 @@ def main():
         # HBM traffic and flop counts come from the committed rocprofv3 PMC passes of
         # this same command (tools/profile_bench.sh -> profiles/pmc.json): PMC
         # collection needs its own rocprofv3 runs and cannot happen inside the bench.
+        hum_quad = params.get("hum_layout", 1) != 0  # one env per lane quad (default)
         kbase = ("AntStepKernel" if args.task == "Ant" else
-                 "HumanoidStepKernel" if args.task.startswith("Humanoid") else
+                 ("Humanoid4StepKernel" if hum_quad else "HumanoidStepKernel")
+                 if args.task.startswith("Humanoid") else
                  "PusherStepKernel" if args.task == "Pusher" else "CheetahStepKernel")
-        kname = kbase + ("" if args.task == "Pusher" else
-                         "<double>" if args.precision == "fp64" or args.task.startswith("Humanoid")
-                         else "<float>")
+        fp64_only = args.task.startswith("Humanoid") or args.task == "Pusher"
+        kname = kbase + ("<double>" if args.precision == "fp64" or fp64_only else "<float>")
         if args.task in ("Walker2d", "Hopper"):
             kname += f"[{args.task}]"
+        if args.task == "HumanoidStandup":
+            kname += "[Standup]"
         pmc = {}
         try:
             with open(os.path.join(ROOT, "profiles", "pmc.json")) as f:
@@ -217,7 +220,7 @@ def main():
         valu = None
         if pmc and pmc.get("num_envs") == n:
             traffic = pmc["traffic_bytes_per_launch"]
-            peak_tf = 78.6 if args.precision == "fp64" else 157.3
+            peak_tf = 78.6 if args.precision == "fp64" or fp64_only else 157.3
             tf = pmc["flops_per_launch"] / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
             valu = {"achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf,
                     "flops_per_env_step": pmc["flops_per_env_step"],
@@ -226,10 +229,11 @@ def main():
                "frac": achieved_gbs / 8000.0,
                "algorithmic_bytes_per_env_step": alg_bytes,
                "note": "algorithmic bytes / kernel time, the fraction BASELINE.md asks for"}
-        humanoid = args.task.startswith("Humanoid")
+        humanoid = args.task.startswith("Humanoid") and not hum_quad
         if humanoid or valu is None:
-            # Humanoid streams its workspace through HBM: HBM binds.  Without
-            # PMC flop counts for this exact configuration only the HBM figure can be stated.
+            # The one-env-per-lane Humanoid kernel streams its workspace through HBM (DESIGN.md
+            # K3c): HBM binds.  Without PMC flop counts for this exact configuration only the HBM
+            # figure can be stated.
             roof = {"bound": "hbm", **{k: hbm[k] for k in ("achieved", "peak", "unit", "frac")},
                     "traffic": traffic, "valu": valu}
         else:

@@ -788,3 +788,31 @@ def test_humanoid_deterministic_and_partial_batches():
                 rows[int(e)] = r["obs"][j]
         got = np.stack([rows[e] for e in range(n)])
         np.testing.assert_allclose(got, a["obs"], rtol=1e-9, atol=1e-10, err_msg=f"step {t}")
+
+
+@pytest.mark.parametrize("task", ["Humanoid", "HumanoidStandup"])
+def test_humanoid_layouts_and_scheduling_agree(task):
+    """The one-env-per-lane-quad kernel (mj_hum4.hip.h, default), with and without the cost-sorted
+    scheduling of its waves, and the one-env-per-lane kernel (mj_tree.hip.h, hum_layout=0) are three
+    schedules of the same arithmetic: free running from the same seed with the same actions they
+    stay together to PGS-rounding level (which solver formulation an env gets depends on the envs
+    that share its wave), and the rows come back in send order whatever order the waves ran in."""
+    n = 512  # 32 waves of 16 envs: the sort has something to reorder
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-0.4, 0.4, size=(25, n, 17))
+    outs = []
+    for params in ({"hum_layout": 1, "hum_sort": 1}, {"hum_layout": 1, "hum_sort": 0}, {"hum_layout": 0}):
+        p = DevicePool(task, n, seed=3, max_episode_steps=1000, params={"post_constraint": 1, **params})
+        hip_reset(p)
+        seq = []
+        for t in range(25):
+            a = hip_step(p, acts[t])
+            assert a["info:env_id"].ravel().tolist() == list(range(n))
+            seq.append(np.concatenate([a["obs"], a["reward"].reshape(n, 1), a["done"].reshape(n, 1)], axis=1))
+        outs.append(np.stack(seq))
+    for other, what in ((outs[1], "sorted vs unsorted waves"), (outs[2], "quad vs one-env-per-lane layout")):
+        rel = np.abs(outs[0] - other) / (1.0 + np.abs(other))
+        # a free-running humanoid amplifies rounding differences: bulk tight, tail bounded
+        assert np.median(rel.max(axis=2)) < 1e-10, what
+        assert (rel.max(axis=2) < 1e-6).mean() > 0.99, what
+        print(f"{task}: {what}: median rel {np.median(rel.max(axis=2)):.1e}, max {rel.max():.1e}")

@@ -29,7 +29,8 @@ for path in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}_*"
     sfx = "F64" if f64 else "F32"
     flops = 64.0 * (2 * ctr.get(f"SQ_INSTS_VALU_FMA_{sfx}", 0) + ctr.get(f"SQ_INSTS_VALU_ADD_{sfx}", 0) +
                     ctr.get(f"SQ_INSTS_VALU_MUL_{sfx}", 0) + ctr.get(f"SQ_INSTS_VALU_TRANS_{sfx}", 0))
-    waves = (num_envs + 63) // 64 if "Ant" not in kernel else (num_envs + 15) // 16  # Ant: 16 envs per wave
+    quad = "Ant" in kernel or "Humanoid4" in kernel  # one env per lane quad: 16 envs per wave
+    waves = (num_envs + 15) // 16 if quad else (num_envs + 63) // 64
     out[f"{kernel}@{num_envs}"] = {
         "fetch_size_kb": ctr.get("FETCH_SIZE"),
         "write_size_kb": ctr.get("WRITE_SIZE"),

@@ -26,8 +26,12 @@ def short(name):
                  ("AntStepKernel<double, true>", "AntStepKernel<double>[v5 cfrc_ext]")):
         if k in name:
             return v
+    if "Humanoid4StepKernel" in name:  # one env per lane quad (mujoco_humanoid4.hip)
+        return "Humanoid4StepKernel<double>" + ("[Standup]" if "StandupMP" in name else "")
     if "HumanoidStepKernel" in name:
-        return "HumanoidStepKernel" + ("[Standup]" if "StandupMP" in name else "")
+        return "HumanoidStepKernel<double>" + ("[Standup]" if "StandupMP" in name else "")
+    if "PusherStepKernel" in name:
+        return "PusherStepKernel<double>"
     for k in ("PendStepKernel", "ReacherStepKernel", "SwimmerStepKernel", "ClassicStepKernel",
               "ToyStepKernel", "AtariPostKernel"):
         if k in name:
