@@ -1453,7 +1453,7 @@ struct Hum4 {
           improvement -= keep ? change : E(0);
           if (++r == nrow) {  // end of a sweep
             r = 0;
-            stat[4] += done ? 0 : 1;
+            stat[4] += done ? 0 : nrow_e;
             done = done || improvement * scale < E(1e-8);
             improvement = E(0);
             more = ++iter < max_iter && AnyWave(!done);
@@ -1563,7 +1563,7 @@ struct Hum4 {
         }
       });
       ++stat[1];
-      stat[4] += done ? 0 : 1;  // this env's own sweeps: the key of the cost-sorted scheduling
+      stat[4] += done ? 0 : nrow_e;  // this env's own row visits: the key of the cost-sorted scheduling
       done = done || improvement * scale < E(1e-8);
       if (!AnyWave(!done)) break;
     }
@@ -1589,7 +1589,7 @@ struct Hum4 {
   };
   // mj_forward: qacc (at, al); `commit`: store it as the warm start
   // `dbg` (timing runs only, wave uniform): 1 no constraint solve, 2 no rows, 4 no detection, 8 no sweeps;
-  // stat[0..4] += row visits, sweeps, the wave's rows (register path), streaming solves, this env's own sweeps
+  // stat[0..4] += row visits, sweeps, the wave's rows (register path), streaming solves, this env's solver cost (own row visits + 16 per row built)
   // `after_velocity(f)`: hook right after the smooth dynamics, while cinert / cvel / qfrc_actuator
   // are at hand (the kernel writes its observation there on the last pass; nothing of them has to
   // stay live through the constraint solve)
@@ -1611,6 +1611,7 @@ struct Hum4 {
     E cost;
     V zsd[kND];
     RowCount rc = MakeRows(c, f, act, s.qt, s.ql, s.vt, s.vl, s.wt, s.wl, zsd, &cost);
+    stat[4] += 16 * rc.rows();  // building a row costs about as much as 16 visits of it
     if (dbg & 1) rc = RowCount{0, 0, 0};
     if (!AnyWave(rc.rows() > kRegRows)) {
       SolvePgsR(c, f, rc.rows(), zsd, cost, at, al, (dbg & 8) ? 0 : MP::kM.iterations, stat);

@@ -455,7 +455,9 @@ namespace {
 // order.  Deterministic (no atomics): the same costs always give the same waves.
 constexpr int kSortThreads = 512, kSortBuckets = 16;
 __device__ __forceinline__ int CostBucket(int cost) {
-  const int b = cost >> 5;  // own sweeps of the last env-step (20 forward passes, <= 50 each)
+  // the env's solver cost of its last env-step (row visits + rows built, see Hum4::Forward):
+  // geometric buckets, 0 | 1-63 | 64-127 | ... | >= 2^18
+  const int b = cost <= 0 ? 0 : 32 - __clz(cost >> 5);
   return b < kSortBuckets - 1 ? b : kSortBuckets - 1;
 }
 __global__ __launch_bounds__(kSortThreads) void Hum4SortKernel(HumDev dev, StepArgs a) {

@@ -10,7 +10,7 @@ namespace epa {
 struct HumDev {
   double* ws;     // [ceil(N / 64)][Layout::total][64]: block b belongs to wave b of a launch
   double* state;  // [Layout::npersist][N]: what persists between steps, per env
-  // quad kernel, cost-sorted scheduling: an env's PGS sweeps of its last step, and the launch's
+  // quad kernel, cost-sorted scheduling: an env's solver cost of its last step, and the launch's
   // row order (slot -> row) that puts envs of similar cost into the same wave
   int* cost;  // [N]
   int* perm;  // [N], nullptr: rows in order
