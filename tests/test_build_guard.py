@@ -1,0 +1,54 @@
+"""Build guard for the MuJoCo kernels (no GPU needed): ROCm 7.2 / gfx950 builds of these
+one-wave-per-SIMD kernels with HEAVY SGPR spilling have returned wrong results (mj_cheetah with
+170 SGPR spills, run-to-run different; mujoco_pusher with the model as a kernel argument, ~250
+spills: joint-limit forces wrong on 75 % of the envs while the same source was right in an
+isolated harness -- see envpool_amd/csrc/Makefile).  The GPU parity tests catch a
+bad build; this test catches the precondition already on the build box, from the code object's
+own metadata."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "envpool_amd", "lib", "libenvpool_amd.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+# the largest count a parity-green build has shipped with is 124 (PendStepKernel<2>: the chain
+# kernels still take their model as a kernel argument); the known-bad builds had 170 and ~250
+MAX_SGPR_SPILLS = 130
+
+
+def _kernel_metadata():
+    if not os.path.exists(LIB):
+        pytest.skip("libenvpool_amd.so not built")
+    if not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("ROCm llvm tools not installed")
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(LIB, tmp)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "libenvpool_amd.so"],
+                       cwd=tmp, check=True, capture_output=True)
+        for f in sorted(os.listdir(tmp)):
+            if "hipv4" not in f:
+                continue
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", f], cwd=tmp,
+                                   check=True, capture_output=True, text=True).stdout
+            for block in notes.split("- .agpr_count")[1:]:
+                name = re.search(r"\.name:\s+(\S+)", block)
+                sgpr = re.search(r"\.sgpr_spill_count:\s+(\d+)", block)
+                scratch = re.search(r"\.private_segment_fixed_size:\s+(\d+)", block)
+                if name and sgpr:
+                    out[name.group(1)] = (int(sgpr.group(1)), int(scratch.group(1)) if scratch else 0)
+    return out
+
+
+def test_step_kernels_do_not_spill_sgprs_heavily():
+    meta = {k: v for k, v in _kernel_metadata().items() if "StepKernel" in k}
+    assert len(meta) >= 30, sorted(meta)  # classic 5, toy 6, planar 8, Ant 4, chains 4, Humanoid 4, Pusher 2
+    worst = max(meta.items(), key=lambda kv: kv[1][0])
+    print("most SGPR spills:", worst)
+    bad = {k: v for k, v in meta.items() if v[0] > MAX_SGPR_SPILLS}
+    assert not bad, bad
