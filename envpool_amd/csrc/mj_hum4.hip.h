@@ -1587,6 +1587,20 @@ struct Hum4 {
     E ut[3];   // ctrl of dofs 6 7 8
     V ul[kNS];
   };
+  enum { kSttQ = 0, kSttV = 10, kSttW = 19, kSttU = 28, kSttSlots = 31 };
+  // bits: 1 qpos, 2 qvel, 4 warm start, 8 ctrl
+  static EPA_HD void LoadTrunk(Ctx& c, State& s, int bits) {
+    if (bits & 1) static_for<0, 10>([&](auto ic) { s.qt[decltype(ic)::value] = c.SttGet(kSttQ + decltype(ic)::value); });
+    if (bits & 2) static_for<0, kNT>([&](auto ic) { s.vt[decltype(ic)::value] = c.SttGet(kSttV + decltype(ic)::value); });
+    if (bits & 4) static_for<0, kNT>([&](auto ic) { s.wt[decltype(ic)::value] = c.SttGet(kSttW + decltype(ic)::value); });
+    if (bits & 8) static_for<0, 3>([&](auto ic) { s.ut[decltype(ic)::value] = c.SttGet(kSttU + decltype(ic)::value); });
+  }
+  static EPA_HD void StoreTrunk(Ctx& c, const State& s, int bits) {
+    if (bits & 1) static_for<0, 10>([&](auto ic) { c.SttPut(kSttQ + decltype(ic)::value, s.qt[decltype(ic)::value]); });
+    if (bits & 2) static_for<0, kNT>([&](auto ic) { c.SttPut(kSttV + decltype(ic)::value, s.vt[decltype(ic)::value]); });
+    if (bits & 4) static_for<0, kNT>([&](auto ic) { c.SttPut(kSttW + decltype(ic)::value, s.wt[decltype(ic)::value]); });
+    if (bits & 8) static_for<0, 3>([&](auto ic) { c.SttPut(kSttU + decltype(ic)::value, s.ut[decltype(ic)::value]); });
+  }
   // mj_forward: qacc (at, al); `commit`: store it as the warm start
   // `dbg` (timing runs only, wave uniform): 1 no constraint solve, 2 no rows, 4 no detection, 8 no sweeps;
   // stat[0..4] += row visits, sweeps, the wave's rows (register path), streaming solves, this env's solver cost (own row visits + 16 per row built)
@@ -1596,6 +1610,10 @@ struct Hum4 {
   template <typename Hook>
   static EPA_HD RowCount Forward(Ctx& c, State& s, Fwd<V>& f, bool commit, E* at, V* al, int dbg,
                                  Hook&& after_velocity, int* stat) {
+    // The trunk part of the state (31 numbers, env level) lives in the env's shared block between
+    // the stages (Ctx::SttGet / SttPut) and every stage loads what it reads: replicated in the four
+    // lanes' registers through the whole pass it costs 62 VGPRs at the register peaks.
+    LoadTrunk(c, s, 1);
     Position(c, s.qt, s.ql, f);
     EMask act;
     if (dbg & 4) {
@@ -1604,13 +1622,18 @@ struct Hum4 {
       Detect(c, s.qt, s.ql, act);
     }
     if (dbg & 2) act.w[0] = act.w[1] = act.w[2] = 0ull;
+    EPA_LDS_FENCE();
+    LoadTrunk(c, s, 1 | 2 | 8);
     Velocity(c, s.qt, s.ql, s.vt, s.vl, s.ut, s.ul, f);
     after_velocity(f);
     MassFactor(c, f);
     SmoothAcc(c, f);
+    EPA_LDS_FENCE();
     E cost;
     V zsd[kND];
+    LoadTrunk(c, s, 1 | 2 | 4);
     RowCount rc = MakeRows(c, f, act, s.qt, s.ql, s.vt, s.vl, s.wt, s.wl, zsd, &cost);
+    EPA_LDS_FENCE();
     stat[4] += 16 * rc.rows();  // building a row costs about as much as 16 visits of it
     if (dbg & 1) rc = RowCount{0, 0, 0};
     if (!AnyWave(rc.rows() > kRegRows)) {
@@ -1620,7 +1643,9 @@ struct Hum4 {
       SolvePgs(c, f, rc.rows(), zsd, cost, at, al, (dbg & 8) ? 0 : MP::kM.iterations, stat);
       ++stat[3];
     }
-    static_for<0, kNT>([&](auto jc) { s.wt[decltype(jc)::value] = commit ? at[decltype(jc)::value] : s.wt[decltype(jc)::value]; });
+    static_for<0, kNT>([&](auto jc) {
+      if (commit) c.SttPut(kSttW + decltype(jc)::value, at[decltype(jc)::value]);  // (four lanes, one value)
+    });
     static_for<0, kNS>([&](auto sc) { s.wl[decltype(sc)::value] = Sel(commit, al[decltype(sc)::value], s.wl[decltype(sc)::value]); });
     return rc;
   }
@@ -1665,8 +1690,9 @@ struct Hum4 {
   // One stage boundary, called after the forward evaluation of stage `stage` (0: at the start
   // state) with its qacc (at, al).  Stages 0..2 move the state to the next stage point, stage 3
   // finishes the step.  `live`: envs that really integrate.
-  static EPA_HD void RkAdvance(State& s, Rk& k, int stage, bool live, const E* at, const V* al) {
+  static EPA_HD void RkAdvance(Ctx& c, State& s, Rk& k, int stage, bool live, const E* at, const V* al) {
     constexpr TreeModel m = MP::kM;
+    LoadTrunk(c, s, 1 | 2);
     const E h = E(m.timestep);
     const E B = stage == 0 || stage == 3 ? E(1.0 / 6.0) : E(1.0 / 3.0);
     const E A = stage == 2 ? E(1.0) : E(0.5);
@@ -1723,6 +1749,8 @@ struct Hum4 {
       });
       IntegratePos(k.x0q, k.x0ql, k.accq, k.accql, h, live, s.qt, s.ql);
     }
+      StoreTrunk(c, s, 1 | 2);
+    EPA_LDS_FENCE();
   }
 
   // mj_rnePostConstraint, cfrc_ext part: contact forces of the LAST forward evaluation as spatial

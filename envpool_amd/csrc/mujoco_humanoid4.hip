@@ -46,7 +46,8 @@ constexpr int kGeoSlots = 102, kTcdSlots = 54, kLttSlots = 45 + 9;
 constexpr int kUSlots = kGeoSlots + kTcdSlots;  // = Hum4::kFSlots: the PGS stage's shared block
 constexpr int kLdsTab = 0, kLdsU = H::kNLC * 4, kLdsGeo = kLdsU, kLdsTcd = kLdsU + kGeoSlots * 16, kLdsSh = kLdsU;
 constexpr int kLdsLtt = kLdsU + kUSlots * 16;
-constexpr int kLdsElems = kLdsLtt + kLttSlots * 16;  // 30 KB
+constexpr int kLdsStt = kLdsLtt + kLttSlots * 16;  // the trunk part of the env's state (Hum4::kSttSlots)
+constexpr int kLdsElems = kLdsStt + 31 * 16;  // 34 KB (+ 3.6 KB of candidate tables)
 
 template <int K>
 __device__ __forceinline__ double Bcast(double x) {  // lane K of the quad
@@ -86,6 +87,8 @@ struct DevCtx {
     *pos = {GeoGet(s), GeoGet(s + 1), GeoGet(s + 2)};
     *axis = {GeoGet(s + 3), GeoGet(s + 4), GeoGet(s + 5)};
   }
+  __device__ void SttPut(int i, double v) { lds[kLdsStt + i * 16 + quad] = v; }
+  __device__ double SttGet(int i) const { return lds[kLdsStt + i * 16 + quad]; }
   __device__ void TcdPut(int i, double v) { lds[kLdsTcd + i * 16 + quad] = v; }
   __device__ double TcdGet(int i) const { return lds[kLdsTcd + i * 16 + quad]; }
   __device__ void LttPut(int i, double v) { lds[kLdsLtt + i * 16 + quad] = v; }
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
       s.ul[k] = dof[k] >= 0 ? act[CtrlOfDof(dof[k] >= 0 ? dof[k] : 9)] : 0.0;
     });
   }
+  Eng::StoreTrunk(c, s, 15);
   // reset envs: mj_forward once; stepping envs: frame_skip x (4 RK stages).  Every env runs the
   // wave's trip count with its own state updates predicated (no divergent control flow).
   const int nfwd = reset ? 1 : 4 * task.frame_skip;
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
         rk.accvl[j] = c.Ws(k++);
       });
     }
-    Eng::RkAdvance(s, rk, it & 3, live && !reset, at, al);
+    Eng::RkAdvance(c, s, rk, it & 3, live && !reset, at, al);
     if ((it & 3) != 3) {
       int k = kWsRk;
       mj::static_for<0, 10>([&](auto ic) { c.Ws(k++) = rk.x0q[decltype(ic)::value]; });
@@ -323,6 +327,7 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
       });
     }
   }
+  Eng::LoadTrunk(c, s, 7);
   // mj_rnePostConstraint after the last mj_step (mujoco_env.h:145-147)
   const bool wrench = task.post_constraint != 0;
   H::Sp6<double> ext_t[H::kNTB + 1], ext_l[3];

@@ -30,6 +30,9 @@ struct HostCtx {
     for (int i = 0; i < 7; ++i) yd[i] = rows[r][i];
   }
   const typename H::Hum4<MP, HostCtx<MP>>::Tabs& T() const { return H::Hum4<MP, HostCtx<MP>>::kT; }
+  double stt[31];
+  void SttPut(int i, double v) { stt[i] = v; }
+  double SttGet(int i) const { return stt[i]; }
   double tcd[54], ltt[45], dt[9];
   void TcdPut(int i, double v) { tcd[i] = v; }
   double TcdGet(int i) const { return tcd[i]; }
@@ -209,6 +212,7 @@ static void Step4(const double* q, const double* v, const double* warm, const do
   SplitV(warm, s.wt, s.wl);
   SplitV(ud, tmp, s.ul);
   for (int i = 0; i < 3; ++i) s.ut[i] = ud[6 + i];
+  Eng::StoreTrunk(c, s, 15);
   double at[9];
   Q4<double> al[4];
   typename Eng::RowCount rc{0, 0, 0};
@@ -217,9 +221,10 @@ static void Step4(const double* q, const double* v, const double* warm, const do
   for (int k = 0; k < nsub; ++k) {
     for (int stage = 0; stage < 4; ++stage) {
       rc = Eng::Forward(c, s, f, true, at, al, 0, [](const H::Fwd<Q4<double>>&) {}, stat);
-      Eng::RkAdvance(s, rk, stage, true, at, al);
+      Eng::RkAdvance(c, s, rk, stage, true, at, al);
     }
   }
+  Eng::LoadTrunk(c, s, 7);
   H::Sp6<double> ext_t[4];
   H::Sp6<Q4<double>> ext_l[3];
   if (post_constraint) Eng::ContactWrench(c, f, rc, ext_t, ext_l);
