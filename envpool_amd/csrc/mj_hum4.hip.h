@@ -1393,10 +1393,7 @@ struct Hum4 {
   };
   static EPA_HD void LoadRowConst(Ctx& c, int r, RowConst& t) {
     c.RowGet(r, t.yd);
-    t.arr = c.RsGet(r, kRsArr);
-    t.R = c.RsGet(r, kRsR);
-    t.b = c.RsGet(r, kRsB);
-    t.ainv = c.RsGet(r, kRsAinv);
+    c.RsGet4(r, &t.arr, &t.R, &t.b, &t.ainv);  // one load per lane + broadcasts: the sweep is HBM bound
   }
   // nrow_e: this env's rows (0 .. nrow_e - 1, compact); the wave walks max-over-envs rows, an env
   // treats the rows beyond its own as absent (its slots there hold stale data)

@@ -36,7 +36,7 @@ struct StandupMP {
 constexpr int kBlock = 64, kEnvsPerBlock = 16;
 // rows: 17 limits + 4 x 29 floor contacts + 109 pairs; contacts: 29 + 109
 constexpr int kMaxRows = 17 + 4 * 29 + 128, kMaxCon = 29 + 128;
-constexpr int kRowSlots = 12, kRecSlots = 2;
+constexpr int kRowSlots = 13, kRecSlots = 2;
 constexpr int kRkSlots = 10 + 3 * H::kNT + 4 * H::kNS;  // RK4 bookkeeping of the running mj_step
 constexpr int kWsRk = kMaxRows * kRowSlots + kMaxCon * kRecSlots;
 constexpr int kWsSlots = kWsRk + kRkSlots;  // per lane
@@ -107,8 +107,20 @@ struct DevCtx {
   __device__ void RowGet(int r, double* yd) const {
     mj::static_for<0, 7>([&](auto ic) { yd[decltype(ic)::value] = Ws(r * kRowSlots + decltype(ic)::value); });
   }
-  __device__ void RsPut(int r, int k, double v) { Ws(r * kRowSlots + 7 + k) = v; }
+  // (+ slot 12: scalars 1..4 packed, lane l holds number 1 + l -- what the streaming sweep reads)
+  __device__ void RsPut(int r, int k, double v) {
+    Ws(r * kRowSlots + 7 + k) = v;
+    if (k - 1 == l) Ws(r * kRowSlots + 12) = v;
+  }
   __device__ double RsGet(int r, int k) const { return Ws(r * kRowSlots + 7 + k); }
+  // scalars 1..4 (A_rr + R_r, R_r, b_r, 1 / (A_rr + R_r)) from the packed slot: one 512-byte line per row
+  __device__ void RsGet4(int r, double* arr, double* R, double* b, double* ainv) const {
+    const double v = Ws(r * kRowSlots + 12);
+    *arr = Bcast<0>(v);
+    *R = Bcast<1>(v);
+    *b = Bcast<2>(v);
+    *ainv = Bcast<3>(v);
+  }
   __device__ double RsGetLane(int r0, int k) const { return Ws((r0 + l) * kRowSlots + 7 + k); }  // row r0 + lane
   __device__ double RowIndexLane(int r0) const { return (double)(r0 + l); }
   __device__ void RecPut(int t, int k, double v) {

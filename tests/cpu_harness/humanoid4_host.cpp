@@ -44,6 +44,12 @@ struct HostCtx {
   void ShPut(int slot, double v) { sh[slot] = v; }
   double ShGet(int slot) const { return sh[slot]; }
   void RsPut(int r, int k, double v) { rs[r][k] = v; }
+  void RsGet4(int r, double* arr, double* R, double* b, double* ainv) const {
+    *arr = rs[r][1];
+    *R = rs[r][2];
+    *b = rs[r][3];
+    *ainv = rs[r][4];
+  }
   V RsGetLane(int r0, int k) const {  // scalar k of row r0 + lane
     V x;
     for (int l = 0; l < 4; ++l) x.v[l] = rs[r0 + l][k];

@@ -17,7 +17,7 @@ prefix = sys.argv[1] if len(sys.argv) > 1 else "r1f"
 num_envs = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
-for path in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}_*", "summary.md"))):
+for path in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}*", "summary.md"))):
     text = open(path).read()
     m = re.search(r"## PMC per launch \(mean over launches\): (.+)", text)
     if not m:
