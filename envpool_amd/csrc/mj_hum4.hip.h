@@ -60,7 +60,6 @@ using mj::Sum4;
 constexpr int kNT = 9;        // trunk dofs 0..8 (free joint 0..5, abdomen z, y, x)
 constexpr int kNS = 4;        // limb dof slots of a lane: A0 A1 A2 (first limb body), B (second)
 constexpr int kNLimb = 4;
-constexpr int kRegRows = 12;  // rows (per env) that the register-resident PGS holds
 constexpr int kNTB = 3;       // trunk bodies 1, 2, 3
 
 // ---- the model, re-indexed by limb ----------------------------------------------------------
@@ -1468,35 +1467,64 @@ struct Hum4 {
   // Up to kRegRows rows per env.  A PGS row visit is ONE dependent chain (residual -> clamped force ->
   // cost change -> accept) and a wave runs alone on its SIMD, so the chain length is the cost of a
   // visit.  Working on  z = sum f y / D  puts a 7-term dot product, a quad reduction and an LDS
-  // round trip on it (~60 instructions, ~900 cycles measured).  Instead the rows are loaded once,
-  // A + R = Y D^-1 Y' + diag(R) is formed in registers -- lane l of the quad owns the rows r with
-  // (r & 3) == l: 3 x 12 entries -- and the residuals S_r = b_r + sum_c (A + R)_rc f_c are kept UP TO
-  // DATE: a visit reads S_r, decides, broadcasts the accepted change (DPP) and every lane adds
-  // (A + R)_{its rows, r} * change to its three residuals.  ~15 dependent operations per visit.
+  // round trip on it (~60 instructions, ~900 cycles measured).  Instead A + R = Y D^-1 Y' + diag(R)
+  // is formed once -- the rows stream past four register-resident columns, the entries are staged in
+  // the env's shared block (LDS) -- then lane l of the quad takes the rows r with (r & 3) == l into
+  // registers (kOwn x kRegRows entries) and the residuals S_r = b_r + sum_c (A + R)_rc f_c are kept UP
+  // TO DATE: a visit reads S_r, decides, broadcasts the accepted change (DPP) and every lane adds
+  // (A + R)_{its rows, r} * change to its residuals.  ~15 dependent operations per visit.
   static constexpr int kFSlots = 156;  // capacity of the shared block (Ctx::ShGet / ShPut)
+  // rows (per env) the register-resident PGS holds: MP::kRegRows (a multiple of 4; Humanoid 12: the
+  // benchmark never has more; HumanoidStandup 16: lying on the floor it often has)
+  static constexpr int kRegRows = MP::kRegRows;
   static constexpr int kOwn = kRegRows / 4;
+  static_assert(kRegRows * (kRegRows + 1) / 2 <= kFSlots, "A + R is staged in the shared block");
+  static EPA_HD constexpr int Tri(int r, int cc) { return r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r; }
   static EPA_HD void SolvePgsR(Ctx& c, const Fwd<V>& f, int nrow_e, const V* zsd, E cost, E* at, V* al, int max_iter,
                                int* stat) {
     constexpr TreeModel m = MP::kM;
+    const int nrow = WaveMax(nrow_e);
     V dd[kND];
     DinvD(c, f, dd);
     const bool cold = ColdStart(zsd, dd, cost);
-    V y[kRegRows][kND];
-    static_for<0, kRegRows>([&](auto rc0) {
-      constexpr int r = decltype(rc0)::value;
+    // A_rc = y_r . (y_c / D) for c < r, four columns at a time, one row of lookahead; rows an env does
+    // not have count as zero
+    auto load = [&](int r, V* y) {
+      c.RowGet(r, y);
       const bool valid = r < nrow_e;
-      if (AnyWave(valid)) {
-        c.RowGet(r, y[r]);
-        static_for<0, kND>([&](auto ic) { y[r][decltype(ic)::value] = Sel(valid, y[r][decltype(ic)::value], V(0)); });
-      } else {
-        static_for<0, kND>([&](auto ic) { y[r][decltype(ic)::value] = V(0); });
+      static_for<0, kND>([&](auto ic) { y[decltype(ic)::value] = Sel(valid, y[decltype(ic)::value], V(0)); });
+    };
+    for (int c0 = 0; c0 < nrow; c0 += 4) {
+      V w[4][kND];
+      static_for<0, 4>([&](auto kc) { load(c0 + decltype(kc)::value < nrow ? c0 + decltype(kc)::value : c0, w[decltype(kc)::value]); });
+      static_for<0, 4>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        V wk[kND];
+        static_for<0, kND>([&](auto ic) { wk[decltype(ic)::value] = w[k][decltype(ic)::value] * dd[decltype(ic)::value]; });
+        static_for<k + 1, 4>([&](auto rc4) {
+          constexpr int r = decltype(rc4)::value;
+          const E a = DotD(w[r], wk);
+          if (c0 + r < nrow) c.ShPut(Tri(c0 + r, c0 + k), a);
+        });
+        static_for<0, kND>([&](auto ic) { w[k][decltype(ic)::value] = wk[decltype(ic)::value]; });
+      });
+      if (c0 + 4 < nrow) {
+        V nx[kND];
+        load(c0 + 4, nx);
+        for (int r = c0 + 4; r < nrow; ++r) {
+          V y[kND];
+          static_for<0, kND>([&](auto ic) { y[decltype(ic)::value] = nx[decltype(ic)::value]; });
+          load(r + 1 < nrow ? r + 1 : r, nx);
+          static_for<0, 4>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const E a = DotD(y, w[k]);
+            if (c0 + k < nrow) c.ShPut(Tri(r, c0 + k), a);
+          });
+        }
       }
-    });
-    // the scalars of the lane's own rows r = 4 k + l (lane level), absent rows: inert
+    }
+    // the lane's own rows r = 4 k + l: scalars from the rows' records, (A + R)_r* from the shared block
     V fo[kOwn], ainv[kOwn], arr[kOwn], S[kOwn], AR[kOwn][kRegRows];
-    static_for<0, kOwn>([&](auto kc) {
-      static_for<0, kRegRows>([&](auto cc) { AR[decltype(kc)::value][decltype(cc)::value] = V(0); });
-    });
     static_for<0, kOwn>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       const BV have = c.RowIndexLane(4 * k) < V(nrow_e);  // 4 k + lane < nrow_e
@@ -1504,32 +1532,13 @@ struct Hum4 {
       ainv[k] = Sel(have, c.RsGetLane(4 * k, kRsAinv), V(0));
       arr[k] = Sel(have, c.RsGetLane(4 * k, kRsArr), V(0));
       S[k] = Sel(have, c.RsGetLane(4 * k, kRsB), V(0));
-    });
-    // A_rc = y_r . (y_c / D); the owner lanes of r and of c keep it
-    static_for<0, kRegRows>([&](auto cc) {
-      constexpr int cidx = decltype(cc)::value;
-      if (AnyWave(cidx < nrow_e)) {
-        V w[kND];
-        static_for<0, kND>([&](auto ic) { w[decltype(ic)::value] = y[cidx][decltype(ic)::value] * dd[decltype(ic)::value]; });
-        static_for<cidx + 1, kRegRows>([&](auto rc0) {
-          constexpr int r = decltype(rc0)::value;
-          if (AnyWave(r < nrow_e)) {
-            const E a = DotD(y[r], w);
-            AR[r >> 2][cidx] = Sel(LaneOps<V>::Is(r & 3), V(a), AR[r >> 2][cidx]);
-            AR[cidx >> 2][r] = Sel(LaneOps<V>::Is(cidx & 3), V(a), AR[cidx >> 2][r]);
-          } else {
-            AR[r >> 2][cidx] = Sel(LaneOps<V>::Is(r & 3), V(0), AR[r >> 2][cidx]);
-            AR[cidx >> 2][r] = Sel(LaneOps<V>::Is(cidx & 3), V(0), AR[cidx >> 2][r]);
-          }
-        });
-      } else {
-        static_for<cidx + 1, kRegRows>([&](auto rc0) {
-          constexpr int r = decltype(rc0)::value;
-          AR[r >> 2][cidx] = Sel(LaneOps<V>::Is(r & 3), V(0), AR[r >> 2][cidx]);
-          AR[cidx >> 2][r] = Sel(LaneOps<V>::Is(cidx & 3), V(0), AR[cidx >> 2][r]);
-        });
-      }
-      AR[cidx >> 2][cidx] = Sel(LaneOps<V>::Is(cidx & 3), arr[cidx >> 2], AR[cidx >> 2][cidx]);  // A_rr + R_r
+      static_for<0, kRegRows>([&](auto cc) {
+        constexpr int cidx = decltype(cc)::value;
+        // (entries of rows / columns beyond the wave's row count are stale but finite: they only
+        // ever meet a zero force)
+        const V a = c.ShGetTriLane(4 * k, cidx);
+        AR[k][cidx] = Sel(c.RowIndexLane(4 * k) == V(cidx), arr[k], Sel(have, a, V(0)));
+      });
     });
     // S_r = b_r + sum_c (A + R)_rc f_c at the start forces
     static_for<0, kRegRows>([&](auto cc) {
@@ -1564,14 +1573,20 @@ struct Hum4 {
       done = done || improvement * scale < E(1e-8);
       if (!AnyWave(!done)) break;
     }
-    // z = D^-1 sum_r f_r y_r; efc_force goes back to the rows (mj_rnePostConstraint)
+    // z = D^-1 sum_r f_r y_r (the rows stream past once more); efc_force goes back to the rows
+    // (mj_rnePostConstraint)
+    E fr[kRegRows];
+    static_for<0, kRegRows>([&](auto rc0) { fr[decltype(rc0)::value] = BcastQS<decltype(rc0)::value & 3>(fo[decltype(rc0)::value >> 2]); });
     V zd[kND];
     static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] = V(0); });
     static_for<0, kRegRows>([&](auto rc0) {
       constexpr int r = decltype(rc0)::value;
-      const E fr = BcastQS<r & 3>(fo[r >> 2]);
-      if (r < nrow_e) c.RsPut(r, kRsF, fr);
-      static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] += V(fr) * y[r][decltype(ic)::value]; });
+      if (AnyWave(r < nrow_e)) {
+        V y[kND];
+        load(r, y);
+        if (r < nrow_e) c.RsPut(r, kRsF, fr[r]);
+        static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] += V(fr[r]) * y[decltype(ic)::value]; });
+      }
     });
     static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] *= dd[decltype(ic)::value]; });
     Finish(c, f, zd, at, al);

@@ -28,9 +28,11 @@ namespace T = mj::tree;
 
 struct HumanoidMP {
   static constexpr T::TreeModel kM = kHumanoidModelConst;
+  static constexpr int kRegRows = 12;
 };
 struct StandupMP {
   static constexpr T::TreeModel kM = kHumanoidStandupModelConst;
+  static constexpr int kRegRows = 16;
 };
 
 constexpr int kBlock = 64, kEnvsPerBlock = 16;
@@ -123,6 +125,10 @@ struct DevCtx {
   }
   __device__ double RsGetLane(int r0, int k) const { return Ws((r0 + l) * kRowSlots + 7 + k); }  // row r0 + lane
   __device__ double RowIndexLane(int r0) const { return (double)(r0 + l); }
+  __device__ double ShGetTriLane(int r0, int cc) const {  // entry (r0 + lane, cc) of the packed symmetric matrix
+    const int r = r0 + l;
+    return ShGet(r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r);
+  }
   __device__ void RecPut(int t, int k, double v) {
     if ((k & 3) == l) Ws(kMaxRows * kRowSlots + t * kRecSlots + (k >> 2)) = v;
   }

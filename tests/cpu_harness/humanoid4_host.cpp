@@ -11,8 +11,8 @@
 namespace T = epa::mj::tree;
 namespace H = epa::mj::hum4;
 using epa::mj::Q4;
-struct Walk { static constexpr T::TreeModel kM = kHumanoidModelConst; };
-struct Stand { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; };
+struct Walk { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 12; };
+struct Stand { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 16; };
 
 template <class MP>
 struct HostCtx {
@@ -53,6 +53,14 @@ struct HostCtx {
   V RsGetLane(int r0, int k) const {  // scalar k of row r0 + lane
     V x;
     for (int l = 0; l < 4; ++l) x.v[l] = rs[r0 + l][k];
+    return x;
+  }
+  V ShGetTriLane(int r0, int cc) const {  // entry (r0 + lane, cc) of the packed symmetric matrix
+    V x;
+    for (int l = 0; l < 4; ++l) {
+      const int r = r0 + l;
+      x.v[l] = sh[r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r];
+    }
     return x;
   }
   V RowIndexLane(int r0) const {
