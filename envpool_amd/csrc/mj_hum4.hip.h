@@ -1625,6 +1625,8 @@ struct Hum4 {
     // The trunk part of the state (31 numbers, env level) lives in the env's shared block between
     // the stages (Ctx::SttGet / SttPut) and every stage loads what it reads: replicated in the four
     // lanes' registers through the whole pass it costs 62 VGPRs at the register peaks.
+    c.Refresh();  // (device: keeps the loop-invariant LDS reads -- 112 limb constants -- from being hoisted out
+                  // of the step loop and spilled)
     LoadTrunk(c, s, 1);
     Position(c, s.qt, s.ql, f);
     EMask act;

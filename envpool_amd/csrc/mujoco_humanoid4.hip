@@ -70,6 +70,14 @@ struct DevCtx {
   double* ws;  // the wave's block, [slot][64]
   int lane, l, quad;
 
+  // the lane coordinates become opaque to the optimiser: what is read through them afterwards cannot
+  // be hoisted above this point
+  __device__ void Refresh() {
+    asm volatile("" : "+v"(l), "+v"(quad), "+v"(lane));
+    l &= 3;
+    quad &= 15;
+    lane &= 63;
+  }
   __device__ double LC(int idx) const { return lds[kLdsTab + idx * 4 + l]; }
   // geoms 1..17, 6 slots each, [slot][quad]
   __device__ void GeoPut(int slot, double v) { lds[kLdsGeo + (slot - 6) * 16 + quad] = v; }

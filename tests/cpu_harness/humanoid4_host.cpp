@@ -30,6 +30,7 @@ struct HostCtx {
     for (int i = 0; i < 7; ++i) yd[i] = rows[r][i];
   }
   const typename H::Hum4<MP, HostCtx<MP>>::Tabs& T() const { return H::Hum4<MP, HostCtx<MP>>::kT; }
+  void Refresh() {}
   double stt[31];
   void SttPut(int i, double v) { stt[i] = v; }
   double SttGet(int i) const { return stt[i]; }
