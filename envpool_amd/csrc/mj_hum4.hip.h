@@ -1696,74 +1696,68 @@ struct Hum4 {
     });
   }
 
-  // RK4 bookkeeping of one mj_step (mj_RungeKutta, N = 4)
-  struct Rk {
-    E x0q[10], x0v[kNT], accq[kNT], accv[kNT];
-    V x0ql[kNS], x0vl[kNS], accql[kNS], accvl[kNS];
-  };
+  // RK4 bookkeeping of one mj_step (mj_RungeKutta, N = 4): X0 and the weighted sums of the stage
+  // derivatives, kept by the Ctx between the stages (RkGet / RkPut: trunk numbers, env level;
+  // RkGetL / RkPutL: the lane's limb numbers) and touched element by element -- loaded as one
+  // block next to the state they cost ~100 registers at the end of every forward pass.
+  enum { kRkX0q = 0, kRkX0v = 10, kRkAccq = 19, kRkAccv = 28, kRkTrunk = 37,
+         kRkX0ql = 0, kRkX0vl = 4, kRkAccql = 8, kRkAccvl = 12, kRkLimb = 16 };
   // One stage boundary, called after the forward evaluation of stage `stage` (0: at the start
   // state) with its qacc (at, al).  Stages 0..2 move the state to the next stage point, stage 3
   // finishes the step.  `live`: envs that really integrate.
-  static EPA_HD void RkAdvance(Ctx& c, State& s, Rk& k, int stage, bool live, const E* at, const V* al) {
+  static EPA_HD void RkAdvance(Ctx& c, State& s, int stage, bool live, const E* at, const V* al) {
     constexpr TreeModel m = MP::kM;
     LoadTrunk(c, s, 1 | 2);
     const E h = E(m.timestep);
     const E B = stage == 0 || stage == 3 ? E(1.0 / 6.0) : E(1.0 / 3.0);
     const E A = stage == 2 ? E(1.0) : E(0.5);
-    if (stage == 0) {
-      static_for<0, 10>([&](auto ic) { k.x0q[decltype(ic)::value] = s.qt[decltype(ic)::value]; });
-      static_for<0, kNS>([&](auto sc) { k.x0ql[decltype(sc)::value] = s.ql[decltype(sc)::value]; });
-      static_for<0, kNT>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        k.x0v[i] = s.vt[i];
-        k.accq[i] = B * s.vt[i];
-        k.accv[i] = B * at[i];
-      });
-      static_for<0, kNS>([&](auto sc) {
-        constexpr int i = decltype(sc)::value;
-        k.x0vl[i] = s.vl[i];
-        k.accql[i] = V(B) * s.vl[i];
-        k.accvl[i] = V(B) * al[i];
-      });
-    } else {
-      static_for<0, kNT>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        k.accq[i] += B * s.vt[i];
-        k.accv[i] += B * at[i];
-      });
-      static_for<0, kNS>([&](auto sc) {
-        constexpr int i = decltype(sc)::value;
-        k.accql[i] += V(B) * s.vl[i];
-        k.accvl[i] += V(B) * al[i];
-      });
-    }
-    if (stage < 3) {
-      // X[i+1] = X0 + h A (Xv[i], F[i])
-      E dq[kNT];
-      V dql[kNS];
-      static_for<0, kNT>([&](auto ic) { dq[decltype(ic)::value] = A * s.vt[decltype(ic)::value]; });
-      static_for<0, kNS>([&](auto sc) { dql[decltype(sc)::value] = V(A) * s.vl[decltype(sc)::value]; });
-      IntegratePos(k.x0q, k.x0ql, dq, dql, h, live, s.qt, s.ql);
-      static_for<0, kNT>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        s.vt[i] = live ? k.x0v[i] + h * A * at[i] : s.vt[i];
-      });
-      static_for<0, kNS>([&](auto sc) {
-        constexpr int i = decltype(sc)::value;
-        s.vl[i] = Sel(live, k.x0vl[i] + V(h * A) * al[i], s.vl[i]);
-      });
-    } else {
-      static_for<0, kNT>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        s.vt[i] = live ? k.x0v[i] + h * k.accv[i] : s.vt[i];
-      });
-      static_for<0, kNS>([&](auto sc) {
-        constexpr int i = decltype(sc)::value;
-        s.vl[i] = Sel(live, k.x0vl[i] + V(h) * k.accvl[i], s.vl[i]);
-      });
-      IntegratePos(k.x0q, k.x0ql, k.accq, k.accql, h, live, s.qt, s.ql);
-    }
-      StoreTrunk(c, s, 1 | 2);
+    const bool first = stage == 0, last = stage == 3;
+    // velocities and their weighted sums; dq: what mj_integratePos advances the positions by
+    E dq[kNT];
+    V dql[kNS];
+    static_for<0, kNT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if (first) c.RkPut(kRkX0v + i, s.vt[i]);
+      const E x0v = first ? s.vt[i] : c.RkGet(kRkX0v + i);
+      const E accq = (first ? E(0) : c.RkGet(kRkAccq + i)) + B * s.vt[i];
+      const E accv = (first ? E(0) : c.RkGet(kRkAccv + i)) + B * at[i];
+      if (!last) {
+        c.RkPut(kRkAccq + i, accq);
+        c.RkPut(kRkAccv + i, accv);
+      }
+      dq[i] = last ? accq : A * s.vt[i];
+      const E vn = last ? x0v + h * accv : x0v + h * A * at[i];
+      s.vt[i] = live ? vn : s.vt[i];
+    });
+    static_for<0, kNS>([&](auto sc) {
+      constexpr int i = decltype(sc)::value;
+      if (first) c.RkPutL(kRkX0vl + i, s.vl[i]);
+      const V x0v = first ? s.vl[i] : c.RkGetL(kRkX0vl + i);
+      const V accq = (first ? V(0) : c.RkGetL(kRkAccql + i)) + V(B) * s.vl[i];
+      const V accv = (first ? V(0) : c.RkGetL(kRkAccvl + i)) + V(B) * al[i];
+      if (!last) {
+        c.RkPutL(kRkAccql + i, accq);
+        c.RkPutL(kRkAccvl + i, accv);
+      }
+      dql[i] = last ? accq : V(A) * s.vl[i];
+      const V vn = last ? x0v + V(h) * accv : x0v + V(h * A) * al[i];
+      s.vl[i] = Sel(live, vn, s.vl[i]);
+    });
+    // positions: X0 (+) h dq
+    E x0q[10];
+    V x0ql[kNS];
+    static_for<0, 10>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if (first) c.RkPut(kRkX0q + i, s.qt[i]);
+      x0q[i] = first ? s.qt[i] : c.RkGet(kRkX0q + i);
+    });
+    static_for<0, kNS>([&](auto sc) {
+      constexpr int i = decltype(sc)::value;
+      if (first) c.RkPutL(kRkX0ql + i, s.ql[i]);
+      x0ql[i] = first ? s.ql[i] : c.RkGetL(kRkX0ql + i);
+    });
+    IntegratePos(x0q, x0ql, dq, dql, h, live, s.qt, s.ql);
+    StoreTrunk(c, s, 1 | 2);
     EPA_LDS_FENCE();
   }
 

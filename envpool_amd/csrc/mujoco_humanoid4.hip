@@ -133,6 +133,11 @@ struct DevCtx {
   }
   __device__ double RsGetLane(int r0, int k) const { return Ws((r0 + l) * kRowSlots + 7 + k); }  // row r0 + lane
   __device__ double RowIndexLane(int r0) const { return (double)(r0 + l); }
+  // RK4 bookkeeping (Hum4::RkAdvance): 37 trunk numbers (every lane its copy) + 16 limb numbers
+  __device__ void RkPut(int i, double v) { Ws(kWsRk + i) = v; }
+  __device__ double RkGet(int i) const { return Ws(kWsRk + i); }
+  __device__ void RkPutL(int i, double v) { Ws(kWsRk + 37 + i) = v; }
+  __device__ double RkGetL(int i) const { return Ws(kWsRk + 37 + i); }
   __device__ double ShGetTriLane(int r0, int cc) const {  // entry (r0 + lane, cc) of the packed symmetric matrix
     const int r = r0 + l;
     return ShGet(r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r);
@@ -315,43 +320,7 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
         }
       });
     }, stat);
-    // RK4 bookkeeping lives in the wave's HBM block between the stages (53 numbers per lane)
-    typename Eng::Rk rk;
-    if ((it & 3) != 0) {
-      int k = kWsRk;
-      mj::static_for<0, 10>([&](auto ic) { rk.x0q[decltype(ic)::value] = c.Ws(k++); });
-      mj::static_for<0, H::kNT>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        rk.x0v[j] = c.Ws(k++);
-        rk.accq[j] = c.Ws(k++);
-        rk.accv[j] = c.Ws(k++);
-      });
-      mj::static_for<0, H::kNS>([&](auto sc) {
-        constexpr int j = decltype(sc)::value;
-        rk.x0ql[j] = c.Ws(k++);
-        rk.x0vl[j] = c.Ws(k++);
-        rk.accql[j] = c.Ws(k++);
-        rk.accvl[j] = c.Ws(k++);
-      });
-    }
-    Eng::RkAdvance(c, s, rk, it & 3, live && !reset, at, al);
-    if ((it & 3) != 3) {
-      int k = kWsRk;
-      mj::static_for<0, 10>([&](auto ic) { c.Ws(k++) = rk.x0q[decltype(ic)::value]; });
-      mj::static_for<0, H::kNT>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        c.Ws(k++) = rk.x0v[j];
-        c.Ws(k++) = rk.accq[j];
-        c.Ws(k++) = rk.accv[j];
-      });
-      mj::static_for<0, H::kNS>([&](auto sc) {
-        constexpr int j = decltype(sc)::value;
-        c.Ws(k++) = rk.x0ql[j];
-        c.Ws(k++) = rk.x0vl[j];
-        c.Ws(k++) = rk.accql[j];
-        c.Ws(k++) = rk.accvl[j];
-      });
-    }
+    Eng::RkAdvance(c, s, it & 3, live && !reset, at, al);
   }
   Eng::LoadTrunk(c, s, 7);
   // mj_rnePostConstraint after the last mj_step (mujoco_env.h:145-147)

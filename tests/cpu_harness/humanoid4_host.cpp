@@ -31,6 +31,12 @@ struct HostCtx {
   }
   const typename H::Hum4<MP, HostCtx<MP>>::Tabs& T() const { return H::Hum4<MP, HostCtx<MP>>::kT; }
   void Refresh() {}
+  double rk_t[37];
+  Q4<double> rk_l[16];
+  void RkPut(int i, double v) { rk_t[i] = v; }
+  double RkGet(int i) const { return rk_t[i]; }
+  void RkPutL(int i, V v) { rk_l[i] = v; }
+  V RkGetL(int i) const { return rk_l[i]; }
   double stt[31];
   void SttPut(int i, double v) { stt[i] = v; }
   double SttGet(int i) const { return stt[i]; }
@@ -217,7 +223,6 @@ static void Step4(const double* q, const double* v, const double* warm, const do
   static C c;  // (large)
   H::Fwd<Q4<double>> f;
   typename Eng::State s;
-  typename Eng::Rk rk;
   for (int i = 0; i < 10; ++i) s.qt[i] = q[i];
   double qd[23], ud[23] = {0}, tmp[9];
   for (int d = 0; d < 23; ++d) qd[d] = d < 6 ? 0.0 : q[d + 1];
@@ -236,7 +241,7 @@ static void Step4(const double* q, const double* v, const double* warm, const do
   for (int k = 0; k < nsub; ++k) {
     for (int stage = 0; stage < 4; ++stage) {
       rc = Eng::Forward(c, s, f, true, at, al, 0, [](const H::Fwd<Q4<double>>&) {}, stat);
-      Eng::RkAdvance(c, s, rk, stage, true, at, al);
+      Eng::RkAdvance(c, s, stage, true, at, al);
     }
   }
   Eng::LoadTrunk(c, s, 7);
