@@ -38,7 +38,7 @@ struct StandupMP {
 constexpr int kBlock = 64, kEnvsPerBlock = 16;
 // rows: 17 limits + 4 x 29 floor contacts + 109 pairs; contacts: 29 + 109
 constexpr int kMaxRows = 17 + 4 * 29 + 128, kMaxCon = 29 + 128;
-constexpr int kRowSlots = 13, kRecSlots = 2;
+constexpr int kRowSlots = 9, kRecSlots = 2;
 constexpr int kRkSlots = 10 + 3 * H::kNT + 4 * H::kNS;  // RK4 bookkeeping of the running mj_step
 constexpr int kWsRk = kMaxRows * kRowSlots + kMaxCon * kRecSlots;
 constexpr int kWsSlots = kWsRk + kRkSlots;  // per lane
@@ -109,29 +109,41 @@ struct DevCtx {
   __device__ void ShPut(int slot, double v) { lds[kLdsSh + slot * 16 + quad] = v; }
   __device__ double ShGet(int slot) const { return lds[kLdsSh + slot * 16 + quad]; }
   __device__ double& Ws(int slot) const { return ws[(size_t)slot * 64 + lane]; }
-  // row r: slots 0..6 the lane's share of y (Hum4::kND), 7..11 the row's five scalars (every lane
-  // keeps its own copy: a lane only ever reads back what it wrote itself)
+  // row r: slots 0..6 the lane's share of y (Hum4::kND); slot 7 the row's scalars 1..4 (A_rr + R_r,
+  // R_r, b_r, 1 / (A_rr + R_r)), lane l of the quad holding number 1 + l; slot 8 its force f (every
+  // lane a copy).  A lane only ever reads back what it wrote itself; the other lanes' numbers
+  // arrive by DPP.
   __device__ void RowPut(int r, const double* yd) {
     mj::static_for<0, 7>([&](auto ic) { Ws(r * kRowSlots + decltype(ic)::value) = yd[decltype(ic)::value]; });
   }
   __device__ void RowGet(int r, double* yd) const {
     mj::static_for<0, 7>([&](auto ic) { yd[decltype(ic)::value] = Ws(r * kRowSlots + decltype(ic)::value); });
   }
-  // (+ slot 12: scalars 1..4 packed, lane l holds number 1 + l -- what the streaming sweep reads)
   __device__ void RsPut(int r, int k, double v) {
-    Ws(r * kRowSlots + 7 + k) = v;
-    if (k - 1 == l) Ws(r * kRowSlots + 12) = v;
+    if (k == 0) Ws(r * kRowSlots + 8) = v;
+    else if (k - 1 == l) Ws(r * kRowSlots + 7) = v;
   }
-  __device__ double RsGet(int r, int k) const { return Ws(r * kRowSlots + 7 + k); }
-  // scalars 1..4 (A_rr + R_r, R_r, b_r, 1 / (A_rr + R_r)) from the packed slot: one 512-byte line per row
+  __device__ double RsGet(int r, int k) const {
+    if (k == 0) return Ws(r * kRowSlots + 8);
+    return mj::hum4::BcastQ(Ws(r * kRowSlots + 7), k - 1);
+  }
   __device__ void RsGet4(int r, double* arr, double* R, double* b, double* ainv) const {
-    const double v = Ws(r * kRowSlots + 12);
+    const double v = Ws(r * kRowSlots + 7);
     *arr = Bcast<0>(v);
     *R = Bcast<1>(v);
     *b = Bcast<2>(v);
     *ainv = Bcast<3>(v);
   }
-  __device__ double RsGetLane(int r0, int k) const { return Ws((r0 + l) * kRowSlots + 7 + k); }  // row r0 + lane
+  // scalar k of row r0 + lane
+  __device__ double RsGetLane(int r0, int k) const {
+    if (k == 0) return Ws((r0 + l) * kRowSlots + 8);
+    double t[4];
+    mj::static_for<0, 4>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      t[j] = mj::hum4::BcastQ(Ws((r0 + j) * kRowSlots + 7), k - 1);  // scalar k of row r0 + j
+    });
+    return l == 0 ? t[0] : (l == 1 ? t[1] : (l == 2 ? t[2] : t[3]));
+  }
   __device__ double RowIndexLane(int r0) const { return (double)(r0 + l); }
   // RK4 bookkeeping (Hum4::RkAdvance): 37 trunk numbers (every lane its copy) + 16 limb numbers
   __device__ void RkPut(int i, double v) { Ws(kWsRk + i) = v; }
