@@ -39,7 +39,7 @@ constexpr int kBlock = 64, kEnvsPerBlock = 16;
 // rows: 17 limits + 4 x 29 floor contacts + 109 pairs; contacts: 29 + 109
 constexpr int kMaxRows = 17 + 4 * 29 + 128, kMaxCon = 29 + 128;
 constexpr int kRowSlots = 9, kRecSlots = 2;
-constexpr int kRkSlots = 10 + 3 * H::kNT + 4 * H::kNS;  // RK4 bookkeeping of the running mj_step
+constexpr int kRkSlots = 10 + 4 * H::kNS;  // RK4 bookkeeping of the running mj_step (trunk part spread over the quad)
 constexpr int kWsRk = kMaxRows * kRowSlots + kMaxCon * kRecSlots;
 constexpr int kWsSlots = kWsRk + kRkSlots;  // per lane
 // LDS of a wave, in doubles.  Env-level slots are [slot][quad].  The geoms + trunk cdof (Position
@@ -145,11 +145,14 @@ struct DevCtx {
     return l == 0 ? t[0] : (l == 1 ? t[1] : (l == 2 ? t[2] : t[3]));
   }
   __device__ double RowIndexLane(int r0) const { return (double)(r0 + l); }
-  // RK4 bookkeeping (Hum4::RkAdvance): 37 trunk numbers (every lane its copy) + 16 limb numbers
-  __device__ void RkPut(int i, double v) { Ws(kWsRk + i) = v; }
-  __device__ double RkGet(int i) const { return Ws(kWsRk + i); }
-  __device__ void RkPutL(int i, double v) { Ws(kWsRk + 37 + i) = v; }
-  __device__ double RkGetL(int i) const { return Ws(kWsRk + 37 + i); }
+  // RK4 bookkeeping (Hum4::RkAdvance): 37 trunk numbers, number i kept by lane i & 3 in its slot
+  // i >> 2 (read back by that lane, broadcast by DPP), + 16 limb numbers
+  __device__ void RkPut(int i, double v) {
+    if ((i & 3) == l) Ws(kWsRk + (i >> 2)) = v;
+  }
+  __device__ double RkGet(int i) const { return mj::hum4::BcastQ(Ws(kWsRk + (i >> 2)), i & 3); }
+  __device__ void RkPutL(int i, double v) { Ws(kWsRk + 10 + i) = v; }
+  __device__ double RkGetL(int i) const { return Ws(kWsRk + 10 + i); }
   __device__ double ShGetTriLane(int r0, int cc) const {  // entry (r0 + lane, cc) of the packed symmetric matrix
     const int r = r0 + l;
     return ShGet(r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r);
