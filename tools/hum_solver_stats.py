@@ -1,4 +1,4 @@
-"""Per-env solver statistics of the quad Humanoid kernel ("hum_debug" import sys, numpy as np 16: the info keys carry row
+"""Per-env solver statistics of the quad Humanoid kernel ("hum_debug" & 16: the info keys carry row
 visits, sweeps, the wave's rows and streaming solves of the env-step) -- run on a GPU box."""
 import sys, numpy as np
 sys.path.insert(0,'/root/repo')
