@@ -4,11 +4,13 @@
 // arithmetic) instead of ~150 kernel-argument scalars that have to live in —
 // and spill out of — SGPRs.  Invoked by the Makefile: `gen cheetah` -> build/mj_cheetah_consts.inc,
 // `gen walker` -> build/mj_walker_consts.inc, `gen ant` -> build/mj_ant_consts.inc,
-// `gen humanoid` -> build/mj_humanoid_consts.inc, `gen pusher` -> build/mj_pusher_consts.inc.
+// `gen humanoid` -> build/mj_humanoid_consts.inc, `gen pusher` -> build/mj_pusher_consts.inc,
+// `gen chain` -> build/mj_pendulum_consts.inc (InvertedPendulum, InvertedDoublePendulum, Reacher, Swimmer).
 #include <cstdio>
 
 #include "mj_ant_model.h"
 #include "mj_cheetah_model.h"
+#include "mj_pendulum_model.h"
 #include "mj_pusher_model.h"
 #include "mj_tree_model.h"
 
@@ -70,11 +72,39 @@ static void EmitTree(const char* name, const epa::mj::tree::TreeModel& m) {
   std::printf("};\n");
 }
 
+template <int NL, int kBase>
+static void PrintPend(const char* name, const epa::mj::pend::PendModel<double, NL, kBase>& m) {
+  std::printf("constexpr ::epa::mj::pend::PendModel<double, %d, %d> %s = {\n", NL, kBase, name);
+  S(cart_mass);
+  Arr("mass", m.mass, NL); Arr("iyy", m.iyy, NL); Arr("cx", m.cx, NL); Arr("cz", m.cz, NL);
+  Arr("lx", m.lx, NL); Arr("lz", m.lz, NL); Arr("damp", m.damp, NL + 2); Arr("arm", m.arm, NL + 2);
+  S(grav_x); S(grav_z);
+  Arr("gear", m.gear, NL + 2);
+  S(ctrl_lo); S(ctrl_hi);
+  IArr("limited", m.limited, NL + 2);
+  Arr("lo", m.lo, NL + 2); Arr("hi", m.hi, NL + 2); Arr("margin", m.margin, NL + 2);
+  Arr("dof_invw", m.dof_invw, NL + 2);
+  S(lim_K); S(lim_B); S(lim_d0); S(lim_dmax); S(lim_width);
+  S(fluid_density); S(fluid_viscosity);
+  Arr2("box", &m.box[0][0], NL, 3);
+  S(timestep); S(total_mass);
+  std::printf("};\n");
+}
+
 int main(int argc, char** argv) {
   if (argc > 1 && argv[1][0] == 'h') {  // humanoid
     std::printf("// generated by gen_mj_consts.cpp -- do not edit\n");
     EmitTree("kHumanoidModelConst", epa::mj::tree::BuildHumanoidModel(false));
     EmitTree("kHumanoidStandupModelConst", epa::mj::tree::BuildHumanoidModel(true));
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'c' && argv[1][1] == 'h' && argv[1][2] == 'a') {  // chain families
+    using namespace epa::mj::pend;
+    std::printf("// generated by gen_mj_consts.cpp -- do not edit\n");
+    PrintPend("kInvertedPendulumModelConst", BuildInvertedPendulum());
+    PrintPend("kInvertedDoublePendulumModelConst", BuildInvertedDoublePendulum());
+    PrintPend("kReacherModelConst", BuildReacher());
+    PrintPend("kSwimmerModelConst", BuildSwimmer());
     return 0;
   }
   if (argc > 1 && argv[1][0] == 'p') {  // pusher: pusher.xml and pusher_v5.xml

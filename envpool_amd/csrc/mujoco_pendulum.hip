@@ -14,6 +14,7 @@
 #include "engine.h"
 #include "mj_pendulum.hip.h"
 #include "mj_pendulum_model.h"
+#include "build/mj_pendulum_consts.inc"  // generated: k{InvertedPendulum,InvertedDoublePendulum,Reacher,Swimmer}ModelConst
 
 namespace epa {
 namespace {
@@ -41,7 +42,13 @@ constexpr int kPendBlock = 256;
 template <int NL>
 __global__ __launch_bounds__(kPendBlock) void PendStepKernel(
     PendDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
-    P::PendModel<double, NL, P::kBaseCart> m, PendTask task, mj::SolverCfg<double> scfg) {
+    PendTask task, mj::SolverCfg<double> scfg) {
+  // the model is a compile-time constant (gen_mj_consts.cpp): as a kernel argument it lived in --
+  // and spilled out of -- SGPRs (124 spills for NL = 2; see the Makefile note and tests/test_build_guard.py)
+  constexpr P::PendModel<double, NL, P::kBaseCart> m = [] {
+    if constexpr (NL == 1) return kInvertedPendulumModelConst;
+    else return kInvertedDoublePendulumModelConst;
+  }();
   constexpr int NV = NL + 1;
   const int n = cm.n;
   const int row = blockIdx.x * kPendBlock + threadIdx.x;
@@ -205,7 +212,8 @@ struct ReacherTask {
 
 __global__ __launch_bounds__(kPendBlock) void ReacherStepKernel(
     ReacherDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
-    P::PendModel<double, 2, P::kBaseFixed> m, ReacherTask task, mj::SolverCfg<double> scfg) {
+    ReacherTask task, mj::SolverCfg<double> scfg) {
+  constexpr P::PendModel<double, 2, P::kBaseFixed> m = kReacherModelConst;
   const int n = cm.n;
   const int row = blockIdx.x * kPendBlock + threadIdx.x;
   if (row >= a.k) return;
@@ -389,7 +397,7 @@ class ReacherPool : public Pool {
     int blocks = (k + kPendBlock - 1) / kPendBlock;
     const mj::SolverCfg<double> sc{50, 1e-13};
     hipLaunchKernelGGL(ReacherStepKernel, dim3(blocks), dim3(kPendBlock), 0, stream_, dev_,
-                       common_, a, static_cast<const double*>(d_action), out, model_, task_, sc);
+                       common_, a, static_cast<const double*>(d_action), out, task_, sc);
   }
 
  private:
@@ -408,7 +416,8 @@ struct SwimmerTask {
 
 __global__ __launch_bounds__(kPendBlock) void SwimmerStepKernel(
     PendDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
-    P::PendModel<double, 3, P::kBaseFree> m, SwimmerTask task, mj::SolverCfg<double> scfg) {
+    SwimmerTask task, mj::SolverCfg<double> scfg) {
+  constexpr P::PendModel<double, 3, P::kBaseFree> m = kSwimmerModelConst;
   constexpr int NV = 5;
   const int n = cm.n;
   const int row = blockIdx.x * kPendBlock + threadIdx.x;
@@ -560,10 +569,10 @@ class PendPool : public Pool {
     const mj::SolverCfg<double> sc{50, 1e-13};
     if constexpr (NL == 1) {
       hipLaunchKernelGGL(PendStepKernel<1>, dim3(blocks), dim3(kPendBlock), 0, stream_, dev_,
-                         common_, a, static_cast<const double*>(d_action), out, model1_, task_, sc);
+                         common_, a, static_cast<const double*>(d_action), out, task_, sc);
     } else {
       hipLaunchKernelGGL(PendStepKernel<2>, dim3(blocks), dim3(kPendBlock), 0, stream_, dev_,
-                         common_, a, static_cast<const double*>(d_action), out, model2_, task_, sc);
+                         common_, a, static_cast<const double*>(d_action), out, task_, sc);
     }
   }
 
@@ -623,7 +632,7 @@ class SwimmerPool : public Pool {
     int blocks = (k + kPendBlock - 1) / kPendBlock;
     const mj::SolverCfg<double> sc{50, 1e-13};
     hipLaunchKernelGGL(SwimmerStepKernel, dim3(blocks), dim3(kPendBlock), 0, stream_, dev_,
-                       common_, a, static_cast<const double*>(d_action), out, model_, task_, sc);
+                       common_, a, static_cast<const double*>(d_action), out, task_, sc);
   }
 
  private:
