@@ -29,7 +29,8 @@ def _same(a, b, ctx):
     assert np.array_equal(a, b, equal_nan=True), ctx
 
 
-@pytest.mark.parametrize("task_id", ["CartPole-v1", "FrozenLake-v1", "HalfCheetah-v4", "Ant-v4"])
+@pytest.mark.parametrize("task_id", ["CartPole-v1", "FrozenLake-v1", "HalfCheetah-v4", "Ant-v4", "Pusher-v4",
+                                     "Humanoid-v4"])
 def test_two_shards_equal_one_pool(task_id):
     """step()/reset() through device=[0, 0] returns the same rows, in the same order, as a
     single pool with the same seed (env i is seeded seed + i on whichever shard owns it)."""
