@@ -1478,7 +1478,7 @@ struct Hum4 {
   // benchmark never has more; HumanoidStandup 16: lying on the floor it often has)
   static constexpr int kRegRows = MP::kRegRows;
   static constexpr int kOwn = kRegRows / 4;
-  static_assert(kRegRows * (kRegRows + 1) / 2 <= kFSlots, "A + R is staged in the shared block");
+  static_assert(kRegRows % 4 == 0 && kRegRows <= 32, "register rows");
   static EPA_HD constexpr int Tri(int r, int cc) { return r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r; }
   static EPA_HD void SolvePgsR(Ctx& c, const Fwd<V>& f, int nrow_e, const V* zsd, E cost, E* at, V* al, int max_iter,
                                int* stat) {
@@ -1488,42 +1488,13 @@ struct Hum4 {
     DinvD(c, f, dd);
     const bool cold = ColdStart(zsd, dd, cost);
     // A_rc = y_r . (y_c / D) for c < r, four columns at a time, one row of lookahead; rows an env does
-    // not have count as zero
+    // not have count as zero.  The shared block holds 16 rows of the packed triangle: more rows are
+    // staged in a second pass (rows 16.. of the triangle), the registers being filled pass by pass.
     auto load = [&](int r, V* y) {
       c.RowGet(r, y);
       const bool valid = r < nrow_e;
       static_for<0, kND>([&](auto ic) { y[decltype(ic)::value] = Sel(valid, y[decltype(ic)::value], V(0)); });
     };
-    for (int c0 = 0; c0 < nrow; c0 += 4) {
-      V w[4][kND];
-      static_for<0, 4>([&](auto kc) { load(c0 + decltype(kc)::value < nrow ? c0 + decltype(kc)::value : c0, w[decltype(kc)::value]); });
-      static_for<0, 4>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        V wk[kND];
-        static_for<0, kND>([&](auto ic) { wk[decltype(ic)::value] = w[k][decltype(ic)::value] * dd[decltype(ic)::value]; });
-        static_for<k + 1, 4>([&](auto rc4) {
-          constexpr int r = decltype(rc4)::value;
-          const E a = DotD(w[r], wk);
-          if (c0 + r < nrow) c.ShPut(Tri(c0 + r, c0 + k), a);
-        });
-        static_for<0, kND>([&](auto ic) { w[k][decltype(ic)::value] = wk[decltype(ic)::value]; });
-      });
-      if (c0 + 4 < nrow) {
-        V nx[kND];
-        load(c0 + 4, nx);
-        for (int r = c0 + 4; r < nrow; ++r) {
-          V y[kND];
-          static_for<0, kND>([&](auto ic) { y[decltype(ic)::value] = nx[decltype(ic)::value]; });
-          load(r + 1 < nrow ? r + 1 : r, nx);
-          static_for<0, 4>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const E a = DotD(y, w[k]);
-            if (c0 + k < nrow) c.ShPut(Tri(r, c0 + k), a);
-          });
-        }
-      }
-    }
-    // the lane's own rows r = 4 k + l: scalars from the rows' records, (A + R)_r* from the shared block
     V fo[kOwn], ainv[kOwn], arr[kOwn], S[kOwn], AR[kOwn][kRegRows];
     static_for<0, kOwn>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
@@ -1532,12 +1503,59 @@ struct Hum4 {
       ainv[k] = Sel(have, c.RsGetLane(4 * k, kRsAinv), V(0));
       arr[k] = Sel(have, c.RsGetLane(4 * k, kRsArr), V(0));
       S[k] = Sel(have, c.RsGetLane(4 * k, kRsB), V(0));
-      static_for<0, kRegRows>([&](auto cc) {
-        constexpr int cidx = decltype(cc)::value;
-        // (entries of rows / columns beyond the wave's row count are stale but finite: they only
-        // ever meet a zero force)
-        const V a = c.ShGetTriLane(4 * k, cidx);
-        AR[k][cidx] = Sel(c.RowIndexLane(4 * k) == V(cidx), arr[k], Sel(have, a, V(0)));
+    });
+    constexpr int kStage = 16, kPasses = (kRegRows + kStage - 1) / kStage;
+    static_for<0, kPasses>([&](auto pc) {
+      constexpr int r_lo = kStage * decltype(pc)::value;
+      constexpr int r_hi = r_lo + kStage < kRegRows ? r_lo + kStage : kRegRows;
+      constexpr int base = r_lo * (r_lo + 1) / 2;  // Tri(r_lo, 0)
+      static_assert(r_hi * (r_hi + 1) / 2 - base <= kFSlots, "a staging pass fits the shared block");
+      const int nhi = nrow < r_hi ? nrow : r_hi;  // rows of this pass: [r_lo, nhi)
+      if (nhi > r_lo) {  // wave uniform
+        for (int c0 = 0; c0 < nhi; c0 += 4) {
+          V w[4][kND];
+          static_for<0, 4>([&](auto kc) { load(c0 + decltype(kc)::value < nrow ? c0 + decltype(kc)::value : c0, w[decltype(kc)::value]); });
+          static_for<0, 4>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            V wk[kND];
+            static_for<0, kND>([&](auto ic) { wk[decltype(ic)::value] = w[k][decltype(ic)::value] * dd[decltype(ic)::value]; });
+            static_for<k + 1, 4>([&](auto rc4) {
+              constexpr int r = decltype(rc4)::value;
+              if (c0 >= r_lo && c0 + r < nhi) c.ShPut(Tri(c0 + r, c0 + k) - base, DotD(w[r], wk));
+            });
+            static_for<0, kND>([&](auto ic) { w[k][decltype(ic)::value] = wk[decltype(ic)::value]; });
+          });
+          const int r0 = c0 + 4 > r_lo ? c0 + 4 : r_lo;
+          if (r0 < nhi) {
+            V nx[kND];
+            load(r0, nx);
+            for (int r = r0; r < nhi; ++r) {
+              V y[kND];
+              static_for<0, kND>([&](auto ic) { y[decltype(ic)::value] = nx[decltype(ic)::value]; });
+              load(r + 1 < nhi ? r + 1 : r, nx);
+              static_for<0, 4>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const E a = DotD(y, w[k]);
+                if (c0 + k < nrow) c.ShPut(Tri(r, c0 + k) - base, a);
+              });
+            }
+          }
+        }
+      }
+      // the lane's own rows r = 4 k + l take their entries with max(row, column) in this pass's rows
+      static_for<0, kOwn>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const BV have = c.RowIndexLane(4 * k) < V(nrow_e);
+        static_for<0, kRegRows>([&](auto cc) {
+          constexpr int cidx = decltype(cc)::value;
+          constexpr int top = 4 * k > cidx ? 4 * k : cidx;  // (4 k .. 4 k + 3 lie in one pass)
+          if constexpr (top >= r_lo && top < r_hi) {
+            // (entries of rows / columns beyond the wave's row count are stale but finite: they only
+            // ever meet a zero force)
+            const V a = c.ShGetTriLane(4 * k, cidx, base);
+            AR[k][cidx] = Sel(c.RowIndexLane(4 * k) == V(cidx), arr[k], Sel(have, a, V(0)));
+          }
+        });
       });
     });
     // S_r = b_r + sum_c (A + R)_rc f_c at the start forces

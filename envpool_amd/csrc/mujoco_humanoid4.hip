@@ -32,7 +32,7 @@ struct HumanoidMP {
 };
 struct StandupMP {
   static constexpr T::TreeModel kM = kHumanoidStandupModelConst;
-  static constexpr int kRegRows = 16;
+  static constexpr int kRegRows = 20;
 };
 
 constexpr int kBlock = 64, kEnvsPerBlock = 16;
@@ -153,9 +153,9 @@ struct DevCtx {
   __device__ double RkGet(int i) const { return mj::hum4::BcastQ(Ws(kWsRk + (i >> 2)), i & 3); }
   __device__ void RkPutL(int i, double v) { Ws(kWsRk + 10 + i) = v; }
   __device__ double RkGetL(int i) const { return Ws(kWsRk + 10 + i); }
-  __device__ double ShGetTriLane(int r0, int cc) const {  // entry (r0 + lane, cc) of the packed symmetric matrix
+  __device__ double ShGetTriLane(int r0, int cc, int base) const {  // entry (r0 + lane, cc) of the packed triangle
     const int r = r0 + l;
-    return ShGet(r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r);
+    return ShGet((r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r) - base);
   }
   __device__ void RecPut(int t, int k, double v) {
     if ((k & 3) == l) Ws(kMaxRows * kRowSlots + t * kRecSlots + (k >> 2)) = v;

