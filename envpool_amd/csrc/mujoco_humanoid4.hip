@@ -243,9 +243,7 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
     s.vl[k] = real ? get(kV + d) : 0.0;
     s.wl[k] = real ? get(kW + d) : 0.0;
   });
-  const double x_before = get(kLag), y_before = get(kLag + 1);
   __syncthreads();  // xch is about to be overwritten by the geoms
-  double ctrl_cost = 0.0;
   if (reset) {
     cur = 0;
     done = false;
@@ -254,10 +252,6 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
   } else {
     ++cur;
     const double* act = action + (size_t)row * m.nu;
-    for (int i = 0; i < m.nu; ++i) {
-      const double ai = act[i];
-      ctrl_cost += task.ctrl_cost_weight * ai * ai;  // humanoid.h:171-174
-    }
     s.ut[0] = act[CtrlOfDof(6)];  // clamped in mj_fwdActuation
     s.ut[1] = act[CtrlOfDof(7)];
     s.ut[2] = act[CtrlOfDof(8)];
@@ -274,18 +268,28 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
   H::Fwd<double> f;
   typename Eng::RowCount rows{0, 0, 0};
   double at[H::kNT], al[H::kNS];
-  // WriteState, humanoid.h:225-268: qpos[skip:] qvel cinert cvel qfrc_actuator cfrc_ext
-  const int b0 = task.exclude_worldbody ? 1 : 0;
-  const int a0 = task.exclude_root_actuator ? 6 : 0;
-  const int nb = m.nbody - b0;
-  const int nobs = (m.nq - task.obs_skip) + m.nv + 22 * nb + (m.nv - a0);
-  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
-  double* o_q = obs - task.obs_skip;
-  double* o_v = obs + (m.nq - task.obs_skip);
-  double* o_ci = o_v + m.nv - 10 * b0;   // + 10 * body
-  double* o_cv = o_v + m.nv + 10 * nb - 6 * b0;  // + 6 * body
-  double* o_act = o_v + m.nv + 16 * nb - a0;     // + dof
-  double* o_ce = o_v + m.nv + 16 * nb + (m.nv - a0) - 6 * b0;  // + 6 * body
+  // WriteState, humanoid.h:225-268: qpos[skip:] qvel cinert cvel qfrc_actuator cfrc_ext.  The section
+  // pointers are (re)computed where they are used: nothing that is only needed by the epilogue
+  // should have to live through the step loop.
+  struct ObsPtrs {
+    double *q, *v, *ci, *cv, *act, *ce;
+    int b0, a0;
+  };
+  auto obs_ptrs = [&]() {
+    ObsPtrs o;
+    o.b0 = task.exclude_worldbody ? 1 : 0;
+    o.a0 = task.exclude_root_actuator ? 6 : 0;
+    const int nb = m.nbody - o.b0;
+    const int nobs = (m.nq - task.obs_skip) + m.nv + 22 * nb + (m.nv - o.a0);
+    double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
+    o.q = obs - task.obs_skip;
+    o.v = obs + (m.nq - task.obs_skip);
+    o.ci = o.v + m.nv - 10 * o.b0;                               // + 10 * body
+    o.cv = o.v + m.nv + 10 * nb - 6 * o.b0;                      // + 6 * body
+    o.act = o.v + m.nv + 16 * nb - o.a0;                         // + dof
+    o.ce = o.v + m.nv + 16 * nb + (m.nv - o.a0) - 6 * o.b0;      // + 6 * body
+    return o;
+  };
   auto put6 = [](double* p, const H::Sp6<double>& x, bool on) {
     p[0] = on ? x.a.x : 0.0;
     p[1] = on ? x.a.y : 0.0;
@@ -307,6 +311,9 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
       if (!last) return;  // wave uniform
       mx = ff.com.x;  // GetMassCenter, humanoid.h:212-223
       my = ff.com.y;
+      const ObsPtrs o = obs_ptrs();
+      double *o_ci = o.ci, *o_cv = o.cv, *o_act = o.act;
+      const int b0 = o.b0, a0 = o.a0;
       if (l == 0) {
         if (b0 == 0) {
           for (int i = 0; i < 10; ++i) o_ci[i] = 0.0;
@@ -338,6 +345,19 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
     Eng::RkAdvance(c, s, it & 3, live && !reset, at, al);
   }
   Eng::LoadTrunk(c, s, 7);
+  const ObsPtrs o = obs_ptrs();
+  double *o_q = o.q, *o_v = o.v, *o_ce = o.ce;
+  const int b0 = o.b0;
+  const double x_before = reset ? 0.0 : dev.state[(size_t)kLag * n + e];  // the lagged mass centre
+  const double y_before = reset ? 0.0 : dev.state[(size_t)(kLag + 1) * n + e];
+  double ctrl_cost = 0.0;
+  if (!reset) {
+    const double* act = action + (size_t)row * m.nu;
+    for (int i = 0; i < m.nu; ++i) {
+      const double ai = act[i];
+      ctrl_cost += task.ctrl_cost_weight * ai * ai;  // humanoid.h:171-174
+    }
+  }
   // mj_rnePostConstraint after the last mj_step (mujoco_env.h:145-147)
   const bool wrench = task.post_constraint != 0;
   H::Sp6<double> ext_t[H::kNTB + 1], ext_l[3];
