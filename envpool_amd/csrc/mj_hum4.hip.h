@@ -1651,16 +1651,19 @@ struct Hum4 {
     if (dbg & 4) {
       act.w[0] = act.w[1] = act.w[2] = 0ull;
     } else {
+      c.Refresh();
       Detect(c, s.qt, s.ql, act);
     }
     if (dbg & 2) act.w[0] = act.w[1] = act.w[2] = 0ull;
     EPA_LDS_FENCE();
+    c.Refresh();
     LoadTrunk(c, s, 1 | 2 | 8);
     Velocity(c, s.qt, s.ql, s.vt, s.vl, s.ut, s.ul, f);
     after_velocity(f);
     MassFactor(c, f);
     SmoothAcc(c, f);
     EPA_LDS_FENCE();
+    c.Refresh();
     E cost;
     V zsd[kND];
     LoadTrunk(c, s, 1 | 2 | 4);
