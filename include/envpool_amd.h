@@ -55,6 +55,12 @@ typedef struct epa_pool epa_pool;
  * per-family numeric options passed as (key, value) pairs named exactly like
  * the reference's `XxxEnvFns::DefaultConfig()` keys (e.g. "version" for
  * Pendulum, "size" for FrozenLake, "frame_skip", "ctrl_cost_weight", ...).
+ * Unknown keys are ignored.  Engine extensions (not reference keys):
+ *   "precision"   planar / Ant MuJoCo kernels: 1 fp64 (default), 0 fp32 (throughput mode)
+ *   "xml_v5"      Walker2d / Pusher: 1 selects the *_v5 model (the reference's xml_file)
+ *   "hum_layout"  Humanoid / HumanoidStandup: 1 one env per lane quad (default), 0 one env per lane
+ *   "hum_sort"    quad layout: 1 cost-sorted waves (default), 0 rows in send order
+ *   "hum_debug"   quad layout, timing runs only: stages switched off / solver statistics
  */
 typedef struct epa_config {
   int32_t num_envs;          /* common_config "num_envs" */
