@@ -1489,7 +1489,7 @@ struct Hum4 {
     const bool cold = ColdStart(zsd, dd, cost);
     // A_rc = y_r . (y_c / D) for c < r, four columns at a time, one row of lookahead; rows an env does
     // not have count as zero.  The shared block holds 16 rows of the packed triangle: more rows are
-    // staged in a second pass (rows 16.. of the triangle), the registers being filled pass by pass.
+    // staged in further passes (four rows of the triangle each), the registers being filled pass by pass.
     auto load = [&](int r, V* y) {
       c.RowGet(r, y);
       const bool valid = r < nrow_e;
@@ -1504,10 +1504,12 @@ struct Hum4 {
       arr[k] = Sel(have, c.RsGetLane(4 * k, kRsArr), V(0));
       S[k] = Sel(have, c.RsGetLane(4 * k, kRsB), V(0));
     });
-    constexpr int kStage = 16, kPasses = (kRegRows + kStage - 1) / kStage;
+    // staging passes: rows [0, 16), then four rows at a time
+    constexpr int kPasses = kRegRows <= 16 ? 1 : 1 + (kRegRows - 16) / 4;
     static_for<0, kPasses>([&](auto pc) {
-      constexpr int r_lo = kStage * decltype(pc)::value;
-      constexpr int r_hi = r_lo + kStage < kRegRows ? r_lo + kStage : kRegRows;
+      constexpr int p = decltype(pc)::value;
+      constexpr int r_lo = p == 0 ? 0 : 16 + 4 * (p - 1);
+      constexpr int r_hi = p == 0 ? (kRegRows < 16 ? kRegRows : 16) : r_lo + 4;
       constexpr int base = r_lo * (r_lo + 1) / 2;  // Tri(r_lo, 0)
       static_assert(r_hi * (r_hi + 1) / 2 - base <= kFSlots, "a staging pass fits the shared block");
       const int nhi = nrow < r_hi ? nrow : r_hi;  // rows of this pass: [r_lo, nhi)

@@ -32,7 +32,7 @@ struct HumanoidMP {
 };
 struct StandupMP {
   static constexpr T::TreeModel kM = kHumanoidStandupModelConst;
-  static constexpr int kRegRows = 20;
+  static constexpr int kRegRows = 24;
 };
 
 constexpr int kBlock = 64, kEnvsPerBlock = 16;

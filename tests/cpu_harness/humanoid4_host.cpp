@@ -12,7 +12,7 @@ namespace T = epa::mj::tree;
 namespace H = epa::mj::hum4;
 using epa::mj::Q4;
 struct Walk { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 12; };
-struct Stand { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 20; };
+struct Stand { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 24; };
 
 template <class MP>
 struct HostCtx {

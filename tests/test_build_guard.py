@@ -19,11 +19,12 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # every model is a compile-time constant now (gen_mj_consts.cpp); the largest count among the
 # one-env-per-lane kernels is 48 (ClassicStepKernel<4>), the known-bad builds had 170 and ~250
 MAX_SGPR_SPILLS = 64
-# Humanoid4StepKernel: 320 / 490 SGPRs (kernel arguments and literals set up before the step loop and
-# needed again by the observation / reward epilogue) are parked in VGPR lanes ACROSS the loop --
-# all v_writelane before it, all v_readlane after it, none inside the solver loops, which is where
-# the known-bad builds had theirs.  Bounded separately so that growth is noticed.
-MAX_SGPR_SPILLS_BY_KERNEL = {"Humanoid4StepKernel": 550}
+# Humanoid4StepKernel: 290 (Humanoid) / 570 (Standup, 24 register rows) SGPRs -- kernel arguments and
+# literals set up before the step loop and needed again by the observation / reward epilogue -- are
+# parked in VGPR lanes ACROSS the loop: the v_writelane sit before it; Humanoid reads them back after
+# it, Standup also reads ~110 of them back inside the row build (never written there).  Both are
+# checked against the oracle to 1e-13 on the GPU.  Bounded separately so that growth is noticed.
+MAX_SGPR_SPILLS_BY_KERNEL = {"Humanoid4StepKernel": 600}
 
 
 def _kernel_metadata():
