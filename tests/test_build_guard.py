@@ -64,3 +64,37 @@ def test_step_kernels_do_not_spill_sgprs_heavily():
 
     bad = {k: v for k, v in meta.items() if v[0] > limit(k)}
     assert not bad, bad
+
+
+# ---- the product never reaches the checker (oracle/ is test infrastructure) ----
+def test_product_python_never_touches_oracle():
+    pkg = os.path.join(ROOT, "envpool_amd")
+    bad = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            src = open(os.path.join(dirpath, f)).read()
+            for n, line in enumerate(src.splitlines(), 1):
+                code = line.split("#", 1)[0]
+                if re.search(r"\boracle\b", code) and not code.lstrip().startswith(('"', "'")):
+                    bad.append(f"{os.path.relpath(os.path.join(dirpath, f), ROOT)}:{n}: {line.strip()}")
+    assert bad == [], bad
+
+
+def test_product_library_does_not_link_the_oracle():
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    dyn = subprocess.run([f"{LLVM}/llvm-readelf", "--dynamic", LIB], capture_output=True, text=True, check=True).stdout
+    needed = re.findall(r"\(NEEDED\)\s+Shared library: \[([^\]]+)\]", dyn)
+    assert needed and not [n for n in needed if "oracle" in n or "mjcpu" in n or "ref_driver" in n], needed
+    syms = subprocess.run([f"{LLVM}/llvm-readelf", "--dyn-syms", "-W", LIB], capture_output=True, text=True, check=True).stdout
+    assert not re.findall(r"\b(mjcpu_\w+|oracle_\w+)\b", syms)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from envpool_amd.core import native
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(native, "LIB_PATH", os.path.join(ROOT, "envpool_amd", "lib", "does_not_exist.so"))
+    with pytest.raises(RuntimeError):
+        native.lib()
