@@ -144,7 +144,16 @@ EPA_HD unsigned MaskFill(unsigned, unsigned x) { return x; }
 constexpr int kDppSwap1 = 0xB1, kDppSwap2 = 0x4E;
 template <int CTRL>
 __device__ __forceinline__ int DppMov(int x) {
+  // bound_ctrl = true: a quad_perm never reads out of bounds, and with full row/bank masks the compiler then
+  // knows the `old` operand is dead -- with bound_ctrl = false every DPP move carries a `v_mov_b32 dst, 0` in
+  // front of it (864 of the 1116 DPP moves of the Humanoid kernel).  Measured: Ant +3 % without those moves;
+  // the Humanoid quad kernel 1.2 % SLOWER (its reductions sit in dependent chains, where the init moves were
+  // filling the two wait states a DPP read needs after a VALU write), so that TU keeps them (EPA_DPP_OLD_ZERO).
+#ifdef EPA_DPP_OLD_ZERO
   return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false);
+#else
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+#endif
 }
 template <int CTRL>
 __device__ __forceinline__ float DppMov(float x) {
