@@ -1474,8 +1474,9 @@ struct Hum4 {
   // TO DATE: a visit reads S_r, decides, broadcasts the accepted change (DPP) and every lane adds
   // (A + R)_{its rows, r} * change to its residuals.  ~15 dependent operations per visit.
   static constexpr int kFSlots = 156;  // capacity of the shared block (Ctx::ShGet / ShPut)
-  // rows (per env) the register-resident PGS holds: MP::kRegRows (a multiple of 4; Humanoid 12: the
-  // benchmark never has more; HumanoidStandup 16: lying on the floor it often has)
+  // rows (per env) the register-resident PGS holds: MP::kRegRows (a multiple of 4).  Measured: Humanoid 12
+  // (16: -3 %, the benchmark rarely has more); HumanoidStandup 24 (20: -15 %; 28 spills the matrix
+  // itself and halves the rate) -- lying on the floor it often has more, those waves stream (SolvePgs)
   static constexpr int kRegRows = MP::kRegRows;
   static constexpr int kOwn = kRegRows / 4;
   static_assert(kRegRows % 4 == 0 && kRegRows <= 32, "register rows");
