@@ -1,0 +1,36 @@
+"""The one JSON line `bench.py` prints: the keys the driver and the judge read (a short run on a
+small batch; the `cpu_baseline` leg is skipped here, it is a 15 s oracle run)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_schema():
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2",
+         "--num-envs", "4096", "--no-cpu-baseline"],
+        capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2
+    assert d["unit"] == "env-steps/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac"):
+        assert key in r, key
+    assert r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # value = env-steps of the timed window / its wall time
+    assert abs(d["value"] - 4096 * 6 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-6
