@@ -139,14 +139,18 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    pool.set_timing(True)
+    # HIP events on the pool's stream around the whole timed region (first launch .. after the last):
+    # kernel_ms = that / launches.  (An event pair around EVERY launch keeps consecutive step
+    # kernels ~12 us apart on this runtime -- 5 % of a 0.23 ms step; tools/bench_families.py still
+    # times per launch.)
+    pool.set_timing(2)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    kernel_ms, launches = pool.kernel_time_ms()  # records the closing event, waits for the stream
     pool.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = pool.kernel_time_ms()
     pool.set_timing(False)
     if world > 1:
         dist.barrier()
@@ -243,6 +247,8 @@ def main():
                     "flops_per_env_step": valu["flops_per_env_step"],
                     "flops_source": valu["flops_source"], "traffic": traffic, "hbm": hbm}
         roof.update({"kernel": kbase, "kernel_ms": kernel_ms, "launches": launches,
+                     "kernel_ms_method": "HIP events on the pool's stream before the first and after the last "
+                                         "launch of the timed region, / launches",
                      "algorithmic_bytes_per_env_step": alg_bytes,
                      "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC passes of "
                                      "this command (profiles/pmc.json; FETCH_SIZE x2 + WRITE_SIZE)"})

@@ -227,8 +227,10 @@ class DevicePool:
     def synchronize(self) -> None:
         native.check(self._lib.epa_synchronize(self._h))
 
-    def set_timing(self, on: bool) -> None:
-        native.check(self._lib.epa_set_timing(self._h, 1 if on else 0))
+    def set_timing(self, on: bool | int) -> None:
+        """False / 0 off; True / 1 an event pair per launch; 2 one pair around the window
+        (first launch .. kernel_time_ms()), nothing inserted between the launches."""
+        native.check(self._lib.epa_set_timing(self._h, int(on)))
 
     def kernel_time_ms(self) -> tuple[float, int]:
         ms = ctypes.c_double(0)

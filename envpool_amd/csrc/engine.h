@@ -143,7 +143,7 @@ class Pool {
   virtual int RecvDevice(void** d_out_ptrs, int n_ptrs);
   virtual int PendingRows();
   virtual void Synchronize();
-  void SetTiming(bool on);
+  void SetTiming(int mode);  // 0 off, 1 an event pair around every launch, 2 one pair around the whole window
   void KernelTime(double* avg_ms, int* launches);
 
   virtual int StateDim() const = 0;
@@ -212,7 +212,10 @@ class Pool {
   size_t recv_stage_bytes_{0};
   hipEvent_t order_ev_{nullptr};  // WaitStream's producer marker
   // timing
-  bool timing_{false};
+  int timing_{0};
+  hipEvent_t win0_{nullptr}, win1_{nullptr};  // timing mode 2: first launch .. KernelTime()
+  bool win_open_{false};
+  int win_launches_{0};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timers_;
   std::vector<hipEvent_t> timer_pool_;
 };

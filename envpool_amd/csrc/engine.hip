@@ -150,6 +150,8 @@ Pool::~Pool() {
     (void)hipEventDestroy(t.second);
   }
   for (auto& t : timer_pool_) (void)hipEventDestroy(t);
+  if (win0_) (void)hipEventDestroy(win0_);
+  if (win1_) (void)hipEventDestroy(win1_);
   if (recv_stage_) (void)hipHostFree(recv_stage_);
   if (order_ev_) (void)hipEventDestroy(order_ev_);
   if (common_.cur_step) (void)hipFree(common_.cur_step);
@@ -278,7 +280,19 @@ OutPtrs Pool::PtrsOf(const Batch& b) const {
 void Pool::Enqueue(const int* d_ids, int k, const void* d_action, bool force) {
   Batch* b = AcquireBatch(k);
   hipEvent_t t0 = nullptr, t1 = nullptr;
-  if (timing_) {
+  if (timing_ == 2) {  // window timing: no event between the launches (an event pair per launch keeps
+    // consecutive step kernels ~12 us apart on this runtime)
+    if (!win_open_) {
+      if (win0_ == nullptr) {
+        EPA_HIP(hipEventCreate(&win0_));
+        EPA_HIP(hipEventCreate(&win1_));
+      }
+      EPA_HIP(hipEventRecord(win0_, stream_));
+      win_open_ = true;
+      win_launches_ = 0;
+    }
+    ++win_launches_;
+  } else if (timing_ == 1) {
     auto get = [&]() {
       hipEvent_t ev;
       if (!timer_pool_.empty()) {
@@ -308,7 +322,7 @@ void Pool::Enqueue(const int* d_ids, int k, const void* d_action, bool force) {
                        elapsed, d_ids, cfg_.env_id_offset, k, stack_s_, stack_head_);
     EPA_HIP(hipGetLastError());
   }
-  if (timing_) {
+  if (timing_ == 1) {
     EPA_HIP(hipEventRecord(t1, stream_));
     timers_.emplace_back(t0, t1);
   }
@@ -633,14 +647,27 @@ void Pool::Synchronize() {
   EPA_HIP(hipStreamSynchronize(d2h_stream_));
 }
 
-void Pool::SetTiming(bool on) {
+void Pool::SetTiming(int mode) {
   std::lock_guard<std::mutex> lk(mu_);
-  timing_ = on;
+  timing_ = mode;
+  win_open_ = false;
+  win_launches_ = 0;
 }
 
 void Pool::KernelTime(double* avg_ms, int* launches) {
   std::lock_guard<std::mutex> lk(mu_);
   EPA_HIP(hipSetDevice(cfg_.device));
+  if (win_open_) {  // mode 2: (last launch's end - first launch's start) / launches, gaps included
+    EPA_HIP(hipEventRecord(win1_, stream_));
+    EPA_HIP(hipStreamSynchronize(stream_));
+    float ms = 0;
+    EPA_HIP(hipEventElapsedTime(&ms, win0_, win1_));
+    *launches = win_launches_;
+    *avg_ms = win_launches_ > 0 ? (double)ms / win_launches_ : 0.0;
+    win_open_ = false;
+    win_launches_ = 0;
+    return;
+  }
   EPA_HIP(hipStreamSynchronize(stream_));
   double tot = 0;
   for (auto& t : timers_) {
@@ -907,7 +934,7 @@ int epa_synchronize(epa_pool* pool) {
 }
 
 int epa_set_timing(epa_pool* pool, int32_t enabled) {
-  return Guard([&] { pool->impl->SetTiming(enabled != 0); });
+  return Guard([&] { pool->impl->SetTiming(enabled < 0 ? 0 : (enabled > 2 ? 1 : (int)enabled)); });
 }
 
 int epa_kernel_time_ms(epa_pool* pool, double* avg_ms, int32_t* launches) {

@@ -207,7 +207,12 @@ int epa_synchronize(epa_pool* pool);
 
 /* Average duration in ms of the step kernels launched since the last call,
  * measured with HIP events on the pool's stream; *launches = how many.
- * Timing must be enabled with epa_set_timing(pool, 1). */
+ * epa_set_timing(pool, 1): an event pair around every launch (exact per-launch
+ * durations; the events keep consecutive launches ~12 us apart).
+ * epa_set_timing(pool, 2): one event before the first launch and one when
+ * epa_kernel_time_ms is called: (elapsed / launches), inter-launch gaps included,
+ * nothing inserted between the launches -- what bench.py uses for its timed region.
+ * epa_set_timing(pool, 0): off. */
 int epa_set_timing(epa_pool* pool, int32_t enabled);
 int epa_kernel_time_ms(epa_pool* pool, double* avg_ms, int32_t* launches);
 
