@@ -34,3 +34,34 @@ def test_bench_line_schema():
     assert r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     # value = env-steps of the timed window / its wall time
     assert abs(d["value"] - 4096 * 6 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-6
+
+
+def test_kernel_timing_modes_agree():
+    """epa_set_timing: 1 = an event pair per launch, 2 = one pair around the window (what bench.py
+    uses); both count every launch and give the same duration up to the inter-launch gaps."""
+    import numpy as np
+    import torch
+
+    from envpool_amd.core.device_pool import DevicePool
+
+    n = 16384
+    pool = DevicePool("HalfCheetah", n, seed=0, max_episode_steps=1000)
+    act = torch.rand((n, 6), device="cuda", dtype=torch.float64) * 2 - 1
+    pool.send_device(None)
+    pool.recv_device()
+    res = {}
+    for mode in (1, 2, 1, 2):
+        pool.set_timing(mode)
+        for _ in range(30):
+            pool.send_device(act.data_ptr())
+            pool.recv_device()
+        ms, launches = pool.kernel_time_ms()
+        pool.set_timing(0)
+        assert launches == 30
+        res.setdefault(mode, []).append(ms)
+    pool.set_timing(2)  # an empty window reports nothing
+    assert pool.kernel_time_ms() == (0.0, 0)
+    pool.set_timing(0)
+    a, b = min(res[1]), min(res[2])
+    assert 0.05 < a < 5.0 and 0.05 < b < 5.0
+    assert abs(a - b) / a < 0.25, res
