@@ -49,6 +49,27 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
             print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | "
                   f"{float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {r['Percentage']} |")
     print()
+# the bench's timed window inside the trace: bench.py launches 1 reset + W warm-up + K timed steps (then
+# reset / numpy-API legs); tools/profile_bench.sh runs it with --steps 200 --warmup 20
+W, K = int(os.environ.get("EPA_PROF_WARMUP", 20)), int(os.environ.get("EPA_PROF_STEPS", 200))
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    rows = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        name = r.get("Kernel_Name", "")
+        if any(k in name for k in KEY) and "GetState" not in name:
+            rows[short(name)].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    for k, v in rows.items():
+        v.sort()
+        if len(v) < 1 + W + K:
+            continue
+        win = v[1 + W:1 + W + K]
+        dur = [e - b for b, e in win]
+        gap = [win[i + 1][0] - win[i][1] for i in range(len(win) - 1)]
+        print(f"## timed window of the bench inside this trace: {k}\n")
+        print(f"launches {1 + W + 1}..{1 + W + K} of {len(v)}: avg {sum(dur)/len(dur)/1e3:.1f} us "
+              f"(min {min(dur)/1e3:.1f}, max {max(dur)/1e3:.1f}); gap to the next launch avg "
+              f"{sum(gap)/len(gap)/1e3:.1f} us; (last end - first start) / {K} = "
+              f"{(win[-1][1] - win[0][0])/K/1e3:.1f} us\n")
 agg = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
