@@ -75,13 +75,15 @@ class EnvPoolMixin(ABC):
             if not hasattr(self, "_last_action_name"):
                 self._last_action_name = self._spec._action_keys[-1]
             if isinstance(action, np.ndarray):
-                action = action.astype(self._last_action_type, order="C")
+                # (the reference copies here; the pool stages the rows before `send` returns, so an
+                # array that already has the dtype and layout can be passed through)
+                action = action.astype(self._last_action_type, order="C", copy=False)
             adict = {self._last_action_name: action}
         if env_id is None:
             if "env_id" not in adict:
                 adict["env_id"] = self.all_env_ids
         else:
-            adict["env_id"] = env_id.astype(np.int32)
+            adict["env_id"] = env_id.astype(np.int32, copy=False)
         if "players.env_id" not in adict:
             # all hot-path envs are single player: players.env_id == env_id
             adict["players.env_id"] = _normalize_env_id(adict["env_id"])
