@@ -20,7 +20,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(task="HalfCheetah", target_s=15.0):
+# half-width of the task's action space (reference specs: humanoid.h:78, humanoid_standup.h:71 [-0.4, 0.4];
+# pusher.h:61 [-2, 2]; every other gym-MuJoCo task here [-1, 1]): the reference benchmark draws
+# `action_space.sample()` (benchmark/test_envpool.py), i.e. uniform in these bounds
+ACTION_HI = {"Humanoid": 0.4, "HumanoidStandup": 0.4, "Pusher": 2.0}
+
+
+def cpu_baseline(task="HalfCheetah", target_s=15.0, action_hi=1.0):
     """Oracle ("port": oracle/mjcpu fp64 restatement) on a bounded sample of the
     same workload, envs spread over ALL host cores with OpenMP (the analogue of
     the reference's worker threads).  The reference itself cannot run: mj_step
@@ -41,7 +47,7 @@ def cpu_baseline(task="HalfCheetah", target_s=15.0):
     o = Oracle(task, num_envs, seed=0, max_episode_steps=1000)
     o.reset()
     rng = np.random.default_rng(0)
-    act = rng.uniform(-1, 1, size=(num_envs, o.action_elems))
+    act = rng.uniform(-action_hi, action_hi, size=(num_envs, o.action_elems))
     o.time_steps(5, act)  # warm caches / leave the reset steps behind
     t = o.time_steps(20, act)
     steps = max(5, int(target_s / max(t / 20, 1e-6)))
@@ -66,6 +72,8 @@ def main():
     ap.add_argument("--task", default="HalfCheetah")
     ap.add_argument("--precision", default="fp64", choices=["fp32", "fp64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--action-scale", type=float, default=None,
+                    help="actions are uniform in [-s, s]; default: the task's action-space bound")
     ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE",
                     help="extra pool parameter (A/B switches such as sort_by_cost=0)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -109,7 +117,8 @@ def main():
     # ring of 16 pre-generated action batches, Philox seed 1234
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    ring = [torch.rand((n, adim), generator=gen, device=dev, dtype=torch.float64) * 2 - 1
+    ahi = args.action_scale if args.action_scale is not None else ACTION_HI.get(args.task, 1.0)
+    ring = [(torch.rand((n, adim), generator=gen, device=dev, dtype=torch.float64) * 2 - 1) * ahi
             for _ in range(16)]
     torch.cuda.synchronize()
 
@@ -174,7 +183,7 @@ def main():
         #     (H2D), every state key out as numpy (D2H) -- PCIe inclusive; never `value`
         ids = np.arange(rank * n, rank * n + n, dtype=np.int32)
         rng = np.random.default_rng(0)
-        hact = [rng.uniform(-1, 1, size=(n, adim)) for _ in range(4)]
+        hact = [rng.uniform(-ahi, ahi, size=(n, adim)) for _ in range(4)]
         for i in range(3):
             pool.send(ids, hact[i % 4])
             pool.recv()
@@ -267,7 +276,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.task}-v4 num_envs={n} per GPU, frame_skip={frame_skip}, "
-                            "uniform random actions resident in HBM, auto-reset on",
+                            f"actions uniform in the action space [-{ahi:g}, {ahi:g}] resident in HBM, auto-reset on",
                 "num_envs_per_gpu": n,
                 "frames_per_sec": value * frame_skip,
                 "sharding": f"env ids sharded over {world} GPU(s), no collective",
@@ -278,7 +287,7 @@ def main():
             out["reset_step_ms"] = reset_ms
             out["numpy_api"] = numpy_api
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args.task)
+            out["cpu_baseline"] = cpu_baseline(args.task, action_hi=ahi)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
