@@ -58,6 +58,7 @@ struct CheetahTask {
   double healthy_reward, healthy_z_min, healthy_z_max, healthy_angle_min,
       healthy_angle_max, velocity_min, velocity_max, healthy_state_min, healthy_state_max;
   int terminate_when_unhealthy, legacy_healthy_reward;
+  int lanes;  // envs per wave of THIS launch (64 once the batch fills every SIMD; see Launch)
 };
 
 // compile-time model of the planar kernel instance (mj_cheetah.hip.h, PlanarModelId)
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
   __shared__ T lds_buf[mj::kLdsSlots * kCheetahBlock];
   const int lane = threadIdx.x;
   const int n = cm.n;
-  const int row = blockIdx.x * kCheetahBlock + lane;
+  if (lane >= task.lanes) return;
+  const int row = blockIdx.x * task.lanes + lane;
   if (row >= a.k) return;
   const int e = a.ids ? a.ids[row] - a.id_offset : row;
   bool done = cm.done[e] != 0;
@@ -388,6 +390,13 @@ class CheetahPool : public Pool {
     EPA_HIP(hipMalloc(&dev_.iters, sizeof(int) * n));
     trace_.Init("EPA_PLANAR_TRACE", (n + kCheetahBlock - 1) / kCheetahBlock, stream_);
     dev_.trace = trace_.d;
+    spread_ = cfg.Get("planar_spread", 1) != 0;  // extension key, see Launch
+    {
+      hipDeviceProp_t prop;
+      EPA_HIP(hipGetDeviceProperties(&prop, cfg.device));
+      wave_slots_ = prop.multiProcessorCount * 4;  // one wave per SIMD, four SIMDs per CU
+      if (wave_slots_ < 1) wave_slots_ = 1;
+    }
     if (task_.frame_stack > 1) {
       size_t sb = sizeof(double) * n * task_.frame_stack * (2 * kNV - task_.obs_skip);
       EPA_HIP(hipMalloc(&dev_.stack, sb));
@@ -427,7 +436,18 @@ class CheetahPool : public Pool {
               const OutPtrs& out) override {
     StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps,
                cfg_.env_id_offset};
-    int blocks = (k + kCheetahBlock - 1) / kCheetahBlock;
+    // A wave runs as long as its slowest lane and visits every end sphere that touches on ANY of its
+    // lanes, and these kernels hold one wave per SIMD: a batch between 16 and 64 envs per SIMD is spread
+    // over all SIMDs with 16 / 32 / 48 envs per wave (HalfCheetah N = 16384 .. 49152: +5 .. +8 %,
+    // profiles/r2ze_planar_spread.txt).  Not below 16 per SIMD: there partially filled waves measured
+    // SLOWER (N = 8192 as 512 waves of 16: 0.26 ms against 0.21 ms as 128 full waves).
+    int lanes = kCheetahBlock;
+    if (spread_ && trace_.d == nullptr && k >= 16 * wave_slots_) {
+      lanes = ((k + wave_slots_ - 1) / wave_slots_ + 15) / 16 * 16;
+      lanes = lanes > kCheetahBlock ? kCheetahBlock : lanes;
+    }
+    task_.lanes = lanes;
+    int blocks = (k + lanes - 1) / lanes;
     const double* act = static_cast<const double*>(d_action);
     const mj::SolverCfg<double> sd{50, 1e-13};
     const mj::SolverCfg<float> sf{12, 1e-6f};
@@ -453,6 +473,8 @@ class CheetahPool : public Pool {
   int model_id_;
   CheetahTask task_{};
   bool fp64_{false};
+  bool spread_{true};
+  int wave_slots_{1024};
 };
 
 }  // namespace
