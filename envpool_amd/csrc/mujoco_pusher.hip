@@ -35,6 +35,7 @@ struct PusherTask {
   int frame_skip, reward_after_step, weighted_reward_info;
   double ctrl_cost_weight, dist_cost_weight, near_cost_weight, reset_qvel_scale;
   double cyl_x_min, cyl_x_max, cyl_y_min, cyl_y_max, cyl_dist_min;
+  int lanes;  // envs per wave of this launch (mujoco_gym.hip: planar_spread)
 };
 
 constexpr int kPusherBlock = 64;
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(kPusherBlock) void PusherStepKernel(
     PusherTask task, mj::SolverCfg<double> scfg) {
   constexpr PU::PusherModel<double> m = kV5 ? kPusherV5ModelConst : kPusherModelConst;
   const int n = cm.n;
-  const int row = blockIdx.x * kPusherBlock + threadIdx.x;
+  if ((int)threadIdx.x >= task.lanes) return;
+  const int row = blockIdx.x * task.lanes + threadIdx.x;
   if (row >= a.k) return;
   const int e = a.ids ? a.ids[row] - a.id_offset : row;
   bool done = cm.done[e] != 0;
@@ -217,6 +219,12 @@ class PusherPool : public Pool {
     task_.cyl_y_min = cfg.Get("cylinder_y_min", -0.2);
     task_.cyl_y_max = cfg.Get("cylinder_y_max", 0.2);
     task_.cyl_dist_min = cfg.Get("cylinder_dist_min", 0.17);
+    spread_ = cfg.Get("planar_spread", 1) != 0;
+    {
+      hipDeviceProp_t prop;
+      EPA_HIP(hipGetDeviceProperties(&prop, cfg.device));
+      wave_slots_ = prop.multiProcessorCount * 4 < 1 ? 1 : prop.multiProcessorCount * 4;
+    }
     size_t n = cfg.num_envs;
     for (double** p : {&dev_.qpos, &dev_.qvel, &dev_.warm}) {
       EPA_HIP(hipMalloc(p, sizeof(double) * PU::kNQ * n));
@@ -246,7 +254,16 @@ class PusherPool : public Pool {
   void Launch(const int* d_ids, int k, const void* d_action, bool force_reset,
               const OutPtrs& out) override {
     StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps, cfg_.env_id_offset};
-    int blocks = (k + kPusherBlock - 1) / kPusherBlock;
+    // one wave per SIMD, as the planar kernel: a batch of 32 .. 64 envs per SIMD runs with 32 / 48 envs
+    // per wave on all SIMDs (see CheetahPool::Launch, "planar_spread"; measured N = 32768: +5 %, and
+    // 16 per wave at N = 16384: -4 %, hence the floor of 32 here)
+    int lanes = kPusherBlock;
+    if (spread_ && k >= 32 * wave_slots_) {
+      lanes = ((k + wave_slots_ - 1) / wave_slots_ + 15) / 16 * 16;
+      lanes = lanes > kPusherBlock ? kPusherBlock : lanes;
+    }
+    task_.lanes = lanes;
+    int blocks = (k + lanes - 1) / lanes;
     const mj::SolverCfg<double> sc{50, 1e-13};
     auto* kernel = v5_ ? PusherStepKernel<true> : PusherStepKernel<false>;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kPusherBlock), 0, stream_, dev_, common_, a,
@@ -257,6 +274,8 @@ class PusherPool : public Pool {
   PusherDev dev_{};
   bool v5_{false};
   PusherTask task_{};
+  bool spread_{true};
+  int wave_slots_{1024};
 };
 
 }  // namespace

@@ -58,8 +58,8 @@ typedef struct epa_pool epa_pool;
  * Unknown keys are ignored.  Engine extensions (not reference keys):
  *   "precision"   planar / Ant MuJoCo kernels: 1 fp64 (default), 0 fp32 (throughput mode)
  *   "xml_v5"      Walker2d / Pusher: 1 selects the *_v5 model (the reference's xml_file)
- *   "planar_spread" HalfCheetah / Walker2d / Hopper: 1 (default) a batch of 16 .. 64 envs per SIMD is spread
- *                 over all SIMDs with 16 / 32 / 48 envs per wave; 0 always 64 envs per wave
+ *   "planar_spread" HalfCheetah / Walker2d / Hopper / Pusher: 1 (default) a batch of 16 .. 64 (Pusher: 32 .. 64) envs
+ *                 per SIMD is spread over all SIMDs with 16 / 32 / 48 envs per wave; 0 always 64 envs per wave
  *   "hum_layout"  Humanoid / HumanoidStandup: 1 one env per lane quad (default), 0 one env per lane
  *   "hum_sort"    quad layout: 1 cost-sorted waves (default), 0 rows in send order
  *   "hum_debug"   quad layout, timing runs only: stages switched off / solver statistics

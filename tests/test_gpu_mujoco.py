@@ -818,16 +818,16 @@ def test_humanoid_layouts_and_scheduling_agree(task):
         print(f"{task}: {what}: median rel {np.median(rel.max(axis=2)):.1e}, max {rel.max():.1e}")
 
 
-@pytest.mark.parametrize("task,adim", [("HalfCheetah", 6), ("Hopper", 3)])
+@pytest.mark.parametrize("task,adim", [("HalfCheetah", 6), ("Hopper", 3), ("Pusher", 7)])
 def test_planar_spread_is_bit_identical(task, adim):
     """`planar_spread` only changes which lane of which wave computes an env (16 / 32 / 48 envs per wave
     when the batch is between 16 and 64 envs per SIMD): the arithmetic of an env does not depend on
     its neighbours, so every output is bit-identical to the 64-per-wave launch, for whole batches and
     for partial env_id batches (a 17000-env batch of a 20000-env pool runs 32 per wave)."""
-    n = 20000
+    n = 40000 if task == "Pusher" else 20000  # (Pusher spreads from 32 envs per SIMD up: 48 per wave here)
     rng = np.random.default_rng(11)
     acts = rng.uniform(-1, 1, size=(6, n, adim))
-    part = np.sort(rng.choice(n, size=17000, replace=False)).astype(np.int32)
+    part = np.sort(rng.choice(n, size=n - 3000, replace=False)).astype(np.int32)
     outs = []
     for spread in (1, 0):
         p = DevicePool(task, n, seed=5, max_episode_steps=1000, params={"planar_spread": spread})
