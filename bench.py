@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--action-scale", type=float, default=None,
                     help="actions are uniform in [-s, s]; default: the task's action-space bound")
+    ap.add_argument("--min-time", type=float, default=1.0,
+                    help="the timed region repeats the K-step block until it lasts at least this many "
+                         "seconds (same repeat count on every rank); 0 = exactly K steps")
     ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE",
                     help="extra pool parameter (A/B switches such as sort_by_cost=0)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -146,6 +149,23 @@ def main():
         step(i)
     pool.synchronize()
     torch.cuda.synchronize()
+    # The timed region is `repeats` back-to-back blocks of exactly K steps, long enough to last
+    # --min-time seconds: a 20-step HalfCheetah block is 4.5 ms, too short for any outside clock or
+    # busy sampler to see.  The count comes from one untimed calibration block, MAX over ranks.
+    repeats = 1
+    if args.min_time > 0:
+        tc = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        pool.synchronize()
+        torch.cuda.synchronize()
+        tc = time.perf_counter() - tc
+        if world > 1:
+            t = torch.tensor([tc], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tc = float(t.item())
+        repeats = max(1, min(int(np.ceil(args.min_time / max(tc, 1e-6))), max(1, 200000 // max(args.steps, 1))))
+    timed_steps = repeats * args.steps
     if world > 1:
         dist.barrier()
     # HIP events on the pool's stream around the whole timed region (first launch .. after the last):
@@ -154,7 +174,7 @@ def main():
     # times per launch.)
     pool.set_timing(2)
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(timed_steps):
         step(i)
     kernel_ms, launches = pool.kernel_time_ms()  # records the closing event, waits for the stream
     pool.synchronize()
@@ -197,7 +217,7 @@ def main():
                      "steps": k_np, "note": "send(numpy) + recv() -> numpy, PCIe inclusive"}
 
     if rank == 0:
-        total_env_steps = n * world * args.steps
+        total_env_steps = n * world * timed_steps
         value = total_env_steps / elapsed
         # algorithmic bytes / env-step: action+ids
         # in, every state key out, persistent fp64 state read + written
@@ -268,7 +288,9 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * elapsed / timed_steps,
+            "timed_steps": timed_steps,  # = steps x repeats (see --min-time); value = env-steps of ALL of them / timed_s
+            "timed_s": elapsed,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -280,6 +302,7 @@ def main():
                 "num_envs_per_gpu": n,
                 "frames_per_sec": value * frame_skip,
                 "sharding": f"env ids sharded over {world} GPU(s), no collective",
+                "params": params,  # every engine key the pool was created with, --param overrides included
             },
             "roofline": roof,
         }

@@ -32,8 +32,14 @@ def test_bench_line_schema():
     for key in ("bound", "achieved", "peak", "unit", "frac"):
         assert key in r, key
     assert r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    # value = env-steps of the timed window / its wall time
-    assert abs(d["value"] - 4096 * 6 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-6
+    # value = env-steps of the timed window / its wall time; the window is whole K-step blocks and
+    # lasts at least --min-time (1 s by default) however small K is
+    assert d["timed_steps"] % 6 == 0 and d["timed_steps"] >= 6
+    assert d["timed_s"] >= 0.9, d["timed_s"]
+    assert abs(d["ms_per_step"] * 1e-3 * d["timed_steps"] - d["timed_s"]) < 1e-6
+    assert abs(d["value"] - 4096 * d["timed_steps"] / d["timed_s"]) / d["value"] < 1e-6
+    assert d["roofline"]["launches"] == d["timed_steps"]
+    assert d["config"]["params"] == {"precision": 1}
 
 
 def test_kernel_timing_modes_agree():
