@@ -165,14 +165,18 @@ class AtariPool : public Pool {
     sync_ = cfg.batch_size <= 0 || cfg.batch_size >= n;
     batch_size_ = sync_ ? n : cfg.batch_size;
     envs_.resize(n);
-    // num_threads = 0: an eighth of the hardware threads, at most one per env of a batch.
-    // (The reference defaults to min(batch_size, hardware_concurrency); with an emulator that
-    // costs ~1 us per frame -- the synthetic console of the tests -- waking 128+ parked workers
-    // per step costs more than it buys: emulate phase of a 1024-env step 0.9 ms with 32
-    // workers, 4.3 ms with 128, 5.0 ms with 256 on a 256-thread host, profiles/r2e.  With ALE
-    // (~150 us per frame) the work dominates: set num_threads to the core count.)
-    int nthreads = a_.num_threads > 0 ? a_.num_threads
-                                      : std::max(1, (int)std::thread::hardware_concurrency() / 8);
+    // num_threads = 0: the reference's rule, min(batch_size, hardware_concurrency)
+    // (async_envpool.h:115-117) -- with a real emulator (ALE: ~150 us per frame) the emulate phase is
+    // the step and wants every core.  An emulator that costs ~1 us per frame (the synthetic
+    // console of the tests) is better served by fewer workers (emulate phase of a 1024-env step:
+    // 0.9 ms with 32 workers, 4.3 ms with 128, 5.0 ms with 256 on a 256-thread host,
+    // profiles/r2e): set num_threads, or EPA_ATARI_THREADS for a process-wide default.
+    int nthreads = a_.num_threads;
+    if (nthreads <= 0) {
+      const char* ev = getenv("EPA_ATARI_THREADS");
+      nthreads = ev ? atoi(ev) : 0;
+    }
+    if (nthreads <= 0) nthreads = std::max(1, (int)std::thread::hardware_concurrency());
     nthreads = std::max(1, std::min(nthreads, batch_size_));
     // emulators (ROM loading is the slow part: in parallel)
     std::atomic<int> next{0};
@@ -231,6 +235,8 @@ class AtariPool : public Pool {
       throw std::invalid_argument(std::string("Atari: ") + epa_last_error());
     }
     ring_.resize((size_t)4 * n);
+    slot_free_.reset(new std::atomic<uint64_t>[ring_.size()]);
+    for (size_t i = 0; i < ring_.size(); ++i) slot_free_[i].store(i, std::memory_order_relaxed);
     for (int t = 0; t < nthreads; ++t) workers_.emplace_back([this] { WorkerLoop(); });
   }
 
@@ -397,7 +403,10 @@ class AtariPool : public Pool {
     if (b) b->t_send = Now();
     uint64_t tail = tail_.load(std::memory_order_relaxed);
     for (int i = 0; i < k; ++i) {
-      while (tail - done_tickets_.load(std::memory_order_acquire) >= ring_.size()) {
+      // the slot is free once the worker that owned its previous ticket (tail - R) has copied the
+      // task out -- gated per SLOT: a count of copied tickets would let a later lap overwrite the
+      // slot of a worker that has claimed its ticket but not read it yet
+      while (slot_free_[tail % ring_.size()].load(std::memory_order_acquire) != tail) {
         std::this_thread::yield();  // ring full: more than 4 x num_envs steps outstanding
       }
       ring_[tail % ring_.size()] = Task{ids[i] - cfg_.env_id_offset, act ? act[i] : 0, force, b, i};
@@ -591,7 +600,8 @@ class AtariPool : public Pool {
         sleepers_.fetch_sub(1, std::memory_order_acq_rel);
       }
       const Task t = ring_[ticket % ring_.size()];
-      done_tickets_.fetch_add(1, std::memory_order_acq_rel);  // the slot may be reused
+      // the slot may be reused by ticket + R
+      slot_free_[ticket % ring_.size()].store(ticket + ring_.size(), std::memory_order_release);
       Env& e = envs_[t.env];
       const RowOut r = RunEnv(e, t);
       // claim the row (Allocate, state_buffer_queue.h:123-141) and write it (WriteState)
@@ -645,7 +655,8 @@ class AtariPool : public Pool {
   epa_atari_post* post_{nullptr};
   // task ring: tickets [head_, tail_) are published and unclaimed
   std::vector<Task> ring_;
-  std::atomic<uint64_t> head_{0}, tail_{0}, done_tickets_{0};
+  std::unique_ptr<std::atomic<uint64_t>[]> slot_free_;  // per slot: the ticket that may write it next
+  std::atomic<uint64_t> head_{0}, tail_{0};
   std::atomic<int> sleepers_{0};
   std::atomic<uint32_t> wake_seq_{0};
   std::atomic<bool> stop_{false};

@@ -300,7 +300,15 @@ class HumanoidPool : public Pool {
     task_.contact_cost_weight = cfg.Get("contact_cost_weight", 5e-7);
     task_.contact_cost_max = cfg.Get("contact_cost_max", 10.0);
     task_.dt = task_.frame_skip * kHumanoidModelConst.timestep;
+    // "hum_debug" switches stages of the quad kernel off (timing probes) or routes solver statistics
+    // into the info keys: only in the diagnostic build (tools/build_trace_lib.sh, -DEPA_HUM_DEBUG);
+    // the product library refuses it, so no measured figure can come from disabled physics
     task_.debug = (int)cfg.Get("hum_debug", 0);
+#ifndef EPA_HUM_DEBUG
+    if (task_.debug != 0) {
+      throw std::invalid_argument("hum_debug needs the diagnostic build (tools/build_trace_lib.sh)");
+    }
+#endif
     // "hum_layout": 1 (default) one env per lane quad (mj_hum4.hip.h), 0 one env per lane with
     // the HBM workspace (mj_tree.hip.h; kept for A/B runs)
     quad_ = cfg.Get("hum_layout", 1) != 0;

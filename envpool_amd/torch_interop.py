@@ -44,7 +44,16 @@ def send_device_tensors(pool: Any, action: Any, env_id: Any = None) -> None:
             raise RuntimeError("send_device_tensors: env_id must be contiguous int32")
         d_ids = env_id.data_ptr()
         k = int(env_id.shape[0])
-    pool.wait_stream(torch.cuda.current_stream(torch.device("cuda", pool.device)).cuda_stream)
+    dev = torch.device("cuda", pool.device)
+    pool.wait_stream(torch.cuda.current_stream(dev).cuda_stream)
+    # The step kernel reads both tensors on the pool's PRIVATE stream.  Tell torch's caching
+    # allocator, so that a temporary the caller drops right after this call
+    # (`send_device_tensors(pool, policy(obs))`) is not handed to a later kernel on torch's
+    # stream while the step kernel is still reading it.
+    pstream = torch.cuda.ExternalStream(pool.stream, device=dev)
+    for t in (action, env_id):
+        if t is not None and t.is_cuda:
+            t.record_stream(pstream)
     pool.send_device(d_action, k, d_ids)
 
 

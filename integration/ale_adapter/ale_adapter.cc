@@ -2,10 +2,14 @@
 // reference pins: envpool/workspace0.bzl:239-283).  Implements include/envpool_amd_emulator.h
 // with exactly the ALE calls envpool/atari/atari_env.h makes (cited per entry).
 //
-// NOT built by this repository's build(): ALE and its ROMs are un-vendored third parties and
-// absent offline.  A deployer builds it next to an ALE installation:
-//     g++ -std=c++17 -O2 -fPIC -shared integration/ale_adapter/ale_adapter.cc \
+// ALE and its ROMs are un-vendored third parties and absent offline.  A deployer builds this file
+// next to an ALE installation:
+//     g++ -std=c++17 -O2 -fPIC -shared integration/ale_adapter/ale_adapter.cc
 //         -I<ale>/include/ale -L<ale>/lib -lale -o libepa_ale.so
+// The repository's own build compiles THE SAME SOURCE against the ALE-API shim it owns
+// (oracle/ref_shims_atari/ale_interface.hpp: the members atari_env.h touches, over the synthetic
+// console) -> integration/_build/libepa_ale_over_shim.so (`make -C integration adapter`), and
+// tests/test_gpu_atari_env.py runs the reference-generated fixtures through that plugin.
 // and points the pool at it: envpool_amd.make("Pong-v5", ..., emulator_lib="/path/libepa_ale.so",
 // base_path=<dir holding atari/roms/pong.bin>)   (or EPA_ATARI_EMULATOR_LIB in the environment).
 #include <cstring>

@@ -17,6 +17,14 @@ def plugin_path() -> str:
     return SO
 
 
+def adapter_path() -> str:
+    """integration/ale_adapter/ale_adapter.cc (the real-ALE plugin source) compiled against the ALE-API
+    shim of oracle/ref_shims_atari: the same console behind the API a deployment would use."""
+    integ = os.path.join(os.path.dirname(HERE), "integration")
+    subprocess.run(["make", "-s", "-C", integ, "adapter"], check=True)
+    return os.path.join(integ, "_build", "libepa_ale_over_shim.so")
+
+
 def register_synthetic_ids() -> None:
     """`SynthFire-v5` etc.: the ids the reference would derive from ROM files of these names."""
     from envpool_amd.registration import list_all_envs, register

@@ -13,29 +13,36 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import atari_cases as ac  # noqa: E402
-from atari_util import plugin_path, register_synthetic_ids  # noqa: E402
+from atari_util import adapter_path, plugin_path, register_synthetic_ids  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def make_pool(name, batch_size=0, num_threads=3):
+PLUGINS = {"synth_plugin": plugin_path, "ale_adapter_over_shim": adapter_path}
+
+
+def make_pool(name, batch_size=0, num_threads=3, plugin="synth_plugin"):
     from envpool_amd.atari import AtariDevicePool
 
     c = ac.config(name)
     _, n, seed, max_steps, _ = ac.CASES[name]
     conf = {k: c[k] for k in ac.KEYS if k != "rom"}
     conf.update(num_envs=n, task=ac.ROMS[c["rom"]], base_path="/synthetic",
-                emulator_lib=plugin_path(), num_threads=num_threads)
+                emulator_lib=PLUGINS[plugin](), num_threads=num_threads)
     return AtariDevicePool(conf, batch_size=batch_size, seed=seed, max_episode_steps=max_steps)
 
 
+@pytest.mark.parametrize("plugin", list(PLUGINS))
 @pytest.mark.parametrize("name", list(ac.CASES))
-def test_atari_env_matches_reference_fixtures(name):
+def test_atari_env_matches_reference_fixtures(name, plugin):
+    """Both emulator plugins: the synthetic console behind the plugin ABI directly, and the real-ALE
+    adapter source (integration/ale_adapter/ale_adapter.cc: getScreen().getArray(), getRAM().array(),
+    theOSystem->colourPalette(), Logger::setMode ...) compiled against the ALE-API shim."""
     g = np.load(os.path.join(GOLDEN, f"atari_{name}.npz"))
     _, n, seed, max_steps, steps = ac.CASES[name]
     c = ac.config(name)
-    pool = make_pool(name)
+    pool = make_pool(name, plugin=plugin)
     assert pool.action_keys[-1][1] == np.int32
     planes = c["stack_num"] * (1 if c["gray_scale"] else 3)
     assert dict((k, s) for k, _, s in pool.state_keys)["obs"] == (planes, c["img_height"], c["img_width"])

@@ -845,3 +845,10 @@ def test_planar_spread_is_bit_identical(task, adim):
         assert a.keys() == b.keys()
         for k in a:
             assert a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), k
+
+
+def test_product_library_refuses_debug_switches():
+    """`hum_debug` (stages of the Humanoid quad kernel switched off for timing probes) exists in
+    the diagnostic build only: the product library must not produce a figure with physics disabled."""
+    with pytest.raises(Exception, match="hum_debug"):
+        DevicePool("Humanoid", 64, seed=0, max_episode_steps=1000, params={"hum_debug": 1})

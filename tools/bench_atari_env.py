@@ -20,7 +20,9 @@ from envpool_amd.atari import AtariDevicePool  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 gray = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-threads = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+# the synthetic console costs ~1 us per frame: an eighth of the hardware threads serves it best (0 = the
+# reference's default, min(batch_size, hardware_concurrency), the right rule for a real emulator)
+threads = int(sys.argv[4]) if len(sys.argv) > 4 else max(1, (os.cpu_count() or 8) // 8)
 conf = dict(num_envs=n, task="synth_fire", base_path="/synthetic", emulator_lib=plugin_path(),
             stack_num=4, frame_skip=4, noop_max=30, gray_scale=gray, use_inter_area_resize=0,
             img_height=84, img_width=84, num_threads=threads)
