@@ -1,0 +1,1064 @@
+// K3' — `mj_step` of the planar two-legged gym robots (HalfCheetah, Walker2d) with ONE ENV
+// SPLIT OVER A LANE GROUP of 2 or 4 adjacent lanes of a wavefront.
+//
+// Same arithmetic as mj_cheetah.hip.h (MuJoCo 3.6.0's mj_step for
+// third_party/mujoco_gym_xml_patches/{half_cheetah,walker2d,walker2d_v5}_envpool.xml, called
+// `frame_skip` times per env-step from envpool/mujoco/gym/mujoco_env.h:137-148; SURVEY.md §8a
+// M1-M9), re-laid out for the machine instead of for one thread per env:
+//
+//  * the robot is a torso (x / z slides + y hinge) with two 3-link legs, so M and the Newton
+//    Hessian H = M + J^T D J are "arrow" matrices: a 3x3 torso block, two 3x3 couplings, two 3x3
+//    leg blocks and NO leg/leg block.  A lane owns ONE LEG: its three bodies, three hinges, its
+//    capsule end spheres, its 3x3 + 3x3 blocks; the torso quantities (pose, velocity, the
+//    reduced 3x3) are replicated over the group.  A lane therefore carries a packed 6x6 (21
+//    numbers) instead of the 39 structural non-zeros of the 9x9 and 6-vectors instead of
+//    9-vectors: the one-env-per-lane kernel needs all 512 registers of a SIMD lane plus scratch
+//    and runs at one wave per SIMD; this one runs at two or more;
+//  * both legs execute the SAME instructions: everything that differs between the back and the
+//    front leg (link offsets, masses, joint ranges, gears, end spheres) is a per-lane constant
+//    read from a small table (`Cx::C(id)`), everything that is the same for the whole robot is an
+//    immediate of the compile-time model;
+//  * KL = 2: lane = leg, a lane owns the 6 end spheres of its leg and the 2 of "its" torso geom
+//    (back-leg lane: torso capsule, front-leg lane: head capsule), a wave holds 32 envs;
+//    KL = 4: the two lanes of a leg duplicate the leg's state and SPLIT its end spheres by
+//    parity (4 per lane), a wave holds 16 envs -- more waves for small batches;
+//  * leg elimination is local: U U^T from the last dof up eliminates the three hinges inside the
+//    lane, the two 3x3 Schur complements are summed over the group (one DPP quad_perm move + add
+//    per number) and every lane factors the same 3x3 torso block.  Cross-lane traffic per Newton
+//    iteration: 9 numbers for H and the gradient, 9 for the factorisation / solve, 5 for the
+//    products with M, 2 per line-search evaluation -- all in registers, no LDS;
+//  * as in mj_cheetah.hip.h: per-contact constants live in LDS [slot][lane], the solver passes run
+//    a scalar loop over the wave-uniform set of touching end-sphere slots, and there is no
+//    lane-divergent control flow in the solver (branches are on wave-wide ballots, per-lane
+//    differences are selects / zero weights).
+// A wave runs as long as its slowest env and visits the union of its envs' touching slots: with
+// 32 or 16 envs per wave instead of 64 both maxima shrink.
+// The same source runs on the host with V = LV<T, KL> (tests/cpu_harness/planar_lg_host.cpp), so
+// it is diffed against oracle/mjcpu on a CPU box before it ever sees a GPU.
+#ifndef ENVPOOL_AMD_CSRC_MJ_PLANAR_LG_HIP_H_
+#define ENVPOOL_AMD_CSRC_MJ_PLANAR_LG_HIP_H_
+
+#include "mj_cheetah.hip.h"  // EPA_HD, static_for, V3 / In4 algebra, Rsqrt, SinCos, WaveAny, CheetahModel
+
+namespace epa {
+namespace mj {
+namespace plg {
+
+constexpr int kLV = 6;    // local dofs of a lane: rootx rootz rooty (replicated) + the leg's 3 hinges
+constexpr int kLB = 4;    // local bodies: torso (replicated), thigh, shin, foot
+constexpr int kLTri = 21; // packed 6x6
+EPA_HD constexpr int Tri(int i, int j) { return j * (j + 1) / 2 + i; }  // i <= j
+EPA_HD constexpr int LDofBody(int j) { return j < 3 ? 0 : j - 2; }
+EPA_HD constexpr bool LInChain(int j, int b) { return j < 3 || (j - 2) <= b; }
+
+template <int KL>
+struct Grp {
+  static_assert(KL == 2 || KL == 4, "lane group of 2 or 4");
+  static constexpr int kLanes = KL;
+  static constexpr int kEnds = 16 / KL;  // end-sphere slots of a lane
+  // local body of slot s (KL = 2: both ends of a body are consecutive slots; KL = 4: one end per body)
+  EPA_HD static constexpr int SlotBody(int s) { return KL == 2 ? s / 2 : s; }
+  // lane coordinate c (0 .. KL-1) -> leg, parity
+  EPA_HD static constexpr int Leg(int c) { return KL == 2 ? c : c >> 1; }
+  EPA_HD static constexpr int Par(int c) { return KL == 2 ? 0 : c & 1; }
+  // global end-sphere index (mj_cheetah.hip.h numbering: 2 * geom + end) of slot s of lane c
+  EPA_HD static constexpr int GlobalEnd(int c, int s) {
+    const int b = SlotBody(s), leg = Leg(c);
+    const int geom = b == 0 ? leg : 1 + 3 * leg + b;
+    const int end = KL == 2 ? (s & 1) : Par(c);
+    return 2 * geom + end;
+  }
+};
+
+// ---- per-lane constant table -----------------------------------------------------------------
+// [id][c], c = lane coordinate in the group.  Ids of the leg's bodies / hinges are relative
+// (body 1..3 -> +0..2, hinge 0..2).
+enum TabId {
+  kTLx = 0, kTLz = 3, kTMass = 6, kTIyy = 9, kTCx = 12, kTCz = 15,        // bodies 1..3
+  kTStiff = 18, kTDamp = 21, kTArm = 24, kTLo = 27, kTHi = 30, kTGear = 33, kTInvw = 36,  // hinges
+  kTMu = 39, kTDiag = 43, kTD2mu = 47,  // per local body 0..3: mu, body_invw (1 + mu^2), 1 / (2 mu^2)
+  kTEx = 51,                            // kTEx + s, kTEz + s, kTEr + s for slot s (kEnds each)
+};
+template <int KL>
+struct Tab {
+  static constexpr int kEz = kTEx + Grp<KL>::kEnds, kEr = kTEx + 2 * Grp<KL>::kEnds;
+  static constexpr int kIds = kTEx + 3 * Grp<KL>::kEnds;
+  static constexpr int kSize = kIds * KL;
+};
+// fills tab[Tab<KL>::kSize] from the 7-body model (host, at pool construction / in the tests)
+template <int KL>
+inline void BuildTable(const CheetahModel<double>& m, double* tab) {
+  using G = Grp<KL>;
+  for (int c = 0; c < KL; ++c) {
+    const int leg = G::Leg(c);
+    auto put = [&](int id, double x) { tab[id * KL + c] = x; };
+    for (int k = 0; k < 3; ++k) {
+      const int b = 1 + 3 * leg + k, j = 3 * leg + k;
+      put(kTLx + k, m.lx[b]);
+      put(kTLz + k, m.lz[b]);
+      put(kTMass + k, m.mass[b]);
+      put(kTIyy + k, m.iyy[b]);
+      put(kTCx + k, m.cx[b]);
+      put(kTCz + k, m.cz[b]);
+      put(kTStiff + k, m.stiff[j]);
+      put(kTDamp + k, m.damp[j]);
+      put(kTArm + k, m.arm[j]);
+      // KL = 4: the limit rows of a leg are counted by its parity-0 lane only (the other lane's
+      // range is unbounded, so its rows never switch on)
+      put(kTLo + k, G::Par(c) == 0 ? m.lo[j] : -1e30);
+      put(kTHi + k, G::Par(c) == 0 ? m.hi[j] : 1e30);
+      put(kTGear + k, m.gear[j]);
+      put(kTInvw + k, m.dof_invw[j]);
+    }
+    for (int lb = 0; lb < kLB; ++lb) {
+      const int b = lb == 0 ? 0 : 3 * leg + lb;
+      const double mu = m.bmu[b];
+      put(kTMu + lb, mu);
+      put(kTDiag + lb, m.body_invw[b] * (1.0 + mu * mu));  // diagApprox of a pyramidal row
+      put(kTD2mu + lb, 1.0 / (2.0 * mu * mu));             // R_py = 2 mu^2 R
+    }
+    for (int s = 0; s < G::kEnds; ++s) {
+      const int e = G::GlobalEnd(c, s);
+      put(kTEx + s, m.ex[e]);
+      put(Tab<KL>::kEz + s, m.ez[e]);
+      put(Tab<KL>::kEr + s, m.er[e]);
+    }
+  }
+}
+
+// LDS slots of a lane: 5 per end-sphere slot (cpx cpz aref_n B*mu*vx D), [slot][lane]
+constexpr int kSlotsPerEnd = 5;
+template <int KL>
+constexpr int LdsSlots() { return Grp<KL>::kEnds * kSlotsPerEnd; }
+
+// ================================================================================================
+// The lane vocabulary.  Device: a value IS a lane's scalar, conditions are bool, the group
+// reductions are DPP quad_perm moves.  Host: LV<T, KL> carries the KL lanes of ONE env.
+// ================================================================================================
+template <typename T, int K>
+struct LV;
+template <int K>
+struct LB {
+  bool v[K];
+  friend inline LB operator&(LB a, LB b) { LB r; for (int i = 0; i < K; ++i) r.v[i] = a.v[i] && b.v[i]; return r; }
+  friend inline LB operator|(LB a, LB b) { LB r; for (int i = 0; i < K; ++i) r.v[i] = a.v[i] || b.v[i]; return r; }
+  friend inline LB operator!(LB a) { LB r; for (int i = 0; i < K; ++i) r.v[i] = !a.v[i]; return r; }
+};
+template <int K>
+struct LU {
+  unsigned v[K];
+};
+template <typename T, int K>
+struct LV {
+  T v[K];
+  LV() = default;
+  template <typename U, typename = typename std::enable_if<std::is_arithmetic<U>::value>::type>
+  LV(U x) { for (int i = 0; i < K; ++i) v[i] = (T)x; }  // NOLINT: broadcast
+#define EPA_LV_BIN(op)                                                   \
+  friend inline LV operator op(const LV& a, const LV& b) {               \
+    LV r;                                                                \
+    for (int i = 0; i < K; ++i) r.v[i] = a.v[i] op b.v[i];               \
+    return r;                                                            \
+  }
+  EPA_LV_BIN(+)
+  EPA_LV_BIN(-)
+  EPA_LV_BIN(*)
+  EPA_LV_BIN(/)
+#undef EPA_LV_BIN
+  friend inline LV operator-(const LV& a) { LV r; for (int i = 0; i < K; ++i) r.v[i] = -a.v[i]; return r; }
+  LV& operator+=(const LV& b) { return *this = *this + b; }
+  LV& operator-=(const LV& b) { return *this = *this - b; }
+  LV& operator*=(const LV& b) { return *this = *this * b; }
+#define EPA_LV_CMP(op)                                                   \
+  friend inline LB<K> operator op(const LV& a, const LV& b) {            \
+    LB<K> r;                                                             \
+    for (int i = 0; i < K; ++i) r.v[i] = a.v[i] op b.v[i];               \
+    return r;                                                            \
+  }
+  EPA_LV_CMP(<)
+  EPA_LV_CMP(<=)
+  EPA_LV_CMP(>)
+  EPA_LV_CMP(>=)
+  EPA_LV_CMP(==)
+  EPA_LV_CMP(!=)
+#undef EPA_LV_CMP
+};
+using ::epa::mj::SinCos;  // the scalar one (device: FastSinCos)
+template <typename T, int K>
+inline void SinCos(LV<T, K> x, LV<T, K>* s, LV<T, K>* c) {
+  for (int i = 0; i < K; ++i) {
+    s->v[i] = std::sin(x.v[i]);
+    c->v[i] = std::cos(x.v[i]);
+  }
+}
+template <typename T, int K>
+inline LV<T, K> Sel(LB<K> c, const LV<T, K>& a, const LV<T, K>& b) {
+  LV<T, K> r;
+  for (int i = 0; i < K; ++i) r.v[i] = c.v[i] ? a.v[i] : b.v[i];
+  return r;
+}
+template <typename T, int K>
+inline LV<T, K> Rsq(const LV<T, K>& x) {
+  LV<T, K> r;
+  for (int i = 0; i < K; ++i) r.v[i] = T(1) / std::sqrt(x.v[i]);
+  return r;
+}
+// lane permutations of a group: legs <-> the other leg's lane (same parity), par <-> the other parity
+template <int KL>
+constexpr int OtherLeg(int c) { return KL == 2 ? c ^ 1 : c ^ 2; }
+template <int KL, typename T>
+inline LV<T, KL> SumLegs(const LV<T, KL>& x) {
+  LV<T, KL> r;
+  for (int c = 0; c < KL; ++c) r.v[c] = x.v[c] + x.v[OtherLeg<KL>(c)];
+  return r;
+}
+template <int KL, typename T>
+inline LV<T, KL> MaxLegs(const LV<T, KL>& x) {
+  LV<T, KL> r;
+  for (int c = 0; c < KL; ++c) r.v[c] = x.v[c] > x.v[OtherLeg<KL>(c)] ? x.v[c] : x.v[OtherLeg<KL>(c)];
+  return r;
+}
+template <int KL, typename T>
+inline LV<T, KL> SumPar(const LV<T, KL>& x) {
+  if (KL == 2) return x;
+  LV<T, KL> r;
+  for (int c = 0; c < KL; ++c) r.v[c] = x.v[c] + x.v[c ^ 1];
+  return r;
+}
+template <int K>
+inline LB<K> AllEnv(LB<K> c) {
+  bool a = true;
+  for (int i = 0; i < K; ++i) a = a && c.v[i];
+  LB<K> r;
+  for (int i = 0; i < K; ++i) r.v[i] = a;
+  return r;
+}
+template <int K>
+inline bool AnyWave(LB<K> c) {
+  bool a = false;
+  for (int i = 0; i < K; ++i) a = a || c.v[i];
+  return a;
+}
+template <int K>
+inline void MaskSet(LU<K>& m, LB<K> on, int bit) {
+  for (int i = 0; i < K; ++i) m.v[i] |= (on.v[i] ? 1u : 0u) << bit;
+}
+template <int K>
+inline LB<K> MaskSame(const LU<K>& a, const LU<K>& b) {
+  LB<K> r;
+  for (int i = 0; i < K; ++i) r.v[i] = a.v[i] == b.v[i];
+  return r;
+}
+template <typename V>
+struct LaneTypes;
+template <typename T, int K>
+struct LaneTypes<LV<T, K>> {
+  using B = LB<K>;
+  using U = LU<K>;
+  static B False() { B b; for (int i = 0; i < K; ++i) b.v[i] = false; return b; }
+  static B True() { B b; for (int i = 0; i < K; ++i) b.v[i] = true; return b; }
+  static U Fill(unsigned x) { U u; for (int i = 0; i < K; ++i) u.v[i] = x; return u; }
+};
+
+// ---- device (and one-lane host) realisation ---------------------------------------------------
+template <typename T>
+EPA_HD T Sel(bool c, T a, T b) {
+  return c ? a : b;
+}
+EPA_HD double Rsq(double x) { return Rsqrt(x); }
+EPA_HD float Rsq(float x) { return Rsqrt(x); }
+EPA_HD bool AnyWave(bool c) { return WaveAny(c); }
+EPA_HD void MaskSet(unsigned& m, bool on, int bit) { m |= (on ? 1u : 0u) << bit; }
+EPA_HD bool MaskSame(unsigned a, unsigned b) { return a == b; }
+template <>
+struct LaneTypes<double> {
+  using B = bool;
+  using U = unsigned;
+  EPA_HD static B False() { return false; }
+  EPA_HD static B True() { return true; }
+  EPA_HD static U Fill(unsigned x) { return x; }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+// quad_perm selectors: [1,0,3,2] swaps neighbours, [2,3,0,1] swaps pairs.  bound_ctrl = true: a
+// quad_perm never reads out of bounds, and the compiler then knows the `old` operand is dead.
+constexpr int kDppNeighbour = 0xB1, kDppPair = 0x4E;
+template <int CTRL>
+__device__ __forceinline__ int DppMovI(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double DppMovD(double x) {
+  const int lo = DppMovI<CTRL>(__double2loint(x));
+  const int hi = DppMovI<CTRL>(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+template <int KL>
+__device__ __forceinline__ double SumLegs(double x) {
+  return x + DppMovD<KL == 2 ? kDppNeighbour : kDppPair>(x);
+}
+template <int KL>
+__device__ __forceinline__ double MaxLegs(double x) {
+  const double y = DppMovD<KL == 2 ? kDppNeighbour : kDppPair>(x);
+  return x > y ? x : y;
+}
+template <int KL>
+__device__ __forceinline__ double SumPar(double x) {
+  if constexpr (KL == 2) {
+    return x;
+  } else {
+    return x + DppMovD<kDppNeighbour>(x);
+  }
+}
+template <int KL>
+__device__ __forceinline__ bool AllEnvI(bool c) {
+  int x = c ? 1 : 0;
+  x &= DppMovI<kDppNeighbour>(x);
+  if constexpr (KL == 4) x &= DppMovI<kDppPair>(x);
+  return x != 0;
+}
+#else
+template <int KL>
+EPA_HD double SumLegs(double x) { return x; }  // hipcc's host pass only: never executed
+template <int KL>
+EPA_HD double SumPar(double x) { return x; }
+template <int KL>
+EPA_HD double MaxLegs(double x) { return x; }
+template <int KL>
+EPA_HD bool AllEnvI(bool c) { return c; }
+#endif
+// a + b over the WHOLE group
+template <int KL, typename V>
+EPA_HD V SumEnv(const V& x) {
+  return SumLegs<KL>(SumPar<KL>(x));
+}
+template <int KL>
+EPA_HD bool AllEnvOf(bool c) { return AllEnvI<KL>(c); }
+template <int KL>
+inline LB<KL> AllEnvOf(LB<KL> c) { return AllEnv(c); }
+
+template <typename V>
+EPA_HD V Abs(V x) {
+  return Sel(x < V(0), -x, x);
+}
+template <typename T, typename V>
+EPA_HD V ImpedanceV(T d0, T dmax, T width, V r) {  // mj::Impedance with selects
+  V x = Abs(r) * V(T(1) / width);
+  V y = Sel(x <= V(0.5), V(2) * x * x, V(1) - V(2) * (V(1) - x) * (V(1) - x));
+  return Sel(x >= V(1), V(dmax), V(d0) + y * V(dmax - d0));
+}
+
+// ================================================================================================
+// forward pass
+// ================================================================================================
+template <typename V>
+struct Pos {
+  V sn[kLB], cs[kLB], px[kLB], pz[kLB];  // body frames (anchors = body origins); body 0 replicated
+  V comx, comz;                          // COM of the whole robot
+  In4<V> cinert[kLB];
+  V coz[kLV], cox[kLV];                  // cdof[j] = (1, coz[j], -cox[j]) for j >= 2
+  V M[kLTri];                            // rows / columns [torso | my leg] of the joint-space inertia
+};
+template <typename V>
+EPA_HD V3<V> Cdof(const Pos<V>& p, int j) {
+  return j == 0 ? V3<V>{V(0), V(1), V(0)} : j == 1 ? V3<V>{V(0), V(0), V(1)} : V3<V>{V(1), p.coz[j], -p.cox[j]};
+}
+
+// mj_kinematics, mj_comPos, mj_crb
+template <int KL, typename T, typename V, typename Cx>
+EPA_HD void Kinematics(const CheetahModel<T>& m, const Cx& cx, const V* q, Pos<V>& p) {
+  static_for<0, kLB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    V sj, cj;
+    SinCos(q[b + 2], &sj, &cj);
+    if constexpr (b == 0) {
+      p.px[0] = V(m.lx[0]) + q[0];  // q[0] may be a local (re-centred) x; dynamics are invariant
+      p.pz[0] = V(m.lz[0]) + q[1];
+      p.sn[0] = sj;
+      p.cs[0] = cj;
+    } else {
+      const V lx = cx.C(kTLx + b - 1), lz = cx.C(kTLz + b - 1);
+      p.px[b] = p.px[b - 1] + p.cs[b - 1] * lx + p.sn[b - 1] * lz;
+      p.pz[b] = p.pz[b - 1] - p.sn[b - 1] * lx + p.cs[b - 1] * lz;
+      p.sn[b] = p.sn[b - 1] * cj + p.cs[b - 1] * sj;
+      p.cs[b] = p.cs[b - 1] * cj - p.sn[b - 1] * sj;
+    }
+  });
+  V xi[kLB], zi[kLB], mass[kLB];
+  V sx = V(0), sz = V(0);
+  static_for<0, kLB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    if constexpr (b == 0) {
+      xi[0] = p.px[0] + p.cs[0] * V(m.cx[0]) + p.sn[0] * V(m.cz[0]);
+      zi[0] = p.pz[0] - p.sn[0] * V(m.cx[0]) + p.cs[0] * V(m.cz[0]);
+      mass[0] = V(m.mass[0]);
+    } else {
+      const V ccx = cx.C(kTCx + b - 1), ccz = cx.C(kTCz + b - 1);
+      xi[b] = p.px[b] + p.cs[b] * ccx + p.sn[b] * ccz;
+      zi[b] = p.pz[b] - p.sn[b] * ccx + p.cs[b] * ccz;
+      mass[b] = cx.C(kTMass + b - 1);
+      sx += mass[b] * xi[b];
+      sz += mass[b] * zi[b];
+    }
+  });
+  const T inv_total = T(1) / m.total_mass;
+  p.comx = (V(m.mass[0]) * xi[0] + SumLegs<KL>(sx)) * V(inv_total);
+  p.comz = (V(m.mass[0]) * zi[0] + SumLegs<KL>(sz)) * V(inv_total);
+  static_for<0, kLB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    const V dx = xi[b] - p.comx, dz = zi[b] - p.comz;
+    V iyy;
+    if constexpr (b == 0) {
+      iyy = V(m.iyy[0]);
+    } else {
+      iyy = cx.C(kTIyy + b - 1);
+    }
+    p.cinert[b] = {iyy + mass[b] * (dx * dx + dz * dz), mass[b] * dx, mass[b] * dz, mass[b]};
+  });
+  static_for<2, kLV>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    constexpr int b = LDofBody(j);
+    p.coz[j] = p.comz - p.pz[b];  // hinge about +y at the body origin: (1, oz, -ox), o = com - anchor
+    p.cox[j] = p.comx - p.px[b];
+  });
+  // mj_crb: composite inertias up the leg, both legs summed into the torso
+  In4<V> crb[kLB];
+  crb[3] = p.cinert[3];
+  crb[2] = {p.cinert[2].I + crb[3].I, p.cinert[2].mdx + crb[3].mdx, p.cinert[2].mdz + crb[3].mdz,
+            p.cinert[2].m + crb[3].m};
+  crb[1] = {p.cinert[1].I + crb[2].I, p.cinert[1].mdx + crb[2].mdx, p.cinert[1].mdz + crb[2].mdz,
+            p.cinert[1].m + crb[2].m};
+  crb[0] = {p.cinert[0].I + SumLegs<KL>(crb[1].I), p.cinert[0].mdx + SumLegs<KL>(crb[1].mdx),
+            p.cinert[0].mdz + SumLegs<KL>(crb[1].mdz), V(m.total_mass)};
+  static_for<0, kLV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const V3<V> buf = MulInert(crb[LDofBody(i)], Cdof(p, i));
+    static_for<0, i + 1>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      p.M[Tri(j, i)] = Dot(Cdof(p, j), buf);
+    });
+    if constexpr (i >= 3) p.M[Tri(i, i)] += cx.C(kTArm + i - 3);
+  });
+}
+
+// qfrc_smooth = passive - bias + actuator (mj_fwdVelocity, mj_fwdActuation); ctrl: the leg's 3 motors
+template <int KL, typename T, typename V, typename Cx>
+EPA_HD void SmoothForces(const CheetahModel<T>& m, const Cx& cx, const Pos<V>& p, const V* q,
+                         const V* v, const V* ctrl, V* qfrc_smooth) {
+  V3<V> cvel[kLB], cdd[kLV];
+  {
+    V3<V> cv = {V(0), V(0), V(0)};
+    static_for<0, 3>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const V3<V> cd = Cdof(p, j);
+      cdd[j] = CrossMotion(cv, cd);
+      cv.w += cd.w * v[j];
+      cv.x += cd.x * v[j];
+      cv.z += cd.z * v[j];
+    });
+    cvel[0] = cv;
+  }
+  static_for<1, kLB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    constexpr int j = b + 2;
+    V3<V> cv = cvel[b - 1];
+    const V3<V> cd = Cdof(p, j);
+    cdd[j] = CrossMotion(cv, cd);
+    cv.w += cd.w * v[j];
+    cv.x += cd.x * v[j];
+    cv.z += cd.z * v[j];
+    cvel[b] = cv;
+  });
+  // mj_rne (no acceleration term); world cacc = -gravity
+  V3<V> cacc[kLB], cfrc[kLB];
+  static_for<0, kLB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    V3<V> a;
+    if constexpr (b == 0) {
+      a = {V(0), V(0), V(m.gravity)};
+      static_for<0, 3>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        a.w += cdd[j].w * v[j];
+        a.x += cdd[j].x * v[j];
+        a.z += cdd[j].z * v[j];
+      });
+    } else {
+      constexpr int j = b + 2;
+      a = cacc[b - 1];
+      a.w += cdd[j].w * v[j];
+      a.x += cdd[j].x * v[j];
+      a.z += cdd[j].z * v[j];
+    }
+    cacc[b] = a;
+    const V3<V> f = MulInert(p.cinert[b], a);
+    const V3<V> g = CrossForce(cvel[b], MulInert(p.cinert[b], cvel[b]));
+    cfrc[b] = {f.w + g.w, f.x + g.x, f.z + g.z};
+  });
+  cfrc[2] = {cfrc[2].w + cfrc[3].w, cfrc[2].x + cfrc[3].x, cfrc[2].z + cfrc[3].z};
+  cfrc[1] = {cfrc[1].w + cfrc[2].w, cfrc[1].x + cfrc[2].x, cfrc[1].z + cfrc[2].z};
+  cfrc[0] = {cfrc[0].w + SumLegs<KL>(cfrc[1].w), cfrc[0].x + SumLegs<KL>(cfrc[1].x),
+             cfrc[0].z + SumLegs<KL>(cfrc[1].z)};
+  static_for<0, kLV>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const V bias = Dot(Cdof(p, j), cfrc[LDofBody(j)]);
+    if constexpr (j < 3) {
+      qfrc_smooth[j] = -bias;
+    } else {
+      // mj_passive (spring about qpos_spring = 0, damper) + motor
+      qfrc_smooth[j] = -cx.C(kTStiff + j - 3) * q[j] - cx.C(kTDamp + j - 3) * v[j] - bias +
+                       cx.C(kTGear + j - 3) * ctrl[j - 3];
+    }
+  });
+}
+
+// Jacobian columns of a contact point (cpx, cpz) on local body B: f(j, Jn_j, Jx_j) for every
+// chain dof (Jn = d(z velocity)/d qdot_j, Jx = d(x velocity)/d qdot_j)
+template <int B, typename V, typename F>
+EPA_HD void ForChainCols(const Pos<V>& p, V cpx, V cpz, F&& f) {
+  f(IC<0>{}, V(0), V(1));
+  f(IC<1>{}, V(1), V(0));
+  static_for<2, kLV>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (LInChain(j, B)) {
+      constexpr int b = LDofBody(j);
+      f(jc, -(cpx - p.px[b]), cpz - p.pz[b]);
+    }
+  });
+}
+template <typename F>
+EPA_HD void DispatchLocalBody(int b, F&& f) {  // wave-uniform switch
+  switch (b) {
+    case 0: f(IC<0>{}); break;
+    case 1: f(IC<1>{}); break;
+    case 2: f(IC<2>{}); break;
+    default: f(IC<3>{}); break;
+  }
+}
+// friction coefficient of the floor pair of local body B
+template <int B, typename T, typename V, typename Cx>
+EPA_HD V MuOf(const CheetahModel<T>& m, const Cx& cx) {
+  if constexpr (B == 0) {
+    return V(m.bmu[0]);
+  } else {
+    return cx.C(kTMu + B);
+  }
+}
+
+template <typename V>
+struct LimitRows {
+  V sgn[3], aref[3], D[3];
+};
+
+// mj_makeConstraint: limit rows into `lim`, contact constants into the lane's LDS slots.  Returns
+// the wave-uniform set of end-sphere SLOTS (bit s) that touch the plane on any lane of the wave.
+template <int KL, typename T, typename V, typename Cx>
+EPA_HD unsigned MakeConstraint(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const V* q,
+                               const V* v, LimitRows<V>& lim) {
+  const T kMinVal = T(1e-15);
+  static_for<0, 3>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const V qq = q[j + 3];
+    const V dlo = qq - cx.C(kTLo + j), dhi = cx.C(kTHi + j) - qq;
+    const auto blo = dlo < V(0), bhi = dhi < V(0);
+    const V sgn = Sel(blo, V(1), Sel(bhi, V(-1), V(0)));
+    const V dist = Sel(blo, dlo, Sel(bhi, dhi, V(0)));
+    const V imp = ImpedanceV(m.lim_d0, m.lim_dmax, m.lim_width, dist);
+    // R = max(mjMINVAL, (1 - imp) / imp * diagApprox), D = 1 / R
+    const V num = (V(1) - imp) * cx.C(kTInvw + j);
+    const V Dj = Sel(num < V(kMinVal) * imp, V(T(1) / kMinVal), imp / num);
+    lim.sgn[j] = sgn;
+    lim.D[j] = Sel(sgn != V(0), Dj, V(0));
+    lim.aref[j] = -V(m.lim_B) * (sgn * v[j + 3]) - V(m.lim_K) * imp * dist;
+  });
+  unsigned ends = 0;
+  static_for<0, Grp<KL>::kEnds>([&](auto sc) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int b = Grp<KL>::SlotBody(s);
+    const V ex = cx.C(kTEx + s), ez = cx.C(Tab<KL>::kEz + s), er = cx.C(Tab<KL>::kEr + s);
+    const V wx = p.px[b] + p.cs[b] * ex + p.sn[b] * ez;
+    const V wz = p.pz[b] - p.sn[b] * ex + p.cs[b] * ez;
+    const V dist = wz - er;  // unused slots of a model carry er = -1e30: never touch
+    V D = V(0), an = V(0), ax = V(0);
+    const V cpx = wx, cpz = V(0.5) * dist;
+    const auto touch = dist < V(m.con_margin);
+    if (AnyWave(touch)) {
+      ends |= 1u << s;
+      V vn = V(0), vx = V(0);
+      ForChainCols<b>(p, cpx, cpz, [&](auto jc, V jn, V jx) {
+        constexpr int j = decltype(jc)::value;
+        vn += jn * v[j];
+        vx += jx * v[j];
+      });
+      const V r = dist - V(m.con_margin);
+      const V imp = ImpedanceV(m.con_d0, m.con_dmax, m.con_width, r);
+      V diag, d2mu;  // diagApprox (pyramidal) = tran (1 + mu^2); R_py = 2 mu^2 R
+      if constexpr (b == 0) {
+        diag = V(m.body_invw[0] * (T(1) + m.bmu[0] * m.bmu[0]));
+        d2mu = V(T(1) / (T(2) * m.bmu[0] * m.bmu[0]));
+      } else {
+        diag = cx.C(kTDiag + b);
+        d2mu = cx.C(kTD2mu + b);
+      }
+      const V mu = MuOf<b, T, V>(m, cx);
+      const V num = (V(1) - imp) * diag;  // R = max(mjMINVAL, num / imp)
+      const V invR = Sel(num < V(kMinVal) * imp, V(T(1) / kMinVal), imp / num);
+      D = Sel(touch, invR * d2mu, V(0));
+      an = Sel(touch, -V(m.con_B) * vn - V(m.con_K) * imp * r, V(0));
+      ax = Sel(touch, V(m.con_B) * mu * vx, V(0));
+    }
+    cx.Lds(s * kSlotsPerEnd + 0) = cpx;
+    cx.Lds(s * kSlotsPerEnd + 1) = cpz;
+    cx.Lds(s * kSlotsPerEnd + 2) = an;
+    cx.Lds(s * kSlotsPerEnd + 3) = ax;
+    cx.Lds(s * kSlotsPerEnd + 4) = D;
+  });
+  return WaveUniform(ends);
+}
+
+// One pass over the lane's constraint rows at acceleration `a`: accumulates THIS LANE's part of
+// J^T f into gc (6) and, if kHess, of J^T D_active J into Hc (21); the lane's active-row mask in
+// `mask`.  The caller sums the torso entries over the group.
+template <int KL, bool kHess, typename T, typename V, typename Cx, typename U>
+EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRows<V>& lim,
+                     unsigned ends, const V* a, V* gc, V* Hc, U& mask) {
+  static_for<0, 3>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const V jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
+    const auto on = (lim.sgn[j] != V(0)) & (jar < V(0));
+    const V w = Sel(on, lim.D[j], V(0));
+    gc[j + 3] += lim.sgn[j] * w * jar;
+    if constexpr (kHess) Hc[Tri(j + 3, j + 3)] += w;
+    MaskSet(mask, on, j);
+  });
+  EPA_NO_UNROLL
+  for (unsigned rem = ends; rem != 0; rem &= rem - 1) {  // scalar loop over the touching slots
+    const int s = __builtin_ctz(rem);
+    const V D = cx.Lds(s * kSlotsPerEnd + 4);
+    DispatchLocalBody(Grp<KL>::SlotBody(s), [&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      const V cpx = cx.Lds(s * kSlotsPerEnd + 0), cpz = cx.Lds(s * kSlotsPerEnd + 1);
+      const V an = cx.Lds(s * kSlotsPerEnd + 2), ax = cx.Lds(s * kSlotsPerEnd + 3);
+      V jna = V(0), jxa = V(0);
+      ForChainCols<b>(p, cpx, cpz, [&](auto jc, V jn, V jx) {
+        constexpr int j = decltype(jc)::value;
+        jna += jn * a[j];
+        jxa += jx * a[j];
+      });
+      // rows: 2 x (Jn), (Jn - mu Jx), (Jn + mu Jx); D == 0 for lanes not in contact, which
+      // zeroes every weight below
+      const V mu = MuOf<b, T, V>(m, cx);
+      const V jar1 = jna - an;
+      const V jar2 = jna - mu * jxa - (an + ax);
+      const V jar3 = jna + mu * jxa - (an - ax);
+      const auto on = D > V(0);
+      const auto a1 = on & (jar1 < V(0)), a2 = on & (jar2 < V(0)), a3 = on & (jar3 < V(0));
+      const V w1 = Sel(a1, V(2) * D, V(0));
+      const V w2 = Sel(a2, D, V(0));
+      const V w3 = Sel(a3, D, V(0));
+      MaskSet(mask, a1, 3 + 3 * s);
+      MaskSet(mask, a2, 4 + 3 * s);
+      MaskSet(mask, a3, 5 + 3 * s);
+      const V gn = w1 * jar1 + w2 * jar2 + w3 * jar3;  // coefficient of Jn
+      const V gx = mu * (w3 * jar3 - w2 * jar2);      // coefficient of Jx
+      const V A = w1 + w2 + w3, Bc = mu * (w3 - w2), C = mu * mu * (w2 + w3);
+      if (AnyWave(A > V(0))) {
+        ForChainCols<b>(p, cpx, cpz, [&](auto ic, V jni, V jxi) {
+          constexpr int i = decltype(ic)::value;
+          gc[i] += jni * gn + jxi * gx;
+          if constexpr (kHess) {
+            const V ui = A * jni + Bc * jxi, wi = Bc * jni + C * jxi;
+            ForChainCols<b>(p, cpx, cpz, [&](auto kc, V jnk, V jxk) {
+              constexpr int k = decltype(kc)::value;
+              if constexpr (k >= i) Hc[Tri(i, k)] += ui * jnk + wi * jxk;
+            });
+          }
+        });
+      }
+    });
+  }
+}
+
+// this lane's part of phi'(alpha), phi''(alpha) from its rows along `s` from `a`
+template <int KL, typename T, typename V, typename Cx>
+EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRows<V>& lim,
+                     unsigned ends, const V* a, const V* s, V alpha, V* d1, V* d2) {
+  static_for<0, 3>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const V jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
+    const V jv = lim.sgn[j] * s[j + 3];
+    const V x = jar + alpha * jv;
+    const V w = Sel((lim.sgn[j] != V(0)) & (x < V(0)), lim.D[j], V(0));
+    *d1 += w * x * jv;
+    *d2 += w * jv * jv;
+  });
+  EPA_NO_UNROLL
+  for (unsigned rem = ends; rem != 0; rem &= rem - 1) {
+    const int sl = __builtin_ctz(rem);
+    const V D = cx.Lds(sl * kSlotsPerEnd + 4);
+    DispatchLocalBody(Grp<KL>::SlotBody(sl), [&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      const V cpx = cx.Lds(sl * kSlotsPerEnd + 0), cpz = cx.Lds(sl * kSlotsPerEnd + 1);
+      const V an = cx.Lds(sl * kSlotsPerEnd + 2), ax = cx.Lds(sl * kSlotsPerEnd + 3);
+      V jna = V(0), jxa = V(0), jns = V(0), jxs = V(0);
+      ForChainCols<b>(p, cpx, cpz, [&](auto jc, V jn, V jx) {
+        constexpr int j = decltype(jc)::value;
+        jna += jn * a[j];
+        jxa += jx * a[j];
+        jns += jn * s[j];
+        jxs += jx * s[j];
+      });
+      const V mu = MuOf<b, T, V>(m, cx);
+      const V jar1 = jna - an, jv1 = jns;
+      const V jar2 = jna - mu * jxa - (an + ax), jv2 = jns - mu * jxs;
+      const V jar3 = jna + mu * jxa - (an - ax), jv3 = jns + mu * jxs;
+      const V x1 = jar1 + alpha * jv1, x2 = jar2 + alpha * jv2, x3 = jar3 + alpha * jv3;
+      // D == 0 for lanes not in contact
+      const V c1 = Sel(x1 < V(0), V(2) * D, V(0));
+      const V c2 = Sel(x2 < V(0), D, V(0));
+      const V c3 = Sel(x3 < V(0), D, V(0));
+      *d1 += c1 * x1 * jv1 + c2 * x2 * jv2 + c3 * x3 * jv3;
+      *d2 += c1 * jv1 * jv1 + c2 * jv2 * jv2 + c3 * jv3 * jv3;
+    });
+  }
+}
+
+// ---- the arrow system ---------------------------------------------------------------------------
+// A: packed local 6x6 = rows / columns [torso | my leg] of a 9x9 arrow matrix (torso block
+// replicated and COMPLETE, coupling and leg block private).  In place: A = U U^T from the last dof
+// up (tree order: no fill between the legs), diagonal stored INVERTED.
+template <int KL, typename V>
+EPA_HD void FactorArrow(V* A) {
+  static_for_down<kLV, 3>([&](auto jc) {  // the leg's hinges, inside the lane
+    constexpr int j = decltype(jc)::value;
+    V s = A[Tri(j, j)];
+    static_for<j + 1, kLV>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      s -= A[Tri(j, k)] * A[Tri(j, k)];
+    });
+    const V inv = Rsq(s);
+    A[Tri(j, j)] = inv;
+    static_for<0, j>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      V t = A[Tri(i, j)];
+      static_for<j + 1, kLV>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        t -= A[Tri(i, k)] * A[Tri(j, k)];
+      });
+      A[Tri(i, j)] = t * inv;
+    });
+  });
+  // torso block: minus both legs' Schur complements
+  static_for<0, 3>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    static_for<0, j + 1>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      V c = A[Tri(i, 3)] * A[Tri(j, 3)] + A[Tri(i, 4)] * A[Tri(j, 4)] + A[Tri(i, 5)] * A[Tri(j, 5)];
+      A[Tri(i, j)] -= SumLegs<KL>(c);
+    });
+  });
+  static_for_down<3, 0>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    V s = A[Tri(j, j)];
+    static_for<j + 1, 3>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      s -= A[Tri(j, k)] * A[Tri(j, k)];
+    });
+    const V inv = Rsq(s);
+    A[Tri(j, j)] = inv;
+    static_for<0, j>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      V t = A[Tri(i, j)];
+      static_for<j + 1, 3>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        t -= A[Tri(i, k)] * A[Tri(j, k)];
+      });
+      A[Tri(i, j)] = t * inv;
+    });
+  });
+}
+// solve U U^T x = b in place (x: torso part replicated, leg part private)
+template <int KL, typename V>
+EPA_HD void SolveArrow(const V* U, V* x) {
+  static_for_down<kLV, 3>([&](auto jc) {  // U y = b, the leg
+    constexpr int j = decltype(jc)::value;
+    V s = x[j];
+    static_for<j + 1, kLV>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      s -= U[Tri(j, k)] * x[k];
+    });
+    x[j] = s * U[Tri(j, j)];
+  });
+  static_for_down<3, 0>([&](auto jc) {  // the torso rows see both legs
+    constexpr int j = decltype(jc)::value;
+    const V r = U[Tri(j, 3)] * x[3] + U[Tri(j, 4)] * x[4] + U[Tri(j, 5)] * x[5];
+    V s = x[j] - SumLegs<KL>(r);
+    static_for<j + 1, 3>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      s -= U[Tri(j, k)] * x[k];
+    });
+    x[j] = s * U[Tri(j, j)];
+  });
+  static_for<0, kLV>([&](auto jc) {  // U^T x = y: no cross-leg terms
+    constexpr int j = decltype(jc)::value;
+    V s = x[j];
+    static_for<0, j>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      s -= U[Tri(i, j)] * x[i];
+    });
+    x[j] = s * U[Tri(j, j)];
+  });
+}
+// y = A x for the arrow matrix
+template <int KL, typename V>
+EPA_HD void MulArrow(const V* A, const V* x, V* y) {
+  static_for<0, 3>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    V t = V(0), l = V(0);
+    static_for<0, 3>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      t += A[i <= j ? Tri(i, j) : Tri(j, i)] * x[j];
+    });
+    static_for<3, kLV>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      l += A[Tri(i, j)] * x[j];
+    });
+    y[i] = t + SumLegs<KL>(l);
+  });
+  static_for<3, kLV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    V t = V(0);
+    static_for<0, kLV>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      t += A[i <= j ? Tri(i, j) : Tri(j, i)] * x[j];
+    });
+    y[i] = t;
+  });
+}
+// a . b over the 9 dofs of the env (torso part counted once)
+template <int KL, typename V>
+EPA_HD V DotEnv(const V* a, const V* b) {
+  const V t = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  const V l = a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+  return t + SumLegs<KL>(l);
+}
+
+template <typename T>
+struct SolverCfgLg {
+  int max_iter;
+  T gtol;  // stop when |grad| <= gtol * (1 + |qfrc_smooth|_inf)
+};
+
+// mj_fwdConstraint: exact Newton on the primal objective
+//   1/2 (a-a0)^T M (a-a0) + sum_r 1/2 D_r min(0, J_r a - aref_r)^2
+// started from qacc (= qacc_warmstart).  Same iteration as mj_cheetah.hip.h::CheetahSolve: exact
+// piecewise-quadratic line search, finite termination (same active set after a full Newton step),
+// wave-uniform control flow.  Outputs qacc, Ma = M qacc and the final gradient
+// (qfrc_constraint = Ma - qfrc_smooth - grad); returns the env's Newton iterations.
+template <int KL, typename T, typename V, typename Cx>
+EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRows<V>& lim,
+               unsigned ends, const V* qfrc_smooth, const SolverCfgLg<T>& cfg, V* qacc, V* Ma, V* grad) {
+  using LT = LaneTypes<V>;
+  using B = typename LT::B;
+  using U = typename LT::U;
+  V fs = V(0);
+  static_for<0, kLV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const V x = Abs(qfrc_smooth[i]);
+    fs = Sel(x > fs, x, fs);
+  });
+  fs = MaxLegs<KL>(fs);
+  const V gstop = V(cfg.gtol) * (V(1) + fs);
+  const V gstop2 = gstop * gstop;
+  // rounding floor: once the gradient is this small and has stopped shrinking the iterate is as
+  // converged as the arithmetic allows
+  const V gfloor = V(T(1e-9)) * (V(1) + fs);
+  const V gfloor2 = gfloor * gfloor;
+  V prev_gn2 = V(-1);
+  MulArrow<KL>(p.M, qacc, Ma);  // kept current incrementally: Ma += alpha * M s
+  U prev_mask = LT::Fill(~0u);
+  B full_step = LT::False();
+  B live = LT::True();
+  V iter = V(0);
+  for (int it = 0; it < cfg.max_iter; ++it) {
+    // Every lane (also those of finished envs, whose qacc and Ma are frozen) rebuilds H and grad
+    // at its current qacc, so both are current on exit.
+    V H[kLTri], gc[kLV];
+    static_for<0, kLTri>([&](auto kc) { H[decltype(kc)::value] = V(0); });
+    static_for<0, kLV>([&](auto ic) { gc[decltype(ic)::value] = V(0); });
+    U mask = LT::Fill(0u);
+    RowsPass<KL, true>(m, cx, p, lim, ends, qacc, gc, H, mask);
+    // group sums: the torso entries collect every lane of the env, the leg entries the leg's lanes
+    static_for<0, kLV>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j < 3) {
+        gc[j] = SumEnv<KL>(gc[j]);
+      } else {
+        gc[j] = SumPar<KL>(gc[j]);
+      }
+      grad[j] = (Ma[j] - qfrc_smooth[j]) + gc[j];
+      static_for<0, j + 1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (j < 3) {
+          H[Tri(i, j)] = p.M[Tri(i, j)] + SumEnv<KL>(H[Tri(i, j)]);
+        } else {
+          H[Tri(i, j)] = p.M[Tri(i, j)] + SumPar<KL>(H[Tri(i, j)]);
+        }
+      });
+    });
+    const V gn2 = DotEnv<KL>(grad, grad);
+    const B same = AllEnvOf<KL>(MaskSame(mask, prev_mask));
+    // |grad| <= gstop; or finite termination: same active set after a full Newton step; or at the
+    // rounding floor and no longer shrinking (x4)
+    const B stop = (gn2 <= gstop2) | (full_step & same) |
+                   ((prev_gn2 >= V(0)) & (gn2 <= gfloor2) & (gn2 >= V(0.0625) * prev_gn2));
+    live = live & !stop;
+    if (!AnyWave(live)) break;
+    iter += Sel(live, V(1), V(0));
+    prev_gn2 = gn2;
+    prev_mask = mask;
+    V s[kLV];
+    static_for<0, kLV>([&](auto ic) { s[decltype(ic)::value] = -grad[decltype(ic)::value]; });
+    FactorArrow<KL>(H);
+    SolveArrow<KL>(H, s);
+    // exact line search on the convex piecewise-quadratic phi(alpha)
+    V Ms[kLV], r0[kLV];
+    MulArrow<KL>(p.M, s, Ms);
+    static_for<0, kLV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      r0[i] = Ma[i] - qfrc_smooth[i];
+    });
+    const V g1 = DotEnv<KL>(s, r0), g2 = DotEnv<KL>(s, Ms);
+    V alpha = V(1), lo = V(0), hi = V(-1);
+    full_step = LT::False();
+    const V ls_tol = V(T(1e-10)) * Abs(g1);
+    B searching = live;
+    for (int ls = 0; ls < 24; ++ls) {
+      V d1p = V(0), d2p = V(0);
+      LineEval<KL>(m, cx, p, lim, ends, qacc, s, alpha, &d1p, &d2p);
+      const V d1 = (g1 + alpha * g2) + SumEnv<KL>(d1p), d2 = g2 + SumEnv<KL>(d2p);
+      const B hit = Abs(d1) <= ls_tol;
+      // a full Newton step is exact for the active set H was built with
+      if (ls == 0) full_step = searching & hit;
+      searching = searching & !hit;
+      const B neg = d1 < V(0);
+      lo = Sel(searching & neg, alpha, lo);
+      hi = Sel(searching & !neg, alpha, hi);
+      V next = alpha - d1 / d2;
+      next = Sel((hi >= V(0)) & ((next <= lo) | (next >= hi)), V(0.5) * (lo + hi), next);
+      next = Sel(next <= V(0), V(0.5) * alpha, next);
+      searching = searching & (next != alpha);
+      alpha = Sel(searching, next, alpha);
+      if (!AnyWave(searching)) break;
+    }
+    const V step = Sel(live, alpha, V(0));
+    static_for<0, kLV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      qacc[i] += step * s[i];
+      Ma[i] += step * Ms[i];
+    });
+  }
+  if (AnyWave(live)) {  // iteration cap hit somewhere in the wave: refresh grad
+    V gc[kLV];
+    static_for<0, kLV>([&](auto ic) { gc[decltype(ic)::value] = V(0); });
+    U mask = LT::Fill(0u);
+    RowsPass<KL, false>(m, cx, p, lim, ends, qacc, gc, static_cast<V*>(nullptr), mask);
+    static_for<0, kLV>([&](auto jc) {  // only for the envs that did hit the cap
+      constexpr int j = decltype(jc)::value;
+      V g;
+      if constexpr (j < 3) {
+        g = SumEnv<KL>(gc[j]);
+      } else {
+        g = SumPar<KL>(gc[j]);
+      }
+      grad[j] = Sel(live, (Ma[j] - qfrc_smooth[j]) + g, grad[j]);
+    });
+  }
+  return iter;
+}
+
+// mj_forward: qacc at (q, v) under ctrl; `warm` is qacc_warmstart in/out; `p` keeps M for the caller
+template <int KL, typename T, typename V, typename Cx>
+EPA_HD V Forward(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, const V* q, const V* v,
+                 V* warm, const V* ctrl, Pos<V>& p, V* qacc, V* Ma, V* grad) {
+  cx.Refresh();
+  Kinematics<KL>(m, cx, q, p);
+  V qfrc_smooth[kLV];
+  SmoothForces<KL>(m, cx, p, q, v, ctrl, qfrc_smooth);
+  LimitRows<V> lim;
+  const unsigned ends = MakeConstraint<KL>(m, cx, p, q, v, lim);
+  static_for<0, kLV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
+  const V iters = Solve<KL>(m, cx, p, lim, ends, qfrc_smooth, cfg, qacc, Ma, grad);
+  static_for<0, kLV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
+  return iters;
+}
+
+// One mj_step, Euler with implicit joint damping (HalfCheetah).  q[0] is carried as a local offset
+// (the caller accumulates the absolute root x in fp64); returns the env's Newton iterations.
+template <int KL, typename T, typename V, typename Cx>
+EPA_HD V StepEuler(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, V* q, V* v, V* warm,
+                   const V* ctrl) {
+  Pos<V> p;
+  V qacc[kLV], Ma[kLV], grad[kLV];
+  const V iters = Forward<KL>(m, cfg, cx, q, v, warm, ctrl, p, qacc, Ma, grad);
+  // (M + h diag(damping)) qacc_d = qfrc_smooth + qfrc_constraint = Ma - grad
+  V rhs[kLV];
+  static_for<0, kLV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    rhs[i] = Ma[i] - grad[i];
+    if constexpr (i >= 3) p.M[Tri(i, i)] += V(m.timestep) * cx.C(kTDamp + i - 3);
+  });
+  FactorArrow<KL>(p.M);
+  SolveArrow<KL>(p.M, rhs);
+  static_for<0, kLV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    v[i] += V(m.timestep) * rhs[i];
+    q[i] += V(m.timestep) * v[i];
+  });
+  return iters;
+}
+
+// One mj_step with integrator RK4 (mj_RungeKutta(4)), the Walker2d setting
+// (walker2d_envpool.xml:29): four forward evaluations per step, explicit damping (no eulerdamp).
+template <int KL, typename T, typename V, typename Cx>
+EPA_HD V StepRK4(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, V* q, V* v, V* warm,
+                 const V* ctrl) {
+  const V h = V(m.timestep);
+  V q0[kLV], v0[kLV], qs[kLV], vs[kLV], F[kLV], dq[kLV], dv[kLV];
+  static_for<0, kLV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    q0[i] = qs[i] = q[i];
+    v0[i] = vs[i] = v[i];
+    dq[i] = dv[i] = V(0);
+  });
+  // stages 1..4 through ONE instance of the forward pass (a rolled loop):
+  // X_i = X_0 + h a_i (Xv_{i-1}, F_{i-1}), a = 1/2, 1/2, 1; weights 1/6, 1/3, 1/3, 1/6
+  V it = V(0);
+#if defined(__clang__)
+#pragma nounroll
+#endif
+  for (int stage = 0; stage < 4; ++stage) {
+    Pos<V> p;
+    V Ma[kLV], grad[kLV];
+    it += Forward<KL>(m, cfg, cx, qs, vs, warm, ctrl, p, F, Ma, grad);
+    const V bw = V((stage == 0 || stage == 3) ? T(1.0 / 6.0) : T(1.0 / 3.0));
+    const V a = V(stage == 2 ? T(1) : T(0.5));
+    static_for<0, kLV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      dq[i] += bw * vs[i];
+      dv[i] += bw * F[i];
+      qs[i] = q0[i] + h * (a * vs[i]);  // the state of the next stage (unused after stage 4)
+      vs[i] = v0[i] + h * a * F[i];
+    });
+  }
+  static_for<0, kLV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    v[i] = v0[i] + h * dv[i];
+    q[i] = q0[i] + h * dq[i];
+  });
+  return it;
+}
+
+}  // namespace plg
+}  // namespace mj
+}  // namespace epa
+
+#endif  // ENVPOOL_AMD_CSRC_MJ_PLANAR_LG_HIP_H_

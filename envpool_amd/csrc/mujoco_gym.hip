@@ -24,8 +24,7 @@
 #include "engine.h"
 #include "mj_cheetah.hip.h"
 #include "mj_cheetah_model.h"
-#include "build/mj_cheetah_consts.inc"  // generated: kCheetahModelConst (gen_mj_consts.cpp)
-#include "build/mj_walker_consts.inc"   // generated: kWalkerModelConst, kWalkerV5ModelConst, kHopperModelConst
+#include "mujoco_planar_common.h"  // CheetahDev, CheetahTask, PlanarModel<T, model>, the generated models
 
 namespace epa {
 namespace {
@@ -33,49 +32,11 @@ namespace {
 using mj::CheetahModel;
 using mj::kNU;
 using mj::kNV;
+using planar::CheetahDev;
+using planar::CheetahTask;
+using planar::kCheetahBlock;
+using planar::PlanarModel;
 
-struct CheetahDev {
-  double* qpos;  // [9][N]
-  double* qvel;  // [9][N]
-  double* warm;  // [9][N]
-  int* iters;              // Newton iterations of the last step (profiling)
-  double* stack;           // [N][frame_stack * nobs] obs ring (frame_stack > 1 only)
-  double* nsaved;          // normal_distribution::_M_saved
-  unsigned char* navail;   // normal_distribution::_M_saved_available
-  // diagnostic (EPA_PLANAR_TRACE=<file>): per wave of the last launch {wall clock begin,
-  // end (100 MHz), core clock begin, end, Newton iterations the wave executed (sum over
-  // mj_steps of the slowest lane's count), HW_ID}; nullptr otherwise
-  long long* trace;
-};
-
-struct CheetahTask {
-  int frame_skip;
-  int frame_stack;  // TypedFrameStackBuffer depth (envpool/mujoco/frame_stack.h:74-146)
-  int obs_skip;  // 1 if exclude_current_positions_from_observation
-  double ctrl_cost_weight, forward_reward_weight, reset_noise_scale;
-  double dt;     // frame_skip * timestep, computed in fp64 like the reference
-  // Walker2d (walker2d.h:32-47) and Hopper (hopper.h:32-49; healthy_z_max unused there)
-  double healthy_reward, healthy_z_min, healthy_z_max, healthy_angle_min,
-      healthy_angle_max, velocity_min, velocity_max, healthy_state_min, healthy_state_max;
-  int terminate_when_unhealthy, legacy_healthy_reward;
-  int lanes;  // envs per wave of THIS launch (64 once the batch fills every SIMD; see Launch)
-};
-
-// compile-time model of the planar kernel instance (mj_cheetah.hip.h, PlanarModelId)
-template <typename T, int kModel>
-constexpr CheetahModel<T> PlanarModel() {
-  if constexpr (kModel == mj::kPlanarCheetah) {
-    return mj::CastCheetahModel<T>(kCheetahModelConst);
-  } else if constexpr (kModel == mj::kPlanarWalker) {
-    return mj::CastCheetahModel<T>(kWalkerModelConst);
-  } else if constexpr (kModel == mj::kPlanarHopper) {
-    return mj::CastCheetahModel<T>(kHopperModelConst);
-  } else {
-    return mj::CastCheetahModel<T>(kWalkerV5ModelConst);
-  }
-}
-
-constexpr int kCheetahBlock = 64;
 
 template <typename T, int kModel>
 __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
@@ -391,6 +352,23 @@ class CheetahPool : public Pool {
     trace_.Init("EPA_PLANAR_TRACE", (n + kCheetahBlock - 1) / kCheetahBlock, stream_);
     dev_.trace = trace_.d;
     spread_ = cfg.Get("planar_spread", 1) != 0;  // extension key, see Launch
+    // "planar_layout" (extension key): 1 = one env per lane (CheetahStepKernel), 2 / 4 = one env per
+    // group of 2 / 4 lanes (mujoco_planar_lg.hip; fp64, HalfCheetah / Walker2d, frame_stack 1),
+    // 0 (default) = chosen per launch from the batch size, see Launch
+    layout_ = (int)cfg.Get("planar_layout", 0);
+    if (layout_ != 0 && layout_ != 1 && layout_ != 2 && layout_ != 4) {
+      throw std::invalid_argument("planar_layout must be 0, 1, 2 or 4");
+    }
+    lg_ok_ = fp64_ && !hopper && task_.frame_stack == 1;
+    lg_waves_ = (int)cfg.Get("planar_waves", 2) == 1 ? 1 : 2;  // A/B: register budget of the lane-group kernel
+    if (lg_ok_) {
+      for (int i = 0; i < 2; ++i) {
+        std::vector<double> tab(kPlanarLgTabMax, 0.0);
+        const int cnt = PlanarLgBuildTable(i == 0 ? 2 : 4, model_id_, tab.data());
+        EPA_HIP(hipMalloc(&d_tab_[i], sizeof(double) * cnt));
+        EPA_HIP(hipMemcpy(d_tab_[i], tab.data(), sizeof(double) * cnt, hipMemcpyHostToDevice));
+      }
+    }
     {
       hipDeviceProp_t prop;
       EPA_HIP(hipGetDeviceProperties(&prop, cfg.device));
@@ -419,6 +397,9 @@ class CheetahPool : public Pool {
     (void)hipFree(dev_.navail);
     (void)hipFree(dev_.iters);
     if (dev_.stack) (void)hipFree(dev_.stack);
+    for (double* t : d_tab_) {
+      if (t) (void)hipFree(t);
+    }
   }
   int ModelNv() const { return model_id_ == mj::kPlanarHopper ? 6 : kNV; }
   int StateDim() const override { return 3 * ModelNv() + 7; }
@@ -441,6 +422,14 @@ class CheetahPool : public Pool {
     // over all SIMDs with 16 / 32 / 48 envs per wave (HalfCheetah N = 16384 .. 49152: +5 .. +8 %,
     // profiles/r2ze_planar_spread.txt).  Not below 16 per SIMD: there partially filled waves measured
     // SLOWER (N = 8192 as 512 waves of 16: 0.26 ms against 0.21 ms as 128 full waves).
+    // One env per lane group (mj_planar_lg.hip.h) wherever it applies.
+    int layout = lg_ok_ && trace_.d == nullptr ? layout_ : 1;
+    if (layout == 0) layout = 2;
+    if (layout > 1) {
+      PlanarLgLaunch(stream_, layout, lg_waves_, model_id_, dev_, common_, a, static_cast<const double*>(d_action), out,
+                     task_, d_tab_[layout == 2 ? 0 : 1]);
+      return;
+    }
     int lanes = kCheetahBlock;
     if (spread_ && trace_.d == nullptr && k >= 16 * wave_slots_) {
       lanes = ((k + wave_slots_ - 1) / wave_slots_ + 15) / 16 * 16;
@@ -475,6 +464,10 @@ class CheetahPool : public Pool {
   bool fp64_{false};
   bool spread_{true};
   int wave_slots_{1024};
+  int layout_{0};
+  bool lg_ok_{false};
+  int lg_waves_{2};
+  double* d_tab_[2] = {nullptr, nullptr};
 };
 
 }  // namespace

@@ -191,6 +191,12 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
   }
   static_assert(kUSlots == Eng::kFSlots, "LDS layout");
   for (int i = lane; i < H::kNLC * 4; i += kBlock) lds[kLdsTab + i] = kTab.c[i >> 2][i & 3];
+  // The working region starts from zeros, not from what the previous kernel on this CU left behind:
+  // slots of rows / candidates an env does not have are read with ZERO WEIGHTS before anything
+  // writes them, and 0 x (a NaN bit pattern left by someone else's integers) is NaN.  Found by
+  // tools/hum_poison_check.py (every CU's LDS filled with NaN patterns before each launch) after
+  // the run-to-run determinism test failed once in many runs; 68 stores per lane per launch.
+  for (int i = kLdsU + lane; i < kLdsElems; i += kBlock) lds[i] = 0.0;
   const int slot = blockIdx.x * kEnvsPerBlock + quad;
   const bool valid = slot < a.k;
   const int row = valid && dev.perm ? dev.perm[slot] : slot;  // cost-sorted scheduling

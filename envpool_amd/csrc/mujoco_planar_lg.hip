@@ -1,0 +1,250 @@
+// K3' — batched step kernel of the planar two-legged gym robots (HalfCheetah, Walker2d) with one
+// env per LANE GROUP (2 or 4 adjacent lanes; mj_planar_lg.hip.h), fp64.
+//
+// Replaces, for the whole batch in one launch, exactly what CheetahStepKernel (mujoco_gym.hip)
+// replaces -- MujocoEnv::{MujocoReset,MujocoStep} (envpool/mujoco/gym/mujoco_env.h:126-148),
+// HalfCheetahEnvBase::{MujocoResetModel,Reset,Step,WriteState} (gym/half_cheetah.h:105-185),
+// Walker2dEnvBase::{...} (gym/walker2d.h:119-219) and the runtime around them
+// (async_envpool.h:118-132, env.h:184-256) -- on the same device state (SoA float64 qpos / qvel /
+// qacc_warmstart [9][N]), so a pool can switch between the two layouts from one launch to the next.
+//
+// Lane c of a group loads the torso state (replicated) and its own leg's; the group's first lane
+// does the env-level work (mt19937 reset draws, reward, bookkeeping, torso outputs), every leg's
+// first lane writes that leg's state and observation entries.
+#include "mj_planar_lg.hip.h"
+#include "mujoco_planar_common.h"
+
+namespace epa {
+namespace {
+
+using mj::CheetahModel;
+using mj::kNU;
+using mj::kNV;
+using planar::CheetahDev;
+using planar::CheetahTask;
+using planar::PlanarModel;
+namespace plg = mj::plg;
+
+constexpr int kBlock = 64;
+
+template <int KL>
+struct DevCx {
+  const double* tab;  // the table's column of this lane: tab[id * KL]
+  double* lds;        // the wave's LDS block at this lane: lds[slot * 64]
+  __device__ __forceinline__ double C(int id) const { return tab[id * KL]; }
+  __device__ __forceinline__ double& Lds(int slot) { return lds[slot * kBlock]; }
+  // the table pointer becomes opaque to the optimiser: what is read through it afterwards cannot be
+  // hoisted above this point (out of the mj_step loop, into registers that then spill)
+  __device__ __forceinline__ void Refresh() { asm volatile("" : "+v"(tab)); }
+};
+
+// W: waves per SIMD the register allocation aims at (512 registers per SIMD lane: 1 -> 512, 2 -> 256)
+template <int KL, int kModel, int W>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(W, W))) void PlanarLgStepKernel(CheetahDev dev, CommonDev cm, StepArgs a,
+                                                             const double* __restrict__ action, OutPtrs out,
+                                                             CheetahTask task, plg::SolverCfgLg<double> scfg,
+                                                             const double* __restrict__ tab) {
+  using G = plg::Grp<KL>;
+  constexpr CheetahModel<double> m = PlanarModel<double, kModel>();
+  constexpr bool kWalker = kModel != mj::kPlanarCheetah;  // RK4, mirrored hinges
+  __shared__ double lds_buf[plg::LdsSlots<KL>() * kBlock];
+  const int lane = threadIdx.x;
+  const int n = cm.n;
+  const int c = lane & (KL - 1);  // lane coordinate in the group
+  const int leg = G::Leg(c);
+  const bool first = c == 0;                  // env-level work
+  const bool leg_first = G::Par(c) == 0;      // leg-level outputs
+  const int row = blockIdx.x * (kBlock / KL) + (lane / KL);
+  if (row >= a.k) return;
+  const int e = a.ids ? a.ids[row] - a.id_offset : row;
+  bool done = cm.done[e] != 0;
+  int cur = cm.cur_step[e];
+  const bool reset = a.force_reset || done;  // async_envpool.h:127
+  const int nobs = 2 * kNV - task.obs_skip;
+  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
+  float reward = 0.0f;
+  double xv = 0.0, ctrl_cost = 0.0, xpos = 0.0, qz = 0.0, qang = 0.0;
+  if (reset) {
+    // MujocoReset: mj_resetData + MujocoResetModel (half_cheetah.h:105-117, walker2d.h:119-126);
+    // the env's RNG stream is sequential: the group's first lane draws everything and writes the
+    // whole state and observation row (the warm start is cleared, see CheetahStepKernel)
+    cur = 0;
+    done = false;
+    if (first) {
+      Mt19937 g(cm, e);
+      double saved = dev.nsaved[e];
+      int avail = dev.navail[e];
+      double qpos[kNV], qvel[kNV];
+      for (int i = 0; i < kNV; ++i) {
+        const double q0 = (kWalker && i == 1) ? 1.25 : 0.0;  // rootz ref (walker2d_envpool.xml:36)
+        qpos[i] = q0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
+      }
+      for (int i = 0; i < kNV; ++i) {
+        if constexpr (kWalker) {
+          qvel[i] = 0.0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
+        } else {
+          qvel[i] = 0.0 + g.Normal(0.0, task.reset_noise_scale, &saved, &avail);
+        }
+      }
+      g.Commit();
+      dev.nsaved[e] = saved;
+      dev.navail[e] = (unsigned char)avail;
+      double* o = obs;
+      for (int i = 0; i < kNV; ++i) {
+        dev.qpos[(size_t)i * n + e] = qpos[i];
+        dev.qvel[(size_t)i * n + e] = qvel[i];
+        dev.warm[(size_t)i * n + e] = 0.0;
+        if (i >= task.obs_skip) *(o++) = qpos[i];
+      }
+      for (int i = 0; i < kNV; ++i) {
+        double x = qvel[i];
+        if constexpr (kWalker) {  // walker2d.h:210-215
+          x = x < task.velocity_max ? x : task.velocity_max;
+          x = x > task.velocity_min ? x : task.velocity_min;
+        }
+        *(o++) = x;
+      }
+    }
+  } else {
+    ++cur;
+    double q[plg::kLV], v[plg::kLV], w[plg::kLV], ctrl[3];
+    double x_before = 0.0;
+    mj::static_for<0, plg::kLV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int gi = i < 3 ? i : 3 * leg + i;  // global dof
+      const double sg = (kWalker && i >= 3) ? -1.0 : 1.0;  // hinge about -y: q' = -q (PlanarDofSign)
+      const double qq = dev.qpos[(size_t)gi * n + e];
+      if constexpr (i == 0) x_before = qq;
+      q[i] = sg * qq;
+      v[i] = sg * dev.qvel[(size_t)gi * n + e];
+      w[i] = sg * dev.warm[(size_t)gi * n + e];
+    });
+    q[0] = 0.0;  // the root x is carried as a local offset per env-step
+    const double* act = action + (size_t)row * kNU;
+    mj::static_for<0, 3>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const double ai = act[3 * leg + i];
+      // ctrllimited motors: MuJoCo clamps ctrl to ctrlrange [-1, 1]
+      ctrl[i] = ai < -1.0 ? -1.0 : (ai > 1.0 ? 1.0 : ai);
+    });
+    if (first) {  // half_cheetah.h:143-146: summed in the reference's order
+      for (int i = 0; i < kNU; ++i) ctrl_cost += task.ctrl_cost_weight * act[i] * act[i];
+    }
+    DevCx<KL> cx{tab + c, lds_buf + lane};
+    double iters = 0.0;
+    for (int s = 0; s < task.frame_skip; ++s) {  // mujoco_env.h:142-144
+      if constexpr (kWalker) {
+        iters += plg::StepRK4<KL>(m, scfg, cx, q, v, w, ctrl);
+      } else {
+        iters += plg::StepEuler<KL>(m, scfg, cx, q, v, w, ctrl);
+      }
+    }
+    const double x_after = x_before + q[0];
+    xv = (x_after - x_before) / task.dt;  // half_cheetah.h:148-149
+    xpos = x_after;
+    qz = q[1];
+    qang = q[2];
+    const int no = kNV - task.obs_skip;  // position entries of the observation
+    mj::static_for<0, plg::kLV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const bool mine = i < 3 ? first : leg_first;
+      const int gi = i < 3 ? i : 3 * leg + i;
+      const double sg = (kWalker && i >= 3) ? -1.0 : 1.0;
+      const double qq = i == 0 ? x_after : sg * q[i];
+      const double vv = sg * v[i];
+      if (mine) {
+        dev.qpos[(size_t)gi * n + e] = qq;
+        dev.qvel[(size_t)gi * n + e] = vv;
+        dev.warm[(size_t)gi * n + e] = sg * w[i];
+        if (gi >= task.obs_skip) obs[gi - task.obs_skip] = qq;
+        double x = vv;
+        if constexpr (kWalker) {  // walker2d.h:210-215
+          x = x < task.velocity_max ? x : task.velocity_max;
+          x = x > task.velocity_min ? x : task.velocity_min;
+        }
+        obs[no + gi] = x;
+      }
+    });
+    if (first) dev.iters[e] = (int)iters;
+    if constexpr (kWalker) {  // walker2d.h:162-177,181-190
+      const bool healthy = !(qz < task.healthy_z_min || qz > task.healthy_z_max ||
+                             qang < task.healthy_angle_min || qang > task.healthy_angle_max);
+      bool give = healthy;
+      if (task.legacy_healthy_reward) give = task.terminate_when_unhealthy || healthy;
+      const double healthy_reward = give ? task.healthy_reward : 0.0;
+      reward = static_cast<float>(xv * task.forward_reward_weight + healthy_reward - ctrl_cost);
+      done = (task.terminate_when_unhealthy ? !healthy : false) || cur >= a.max_episode_steps;
+    } else {
+      reward = static_cast<float>(xv * task.forward_reward_weight - ctrl_cost);
+      done = cur >= a.max_episode_steps;  // ++elapsed_step_ >= max_episode_steps_
+    }
+  }
+  if (!first) return;
+  cm.done[e] = done ? 1 : 0;
+  cm.cur_step[e] = cur;
+  if constexpr (kWalker) {  // walker2d.h:218-219
+    ((double*)out.p[kKeyEnv0 + 1])[row] = reset ? 0.0 : xpos;
+    ((double*)out.p[kKeyEnv0 + 2])[row] = xv;
+  } else {  // half_cheetah.h:158-185
+    ((double*)out.p[kKeyEnv0 + 1])[row] = xv * task.forward_reward_weight;
+    ((double*)out.p[kKeyEnv0 + 2])[row] = -ctrl_cost;
+    ((double*)out.p[kKeyEnv0 + 3])[row] = reset ? 0.0 : xpos;
+    ((double*)out.p[kKeyEnv0 + 4])[row] = xv;
+  }
+  WriteCommon(out, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
+}
+
+template <int KL, int W>
+void LaunchKl(hipStream_t st, int model, const CheetahDev& dev, const CommonDev& cm, const StepArgs& a,
+              const double* action, const OutPtrs& out, const CheetahTask& task, const double* tab) {
+  const int per = kBlock / KL;
+  const int blocks = (a.k + per - 1) / per;
+  const plg::SolverCfgLg<double> sc{50, 1e-13};
+  switch (model) {
+    case mj::kPlanarCheetah:
+      hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarCheetah, W>), dim3(blocks), dim3(kBlock), 0, st, dev, cm,
+                         a, action, out, task, sc, tab);
+      break;
+    case mj::kPlanarWalker:
+      hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarWalker, W>), dim3(blocks), dim3(kBlock), 0, st, dev, cm,
+                         a, action, out, task, sc, tab);
+      break;
+    default:
+      hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarWalkerV5, W>), dim3(blocks), dim3(kBlock), 0, st, dev,
+                         cm, a, action, out, task, sc, tab);
+      break;
+  }
+}
+
+}  // namespace
+
+void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, const planar::CheetahDev& dev,
+                    const CommonDev& cm, const StepArgs& a, const double* action, const OutPtrs& out,
+                    const planar::CheetahTask& task, const double* tab) {
+  if (kl == 2) {
+    if (waves == 1) {
+      LaunchKl<2, 1>(st, model, dev, cm, a, action, out, task, tab);
+    } else {
+      LaunchKl<2, 2>(st, model, dev, cm, a, action, out, task, tab);
+    }
+  } else if (waves == 1) {
+    LaunchKl<4, 1>(st, model, dev, cm, a, action, out, task, tab);
+  } else {
+    LaunchKl<4, 2>(st, model, dev, cm, a, action, out, task, tab);
+  }
+}
+
+int PlanarLgBuildTable(int kl, int model, double* tab) {
+  const CheetahModel<double> m = model == mj::kPlanarCheetah  ? kCheetahModelConst
+                                 : model == mj::kPlanarWalker ? kWalkerModelConst
+                                                              : kWalkerV5ModelConst;
+  if (kl == 2) {
+    static_assert(plg::Tab<2>::kSize <= kPlanarLgTabMax && plg::Tab<4>::kSize <= kPlanarLgTabMax, "table size");
+    plg::BuildTable<2>(m, tab);
+    return plg::Tab<2>::kSize;
+  }
+  plg::BuildTable<4>(m, tab);
+  return plg::Tab<4>::kSize;
+}
+
+}  // namespace epa

@@ -4,6 +4,7 @@ host staging).  torch is only imported here."""
 
 from __future__ import annotations
 
+import collections
 from typing import Any
 
 import numpy as np
@@ -46,15 +47,21 @@ def send_device_tensors(pool: Any, action: Any, env_id: Any = None) -> None:
         k = int(env_id.shape[0])
     dev = torch.device("cuda", pool.device)
     pool.wait_stream(torch.cuda.current_stream(dev).cuda_stream)
-    # The step kernel reads both tensors on the pool's PRIVATE stream.  Tell torch's caching
-    # allocator, so that a temporary the caller drops right after this call
-    # (`send_device_tensors(pool, policy(obs))`) is not handed to a later kernel on torch's
-    # stream while the step kernel is still reading it.
-    pstream = torch.cuda.ExternalStream(pool.stream, device=dev)
-    for t in (action, env_id):
-        if t is not None and t.is_cuda:
-            t.record_stream(pstream)
     pool.send_device(d_action, k, d_ids)
+    # The step kernel reads both tensors on the pool's PRIVATE stream, which torch's caching
+    # allocator knows nothing about: a temporary the caller drops right after this call
+    # (`send_device_tensors(pool, policy(obs))`) could be handed to a later kernel on torch's stream
+    # while the step kernel is still reading it.  So the pool keeps a reference to what it was
+    # sent until an event recorded behind the step kernel has passed.  (Not `Tensor.record_stream`:
+    # that makes the allocator record an event on the pool's stream when the tensor is freed --
+    # possibly after the pool, and its stream, are gone.)
+    sent = pool.__dict__.setdefault("_sent_tensors", collections.deque())
+    while sent and sent[0][0].query():
+        sent.popleft()
+    if action is not None or env_id is not None:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.ExternalStream(pool.stream, device=dev))
+        sent.append((ev, action, env_id))
 
 
 def _torch_dtype(dt: Any) -> Any:

@@ -169,7 +169,7 @@ def test_classic_config2_size(name):
             got = a[key].reshape(N, -1)[tail]
             if want.dtype == np.float32 and not exact:
                 np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6, err_msg=f"{name}:{key}@{k}")
-            elif key == "info:env_id":
+            elif key in ("info:env_id", "info:players.env_id"):
                 assert np.array_equal(got.ravel(), np.arange(N - TAIL, N))
             else:
                 assert np.array_equal(got, want), f"{name}:{key}@{k}"

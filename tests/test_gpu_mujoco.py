@@ -830,7 +830,10 @@ def test_planar_spread_is_bit_identical(task, adim):
     part = np.sort(rng.choice(n, size=n - 3000, replace=False)).astype(np.int32)
     outs = []
     for spread in (1, 0):
-        p = DevicePool(task, n, seed=5, max_episode_steps=1000, params={"planar_spread": spread})
+        params = {"planar_spread": spread}
+        if task == "HalfCheetah":
+            params["planar_layout"] = 1  # the one-env-per-lane kernel (the default is the lane-group one)
+        p = DevicePool(task, n, seed=5, max_episode_steps=1000, params=params)
         ids = np.arange(n, dtype=np.int32)
         p.reset(ids)
         seq = [p.recv_dict()]
@@ -852,3 +855,77 @@ def test_product_library_refuses_debug_switches():
     the diagnostic build only: the product library must not produce a figure with physics disabled."""
     with pytest.raises(Exception, match="hum_debug"):
         DevicePool("Humanoid", 64, seed=0, max_episode_steps=1000, params={"hum_debug": 1})
+
+
+# ---- one env per LANE GROUP (mj_planar_lg.hip.h): HalfCheetah / Walker2d, fp64 --------------------
+@pytest.mark.parametrize("layout,waves", [(2, 2), (2, 1), (4, 2), (4, 1)])
+@pytest.mark.parametrize("task,otask", [("HalfCheetah", "HalfCheetah"), ("Walker2d", "Walker2d"),
+                                        ("Walker2d", "Walker2dV5")])
+def test_planar_lane_group_matches_oracle(task, otask, layout, waves):
+    """Every variant of the lane-group kernel (2 or 4 lanes per env; register budget for 1 or 2 waves per
+    SIMD), teacher forced against the oracle: obs rtol 1e-9 / atol 1e-10, info keys, bookkeeping exact.
+    n = 200 leaves the last wave partially filled; resets are bit-identical to the one-env-per-lane
+    kernel's (the group's first lane makes the same mt19937 draws)."""
+    n, steps = 200, 60
+    params = {"precision": 1, "planar_layout": layout, "planar_waves": waves}
+    if task == "Walker2d":
+        params.update(xml_v5=1 if otask == "Walker2dV5" else 0,
+                      legacy_healthy_reward=0 if otask == "Walker2dV5" else 1)
+    pool = DevicePool(task, n, seed=9, max_episode_steps=1000, params=params)
+    lane = DevicePool(task, n, seed=9, max_episode_steps=1000, params={**params, "planar_layout": 1})
+    orc = Oracle(otask, n, seed=9, max_episode_steps=1000)
+    a, l, b = hip_reset(pool), hip_reset(lane), orc.reset()
+    for k in a:
+        assert a[k].tobytes() == l[k].tobytes(), k
+    rng = np.random.default_rng(3)
+    worst, worst_lane = 0.0, 0.0
+    info = ("info:x_position", "info:x_velocity") + (("info:reward_ctrl", "info:reward_run") if task == "HalfCheetah" else ())
+    for t in range(steps):
+        st = orc.get_state()
+        pool.set_state(st), lane.set_state(st)
+        act = rng.uniform(-1.2, 1.2, size=(n, 6))
+        a, l, b = hip_step(pool, act), hip_step(lane, act), orc.step(act)
+        np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-9, atol=1e-10, err_msg=f"step {t}")
+        np.testing.assert_allclose(a["reward"].ravel(), b["reward"].ravel(), rtol=1e-6, atol=1e-6)
+        for k in info:
+            np.testing.assert_allclose(a[k].ravel(), b[k].ravel(), rtol=1e-9, atol=2e-9, err_msg=k)
+        for k in ("done", "trunc", "elapsed_step", "step_type", "discount", "info:env_id"):
+            np.testing.assert_array_equal(a[k].ravel(), b[k].ravel(), err_msg=f"{k}@{t}")
+        worst = max(worst, float(np.abs(a["obs"] - b["obs"]).max()))
+        worst_lane = max(worst_lane, float(np.abs(a["obs"] - l["obs"]).max()))
+    print(f"{otask} layout {layout} waves {waves}: worst |d obs| vs oracle {worst:.2e}, vs the "
+          f"one-env-per-lane kernel {worst_lane:.2e}")
+
+
+@pytest.mark.parametrize("task", ["HalfCheetah", "Walker2d"])
+@pytest.mark.parametrize("layout", [2, 4])
+def test_planar_lane_group_batch_independent(task, layout):
+    """An env's arithmetic does not depend on the wave it lands in: whole batches, permuted partial
+    env_id batches and a second pool stepping only a subset give bit-identical rows; two runs agree."""
+    n = 5000
+    rng = np.random.default_rng(2)
+    acts = rng.uniform(-1, 1, size=(8, n, 6))
+    sub = np.sort(rng.choice(n, size=777, replace=False)).astype(np.int32)
+    perm = rng.permutation(sub).astype(np.int32)
+    ids = np.arange(n, dtype=np.int32)
+    params = {"planar_layout": layout}
+    full = [DevicePool(task, n, seed=5, max_episode_steps=6, params=params) for _ in range(2)]
+    part = DevicePool(task, n, seed=5, max_episode_steps=6, params=params)
+    for p in full + [part]:
+        p.reset(ids)
+    f0, f1, pp = full[0].recv_dict(), full[1].recv_dict(), part.recv_dict()
+    for t in range(8):
+        for k in f0:
+            assert f0[k].tobytes() == f1[k].tobytes(), (k, t)
+        full[0].send(ids, acts[t]), full[1].send(ids, acts[t])
+        f0, f1 = full[0].recv_dict(), full[1].recv_dict()
+        # the partial pool steps the subset in a permuted order (rows come back in send order),
+        # then the rest
+        part.send(perm, acts[t][perm])
+        a = part.recv_dict()
+        for k in f0:
+            assert a[k].tobytes() == np.ascontiguousarray(f0[k][perm]).tobytes(), (k, t)
+        rest = np.setdiff1d(ids, sub).astype(np.int32)
+        part.send(rest, acts[t][rest])
+        part.recv_dict()
+    assert np.array_equal(full[0].get_state(), part.get_state())
