@@ -99,6 +99,14 @@ struct Batch {
   int consumed{0};                // rows already handed to recv (async mode)
   std::vector<size_t> offsets;    // byte offset of each key's section
   hipEvent_t done{nullptr};
+  hipStream_t stream{nullptr};    // the compute stream its kernel was launched on
+  // async mode with several compute streams: the local env of every row (host-path sends / resets;
+  // empty for device-path batches, whose ids the host never sees), so that recv can mark them idle
+  std::vector<int32_t> host_ids;
+  // several compute streams: a device-path send whose env ids live in THIS (handed-out) batch copies
+  // them out on its own stream first; the next kernel that writes this block waits for that copy
+  hipEvent_t ids_read{nullptr};
+  bool ids_read_pending{false};
 };
 
 // Per-env bookkeeping shared by all families, SoA on device:
@@ -170,7 +178,11 @@ class Pool {
   std::vector<KeySpec> keys_;
   KeySpec action_;
   bool needs_rng_;
-  hipStream_t stream_{nullptr};       // step kernels (and device-path consumers)
+  // The stream the NEXT step kernel goes on.  Sync mode (batch_size == num_envs): always
+  // compute_[0].  Async mode: successive batches rotate over the compute streams so that
+  // independent in-flight batches run concurrently, like the reference's workers run every queued
+  // slice in parallel (envpool/core/async_envpool.h:116-132); see PickStream.
+  hipStream_t stream_{nullptr};
   hipStream_t h2d_stream_{nullptr};   // action uploads of the host path
   hipStream_t d2h_stream_{nullptr};   // result downloads of the host path
   CommonDev common_{};
@@ -182,6 +194,11 @@ class Pool {
   void ReleaseBatch(Batch* b);
   OutPtrs PtrsOf(const Batch& b) const;
   void Enqueue(const int* d_ids, int k, const void* d_action, bool force);
+  // chooses stream_ for the next launch and orders it behind what it may depend on
+  void PickStream(const int32_t* host_ids, int k, bool device_path);
+  void JoinCompute(hipStream_t into);  // `into` waits for everything enqueued on every compute stream
+  void SyncCompute();                  // host waits for every compute stream
+  void MarkIdle(Batch* b, int first, int count);
   struct Staging {
     char* h{nullptr};
     char* d{nullptr};
@@ -211,6 +228,16 @@ class Pool {
   char* recv_stage_{nullptr};  // pinned D2H landing block
   size_t recv_stage_bytes_{0};
   hipEvent_t order_ev_{nullptr};  // WaitStream's producer marker
+  // concurrent batches (async mode)
+  std::vector<hipStream_t> compute_;     // compute_[0] is the sync-mode stream
+  std::vector<hipEvent_t> join_ev_;      // one per compute stream (JoinCompute)
+  size_t rr_{0};
+  bool picked_{false};                   // WaitStream already chose the stream of the next launch
+  std::vector<uint8_t> busy_;            // host path: env is in a batch that was not received yet
+  std::vector<hipEvent_t> frontier_;     // device path: batches handed out whose kernels may still run
+  std::vector<int*> ids_stage_;          // per compute stream: the device-path env ids of its current launch
+  const int32_t* next_host_ids_{nullptr};  // ids of the launch being enqueued (for Batch::host_ids)
+  bool next_identity_{false};
   // timing
   int timing_{0};
   hipEvent_t win0_{nullptr}, win1_{nullptr};  // timing mode 2: first launch .. KernelTime()

@@ -103,6 +103,17 @@ Pool::Pool(const Config& cfg, std::vector<KeySpec> env_state_keys,
   }
   EPA_HIP(hipSetDevice(cfg_.device));
   EPA_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  compute_.push_back(stream_);
+  // "compute_streams" (extension key, default 4): async mode rotates successive batches over this
+  // many streams; 1 = every kernel on one stream (the behaviour up to round 2)
+  const bool async_mode = cfg_.batch_size > 0 && cfg_.batch_size < cfg_.num_envs;
+  const int want = async_mode ? std::max(1, std::min(16, (int)cfg_.Get("compute_streams", 4))) : 1;
+  for (int i = 1; i < want; ++i) {
+    hipStream_t s;
+    EPA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    compute_.push_back(s);
+  }
+  if (compute_.size() > 1) busy_.assign((size_t)cfg_.num_envs, 0);
   EPA_HIP(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
   EPA_HIP(hipStreamCreateWithFlags(&d2h_stream_, hipStreamNonBlocking));
   staging_.resize(3);
@@ -133,11 +144,16 @@ void Pool::InitCommon() {
 Pool::~Pool() {
   (void)hipSetDevice(cfg_.device);
   if (h2d_stream_) (void)hipStreamSynchronize(h2d_stream_);
-  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (hipStream_t s : compute_) (void)hipStreamSynchronize(s);
   if (d2h_stream_) (void)hipStreamSynchronize(d2h_stream_);
+  for (hipEvent_t e : join_ev_) (void)hipEventDestroy(e);
+  for (int* p : ids_stage_) {
+    if (p) (void)hipFree(p);
+  }
   for (auto& b : all_) {
     if (b->dbuf) (void)hipFree(b->dbuf);
     if (b->done) (void)hipEventDestroy(b->done);
+    if (b->ids_read) (void)hipEventDestroy(b->ids_read);
   }
   for (auto& s : staging_) {
     if (s.h) (void)hipHostFree(s.h);
@@ -161,7 +177,7 @@ Pool::~Pool() {
   if (stack_tmp_) (void)hipFree(stack_tmp_);
   if (common_.mt) (void)hipFree(common_.mt);
   if (common_.mti) (void)hipFree(common_.mti);
-  if (stream_) (void)hipStreamDestroy(stream_);
+  for (hipStream_t s : compute_) (void)hipStreamDestroy(s);
   if (h2d_stream_) (void)hipStreamDestroy(h2d_stream_);
   if (d2h_stream_) (void)hipStreamDestroy(d2h_stream_);
 }
@@ -279,6 +295,10 @@ OutPtrs Pool::PtrsOf(const Batch& b) const {
 
 void Pool::Enqueue(const int* d_ids, int k, const void* d_action, bool force) {
   Batch* b = AcquireBatch(k);
+  if (b->ids_read_pending) {  // see SendDevice
+    EPA_HIP(hipStreamWaitEvent(stream_, b->ids_read, 0));
+    b->ids_read_pending = false;
+  }
   hipEvent_t t0 = nullptr, t1 = nullptr;
   if (timing_ == 2) {  // window timing: no event between the launches (an event pair per launch keeps
     // consecutive step kernels ~12 us apart on this runtime)
@@ -327,7 +347,90 @@ void Pool::Enqueue(const int* d_ids, int k, const void* d_action, bool force) {
     timers_.emplace_back(t0, t1);
   }
   EPA_HIP(hipEventRecord(b->done, stream_));
+  b->stream = stream_;
+  b->host_ids.clear();
+  if (!busy_.empty()) {
+    if (next_identity_) {
+      b->host_ids.resize((size_t)k);
+      for (int i = 0; i < k; ++i) b->host_ids[i] = i;
+    } else if (next_host_ids_ != nullptr) {
+      b->host_ids.resize((size_t)k);
+      for (int i = 0; i < k; ++i) b->host_ids[i] = next_host_ids_[i] - cfg_.env_id_offset;
+    }
+  }
+  next_host_ids_ = nullptr;
+  next_identity_ = false;
   pending_.push_back(b);
+}
+
+// ---- concurrent batches ---------------------------------------------------------------
+// The reference's worker threads step every queued slice in parallel (async_envpool.h:116-132):
+// with batch_size < num_envs several batches are in flight and none depends on another, because an
+// env is either queued / stepping or waiting to be received (an action can only be sent for an env
+// that recv handed out).  Here successive launches of an async-mode pool rotate over the compute
+// streams.  What a launch must still be ordered behind:
+//  * the previous step of ITS OWN envs.  Host path: recv returned those rows, so their kernel has
+//    completed (the D2H was synchronised).  Device path: recv_device hands rows out while their
+//    kernel may still be running -- the new launch waits for the `done` events of the handed-out
+//    batches that have not completed yet (`frontier_`);
+//  * a caller that breaks the rule (sends an env again before receiving it; the reference would
+//    race): host-path ids are checked against `busy_`, and such a launch is ordered behind
+//    EVERYTHING enqueued so far, which is the single-stream behaviour.
+void Pool::JoinCompute(hipStream_t into) {
+  if (compute_.size() < 2) return;
+  while (join_ev_.size() < compute_.size()) {
+    hipEvent_t e;
+    EPA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    join_ev_.push_back(e);
+  }
+  for (size_t i = 0; i < compute_.size(); ++i) {
+    if (compute_[i] == into) continue;
+    EPA_HIP(hipEventRecord(join_ev_[i], compute_[i]));
+    EPA_HIP(hipStreamWaitEvent(into, join_ev_[i], 0));
+  }
+}
+
+void Pool::SyncCompute() {
+  for (hipStream_t s : compute_) EPA_HIP(hipStreamSynchronize(s));
+}
+
+void Pool::PickStream(const int32_t* host_ids, int k, bool device_path) {
+  next_host_ids_ = nullptr;
+  next_identity_ = false;
+  if (compute_.size() < 2) return;
+  if (picked_) {
+    picked_ = false;  // WaitStream chose (and ordered) the stream of this launch already
+  } else {
+    rr_ = (rr_ + 1) % compute_.size();
+    stream_ = compute_[rr_];
+  }
+  bool join = false;
+  {  // batches handed out by recv_device whose kernels may still be running
+    size_t keep = 0;
+    for (hipEvent_t ev : frontier_) {
+      if (hipEventQuery(ev) == hipSuccess) continue;
+      EPA_HIP(hipStreamWaitEvent(stream_, ev, 0));
+      frontier_[keep++] = ev;
+    }
+    frontier_.resize(keep);
+    (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
+  }
+  if (!device_path) {
+    const bool identity = host_ids == nullptr;
+    for (int i = 0; i < k; ++i) {
+      const int e = identity ? i : host_ids[i] - cfg_.env_id_offset;
+      if (busy_[(size_t)e]) join = true;
+      busy_[(size_t)e] = 1;
+    }
+    next_host_ids_ = host_ids;
+    next_identity_ = identity;
+  }
+  if (join) JoinCompute(stream_);
+}
+
+void Pool::MarkIdle(Batch* b, int first, int count) {
+  if (busy_.empty() || b->host_ids.empty()) return;
+  for (int i = first; i < first + count; ++i) busy_[(size_t)b->host_ids[(size_t)i]] = 0;
 }
 
 Pool::Staging& Pool::NextStaging(size_t bytes) {
@@ -389,6 +492,7 @@ void Pool::Send(const int32_t* env_id, int k, const void* action) {
   size_t act_bytes = (size_t)k * action_.row_bytes();
   Staging& s = NextStaging(id_bytes + Align(act_bytes));
   bool identity = IsIdentity(env_id, k, cfg_.env_id_offset, cfg_.num_envs);
+  PickStream(identity ? nullptr : env_id, k, false);
   size_t copy_from = identity ? id_bytes : 0;
   if (!identity) std::memcpy(s.h, env_id, (size_t)k * 4);
   std::memcpy(s.h + id_bytes, action, act_bytes);
@@ -418,6 +522,7 @@ void Pool::Reset(const int32_t* env_ids, int k) {
   std::lock_guard<std::mutex> lk(mu_);
   EPA_HIP(hipSetDevice(cfg_.device));
   bool identity = IsIdentity(env_ids, k, cfg_.env_id_offset, cfg_.num_envs);
+  PickStream(identity ? nullptr : env_ids, k, false);
   if (identity) {
     Enqueue(nullptr, k, nullptr, true);
     return;
@@ -440,7 +545,29 @@ void Pool::SendDevice(const int32_t* d_env_id, int k, const void* d_action,
   // the producer of d_action / d_env_id (a learner on another stream) recorded
   // `wait_event` after writing them: the step kernel is ordered behind it
   // (the analogue of the XLA custom call's stream ordering, core/xla.h:151-169)
+  PickStream(nullptr, k, true);
   if (wait_event != nullptr) EPA_HIP(hipStreamWaitEvent(stream_, wait_event, 0));
+  if (compute_.size() > 1 && d_env_id != nullptr) {
+    // The ids usually are the `info:env_id` array of a batch recv_device handed out.  With one
+    // compute stream that block cannot be rewritten before this launch has read it (stream order);
+    // with several, a later launch on ANOTHER stream could reuse the block first.  So the ids are
+    // copied out on this launch's stream (per-stream buffer: the next copy into it is behind this
+    // kernel), and the block's next writer waits for the copy (Batch::ids_read).
+    if (ids_stage_.size() < compute_.size()) ids_stage_.resize(compute_.size(), nullptr);
+    int*& stage = ids_stage_[rr_];
+    if (stage == nullptr) EPA_HIP(hipMalloc(&stage, sizeof(int) * (size_t)cfg_.num_envs));
+    EPA_HIP(hipMemcpyAsync(stage, d_env_id, sizeof(int) * (size_t)k, hipMemcpyDeviceToDevice, stream_));
+    const char* p = reinterpret_cast<const char*>(d_env_id);
+    for (Batch* b : lent_) {
+      if (b == nullptr || p < b->dbuf || p >= b->dbuf + b->offsets.back() + Align((size_t)b->k * keys_.back().row_bytes())) {
+        continue;
+      }
+      if (!b->ids_read) EPA_HIP(hipEventCreateWithFlags(&b->ids_read, hipEventDisableTiming));
+      EPA_HIP(hipEventRecord(b->ids_read, stream_));
+      b->ids_read_pending = true;
+    }
+    d_env_id = stage;
+  }
   Enqueue(d_env_id, k, d_action, d_action == nullptr);
 }
 
@@ -449,6 +576,11 @@ void Pool::WaitStream(hipStream_t producer) {
   EPA_HIP(hipSetDevice(cfg_.device));
   if (!order_ev_) EPA_HIP(hipEventCreateWithFlags(&order_ev_, hipEventDisableTiming));
   EPA_HIP(hipEventRecord(order_ev_, producer));
+  if (compute_.size() > 1 && !picked_) {  // the stream the NEXT launch will use
+    rr_ = (rr_ + 1) % compute_.size();
+    stream_ = compute_[rr_];
+    picked_ = true;
+  }
   EPA_HIP(hipStreamWaitEvent(stream_, order_ev_, 0));
 }
 
@@ -511,7 +643,8 @@ void Pool::CopyRowsToHost(char* dst, const std::vector<size_t>& off, int want) {
     int take = std::min(want - got, b->k - b->consumed);
     // the copies go on the download stream, behind the kernel that produced the
     // rows (its `done` event) but NOT behind kernels enqueued after it
-    if (cs != stream_) EPA_HIP(hipStreamWaitEvent(cs, b->done, 0));
+    if (cs != b->stream) EPA_HIP(hipStreamWaitEvent(cs, b->done, 0));
+    MarkIdle(b, b->consumed, take);
     if (got == 0 && take == want && b->consumed == 0 && take == b->k) {
       // whole batch: one D2H of the packed block (offsets coincide)
       EPA_HIP(hipMemcpyAsync(dst, b->dbuf, total, hipMemcpyDeviceToHost, cs));
@@ -602,6 +735,7 @@ int Pool::RecvInto(void* const* out_ptrs, int n_ptrs, int cap_rows) {
     Batch* b = pending_.front();
     int take = std::min(want - got, b->k - b->consumed);
     EPA_HIP(hipStreamWaitEvent(cs, b->done, 0));
+    MarkIdle(b, b->consumed, take);
     for (size_t i = 0; i < keys_.size(); ++i) {
       if (out_ptrs[i] == nullptr) continue;
       size_t rb = keys_[i].row_bytes();
@@ -631,6 +765,8 @@ int Pool::RecvDevice(void** d_out_ptrs, int n_ptrs) {
     throw std::runtime_error("recv_device: batch partially consumed by recv");
   }
   pending_.pop_front();
+  MarkIdle(b, 0, b->k);
+  if (compute_.size() > 1) frontier_.push_back(b->done);
   for (size_t i = 0; i < keys_.size(); ++i) {
     d_out_ptrs[i] = b->dbuf + b->offsets[i];
   }
@@ -643,7 +779,7 @@ int Pool::RecvDevice(void** d_out_ptrs, int n_ptrs) {
 void Pool::Synchronize() {
   EPA_HIP(hipSetDevice(cfg_.device));
   EPA_HIP(hipStreamSynchronize(h2d_stream_));
-  EPA_HIP(hipStreamSynchronize(stream_));
+  SyncCompute();
   EPA_HIP(hipStreamSynchronize(d2h_stream_));
 }
 
@@ -658,6 +794,7 @@ void Pool::KernelTime(double* avg_ms, int* launches) {
   std::lock_guard<std::mutex> lk(mu_);
   EPA_HIP(hipSetDevice(cfg_.device));
   if (win_open_) {  // mode 2: (last launch's end - first launch's start) / launches, gaps included
+    JoinCompute(stream_);  // several compute streams: the window closes behind all of them
     EPA_HIP(hipEventRecord(win1_, stream_));
     EPA_HIP(hipStreamSynchronize(stream_));
     float ms = 0;
@@ -668,7 +805,7 @@ void Pool::KernelTime(double* avg_ms, int* launches) {
     win_launches_ = 0;
     return;
   }
-  EPA_HIP(hipStreamSynchronize(stream_));
+  SyncCompute();
   double tot = 0;
   for (auto& t : timers_) {
     float ms = 0;
@@ -693,6 +830,7 @@ void Pool::GetStateHost(const int32_t* ids, int k, double* out) {
   double* d_buf;
   std::vector<int> local(ids, ids + k);
   for (auto& v : local) v -= cfg_.env_id_offset;
+  if (compute_.size() > 1) SyncCompute();  // the state of envs stepping on other streams
   EPA_HIP(hipMalloc(&d_ids, sizeof(int) * k));
   EPA_HIP(hipMalloc(&d_buf, sizeof(double) * k * dim));
   EPA_HIP(hipMemcpyAsync(d_ids, local.data(), sizeof(int) * k,
@@ -716,6 +854,7 @@ void Pool::SetStateHost(const int32_t* ids, int k, const double* in) {
   double* d_buf;
   std::vector<int> local(ids, ids + k);
   for (auto& v : local) v -= cfg_.env_id_offset;
+  if (compute_.size() > 1) SyncCompute();
   EPA_HIP(hipMalloc(&d_ids, sizeof(int) * k));
   EPA_HIP(hipMalloc(&d_buf, sizeof(double) * k * dim));
   EPA_HIP(hipMemcpyAsync(d_ids, local.data(), sizeof(int) * k,

@@ -677,18 +677,21 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
   }
 }
 
-// this lane's part of phi'(alpha), phi''(alpha) from its rows along `s` from `a`
-template <int KL, typename T, typename V, typename Cx>
+// this lane's part of phi'(alpha), phi''(alpha) from its rows along `s` from `a`; kMask: also the
+// lane's active-row mask AT a + alpha s (same bits as RowsPass)
+template <int KL, bool kMask, typename T, typename V, typename Cx, typename U>
 EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRows<V>& lim,
-                     unsigned ends, const V* a, const V* s, V alpha, V* d1, V* d2) {
+                     unsigned ends, const V* a, const V* s, V alpha, V* d1, V* d2, U& mask) {
   static_for<0, 3>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const V jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
     const V jv = lim.sgn[j] * s[j + 3];
     const V x = jar + alpha * jv;
-    const V w = Sel((lim.sgn[j] != V(0)) & (x < V(0)), lim.D[j], V(0));
+    const auto on = (lim.sgn[j] != V(0)) & (x < V(0));
+    const V w = Sel(on, lim.D[j], V(0));
     *d1 += w * x * jv;
     *d2 += w * jv * jv;
+    if constexpr (kMask) MaskSet(mask, on, j);
   });
   EPA_NO_UNROLL
   for (unsigned rem = ends; rem != 0; rem &= rem - 1) {
@@ -717,6 +720,12 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
       const V c3 = Sel(x3 < V(0), D, V(0));
       *d1 += c1 * x1 * jv1 + c2 * x2 * jv2 + c3 * x3 * jv3;
       *d2 += c1 * jv1 * jv1 + c2 * jv2 * jv2 + c3 * jv3 * jv3;
+      if constexpr (kMask) {
+        const auto on = D > V(0);
+        MaskSet(mask, on & (x1 < V(0)), 3 + 3 * sl);
+        MaskSet(mask, on & (x2 < V(0)), 4 + 3 * sl);
+        MaskSet(mask, on & (x3 < V(0)), 5 + 3 * sl);
+      }
     });
   }
 }
@@ -931,13 +940,24 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
     full_step = LT::False();
     const V ls_tol = V(T(1e-10)) * Abs(g1);
     B searching = live;
+    B exact = LT::False();
     for (int ls = 0; ls < 24; ++ls) {
       V d1p = V(0), d2p = V(0);
-      LineEval<KL>(m, cx, p, lim, ends, qacc, s, alpha, &d1p, &d2p);
+      U mask1 = LT::Fill(0u);
+      if (ls == 0) {
+        LineEval<KL, true>(m, cx, p, lim, ends, qacc, s, alpha, &d1p, &d2p, mask1);
+      } else {
+        LineEval<KL, false>(m, cx, p, lim, ends, qacc, s, alpha, &d1p, &d2p, mask1);
+      }
       const V d1 = (g1 + alpha * g2) + SumEnv<KL>(d1p), d2 = g2 + SumEnv<KL>(d2p);
       const B hit = Abs(d1) <= ls_tol;
-      // a full Newton step is exact for the active set H was built with
-      if (ls == 0) full_step = searching & hit;
+      // a full Newton step is exact for the active set H was built with: if the rows active at
+      // a + s are the rows H was built with, a + s IS the minimiser (finite termination) and the
+      // env is done without another pass over the rows
+      if (ls == 0) {
+        full_step = searching & hit;
+        exact = full_step & AllEnvOf<KL>(MaskSame(mask1, mask));
+      }
       searching = searching & !hit;
       const B neg = d1 < V(0);
       lo = Sel(searching & neg, alpha, lo);
@@ -954,7 +974,11 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
       constexpr int i = decltype(ic)::value;
       qacc[i] += step * s[i];
       Ma[i] += step * Ms[i];
+      // at the minimiser the gradient vanishes (to rounding: what the next pass would have found)
+      grad[i] = Sel(exact, V(0), grad[i]);
     });
+    live = live & !exact;
+    if (!AnyWave(live)) break;
   }
   if (AnyWave(live)) {  // iteration cap hit somewhere in the wave: refresh grad
     V gc[kLV];

@@ -400,6 +400,7 @@ class CheetahPool : public Pool {
     for (double* t : d_tab_) {
       if (t) (void)hipFree(t);
     }
+    for (auto& kv : tickets_) (void)hipFree(kv.second.d);
   }
   int ModelNv() const { return model_id_ == mj::kPlanarHopper ? 6 : kNV; }
   int StateDim() const override { return 3 * ModelNv() + 7; }
@@ -426,8 +427,13 @@ class CheetahPool : public Pool {
     int layout = lg_ok_ && trace_.d == nullptr ? layout_ : 1;
     if (layout == 0) layout = 2;
     if (layout > 1) {
-      PlanarLgLaunch(stream_, layout, lg_waves_, model_id_, dev_, common_, a, static_cast<const double*>(d_action), out,
-                     task_, d_tab_[layout == 2 ? 0 : 1]);
+      Ticket& tk = tickets_[stream_];  // launches on different streams run concurrently: a queue each
+      if (tk.d == nullptr) {
+        EPA_HIP(hipMalloc(&tk.d, sizeof(unsigned)));
+        EPA_HIP(hipMemsetAsync(tk.d, 0, sizeof(unsigned), stream_));
+      }
+      PlanarLgLaunch(stream_, layout, lg_waves_, model_id_, wave_slots_, dev_, common_, a,
+                     static_cast<const double*>(d_action), out, task_, d_tab_[layout == 2 ? 0 : 1], tk.d, &tk.base);
       return;
     }
     int lanes = kCheetahBlock;
@@ -468,6 +474,11 @@ class CheetahPool : public Pool {
   bool lg_ok_{false};
   int lg_waves_{2};
   double* d_tab_[2] = {nullptr, nullptr};
+  struct Ticket {
+    unsigned* d{nullptr};
+    unsigned base{0};
+  };
+  std::map<hipStream_t, Ticket> tickets_;  // chunk queue of the lane-group kernel, per launch stream
 };
 
 }  // namespace

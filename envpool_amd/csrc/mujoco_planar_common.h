@@ -64,9 +64,11 @@ constexpr int kCheetahBlock = 64;
 // mujoco_planar_lg.hip: one env per group of `kl` (2 or 4) lanes; `tab` = the device copy of
 // mj::plg::BuildTable<kl>(model); model = mj::PlanarModelId (not the Hopper); frame_stack must be 1;
 // waves = 1 or 2: the kernel variant whose register allocation aims at that many waves per SIMD
-void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, const planar::CheetahDev& dev,
+// `wave_slots`: SIMDs of the device; `ticket` / `ticket_base`: the chunk queue's device counter and the
+// host's copy of its value (one pair per stream that launches concurrently, see PlanarLgStepKernel)
+void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots, const planar::CheetahDev& dev,
                     const CommonDev& cm, const StepArgs& a, const double* action, const OutPtrs& out,
-                    const planar::CheetahTask& task, const double* tab);
+                    const planar::CheetahTask& task, const double* tab, unsigned* ticket, unsigned* ticket_base);
 // fills `tab` (host) for lane groups of `kl`; returns the number of doubles (<= kPlanarLgTabMax)
 constexpr int kPlanarLgTabMax = 512;
 int PlanarLgBuildTable(int kl, int model, double* tab);

@@ -29,32 +29,67 @@ constexpr int kBlock = 64;
 
 template <int KL>
 struct DevCx {
-  const double* tab;  // the table's column of this lane: tab[id * KL]
+  const double* tab;  // the wave's LDS copy of the table at this lane's column: tab[id * KL]
   double* lds;        // the wave's LDS block at this lane: lds[slot * 64]
   __device__ __forceinline__ double C(int id) const { return tab[id * KL]; }
   __device__ __forceinline__ double& Lds(int slot) { return lds[slot * kBlock]; }
   // the table pointer becomes opaque to the optimiser: what is read through it afterwards cannot be
-  // hoisted above this point (out of the mj_step loop, into registers that then spill)
+  // hoisted above this point (out of the mj_step loop, into registers that then spill).  The
+  // constants are read from LDS where they are used (~90 ds_read_b64 per forward pass, ~100 cycles
+  // each, off the VALU); from global memory every one of them was an L2 round trip.
   __device__ __forceinline__ void Refresh() { asm volatile("" : "+v"(tab)); }
 };
 
-// W: waves per SIMD the register allocation aims at (512 registers per SIMD lane: 1 -> 512, 2 -> 256)
-template <int KL, int kModel, int W>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(W, W))) void PlanarLgStepKernel(CheetahDev dev, CommonDev cm, StepArgs a,
-                                                             const double* __restrict__ action, OutPtrs out,
-                                                             CheetahTask task, plg::SolverCfgLg<double> scfg,
-                                                             const double* __restrict__ tab) {
+// Everything the kernel is given, as ONE by-value argument: it sits at offset 0 of the kernarg
+// segment and is read from there (scalar loads) where it is needed, see KernArgs().
+struct LgArgs {
+  CheetahDev dev;
+  CommonDev cm;
+  StepArgs a;
+  const double* action;
+  OutPtrs out;
+  CheetahTask task;
+  plg::SolverCfgLg<double> scfg;
+  const double* tab;
+  unsigned* ticket;
+  unsigned ticket_base;
+  int nchunks;
+};
+using LgArgsK = const __attribute__((address_space(4))) LgArgs;
+// The kernel's arguments, re-read from the kernarg segment through a pointer that is opaque to the
+// optimiser.  With the arguments as ordinary by-value parameters the persistent loop below makes
+// every one of them (48 output pointers, 20 task scalars, ...) a loop invariant that is loaded once
+// and then kept in SGPRs across the whole solver: 90 SGPR spills.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ LgArgsK* KernArgs() {
+  LgArgsK* p = (LgArgsK*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+#endif
+
+// One chunk of 64 / KL envs (rows chunk * 64 / KL ...) on this wave.
+template <int KL, int kModel>
+__device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, double* lds_buf) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (address-space-4 reads: nothing for hipcc's host pass to compile)
+  LgArgsK* ap = KernArgs();
+  const CheetahDev dev = ap->dev;
+  const CommonDev cm = ap->cm;
+  const StepArgs a = ap->a;
+  const double* __restrict__ action = ap->action;
+  const plg::SolverCfgLg<double> scfg = ap->scfg;
+#define task (ap->task)
+#define out (ap->out)
   using G = plg::Grp<KL>;
   constexpr CheetahModel<double> m = PlanarModel<double, kModel>();
   constexpr bool kWalker = kModel != mj::kPlanarCheetah;  // RK4, mirrored hinges
-  __shared__ double lds_buf[plg::LdsSlots<KL>() * kBlock];
   const int lane = threadIdx.x;
   const int n = cm.n;
   const int c = lane & (KL - 1);  // lane coordinate in the group
   const int leg = G::Leg(c);
   const bool first = c == 0;                  // env-level work
   const bool leg_first = G::Par(c) == 0;      // leg-level outputs
-  const int row = blockIdx.x * (kBlock / KL) + (lane / KL);
+  const int row = chunk * (kBlock / KL) + (lane / KL);
   if (row >= a.k) return;
   const int e = a.ids ? a.ids[row] - a.id_offset : row;
   bool done = cm.done[e] != 0;
@@ -130,7 +165,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(W, W))) 
     if (first) {  // half_cheetah.h:143-146: summed in the reference's order
       for (int i = 0; i < kNU; ++i) ctrl_cost += task.ctrl_cost_weight * act[i] * act[i];
     }
-    DevCx<KL> cx{tab + c, lds_buf + lane};
+    DevCx<KL> cx{tab_lds + c, lds_buf + lane};
     double iters = 0.0;
     for (int s = 0; s < task.frame_skip; ++s) {  // mujoco_env.h:142-144
       if constexpr (kWalker) {
@@ -191,47 +226,89 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(W, W))) 
     ((double*)out.p[kKeyEnv0 + 3])[row] = reset ? 0.0 : xpos;
     ((double*)out.p[kKeyEnv0 + 4])[row] = xv;
   }
-  WriteCommon(out, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
+  const OutPtrs outv = out;
+  WriteCommon(outv, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
+#undef task
+#undef out
+#endif
+}
+
+// PERSISTENT waves over a dynamic queue of chunks.  A wave runs as long as its slowest env and
+// visits the union of its envs' touching slots, so chunks differ a lot in duration (mean wave 80 us,
+// slowest 143 us at N = 32768: profiles/r3e_*): with one chunk per wave the launch lasts as long as
+// its slowest wave.  Here the grid is the number of waves that are resident at once, wave i starts
+// with chunk i and then takes the next chunk off an atomic ticket counter until none is left --
+// whoever finishes early does the extra work.  `ticket_base`: the counter's value before this
+// launch; every wave makes exactly one failing fetch, so a launch advances the counter by exactly
+// its number of chunks and the host never has to reset it.
+// W: waves per SIMD the register allocation aims at (512 registers per SIMD lane: 1 -> 512, 2 -> 256)
+template <int KL, int kModel, int W>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(W, W))) void PlanarLgStepKernel(LgArgs args) {
+  __shared__ double lds_buf[plg::LdsSlots<KL>() * kBlock];
+  __shared__ double tab_lds[plg::Tab<KL>::kSize];
+  {
+    const double* __restrict__ tab = args.tab;
+    for (int i = threadIdx.x; i < plg::Tab<KL>::kSize; i += kBlock) tab_lds[i] = tab[i];
+  }
+  __syncthreads();
+#if defined(__HIP_DEVICE_COMPILE__)
+  int chunk = blockIdx.x;
+  for (;;) {
+    StepChunk<KL, kModel>(chunk, tab_lds, lds_buf);
+    LgArgsK* ap = KernArgs();
+    unsigned t = 0;
+    if (threadIdx.x == 0) t = atomicAdd(ap->ticket, 1u);
+    t = __builtin_amdgcn_readfirstlane(t);
+    chunk = (int)gridDim.x + (int)(t - ap->ticket_base);
+    if (chunk >= ap->nchunks) break;
+  }
+#endif
 }
 
 template <int KL, int W>
-void LaunchKl(hipStream_t st, int model, const CheetahDev& dev, const CommonDev& cm, const StepArgs& a,
-              const double* action, const OutPtrs& out, const CheetahTask& task, const double* tab) {
+void LaunchKl(hipStream_t st, int model, int wave_slots, const CheetahDev& dev, const CommonDev& cm,
+              const StepArgs& a, const double* action, const OutPtrs& out, const CheetahTask& task,
+              const double* tab, unsigned* ticket, unsigned* ticket_base) {
   const int per = kBlock / KL;
-  const int blocks = (a.k + per - 1) / per;
-  const plg::SolverCfgLg<double> sc{50, 1e-13};
+  const int nchunks = (a.k + per - 1) / per;
+  // waves resident at once: W per SIMD by registers; LDS (ends + table) allows 7 waves per CU at KL = 2
+  int resident = wave_slots * W;
+  if (KL == 2 && W == 2) resident = wave_slots / 4 * 7;
+  const int blocks = nchunks < resident ? nchunks : resident;
+  const unsigned base = *ticket_base;
+  *ticket_base = base + (unsigned)nchunks;  // see PlanarLgStepKernel
+  const LgArgs args{dev, cm, a, action, out, task, plg::SolverCfgLg<double>{50, 1e-13}, tab, ticket, base, nchunks};
   switch (model) {
     case mj::kPlanarCheetah:
-      hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarCheetah, W>), dim3(blocks), dim3(kBlock), 0, st, dev, cm,
-                         a, action, out, task, sc, tab);
+      hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarCheetah, W>), dim3(blocks), dim3(kBlock), 0, st, args);
       break;
     case mj::kPlanarWalker:
-      hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarWalker, W>), dim3(blocks), dim3(kBlock), 0, st, dev, cm,
-                         a, action, out, task, sc, tab);
+      hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarWalker, W>), dim3(blocks), dim3(kBlock), 0, st, args);
       break;
     default:
-      hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarWalkerV5, W>), dim3(blocks), dim3(kBlock), 0, st, dev,
-                         cm, a, action, out, task, sc, tab);
+      hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarWalkerV5, W>), dim3(blocks), dim3(kBlock), 0, st, args);
       break;
   }
 }
 
 }  // namespace
 
-void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, const planar::CheetahDev& dev,
+void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots, const planar::CheetahDev& dev,
                     const CommonDev& cm, const StepArgs& a, const double* action, const OutPtrs& out,
-                    const planar::CheetahTask& task, const double* tab) {
+                    const planar::CheetahTask& task, const double* tab, unsigned* ticket, unsigned* ticket_base) {
+#define EPA_LG(KL, W) LaunchKl<KL, W>(st, model, wave_slots, dev, cm, a, action, out, task, tab, ticket, ticket_base)
   if (kl == 2) {
     if (waves == 1) {
-      LaunchKl<2, 1>(st, model, dev, cm, a, action, out, task, tab);
+      EPA_LG(2, 1);
     } else {
-      LaunchKl<2, 2>(st, model, dev, cm, a, action, out, task, tab);
+      EPA_LG(2, 2);
     }
   } else if (waves == 1) {
-    LaunchKl<4, 1>(st, model, dev, cm, a, action, out, task, tab);
+    EPA_LG(4, 1);
   } else {
-    LaunchKl<4, 2>(st, model, dev, cm, a, action, out, task, tab);
+    EPA_LG(4, 2);
   }
+#undef EPA_LG
 }
 
 int PlanarLgBuildTable(int kl, int model, double* tab) {

@@ -279,3 +279,82 @@ def test_mujoco_full_episode_determinism_and_truncation(task, adim, horizon):
         if task.startswith("HalfCheetah"):  # never terminates early: one clock for all envs
             assert (el == (t if t <= horizon else 0)).all()
             assert trunc.all() == (t == horizon)
+
+
+# ---- async mode: independent batches on several compute streams ---------------------------------
+def _async_rollout(task, adim, n, b, streams, recvs, device_path, break_rule=False):
+    """recv -> send loop of an async pool; returns {env: [(elapsed_step, reward, obs bytes), ...]}.
+    The action of (env, its k-th step) is a fixed function, so streams / scheduling cannot matter."""
+    from envpool_amd.core.device_pool import DevicePool
+
+    pool = DevicePool(task, n, batch_size=b, seed=3, max_episode_steps=9, params={"compute_streams": streams})
+    ids = np.arange(n, dtype=np.int32)
+    table = np.random.default_rng(7).uniform(-1, 1, size=(64, n, adim))
+    count = np.zeros(n, dtype=np.int64)
+    seq = {e: [] for e in range(n)}
+    if device_path:
+        import torch
+
+        from envpool_amd.torch_interop import recv_device_tensors, send_device_tensors
+        dev = torch.device("cuda", 0)
+        ttable = torch.as_tensor(table, device=dev)
+        tids = torch.arange(n, device=dev, dtype=torch.int32)
+        for j in range(n // b):  # recv_device hands out whole launches: n / b reset launches of b rows
+            send_device_tensors(pool, None, tids[j * b:(j + 1) * b])
+    else:
+        pool.reset(ids)
+    for r in range(recvs):
+        if device_path:
+            out = recv_device_tensors(pool)
+            eids_t = out["info:env_id"].reshape(-1).clone()
+            host = {k: v.cpu().numpy() for k, v in out.items()}
+        else:
+            host = pool.recv_dict()
+        eids = host["info:env_id"].ravel().astype(np.int64)
+        assert len(eids) == b
+        for row, e in enumerate(eids):
+            seq[int(e)].append((int(host["elapsed_step"][row]), float(host["reward"][row]),
+                                host["obs"][row].tobytes()))
+        act = table[count[eids] % 64, eids]
+        count[eids] += 1
+        if device_path:
+            act_t = torch.as_tensor(np.ascontiguousarray(act), device=dev)
+            send_device_tensors(pool, act_t, eids_t)
+        else:
+            pool.send(eids.astype(np.int32), act)
+            if break_rule and r % 5 == 2:
+                # against the rule: the same envs again before they were received (their rows come
+                # back twice); must behave as on one stream, where launches simply queue up
+                act2 = table[count[eids] % 64, eids]
+                count[eids] += 1
+                pool.send(eids.astype(np.int32), act2)
+    pool.synchronize()
+    return seq
+
+
+@pytest.mark.parametrize("task,adim", [("HalfCheetah", 6), ("Ant", 8)])
+@pytest.mark.parametrize("device_path", [False, True])
+def test_async_batches_on_several_streams_match_one_stream(task, adim, device_path):
+    """batch_size < num_envs: successive batches run on different compute streams (the reference's workers
+    step all queued slices in parallel, async_envpool.h:116-132).  Every env's own sequence of outputs is
+    bit-identical to the single-stream run, through auto-resets, on the host and the device path."""
+    if device_path:
+        pytest.importorskip("torch")
+    n, b, recvs = 4096, 512, 120
+    one = _async_rollout(task, adim, n, b, 1, recvs, device_path)
+    many = _async_rollout(task, adim, n, b, 4, recvs, device_path)
+    steps = 0
+    for e in range(n):
+        assert one[e] == many[e], e
+        steps += len(one[e])
+    assert steps == recvs * b and max(len(v) for v in one.values()) >= 10
+
+
+def test_async_streams_tolerate_a_resend_before_recv():
+    """An env sent again before it was received (the reference would race) is ordered behind its own
+    previous step: same per-env sequences as the single-stream engine."""
+    n, b, recvs = 2048, 256, 40
+    one = _async_rollout("HalfCheetah", 6, n, b, 1, recvs, False, break_rule=True)
+    many = _async_rollout("HalfCheetah", 6, n, b, 4, recvs, False, break_rule=True)
+    for e in range(n):
+        assert one[e] == many[e], e

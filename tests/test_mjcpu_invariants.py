@@ -589,3 +589,55 @@ def test_product_humanoid_quad_code_matches_oracle_on_cpu():
         print(f"{task} (quad layout): worst teacher-forced rel |d obs| = {worst:.2e}; max active groups {most}")
         assert worst < 1e-8, (task, worst)
         assert most >= (10 if su else 3)
+
+
+def test_product_planar_lane_group_code_matches_oracle_on_cpu():
+    """Host instantiation of the lane-group planar step (mj_planar_lg.hip.h: one env over 2 or 4 lanes,
+    emulated by LV<double, KL>) vs the oracle and vs the one-env-per-lane formulation
+    (mj_cheetah.hip.h), teacher forced.  The harness also checks that every value that must be
+    replicated over the group (torso state, the parity lanes of a leg) is bit-identical in all lanes."""
+    from oracle.orc import Oracle
+
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    csrc = os.path.join(ROOT, "envpool_amd", "csrc")
+    for name, hdrs in (("planar_lg", ("mj_planar_lg.hip.h", "mj_cheetah.hip.h", "mj_cheetah_model.h")),
+                       ("cheetah", ("mj_cheetah.hip.h", "mj_cheetah_model.h"))):
+        so, src = os.path.join(h, f"lib{name}_host.so"), os.path.join(h, f"{name}_host.cpp")
+        newest = max(os.path.getmtime(f) for f in [src] + [os.path.join(csrc, x) for x in hdrs])
+        if not os.path.exists(so) or os.path.getmtime(so) < newest:
+            subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(os.path.join(h, "libplanar_lg_host.so"))
+    Lo = ctypes.CDLL(os.path.join(h, "libcheetah_host.so"))
+    vp = ctypes.c_void_p
+    L.planar_lg_step.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp]
+    rng = np.random.default_rng(3)
+    for task, model, nsub in (("HalfCheetah", 0, 5), ("Walker2d", 1, 4), ("Walker2dV5", 2, 4)):
+        for kl in (2, 4):
+            n = 8
+            orc = Oracle(task, n, seed=9, max_episode_steps=1000)
+            orc.reset()
+            worst, worst_lane = 0.0, 0.0
+            for t in range(40):
+                st = orc.get_state()
+                act = rng.uniform(-1, 1, size=(n, 6))
+                b = orc.step(act)
+                for e in range(n):
+                    if b["elapsed_step"][e, 0] == 0:
+                        continue
+                    q, v, w = st[e, :9].copy(), st[e, 9:18].copy(), st[e, 18:27].copy()
+                    a = np.ascontiguousarray(act[e])
+                    qo, vo, wo, it = np.zeros(9), np.zeros(9), np.zeros(9), ctypes.c_int(0)
+                    rc = L.planar_lg_step(model, kl, q.ctypes.data, v.ctypes.data, w.ctypes.data, a.ctypes.data,
+                                          nsub, qo.ctypes.data, vo.ctypes.data, wo.ctypes.data, ctypes.byref(it))
+                    assert rc == 0, (task, kl, rc)  # replicated values agree bit for bit
+                    vv = np.clip(vo, -10, 10) if model else vo
+                    worst = max(worst, np.abs(np.concatenate([qo[1:], vv]) - b["obs"][e]).max())
+                    q2, v2, w2, it2 = np.zeros(9), np.zeros(9), np.zeros(9), ctypes.c_int(0)
+                    args = [x.ctypes.data_as(vp) for x in (q, v, w, a)]
+                    outs = [x.ctypes.data_as(vp) for x in (q2, v2, w2)]
+                    if model:
+                        Lo.walker_host_step(*args, 4, int(model == 2), 0, *outs, ctypes.byref(it2))
+                    else:
+                        Lo.cheetah_host_step(*args, 5, 0, *outs, ctypes.byref(it2))
+                    worst_lane = max(worst_lane, np.abs(qo - q2).max(), np.abs(vo - v2).max())
+            assert worst < 1e-9 and worst_lane < 1e-9, (task, kl, worst, worst_lane)

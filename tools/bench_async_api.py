@@ -44,7 +44,45 @@ def run_async(task, n, batch, steps):
     return batch * steps / dt
 
 
+def run_async_device(task, n, batch, steps, streams, adim=6):
+    """Device path: recv_device -> send_device with the env ids and actions resident in HBM, `n / batch`
+    batches in flight, successive batches on `streams` compute streams (engine key compute_streams)."""
+    import torch
+
+    from envpool_amd.core.device_pool import DevicePool
+
+    fam = task.split("-")[0]
+    pool = DevicePool(fam, n, batch_size=batch, seed=0, max_episode_steps=1000, params={"compute_streams": streams})
+    dev = torch.device("cuda", 0)
+    ring = [torch.rand((batch, adim), device=dev, dtype=torch.float64) * 2 - 1 for _ in range(8)]
+    torch.cuda.synchronize()
+    ids = torch.arange(n, device=dev, dtype=torch.int32)
+    torch.cuda.synchronize()
+    for j in range(n // batch):  # n / batch reset launches = the batches in flight
+        pool.send_device(None, batch, ids[j * batch:].data_ptr())
+
+    def cycle(i):
+        ptrs, k = pool.recv_device()
+        pool.send_device(ring[i % 8].data_ptr(), k, ptrs[0])  # ptrs[0] = info:env_id of the batch
+    for i in range(4 * (n // batch)):
+        cycle(i)
+    pool.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        cycle(i)
+    pool.synchronize()
+    return batch * steps / (time.perf_counter() - t0)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "streams":
+        # independent in-flight batches on several compute streams (round 3): 8 batches of 8192 in flight
+        for task, n, b, adim in (("HalfCheetah-v4", 65536, 8192, 6), ("Ant-v4", 65536, 8192, 8)):
+            rec = {"task": task, "num_envs": n, "batch_size": b}
+            for k in (1, 2, 4, 8):
+                rec[f"device_path_{k}_streams_env_steps_per_s"] = run_async_device(task, n, b, 400 if "Half" in task else 100, k, adim)
+            print(json.dumps(rec), flush=True)
+        sys.exit(0)
     for task, b in (("HalfCheetah-v4", 65536), ("HalfCheetah-v4", 8192), ("Ant-v4", 32768)):
         steps = 100 if task.startswith("Half") else 20
         rec = {"task": task, "batch_size": b,
