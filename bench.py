@@ -233,12 +233,19 @@ def main():
         # this same command (tools/profile_bench.sh -> profiles/pmc.json): PMC
         # collection needs its own rocprofv3 runs and cannot happen inside the bench.
         hum_quad = params.get("hum_layout", 1) != 0  # one env per lane quad (default)
+        # HalfCheetah / Walker2d in fp64 run on the lane-group kernel (planar_layout 2 or 4, default 2)
+        lg_layout = int(params.get("planar_layout", 0)) or 2
+        lg = (args.task in ("HalfCheetah", "Walker2d") and args.precision == "fp64" and lg_layout > 1
+              and params.get("frame_stack", 1) == 1)
         kbase = ("AntStepKernel" if args.task == "Ant" else
                  ("Humanoid4StepKernel" if hum_quad else "HumanoidStepKernel")
                  if args.task.startswith("Humanoid") else
                  "PusherStepKernel" if args.task == "Pusher" else "CheetahStepKernel")
         fp64_only = args.task.startswith("Humanoid") or args.task == "Pusher"
         kname = kbase + ("<double>" if args.precision == "fp64" or fp64_only else "<float>")
+        if lg:
+            kbase = "PlanarLgStepKernel"
+            kname = f"PlanarLgStepKernel<{lg_layout},{int(params.get('planar_waves', 2))}>"
         if args.task in ("Walker2d", "Hopper"):
             kname += f"[{args.task}]"
         if args.task == "HumanoidStandup":
@@ -251,7 +258,14 @@ def main():
             pass
         traffic = None
         valu = None
-        if pmc and pmc.get("num_envs") == n:
+        stale = None
+        if pmc:
+            # PMC counts belong to the build they were collected on: the entry carries a hash of the
+            # kernel's sources + Makefile (tools/kernel_sources.py); a changed kernel is not priced with them
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from kernel_sources import source_hash
+            stale = pmc.get("src_hash") != source_hash(kname)
+        if pmc and pmc.get("num_envs") == n and not stale:
             traffic = pmc["traffic_bytes_per_launch"]
             peak_tf = 78.6 if args.precision == "fp64" or fp64_only else 157.3
             tf = pmc["flops_per_launch"] / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
@@ -275,6 +289,8 @@ def main():
             roof = {"bound": "valu", **{k: valu[k] for k in ("achieved", "peak", "unit", "frac")},
                     "flops_per_env_step": valu["flops_per_env_step"],
                     "flops_source": valu["flops_source"], "traffic": traffic, "hbm": hbm}
+        if stale:
+            roof["stale"] = True  # profiles/pmc.json holds counts of an older build of this kernel: not used
         roof.update({"kernel": kbase, "kernel_ms": kernel_ms, "launches": launches,
                      "kernel_ms_method": "HIP events on the pool's stream before the first and after the last "
                                          "launch of the timed region, / launches",

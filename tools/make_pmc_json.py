@@ -13,6 +13,9 @@ import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_sources import source_hash  # noqa: E402
+
 prefix = sys.argv[1] if len(sys.argv) > 1 else "r1f"
 num_envs = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,12 +28,17 @@ for path in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}*",
     kernel = m.group(1).strip()
     ctr = {k: float(v) for k, v in re.findall(r"\| (\w+) \| ([0-9.e+-]+) \| \d+ \|", text)}
     tr = re.search(r"\| %s \| (\d+) \| ([0-9.]+) \|" % re.escape(kernel), text)
-    f64 = "<double>" in kernel
+    lg = re.search(r"PlanarLgStepKernel<(\d), (\d), (\d)>", kernel)  # <lanes per env, model, waves per SIMD>
+    if lg:  # canonical name (bench.py builds the same): all lane-group kernels are fp64
+        model = {"0": "", "1": "[Walker2d]", "2": "[Walker2d-v5]"}[lg.group(2)]
+        kernel = f"PlanarLgStepKernel<{lg.group(1)},{lg.group(3)}>{model}"
+    f64 = "<double>" in kernel or lg is not None
     sfx = "F64" if f64 else "F32"
     flops = 64.0 * (2 * ctr.get(f"SQ_INSTS_VALU_FMA_{sfx}", 0) + ctr.get(f"SQ_INSTS_VALU_ADD_{sfx}", 0) +
                     ctr.get(f"SQ_INSTS_VALU_MUL_{sfx}", 0) + ctr.get(f"SQ_INSTS_VALU_TRANS_{sfx}", 0))
     quad = "Ant" in kernel or "Humanoid4" in kernel  # one env per lane quad: 16 envs per wave
-    waves = (num_envs + 15) // 16 if quad else (num_envs + 63) // 64
+    per_wave = 64 // int(lg.group(1)) if lg else (16 if quad else 64)
+    waves = (num_envs + per_wave - 1) // per_wave
     out[f"{kernel}@{num_envs}"] = {
         "fetch_size_kb": ctr.get("FETCH_SIZE"),
         "write_size_kb": ctr.get("WRITE_SIZE"),
@@ -44,6 +52,7 @@ for path in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}*",
         "note": "gfx950: FETCH_SIZE counts half the bytes of a coalesced stream -> x2",
         "source": f"profiles/{os.path.basename(os.path.dirname(path)).replace('prof_', '')}_summary.md",
         "num_envs": num_envs,
+        "src_hash": source_hash(kernel),  # the kernel's sources + Makefile at the time of the profile
     }
 dst = os.path.join(root, "profiles", "pmc.json")
 try:
