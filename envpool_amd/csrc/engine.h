@@ -99,14 +99,11 @@ struct Batch {
   int consumed{0};                // rows already handed to recv (async mode)
   std::vector<size_t> offsets;    // byte offset of each key's section
   hipEvent_t done{nullptr};
-  hipStream_t stream{nullptr};    // the compute stream its kernel was launched on
+  hipStream_t stream{nullptr};    // the compute stream its kernel was launched on ...
+  int stream_idx{0};              // ... and always will be: blocks are recycled per stream
   // async mode with several compute streams: the local env of every row (host-path sends / resets;
   // empty for device-path batches, whose ids the host never sees), so that recv can mark them idle
   std::vector<int32_t> host_ids;
-  // several compute streams: a device-path send whose env ids live in THIS (handed-out) batch copies
-  // them out on its own stream first; the next kernel that writes this block waits for that copy
-  hipEvent_t ids_read{nullptr};
-  bool ids_read_pending{false};
 };
 
 // Per-env bookkeeping shared by all families, SoA on device:
@@ -195,7 +192,7 @@ class Pool {
   OutPtrs PtrsOf(const Batch& b) const;
   void Enqueue(const int* d_ids, int k, const void* d_action, bool force);
   // chooses stream_ for the next launch and orders it behind what it may depend on
-  void PickStream(const int32_t* host_ids, int k, bool device_path);
+  void PickStream(const int32_t* host_ids, int k, bool device_path, const void* d_env_id = nullptr);
   void JoinCompute(hipStream_t into);  // `into` waits for everything enqueued on every compute stream
   void SyncCompute();                  // host waits for every compute stream
   void MarkIdle(Batch* b, int first, int count);
@@ -220,7 +217,7 @@ class Pool {
   double* stack_tmp_{nullptr};   // [N][nobs] un-stacked obs of the current launch
   std::mutex mu_;
   std::deque<Batch*> pending_;
-  std::vector<Batch*> free_;
+  std::vector<std::vector<Batch*>> free_;  // per compute stream
   std::vector<std::unique_ptr<Batch>> all_;
   Batch* lent_[2]{nullptr, nullptr};  // batches handed out by RecvDevice
   std::vector<Staging> staging_;
@@ -234,8 +231,7 @@ class Pool {
   size_t rr_{0};
   bool picked_{false};                   // WaitStream already chose the stream of the next launch
   std::vector<uint8_t> busy_;            // host path: env is in a batch that was not received yet
-  std::vector<hipEvent_t> frontier_;     // device path: batches handed out whose kernels may still run
-  std::vector<int*> ids_stage_;          // per compute stream: the device-path env ids of its current launch
+  std::vector<Batch*> frontier_;         // device path: batches handed out whose kernels may still run
   const int32_t* next_host_ids_{nullptr};  // ids of the launch being enqueued (for Batch::host_ids)
   bool next_identity_{false};
   // timing

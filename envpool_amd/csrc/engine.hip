@@ -114,6 +114,7 @@ Pool::Pool(const Config& cfg, std::vector<KeySpec> env_state_keys,
     compute_.push_back(s);
   }
   if (compute_.size() > 1) busy_.assign((size_t)cfg_.num_envs, 0);
+  free_.resize(compute_.size());
   EPA_HIP(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
   EPA_HIP(hipStreamCreateWithFlags(&d2h_stream_, hipStreamNonBlocking));
   staging_.resize(3);
@@ -147,13 +148,9 @@ Pool::~Pool() {
   for (hipStream_t s : compute_) (void)hipStreamSynchronize(s);
   if (d2h_stream_) (void)hipStreamSynchronize(d2h_stream_);
   for (hipEvent_t e : join_ev_) (void)hipEventDestroy(e);
-  for (int* p : ids_stage_) {
-    if (p) (void)hipFree(p);
-  }
   for (auto& b : all_) {
     if (b->dbuf) (void)hipFree(b->dbuf);
     if (b->done) (void)hipEventDestroy(b->done);
-    if (b->ids_read) (void)hipEventDestroy(b->ids_read);
   }
   for (auto& s : staging_) {
     if (s.h) (void)hipHostFree(s.h);
@@ -262,9 +259,12 @@ void Pool::EnableObsStack() {
 
 Batch* Pool::AcquireBatch(int k) {
   Batch* b = nullptr;
-  if (!free_.empty()) {
-    b = free_.back();
-    free_.pop_back();
+  // a block is always written by kernels of ONE compute stream (the one it was created for): the
+  // next launch into a recycled block is stream-ordered behind everything that stream did with it
+  auto& fl = free_[rr_];
+  if (!fl.empty()) {
+    b = fl.back();
+    fl.pop_back();
   } else {
     all_.push_back(std::make_unique<Batch>());
     b = all_.back().get();
@@ -273,6 +273,7 @@ Batch* Pool::AcquireBatch(int k) {
     for (auto& key : keys_) total += Align(b->cap_rows * key.row_bytes());
     EPA_HIP(hipMalloc(&b->dbuf, total));
     EPA_HIP(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
+    b->stream_idx = (int)rr_;
   }
   b->k = k;
   b->consumed = 0;
@@ -285,7 +286,7 @@ Batch* Pool::AcquireBatch(int k) {
   return b;
 }
 
-void Pool::ReleaseBatch(Batch* b) { free_.push_back(b); }
+void Pool::ReleaseBatch(Batch* b) { free_[(size_t)b->stream_idx].push_back(b); }
 
 OutPtrs Pool::PtrsOf(const Batch& b) const {
   OutPtrs o{};
@@ -295,10 +296,6 @@ OutPtrs Pool::PtrsOf(const Batch& b) const {
 
 void Pool::Enqueue(const int* d_ids, int k, const void* d_action, bool force) {
   Batch* b = AcquireBatch(k);
-  if (b->ids_read_pending) {  // see SendDevice
-    EPA_HIP(hipStreamWaitEvent(stream_, b->ids_read, 0));
-    b->ids_read_pending = false;
-  }
   hipEvent_t t0 = nullptr, t1 = nullptr;
   if (timing_ == 2) {  // window timing: no event between the launches (an event pair per launch keeps
     // consecutive step kernels ~12 us apart on this runtime)
@@ -367,15 +364,18 @@ void Pool::Enqueue(const int* d_ids, int k, const void* d_action, bool force) {
 // The reference's worker threads step every queued slice in parallel (async_envpool.h:116-132):
 // with batch_size < num_envs several batches are in flight and none depends on another, because an
 // env is either queued / stepping or waiting to be received (an action can only be sent for an env
-// that recv handed out).  Here successive launches of an async-mode pool rotate over the compute
-// streams.  What a launch must still be ordered behind:
-//  * the previous step of ITS OWN envs.  Host path: recv returned those rows, so their kernel has
-//    completed (the D2H was synchronised).  Device path: recv_device hands rows out while their
-//    kernel may still be running -- the new launch waits for the `done` events of the handed-out
-//    batches that have not completed yet (`frontier_`);
-//  * a caller that breaks the rule (sends an env again before receiving it; the reference would
-//    race): host-path ids are checked against `busy_`, and such a launch is ordered behind
-//    EVERYTHING enqueued so far, which is the single-stream behaviour.
+// that recv handed out).  Here an async-mode pool owns several compute streams, each an
+// independent pipeline with its own result blocks, and a launch is placed so that stream order
+// alone gives it what it depends on -- the previous step of ITS OWN envs:
+//  * device path: the env ids of a send are (normally) the `info:env_id` array of a batch that
+//    recv_device handed out; the launch goes on THAT batch's stream, behind the kernel that produced
+//    the ids and the state, and ahead of whatever will recycle the block.  No event is waited for.
+//    Ids from anywhere else: round robin, ordered behind every handed-out batch whose kernel has not
+//    completed (`frontier_`);
+//  * host path: recv returned the rows, so their kernel has completed (the D2H was synchronised):
+//    round robin.  A caller that breaks the rule (sends an env again before receiving it; the
+//    reference would race) is caught by the per-env `busy_` flags, and that launch is ordered behind
+//    EVERYTHING enqueued so far -- the single-stream behaviour.
 void Pool::JoinCompute(hipStream_t into) {
   if (compute_.size() < 2) return;
   while (join_ev_.size() < compute_.size()) {
@@ -394,23 +394,36 @@ void Pool::SyncCompute() {
   for (hipStream_t s : compute_) EPA_HIP(hipStreamSynchronize(s));
 }
 
-void Pool::PickStream(const int32_t* host_ids, int k, bool device_path) {
+void Pool::PickStream(const int32_t* host_ids, int k, bool device_path, const void* d_env_id) {
   next_host_ids_ = nullptr;
   next_identity_ = false;
   if (compute_.size() < 2) return;
-  if (picked_) {
-    picked_ = false;  // WaitStream chose (and ordered) the stream of this launch already
-  } else {
-    rr_ = (rr_ + 1) % compute_.size();
-    stream_ = compute_[rr_];
+  Batch* cont = nullptr;  // the handed-out batch this send continues
+  if (device_path && d_env_id != nullptr) {
+    const char* p = static_cast<const char*>(d_env_id);
+    for (Batch* b : lent_) {
+      if (b != nullptr && p >= b->dbuf && p < b->dbuf + b->offsets[1]) cont = b;  // inside its info:env_id
+    }
   }
+  const bool was_picked = picked_;
+  const size_t picked_rr = rr_;
+  picked_ = false;
+  if (cont != nullptr) {
+    rr_ = (size_t)cont->stream_idx;
+  } else if (!was_picked) {
+    rr_ = (rr_ + 1) % compute_.size();
+  }
+  stream_ = compute_[rr_];
+  // WaitStream ordered the stream IT chose behind the producer; if the launch goes elsewhere, again
+  if (was_picked && rr_ != picked_rr) EPA_HIP(hipStreamWaitEvent(stream_, order_ev_, 0));
   bool join = false;
-  {  // batches handed out by recv_device whose kernels may still be running
+  if (cont == nullptr) {
+    // batches handed out by recv_device whose kernels may still be running, on other streams
     size_t keep = 0;
-    for (hipEvent_t ev : frontier_) {
-      if (hipEventQuery(ev) == hipSuccess) continue;
-      EPA_HIP(hipStreamWaitEvent(stream_, ev, 0));
-      frontier_[keep++] = ev;
+    for (Batch* b : frontier_) {
+      if (hipEventQuery(b->done) == hipSuccess) continue;
+      if (b->stream != stream_) EPA_HIP(hipStreamWaitEvent(stream_, b->done, 0));
+      frontier_[keep++] = b;
     }
     frontier_.resize(keep);
     (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
@@ -545,29 +558,8 @@ void Pool::SendDevice(const int32_t* d_env_id, int k, const void* d_action,
   // the producer of d_action / d_env_id (a learner on another stream) recorded
   // `wait_event` after writing them: the step kernel is ordered behind it
   // (the analogue of the XLA custom call's stream ordering, core/xla.h:151-169)
-  PickStream(nullptr, k, true);
+  PickStream(nullptr, k, true, d_env_id);
   if (wait_event != nullptr) EPA_HIP(hipStreamWaitEvent(stream_, wait_event, 0));
-  if (compute_.size() > 1 && d_env_id != nullptr) {
-    // The ids usually are the `info:env_id` array of a batch recv_device handed out.  With one
-    // compute stream that block cannot be rewritten before this launch has read it (stream order);
-    // with several, a later launch on ANOTHER stream could reuse the block first.  So the ids are
-    // copied out on this launch's stream (per-stream buffer: the next copy into it is behind this
-    // kernel), and the block's next writer waits for the copy (Batch::ids_read).
-    if (ids_stage_.size() < compute_.size()) ids_stage_.resize(compute_.size(), nullptr);
-    int*& stage = ids_stage_[rr_];
-    if (stage == nullptr) EPA_HIP(hipMalloc(&stage, sizeof(int) * (size_t)cfg_.num_envs));
-    EPA_HIP(hipMemcpyAsync(stage, d_env_id, sizeof(int) * (size_t)k, hipMemcpyDeviceToDevice, stream_));
-    const char* p = reinterpret_cast<const char*>(d_env_id);
-    for (Batch* b : lent_) {
-      if (b == nullptr || p < b->dbuf || p >= b->dbuf + b->offsets.back() + Align((size_t)b->k * keys_.back().row_bytes())) {
-        continue;
-      }
-      if (!b->ids_read) EPA_HIP(hipEventCreateWithFlags(&b->ids_read, hipEventDisableTiming));
-      EPA_HIP(hipEventRecord(b->ids_read, stream_));
-      b->ids_read_pending = true;
-    }
-    d_env_id = stage;
-  }
   Enqueue(d_env_id, k, d_action, d_action == nullptr);
 }
 
@@ -766,7 +758,11 @@ int Pool::RecvDevice(void** d_out_ptrs, int n_ptrs) {
   }
   pending_.pop_front();
   MarkIdle(b, 0, b->k);
-  if (compute_.size() > 1) frontier_.push_back(b->done);
+  if (compute_.size() > 1) {
+    // (a block is recycled two recv_device calls later: drop the entry it may still have)
+    frontier_.erase(std::remove(frontier_.begin(), frontier_.end(), b), frontier_.end());
+    frontier_.push_back(b);
+  }
   for (size_t i = 0; i < keys_.size(); ++i) {
     d_out_ptrs[i] = b->dbuf + b->offsets[i];
   }

@@ -886,6 +886,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
   U prev_mask = LT::Fill(~0u);
   B full_step = LT::False();
   B live = LT::True();
+  B at_min = LT::False();  // the env stopped at an exact minimiser (finite termination in the line search)
   V iter = V(0);
   for (int it = 0; it < cfg.max_iter; ++it) {
     // Every lane (also those of finished envs, whose qacc and Ma are frozen) rebuilds H and grad
@@ -974,12 +975,18 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
       constexpr int i = decltype(ic)::value;
       qacc[i] += step * s[i];
       Ma[i] += step * Ms[i];
-      // at the minimiser the gradient vanishes (to rounding: what the next pass would have found)
-      grad[i] = Sel(exact, V(0), grad[i]);
     });
+    at_min = at_min | exact;
     live = live & !exact;
     if (!AnyWave(live)) break;
   }
+  // At the minimiser the gradient vanishes (to rounding).  Set for every env that stopped there,
+  // whether or not its wave went on iterating for other envs and re-evaluated this env's rows:
+  // an env's result must not depend on its neighbours.
+  static_for<0, kLV>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    grad[i] = Sel(at_min, V(0), grad[i]);
+  });
   if (AnyWave(live)) {  // iteration cap hit somewhere in the wave: refresh grad
     V gc[kLV];
     static_for<0, kLV>([&](auto ic) { gc[decltype(ic)::value] = V(0); });

@@ -306,7 +306,9 @@ def _async_rollout(task, adim, n, b, streams, recvs, device_path, break_rule=Fal
     for r in range(recvs):
         if device_path:
             out = recv_device_tensors(pool)
-            eids_t = out["info:env_id"].reshape(-1).clone()
+            eids_t = out["info:env_id"].reshape(-1)  # aliases the handed-out batch: the send continues ITS stream
+            if device_path == "clone":
+                eids_t = eids_t.clone()  # ids from elsewhere: ordered behind the handed-out batches by events
             host = {k: v.cpu().numpy() for k, v in out.items()}
         else:
             host = pool.recv_dict()
@@ -333,7 +335,7 @@ def _async_rollout(task, adim, n, b, streams, recvs, device_path, break_rule=Fal
 
 
 @pytest.mark.parametrize("task,adim", [("HalfCheetah", 6), ("Ant", 8)])
-@pytest.mark.parametrize("device_path", [False, True])
+@pytest.mark.parametrize("device_path", [False, "lent", "clone"])
 def test_async_batches_on_several_streams_match_one_stream(task, adim, device_path):
     """batch_size < num_envs: successive batches run on different compute streams (the reference's workers
     step all queued slices in parallel, async_envpool.h:116-132).  Every env's own sequence of outputs is
