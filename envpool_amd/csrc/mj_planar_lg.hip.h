@@ -126,10 +126,15 @@ inline void BuildTable(const CheetahModel<double>& m, double* tab) {
   }
 }
 
-// LDS slots of a lane: 5 per end-sphere slot (cpx cpz aref_n B*mu*vx D), [slot][lane]
-constexpr int kSlotsPerEnd = 5;
+// LDS slots of a lane, [slot][lane]: 5 per end-sphere slot (cpx cpz aref_n B*mu*vx D), then 4 per
+// end-sphere slot that live for one Newton iteration: (Jn.a, Jx.a) left by the pass over the rows and
+// (Jn.s, Jx.s) left by the first line-search evaluation, so that the further evaluations of that
+// line search (2.1 per iteration on average) do not rebuild the Jacobian columns
+constexpr int kSlotsPerEnd = 5, kCachePerEnd = 4;
 template <int KL>
-constexpr int LdsSlots() { return Grp<KL>::kEnds * kSlotsPerEnd; }
+constexpr int CacheBase() { return Grp<KL>::kEnds * kSlotsPerEnd; }
+template <int KL>
+constexpr int LdsSlots() { return Grp<KL>::kEnds * (kSlotsPerEnd + kCachePerEnd); }
 
 // ================================================================================================
 // The lane vocabulary.  Device: a value IS a lane's scalar, conditions are bool, the group
@@ -643,6 +648,10 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
         jna += jn * a[j];
         jxa += jx * a[j];
       });
+      if constexpr (kHess) {  // the per-iteration pass: kept for the line search
+        cx.Lds(CacheBase<KL>() + s * kCachePerEnd + 0) = jna;
+        cx.Lds(CacheBase<KL>() + s * kCachePerEnd + 1) = jxa;
+      }
       // rows: 2 x (Jn), (Jn - mu Jx), (Jn + mu Jx); D == 0 for lanes not in contact, which
       // zeroes every weight below
       const V mu = MuOf<b, T, V>(m, cx);
@@ -697,36 +706,51 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
   for (unsigned rem = ends; rem != 0; rem &= rem - 1) {
     const int sl = __builtin_ctz(rem);
     const V D = cx.Lds(sl * kSlotsPerEnd + 4);
-    DispatchLocalBody(Grp<KL>::SlotBody(sl), [&](auto bc) {
-      constexpr int b = decltype(bc)::value;
+    const V an = cx.Lds(sl * kSlotsPerEnd + 2), ax = cx.Lds(sl * kSlotsPerEnd + 3);
+    const V jna = cx.Lds(CacheBase<KL>() + sl * kCachePerEnd + 0);  // RowsPass<true> at the same `a`
+    const V jxa = cx.Lds(CacheBase<KL>() + sl * kCachePerEnd + 1);
+    V jns, jxs;
+    if constexpr (kMask) {  // first evaluation of this line search: J . s, kept for the others
       const V cpx = cx.Lds(sl * kSlotsPerEnd + 0), cpz = cx.Lds(sl * kSlotsPerEnd + 1);
-      const V an = cx.Lds(sl * kSlotsPerEnd + 2), ax = cx.Lds(sl * kSlotsPerEnd + 3);
-      V jna = V(0), jxa = V(0), jns = V(0), jxs = V(0);
-      ForChainCols<b>(p, cpx, cpz, [&](auto jc, V jn, V jx) {
-        constexpr int j = decltype(jc)::value;
-        jna += jn * a[j];
-        jxa += jx * a[j];
-        jns += jn * s[j];
-        jxs += jx * s[j];
-      });
-      const V mu = MuOf<b, T, V>(m, cx);
-      const V jar1 = jna - an, jv1 = jns;
-      const V jar2 = jna - mu * jxa - (an + ax), jv2 = jns - mu * jxs;
-      const V jar3 = jna + mu * jxa - (an - ax), jv3 = jns + mu * jxs;
-      const V x1 = jar1 + alpha * jv1, x2 = jar2 + alpha * jv2, x3 = jar3 + alpha * jv3;
-      // D == 0 for lanes not in contact
-      const V c1 = Sel(x1 < V(0), V(2) * D, V(0));
-      const V c2 = Sel(x2 < V(0), D, V(0));
-      const V c3 = Sel(x3 < V(0), D, V(0));
-      *d1 += c1 * x1 * jv1 + c2 * x2 * jv2 + c3 * x3 * jv3;
-      *d2 += c1 * jv1 * jv1 + c2 * jv2 * jv2 + c3 * jv3 * jv3;
-      if constexpr (kMask) {
-        const auto on = D > V(0);
-        MaskSet(mask, on & (x1 < V(0)), 3 + 3 * sl);
-        MaskSet(mask, on & (x2 < V(0)), 4 + 3 * sl);
-        MaskSet(mask, on & (x3 < V(0)), 5 + 3 * sl);
+      // s . (Jacobian columns of a point on local body b): torso dofs, then the hinges up to b
+      jns = s[1] - (cpx - p.px[0]) * s[2];
+      jxs = s[0] + (cpz - p.pz[0]) * s[2];
+      const int b = Grp<KL>::SlotBody(sl);  // wave uniform
+      if (b >= 1) {
+        jns -= (cpx - p.px[1]) * s[3];
+        jxs += (cpz - p.pz[1]) * s[3];
       }
-    });
+      if (b >= 2) {
+        jns -= (cpx - p.px[2]) * s[4];
+        jxs += (cpz - p.pz[2]) * s[4];
+      }
+      if (b >= 3) {
+        jns -= (cpx - p.px[3]) * s[5];
+        jxs += (cpz - p.pz[3]) * s[5];
+      }
+      cx.Lds(CacheBase<KL>() + sl * kCachePerEnd + 2) = jns;
+      cx.Lds(CacheBase<KL>() + sl * kCachePerEnd + 3) = jxs;
+    } else {
+      jns = cx.Lds(CacheBase<KL>() + sl * kCachePerEnd + 2);
+      jxs = cx.Lds(CacheBase<KL>() + sl * kCachePerEnd + 3);
+    }
+    const V mu = cx.C(kTMu + Grp<KL>::SlotBody(sl));  // (the table also carries the torso's)
+    const V jar1 = jna - an, jv1 = jns;
+    const V jar2 = jna - mu * jxa - (an + ax), jv2 = jns - mu * jxs;
+    const V jar3 = jna + mu * jxa - (an - ax), jv3 = jns + mu * jxs;
+    const V x1 = jar1 + alpha * jv1, x2 = jar2 + alpha * jv2, x3 = jar3 + alpha * jv3;
+    // D == 0 for lanes not in contact
+    const V c1 = Sel(x1 < V(0), V(2) * D, V(0));
+    const V c2 = Sel(x2 < V(0), D, V(0));
+    const V c3 = Sel(x3 < V(0), D, V(0));
+    *d1 += c1 * x1 * jv1 + c2 * x2 * jv2 + c3 * x3 * jv3;
+    *d2 += c1 * jv1 * jv1 + c2 * jv2 * jv2 + c3 * jv3 * jv3;
+    if constexpr (kMask) {
+      const auto on = D > V(0);
+      MaskSet(mask, on & (x1 < V(0)), 3 + 3 * sl);
+      MaskSet(mask, on & (x2 < V(0)), 4 + 3 * sl);
+      MaskSet(mask, on & (x3 < V(0)), 5 + 3 * sl);
+    }
   }
 }
 

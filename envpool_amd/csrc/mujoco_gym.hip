@@ -360,7 +360,10 @@ class CheetahPool : public Pool {
       throw std::invalid_argument("planar_layout must be 0, 1, 2 or 4");
     }
     lg_ok_ = fp64_ && !hopper && task_.frame_stack == 1;
-    lg_waves_ = (int)cfg.Get("planar_waves", 2) == 1 ? 1 : 2;  // A/B: register budget of the lane-group kernel
+    // register budget of the lane-group kernel: one wave per SIMD with all 512 registers (default;
+    // measured faster at every batch size, profiles/r3f_lane_group_sweep.txt) or two with 256 + spills
+    lg_waves_ = (int)cfg.Get("planar_waves", 1) == 2 ? 2 : 1;
+    lpt_ = cfg.Get("planar_lpt", 1) != 0;
     if (lg_ok_) {
       for (int i = 0; i < 2; ++i) {
         std::vector<double> tab(kPlanarLgTabMax, 0.0);
@@ -401,6 +404,7 @@ class CheetahPool : public Pool {
       if (t) (void)hipFree(t);
     }
     for (auto& kv : tickets_) (void)hipFree(kv.second.d);
+    if (order_.d) (void)hipFree(order_.d);
   }
   int ModelNv() const { return model_id_ == mj::kPlanarHopper ? 6 : kNV; }
   int StateDim() const override { return 3 * ModelNv() + 7; }
@@ -432,8 +436,29 @@ class CheetahPool : public Pool {
         EPA_HIP(hipMalloc(&tk.d, sizeof(unsigned)));
         EPA_HIP(hipMemsetAsync(tk.d, 0, sizeof(unsigned), stream_));
       }
+      // longest-chunk-first dispatch: whole-pool batches only (the chunks are then the same envs
+      // from launch to launch); "planar_lpt" = 0 switches it off (A/B)
+      planar::LgOrder lo;
+      if (lpt_ && d_ids == nullptr && !force_reset) {
+        const int per = kCheetahBlock / layout, nchunks = (k + per - 1) / per;
+        if (order_.d == nullptr) {
+          order_.cap = (cfg_.num_envs + 15) / 16;
+          EPA_HIP(hipMalloc(&order_.d, PlanarLgOrderBytes(order_.cap)));
+          EPA_HIP(hipMemsetAsync(order_.d, 0, PlanarLgOrderBytes(order_.cap), stream_));
+          order_.gen = 0;
+          order_shape_ = -1;
+        }
+        const int shape = nchunks * 8 + layout;
+        order_.use = (shape == order_shape_ && order_stream_ == stream_) ? 1 : 0;
+        lo = order_;
+        ++order_.gen;
+        order_shape_ = shape;
+        order_stream_ = stream_;
+      } else {
+        order_shape_ = -1;  // the chain of same-shape launches is broken
+      }
       PlanarLgLaunch(stream_, layout, lg_waves_, model_id_, wave_slots_, dev_, common_, a,
-                     static_cast<const double*>(d_action), out, task_, d_tab_[layout == 2 ? 0 : 1], tk.d, &tk.base);
+                     static_cast<const double*>(d_action), out, task_, d_tab_[layout == 2 ? 0 : 1], tk.d, &tk.base, lo);
       return;
     }
     int lanes = kCheetahBlock;
@@ -472,13 +497,17 @@ class CheetahPool : public Pool {
   int wave_slots_{1024};
   int layout_{0};
   bool lg_ok_{false};
-  int lg_waves_{2};
+  int lg_waves_{1};
   double* d_tab_[2] = {nullptr, nullptr};
   struct Ticket {
     unsigned* d{nullptr};
     unsigned base{0};
   };
   std::map<hipStream_t, Ticket> tickets_;  // chunk queue of the lane-group kernel, per launch stream
+  planar::LgOrder order_;
+  int order_shape_{-1};
+  hipStream_t order_stream_{nullptr};
+  bool lpt_{true};
 };
 
 }  // namespace

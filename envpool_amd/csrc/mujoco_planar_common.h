@@ -59,6 +59,16 @@ constexpr CheetahModel<T> PlanarModel() {
 
 constexpr int kCheetahBlock = 64;
 
+// longest-chunk-first dispatch state of the lane-group kernel (mujoco_planar_lg.hip): `d` = device
+// block of PlanarLgOrderBytes(cap) bytes (zeroed), cap >= chunks of any launch that uses it;
+// gen = launches that used it so far; use = this launch follows one of the same shape
+struct LgOrder {
+  unsigned* d{nullptr};
+  int cap{0};
+  int gen{0};
+  int use{0};
+};
+
 }  // namespace planar
 
 // mujoco_planar_lg.hip: one env per group of `kl` (2 or 4) lanes; `tab` = the device copy of
@@ -68,7 +78,9 @@ constexpr int kCheetahBlock = 64;
 // host's copy of its value (one pair per stream that launches concurrently, see PlanarLgStepKernel)
 void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots, const planar::CheetahDev& dev,
                     const CommonDev& cm, const StepArgs& a, const double* action, const OutPtrs& out,
-                    const planar::CheetahTask& task, const double* tab, unsigned* ticket, unsigned* ticket_base);
+                    const planar::CheetahTask& task, const double* tab, unsigned* ticket, unsigned* ticket_base,
+                    const planar::LgOrder& order);
+size_t PlanarLgOrderBytes(int cap);
 // fills `tab` (host) for lane groups of `kl`; returns the number of doubles (<= kPlanarLgTabMax)
 constexpr int kPlanarLgTabMax = 512;
 int PlanarLgBuildTable(int kl, int model, double* tab);

@@ -27,9 +27,12 @@ namespace plg = mj::plg;
 
 constexpr int kBlock = 64;
 
+// (an LDS pointer typed as such: through a generic pointer the optimiser-opaque Refresh() below turns
+// every table read into a flat_load, which takes the long way round to the LDS)
+using LdsConstDouble = const __attribute__((address_space(3))) double;
 template <int KL>
 struct DevCx {
-  const double* tab;  // the wave's LDS copy of the table at this lane's column: tab[id * KL]
+  LdsConstDouble* tab;  // the wave's LDS copy of the table at this lane's column: tab[id * KL]
   double* lds;        // the wave's LDS block at this lane: lds[slot * 64]
   __device__ __forceinline__ double C(int id) const { return tab[id * KL]; }
   __device__ __forceinline__ double& Lds(int slot) { return lds[slot * kBlock]; }
@@ -54,7 +57,17 @@ struct LgArgs {
   unsigned* ticket;
   unsigned ticket_base;
   int nchunks;
+  // longest-chunk-first dispatch (see PlanarLgStepKernel): three generations of
+  // {cnt[kLptBuckets], sum, n, list[kLptBuckets][lpt_cap]}; this launch reads generation lpt_gen % 3
+  // (if lpt_use), fills (lpt_gen + 1) % 3 and clears (lpt_gen + 2) % 3.  nullptr: off.
+  unsigned* lpt;
+  int lpt_cap;
+  int lpt_gen;
+  int lpt_use;
 };
+constexpr int kLptBuckets = 16;
+constexpr int kLptHead = kLptBuckets + 4;  // cnt[16], sum (2 words), n, pad
+__host__ __device__ constexpr size_t LptGenWords(int cap) { return (size_t)kLptHead + (size_t)kLptBuckets * cap; }
 using LgArgsK = const __attribute__((address_space(4))) LgArgs;
 // The kernel's arguments, re-read from the kernarg segment through a pointer that is opaque to the
 // optimiser.  With the arguments as ordinary by-value parameters the persistent loop below makes
@@ -165,7 +178,7 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
     if (first) {  // half_cheetah.h:143-146: summed in the reference's order
       for (int i = 0; i < kNU; ++i) ctrl_cost += task.ctrl_cost_weight * act[i] * act[i];
     }
-    DevCx<KL> cx{tab_lds + c, lds_buf + lane};
+    DevCx<KL> cx{(LdsConstDouble*)tab_lds + c, lds_buf + lane};
     double iters = 0.0;
     for (int s = 0; s < task.frame_skip; ++s) {  // mujoco_env.h:142-144
       if constexpr (kWalker) {
@@ -241,6 +254,14 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
 // whoever finishes early does the extra work.  `ticket_base`: the counter's value before this
 // launch; every wave makes exactly one failing fetch, so a launch advances the counter by exactly
 // its number of chunks and the host never has to reset it.
+// LONGEST CHUNK FIRST.  With about two chunks per resident wave (N = 65536: 2048 chunks, 1024 waves)
+// the order of the queue decides the makespan: a slow chunk (many touching end spheres) taken last
+// keeps one SIMD busy while 1023 idle.  A chunk's duration is strongly correlated from one env-step
+// to the next (contact states persist), so every chunk times itself (s_memtime) and files itself
+// into one of 16 duration buckets (relative to the previous launch's mean) for the NEXT launch,
+// which serves the buckets slowest first.  Only the order of dispatch changes, never which envs
+// share a wave: results are bit-identical with and without it.  Used for whole-pool batches
+// (ids == nullptr) that follow a launch of the same shape; everything else runs in index order.
 // W: waves per SIMD the register allocation aims at (512 registers per SIMD lane: 1 -> 512, 2 -> 256)
 template <int KL, int kModel, int W>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(W, W))) void PlanarLgStepKernel(LgArgs args) {
@@ -252,15 +273,51 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(W, W))) 
   }
   __syncthreads();
 #if defined(__HIP_DEVICE_COMPILE__)
-  int chunk = blockIdx.x;
+  if (args.lpt != nullptr && blockIdx.x == 0 && threadIdx.x < kLptHead) {  // generation + 2: cleared for the next launch to fill
+    args.lpt[LptGenWords(args.lpt_cap) * ((args.lpt_gen + 2) % 3) + threadIdx.x] = 0u;
+  }
+  int tk = blockIdx.x;  // position in the queue: the first one is the wave's index, then tickets
   for (;;) {
-    StepChunk<KL, kModel>(chunk, tab_lds, lds_buf);
     LgArgsK* ap = KernArgs();
+    int chunk = tk;
+    unsigned mean = 0;
+    if (ap->lpt != nullptr) {
+      const unsigned* cur = ap->lpt + LptGenWords(ap->lpt_cap) * (ap->lpt_gen % 3);
+      if (ap->lpt_use) {
+        int rem = tk;
+        for (int b = kLptBuckets - 1; b >= 0; --b) {  // slowest bucket first
+          const int c = (int)cur[b];
+          if (rem < c) {
+            chunk = (int)cur[kLptHead + (size_t)b * ap->lpt_cap + rem];
+            break;
+          }
+          rem -= c;
+        }
+        const unsigned long long sum = ((unsigned long long)cur[kLptBuckets + 1] << 32) | cur[kLptBuckets];
+        mean = cur[kLptBuckets + 2] ? (unsigned)(sum / cur[kLptBuckets + 2]) : 0u;
+      }
+    }
+    chunk = __builtin_amdgcn_readfirstlane(chunk);
+    const long long t0 = clock64();
+    StepChunk<KL, kModel>(chunk, tab_lds, lds_buf);
+    ap = KernArgs();
     unsigned t = 0;
-    if (threadIdx.x == 0) t = atomicAdd(ap->ticket, 1u);
+    if (threadIdx.x == 0) {
+      if (ap->lpt != nullptr) {  // file this chunk for the next launch
+        unsigned* nxt = ap->lpt + LptGenWords(ap->lpt_cap) * ((ap->lpt_gen + 1) % 3);
+        const unsigned d = (unsigned)(clock64() - t0);
+        int b = mean ? (int)(((unsigned long long)d * 8u) / mean) : (int)(d >> 14);  // no mean yet: ~16k-cycle steps
+        b = b > kLptBuckets - 1 ? kLptBuckets - 1 : b;
+        const unsigned pos = atomicAdd(&nxt[b], 1u);
+        nxt[kLptHead + (size_t)b * ap->lpt_cap + pos] = (unsigned)chunk;
+        atomicAdd(reinterpret_cast<unsigned long long*>(&nxt[kLptBuckets]), (unsigned long long)d);
+        atomicAdd(&nxt[kLptBuckets + 2], 1u);
+      }
+      t = atomicAdd(ap->ticket, 1u);
+    }
     t = __builtin_amdgcn_readfirstlane(t);
-    chunk = (int)gridDim.x + (int)(t - ap->ticket_base);
-    if (chunk >= ap->nchunks) break;
+    tk = (int)gridDim.x + (int)(t - ap->ticket_base);
+    if (tk >= ap->nchunks) break;
   }
 #endif
 }
@@ -268,7 +325,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(W, W))) 
 template <int KL, int W>
 void LaunchKl(hipStream_t st, int model, int wave_slots, const CheetahDev& dev, const CommonDev& cm,
               const StepArgs& a, const double* action, const OutPtrs& out, const CheetahTask& task,
-              const double* tab, unsigned* ticket, unsigned* ticket_base) {
+              const double* tab, unsigned* ticket, unsigned* ticket_base, const planar::LgOrder& lo) {
   const int per = kBlock / KL;
   const int nchunks = (a.k + per - 1) / per;
   // waves resident at once: W per SIMD by registers; LDS (ends + table) allows 7 waves per CU at KL = 2
@@ -277,7 +334,8 @@ void LaunchKl(hipStream_t st, int model, int wave_slots, const CheetahDev& dev, 
   const int blocks = nchunks < resident ? nchunks : resident;
   const unsigned base = *ticket_base;
   *ticket_base = base + (unsigned)nchunks;  // see PlanarLgStepKernel
-  const LgArgs args{dev, cm, a, action, out, task, plg::SolverCfgLg<double>{50, 1e-13}, tab, ticket, base, nchunks};
+  const LgArgs args{dev, cm, a, action, out, task, plg::SolverCfgLg<double>{50, 1e-13}, tab, ticket, base, nchunks,
+                    lo.d, lo.cap, lo.gen, lo.use};
   switch (model) {
     case mj::kPlanarCheetah:
       hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarCheetah, W>), dim3(blocks), dim3(kBlock), 0, st, args);
@@ -295,8 +353,9 @@ void LaunchKl(hipStream_t st, int model, int wave_slots, const CheetahDev& dev, 
 
 void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots, const planar::CheetahDev& dev,
                     const CommonDev& cm, const StepArgs& a, const double* action, const OutPtrs& out,
-                    const planar::CheetahTask& task, const double* tab, unsigned* ticket, unsigned* ticket_base) {
-#define EPA_LG(KL, W) LaunchKl<KL, W>(st, model, wave_slots, dev, cm, a, action, out, task, tab, ticket, ticket_base)
+                    const planar::CheetahTask& task, const double* tab, unsigned* ticket, unsigned* ticket_base,
+                    const planar::LgOrder& lo) {
+#define EPA_LG(KL, W) LaunchKl<KL, W>(st, model, wave_slots, dev, cm, a, action, out, task, tab, ticket, ticket_base, lo)
   if (kl == 2) {
     if (waves == 1) {
       EPA_LG(2, 1);
@@ -310,6 +369,8 @@ void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots
   }
 #undef EPA_LG
 }
+
+size_t PlanarLgOrderBytes(int cap) { return sizeof(unsigned) * 3 * LptGenWords(cap); }
 
 int PlanarLgBuildTable(int kl, int model, double* tab) {
   const CheetahModel<double> m = model == mj::kPlanarCheetah  ? kCheetahModelConst
