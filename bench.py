@@ -234,7 +234,7 @@ def main():
         # collection needs its own rocprofv3 runs and cannot happen inside the bench.
         hum_quad = params.get("hum_layout", 1) != 0  # one env per lane quad (default)
         # HalfCheetah / Walker2d in fp64 run on the lane-group kernel (planar_layout 2 or 4, default 2)
-        lg_layout = int(params.get("planar_layout", 0)) or 2
+        lg_layout = int(params.get("planar_layout", 0)) or (2 if n >= 24576 else 4)  # the pool's own rule
         lg = (args.task in ("HalfCheetah", "Walker2d") and args.precision == "fp64" and lg_layout > 1
               and params.get("frame_stack", 1) == 1)
         kbase = ("AntStepKernel" if args.task == "Ant" else
@@ -245,7 +245,7 @@ def main():
         kname = kbase + ("<double>" if args.precision == "fp64" or fp64_only else "<float>")
         if lg:
             kbase = "PlanarLgStepKernel"
-            kname = f"PlanarLgStepKernel<{lg_layout},{int(params.get('planar_waves', 2))}>"
+            kname = f"PlanarLgStepKernel<{lg_layout},{int(params.get('planar_waves', 1))}>"
         if args.task in ("Walker2d", "Hopper"):
             kname += f"[{args.task}]"
         if args.task == "HumanoidStandup":

@@ -248,6 +248,10 @@ template <int K>
 inline void MaskSet(LU<K>& m, LB<K> on, int bit) {
   for (int i = 0; i < K; ++i) m.v[i] |= (on.v[i] ? 1u : 0u) << bit;
 }
+template <typename T, int K>
+inline void MaskSetNZ(LU<K>& m, const LV<T, K>& w, int bit) {  // bit set where w != 0
+  for (int i = 0; i < K; ++i) m.v[i] |= (w.v[i] != T(0) ? 1u : 0u) << bit;
+}
 template <int K>
 inline LB<K> MaskSame(const LU<K>& a, const LU<K>& b) {
   LB<K> r;
@@ -275,6 +279,18 @@ EPA_HD float Rsq(float x) { return Rsqrt(x); }
 EPA_HD bool AnyWave(bool c) { return WaveAny(c); }
 EPA_HD void MaskSet(unsigned& m, bool on, int bit) { m |= (on ? 1u : 0u) << bit; }
 EPA_HD bool MaskSame(unsigned a, unsigned b) { return a == b; }
+// bit set where w != 0, for a weight that is either +0.0 or a positive normal number: its high word is
+// then zero / non-zero, and min(1, high word) is the bit -- two integer VALU ops, no compare, no
+// lane-mask logic on the scalar unit (the row weights are already selected by `jar < 0` and carry
+// D == 0 for lanes without the contact)
+EPA_HD void MaskSetNZ(unsigned& m, double w, int bit) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned hi = (unsigned)__double2hiint(w);
+  m |= (hi < 1u ? hi : 1u) << bit;
+#else
+  m |= (w != 0.0 ? 1u : 0u) << bit;
+#endif
+}
 template <>
 struct LaneTypes<double> {
   using B = bool;
@@ -628,11 +644,10 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
   static_for<0, 3>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const V jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
-    const auto on = (lim.sgn[j] != V(0)) & (jar < V(0));
-    const V w = Sel(on, lim.D[j], V(0));
+    const V w = Sel(jar < V(0), lim.D[j], V(0));  // lim.D == 0 where the limit is not violated
     gc[j + 3] += lim.sgn[j] * w * jar;
     if constexpr (kHess) Hc[Tri(j + 3, j + 3)] += w;
-    MaskSet(mask, on, j);
+    MaskSetNZ(mask, w, j);
   });
   EPA_NO_UNROLL
   for (unsigned rem = ends; rem != 0; rem &= rem - 1) {  // scalar loop over the touching slots
@@ -658,14 +673,12 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
       const V jar1 = jna - an;
       const V jar2 = jna - mu * jxa - (an + ax);
       const V jar3 = jna + mu * jxa - (an - ax);
-      const auto on = D > V(0);
-      const auto a1 = on & (jar1 < V(0)), a2 = on & (jar2 < V(0)), a3 = on & (jar3 < V(0));
-      const V w1 = Sel(a1, V(2) * D, V(0));
-      const V w2 = Sel(a2, D, V(0));
-      const V w3 = Sel(a3, D, V(0));
-      MaskSet(mask, a1, 3 + 3 * s);
-      MaskSet(mask, a2, 4 + 3 * s);
-      MaskSet(mask, a3, 5 + 3 * s);
+      const V w1 = Sel(jar1 < V(0), V(2) * D, V(0));
+      const V w2 = Sel(jar2 < V(0), D, V(0));
+      const V w3 = Sel(jar3 < V(0), D, V(0));
+      MaskSetNZ(mask, w1, 3 + 3 * s);
+      MaskSetNZ(mask, w2, 4 + 3 * s);
+      MaskSetNZ(mask, w3, 5 + 3 * s);
       const V gn = w1 * jar1 + w2 * jar2 + w3 * jar3;  // coefficient of Jn
       const V gx = mu * (w3 * jar3 - w2 * jar2);      // coefficient of Jx
       const V A = w1 + w2 + w3, Bc = mu * (w3 - w2), C = mu * mu * (w2 + w3);
@@ -696,11 +709,10 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
     const V jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
     const V jv = lim.sgn[j] * s[j + 3];
     const V x = jar + alpha * jv;
-    const auto on = (lim.sgn[j] != V(0)) & (x < V(0));
-    const V w = Sel(on, lim.D[j], V(0));
+    const V w = Sel(x < V(0), lim.D[j], V(0));
     *d1 += w * x * jv;
     *d2 += w * jv * jv;
-    if constexpr (kMask) MaskSet(mask, on, j);
+    if constexpr (kMask) MaskSetNZ(mask, w, j);
   });
   EPA_NO_UNROLL
   for (unsigned rem = ends; rem != 0; rem &= rem - 1) {
@@ -746,10 +758,9 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
     *d1 += c1 * x1 * jv1 + c2 * x2 * jv2 + c3 * x3 * jv3;
     *d2 += c1 * jv1 * jv1 + c2 * jv2 * jv2 + c3 * jv3 * jv3;
     if constexpr (kMask) {
-      const auto on = D > V(0);
-      MaskSet(mask, on & (x1 < V(0)), 3 + 3 * sl);
-      MaskSet(mask, on & (x2 < V(0)), 4 + 3 * sl);
-      MaskSet(mask, on & (x3 < V(0)), 5 + 3 * sl);
+      MaskSetNZ(mask, c1, 3 + 3 * sl);
+      MaskSetNZ(mask, c2, 4 + 3 * sl);
+      MaskSetNZ(mask, c3, 5 + 3 * sl);
     }
   }
 }

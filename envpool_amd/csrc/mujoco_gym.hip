@@ -354,12 +354,20 @@ class CheetahPool : public Pool {
     spread_ = cfg.Get("planar_spread", 1) != 0;  // extension key, see Launch
     // "planar_layout" (extension key): 1 = one env per lane (CheetahStepKernel), 2 / 4 = one env per
     // group of 2 / 4 lanes (mujoco_planar_lg.hip; fp64, HalfCheetah / Walker2d, frame_stack 1),
-    // 0 (default) = chosen per launch from the batch size, see Launch
+    // 0 (default) = chosen HERE from the rows a launch of this pool normally has (batch_size in async
+    // mode, else num_envs): 2 lanes per env from 24576 rows up, 4 below (profiles/r3i_lane_group_sweep.txt:
+    // N = 32768: 2.5e8 vs 2.0e8, N = 16384: 1.3e8 vs 1.7e8).  Fixed per pool, not per launch: the two
+    // layouts sum the contact rows in different orders, and an env's bits must not depend on how
+    // many other envs a particular send happens to carry.
     layout_ = (int)cfg.Get("planar_layout", 0);
     if (layout_ != 0 && layout_ != 1 && layout_ != 2 && layout_ != 4) {
       throw std::invalid_argument("planar_layout must be 0, 1, 2 or 4");
     }
     lg_ok_ = fp64_ && !hopper && task_.frame_stack == 1;
+    if (layout_ == 0) {
+      const int rows = (cfg.batch_size > 0 && cfg.batch_size < cfg.num_envs) ? cfg.batch_size : cfg.num_envs;
+      layout_ = rows >= 24576 ? 2 : 4;
+    }
     // register budget of the lane-group kernel: one wave per SIMD with all 512 registers (default;
     // measured faster at every batch size, profiles/r3f_lane_group_sweep.txt) or two with 256 + spills
     lg_waves_ = (int)cfg.Get("planar_waves", 1) == 2 ? 2 : 1;
@@ -429,7 +437,6 @@ class CheetahPool : public Pool {
     // SLOWER (N = 8192 as 512 waves of 16: 0.26 ms against 0.21 ms as 128 full waves).
     // One env per lane group (mj_planar_lg.hip.h) wherever it applies.
     int layout = lg_ok_ && trace_.d == nullptr ? layout_ : 1;
-    if (layout == 0) layout = 2;
     if (layout > 1) {
       Ticket& tk = tickets_[stream_];  // launches on different streams run concurrently: a queue each
       if (tk.d == nullptr) {
