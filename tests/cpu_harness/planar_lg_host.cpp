@@ -2,6 +2,7 @@
 // (envpool_amd/csrc/mj_planar_lg.hip.h) with g++, the KL lanes of one env emulated by LV<double, KL>,
 // so the exact kernel source can be diffed against oracle/mjcpu and against the one-env-per-lane
 // formulation (mj_cheetah.hip.h) on a CPU box.  Nothing in envpool_amd/ links or loads this.
+#include <cstdlib>
 #include <cstring>
 
 #include "../../envpool_amd/csrc/mj_cheetah_model.h"
@@ -37,6 +38,7 @@ static int Run(int model, const double* q, const double* v, const double* warm, 
   HostCx<KL> cx;
   cx.tab = tab;
   plg::SolverCfgLg<double> cfg{50, 1e-13};
+  if (const char* g = getenv("EPA_LG_GTOL")) cfg.gtol = atof(g);  // experiments with the stopping rule
   V lq[plg::kLV], lv[plg::kLV], lw[plg::kLV], lc[3];
   const double x0 = q[0];
   for (int c = 0; c < KL; ++c) {
