@@ -387,6 +387,7 @@ const FamilyInfo* Find(const std::string& name) {
 template <int KIND>
 class ClassicPool : public Pool {
  public:
+  bool ConcurrentSafe() const override { return true; }  // per-env state + the launch's own block only
   ClassicPool(const Config& cfg, const FamilyInfo& fi)
       : Pool(cfg, fi.keys, fi.action, /*needs_rng=*/true),
         version_((int)cfg.Get("version", 0)) {

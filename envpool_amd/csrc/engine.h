@@ -151,6 +151,11 @@ class Pool {
   void SetTiming(int mode);  // 0 off, 1 an event pair around every launch, 2 one pair around the whole window
   void KernelTime(double* avg_ms, int* launches);
 
+  // May launches of this family run concurrently on several streams (async mode)?  True only if
+  // a launch touches nothing but the per-env state of ITS rows and its own result block: no
+  // per-launch scratch shared through the pool (the Humanoid kernels' HBM workspace and sort
+  // buffer are indexed by the wave of the launch: they say no and keep one compute stream).
+  virtual bool ConcurrentSafe() const { return false; }
   virtual int StateDim() const = 0;
   // family hooks: flat double state <-> device SoA, for the listed local ids
   virtual void GetState(const int* d_ids, int k, double* d_out) = 0;

@@ -397,7 +397,12 @@ void Pool::SyncCompute() {
 void Pool::PickStream(const int32_t* host_ids, int k, bool device_path, const void* d_env_id) {
   next_host_ids_ = nullptr;
   next_identity_ = false;
-  if (compute_.size() < 2) return;
+  // one stream for families with per-launch scratch, and while the generic observation stack is on
+  // (its un-stacked frame buffer is indexed by the row of the launch)
+  if (compute_.size() < 2 || !ConcurrentSafe() || stack_s_ > 1) {
+    picked_ = false;
+    return;
+  }
   Batch* cont = nullptr;  // the handed-out batch this send continues
   if (device_path && d_env_id != nullptr) {
     const char* p = static_cast<const char*>(d_env_id);
@@ -568,7 +573,7 @@ void Pool::WaitStream(hipStream_t producer) {
   EPA_HIP(hipSetDevice(cfg_.device));
   if (!order_ev_) EPA_HIP(hipEventCreateWithFlags(&order_ev_, hipEventDisableTiming));
   EPA_HIP(hipEventRecord(order_ev_, producer));
-  if (compute_.size() > 1 && !picked_) {  // the stream the NEXT launch will use
+  if (compute_.size() > 1 && !picked_ && ConcurrentSafe() && stack_s_ == 1) {  // the stream the NEXT launch will use
     rr_ = (rr_ + 1) % compute_.size();
     stream_ = compute_[rr_];
     picked_ = true;

@@ -358,6 +358,7 @@ std::vector<KeySpec> AntKeys(const Config& cfg) {
 
 class AntPool : public Pool {
  public:
+  bool ConcurrentSafe() const override { return true; }  // per-env state + the launch's own block only
   explicit AntPool(const Config& cfg)
       : Pool(cfg, AntKeys(cfg), KeySpec{"action", EPA_F64, {A::kNU}}, true) {
     task_.use_contact_force = cfg.Get("use_contact_force", 0) != 0;

@@ -307,6 +307,7 @@ std::vector<KeySpec> CheetahKeys(const Config& cfg, bool walker = false, bool ho
 
 class CheetahPool : public Pool {
  public:
+  bool ConcurrentSafe() const override { return true; }  // per-env state + the launch's own block only
   // model: mj::kPlanarCheetah / kPlanarWalker / kPlanarWalkerV5 / kPlanarHopper
   CheetahPool(const Config& cfg, int model)
       : Pool(cfg, CheetahKeys(cfg, model != mj::kPlanarCheetah, model == mj::kPlanarHopper),
@@ -362,6 +363,13 @@ class CheetahPool : public Pool {
     layout_ = (int)cfg.Get("planar_layout", 0);
     if (layout_ != 0 && layout_ != 1 && layout_ != 2 && layout_ != 4) {
       throw std::invalid_argument("planar_layout must be 0, 1, 2 or 4");
+    }
+    // frame_stack > 1 on the fp64 two-legged models: the generic ring of the engine (EnableObsStack; the
+    // kernels then write one frame per row), so that stacked and plain pools run the same step kernel
+    // and agree bit for bit; the other configurations keep this file's in-kernel ring (dev_.stack)
+    if (task_.frame_stack > 1 && fp64_ && !hopper) {
+      EnableObsStack();
+      task_.frame_stack = 1;
     }
     lg_ok_ = fp64_ && !hopper && task_.frame_stack == 1;
     if (layout_ == 0) {

@@ -352,6 +352,7 @@ std::vector<KeySpec> ReacherKeys(const Config& cfg) {  // reacher.h:44-60
 
 class ReacherPool : public Pool {
  public:
+  bool ConcurrentSafe() const override { return true; }  // per-env state + the launch's own block only
   explicit ReacherPool(const Config& cfg)
       : Pool(cfg, ReacherKeys(cfg), KeySpec{"action", EPA_F64, {2}}, /*needs_rng=*/true) {
     EnableObsStack();
@@ -511,6 +512,7 @@ int PendObsDim(const Config& cfg, int nl) {
 template <int NL>
 class PendPool : public Pool {
  public:
+  bool ConcurrentSafe() const override { return true; }  // per-env state + the launch's own block only
   static constexpr int NV = NL + 1;
   explicit PendPool(const Config& cfg)
       : Pool(cfg, {{"obs", EPA_F64, StackedObsShape(cfg, PendObsDim(cfg, NL))}},
@@ -585,6 +587,7 @@ class PendPool : public Pool {
 
 class SwimmerPool : public Pool {
  public:
+  bool ConcurrentSafe() const override { return true; }  // per-env state + the launch's own block only
   static constexpr int NV = 5;
   explicit SwimmerPool(const Config& cfg)
       : Pool(cfg, SwimmerKeys(cfg), KeySpec{"action", EPA_F64, {2}}, /*needs_rng=*/true) {

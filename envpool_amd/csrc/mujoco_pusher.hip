@@ -202,6 +202,7 @@ std::vector<KeySpec> PusherKeys(const Config& cfg) {  // pusher.h:47-60
 
 class PusherPool : public Pool {
  public:
+  bool ConcurrentSafe() const override { return true; }  // per-env state + the launch's own block only
   explicit PusherPool(const Config& cfg)
       : Pool(cfg, PusherKeys(cfg), KeySpec{"action", EPA_F64, {PU::kNL}}, /*needs_rng=*/true) {
     EnableObsStack();

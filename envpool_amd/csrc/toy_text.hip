@@ -403,6 +403,7 @@ std::vector<KeySpec> EnvKeys(int kind, const ToyCfg& c) {
 template <int KIND>
 class ToyPool : public Pool {
  public:
+  bool ConcurrentSafe() const override { return true; }  // per-env state + the launch's own block only
   explicit ToyPool(const Config& cfg)
       : Pool(cfg, EnvKeys(KIND, MakeCfg(cfg)), KeySpec{"action", EPA_I32, {}},
              /*needs_rng=*/true),
