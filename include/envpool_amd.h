@@ -62,7 +62,24 @@ typedef struct epa_pool epa_pool;
  *                 per SIMD is spread over all SIMDs with 16 / 32 / 48 envs per wave; 0 always 64 envs per wave
  *   "hum_layout"  Humanoid / HumanoidStandup: 1 one env per lane quad (default), 0 one env per lane
  *   "hum_sort"    quad layout: 1 cost-sorted waves (default), 0 rows in send order
- *   "hum_debug"   quad layout, timing runs only: stages switched off / solver statistics
+ *   "hum_debug"   quad layout: stages switched off / solver statistics; accepted by the diagnostic
+ *                 build only (tools/build_trace_lib.sh), the product library refuses it
+ *   "planar_layout" HalfCheetah / Walker2d, fp64: lanes per env of the step kernel -- 2 or 4 (one env per
+ *                 lane group, mujoco_planar_lg.hip), 1 (one env per lane, mujoco_gym.hip), 0 (default)
+ *                 chosen once per pool: 2 from 24576 rows per launch up, else 4
+ *   "planar_waves" lane-group kernel: register budget for 1 (default) or 2 waves per SIMD
+ *   "planar_lpt"  lane-group kernel: 1 (default) whole-pool launches serve the chunks of envs slowest
+ *                 first, by their duration in the previous launch; 0 index order.  Never changes results.
+ *   "compute_streams" async mode (batch_size < num_envs): successive batches run on this many
+ *                 compute streams (default 4, 1 = one stream), like the reference's worker threads
+ *                 step all queued slices in parallel (core/async_envpool.h:116-132).  Families whose
+ *                 kernels share per-launch scratch (Humanoid*) and pools with the generic frame stack
+ *                 keep one stream.  The rule for the caller is the reference's: an env may be sent
+ *                 again only after recv handed it out (host path: a violation is detected and that
+ *                 launch is ordered behind everything enqueued; device path: the env ids of a send
+ *                 should be the `info:env_id` array of a batch recv_device returned -- the launch then
+ *                 continues that batch's stream -- any other pointer is ordered behind every batch
+ *                 still executing).
  */
 typedef struct epa_config {
   int32_t num_envs;          /* common_config "num_envs" */
