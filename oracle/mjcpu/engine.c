@@ -360,53 +360,44 @@ static double capcyl_g(const double* p0, const double* dp, double t, const doubl
   }
   return g;
 }
-static void add_capsule_cylinder(const mjc_model* m, mjc_data* d, int g1, int g2, double margin) {
-  const double* cm1 = d->geom_xmat[g1];
-  const double* cm2 = d->geom_xmat[g2];
-  double a1[3] = {cm1[2], cm1[5], cm1[8]}, u[3] = {cm2[2], cm2[5], cm2[8]};
-  double hl = m->geom_size[g1][1], rc = m->geom_size[g1][0];
-  double R = m->geom_size[g2][0], H = m->geom_size[g2][1];
-  double p0[3], dp[3];
-  for (int k = 0; k < 3; ++k) {
-    p0[k] = d->geom_xpos[g1][k] - hl * a1[k];
-    dp[k] = 2 * hl * a1[k];
-  }
-  const double eps = 1e-10 * 4 * hl * hl;
+/* the geometric part: capsule axis segment p0 + t dp (t in [0, 1]), radius rc, against the solid
+ * cylinder (centre c, unit axis u, radius R, half height H).  Returns the distance between the
+ * surfaces; pos = contact point, n = unit normal from the capsule to the cylinder. */
+static double capcyl_contact(const double* p0, const double* dp, double rc, const double* cc,
+                             const double* u, double R, double H, double* pos, double* n) {
+  const double eps = 1e-10 * v3_dot(dp, dp);
   double lo = 0, hi = 1; /* ta: largest t with g < -eps */
-  if (capcyl_g(p0, dp, 0, d->geom_xpos[g2], u, R, H, NULL, NULL) >= -eps) {
+  if (capcyl_g(p0, dp, 0, cc, u, R, H, NULL, NULL) >= -eps) {
     hi = 0;
-  } else if (capcyl_g(p0, dp, 1, d->geom_xpos[g2], u, R, H, NULL, NULL) < -eps) {
+  } else if (capcyl_g(p0, dp, 1, cc, u, R, H, NULL, NULL) < -eps) {
     lo = 1;
   } else {
     for (int it = 0; it < 48; ++it) {
       double mid = 0.5 * (lo + hi);
-      if (capcyl_g(p0, dp, mid, d->geom_xpos[g2], u, R, H, NULL, NULL) < -eps) lo = mid; else hi = mid;
+      if (capcyl_g(p0, dp, mid, cc, u, R, H, NULL, NULL) < -eps) lo = mid; else hi = mid;
     }
   }
   const double ta = lo <= 0 && hi <= 0 ? 0 : (lo >= 1 ? 1 : 0.5 * (lo + hi));
   lo = 0;
   hi = 1; /* tb: smallest t with g > +eps */
-  if (capcyl_g(p0, dp, 1, d->geom_xpos[g2], u, R, H, NULL, NULL) <= eps) {
+  if (capcyl_g(p0, dp, 1, cc, u, R, H, NULL, NULL) <= eps) {
     lo = 1;
-  } else if (capcyl_g(p0, dp, 0, d->geom_xpos[g2], u, R, H, NULL, NULL) > eps) {
+  } else if (capcyl_g(p0, dp, 0, cc, u, R, H, NULL, NULL) > eps) {
     hi = 0;
   } else {
     for (int it = 0; it < 48; ++it) {
       double mid = 0.5 * (lo + hi);
-      if (capcyl_g(p0, dp, mid, d->geom_xpos[g2], u, R, H, NULL, NULL) > eps) hi = mid; else lo = mid;
+      if (capcyl_g(p0, dp, mid, cc, u, R, H, NULL, NULL) > eps) hi = mid; else lo = mid;
     }
   }
   const double tb = hi <= 0 ? 0 : (lo >= 1 && hi >= 1 ? 1 : 0.5 * (lo + hi));
-  double t = 0.5 * (ta + tb), P[3], Q[3], n[3];
-  capcyl_g(p0, dp, t, d->geom_xpos[g2], u, R, H, P, Q);
+  double t = 0.5 * (ta + tb), P[3], Q[3];
+  capcyl_g(p0, dp, t, cc, u, R, H, P, Q);
   v3_sub(n, Q, P);
   double cd = v3_norm(n);
-  if (cd - rc > margin) return;
-  if (d->ncon >= MJC_MAXCON) return;
-  mjc_contact* c = &d->contact[d->ncon++];
   if (cd < 1e-12) { /* the axis itself is inside the solid: push out radially */
     double rel[3];
-    v3_sub(rel, P, d->geom_xpos[g2]);
+    v3_sub(rel, P, cc);
     double z = v3_dot(rel, u);
     for (int k = 0; k < 3; ++k) n[k] = -(rel[k] - z * u[k]);
     if (v3_norm(n) < 1e-12) {
@@ -418,10 +409,37 @@ static void add_capsule_cylinder(const mjc_model* m, mjc_data* d, int g1, int g2
   } else {
     for (int k = 0; k < 3; ++k) n[k] /= cd;
   }
-  c->dist = cd - rc;
+  const double dist = cd - rc;
+  for (int k = 0; k < 3; ++k) pos[k] = P[k] + n[k] * (rc + 0.5 * dist);
+  return dist;
+}
+/* test hook (tests/test_mjcpu_invariants.py): the rule above on raw geometry, cylinder axis +z */
+void mjcpu_capsule_cylinder(const double* p0, const double* p1, double rc, const double* cc, double R,
+                            double H, double* out7) {
+  const double u[3] = {0, 0, 1};
+  double dp[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+  out7[0] = capcyl_contact(p0, dp, rc, cc, u, R, H, out7 + 1, out7 + 4);
+}
+static void add_capsule_cylinder(const mjc_model* m, mjc_data* d, int g1, int g2, double margin) {
+  const double* cm1 = d->geom_xmat[g1];
+  const double* cm2 = d->geom_xmat[g2];
+  double a1[3] = {cm1[2], cm1[5], cm1[8]}, u[3] = {cm2[2], cm2[5], cm2[8]};
+  double hl = m->geom_size[g1][1], rc = m->geom_size[g1][0];
+  double R = m->geom_size[g2][0], H = m->geom_size[g2][1];
+  double p0[3], dp[3];
+  for (int k = 0; k < 3; ++k) {
+    p0[k] = d->geom_xpos[g1][k] - hl * a1[k];
+    dp[k] = 2 * hl * a1[k];
+  }
+  double pos[3], n[3];
+  const double dist = capcyl_contact(p0, dp, rc, d->geom_xpos[g2], u, R, H, pos, n);
+  if (dist > margin) return;
+  if (d->ncon >= MJC_MAXCON) return;
+  mjc_contact* c = &d->contact[d->ncon++];
+  c->dist = dist;
   for (int k = 0; k < 3; ++k) {
     c->frame[k] = n[k];
-    c->pos[k] = P[k] + n[k] * (rc + 0.5 * c->dist);
+    c->pos[k] = pos[k];
   }
   make_frame(c->frame);
   contact_params(m, c, g1, g2, margin);

@@ -37,6 +37,16 @@ void pusher_host_step(const double* q, const double* v, const double* warm, cons
   lag[4] = lg.obj[1];
   *iters = it;
 }
+// the product's capsule - cylinder rule on raw geometry: out = dist, pos(3), normal(3)
+void pusher_host_capcyl(const double* p0, const double* p1, double rc, const double* c, double R, double H,
+                        double* out7) {
+  using V = epa::mj::ant::Vec3<double>;
+  const CapCyl<double> r = CapsuleCylinder<double>(V{p0[0], p0[1], p0[2]}, V{p1[0], p1[1], p1[2]}, rc,
+                                                   V{c[0], c[1], c[2]}, R, H);
+  out7[0] = r.dist;
+  out7[1] = r.pos.x; out7[2] = r.pos.y; out7[3] = r.pos.z;
+  out7[4] = r.n.x; out7[5] = r.n.y; out7[6] = r.n.z;
+}
 // [mass(7) dof_invw(7) wrist_invw obj_invw obj_mass]
 void pusher_host_model(int v5, double* out) {
   const PusherModel<double> m = BuildPusherModel(v5 != 0);

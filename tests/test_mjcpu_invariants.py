@@ -641,3 +641,65 @@ def test_product_planar_lane_group_code_matches_oracle_on_cpu():
                         Lo.cheetah_host_step(*args, 5, 0, *outs, ctypes.byref(it2))
                     worst_lane = max(worst_lane, np.abs(qo - q2).max(), np.abs(vo - v2).max())
             assert worst < 1e-9 and worst_lane < 1e-9, (task, kl, worst, worst_lane)
+
+
+def test_pusher_capsule_cylinder_rule_in_the_degenerate_poses():
+    """Pusher's wrist capsule vs the object's cylinder goes through MuJoCo's convex collider; product
+    (mj_pusher.hip.h::CapsuleCylinder) and oracle (oracle/mjcpu/engine.c::capcyl_contact) restate it as the
+    closest points between the capsule's axis segment and the solid cylinder, with the MIDPOINT of the
+    closest stretch when the minimiser is not unique.  The two independently written routines must agree
+    everywhere -- in general position and exactly in the tie cases (axis parallel to the cylinder's side,
+    to a flat face, along its axis, inside the solid) -- and the tie cases must obey the stated rule.
+    PARITY NOTE: this pins product == oracle only.  How MuJoCo's GJK / EPA resolves a non-unique closest
+    pair (and its 1e-6 tolerance) is not pinned by anything here (no MuJoCo wheel)."""
+    import ctypes
+
+    from oracle import orc
+
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    csrc = os.path.join(ROOT, "envpool_amd", "csrc")
+    so, src = os.path.join(h, "libpusher_host.so"), os.path.join(h, "pusher_host.cpp")
+    deps = [src, os.path.join(csrc, "mj_pusher.hip.h"), os.path.join(csrc, "mj_pusher_model.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    P = ctypes.CDLL(so)
+    O = ctypes.CDLL(orc.PORT_LIB)
+    vp, dbl = ctypes.c_void_p, ctypes.c_double
+    for f in (P.pusher_host_capcyl, O.mjcpu_capsule_cylinder):
+        f.argtypes = [vp, vp, dbl, vp, dbl, dbl, vp]
+        f.restype = None
+
+    def both(p0, p1, rc, c, R, H):
+        outs = []
+        for f in (P.pusher_host_capcyl, O.mjcpu_capsule_cylinder):
+            a, b, cc, o = (np.ascontiguousarray(x, dtype=np.float64) for x in (p0, p1, c, np.zeros(7)))
+            f(a.ctypes.data, b.ctypes.data, rc, cc.ctypes.data, R, H, o.ctypes.data)
+            outs.append(o)
+        np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=1e-12, err_msg=f"{p0} {p1}")
+        return outs[0]
+
+    R, H, rc, c = 0.05, 0.05, 0.02, np.array([0.45, -0.05, -0.275])
+    rng = np.random.default_rng(0)
+    for _ in range(2000):  # general position, all regions (beside, above, diagonal, penetrating)
+        p0 = c + rng.uniform(-0.2, 0.2, 3)
+        p1 = p0 + rng.uniform(-0.12, 0.12, 3)
+        o = both(p0, p1, rc, c, R, H)
+        assert abs(np.linalg.norm(o[4:7]) - 1) < 1e-12
+    # axis parallel to the cylinder's axis, beside it, overlapping in z over [-0.03, 0.05]:
+    # every point of the overlap is closest -> its midpoint z = 0.01, normal radial
+    o = both(c + [0.1, 0, -0.03], c + [0.1, 0, 0.09], rc, c, R, H)
+    np.testing.assert_allclose(o[0], 0.1 - R - rc, atol=1e-12)
+    np.testing.assert_allclose(o[4:7], [-1, 0, 0], atol=1e-12)
+    np.testing.assert_allclose(o[3] - c[2], 0.01, atol=1e-9)
+    # axis parallel to the top face, above it, crossing the whole disc: midpoint of the chord over the disc
+    o = both(c + [-0.2, 0.01, 0.09], c + [0.2, 0.01, 0.09], rc, c, R, H)
+    np.testing.assert_allclose(o[0], 0.04 - rc, atol=1e-12)
+    np.testing.assert_allclose(o[4:7], [0, 0, -1], atol=1e-12)
+    np.testing.assert_allclose(o[1:3] - c[:2], [0.0, 0.01], atol=1e-9)
+    # along the cylinder's own axis, above it: the lower end is closest (unique)
+    o = both(c + [0, 0, 0.08], c + [0, 0, 0.2], rc, c, R, H)
+    np.testing.assert_allclose(o[0], 0.03 - rc, atol=1e-12)
+    # axis inside the solid: pushed out radially, surfaces "distance" = -rc
+    o = both(c + [0.01, 0, -0.01], c + [0.02, 0, 0.01], rc, c, R, H)
+    np.testing.assert_allclose(o[0], -rc, atol=1e-12)
+    np.testing.assert_allclose(o[4:7], [-1, 0, 0], atol=1e-9)
