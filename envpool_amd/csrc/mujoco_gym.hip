@@ -455,9 +455,9 @@ class CheetahPool : public Pool {
       // from launch to launch); "planar_lpt" = 0 switches it off (A/B)
       planar::LgOrder lo;
       if (lpt_ && d_ids == nullptr && !force_reset) {
-        const int per = kCheetahBlock / layout, nchunks = (k + per - 1) / per;
+        const int nchunks = k;  // (only its sameness from launch to launch matters here)
         if (order_.d == nullptr) {
-          order_.cap = (cfg_.num_envs + 15) / 16;
+          order_.cap = (cfg_.num_envs + 3) / 4;  // the smallest chunk is a quarter wave of 4 lanes per env
           EPA_HIP(hipMalloc(&order_.d, PlanarLgOrderBytes(order_.cap)));
           EPA_HIP(hipMemsetAsync(order_.d, 0, PlanarLgOrderBytes(order_.cap), stream_));
           order_.gen = 0;
@@ -472,7 +472,7 @@ class CheetahPool : public Pool {
       } else {
         order_shape_ = -1;  // the chain of same-shape launches is broken
       }
-      PlanarLgLaunch(stream_, layout, lg_waves_, model_id_, wave_slots_, dev_, common_, a,
+      PlanarLgLaunch(stream_, layout, lg_waves_, model_id_, wave_slots_, spread_, dev_, common_, a,
                      static_cast<const double*>(d_action), out, task_, d_tab_[layout == 2 ? 0 : 1], tk.d, &tk.base, lo);
       return;
     }

@@ -76,7 +76,9 @@ struct LgOrder {
 // waves = 1 or 2: the kernel variant whose register allocation aims at that many waves per SIMD
 // `wave_slots`: SIMDs of the device; `ticket` / `ticket_base`: the chunk queue's device counter and the
 // host's copy of its value (one pair per stream that launches concurrently, see PlanarLgStepKernel)
-void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots, const planar::CheetahDev& dev,
+// spread: partly filled waves while there are fewer full chunks than resident waves ("planar_spread")
+void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots, bool spread,
+                    const planar::CheetahDev& dev,
                     const CommonDev& cm, const StepArgs& a, const double* action, const OutPtrs& out,
                     const planar::CheetahTask& task, const double* tab, unsigned* ticket, unsigned* ticket_base,
                     const planar::LgOrder& order);

@@ -57,6 +57,7 @@ struct LgArgs {
   unsigned* ticket;
   unsigned ticket_base;
   int nchunks;
+  int per;  // envs per chunk: 64 / KL, or fewer (partly filled waves) while that still gives every SIMD a chunk
   // longest-chunk-first dispatch (see PlanarLgStepKernel): three generations of
   // {cnt[kLptBuckets], sum, n, list[kLptBuckets][lpt_cap]}; this launch reads generation lpt_gen % 3
   // (if lpt_use), fills (lpt_gen + 1) % 3 and clears (lpt_gen + 2) % 3.  nullptr: off.
@@ -102,8 +103,8 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
   const int leg = G::Leg(c);
   const bool first = c == 0;                  // env-level work
   const bool leg_first = G::Par(c) == 0;      // leg-level outputs
-  const int row = chunk * (kBlock / KL) + (lane / KL);
-  if (row >= a.k) return;
+  const int row = chunk * ap->per + (lane / KL);
+  if (lane / KL >= ap->per || row >= a.k) return;
   const int e = a.ids ? a.ids[row] - a.id_offset : row;
   bool done = cm.done[e] != 0;
   int cur = cm.cur_step[e];
@@ -323,19 +324,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(W, W))) 
 }
 
 template <int KL, int W>
-void LaunchKl(hipStream_t st, int model, int wave_slots, const CheetahDev& dev, const CommonDev& cm,
+void LaunchKl(hipStream_t st, int model, int wave_slots, bool spread, const CheetahDev& dev, const CommonDev& cm,
               const StepArgs& a, const double* action, const OutPtrs& out, const CheetahTask& task,
               const double* tab, unsigned* ticket, unsigned* ticket_base, const planar::LgOrder& lo) {
-  const int per = kBlock / KL;
+  // waves resident at once: W per SIMD by registers (LDS allows no more than one at KL = 2)
+  const int resident = wave_slots * ((KL == 2 || W == 1) ? 1 : 2);
+  // A wave runs as long as its slowest env and visits the union of its envs' touching slots: while
+  // there are fewer full chunks than resident waves, smaller chunks (partly filled waves) on more
+  // SIMDs are faster (N = 8192 at 4 lanes per env: 512 waves of 16 envs 95 us, 1024 waves of 8 envs
+  // 90 us; N = 12288 as 12 per wave: 96 -> 93 us; profiles/r3l_lane_group_spread_ab.txt).  Half, three
+  // quarters or all of a wave: quarter-filled waves measured SLOWER (N = 2048: 87 -> 112 us).
+  const int full = kBlock / KL, q = full / 4;
+  int per = ((a.k + resident - 1) / resident + q - 1) / q * q;
+  per = per < full / 2 ? full / 2 : (per > full ? full : per);
+  if (!spread) per = full;
   const int nchunks = (a.k + per - 1) / per;
-  // waves resident at once: W per SIMD by registers; LDS (ends + table) allows 7 waves per CU at KL = 2
-  int resident = wave_slots * W;
-  if (KL == 2 && W == 2) resident = wave_slots / 4 * 7;
   const int blocks = nchunks < resident ? nchunks : resident;
   const unsigned base = *ticket_base;
   *ticket_base = base + (unsigned)nchunks;  // see PlanarLgStepKernel
   const LgArgs args{dev, cm, a, action, out, task, plg::SolverCfgLg<double>{50, 1e-13}, tab, ticket, base, nchunks,
-                    lo.d, lo.cap, lo.gen, lo.use};
+                    per, lo.d, lo.cap, lo.gen, lo.use};
   switch (model) {
     case mj::kPlanarCheetah:
       hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarCheetah, W>), dim3(blocks), dim3(kBlock), 0, st, args);
@@ -351,11 +359,13 @@ void LaunchKl(hipStream_t st, int model, int wave_slots, const CheetahDev& dev, 
 
 }  // namespace
 
-void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots, const planar::CheetahDev& dev,
+void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots, bool spread,
+                    const planar::CheetahDev& dev,
                     const CommonDev& cm, const StepArgs& a, const double* action, const OutPtrs& out,
                     const planar::CheetahTask& task, const double* tab, unsigned* ticket, unsigned* ticket_base,
                     const planar::LgOrder& lo) {
-#define EPA_LG(KL, W) LaunchKl<KL, W>(st, model, wave_slots, dev, cm, a, action, out, task, tab, ticket, ticket_base, lo)
+#define EPA_LG(KL, W) \
+  LaunchKl<KL, W>(st, model, wave_slots, spread, dev, cm, a, action, out, task, tab, ticket, ticket_base, lo)
   if (kl == 2) {
     if (waves == 1) {
       EPA_LG(2, 1);

@@ -27,3 +27,21 @@ def _build_port_oracle():
     subprocess.run(
         ["make", "-s", "-C", os.path.join(ROOT, "oracle"), "port"], check=True
     )
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_runtime_first():
+    """On a GPU box, initialise torch's HIP runtime BEFORE the product library's.  The torch wheel
+    bundles its own ROCm runtime; libenvpool_amd.so links the system one.  Both work in one process
+    (the device-path tests rely on it), but a torch runtime that comes up late -- after the other
+    one has created and destroyed dozens of pools with six streams each -- was once refused its
+    devices ("No HIP GPUs are available", profiles/r3l_*): the order is made deterministic here."""
+    if not os.path.exists("/dev/kfd"):
+        return
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # no torch / no device: the tests that need them skip or fail on their own
+        pass
