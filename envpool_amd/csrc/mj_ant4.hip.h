@@ -359,18 +359,23 @@ EPA_HD void RowsPass(const AntModel<T>& m, const Leg<V, B>& lg, const G& g, unsi
   *mask = m0;
 }
 
-// lane-partial first / second derivative of the constraint cost along s at step alpha
-template <typename T, typename V, typename B, typename G>
+// lane-partial first / second derivative of the constraint cost along s at step alpha; kMask: also
+// the lane's active-row mask AT a + alpha s (the bits of RowsPass)
+template <bool kMask, typename T, typename V, typename B, typename U, typename G>
 EPA_HD void LineEval(const AntModel<T>& m, const Leg<V, B>& lg, const G& g, unsigned sph,
-                     const Rows<V>& r, const V* v, const V* a, const V* s, V alpha, V* d1, V* d2) {
+                     const Rows<V>& r, const V* v, const V* a, const V* s, V alpha, V* d1, V* d2,
+                     U* mask) {
+  U m1 = MaskFill(*mask, 0u);
   static_for<0, 2>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const V jar = r.sgn[j] * a[6 + j] - r.aref[j];
     const V jv = r.sgn[j] * s[6 + j];
     const V x = jar + alpha * jv;
-    const V w = Sel((r.sgn[j] != V(0)) & (x < V(0)), r.D[j], V(0));
+    const B on = (r.sgn[j] != V(0)) & (x < V(0));
+    const V w = Sel(on, r.D[j], V(0));
     *d1 += w * x * jv;
     *d2 += w * jv * jv;
+    if constexpr (kMask) MaskSet(m1, on, j);
   });
   EPA_ANT4_NO_UNROLL
   for (unsigned rem = sph; rem != 0; rem &= rem - 1) {
@@ -392,9 +397,11 @@ EPA_HD void LineEval(const AntModel<T>& m, const Leg<V, B>& lg, const G& g, unsi
         const V wt = Sel(x < V(0), c.D, V(0));  // D == 0 on lanes without contact
         *d1 += wt * x * jv[k];
         *d2 += wt * jv[k] * jv[k];
+        if constexpr (kMask) MaskSet(m1, (c.D > V(0)) & (x < V(0)), 2 + 4 * w + k);
       });
     });
   }
+  if constexpr (kMask) *mask = m1;
 }
 
 // y = M x for the arrow-structured M held as the lane-local packed 8x8 in LDS
@@ -540,12 +547,24 @@ EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned
     full_step = V(0) > V(0);
     const V ls_tol = V(sizeof(T) == 4 ? T(1e-4) : T(1e-10)) * Abs(g1);
     B searching = live;
+    B exact = V(0) > V(0);
     for (int ls = 0; ls < 24; ++ls) {
       V p1 = V(0), p2 = V(0);
-      LineEval(m, lg, g, sph, r, v, qacc, s, alpha, &p1, &p2);
+      U m1 = MaskFill(U(), 0u);
+      if (ls == 0) {
+        LineEval<true>(m, lg, g, sph, r, v, qacc, s, alpha, &p1, &p2, &m1);
+      } else {
+        LineEval<false>(m, lg, g, sph, r, v, qacc, s, alpha, &p1, &p2, &m1);
+      }
       const V d1 = g1 + alpha * g2 + Sum4(p1), d2 = g2 + Sum4(p2);
       const B hit = Abs(d1) <= ls_tol;
-      if (ls == 0) full_step = searching & hit;
+      // a full Newton step whose active set at a + s is the one H was built with lands ON the
+      // minimiser (finite termination): the env is done without another pass over the rows -- the
+      // pass that would only have found `full_step & same` at the top of the next iteration
+      if (ls == 0) {
+        full_step = searching & hit;
+        exact = full_step & All4(MaskSame(m1, m0));
+      }
       searching = searching & !hit;
       lo = Sel(searching & (d1 < V(0)), alpha, lo);
       hi = Sel(searching & !(d1 < V(0)), alpha, hi);
@@ -562,6 +581,8 @@ EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned
       qacc[i] += step * s[i];
       res[i] += step * Ms[i];
     });
+    live = live & !exact;
+    if (!AnyWave(live)) break;
   }
 }
 

@@ -467,29 +467,37 @@ EPA_HD int PusherForward(const PusherModel<T>& m, const SolverCfg<T>& cfg, const
     full_step = false;
     const T ag1 = g1 < T(0) ? -g1 : g1;
     const T ls_tol = T(1e-10) * ag1;
-    bool searching = live;
+    bool searching = live, exact = false;
     for (int ls = 0; ls < 24; ++ls) {
       T d1 = g1 + alpha * g2, d2 = g2;
+      unsigned mask1 = 0;  // the rows active at qacc + alpha s (the bits of `mask`)
       static_for<0, kNL>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const T jar = lsgn[j] * qacc[j] - laref[j], jv = lsgn[j] * s[j];
         const T xx = jar + alpha * jv;
-        const T w = (lsgn[j] != T(0) && xx < T(0)) ? lD[j] : T(0);
+        const bool on = lsgn[j] != T(0) && xx < T(0);
+        const T w = on ? lD[j] : T(0);
         d1 += w * xx * jv;
         d2 += w * jv * jv;
+        mask1 |= (on ? 1u : 0u) << j;
       });
       if (wave_contact) {
         static_for<0, kNCon>([&](auto rc) {
           constexpr int r = decltype(rc)::value;
           const T xx = cjar[r] + alpha * cjv[r];
-          const T w = xx < T(0) ? rows[r].D : T(0);
+          const bool on = rows[r].D > T(0) && xx < T(0);
+          const T w = on ? rows[r].D : T(0);
           d1 += w * xx * cjv[r];
           d2 += w * cjv[r] * cjv[r];
+          mask1 |= (on ? 1u : 0u) << (kNL + r);
         });
       }
       const T ad1 = d1 < T(0) ? -d1 : d1;
       const bool hit = ad1 <= ls_tol;
       full_step = full_step || (searching && hit && ls == 0);
+      // finite termination: the full Newton step keeps the active set H was built with, so it lands
+      // on the minimiser; no further pass over the rows is needed to find that out
+      exact = exact || (searching && hit && ls == 0 && mask1 == mask);
       searching = searching && !hit;
       lo = (searching && d1 < T(0)) ? alpha : lo;
       hi = (searching && !(d1 < T(0))) ? alpha : hi;
@@ -502,6 +510,8 @@ EPA_HD int PusherForward(const PusherModel<T>& m, const SolverCfg<T>& cfg, const
     }
     const T step = live ? alpha : T(0);
     static_for<0, kNV>([&](auto ic) { qacc[decltype(ic)::value] += step * s[decltype(ic)::value]; });
+    live = live && !exact;
+    if (!WaveAny(live)) break;
   }
   static_for<0, kNV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
   // qfrc_smooth + qfrc_constraint for the integrator: M qacc at the solution
