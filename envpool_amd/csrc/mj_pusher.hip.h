@@ -176,11 +176,15 @@ EPA_HD CapCyl<T> CapsuleCylinder(Vec3<T> p0, Vec3<T> p1, T rc, Vec3<T> c, T R, T
   const bool b_none = g1 <= eps, b_all = g0 > eps;
   for (int it = 0; it < 48; ++it) {
     const T mid = T(0.5) * (lo + hi);
-    const bool neg = CapCylG<T>(p0, dp, mid, c, R, H, nullptr, nullptr) < -eps;
+    const T mid2 = T(0.5) * (lo2 + hi2);
+    // The two brackets coincide until |g| drops below eps (both predicates then agree on every
+    // probe): one evaluation serves both searches while they do on every lane of the wave.
+    const T gm = CapCylG<T>(p0, dp, mid, c, R, H, nullptr, nullptr);
+    const T gm2 = WaveAny(mid2 != mid) ? CapCylG<T>(p0, dp, mid2, c, R, H, nullptr, nullptr) : gm;
+    const bool neg = gm < -eps;
     lo = neg ? mid : lo;
     hi = neg ? hi : mid;
-    const T mid2 = T(0.5) * (lo2 + hi2);
-    const bool pos = CapCylG<T>(p0, dp, mid2, c, R, H, nullptr, nullptr) > eps;
+    const bool pos = gm2 > eps;
     hi2 = pos ? mid2 : hi2;
     lo2 = pos ? lo2 : mid2;
   }
@@ -204,18 +208,24 @@ EPA_HD CapCyl<T> CapsuleCylinder(Vec3<T> p0, Vec3<T> p1, T rc, Vec3<T> c, T R, T
   return r;
 }
 
-// One constraint row of the lane: J over the 9 dofs, aref, D (D = 0: inactive)
+// One constraint row of the lane: aref, D (D = 0: inactive) in registers; its Jacobian over the dofs
+// in the lane's LDS slots [slot][lane] (the nine rows' J, M, H and the link frames together do not
+// fit a lane's 512 registers: 267 spilled VGPRs and 5x the algorithmic HBM traffic before).  Table
+// rows (wrist sphere vs plane) only involve the 7 arm dofs, the capsule - cylinder rows all 9.
 template <typename T>
 struct Row {
-  T J[kNV], aref, D;
+  T aref, D;
 };
+EPA_HD constexpr int RowCols(int r) { return r < kNSph ? kNL : kNV; }
+EPA_HD constexpr int RowSlot(int r, int i) { return r < kNSph ? r * kNL + i : kNSph * kNL + (r - kNSph) * kNV + i; }
+constexpr int kRowSlots = kNSph * kNL + kNCap * kNV;  // 69 slots = 35 KB per 64-lane wave in fp64
 
 // mj_forward: qacc for (q, v) under ctrl; warm = qacc_warmstart in / out.  q[0..6] arm,
 // q[7] obj_slidey, q[8] obj_slidex.  Fills `lag` with the xpos the task reads.
-template <typename T>
+template <typename T, typename Lds>
 EPA_HD int PusherForward(const PusherModel<T>& m, const SolverCfg<T>& cfg, const T* q, const T* v,
                          const T* ctrl, T* warm, T* qacc, T* Mout, T* qfrc_out,
-                         PusherLag<T>* lag) {
+                         PusherLag<T>* lag, Lds&& lds) {
   // ---- mj_kinematics + mj_comPos: link frames, spatial inertias about the world origin
   Vec3<T> org[kNL], axw[kNL];
   Mat3<T> R = {{T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)}};
@@ -326,26 +336,30 @@ EPA_HD int PusherForward(const PusherModel<T>& m, const SolverCfg<T>& cfg, const
   });
   // contact rows: frictionless (condim 1), J = n . (Jac_body2 - Jac_body1) at the contact point
   Row<T> rows[kNCon];
-  bool any_contact = false;
-  auto fill_row = [&](Row<T>& r, bool touch, T dist, Vec3<T> pos, Vec3<T> n, T sign_arm, T jy, T jx,
+  unsigned rmask = 0;  // wave uniform: rows that touch on ANY lane; only those are built and visited
+  auto fill_row = [&](auto rc, bool touch, T dist, Vec3<T> pos, Vec3<T> n, T sign_arm, T jy, T jx,
                       T diag) {
+    constexpr int r = decltype(rc)::value;
     // arm columns: point Jacobian of `pos` on the wrist link
     T vel = T(0);
     static_for<0, kNL>([&](auto lc) {
       constexpr int l = decltype(lc)::value;
       const Vec3<T> col = Cross(axw[l], pos - org[l]);
-      r.J[l] = sign_arm * Dot(n, col);
-      vel += r.J[l] * v[l];
+      const T J = sign_arm * Dot(n, col);
+      lds(RowSlot(r, l)) = J;
+      vel += J * v[l];
     });
-    r.J[7] = jy;
-    r.J[8] = jx;
-    vel += jy * v[7] + jx * v[8];
+    if constexpr (r >= kNSph) {
+      lds(RowSlot(r, 7)) = jy;
+      lds(RowSlot(r, 8)) = jx;
+      vel += jy * v[7] + jx * v[8];
+    }
     const T rr = dist - m.margin;
     const T imp = Impedance(m.imp_d0, m.imp_dmax, m.imp_width, rr);
     const T num = (T(1) - imp) * diag;
     const T invR = num < T(1e-15) * imp ? T(1e15) : imp / num;
-    r.D = touch ? invR : T(0);
-    r.aref = touch ? -m.sol_B * vel - m.sol_K * imp * rr : T(0);
+    rows[r].D = touch ? invR : T(0);
+    rows[r].aref = touch ? -m.sol_B * vel - m.sol_K * imp * rr : T(0);
   };
   {
     // wrist capsule end spheres vs the table (mjc_PlaneCapsule): "+axis" end first
@@ -357,24 +371,51 @@ EPA_HD int PusherForward(const PusherModel<T>& m, const SolverCfg<T>& cfg, const
       const Vec3<T> ctr = xw + Mul(Rw, Vec3<T>{lp[0], lp[1], lp[2]});
       const T dist = ctr.z - m.table_z - m.cap_r;
       const bool touch = dist < m.margin;
-      any_contact = any_contact || touch;
-      const Vec3<T> pos = {ctr.x, ctr.y, ctr.z - m.cap_r - T(0.5) * dist};
-      // geom1 = plane (world), geom2 = capsule: J = +n . Jac_arm, n = +z
-      fill_row(rows[s], touch, dist, pos, Vec3<T>{T(0), T(0), T(1)}, T(1), T(0), T(0), m.wrist_invw);
+      rows[s].D = T(0);
+      rows[s].aref = T(0);
+      if (WaveAny(touch)) {
+        rmask |= 1u << s;
+        const Vec3<T> pos = {ctr.x, ctr.y, ctr.z - m.cap_r - T(0.5) * dist};
+        // geom1 = plane (world), geom2 = capsule: J = +n . Jac_arm, n = +z
+        fill_row(sc, touch, dist, pos, Vec3<T>{T(0), T(0), T(1)}, T(1), T(0), T(0), m.wrist_invw);
+      }
     });
     // wrist capsules vs the object's cylinder: geom1 = capsule (arm), geom2 = cylinder (object)
     static_for<0, kNCap>([&](auto cc) {
       constexpr int k = decltype(cc)::value;
       const Vec3<T> p0 = xw + Mul(Rw, Vec3<T>{m.cap_p0[k][0], m.cap_p0[k][1], m.cap_p0[k][2]});
       const Vec3<T> p1 = xw + Mul(Rw, Vec3<T>{m.cap_p1[k][0], m.cap_p1[k][1], m.cap_p1[k][2]});
+      rows[kNSph + k].D = T(0);
+      rows[kNSph + k].aref = T(0);
+      // broad phase (MuJoCo's bounding-sphere test): while the capsule's and the cylinder's bounding
+      // spheres are further apart than the margin on EVERY lane of the wave, the narrow phase -- 48
+      // bisection steps, a third of this kernel's instructions -- cannot produce a contact
+      const Vec3<T> dm = (p0 + p1) * T(0.5) - objc, dh = (p1 - p0) * T(0.5);
+      const T reach = Sqrt(Dot(dh, dh)) + m.cap_r + Sqrt(m.cyl_r * m.cyl_r + m.cyl_h * m.cyl_h) + m.margin;
+      if (!WaveAny(Dot(dm, dm) <= reach * reach)) return;
       const CapCyl<T> cc2 = CapsuleCylinder(p0, p1, m.cap_r, objc, m.cyl_r, m.cyl_h);
       const bool touch = cc2.dist < m.margin;
-      any_contact = any_contact || touch;
-      fill_row(rows[kNSph + k], touch, cc2.dist, cc2.pos, cc2.n, T(-1), cc2.n.y, cc2.n.x,
-               m.wrist_invw + m.obj_invw);
+      if (WaveAny(touch)) {
+        rmask |= 1u << (kNSph + k);
+        fill_row(IC<kNSph + k>{}, touch, cc2.dist, cc2.pos, cc2.n, T(-1), cc2.n.y, cc2.n.x,
+                 m.wrist_invw + m.obj_invw);
+      }
     });
   }
-  const bool wave_contact = WaveAny(any_contact);
+  rmask = WaveUniform(rmask);
+  // the row's Jacobian out of LDS (columns the row does not have are structural zeros)
+  auto load_row = [&](auto rc, T* J) {
+    constexpr int r = decltype(rc)::value;
+    static_for<0, kNV>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i < RowCols(r)) {
+        J[i] = lds(RowSlot(r, i));
+      } else {
+        J[i] = T(0);
+      }
+    });
+  };
+  const bool wave_contact = rmask != 0;
   // ---- mj_fwdConstraint: Newton on 1/2 (a-a0)^T M (a-a0) + sum 1/2 D min(0, J a - aref)^2
   static_for<0, kNV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
   T fs = T(0);
@@ -410,20 +451,24 @@ EPA_HD int PusherForward(const PusherModel<T>& m, const SolverCfg<T>& cfg, const
     if (wave_contact) {
       static_for<0, kNCon>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
-        T jar = -rows[r].aref;
-        static_for<0, kNV>([&](auto ic) { jar += rows[r].J[decltype(ic)::value] * qacc[decltype(ic)::value]; });
-        const bool on = rows[r].D > T(0) && jar < T(0);
-        const T w = on ? rows[r].D : T(0);
-        mask |= (on ? 1u : 0u) << (kNL + r);
-        static_for<0, kNV>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          grad[i] += rows[r].J[i] * w * jar;
-          const T wi = w * rows[r].J[i];
-          static_for<0, kNV>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            H[i * kNV + j] += wi * rows[r].J[j];
+        if ((rmask >> r) & 1u) {  // wave uniform
+          T J[kNV];
+          load_row(rc, J);
+          T jar = -rows[r].aref;
+          static_for<0, RowCols(r)>([&](auto ic) { jar += J[decltype(ic)::value] * qacc[decltype(ic)::value]; });
+          const bool on = rows[r].D > T(0) && jar < T(0);
+          const T w = on ? rows[r].D : T(0);
+          mask |= (on ? 1u : 0u) << (kNL + r);
+          static_for<0, RowCols(r)>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            grad[i] += J[i] * w * jar;
+            const T wi = w * J[i];
+            static_for<0, RowCols(r)>([&](auto jc) {
+              constexpr int j = decltype(jc)::value;
+              H[i * kNV + j] += wi * J[j];
+            });
           });
-        });
+        }
       });
     }
     T gn2 = T(0);
@@ -454,11 +499,15 @@ EPA_HD int PusherForward(const PusherModel<T>& m, const SolverCfg<T>& cfg, const
       static_for<0, kNCon>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         T a = -rows[r].aref, b = T(0);
-        static_for<0, kNV>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          a += rows[r].J[i] * qacc[i];
-          b += rows[r].J[i] * s[i];
-        });
+        if ((rmask >> r) & 1u) {  // wave uniform; rows nobody touches keep D = 0 and a = b = 0
+          T J[kNV];
+          load_row(rc, J);
+          static_for<0, RowCols(r)>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            a += J[i] * qacc[i];
+            b += J[i] * s[i];
+          });
+        }
         cjar[r] = a;
         cjv[r] = b;
       });
@@ -527,11 +576,11 @@ EPA_HD int PusherForward(const PusherModel<T>& m, const SolverCfg<T>& cfg, const
 
 // One mj_step, mj_Euler with implicit joint damping (eulerdamp):
 //   (M + h diag(damping)) qacc_d = qfrc_smooth + qfrc_constraint = M qacc
-template <typename T>
+template <typename T, typename Lds>
 EPA_HD int PusherStep(const PusherModel<T>& m, const SolverCfg<T>& cfg, T* q, T* v, T* warm,
-                      const T* ctrl, PusherLag<T>* lag) {
+                      const T* ctrl, PusherLag<T>* lag, Lds&& lds) {
   T qacc[kNV], M[kNV * kNV], rhs[kNV];
-  const int it = PusherForward(m, cfg, q, v, ctrl, warm, qacc, M, rhs, lag);
+  const int it = PusherForward(m, cfg, q, v, ctrl, warm, qacc, M, rhs, lag, lds);
   static_for<0, kNV>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     M[i * kNV + i] += m.timestep * m.damp[i];

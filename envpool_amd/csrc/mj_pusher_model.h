@@ -147,7 +147,8 @@ inline PusherModel<double> BuildPusherModel(bool v5) {
   SolverCfg<double> cfg{50, 1e-13};
   m.wrist_invw = m.obj_invw = 1.0;
   for (int l = 0; l < kNL; ++l) m.dof_invw[l] = 1.0;
-  PusherForward(m, cfg, q, v, ctrl, warm, qacc, M, f, &lag);
+  double row_lds[kRowSlots];
+  PusherForward(m, cfg, q, v, ctrl, warm, qacc, M, f, &lag, [&](int slot) -> double& { return row_lds[slot]; });
   double Minv[kNV][kNV];
   for (int c = 0; c < kNV; ++c) {
     double A[kNV * kNV], e[kNV] = {0};

@@ -49,6 +49,9 @@ __global__ __launch_bounds__(kPusherBlock) void PusherStepKernel(
     PusherDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
     PusherTask task, mj::SolverCfg<double> scfg) {
   constexpr PU::PusherModel<double> m = kV5 ? kPusherV5ModelConst : kPusherModelConst;
+  // Jacobians of the constraint rows that touch somewhere in the wave, [slot][lane] (mj_pusher.hip.h, Row)
+  __shared__ double row_lds[PU::kRowSlots * kPusherBlock];
+  auto lds = [&](int slot) -> double& { return row_lds[slot * kPusherBlock + threadIdx.x]; };
   const int n = cm.n;
   if ((int)threadIdx.x >= task.lanes) return;
   const int row = blockIdx.x * task.lanes + threadIdx.x;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(kPusherBlock) void PusherStepKernel(
       double qacc[PU::kNV], M[PU::kNV * PU::kNV], f[PU::kNV], ww[PU::kNV];
       const double zero[PU::kNL] = {0, 0, 0, 0, 0, 0, 0};
       for (int i = 0; i < PU::kNV; ++i) ww[i] = 0.0;
-      PU::PusherForward(m, scfg, q, v, zero, ww, qacc, M, f, &lag);
+      PU::PusherForward(m, scfg, q, v, zero, ww, qacc, M, f, &lag, lds);
     }
   } else {
     ++cur;
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(kPusherBlock) void PusherStepKernel(
       act[i] = action[(size_t)row * PU::kNL + i];
       ctrl_cost += act[i] * act[i];  // pusher.h:171-175
     });
-    for (int s = 0; s < task.frame_skip; ++s) PU::PusherStep(m, scfg, q, v, w, act, &lag);
+    for (int s = 0; s < task.frame_skip; ++s) PU::PusherStep(m, scfg, q, v, w, act, &lag, lds);
     if (task.reward_after_step) dists(&near_cost, &dist_cost);
     reward = static_cast<float>(-ctrl_cost * task.ctrl_cost_weight - dist_cost * task.dist_cost_weight -
                                 near_cost * task.near_cost_weight);

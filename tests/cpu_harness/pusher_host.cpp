@@ -26,7 +26,10 @@ void pusher_host_step(const double* q, const double* v, const double* warm, cons
   }
   PusherLag<double> lg{};
   int it = 0;
-  for (int s = 0; s < nsub; ++s) it += PusherStep(m, cfg, tq, tv, tw, ctrl, &lg);
+  double row_lds[kRowSlots];
+  for (int s = 0; s < nsub; ++s) {
+    it += PusherStep(m, cfg, tq, tv, tw, ctrl, &lg, [&](int slot) -> double& { return row_lds[slot]; });
+  }
   for (int i = 0; i < kNV; ++i) {
     qo[i] = tq[i];
     vo[i] = tv[i];
