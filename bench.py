@@ -216,6 +216,46 @@ def main():
         numpy_api = {"value": n * k_np / dt_np, "unit": "env-steps/s", "ms_per_step": 1e3 * dt_np / k_np,
                      "steps": k_np, "note": "send(numpy) + recv() -> numpy, PCIe inclusive"}
 
+    async_mode = None
+    if world == 1 and n % 2 == 0:
+        # (c) the reference benchmark's OWN loop (benchmark/test_envpool.py:94-105): async mode,
+        #     `recv()` then `send(action, env_id)` of batch_size rows with num_envs / batch_size batches
+        #     in flight -- here on the device path, batch_size = num_envs / 2.  Successive batches run
+        #     on different compute streams and fill each other's tails.  Reported
+        #     next to `value` (the sync step() of SURVEY 8d), never as it.
+        del pool
+        b = n // 2
+        apool = DevicePool(args.task, n, batch_size=b, seed=0, max_episode_steps=1000, device=dev_index,
+                           env_id_offset=rank * n, params=params)
+        aids = torch.arange(rank * n, rank * n + n, device=dev, dtype=torch.int32)
+        torch.cuda.synchronize()
+        for j in range(2):
+            apool.send_device(None, b, aids[j * b:].data_ptr())
+
+        def cycle(i):
+            ptrs, k = apool.recv_device()
+            apool.send_device(ring[i % 16].data_ptr(), k, ptrs[0])  # ptrs[0]: the batch's info:env_id
+
+        for i in range(16):
+            cycle(i)
+        apool.synchronize()
+        ta = time.perf_counter()
+        for i in range(8):
+            cycle(i)
+        apool.synchronize()
+        ta = time.perf_counter() - ta
+        k_async = max(8, int(np.ceil(0.5 / max(ta / 8, 1e-6))))
+        ta = time.perf_counter()
+        for i in range(k_async):
+            cycle(i)
+        apool.synchronize()
+        ta = time.perf_counter() - ta
+        async_mode = {"value": b * k_async / ta, "unit": "env-steps/s", "batch_size": b, "batches_in_flight": 2,
+                      "steps": k_async, "ms_per_step": 1e3 * ta / k_async,
+                      "note": "async recv_device -> send_device loop of batch_size rows (the reference benchmark's "
+                              "loop, benchmark/test_envpool.py:94-105), device path"}
+        del apool
+
     if rank == 0:
         total_env_steps = n * world * timed_steps
         value = total_env_steps / elapsed
@@ -325,6 +365,7 @@ def main():
         if world == 1:
             out["reset_step_ms"] = reset_ms
             out["numpy_api"] = numpy_api
+            out["async_mode"] = async_mode
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.task, action_hi=ahi)
         print(json.dumps(out))

@@ -40,6 +40,10 @@ def test_bench_line_schema():
     assert abs(d["value"] - 4096 * d["timed_steps"] / d["timed_s"]) / d["value"] < 1e-6
     assert d["roofline"]["launches"] == d["timed_steps"]
     assert d["config"]["params"] == {"precision": 1}
+    # the reference benchmark's own (async) loop beside the sync value: two batches of num_envs / 2 in flight
+    am = d["async_mode"]
+    assert am["batch_size"] == 2048 and am["batches_in_flight"] == 2 and am["value"] > 0
+    assert abs(am["value"] - am["batch_size"] * am["steps"] / (am["ms_per_step"] * 1e-3 * am["steps"])) / am["value"] < 1e-6
 
 
 def test_kernel_timing_modes_agree():

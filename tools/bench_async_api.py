@@ -77,7 +77,10 @@ def run_async_device(task, n, batch, steps, streams, adim=6):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "streams":
         # independent in-flight batches on several compute streams (round 3): 8 batches of 8192 in flight
-        for task, n, b, adim in (("HalfCheetah-v4", 65536, 8192, 6), ("Ant-v4", 65536, 8192, 8)):
+        # then fewer, larger batches: two 32768-env batches in flight fill each other's tail
+        for task, n, b, adim in (("HalfCheetah-v4", 65536, 8192, 6), ("Ant-v4", 65536, 8192, 8),
+                                 ("HalfCheetah-v4", 65536, 16384, 6), ("HalfCheetah-v4", 65536, 32768, 6),
+                                 ("HalfCheetah-v4", 131072, 65536, 6)):
             rec = {"task": task, "num_envs": n, "batch_size": b}
             for k in (1, 2, 4, 8):
                 rec[f"device_path_{k}_streams_env_steps_per_s"] = run_async_device(task, n, b, 400 if "Half" in task else 100, k, adim)
