@@ -57,6 +57,35 @@ using tree::TreeModel;
 using mj::Sel;
 using mj::Sum4;
 
+// stage timers of the diagnostic build ("hum_debug" & 32 / 64: stat[5..12] += cycles / 16 of
+// position + detection, smooth dynamics, rows, solver staging, sweeps, solver epilogue, streaming solver; forwards)
+#if defined(EPA_HUM_DEBUG) && defined(__HIP_DEVICE_COMPILE__)
+#define EPA_HUM_TICK() ((long long)clock64())
+#else
+#define EPA_HUM_TICK() (0ll)
+#endif
+// a function that is NOT inlined on the device (its own register allocation; see Hum4::SolvePgsCall)
+// (the device context is a handful of pointers and goes by value; the host harness's context owns its storage)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EPA_HUM_NOINLINE __device__ __noinline__
+#define EPA_HUM_CTX(Ctx) Ctx
+#else
+#define EPA_HUM_NOINLINE inline
+#define EPA_HUM_CTX(Ctx) Ctx&
+#endif
+// a register value the optimiser cannot rematerialise or fold
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EPA_HUM_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define EPA_HUM_PIN(x) ((void)0)
+#endif
+// counters that only the diagnostic build reports (the host harness counts too)
+#if defined(EPA_HUM_DEBUG) || !defined(__HIP_DEVICE_COMPILE__)
+#define EPA_HUM_COUNT(x) (++(x))
+#else
+#define EPA_HUM_COUNT(x) ((void)0)
+#endif
+constexpr int kNStat = 20;
 constexpr int kNT = 9;        // trunk dofs 0..8 (free joint 0..5, abdomen z, y, x)
 constexpr int kNS = 4;        // limb dof slots of a lane: A0 A1 A2 (first limb body), B (second)
 constexpr int kNLimb = 4;
@@ -346,6 +375,31 @@ EPA_HD void LimbUnit(double* xl, int limb, int slot, double val) {
   for (int s = 0; s < kNS; ++s) xl[s] = (mine && s == slot) ? val : 0.0;
 }
 
+// max(x, 0) (device: one v_max_f64; the generic form is a compare and two selects per half)
+template <typename T>
+inline Q4<T> Max0(const Q4<T>& x) {
+  Q4<T> r;
+  for (int i = 0; i < 4; ++i) r.v[i] = x.v[i] > T(0) ? x.v[i] : T(0);
+  return r;
+}
+EPA_HD double Max0(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_fmax(x, 0.0);
+#else
+  return x > 0.0 ? x : 0.0;
+#endif
+}
+// 1 in lane K of the quad, 0 in the others
+template <int K, typename T>
+inline Q4<T> LaneUnit(Q4<T>) {
+  Q4<T> r(T(0));
+  r.v[K] = T(1);
+  return r;
+}
+template <int K>
+EPA_HD double LaneUnit(double) {
+  return LaneOps<double>::Is(K) ? 1.0 : 0.0;
+}
 // lane K (compile time) of the quad as an env-level value
 template <int K, typename T>
 inline T BcastQS(const Q4<T>& x) {
@@ -1180,10 +1234,11 @@ struct Hum4 {
     return SumQ((p0 + p1) + p2);
   }
   // 1 / D in distributed form
-  static EPA_HD void DinvD(Ctx& c, const Fwd<V>& f, V* dd) {
+  static EPA_HD void DinvD(Ctx& c, const Fwd<V>& f, V* dd) { DinvD(c, f.dinv_l, dd); }
+  static EPA_HD void DinvD(Ctx& c, const V* dinv_l, V* dd) {
     E dt[kNT];
     static_for<0, kNT>([&](auto jc) { dt[decltype(jc)::value] = c.DtGet(decltype(jc)::value); });
-    Distribute(dt, f.dinv_l, dd);
+    Distribute(dt, dinv_l, dd);
   }
   // Row storage (Ctx): RowPut / RowGet(r, yd) the row's y = L^-T J' (distributed); RsPut / RsGet(r, k) its
   // scalars k = 0 f, 1 A_rr + R_r, 2 R_r, 3 b_r = J_r qacc_smooth - aref_r, 4 1 / (A_rr + R_r);
@@ -1481,12 +1536,72 @@ struct Hum4 {
   static constexpr int kOwn = kRegRows / 4;
   static_assert(kRegRows % 4 == 0 && kRegRows <= 32, "register rows");
   static EPA_HD constexpr int Tri(int r, int cc) { return r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r; }
-  static EPA_HD void SolvePgsR(Ctx& c, const Fwd<V>& f, int nrow_e, const V* zsd, E cost, E* at, V* al, int max_iter,
-                               int* stat) {
+  // kOv (a wave in which some env has more than kRegRows rows, none more than kRegRows + kC): the
+  // HYBRID.  Rows 0 .. kRegRows - 1 of every env stay on the register-resident dual matrix with tracked
+  // residuals; the next kC rows -- the OVERFLOW rows c = kRegRows + j -- are kept on chip in a cheaper form:
+  //   av_j[k] = A_{c, 4 k + l}   the row's entries against the lane's own register rows (kOwn registers),
+  //   (A + R)_{c, c'}            the overflow block, packed triangle in the env's shared block (LDS),
+  //   So_j = b_c + sum_j' (A + R)_{c c'} f_c'   tracked, and f_c: env-level registers,
+  // and a visit forms  res_c = So_j + sum_k av_j[k] f_{4 k + l}  with kOwn multiply-adds and one quad
+  // reduction; an accepted change goes through the same av_j into the tracked residuals of the register rows
+  // and through one column of the overflow block into So.  Visit order = row order, as in mj_solPGS.
+  // An env of such a wave without overflow rows executes the arithmetic of the plain register form plus
+  // additions of exact zeros.  Why: HumanoidStandup's benchmark has more than 24 rows in 2 % of its envs
+  // (at most ~30) and more than 20 in 10 %, but a wave used to stream ALL rows of ALL its 16 envs in the
+  // y-space form (SolvePgs: an HBM round trip per visit) as soon as one env had one row too many --
+  // 172 GB of HBM traffic per launch.
+  static constexpr int kC = MP::kCacheRows;
+  static EPA_HD constexpr int TriO(int r, int cc) { return r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r; }
+  static constexpr int kShAinv = kC * (kC + 1) / 2;  // shared block: the packed overflow block, then 1 / (A_cc + R_c)
+  // what a solve reads of the forward pass and what it returns
+  struct SolveIn {
+    V Llt[kNS][kNT], Lll[kNLL], dinv_l[kNS], accs_l[kNS], zsd[kND];
+    E accs_t[kNT], cost;
+    int nrow_e, max_iter;
+  };
+  struct SolveOut {
+    E at[kNT];
+    V al[kNS];
+    int stat[kNStat];
+    bool rej;  // the cost check of a visit fired: the caller solves again in the exact form
+  };
+  static EPA_HD void MakeSolveIn(const Fwd<V>& f, int nrow_e, const V* zsd, E cost, int max_iter, SolveIn& in) {
+    static_for<0, kNS>([&](auto sc) {
+      constexpr int k = decltype(sc)::value;
+      static_for<0, kNT>([&](auto jc) { in.Llt[k][decltype(jc)::value] = f.Llt[k][decltype(jc)::value]; });
+      in.dinv_l[k] = f.dinv_l[k];
+      in.accs_l[k] = f.accs_l[k];
+    });
+    static_for<0, kNLL>([&](auto ic) { in.Lll[decltype(ic)::value] = f.Lll[decltype(ic)::value]; });
+    static_for<0, kND>([&](auto ic) { in.zsd[decltype(ic)::value] = zsd[decltype(ic)::value]; });
+    static_for<0, kNT>([&](auto jc) { in.accs_t[decltype(jc)::value] = f.accs_t[decltype(jc)::value]; });
+    in.cost = cost;
+    in.nrow_e = nrow_e;
+    in.max_iter = max_iter;
+  }
+  static EPA_HD void FactorOf(const SolveIn& in, Fwd<V>& g) {
+    static_for<0, kNS>([&](auto sc) {
+      constexpr int k = decltype(sc)::value;
+      static_for<0, kNT>([&](auto jc) { g.Llt[k][decltype(jc)::value] = in.Llt[k][decltype(jc)::value]; });
+      g.dinv_l[k] = in.dinv_l[k];
+      g.accs_l[k] = in.accs_l[k];
+    });
+    static_for<0, kNLL>([&](auto ic) { g.Lll[decltype(ic)::value] = in.Lll[decltype(ic)::value]; });
+    static_for<0, kNT>([&](auto jc) { g.accs_t[decltype(jc)::value] = in.accs_t[decltype(jc)::value]; });
+  }
+  template <bool kOv>
+  static EPA_HD void SolvePgsT(Ctx& c, const SolveIn& in, SolveOut& out) {
+    const int nrow_e = in.nrow_e, max_iter = in.max_iter;
+    const V* zsd = in.zsd;
+    const E cost = in.cost;
+    int* stat = out.stat;
+    for (int i = 0; i < kNStat; ++i) stat[i] = 0;
+    out.rej = false;
     constexpr TreeModel m = MP::kM;
+    const long long tk_in = EPA_HUM_TICK();
     const int nrow = WaveMax(nrow_e);
     V dd[kND];
-    DinvD(c, f, dd);
+    DinvD(c, in.dinv_l, dd);
     const bool cold = ColdStart(zsd, dd, cost);
     // A_rc = y_r . (y_c / D) for c < r, four columns at a time, one row of lookahead; rows an env does
     // not have count as zero.  The shared block holds 16 rows of the packed triangle: more rows are
@@ -1496,6 +1611,28 @@ struct Hum4 {
       const bool valid = r < nrow_e;
       static_for<0, kND>([&](auto ic) { y[decltype(ic)::value] = Sel(valid, y[decltype(ic)::value], V(0)); });
     };
+    // (hybrid) the overflow rows' entries against the register rows go through the workspace (Ctx::OvPut) FIRST,
+    // while the registers are still empty: four register rows resident at a time, the overflow rows stream past.
+    // Done after the dual matrix is in registers, the temporaries of this loop push parts of the matrix out to
+    // scratch memory for the whole solve.
+    if constexpr (kOv) {
+      const int nov = nrow - kRegRows;
+      for (int c0 = 0; c0 < kRegRows; c0 += 4) {
+        V w[4][kND];
+        static_for<0, 4>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          load(c0 + k, w[k]);
+          static_for<0, kND>([&](auto ic) { w[k][decltype(ic)::value] *= dd[decltype(ic)::value]; });
+        });
+        for (int j = 0; j < nov; ++j) {
+          V y[kND];
+          load(kRegRows + j, y);
+          E a4[4];
+          static_for<0, 4>([&](auto kc) { a4[decltype(kc)::value] = DotD(y, w[decltype(kc)::value]); });
+          c.OvPut(j, c0 >> 2, LanePickV(a4, 0));
+        }
+      }
+    }
     V fo[kOwn], ainv[kOwn], arr[kOwn], S[kOwn], AR[kOwn][kRegRows];
     static_for<0, kOwn>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
@@ -1567,35 +1704,162 @@ struct Hum4 {
       const E fc = BcastQS<cidx & 3>(fo[cidx >> 2]);
       static_for<0, kOwn>([&](auto kc) { S[decltype(kc)::value] += AR[decltype(kc)::value][cidx] * V(fc); });
     });
+    // overflow rows: A_{c, register rows} (four register rows resident at a time, the overflow rows
+    // stream past; through Ctx::OvPut / OvGet into registers indexed at compile time), the overflow block,
+    // the start forces and their share of S
+    constexpr int kCo = kC / 4;
+    static_assert(kC % 4 == 0, "overflow rows: a multiple of 4");
+    V av[kC][kOwn], Sov[kCo], fv[kCo];
+    typename Ctx::TriBase trb[kCo];  // the lane's overflow rows in the packed triangle (LDS addresses without arithmetic)
+    if constexpr (kOv) {
+      static_assert(kShAinv + kC <= kFSlots, "the overflow block fits the shared block");
+      const int nov = nrow - kRegRows;  // wave level, 1 .. kC
+      for (int i = 0; i < kShAinv + kC; ++i) c.ShPut(i, E(0));  // (rows the wave does not have: exact zeros)
+      for (int jc = 0; jc < nov; ++jc) {
+        V w[kND];
+        load(kRegRows + jc, w);
+        static_for<0, kND>([&](auto ic) { w[decltype(ic)::value] *= dd[decltype(ic)::value]; });
+        const bool hv = kRegRows + jc < nrow_e;
+        c.ShPut(TriO(jc, jc), hv ? c.RsGet(kRegRows + jc, kRsArr) : E(0));
+        c.ShPut(kShAinv + jc, hv ? c.RsGet(kRegRows + jc, kRsAinv) : E(0));
+        for (int jr = jc + 1; jr < nov; ++jr) {
+          V y[kND];
+          load(kRegRows + jr, y);
+          c.ShPut(TriO(jr, jc), DotD(y, w));
+        }
+      }
+      static_for<0, kC>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const bool hv = kRegRows + j < nrow_e;
+        static_for<0, kOwn>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          av[j][k] = V(0);
+          if (j < nov) av[j][k] = Sel(hv, c.OvGet(j, k), V(0));  // (wave uniform branch)
+        });
+      });
+      // lane l keeps the force and the tracked part of the residual of the overflow rows j = 4 m + l
+      static_for<0, kCo>([&](auto mc) {
+        constexpr int mm = decltype(mc)::value;
+        const BV have = c.RowIndexLane(kRegRows + 4 * mm) < V(nrow_e);
+        fv[mm] = V(0);
+        Sov[mm] = V(0);
+        if (4 * mm < nov) {
+          fv[mm] = Sel(have, Sel(cold, V(0), c.RsGetLane(kRegRows + 4 * mm, kRsF)), V(0));
+          Sov[mm] = Sel(have, c.RsGetLane(kRegRows + 4 * mm, kRsB), V(0));
+        }
+      });
+      static_for<0, kCo>([&](auto mc) { trb[decltype(mc)::value] = c.TriRow(4 * decltype(mc)::value); });
+      static_for<0, kC>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const E fj = BcastQS<j & 3>(fv[j >> 2]);
+        static_for<0, kCo>([&](auto mc) {
+          constexpr int mm = decltype(mc)::value;
+          Sov[mm] += c.template ShGetTriRow<4 * mm, j>(trb[mm]) * V(fj);
+        });
+        static_for<0, kOwn>([&](auto kc) { S[decltype(kc)::value] += av[j][decltype(kc)::value] * V(fj); });
+      });
+    }
     const E scale = E(1.0 / (m.meaninertia * 23.0));
     bool done = nrow_e == 0;
+    V unit[4] = {LaneUnit<0>(V()), LaneUnit<1>(V()), LaneUnit<2>(V()), LaneUnit<3>(V())};
+    EPA_HUM_PIN(unit[0]);
+    EPA_HUM_PIN(unit[1]);
+    EPA_HUM_PIN(unit[2]);
+    EPA_HUM_PIN(unit[3]);
+    const long long tk1 = EPA_HUM_TICK();
+    stat[kOv ? 15 : 8] += (int)((tk1 - tk_in) >> 4);
+    EPA_HUM_COUNT(stat[kOv ? 17 : 16]);
+    // A visit is one dependent chain on a SIMD that runs a single wave, so its LENGTH is the cost.  Kept
+    // on the chain: S -> clamped force -> change dv -> broadcast -> S.  Taken off it:
+    //  * mj_solPGS's safety check "the cost went up by more than 1e-10: take the update back" -- the update is
+    //    applied at once, the cost change follows beside the chain, and a wave that ever sees the check fire
+    //    (the exact 1-D minimiser of a convex quadratic does not raise it) starts over in the exact y-space
+    //    form (SolvePgs), whose visits decide before they apply;
+    //  * the masks: a row the env does not have, or any row of an env that is done, has 1 / (A_rr + R_r) = 0
+    //    here, which makes dv an exact zero (forces are >= 0).
+    V harr[kOwn];
+    static_for<0, kOwn>([&](auto kc) { harr[decltype(kc)::value] = V(0.5) * arr[decltype(kc)::value]; });
+    bool rej = false;
     for (int iter = 0; iter < max_iter; ++iter) {
       E improvement = E(0);
+      // (device: the overflow block is loop invariant -- without this its LDS reads are hoisted out of the
+      // sweep loop into ~90 registers, which then spill)
+      if constexpr (kOv) c.Refresh();
+      // rows of this env the sweep still visits (none once it is done), and the most of them over the wave:
+      // one scalar compare per visit decides whether the wave runs it
+      const int nlive = done ? 0 : nrow_e;
+      const int nact = WaveMax(nlive);
+      V ainv_e[kOwn];
+      static_for<0, kOwn>([&](auto kc) { ainv_e[decltype(kc)::value] = Sel(done, V(0), ainv[decltype(kc)::value]); });
       static_for<0, kRegRows>([&](auto rc0) {
         constexpr int r = decltype(rc0)::value;
         constexpr int k = r >> 2, o = r & 3;
-        const bool valid = r < nrow_e;
-        if (AnyWave(valid && !done)) {
-          ++stat[0];
+        if (r < nact) {
+          EPA_HUM_COUNT(stat[kOv ? 19 : 0]);
           // (only lane o's numbers mean row r; the others are never looked at)
-          const V fn = MaxX(V(0), fo[k] - S[k] * ainv[k]);
-          const V dv = fn - fo[k];
-          const V cv = V(0.5) * dv * dv * arr[k] + dv * S[k];
-          const E change = BcastQS<o>(cv);
-          const bool keep = valid && !done && !(change > E(1e-10));
-          const E delta = keep ? BcastQS<o>(dv) : E(0);
-          fo[k] += Sel(LaneOps<V>::Is(o), V(delta), V(0));
+          const V dv = Max0(fo[k] - S[k] * ainv_e[k]) - fo[k];
+          const V cv = (dv * dv) * harr[k] + dv * S[k];
+          const E delta = BcastQS<o>(dv);
+          fo[k] += V(delta) * unit[o];
           static_for<0, kOwn>([&](auto kc) { S[decltype(kc)::value] += AR[decltype(kc)::value][r] * V(delta); });
-          improvement -= keep ? change : E(0);
+          const E change = BcastQS<o>(cv);
+          improvement -= change;
+          rej = rej || change > E(1e-10);
         }
       });
+      if constexpr (kOv) {
+        const E livef = done ? E(0) : E(1);
+        static_for<0, kC>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if (kRegRows + j < nact) {
+            EPA_HUM_COUNT(stat[0]);
+            constexpr int mo = j >> 2, o = j & 3;
+            // (all LDS reads of the visit first: their latency passes during the dot product)
+            V aoo[kCo];
+            static_for<0, kCo>([&](auto mc) {
+              constexpr int mm = decltype(mc)::value;
+              aoo[mm] = c.template ShGetTriRow<4 * mm, j>(trb[mm]);
+            });
+            const E harr_j = E(0.5) * c.ShGet(TriO(j, j)), ainv_j = c.ShGet(kShAinv + j) * livef;
+            V aj[kOwn];
+            static_for<0, kOwn>([&](auto kc) { aj[decltype(kc)::value] = av[j][decltype(kc)::value]; });
+            V p0 = aj[0] * fo[0], p1 = V(0), p2 = V(0);
+            static_for<1, kOwn>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              if constexpr (k % 3 == 0) p0 += aj[k] * fo[k];
+              else if constexpr (k % 3 == 1) p1 += aj[k] * fo[k];
+              else p2 += aj[k] * fo[k];
+            });
+            // (only lane o's numbers mean row j from here on)
+            const V res = Sov[mo] + V(SumQ((p0 + p1) + p2));
+            const V dv = Max0(fv[mo] - res * V(ainv_j)) - fv[mo];
+            const V cv = (dv * dv) * V(harr_j) + dv * res;
+            const E delta = BcastQS<o>(dv);
+            fv[mo] += V(delta) * unit[o];
+            static_for<0, kCo>([&](auto mc) { Sov[decltype(mc)::value] += aoo[decltype(mc)::value] * V(delta); });
+            static_for<0, kOwn>([&](auto kc) { S[decltype(kc)::value] += aj[decltype(kc)::value] * V(delta); });
+            const E change = BcastQS<o>(cv);
+            improvement -= change;
+            rej = rej || change > E(1e-10);
+          }
+        });
+      }
       ++stat[1];
       stat[4] += done ? 0 : nrow_e;  // this env's own row visits: the key of the cost-sorted scheduling
+      if (AnyWave(rej)) break;
       done = done || improvement * scale < E(1e-8);
       if (!AnyWave(!done)) break;
     }
+    if (AnyWave(rej)) {  // (never seen) the wave starts over in the exact form; the rows still hold the start forces
+      EPA_HUM_COUNT(stat[13]);
+      out.rej = true;
+      return;
+    }
     // z = D^-1 sum_r f_r y_r (the rows stream past once more); efc_force goes back to the rows
     // (mj_rnePostConstraint)
+    const long long tk2 = EPA_HUM_TICK();
+    stat[kOv ? 14 : 9] += (int)((tk2 - tk1) >> 4);
+    if constexpr (kOv) stat[18] += nrow;
     E fr[kRegRows];
     static_for<0, kRegRows>([&](auto rc0) { fr[decltype(rc0)::value] = BcastQS<decltype(rc0)::value & 3>(fo[decltype(rc0)::value >> 2]); });
     V zd[kND];
@@ -1609,8 +1873,23 @@ struct Hum4 {
         static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] += V(fr[r]) * y[decltype(ic)::value]; });
       }
     });
+    if constexpr (kOv) {
+      static_for<0, kC>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if (AnyWave(kRegRows + j < nrow_e)) {
+          V y[kND];
+          load(kRegRows + j, y);
+          const E fj = BcastQS<j & 3>(fv[j >> 2]);
+          if (kRegRows + j < nrow_e) c.RsPut(kRegRows + j, kRsF, fj);
+          static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] += V(fj) * y[decltype(ic)::value]; });
+        }
+      });
+    }
     static_for<0, kND>([&](auto ic) { zd[decltype(ic)::value] *= dd[decltype(ic)::value]; });
-    Finish(c, f, zd, at, al);
+    Fwd<V> g;  // (only what Finish reads)
+    FactorOf(in, g);
+    Finish(c, g, zd, out.at, out.al);
+    stat[10] += (int)((EPA_HUM_TICK() - tk2) >> 4);
   }
 
   // the env's state, distributed: trunk (env level) + this lane's limb
@@ -1634,6 +1913,95 @@ struct Hum4 {
     if (bits & 4) static_for<0, kNT>([&](auto ic) { c.SttPut(kSttW + decltype(ic)::value, s.wt[decltype(ic)::value]); });
     if (bits & 8) static_for<0, 3>([&](auto ic) { c.SttPut(kSttU + decltype(ic)::value, s.ut[decltype(ic)::value]); });
   }
+  // ---- the constraint stage of a forward pass: mj_makeConstraint + mj_solPGS, behind a CALL -----------------
+  // Inlined into the step kernel, the solver's sweep loops share one register allocation with the tree stages:
+  // ~1000 spilled numbers compete for 256 AGPRs, which of them end up in scratch memory does not depend on how hot
+  // they are, and a sweep that reloads part of its matrix from scratch waits ~600 cycles per reload (measured:
+  // hybrid sweeps 6x the cost of register-form sweeps per row).  Behind a call the stage is allocated on its own and
+  // the caller's live numbers are saved once around it.  The rows are built on this side of the call as well: with
+  // only the solver behind it, the row loop -- the hungriest of what was left -- paid for the registers that the
+  // values living across the call then occupied (5x slower).  What the stage reads of the pass goes by value.
+  struct ConIn {
+    Sp6<V> lcd[kNS];
+    Vec3<E> com;
+    V Llt[kNS][kNT], Lll[kNLL], dinv_l[kNS], accs_l[kNS], ql[kNS], vl[kNS], wl[kNS];
+    E accs_t[kNT];
+    EMask act;
+    int dbg;
+  };
+  struct ConOut {
+    E at[kNT];
+    V al[kNS];
+    RowCount rc;
+    int stat[kNStat];
+  };
+  // MP::kStageCall: HumanoidStandup (many rows, long solves) gains from the call; Humanoid's solves are short
+  // and the call's save / restore of ~500 registers costs more than the cleaner loops give back (-15 %): inlined.
+  static EPA_HUM_NOINLINE ConOut ConstraintStage(EPA_HUM_CTX(Ctx) c, ConIn ci) { return ConstraintStageBody(c, ci); }
+  static EPA_HD ConOut ConstraintStageBody(Ctx& c, const ConIn& ci) {
+    ConOut out;
+    int* stat = out.stat;
+    for (int i = 0; i < kNStat; ++i) stat[i] = 0;
+    long long tk0 = EPA_HUM_TICK();
+    auto lap = [&](int slot) {
+      const long long t = EPA_HUM_TICK();
+      stat[slot] += (int)((t - tk0) >> 4);
+      tk0 = t;
+    };
+    const int dbg = ci.dbg;
+    Fwd<V> f;  // (only what the rows and the solver read)
+    State s;
+    static_for<0, kNS>([&](auto sc) {
+      constexpr int k = decltype(sc)::value;
+      f.lcd[k] = ci.lcd[k];
+      static_for<0, kNT>([&](auto jc) { f.Llt[k][decltype(jc)::value] = ci.Llt[k][decltype(jc)::value]; });
+      f.dinv_l[k] = ci.dinv_l[k];
+      f.accs_l[k] = ci.accs_l[k];
+      s.ql[k] = ci.ql[k];
+      s.vl[k] = ci.vl[k];
+      s.wl[k] = ci.wl[k];
+    });
+    static_for<0, kNLL>([&](auto ic) { f.Lll[decltype(ic)::value] = ci.Lll[decltype(ic)::value]; });
+    static_for<0, kNT>([&](auto jc) { f.accs_t[decltype(jc)::value] = ci.accs_t[decltype(jc)::value]; });
+    f.com = ci.com;
+    E* at = out.at;
+    V* al = out.al;
+    E cost;
+    V zsd[kND];
+    LoadTrunk(c, s, 1 | 2 | 4);
+    RowCount rc = MakeRows(c, f, ci.act, s.qt, s.ql, s.vt, s.vl, s.wt, s.wl, zsd, &cost);
+    EPA_LDS_FENCE();
+    out.rc = rc;
+    stat[4] += 16 * rc.rows();  // building a row costs about as much as 16 visits of it
+    lap(7);
+    ++stat[12];
+    if (dbg & 1) rc = RowCount{0, 0, 0};
+    const int max_iter = (dbg & 8) ? 0 : MP::kM.iterations;
+    bool exact = AnyWave(rc.rows() > kRegRows + kC);  // more rows than the chip holds: the whole wave streams
+    if (!exact) {
+      SolveIn in;
+      MakeSolveIn(f, rc.rows(), zsd, cost, max_iter, in);
+      SolveOut o;
+      if (!AnyWave(rc.rows() > kRegRows)) {
+        SolvePgsT<false>(c, in, o);
+        stat[2] += WaveMax(rc.rows());
+      } else {
+        SolvePgsT<true>(c, in, o);
+        ++stat[3];
+      }
+      exact = AnyWave(o.rej);
+      static_for<0, kNStat>([&](auto ic) { stat[decltype(ic)::value] += o.stat[decltype(ic)::value]; });
+      static_for<0, kNT>([&](auto jc) { at[decltype(jc)::value] = o.at[decltype(jc)::value]; });
+      static_for<0, kNS>([&](auto sc) { al[decltype(sc)::value] = o.al[decltype(sc)::value]; });
+    }
+    if (exact) {
+      SolvePgs(c, f, rc.rows(), zsd, cost, at, al, max_iter, stat);
+      stat[3] += 1000;
+      lap(11);
+    }
+    return out;
+  }
+
   // mj_forward: qacc (at, al); `commit`: store it as the warm start
   // `dbg` (timing runs only, wave uniform): 1 no constraint solve, 2 no rows, 4 no detection, 8 no sweeps;
   // stat[0..4] += row visits, sweeps, the wave's rows (register path), streaming solves, this env's solver cost (own row visits + 16 per row built)
@@ -1648,6 +2016,12 @@ struct Hum4 {
     // lanes' registers through the whole pass it costs 62 VGPRs at the register peaks.
     c.Refresh();  // (device: keeps the loop-invariant LDS reads -- 112 limb constants -- from being hoisted out
                   // of the step loop and spilled)
+    long long tk0 = EPA_HUM_TICK();
+    auto lap = [&](int slot) {
+      const long long t = EPA_HUM_TICK();
+      stat[slot] += (int)((t - tk0) >> 4);
+      tk0 = t;
+    };
     LoadTrunk(c, s, 1);
     Position(c, s.qt, s.ql, f);
     EMask act;
@@ -1660,6 +2034,7 @@ struct Hum4 {
     if (dbg & 2) act.w[0] = act.w[1] = act.w[2] = 0ull;
     EPA_LDS_FENCE();
     c.Refresh();
+    lap(5);
     LoadTrunk(c, s, 1 | 2 | 8);
     Velocity(c, s.qt, s.ql, s.vt, s.vl, s.ut, s.ul, f);
     after_velocity(f);
@@ -1667,20 +2042,31 @@ struct Hum4 {
     SmoothAcc(c, f);
     EPA_LDS_FENCE();
     c.Refresh();
-    E cost;
-    V zsd[kND];
-    LoadTrunk(c, s, 1 | 2 | 4);
-    RowCount rc = MakeRows(c, f, act, s.qt, s.ql, s.vt, s.vl, s.wt, s.wl, zsd, &cost);
-    EPA_LDS_FENCE();
-    stat[4] += 16 * rc.rows();  // building a row costs about as much as 16 visits of it
-    if (dbg & 1) rc = RowCount{0, 0, 0};
-    if (!AnyWave(rc.rows() > kRegRows)) {
-      SolvePgsR(c, f, rc.rows(), zsd, cost, at, al, (dbg & 8) ? 0 : MP::kM.iterations, stat);
-      stat[2] += WaveMax(rc.rows());
-    } else {
-      SolvePgs(c, f, rc.rows(), zsd, cost, at, al, (dbg & 8) ? 0 : MP::kM.iterations, stat);
-      ++stat[3];
-    }
+    lap(6);
+    // mj_makeConstraint + mj_solPGS: behind a call (ConstraintStage), with what they read of this pass as values
+    ConIn in;
+    static_for<0, kNS>([&](auto sc) {
+      constexpr int k = decltype(sc)::value;
+      in.lcd[k] = f.lcd[k];
+      static_for<0, kNT>([&](auto jc) { in.Llt[k][decltype(jc)::value] = f.Llt[k][decltype(jc)::value]; });
+      in.dinv_l[k] = f.dinv_l[k];
+      in.accs_l[k] = f.accs_l[k];
+      in.ql[k] = s.ql[k];
+      in.vl[k] = s.vl[k];
+      in.wl[k] = s.wl[k];
+    });
+    static_for<0, kNLL>([&](auto ic) { in.Lll[decltype(ic)::value] = f.Lll[decltype(ic)::value]; });
+    static_for<0, kNT>([&](auto jc) { in.accs_t[decltype(jc)::value] = f.accs_t[decltype(jc)::value]; });
+    in.com = f.com;
+    in.act = act;
+    in.dbg = dbg;
+    ConOut o;
+    if constexpr (MP::kStageCall) o = ConstraintStage(c, in);
+    else o = ConstraintStageBody(c, in);
+    static_for<0, kNStat>([&](auto ic) { stat[decltype(ic)::value] += o.stat[decltype(ic)::value]; });
+    static_for<0, kNT>([&](auto jc) { at[decltype(jc)::value] = o.at[decltype(jc)::value]; });
+    static_for<0, kNS>([&](auto sc) { al[decltype(sc)::value] = o.al[decltype(sc)::value]; });
+    const RowCount rc = o.rc;
     static_for<0, kNT>([&](auto jc) {
       if (commit) c.SttPut(kSttW + decltype(jc)::value, at[decltype(jc)::value]);  // (four lanes, one value)
     });

@@ -26,13 +26,28 @@ namespace {
 namespace H = mj::hum4;
 namespace T = mj::tree;
 
+// rows of an env on the register-resident dual matrix (A/B builds: tools/build_alt_hum4.sh)
+#ifndef EPA_HUM_REGROWS
+#define EPA_HUM_REGROWS 12
+#endif
+#ifndef EPA_STANDUP_REGROWS
+#define EPA_STANDUP_REGROWS 16
+#endif
+#ifndef EPA_HUM_CACHEROWS
+#define EPA_HUM_CACHEROWS 8
+#endif
+#ifndef EPA_STANDUP_CACHEROWS
+#define EPA_STANDUP_CACHEROWS 16
+#endif
 struct HumanoidMP {
   static constexpr T::TreeModel kM = kHumanoidModelConst;
-  static constexpr int kRegRows = 12;
+  static constexpr int kRegRows = EPA_HUM_REGROWS, kCacheRows = EPA_HUM_CACHEROWS;
+  static constexpr bool kStageCall = false;
 };
 struct StandupMP {
   static constexpr T::TreeModel kM = kHumanoidStandupModelConst;
-  static constexpr int kRegRows = 24;
+  static constexpr int kRegRows = EPA_STANDUP_REGROWS, kCacheRows = EPA_STANDUP_CACHEROWS;
+  static constexpr bool kStageCall = true;
 };
 
 constexpr int kBlock = 64, kEnvsPerBlock = 16;
@@ -41,7 +56,10 @@ constexpr int kMaxRows = 17 + 4 * 29 + 128, kMaxCon = 29 + 128;
 constexpr int kRowSlots = 9, kRecSlots = 2;
 constexpr int kRkSlots = 10 + 4 * H::kNS;  // RK4 bookkeeping of the running mj_step (trunk part spread over the quad)
 constexpr int kWsRk = kMaxRows * kRowSlots + kMaxCon * kRecSlots;
-constexpr int kWsSlots = kWsRk + kRkSlots;  // per lane
+// overflow rows of the hybrid PGS (Hum4::SolvePgsT<true>): their dual-matrix entries against the register rows
+constexpr int kMaxOv = 16, kOvSlots = 8;
+constexpr int kWsOv = kWsRk + kRkSlots;
+constexpr int kWsSlots = kWsOv + kMaxOv * kOvSlots;  // per lane
 // LDS of a wave, in doubles.  Env-level slots are [slot][quad].  The geoms + trunk cdof (Position
 // .. MakeRows) and the dual problem of the PGS solve (SolvePgsA, after MakeRows) share region U.
 constexpr int kGeoSlots = 102, kTcdSlots = 54, kLttSlots = 45 + 9;
@@ -60,14 +78,19 @@ __device__ __forceinline__ double Bcast(double x) {  // lane K of the quad
 #endif
 }
 
+// (the context crosses a call boundary by value -- Hum4::SolvePgsCall -- so its LDS pointer carries the address
+// space in its type: a plain double* would turn every LDS access behind the call into a flat load)
+using LdsDouble = __attribute__((address_space(3))) double;
+using GlobalDouble = __attribute__((address_space(1))) double;
+
 template <class MP>
 struct DevCtx {
   using V = double;
   using Tabs = typename H::Hum4<MP, DevCtx<MP>>::Tabs;
   const Tabs* tabs;  // the wave's LDS copy of the candidate tables
   __device__ const Tabs& T() const { return *tabs; }
-  double* lds;
-  double* ws;  // the wave's block, [slot][64]
+  LdsDouble* lds;
+  GlobalDouble* ws;  // the wave's block, [slot][64]
   int lane, l, quad;
 
   // the lane coordinates become opaque to the optimiser: what is read through them afterwards cannot
@@ -108,7 +131,7 @@ struct DevCtx {
   // the env's shared block [slot][quad] (PGS on the dual matrix)
   __device__ void ShPut(int slot, double v) { lds[kLdsSh + slot * 16 + quad] = v; }
   __device__ double ShGet(int slot) const { return lds[kLdsSh + slot * 16 + quad]; }
-  __device__ double& Ws(int slot) const { return ws[(size_t)slot * 64 + lane]; }
+  __device__ GlobalDouble& Ws(int slot) const { return ws[(size_t)slot * 64 + lane]; }
   // row r: slots 0..6 the lane's share of y (Hum4::kND); slot 7 the row's scalars 1..4 (A_rr + R_r,
   // R_r, b_r, 1 / (A_rr + R_r)), lane l of the quad holding number 1 + l; slot 8 its force f (every
   // lane a copy).  A lane only ever reads back what it wrote itself; the other lanes' numbers
@@ -145,6 +168,9 @@ struct DevCtx {
     return l == 0 ? t[0] : (l == 1 ? t[1] : (l == 2 ? t[2] : t[3]));
   }
   __device__ double RowIndexLane(int r0) const { return (double)(r0 + l); }
+  // overflow row o: entry k = (A)_{kRegRows + o, 4 k + l}
+  __device__ void OvPut(int o, int k, double v) { Ws(kWsOv + o * kOvSlots + k) = v; }
+  __device__ double OvGet(int o, int k) const { return Ws(kWsOv + o * kOvSlots + k); }
   // RK4 bookkeeping (Hum4::RkAdvance): 37 trunk numbers, number i kept by lane i & 3 in its slot
   // i >> 2 (read back by that lane, broadcast by DPP), + 16 limb numbers
   __device__ void RkPut(int i, double v) {
@@ -156,6 +182,18 @@ struct DevCtx {
   __device__ double ShGetTriLane(int r0, int cc, int base) const {  // entry (r0 + lane, cc) of the packed triangle
     const int r = r0 + l;
     return ShGet((r >= cc ? r * (r + 1) / 2 + cc : cc * (cc + 1) / 2 + r) - base);
+  }
+  // the same without index arithmetic at the point of use: TriRow(r0) once, then entry (R0 + lane, CC) of the
+  // packed triangle at base 0 is one LDS read at a per-lane base + a compile-time offset (only the 4 x 4 block
+  // on the diagonal needs a per-lane select)
+  using TriBase = int;
+  __device__ int TriRow(int r0) const { return ((r0 + l) * (r0 + l + 1) / 2) * 16 + quad; }
+  template <int R0, int CC>
+  __device__ double ShGetTriRow(int rb) const {
+    constexpr int kUp = CC * (CC + 1) / 2 + R0;  // + l: the entry above the diagonal, by symmetry
+    if constexpr (CC < R0) return lds[kLdsSh + rb + CC * 16];
+    else if constexpr (CC > R0 + 3) return lds[kLdsSh + (kUp + l) * 16 + quad];
+    else return lds[kLdsSh + (R0 + l >= CC ? rb + CC * 16 : (kUp + l) * 16 + quad)];
   }
   __device__ void RecPut(int t, int k, double v) {
     if ((k & 3) == l) Ws(kMaxRows * kRowSlots + t * kRecSlots + (k >> 2)) = v;
@@ -180,6 +218,7 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
                     m.act_dof[16] == 22,
                 "CtrlOfDof");
   static constexpr H::LimbTab kTab = H::MakeLimbTab(MP::kM);
+  static_assert(MP::kCacheRows <= kMaxOv && MP::kRegRows / 4 <= kOvSlots, "overflow rows fit the workspace");
   __shared__ double lds[kLdsElems];
   __shared__ typename Ctx::Tabs lds_tabs;  // 3.6 KB: pair / geom / body / limit tables, indexed at run time
   const int lane = threadIdx.x, l = lane & 3, quad = lane >> 2;
@@ -222,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
   }
   __syncthreads();
   if (!valid) return;  // whole quads leave together
-  Ctx c{&lds_tabs, lds, dev.ws + (size_t)blockIdx.x * kWsSlots * 64, lane, l, quad};
+  Ctx c{&lds_tabs, (LdsDouble*)lds, (GlobalDouble*)(dev.ws + (size_t)blockIdx.x * kWsSlots * 64), lane, l, quad};
   // persistent state: qpos[24] qvel[23] warm[23] lag[2], SoA [slot][n]
   constexpr int kQ = 0, kV = 24, kW = 47, kLag = 70;
   auto get = [&](int slot) -> double {
@@ -307,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
   const int bodyA = l == 0 ? 4 : (l == 1 ? 7 : (l == 2 ? 10 : 12));
   const int nlb = l < 2 ? 3 : 2;
   double mx = 0.0, my = 0.0;
-  int stat[5] = {0, 0, 0, 0, 0};  // solver statistics of this env-step ("hum_debug" & 16: into info)
+  int stat[H::kNStat] = {};  // solver statistics of this env-step ("hum_debug" & 16: into info)
   for (int it = 0; it < nmax; ++it) {
     const bool live = it < nfwd;
     const bool last = it == nmax - 1;
@@ -418,6 +457,19 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
       info[1] = -ctrl_cost;
       info[2] = task.healthy_reward;
       info[3] = -contact_cost;
+      if (task.debug & 16) {
+        info[0] = stat[0];
+        info[1] = stat[1];
+        info[2] = stat[2];
+        info[3] = stat[3];
+      }
+      if (task.debug & (32 | 64 | 128 | 256)) {  // stage timers (diagnostic build)
+        const int o = (task.debug & 32) ? 5 : ((task.debug & 64) ? 9 : ((task.debug & 128) ? 13 : 17));
+        info[0] = stat[o];
+        info[1] = stat[o + 1];
+        info[2] = stat[o + 2];
+        info[3] = stat[o + 3];
+      }
     } else {
       const double xv = (mx - x_before) / task.dt, yv = (my - y_before) / task.dt;
       const bool healthy = task.healthy_z_min < z && z < task.healthy_z_max;

@@ -11,8 +11,11 @@
 namespace T = epa::mj::tree;
 namespace H = epa::mj::hum4;
 using epa::mj::Q4;
-struct Walk { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 12; };
-struct Stand { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 24; };
+struct Walk { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 12, kCacheRows = 8; static constexpr bool kStageCall = false; };
+struct Stand { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 16, kCacheRows = 16; static constexpr bool kStageCall = true; };
+// few register rows: nearly every solve takes the hybrid (overflow) form of the PGS
+struct StandOv { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 8, kCacheRows = 12; static constexpr bool kStageCall = true; };
+struct WalkOv { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 4, kCacheRows = 8; static constexpr bool kStageCall = false; };
 
 template <class MP>
 struct HostCtx {
@@ -70,6 +73,13 @@ struct HostCtx {
     }
     return x;
   }
+  Q4<double> ov[64][8];
+  void OvPut(int o, int k, V v) { ov[o][k] = v; }
+  V OvGet(int o, int k) const { return ov[o][k]; }
+  struct TriBase { int r0; };
+  TriBase TriRow(int r0) const { return {r0}; }
+  template <int R0, int CC>
+  V ShGetTriRow(TriBase) const { return ShGetTriLane(R0, CC, 0); }
   V RowIndexLane(int r0) const {
     V x;
     for (int l = 0; l < 4; ++l) x.v[l] = r0 + l;
@@ -236,7 +246,7 @@ static void Step4(const double* q, const double* v, const double* warm, const do
   double at[9];
   Q4<double> al[4];
   typename Eng::RowCount rc{0, 0, 0};
-  int stat[5] = {0, 0, 0, 0, 0};
+  int stat[H::kNStat] = {};
   if (nsub == 0) rc = Eng::Forward(c, s, f, true, at, al, 0, [](const H::Fwd<Q4<double>>&) {}, stat);
   for (int k = 0; k < nsub; ++k) {
     for (int stage = 0; stage < 4; ++stage) {
@@ -297,12 +307,17 @@ static void Step4(const double* q, const double* v, const double* warm, const do
   out[k++] = f.com.x;
   out[k++] = f.com.y;
   out[k++] = rc.nl + rc.nf + rc.np;
+  out[k++] = stat[3];  // solves that took the hybrid / streaming form
+  out[k++] = rc.rows();
+  out[k++] = stat[13];  // solves that started over in the exact form (the cost check of a visit fired)
 }
 
 extern "C" {
 void humanoid4_host_step(const double* q, const double* v, const double* warm, const double* ctrl,
                          int nsub, int standup, int post_constraint, double* out) {
-  if (standup) Step4<Stand>(q, v, warm, ctrl, nsub, post_constraint, out);
+  if (standup == 1) Step4<Stand>(q, v, warm, ctrl, nsub, post_constraint, out);
+  else if (standup == 3) Step4<StandOv>(q, v, warm, ctrl, nsub, post_constraint, out);
+  else if (standup == 2) Step4<WalkOv>(q, v, warm, ctrl, nsub, post_constraint, out);
   else Step4<Walk>(q, v, warm, ctrl, nsub, post_constraint, out);
 }
 // out: accs[23] com[3] cinert[140] cvel[84] act[23] geoms[108] = 381

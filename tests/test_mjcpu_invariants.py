@@ -561,13 +561,17 @@ def test_product_humanoid_quad_code_matches_oracle_on_cpu():
             a[273:].reshape(18, 6)[[2, 8, 11, 14, 17], 3:] = 0  # sphere "axes": unused
             worst = max(worst, float((np.abs(a - b) / (1.0 + np.abs(b))).max()))
         assert worst < 1e-10, (su, worst)
-    for su, task, steps in ((0, "Humanoid", 40), (1, "HumanoidStandup", 120)):
+    # variants 2 / 3: the same models with 4 / 8 register rows (+ 8 / 12 overflow rows), so that nearly every
+    # solve takes the hybrid form of the PGS (tracked register rows + on-chip overflow rows; the product holds
+    # 12 + 8 / 16 + 16) and some fall through to the streaming form
+    for su, task, steps in ((0, "Humanoid", 40), (1, "HumanoidStandup", 120), (2, "Humanoid", 30),
+                            (3, "HumanoidStandup", 60)):
         n = 8
-        extra = [5, 0.1, 1.0 if su else 1.25, 0.01, 0, 0, 0, 0, -1, 0, 0, 3, 1, 1]
+        extra = [5, 0.1, 1.0 if su & 1 else 1.25, 0.01, 0, 0, 0, 0, -1, 0, 0, 3, 1, 1]
         orc = Oracle(task, n, seed=5, max_episode_steps=1000, extra=extra)
         orc.reset()
         rng = np.random.default_rng(1)
-        worst, most = 0.0, 0
+        worst, most, hybrid, stream, rows, again = 0.0, 0, 0, 0, 0, 0
         for t in range(steps):
             st = orc.get_state()
             act = rng.uniform(-0.4, 0.4, size=(n, nu))
@@ -586,9 +590,16 @@ def test_product_humanoid_quad_code_matches_oracle_on_cpu():
                 ref = b["obs"][e]
                 worst = max(worst, float((np.abs(obs - ref) / (1.0 + np.abs(ref))).max()))
                 most = max(most, int(o[k + 331 + 2]))
-        print(f"{task} (quad layout): worst teacher-forced rel |d obs| = {worst:.2e}; max active groups {most}")
+                hybrid += int(o[k + 331 + 3]) % 1000
+                stream += int(o[k + 331 + 3]) // 1000
+                rows = max(rows, int(o[k + 331 + 4]))
+                again += int(o[k + 331 + 5])
+        print(f"{task} (quad layout, variant {su}): worst teacher-forced rel |d obs| = {worst:.2e}; max active "
+              f"groups {most}, most rows {rows}, hybrid solves {hybrid}, streaming solves {stream}, started over {again}")
         assert worst < 1e-8, (task, worst)
-        assert most >= (10 if su else 3)
+        assert most >= (10 if su & 1 else 3)
+        if su >= 2:
+            assert hybrid > 100 * steps // 30, (task, hybrid)
 
 
 def test_product_planar_lane_group_code_matches_oracle_on_cpu():
