@@ -1624,9 +1624,12 @@ struct Hum4 {
           load(c0 + k, w[k]);
           static_for<0, kND>([&](auto ic) { w[k][decltype(ic)::value] *= dd[decltype(ic)::value]; });
         });
+        V nx[kND];  // (one row of lookahead: a row load is an exposed ~700-cycle round trip otherwise)
+        load(kRegRows, nx);
         for (int j = 0; j < nov; ++j) {
           V y[kND];
-          load(kRegRows + j, y);
+          static_for<0, kND>([&](auto ic) { y[decltype(ic)::value] = nx[decltype(ic)::value]; });
+          load(kRegRows + (j + 1 < nov ? j + 1 : j), nx);
           E a4[4];
           static_for<0, 4>([&](auto kc) { a4[decltype(kc)::value] = DotD(y, w[decltype(kc)::value]); });
           c.OvPut(j, c0 >> 2, LanePickV(a4, 0));
@@ -1722,10 +1725,15 @@ struct Hum4 {
         const bool hv = kRegRows + jc < nrow_e;
         c.ShPut(TriO(jc, jc), hv ? c.RsGet(kRegRows + jc, kRsArr) : E(0));
         c.ShPut(kShAinv + jc, hv ? c.RsGet(kRegRows + jc, kRsAinv) : E(0));
-        for (int jr = jc + 1; jr < nov; ++jr) {
-          V y[kND];
-          load(kRegRows + jr, y);
-          c.ShPut(TriO(jr, jc), DotD(y, w));
+        if (jc + 1 < nov) {
+          V nx[kND];
+          load(kRegRows + jc + 1, nx);
+          for (int jr = jc + 1; jr < nov; ++jr) {
+            V y[kND];
+            static_for<0, kND>([&](auto ic) { y[decltype(ic)::value] = nx[decltype(ic)::value]; });
+            load(kRegRows + (jr + 1 < nov ? jr + 1 : jr), nx);
+            c.ShPut(TriO(jr, jc), DotD(y, w));
+          }
         }
       }
       static_for<0, kC>([&](auto jc) {
