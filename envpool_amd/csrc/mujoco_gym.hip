@@ -372,8 +372,16 @@ class CheetahPool : public Pool {
       task_.frame_stack = 1;
     }
     lg_ok_ = fp64_ && !hopper && task_.frame_stack == 1;
+    // (async mode: several batches are in flight on the pool's compute streams, so what fills the machine is
+    // batch_size x streams, not one batch: 8 x 8192 of 65536 envs measured 2.83e8 with 2 lanes per env against
+    // 2.06e8 with 4, profiles/r3r_async_probe.jsonl; and partly filled waves -- made to occupy more SIMDs with ONE
+    // small batch -- only take lanes from the other batches there)
+    async_ = cfg.batch_size > 0 && cfg.batch_size < cfg.num_envs;
     if (layout_ == 0) {
-      const int rows = (cfg.batch_size > 0 && cfg.batch_size < cfg.num_envs) ? cfg.batch_size : cfg.num_envs;
+      long long rows = cfg.num_envs;
+      // (4 = the default number of compute streams; NOT the pool's own "compute_streams", so that an env's bits
+      // do not depend on that knob: tests compare 1 stream with several bit for bit)
+      if (async_) rows = std::min<long long>(cfg.num_envs, 4ll * cfg.batch_size);
       layout_ = rows >= 24576 ? 2 : 4;
     }
     // register budget of the lane-group kernel: one wave per SIMD with all 512 registers (default;
@@ -472,7 +480,7 @@ class CheetahPool : public Pool {
       } else {
         order_shape_ = -1;  // the chain of same-shape launches is broken
       }
-      PlanarLgLaunch(stream_, layout, lg_waves_, model_id_, wave_slots_, spread_, dev_, common_, a,
+      PlanarLgLaunch(stream_, layout, lg_waves_, model_id_, wave_slots_, spread_ && !async_, dev_, common_, a,
                      static_cast<const double*>(d_action), out, task_, d_tab_[layout == 2 ? 0 : 1], tk.d, &tk.base, lo);
       return;
     }
@@ -509,6 +517,7 @@ class CheetahPool : public Pool {
   CheetahTask task_{};
   bool fp64_{false};
   bool spread_{true};
+  bool async_{false};
   int wave_slots_{1024};
   int layout_{0};
   bool lg_ok_{false};
