@@ -62,11 +62,13 @@ typedef struct epa_pool epa_pool;
  *                 per SIMD is spread over all SIMDs with 16 / 32 / 48 envs per wave; 0 always 64 envs per wave
  *   "hum_layout"  Humanoid / HumanoidStandup: 1 one env per lane quad (default), 0 one env per lane
  *   "hum_sort"    quad layout: 1 cost-sorted waves (default), 0 rows in send order
- *   "hum_debug"   quad layout: stages switched off / solver statistics; accepted by the diagnostic
- *                 build only (tools/build_trace_lib.sh), the product library refuses it
+ *   "hum_debug"   quad layout: stages switched off (bits 1 2 4 8), solver statistics (16) or cycles per stage
+ *                 (32 64 128 256) routed into the info keys; accepted by the diagnostic build only
+ *                 (-DEPA_HUM_DEBUG: tools/build_trace_lib.sh, tools/build_alt_hum4.sh), the product library refuses it
  *   "planar_layout" HalfCheetah / Walker2d, fp64: lanes per env of the step kernel -- 2 or 4 (one env per
  *                 lane group, mujoco_planar_lg.hip), 1 (one env per lane, mujoco_gym.hip), 0 (default)
- *                 chosen once per pool: 2 from 24576 rows per launch up, else 4
+ *                 chosen once per pool: 2 from 24576 rows up, else 4 (rows = num_envs in sync mode,
+ *                 min(num_envs, 4 x batch_size) in async mode: what is in flight on the compute streams)
  *   "planar_waves" lane-group kernel: register budget for 1 (default) or 2 waves per SIMD
  *   "planar_lpt"  lane-group kernel: 1 (default) whole-pool launches serve the chunks of envs slowest
  *                 first, by their duration in the previous launch; 0 index order.  Never changes results.
