@@ -306,8 +306,11 @@ struct LaneOps<Q4<T>> {
 // a per-lane integer constant (tab[l] for the lane of limb l)
 EPA_HD int LaneInt(const int (&tab)[4]) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const int l = (int)(threadIdx.x & 3u);
-  return l == 0 ? tab[0] : (l == 1 ? tab[1] : (l == 2 ? tab[2] : tab[3]));
+  // (the four values, -128 .. 127 each, packed into one constant and picked with a shift: written as a chain of
+  // selects this compiled to lane-divergent BRANCHES -- ~16 instructions per use, 8 uses per constraint row)
+  const unsigned packed = ((unsigned)tab[0] & 0xffu) | (((unsigned)tab[1] & 0xffu) << 8) |
+                          (((unsigned)tab[2] & 0xffu) << 16) | (((unsigned)tab[3] & 0xffu) << 24);
+  return (int)(signed char)((packed >> ((threadIdx.x & 3u) * 8u)) & 0xffu);
 #else
   return tab[0];
 #endif
@@ -342,8 +345,10 @@ EPA_HD double BcastQ(double x, int k) { return SumQ(Sel(LaneOps<double>::Is(k), 
 // entries base + 0..3 of an env-level array, one per lane of the quad
 EPA_HD double LanePick4(const double* x, int base) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const int l = (int)(threadIdx.x & 3u);
-  return l == 0 ? x[base] : (l == 1 ? x[base + 1] : (l == 2 ? x[base + 2] : x[base + 3]));
+  // (a tree of selects on the lane's two bits: the chain form compiled to lane-divergent branches)
+  const unsigned l = threadIdx.x & 3u;
+  const double lo = (l & 1u) ? x[base + 1] : x[base], hi = (l & 1u) ? x[base + 3] : x[base + 2];
+  return (l & 2u) ? hi : lo;
 #else
   return x[base];
 #endif
@@ -1390,10 +1395,7 @@ struct Hum4 {
             if (on) {  // (the one lane-divergent branch of this stage: a handful of stores)
               c.RowPut(r, yd);
               c.RsPut(r, kRsF, fw);
-              c.RsPut(r, kRsArr, arr);
-              c.RsPut(r, kRsR, Rr);
-              c.RsPut(r, kRsB, b);
-              c.RsPut(r, kRsAinv, E(1) / arr);
+              c.RsPut4(r, arr, Rr, b, E(1) / arr);  // (one store per lane: four guarded stores are four divergent branches)
             }
             cost += fw * (E(0.5) * Rr * fw + b);
             static_for<0, kND>([&](auto ic) { zsd[decltype(ic)::value] += V(fw) * yd[decltype(ic)::value]; });

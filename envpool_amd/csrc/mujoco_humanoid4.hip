@@ -146,6 +146,10 @@ struct DevCtx {
     if (k == 0) Ws(r * kRowSlots + 8) = v;
     else if (k - 1 == l) Ws(r * kRowSlots + 7) = v;
   }
+  __device__ void RsPut4(int r, double arr, double R, double b, double ainv) {
+    const double lo = (l & 1) ? R : arr, hi = (l & 1) ? ainv : b;
+    Ws(r * kRowSlots + 7) = (l & 2) ? hi : lo;
+  }
   __device__ double RsGet(int r, int k) const {
     if (k == 0) return Ws(r * kRowSlots + 8);
     return mj::hum4::BcastQ(Ws(r * kRowSlots + 7), k - 1);

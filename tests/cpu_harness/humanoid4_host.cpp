@@ -54,6 +54,12 @@ struct HostCtx {
   void ShPut(int slot, double v) { sh[slot] = v; }
   double ShGet(int slot) const { return sh[slot]; }
   void RsPut(int r, int k, double v) { rs[r][k] = v; }
+  void RsPut4(int r, double arr, double R, double b, double ainv) {
+    rs[r][1] = arr;
+    rs[r][2] = R;
+    rs[r][3] = b;
+    rs[r][4] = ainv;
+  }
   void RsGet4(int r, double* arr, double* R, double* b, double* ainv) const {
     *arr = rs[r][1];
     *R = rs[r][2];
