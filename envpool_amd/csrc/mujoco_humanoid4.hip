@@ -33,6 +33,13 @@ namespace T = mj::tree;
 #ifndef EPA_STANDUP_REGROWS
 #define EPA_STANDUP_REGROWS 16
 #endif
+// the constraint stage (rows + solve) behind a call: Hum4::ConstraintStage
+#ifndef EPA_HUM_STAGECALL
+#define EPA_HUM_STAGECALL 0
+#endif
+#ifndef EPA_STANDUP_STAGECALL
+#define EPA_STANDUP_STAGECALL 1
+#endif
 #ifndef EPA_HUM_CACHEROWS
 #define EPA_HUM_CACHEROWS 8
 #endif
@@ -42,12 +49,12 @@ namespace T = mj::tree;
 struct HumanoidMP {
   static constexpr T::TreeModel kM = kHumanoidModelConst;
   static constexpr int kRegRows = EPA_HUM_REGROWS, kCacheRows = EPA_HUM_CACHEROWS;
-  static constexpr bool kStageCall = false;
+  static constexpr bool kStageCall = EPA_HUM_STAGECALL != 0;
 };
 struct StandupMP {
   static constexpr T::TreeModel kM = kHumanoidStandupModelConst;
   static constexpr int kRegRows = EPA_STANDUP_REGROWS, kCacheRows = EPA_STANDUP_CACHEROWS;
-  static constexpr bool kStageCall = true;
+  static constexpr bool kStageCall = EPA_STANDUP_STAGECALL != 0;
 };
 
 constexpr int kBlock = 64, kEnvsPerBlock = 16;
