@@ -853,7 +853,27 @@ struct Hum4 {
   }
 
   // y = L^-T x (in place): the first half of mj_solveM.  Returns sum_i y_i^2 / D_i.
+  // MP::kRowCache: the trunk's cdofs and the trunk block of the factor of M in registers for the duration of the
+  // row loop (108 numbers).  Read through from LDS they are ~40 exposed round trips per constraint row; held in
+  // registers they only fit where the loop has the register file to itself (HumanoidStandup: behind the call).
+  struct TrunkRegs {
+    Sp6<E> cd[kNT];
+    E ltt[kNTT], dt[kNT];
+  };
+  static EPA_HD void LoadTrunkRegs(Ctx& c, TrunkRegs& t) {
+    static_for<0, kNT>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      t.cd[j] = Tcd(c, j);
+      t.dt[j] = c.DtGet(j);
+    });
+    static_for<0, kNTT>([&](auto ic) { t.ltt[decltype(ic)::value] = c.LttGet(decltype(ic)::value); });
+  }
   static EPA_HD E HalfSolve(Ctx& c, const Fwd<V>& f, E* xt, V* xl) {
+    TrunkRegs none;
+    return HalfSolveT<false>(c, f, xt, xl, none);
+  }
+  template <bool kPre>
+  static EPA_HD E HalfSolveT(Ctx& c, const Fwd<V>& f, E* xt, V* xl, const TrunkRegs& tr) {
     V ct[kNT];
     static_for<0, kNT>([&](auto jc) { ct[decltype(jc)::value] = V(0); });
     static_for_down<kNS, 0>([&](auto kc) {
@@ -872,7 +892,8 @@ struct Hum4 {
       constexpr int k = decltype(kc)::value;
       static_for<0, k>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        xt[i] -= c.LttGet(TT(k, i)) * xt[k];
+        if constexpr (kPre) xt[i] -= tr.ltt[TT(k, i)] * xt[k];
+        else xt[i] -= c.LttGet(TT(k, i)) * xt[k];
       });
     });
     V ql = V(0);
@@ -883,7 +904,8 @@ struct Hum4 {
     E qt = E(0);
     static_for<0, kNT>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      qt += xt[j] * xt[j] * c.DtGet(j);
+      if constexpr (kPre) qt += xt[j] * xt[j] * tr.dt[j];
+      else qt += xt[j] * xt[j] * c.DtGet(j);
     });
     return qt + SumQ(ql);
   }
@@ -1270,6 +1292,8 @@ struct Hum4 {
     RowCount rc{0, 0, 0};
     E cost = E(0);
     static_for<0, kND>([&](auto ic) { zsd[decltype(ic)::value] = V(0); });
+    TrunkRegs tr;
+    if constexpr (MP::kRowCache != 0) LoadTrunkRegs(c, tr);  // (1 all of it, 2 the factor only, 3 the cdofs only)
     int row = 0;
     for (int phase = 0; phase < 3; ++phase) {
       const int glo = phase == 0 ? 0 : (phase == 1 ? kG0Floor : kG0Pair);
@@ -1353,7 +1377,9 @@ struct Hum4 {
               static_for<0, kNT>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 const E coef = E((int)((m2 >> j) & 1u) - (int)((m1 >> j) & 1u));
-                const Sp6<E> cd = Tcd(c, j);
+                Sp6<E> cd;
+                if constexpr (MP::kRowCache == 1 || MP::kRowCache == 3) cd = tr.cd[j];
+                else cd = Tcd(c, j);
                 const E jc0 = coef * (Dot(dir, cd.l) + Dot(mdir, cd.a));
                 Jt[j] = on ? jc0 : E(0);
               });
@@ -1388,7 +1414,7 @@ struct Hum4 {
             const E fw = (on && jar < E(0)) ? -jar / R : E(0);
             const E b = on ? ja - aref : E(0);
             const E Rr = on ? R : E(0);
-            const E quad = HalfSolve(c, f, Jt, Jl);  // J -> y in place
+            const E quad = HalfSolveT<MP::kRowCache == 1 || MP::kRowCache == 2>(c, f, Jt, Jl, tr);  // J -> y in place
             V yd[kND];
             Distribute(Jt, Jl, yd);
             const E arr = Rr + quad;

@@ -40,6 +40,9 @@ namespace T = mj::tree;
 #ifndef EPA_STANDUP_STAGECALL
 #define EPA_STANDUP_STAGECALL 1
 #endif
+#ifndef EPA_STANDUP_ROWCACHE
+#define EPA_STANDUP_ROWCACHE 2
+#endif
 #ifndef EPA_HUM_CACHEROWS
 #define EPA_HUM_CACHEROWS 8
 #endif
@@ -50,11 +53,13 @@ struct HumanoidMP {
   static constexpr T::TreeModel kM = kHumanoidModelConst;
   static constexpr int kRegRows = EPA_HUM_REGROWS, kCacheRows = EPA_HUM_CACHEROWS;
   static constexpr bool kStageCall = EPA_HUM_STAGECALL != 0;
+  static constexpr int kRowCache = 0;
 };
 struct StandupMP {
   static constexpr T::TreeModel kM = kHumanoidStandupModelConst;
   static constexpr int kRegRows = EPA_STANDUP_REGROWS, kCacheRows = EPA_STANDUP_CACHEROWS;
   static constexpr bool kStageCall = EPA_STANDUP_STAGECALL != 0;
+  static constexpr int kRowCache = EPA_STANDUP_ROWCACHE;
 };
 
 constexpr int kBlock = 64, kEnvsPerBlock = 16;

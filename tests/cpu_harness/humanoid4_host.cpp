@@ -11,11 +11,11 @@
 namespace T = epa::mj::tree;
 namespace H = epa::mj::hum4;
 using epa::mj::Q4;
-struct Walk { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 12, kCacheRows = 8; static constexpr bool kStageCall = false; };
-struct Stand { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 16, kCacheRows = 16; static constexpr bool kStageCall = true; };
+struct Walk { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 12, kCacheRows = 8; static constexpr bool kStageCall = false; static constexpr int kRowCache = 0; };
+struct Stand { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 16, kCacheRows = 16; static constexpr bool kStageCall = true; static constexpr int kRowCache = 2; };
 // few register rows: nearly every solve takes the hybrid (overflow) form of the PGS
-struct StandOv { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 8, kCacheRows = 12; static constexpr bool kStageCall = true; };
-struct WalkOv { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 4, kCacheRows = 8; static constexpr bool kStageCall = false; };
+struct StandOv { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 8, kCacheRows = 12; static constexpr bool kStageCall = true; static constexpr int kRowCache = 1; };
+struct WalkOv { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 4, kCacheRows = 8; static constexpr bool kStageCall = false; static constexpr int kRowCache = 0; };
 
 template <class MP>
 struct HostCtx {
