@@ -40,6 +40,9 @@ namespace T = mj::tree;
 #ifndef EPA_STANDUP_STAGECALL
 #define EPA_STANDUP_STAGECALL 1
 #endif
+#ifndef EPA_HUM_ROWCACHE
+#define EPA_HUM_ROWCACHE 0
+#endif
 #ifndef EPA_STANDUP_ROWCACHE
 #define EPA_STANDUP_ROWCACHE 2
 #endif
@@ -53,7 +56,7 @@ struct HumanoidMP {
   static constexpr T::TreeModel kM = kHumanoidModelConst;
   static constexpr int kRegRows = EPA_HUM_REGROWS, kCacheRows = EPA_HUM_CACHEROWS;
   static constexpr bool kStageCall = EPA_HUM_STAGECALL != 0;
-  static constexpr int kRowCache = 0;
+  static constexpr int kRowCache = EPA_HUM_ROWCACHE;
 };
 struct StandupMP {
   static constexpr T::TreeModel kM = kHumanoidStandupModelConst;
