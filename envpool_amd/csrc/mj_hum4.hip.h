@@ -1723,6 +1723,8 @@ struct Hum4 {
           if constexpr (top >= r_lo && top < r_hi) {
             // (entries of rows / columns beyond the wave's row count are stale but finite: they only
             // ever meet a zero force)
+            // (the run-time index here; the compile-time form of the overflow visits -- ShGetTriRow -- measured
+            // 3 % slower for HumanoidStandup in this place, profiles/r3zj_*)
             const V a = c.ShGetTriLane(4 * k, cidx, base);
             AR[k][cidx] = Sel(c.RowIndexLane(4 * k) == V(cidx), arr[k], Sel(have, a, V(0)));
           }
@@ -1790,7 +1792,7 @@ struct Hum4 {
         const E fj = BcastQS<j & 3>(fv[j >> 2]);
         static_for<0, kCo>([&](auto mc) {
           constexpr int mm = decltype(mc)::value;
-          Sov[mm] += c.template ShGetTriRow<4 * mm, j>(trb[mm]) * V(fj);
+          Sov[mm] += c.template ShGetTriRow<4 * mm, j, 0>(trb[mm]) * V(fj);
         });
         static_for<0, kOwn>([&](auto kc) { S[decltype(kc)::value] += av[j][decltype(kc)::value] * V(fj); });
       });
@@ -1816,6 +1818,8 @@ struct Hum4 {
     V harr[kOwn];
     static_for<0, kOwn>([&](auto kc) { harr[decltype(kc)::value] = V(0.5) * arr[decltype(kc)::value]; });
     bool rej = false;
+    bool done_seen = done;
+    int nact = WaveMax(done ? 0 : nrow_e);
     for (int iter = 0; iter < max_iter; ++iter) {
       E improvement = E(0);
       // (device: the overflow block is loop invariant -- without this its LDS reads are hoisted out of the
@@ -1824,7 +1828,12 @@ struct Hum4 {
       // rows of this env the sweep still visits (none once it is done), and the most of them over the wave:
       // one scalar compare per visit decides whether the wave runs it
       const int nlive = done ? 0 : nrow_e;
-      const int nact = WaveMax(nlive);
+      // (MP::kLazyNact: the wave-level maximum changes only when an env finishes -- Humanoid + 2.5 %, HumanoidStandup
+      // - 1 %, profiles/r3zj_*; otherwise every sweep)
+      if (!MP::kLazyNact || AnyWave(done != done_seen)) {
+        nact = WaveMax(nlive);
+        done_seen = done;
+      }
       V ainv_e[kOwn];
       static_for<0, kOwn>([&](auto kc) { ainv_e[decltype(kc)::value] = Sel(done, V(0), ainv[decltype(kc)::value]); });
       static_for<0, kRegRows>([&](auto rc0) {
@@ -1854,7 +1863,7 @@ struct Hum4 {
             V aoo[kCo];
             static_for<0, kCo>([&](auto mc) {
               constexpr int mm = decltype(mc)::value;
-              aoo[mm] = c.template ShGetTriRow<4 * mm, j>(trb[mm]);
+              aoo[mm] = c.template ShGetTriRow<4 * mm, j, 0>(trb[mm]);
             });
             const E harr_j = E(0.5) * c.ShGet(TriO(j, j)), ainv_j = c.ShGet(kShAinv + j) * livef;
             V aj[kOwn];

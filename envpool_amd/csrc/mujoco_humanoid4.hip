@@ -57,12 +57,14 @@ struct HumanoidMP {
   static constexpr int kRegRows = EPA_HUM_REGROWS, kCacheRows = EPA_HUM_CACHEROWS;
   static constexpr bool kStageCall = EPA_HUM_STAGECALL != 0;
   static constexpr int kRowCache = EPA_HUM_ROWCACHE;
+  static constexpr bool kLazyNact = true;
 };
 struct StandupMP {
   static constexpr T::TreeModel kM = kHumanoidStandupModelConst;
   static constexpr int kRegRows = EPA_STANDUP_REGROWS, kCacheRows = EPA_STANDUP_CACHEROWS;
   static constexpr bool kStageCall = EPA_STANDUP_STAGECALL != 0;
   static constexpr int kRowCache = EPA_STANDUP_ROWCACHE;
+  static constexpr bool kLazyNact = false;
 };
 
 constexpr int kBlock = 64, kEnvsPerBlock = 16;
@@ -207,12 +209,12 @@ struct DevCtx {
   // on the diagonal needs a per-lane select)
   using TriBase = int;
   __device__ int TriRow(int r0) const { return ((r0 + l) * (r0 + l + 1) / 2) * 16 + quad; }
-  template <int R0, int CC>
-  __device__ double ShGetTriRow(int rb) const {
-    constexpr int kUp = CC * (CC + 1) / 2 + R0;  // + l: the entry above the diagonal, by symmetry
-    if constexpr (CC < R0) return lds[kLdsSh + rb + CC * 16];
+  template <int R0, int CC, int BASE>
+  __device__ double ShGetTriRow(int rb) const {  // (BASE: the triangle entry that sits in slot 0)
+    constexpr int kUp = CC * (CC + 1) / 2 + R0 - BASE;  // + l: the entry above the diagonal, by symmetry
+    if constexpr (CC < R0) return lds[kLdsSh + rb + (CC - BASE) * 16];
     else if constexpr (CC > R0 + 3) return lds[kLdsSh + (kUp + l) * 16 + quad];
-    else return lds[kLdsSh + (R0 + l >= CC ? rb + CC * 16 : (kUp + l) * 16 + quad)];
+    else return lds[kLdsSh + (R0 + l >= CC ? rb + (CC - BASE) * 16 : (kUp + l) * 16 + quad)];
   }
   __device__ void RecPut(int t, int k, double v) {
     if ((k & 3) == l) Ws(kMaxRows * kRowSlots + t * kRecSlots + (k >> 2)) = v;

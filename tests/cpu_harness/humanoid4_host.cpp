@@ -11,11 +11,11 @@
 namespace T = epa::mj::tree;
 namespace H = epa::mj::hum4;
 using epa::mj::Q4;
-struct Walk { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 12, kCacheRows = 8; static constexpr bool kStageCall = false; static constexpr int kRowCache = 0; };
-struct Stand { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 16, kCacheRows = 16; static constexpr bool kStageCall = true; static constexpr int kRowCache = 2; };
+struct Walk { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 12, kCacheRows = 8; static constexpr bool kStageCall = false; static constexpr int kRowCache = 0; static constexpr bool kLazyNact = true; };
+struct Stand { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 16, kCacheRows = 16; static constexpr bool kStageCall = true; static constexpr int kRowCache = 2; static constexpr bool kLazyNact = false; };
 // few register rows: nearly every solve takes the hybrid (overflow) form of the PGS
-struct StandOv { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 8, kCacheRows = 12; static constexpr bool kStageCall = true; static constexpr int kRowCache = 1; };
-struct WalkOv { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 4, kCacheRows = 8; static constexpr bool kStageCall = false; static constexpr int kRowCache = 0; };
+struct StandOv { static constexpr T::TreeModel kM = kHumanoidStandupModelConst; static constexpr int kRegRows = 8, kCacheRows = 12; static constexpr bool kStageCall = true; static constexpr int kRowCache = 1; static constexpr bool kLazyNact = true; };
+struct WalkOv { static constexpr T::TreeModel kM = kHumanoidModelConst; static constexpr int kRegRows = 4, kCacheRows = 8; static constexpr bool kStageCall = false; static constexpr int kRowCache = 0; static constexpr bool kLazyNact = true; };
 
 template <class MP>
 struct HostCtx {
@@ -84,8 +84,8 @@ struct HostCtx {
   V OvGet(int o, int k) const { return ov[o][k]; }
   struct TriBase { int r0; };
   TriBase TriRow(int r0) const { return {r0}; }
-  template <int R0, int CC>
-  V ShGetTriRow(TriBase) const { return ShGetTriLane(R0, CC, 0); }
+  template <int R0, int CC, int BASE>
+  V ShGetTriRow(TriBase) const { return ShGetTriLane(R0, CC, BASE); }
   V RowIndexLane(int r0) const {
     V x;
     for (int l = 0; l < 4; ++l) x.v[l] = r0 + l;
