@@ -95,7 +95,7 @@ __device__ __forceinline__ double Bcast(double x) {  // lane K of the quad
 #endif
 }
 
-// (the context crosses a call boundary by value -- Hum4::ConstraintStage -- so its LDS pointer carries the address
+// (the context crosses a call boundary by value -- Hum4::SolvePgsCall -- so its LDS pointer carries the address
 // space in its type: a plain double* would turn every LDS access behind the call into a flat load)
 using LdsDouble = __attribute__((address_space(3))) double;
 using GlobalDouble = __attribute__((address_space(1))) double;
