@@ -64,7 +64,7 @@ using mj::Sum4;
 #else
 #define EPA_HUM_TICK() (0ll)
 #endif
-// a function that is NOT inlined on the device (its own register allocation; see Hum4::SolvePgsCall)
+// a function that is NOT inlined on the device (its own register allocation; see Hum4::ConstraintStage)
 // (the device context is a handful of pointers and goes by value; the host harness's context owns its storage)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define EPA_HUM_NOINLINE __device__ __noinline__

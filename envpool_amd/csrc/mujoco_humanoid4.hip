@@ -95,7 +95,7 @@ __device__ __forceinline__ double Bcast(double x) {  // lane K of the quad
 #endif
 }
 
-// (the context crosses a call boundary by value -- Hum4::SolvePgsCall -- so its LDS pointer carries the address
+// (the context crosses a call boundary by value -- Hum4::ConstraintStage -- so its LDS pointer carries the address
 // space in its type: a plain double* would turn every LDS access behind the call into a flat load)
 using LdsDouble = __attribute__((address_space(3))) double;
 using GlobalDouble = __attribute__((address_space(1))) double;
@@ -514,6 +514,13 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
         info[5] = stat[1];
         info[6] = stat[2];
         info[7] = stat[3];
+      }
+      if (task.debug & (32 | 64 | 128 | 256)) {  // stage timers (diagnostic build)
+        const int o = (task.debug & 32) ? 5 : ((task.debug & 64) ? 9 : ((task.debug & 128) ? 13 : 17));
+        info[4] = stat[o];
+        info[5] = stat[o + 1];
+        info[6] = stat[o + 2];
+        info[7] = stat[o + 3];
       }
     }
   } else if (kStandup) {
