@@ -536,6 +536,20 @@ static void env_step(mj_pool* p, int eid, int force_reset, const double* act,
     mujoco_reset(p, e);
     /* WriteState(0.0, 0, ...) on reset: ant.h:160-164 passes zeros */
     if (p->is_ant) info[6] = sqrt(0.0);
+    /* The reset WriteState receives the costs as +0.0 and stores them NEGATED: the info key
+     * holds -0.0 (found by running the reference's own wrappers, oracle/_ref/libref_mujoco.so).
+     * half_cheetah.h:178, ant.h:262-263, swimmer.h:172, reacher.h:219-220, pusher.h:225-232,
+     * humanoid.h:272-274, humanoid_standup.h:227-228 */
+    switch (p->task) {
+      case TASK_CHEETAH: info[1] = -0.0; break;
+      case TASK_ANT: info[1] = info[2] = -0.0; break;
+      case TASK_SWIMMER: info[1] = -0.0; break;
+      case TASK_REACHER: info[0] = info[1] = -0.0; break;
+      case TASK_PUSHER: info[0] = info[1] = info[2] = -0.0; break;
+      case TASK_HUMANOID: info[1] = info[3] = -0.0; break;
+      case TASK_STANDUP: info[1] = info[3] = -0.0; break;
+      default: break;
+    }
     /* humanoid_standup.h:226: WriteState stores the member healthy_reward_ on resets too */
     if (p->task == TASK_STANDUP) info[2] = p->healthy_reward;
     e->lag_set = 0;

@@ -6,6 +6,10 @@ ctypes wrapper over the small `orc_*` C API that both oracles export:
   from /root/reference (kind "reference"; exists only where it was built).
 * ``oracle/_ref/libref_atari.so``   — the reference's own atari_env.h compiled in place
   over the synthetic console of tests/synth_ale (kind "reference_atari").
+* ``oracle/_ref/libref_mujoco.so``  — the reference's own gym-MuJoCo task wrappers
+  (envpool/mujoco/gym/*.h) inside its own AsyncEnvPool, compiled in place over a mujoco.h
+  shim whose engine calls forward to oracle/mjcpu (kind "reference_mujoco": reference
+  wrapper + runtime, ported engine).
 * ``oracle/_build/liboracle.so``    — the plain-C restatement under
   ``oracle/restate`` and ``oracle/mjcpu`` (kind "port"; travels everywhere).
 
@@ -24,6 +28,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REF_LIB = os.path.join(_HERE, "_ref", "libref_oracle.so")
 REF_ATARI_LIB = os.path.join(_HERE, "_ref", "libref_atari.so")
+REF_MUJOCO_LIB = os.path.join(_HERE, "_ref", "libref_mujoco.so")
 PORT_LIB = os.path.join(_HERE, "_build", "liboracle.so")
 
 _DTYPES = {0: np.int32, 1: np.float32, 2: np.float64, 3: np.bool_, 4: np.uint8}
@@ -93,12 +98,16 @@ def have_ref_atari() -> bool:
     return os.path.exists(REF_ATARI_LIB)
 
 
+def have_ref_mujoco() -> bool:
+    return os.path.exists(REF_MUJOCO_LIB)
+
+
 def have_port() -> bool:
     return os.path.exists(PORT_LIB)
 
 
 class Oracle:
-    """One oracle pool. ``kind`` is "reference", "reference_atari" or "port"."""
+    """One oracle pool. ``kind``: "reference", "reference_atari", "reference_mujoco", "port"."""
 
     def __init__(
         self,
@@ -110,7 +119,12 @@ class Oracle:
         kind: str = "port",
         num_threads: int = 1,
     ) -> None:
-        path = {"reference": REF_LIB, "reference_atari": REF_ATARI_LIB}.get(kind, PORT_LIB)
+        path = {
+            "reference": REF_LIB,
+            "reference_atari": REF_ATARI_LIB,
+            "reference_mujoco": REF_MUJOCO_LIB,
+            "port": PORT_LIB,
+        }[kind]
         self.lib = _load(path)
         self.kind = self.lib.orc_kind().decode()
         ex = (ctypes.c_double * max(1, len(extra)))(*extra)

@@ -191,7 +191,10 @@ double orc_time_steps(void* h, int steps, const void* action) {
 
 void orc_destroy(void* h) { delete static_cast<IRef*>(h); }
 
-const char* orc_kind() { return "reference"; }
+#ifndef ORC_KIND
+#define ORC_KIND "reference"
+#endif
+const char* orc_kind() { return ORC_KIND; }
 
 }  // extern "C"
 

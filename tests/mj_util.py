@@ -62,3 +62,66 @@ class RawMj:
         names = ["ke", "pe", "ncon", "nefc", "iters", "time", "fmin", "resid",
                  "asym", "torso_z", "fsum"]
         return qpos, qvel, dict(zip(names, misc))
+
+
+# ---- positional `extra` of mjcpu_create / ref_mujoco_driver.cc (oracle/mjcpu/tasks.c) --------
+_EXTRA_NAMES = {
+    "frame_skip": 0, "ctrl_cost_weight": 1, "forward_reward_weight": 2, "reset_noise_scale": 3,
+    "disable_contact": 4, "disable_limit": 5, "disable_actuation": 6, "disable_passive": 7,
+    "integrator": 8, "timestep": 9, "reward_if_not_terminated": 10, "constraint_obs_dim": 11,
+    "use_contact_force": 12, "post_constraint": 13, "exclude_worldbody": 14,
+    "legacy_healthy_reward": 15, "reward_after_step": 16, "obs_include_z": 17,
+    "disable_selfcollide": 18, "exclude_root_actuator": 19, "dist_cost_weight": 20,
+    "near_cost_weight": 21, "weighted_reward_info": 22, "frame_stack": 23,
+}
+
+
+def mj_extra(task, **over):
+    """Full `extra` tuple for `task` with the task's own defaults and `over` applied."""
+    base = task.replace("V5", "")
+    fs = 4 if base in ("Walker2d", "Swimmer", "Hopper") else 2 if base in ("InvertedPendulum", "Reacher") else 5
+    cw = {"Ant": 0.5, "Walker2d": 1e-3, "Hopper": 1e-3, "Reacher": 1.0, "Swimmer": 1e-4}.get(base, 0.1)
+    fw = 1.25 if base == "Humanoid" else 1.0
+    noise = 5e-3 if base in ("Walker2d", "Hopper") else 1e-2 if base in ("InvertedPendulum", "Humanoid", "HumanoidStandup") else 0.1
+    ex = [fs, cw, fw, noise, 0, 0, 0, 0, -1, 0, 0, 3, 0, 0, 0, -1, 0, 1, 0, 0, 1.0, 0.5, 0, 1]
+    for k, v in over.items():
+        ex[_EXTRA_NAMES[k]] = float(v)
+    return tuple(float(v) for v in ex)
+
+
+# registered gym-MuJoCo ids -> (oracle task, max_episode_steps, options); the options are those
+# envpool/mujoco/gym/registration.py:38-93 passes for the version
+GYM_VARIANTS = {
+    "HalfCheetah-v4": ("HalfCheetah", 1000, {}),
+    "HalfCheetah-v5": ("HalfCheetah", 1000, dict(post_constraint=1)),
+    "Ant-v3": ("Ant", 1000, dict(use_contact_force=1)),
+    "Ant-v4": ("Ant", 1000, {}),
+    "Ant-v5": ("Ant", 1000, dict(use_contact_force=1, post_constraint=1, exclude_worldbody=1,
+                                 legacy_healthy_reward=0)),
+    "Walker2d-v4": ("Walker2d", 1000, {}),
+    "Walker2d-v5": ("Walker2dV5", 1000, dict(post_constraint=1)),
+    "Hopper-v4": ("Hopper", 1000, {}),
+    "Hopper-v5": ("Hopper", 1000, dict(post_constraint=1, legacy_healthy_reward=0)),
+    "Swimmer-v4": ("Swimmer", 1000, {}),
+    "Swimmer-v5": ("Swimmer", 1000, dict(post_constraint=1)),
+    "Reacher-v4": ("Reacher", 50, {}),
+    "Reacher-v5": ("Reacher", 50, dict(post_constraint=1, reward_after_step=1, obs_include_z=0)),
+    "Pusher-v4": ("Pusher", 100, {}),
+    "Pusher-v5": ("PusherV5", 100, dict(post_constraint=1, reward_after_step=1,
+                                        weighted_reward_info=1)),
+    "InvertedPendulum-v4": ("InvertedPendulum", 1000, {}),
+    "InvertedPendulum-v5": ("InvertedPendulum", 1000, dict(post_constraint=1,
+                                                           reward_if_not_terminated=1)),
+    "InvertedDoublePendulum-v4": ("InvertedDoublePendulum", 1000, {}),
+    "InvertedDoublePendulum-v5": ("InvertedDoublePendulum", 1000,
+                                  dict(post_constraint=1, reward_if_not_terminated=1,
+                                       constraint_obs_dim=1)),
+    "Humanoid-v3": ("Humanoid", 1000, dict(use_contact_force=1)),
+    "Humanoid-v4": ("Humanoid", 1000, {}),
+    "Humanoid-v5": ("Humanoid", 1000, dict(use_contact_force=1, post_constraint=1,
+                                           exclude_worldbody=1, exclude_root_actuator=1,
+                                           legacy_healthy_reward=0)),
+    "HumanoidStandup-v4": ("HumanoidStandup", 1000, {}),
+    "HumanoidStandup-v5": ("HumanoidStandup", 1000, dict(post_constraint=1, exclude_worldbody=1,
+                                                         exclude_root_actuator=1)),
+}
