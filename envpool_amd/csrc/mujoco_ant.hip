@@ -133,7 +133,9 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
     z = z > task.contact_force_min ? z : task.contact_force_min;
     z = z < task.contact_force_max ? z : task.contact_force_max;
     for (int i = 0; i < ncf; ++i) obs_c[i] = z;
-    for (int i = 0; i < 9; ++i) ((double*)out.p[kKeyEnv0 + 1 + i])[row] = 0.0;  // info[6] = sqrt(0)
+    // WriteState(0.0, 0, ...): info[6] = sqrt(0); reward_ctrl / reward_contact are stored as
+    // `-ctrl_cost` / `-contact_cost` of +0.0, i.e. -0.0 (ant.h:262-263)
+    for (int i = 0; i < 9; ++i) ((double*)out.p[kKeyEnv0 + 1 + i])[row] = (i == 1 || i == 2) ? -0.0 : 0.0;
     WriteCommon(out, row, e + a.id_offset, 0, false, 0.0f, a.max_episode_steps);
     return;
   }

@@ -150,8 +150,11 @@ __global__ __launch_bounds__(kHumBlock) void HumanoidStepKernel(
       info[7] = xv;
       info[8] = yv;
     }
-  } else if (kStandup) {
-    info[2] = task.healthy_reward;  // WriteState(0, 0, 0, 0): reward_alive is the constant
+  } else {
+    // the reset WriteState stores `-ctrl_cost` / `-contact_cost` of +0.0: -0.0 (humanoid.h:272-274)
+    info[1] = -0.0;
+    info[3] = -0.0;
+    if (kStandup) info[2] = task.healthy_reward;  // WriteState(0, 0, 0, 0): reward_alive is the constant
   }
   cm.done[e] = done ? 1 : 0;
   cm.cur_step[e] = cur;

@@ -523,8 +523,11 @@ __global__ __launch_bounds__(kBlock) void Humanoid4StepKernel(HumDev dev, Common
         info[7] = stat[o + 3];
       }
     }
-  } else if (kStandup) {
-    info[2] = task.healthy_reward;  // WriteState(0, 0, 0, 0): reward_alive is the constant
+  } else {
+    // the reset WriteState stores `-ctrl_cost` / `-contact_cost` of +0.0: -0.0 (humanoid.h:272-274)
+    info[1] = -0.0;
+    info[3] = -0.0;
+    if (kStandup) info[2] = task.healthy_reward;  // WriteState(0, 0, 0, 0): reward_alive is the constant
   }
   if (l == 0) {
     mj::static_for<0, 10>([&](auto ic) {

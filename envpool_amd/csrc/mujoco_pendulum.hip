@@ -445,6 +445,7 @@ __global__ __launch_bounds__(kPendBlock) void SwimmerStepKernel(
     const double zero[NV] = {0, 0, 0, 0, 0};
     P::PendForward(m, scfg, q, v, zero, w, qacc, aux);  // mj_forward (warm start)
     info[4] = sqrt(0.0);  // WriteState(0, 0, 0, 0, 0, 0, true): swimmer.h:127
+    info[1] = -0.0;       // `-ctrl_cost` of +0.0 (swimmer.h:172)
   } else {
     ++cur;
     mj::static_for<0, NV>([&](auto ic) {

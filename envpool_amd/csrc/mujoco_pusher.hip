@@ -63,7 +63,8 @@ __global__ __launch_bounds__(kPusherBlock) void PusherStepKernel(
   double q[PU::kNV], v[PU::kNV], w[PU::kNV], gy, gx;  // gy, gx: goal_slidey / goal_slidex
   PU::PusherLag<double> lag;
   float reward = 0.0f;
-  double info[3] = {0.0, 0.0, 0.0};
+  // the reset WriteState stores the NEGATED +0.0 costs: -0.0 in all three keys (pusher.h:225-232)
+  double info[3] = {-0.0, -0.0, -0.0};
   if (reset) {  // MujocoReset + MujocoResetModel, pusher.h:115-136
     cur = 0;
     done = false;

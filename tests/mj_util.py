@@ -125,3 +125,34 @@ GYM_VARIANTS = {
     "HumanoidStandup-v5": ("HumanoidStandup", 1000, dict(post_constraint=1, exclude_worldbody=1,
                                                          exclude_root_actuator=1)),
 }
+
+_NATIVE_NAMES = {
+    "use_contact_force": "use_contact_force", "post_constraint": "post_constraint",
+    "legacy_healthy_reward": "legacy_healthy_reward", "reward_after_step": "reward_after_step",
+    "obs_include_z": "obs_include_z_distance", "weighted_reward_info": "weighted_reward_info",
+    "reward_if_not_terminated": "reward_if_not_terminated", "constraint_obs_dim": "constraint_obs_dim",
+    "exclude_root_actuator": "exclude_root_actuator_forces",
+    "frame_skip": "frame_skip", "ctrl_cost_weight": "ctrl_cost_weight",
+    "forward_reward_weight": "forward_reward_weight", "reset_noise_scale": "reset_noise_scale",
+    "dist_cost_weight": "dist_cost_weight", "near_cost_weight": "near_cost_weight",
+    "frame_stack": "frame_stack",
+}
+
+
+def native_variant(name, **more):
+    """(DevicePool family, params under the reference's config key names) of a GYM_VARIANTS id."""
+    task, max_steps, over = GYM_VARIANTS[name]
+    over = {**over, **more}
+    family = task.replace("V5", "")
+    params = {"post_constraint": 0}
+    if task.endswith("V5"):
+        params["xml_v5"] = 1
+    for k, v in over.items():
+        if k == "exclude_worldbody":
+            params["exclude_worldbody_contact_forces" if family == "Ant"
+                   else "exclude_worldbody_observations"] = v
+        else:
+            params[_NATIVE_NAMES[k]] = v
+    if family in ("HalfCheetah", "Walker2d", "Hopper", "Ant"):
+        params.setdefault("precision", 1)
+    return family, max_steps, params
