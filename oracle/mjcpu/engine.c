@@ -906,7 +906,7 @@ static void fwd_constraint_pgs(const mjc_model* m, mjc_data* d) {
   memcpy(d->qacc, d->qfrc_constraint, sizeof(double) * nv);
   chol_solve(L, nv, d->qacc);
   for (int i = 0; i < nv; ++i) d->qacc[i] += d->qacc_smooth[i];
-  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+  if (m->warmstart_rule == 0) memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
 }
 
 static void fwd_constraint(const mjc_model* m, mjc_data* d) {
@@ -915,7 +915,7 @@ static void fwd_constraint(const mjc_model* m, mjc_data* d) {
   memset(d->qfrc_constraint, 0, sizeof(d->qfrc_constraint));
   if (nefc == 0) {
     memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
-    memcpy(d->qacc_warmstart, d->qacc_smooth, sizeof(double) * nv);
+    if (m->warmstart_rule == 0) memcpy(d->qacc_warmstart, d->qacc_smooth, sizeof(double) * nv);
     return;
   }
   if (m->solver == MJC_SOL_PGS) {
@@ -1040,7 +1040,7 @@ static void fwd_constraint(const mjc_model* m, mjc_data* d) {
     d->efc_force[r] = x < 0 ? -d->efc_D[r] * x : 0;
     for (int i = 0; i < nv; ++i) d->qfrc_constraint[i] += d->efc_J[r][i] * d->efc_force[r];
   }
-  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+  if (m->warmstart_rule == 0) memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
 }
 
 void mjc_forward(const mjc_model* m, mjc_data* d) { /* mj_forward */
@@ -1181,6 +1181,8 @@ void mjc_step(const mjc_model* m, mjc_data* d) { /* mj_step */
   } else {
     euler(m, d);
   }
+  /* warmstart_rule 1: d->qacc is still that of the last forward evaluation */
+  if (m->warmstart_rule == 1) memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * m->nv);
 }
 
 double mjc_energy_kinetic(const mjc_model* m, mjc_data* d) {

@@ -51,6 +51,14 @@ typedef struct {
   int solver, iterations; /* <option solver iterations>: Newton / 100 unless the XML says otherwise */
   int disable_contact, disable_limit, disable_actuation; /* invariant tests */
   int disable_selfcollide; /* tests: drop body-body (capsule-capsule) pairs */
+  /* Where qacc_warmstart is saved (SURVEY Appendix A tags the place "[M]", i.e. from memory):
+   *   0 (default): at the end of every mj_fwdConstraint, so RK4 stages 2-4 warm-start from the
+   *                previous STAGE ("save result for next step warmstart" in mj_fwdConstraint);
+   *   1          : once per mj_step, after the integrator (all four RK4 stages warm-start from
+   *                the last forward evaluation of the previous step).
+   * Converged Newton does not depend on it; the 50-sweep PGS of the Humanoid models does.
+   * tools/warmstart_rule_probe.py measures the difference. */
+  int warmstart_rule;
   /* bodies */
   int body_parent[MJC_MAXBODY], body_rootid[MJC_MAXBODY], body_weldid[MJC_MAXBODY];
   int body_jntadr[MJC_MAXBODY], body_jntnum[MJC_MAXBODY];

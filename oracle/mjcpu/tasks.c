@@ -175,6 +175,7 @@ void* mjcpu_create(const char* task, int num_envs, int seed,
   p->m.disable_limit = extra_or(extra, n_extra, 5, 0) != 0;
   p->m.disable_actuation = extra_or(extra, n_extra, 6, 0) != 0;
   p->m.disable_selfcollide = extra_or(extra, n_extra, 18, 0) != 0;
+  p->m.warmstart_rule = (int)extra_or(extra, n_extra, 24, 0); /* mjcpu.h: 0 per forward, 1 per step */
   if (extra_or(extra, n_extra, 7, 0) != 0) { /* invariant tests: no passive */
     for (int i = 0; i < p->m.nv; ++i) p->m.dof_damping[i] = 0;
     for (int j = 0; j < p->m.njnt; ++j) p->m.jnt_stiffness[j] = 0;

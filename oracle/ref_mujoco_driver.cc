@@ -67,7 +67,7 @@ void* orc_create(const char* task, int num_envs, int seed, int max_episode_steps
   for (int i : {4, 5, 6, 7, 18}) {
     if (x.Get(i, 0) != 0) return nullptr;
   }
-  if (x.Get(8, -1) >= 0 || x.Get(9, 0) > 0) return nullptr;
+  if (x.Get(8, -1) >= 0 || x.Get(9, 0) > 0 || x.Get(24, 0) != 0) return nullptr;
   using namespace mujoco_gym;  // NOLINT
   try {
     if (t == "HalfCheetah") {

@@ -72,7 +72,7 @@ _EXTRA_NAMES = {
     "use_contact_force": 12, "post_constraint": 13, "exclude_worldbody": 14,
     "legacy_healthy_reward": 15, "reward_after_step": 16, "obs_include_z": 17,
     "disable_selfcollide": 18, "exclude_root_actuator": 19, "dist_cost_weight": 20,
-    "near_cost_weight": 21, "weighted_reward_info": 22, "frame_stack": 23,
+    "near_cost_weight": 21, "weighted_reward_info": 22, "frame_stack": 23, "warmstart_rule": 24,
 }
 
 
@@ -83,7 +83,7 @@ def mj_extra(task, **over):
     cw = {"Ant": 0.5, "Walker2d": 1e-3, "Hopper": 1e-3, "Reacher": 1.0, "Swimmer": 1e-4}.get(base, 0.1)
     fw = 1.25 if base == "Humanoid" else 1.0
     noise = 5e-3 if base in ("Walker2d", "Hopper") else 1e-2 if base in ("InvertedPendulum", "Humanoid", "HumanoidStandup") else 0.1
-    ex = [fs, cw, fw, noise, 0, 0, 0, 0, -1, 0, 0, 3, 0, 0, 0, -1, 0, 1, 0, 0, 1.0, 0.5, 0, 1]
+    ex = [fs, cw, fw, noise, 0, 0, 0, 0, -1, 0, 0, 3, 0, 0, 0, -1, 0, 1, 0, 0, 1.0, 0.5, 0, 1, 0]
     for k, v in over.items():
         ex[_EXTRA_NAMES[k]] = float(v)
     return tuple(float(v) for v in ex)
@@ -99,7 +99,7 @@ GYM_VARIANTS = {
     "Ant-v5": ("Ant", 1000, dict(use_contact_force=1, post_constraint=1, exclude_worldbody=1,
                                  legacy_healthy_reward=0)),
     "Walker2d-v4": ("Walker2d", 1000, {}),
-    "Walker2d-v5": ("Walker2dV5", 1000, dict(post_constraint=1)),
+    "Walker2d-v5": ("Walker2dV5", 1000, dict(post_constraint=1, legacy_healthy_reward=0)),
     "Hopper-v4": ("Hopper", 1000, {}),
     "Hopper-v5": ("Hopper", 1000, dict(post_constraint=1, legacy_healthy_reward=0)),
     "Swimmer-v4": ("Swimmer", 1000, {}),
