@@ -26,11 +26,16 @@ sys.path.insert(0, ROOT)
 ACTION_HI = {"Humanoid": 0.4, "HumanoidStandup": 0.4, "Pusher": 2.0}
 
 
-def cpu_baseline(task="HalfCheetah", target_s=15.0, action_hi=1.0):
-    """Oracle ("port": oracle/mjcpu fp64 restatement) on a bounded sample of the
-    same workload, envs spread over ALL host cores with OpenMP (the analogue of
-    the reference's worker threads).  The reference itself cannot run: mj_step
-    lives in un-vendored MuJoCo 3.6.0."""
+def cpu_baseline(task="HalfCheetah", target_s=12.0, action_hi=1.0):
+    """CPU baseline on a bounded sample of the same workload, all host cores.
+
+    Where oracle/_ref/libref_mujoco.so travelled (built in the container that holds
+    /root/reference): the reference's OWN AsyncEnvPool thread pool and task wrapper
+    (envpool/core/async_envpool.h, envpool/mujoco/gym/*.h compiled in place), num_threads = cores,
+    sync Send / Recv loop -- over the oracle/mjcpu fp64 engine, because mj_step itself lives in
+    un-vendored MuJoCo 3.6.0 ("our fp64 CPU restatement inside the reference
+    threadpool on all cores").  The engine does the arithmetic, so kind stays "port".
+    Otherwise: the plain port, envs spread over the cores with OpenMP."""
     import ctypes
     import subprocess
 
@@ -38,13 +43,19 @@ def cpu_baseline(task="HalfCheetah", target_s=15.0, action_hi=1.0):
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "port"], check=True)
+    from oracle import orc
     from oracle.orc import Oracle
 
     probe = Oracle(task, 1, seed=0, max_episode_steps=1000)
     probe.lib.mjcpu_num_threads.restype = ctypes.c_int
     cores = int(probe.lib.mjcpu_num_threads())
     num_envs = 64 * cores
-    o = Oracle(task, num_envs, seed=0, max_episode_steps=1000)
+    threadpool = orc.have_ref_mujoco()
+    if threadpool:
+        o = Oracle(task, num_envs, seed=0, max_episode_steps=1000, kind="reference_mujoco",
+                   num_threads=cores)
+    else:
+        o = Oracle(task, num_envs, seed=0, max_episode_steps=1000)
     o.reset()
     rng = np.random.default_rng(0)
     act = rng.uniform(-action_hi, action_hi, size=(num_envs, o.action_elems))
@@ -53,12 +64,16 @@ def cpu_baseline(task="HalfCheetah", target_s=15.0, action_hi=1.0):
     steps = max(5, int(target_s / max(t / 20, 1e-6)))
     steps = min(steps, 20000)
     t = o.time_steps(steps, act)
+    how = (f"the reference's own AsyncEnvPool threadpool + task wrapper (oracle/_ref/libref_mujoco.so), "
+           f"num_threads={cores}, sync Send/Recv" if threadpool
+           else f"plain port, {cores} OpenMP threads")
     return {
         "value": num_envs * steps / t,
         "unit": "env-steps/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"oracle/mjcpu fp64, {num_envs} envs x {steps} steps, {cores} OpenMP threads, "
+        "runtime": "reference AsyncEnvPool + reference task wrapper" if threadpool else "OpenMP loop",
+        "sample": f"oracle/mjcpu fp64 engine inside {how}; {num_envs} envs x {steps} steps, "
                   f"{t:.1f}s (reference mj_step not runnable: MuJoCo 3.6.0 un-vendored)",
     }
 
@@ -74,7 +89,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--action-scale", type=float, default=None,
                     help="actions are uniform in [-s, s]; default: the task's action-space bound")
-    ap.add_argument("--min-time", type=float, default=1.0,
+    ap.add_argument("--min-time", type=float, default=5.0,
                     help="the timed region repeats the K-step block until it lasts at least this many "
                          "seconds (same repeat count on every rank); 0 = exactly K steps")
     ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE",
@@ -189,6 +204,7 @@ def main():
 
     reset_ms = None
     numpy_api = None
+    gpu_legs_s = elapsed  # wall time of the legs that keep the GPU busy (for the driver's busy sampler)
     if world == 1:
         # (a) one step in which EVERY env resets (mt19937 draws + state init + reset frame):
         #     the spike an episode boundary costs, outside the steady-state figure above
@@ -213,6 +229,7 @@ def main():
             pool.send(ids, hact[i % 4])
             pool.recv()
         dt_np = time.perf_counter() - t1
+        gpu_legs_s += dt_np
         numpy_api = {"value": n * k_np / dt_np, "unit": "env-steps/s", "ms_per_step": 1e3 * dt_np / k_np,
                      "steps": k_np, "note": "send(numpy) + recv() -> numpy, PCIe inclusive"}
 
@@ -244,12 +261,13 @@ def main():
             cycle(i)
         apool.synchronize()
         ta = time.perf_counter() - ta
-        k_async = max(8, int(np.ceil(0.5 / max(ta / 8, 1e-6))))
+        k_async = max(8, int(np.ceil(2.0 / max(ta / 8, 1e-6))))
         ta = time.perf_counter()
         for i in range(k_async):
             cycle(i)
         apool.synchronize()
         ta = time.perf_counter() - ta
+        gpu_legs_s += ta
         async_mode = {"value": b * k_async / ta, "unit": "env-steps/s", "batch_size": b, "batches_in_flight": 2,
                       "steps": k_async, "ms_per_step": 1e3 * ta / k_async,
                       "note": "async recv_device -> send_device loop of batch_size rows (the reference benchmark's "
@@ -329,6 +347,24 @@ def main():
             roof = {"bound": "valu", **{k: valu[k] for k in ("achieved", "peak", "unit", "frac")},
                     "flops_per_env_step": valu["flops_per_env_step"],
                     "flops_source": valu["flops_source"], "traffic": traffic, "hbm": hbm}
+        # algorithmic flops per env-step from the instrumented fp64 restatement (tools/count_flops.py:
+        # oracle/mjcpu compiled with an operation-counting scalar, per stage M1-M9) next to the ISSUED
+        # figure above (wave instructions x 64 from PMC, which also counts frozen lanes, replicated
+        # work and partly filled waves)
+        try:
+            with open(os.path.join(ROOT, "profiles", "flops_algorithmic.json")) as f:
+                alg = json.load(f).get(args.task)
+        except OSError:
+            alg = None
+        if alg and kernel_ms > 0:
+            peak_tf = 78.6 if args.precision == "fp64" or fp64_only else 157.3
+            useful_tf = alg["flops_per_env_step"] * n / (kernel_ms * 1e-3) / 1e12
+            roof["flops_algorithmic"] = alg["flops_per_env_step"]
+            roof["frac_useful"] = useful_tf / peak_tf
+            roof["flops_algorithmic_source"] = (
+                "profiles/flops_algorithmic.json: oracle/mjcpu (general 3-D dense restatement) with an "
+                "operation-counting scalar, mean over a random-action rollout; the planar kernels exploit "
+                "the 2-D structure and can issue fewer")
         if stale:
             roof["stale"] = True  # profiles/pmc.json holds counts of an older build of this kernel: not used
         roof.update({"kernel": kbase, "kernel_ms": kernel_ms, "launches": launches,
@@ -361,6 +397,10 @@ def main():
                 "params": params,  # every engine key the pool was created with, --param overrides included
             },
             "roofline": roof,
+            # wall seconds of the GPU legs (timed sync region + numpy-API leg + async leg), which run
+            # BEFORE the cpu_baseline leg; kernel time inside the timed region = launches x kernel_ms
+            "gpu_active_s": gpu_legs_s,
+            "gpu_kernel_s_timed_region": kernel_ms * launches * 1e-3,
         }
         if world == 1:
             out["reset_step_ms"] = reset_ms

@@ -14,6 +14,12 @@
 #include "mjcpu.h"
 #include "mjmath.h"
 
+/* pipeline-stage markers of the operation-counting build (oracle/flopcount/count_real.h,
+ * -DMJC_COUNT_FLOPS: rows M1-M9 of SURVEY.md section 8a); nothing otherwise */
+#ifndef MJC_STAGE
+#define MJC_STAGE(k) ((void)0)
+#endif
+
 #define MINVAL 1e-15
 #define MINIMP 0.0001
 #define MAXIMP 0.9999
@@ -684,11 +690,16 @@ static void make_constraint(const mjc_model* m, mjc_data* d) {
 
 /* ---- fwdPosition ------------------------------------------------------------------ */
 void mjc_fwd_position(const mjc_model* m, mjc_data* d) {
+  MJC_STAGE(1);
   kinematics(m, d);
   com_pos(m, d);
+  MJC_STAGE(2);
   crb(m, d);
+  MJC_STAGE(3);
   collision(m, d);
+  MJC_STAGE(4);
   make_constraint(m, d);
+  MJC_STAGE(0);
 }
 
 /* ---- M5: mj_fwdVelocity = comVel + passive + rne ------------------------------------- */
@@ -1045,10 +1056,15 @@ static void fwd_constraint(const mjc_model* m, mjc_data* d) {
 
 void mjc_forward(const mjc_model* m, mjc_data* d) { /* mj_forward */
   mjc_fwd_position(m, d);
+  MJC_STAGE(5);
   fwd_velocity(m, d);
+  MJC_STAGE(6);
   fwd_actuation(m, d);
+  MJC_STAGE(7);
   fwd_acceleration(m, d);
+  MJC_STAGE(8);
   fwd_constraint(m, d);
+  MJC_STAGE(0);
 }
 
 /* mj_integratePos */
@@ -1122,6 +1138,7 @@ static void rk4(const mjc_model* m, mjc_data* d) {
     memcpy(Xv[i], d->qvel, sizeof(double) * nv);
     d->time = time + T[i - 1] * h;
     mjc_forward(m, d);
+    MJC_STAGE(9);
     memcpy(F[i], d->qacc, sizeof(double) * nv);
   }
   double dq[MJC_MAXV] = {0}, dv[MJC_MAXV] = {0};
@@ -1143,6 +1160,7 @@ static void rk4(const mjc_model* m, mjc_data* d) {
  * Pyramidal decode as mju_decodePyramid: normal = sum of the 2(dim-1) edge
  * forces, tangent_k = (f[2k] - f[2k+1]) * mu_k. */
 void mjc_rne_post_constraint(const mjc_model* m, mjc_data* d) {
+  MJC_STAGE(10);
   for (int b = 0; b < m->nbody; ++b) {
     for (int k = 0; k < 6; ++k) d->cfrc_ext[b][k] = 0;
   }
@@ -1172,15 +1190,18 @@ void mjc_rne_post_constraint(const mjc_model* m, mjc_data* d) {
       }
     }
   }
+  MJC_STAGE(0);
 }
 
 void mjc_step(const mjc_model* m, mjc_data* d) { /* mj_step */
   mjc_forward(m, d);
+  MJC_STAGE(9);
   if (m->integrator == MJC_INT_RK4) {
-    rk4(m, d);
+    rk4(m, d); /* its three further forward evaluations count under their own stages */
   } else {
     euler(m, d);
   }
+  MJC_STAGE(0);
   /* warmstart_rule 1: d->qacc is still that of the last forward evaluation */
   if (m->warmstart_rule == 1) memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * m->nv);
 }

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_line_schema():
     out = subprocess.run(
         [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2",
-         "--num-envs", "4096", "--no-cpu-baseline"],
+         "--num-envs", "4096", "--no-cpu-baseline", "--min-time", "1"],
         capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -33,13 +33,17 @@ def test_bench_line_schema():
         assert key in r, key
     assert r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     # value = env-steps of the timed window / its wall time; the window is whole K-step blocks and
-    # lasts at least --min-time (1 s by default) however small K is
+    # lasts at least --min-time (5 s by default, 1 s here) however small K is
     assert d["timed_steps"] % 6 == 0 and d["timed_steps"] >= 6
     assert d["timed_s"] >= 0.9, d["timed_s"]
     assert abs(d["ms_per_step"] * 1e-3 * d["timed_steps"] - d["timed_s"]) < 1e-6
     assert abs(d["value"] - 4096 * d["timed_steps"] / d["timed_s"]) / d["value"] < 1e-6
     assert d["roofline"]["launches"] == d["timed_steps"]
     assert d["config"]["params"] == {"precision": 1}
+    # the GPU legs run before the CPU baseline and their wall time is stated (the driver's busy sampler)
+    assert d["gpu_active_s"] >= d["timed_s"] and 0 < d["gpu_kernel_s_timed_region"] <= d["timed_s"]
+    # issued flops (PMC) and the algorithmic count of the instrumented restatement, side by side
+    assert r["flops_algorithmic"] > 1e4 and 0 < r["frac_useful"] < 1
     # the reference benchmark's own (async) loop beside the sync value: two batches of num_envs / 2 in flight
     am = d["async_mode"]
     assert am["batch_size"] == 2048 and am["batches_in_flight"] == 2 and am["value"] > 0
