@@ -235,7 +235,7 @@ class Pool {
   std::vector<hipEvent_t> join_ev_;      // one per compute stream (JoinCompute)
   size_t rr_{0};
   bool picked_{false};                   // WaitStream already chose the stream of the next launch
-  std::vector<uint8_t> busy_;            // host path: env is in a batch that was not received yet
+  std::vector<uint32_t> busy_;           // host path: rows of this env launched and not received yet (a count)
   std::vector<Batch*> frontier_;         // device path: batches handed out whose kernels may still run
   const int32_t* next_host_ids_{nullptr};  // ids of the launch being enqueued (for Batch::host_ids)
   bool next_identity_{false};

@@ -431,14 +431,23 @@ void Pool::PickStream(const int32_t* host_ids, int k, bool device_path, const vo
       frontier_[keep++] = b;
     }
     frontier_.resize(keep);
+    if (device_path) {
+      // ... and batches recv_device has NOT handed out yet (still in pending_): a device-path send whose ids
+      // do not continue a handed-out batch (identity ids, ids from elsewhere) may name their envs
+      for (Batch* b : pending_) {
+        if (b->stream != stream_ && hipEventQuery(b->done) != hipSuccess) {
+          EPA_HIP(hipStreamWaitEvent(stream_, b->done, 0));
+        }
+      }
+    }
     (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
   }
   if (!device_path) {
     const bool identity = host_ids == nullptr;
     for (int i = 0; i < k; ++i) {
       const int e = identity ? i : host_ids[i] - cfg_.env_id_offset;
-      if (busy_[(size_t)e]) join = true;
-      busy_[(size_t)e] = 1;
+      if (busy_[(size_t)e] != 0) join = true;  // rows of this env are still outstanding
+      ++busy_[(size_t)e];
     }
     next_host_ids_ = host_ids;
     next_identity_ = identity;
@@ -448,7 +457,12 @@ void Pool::PickStream(const int32_t* host_ids, int k, bool device_path, const vo
 
 void Pool::MarkIdle(Batch* b, int first, int count) {
   if (busy_.empty() || b->host_ids.empty()) return;
-  for (int i = first; i < first + count; ++i) busy_[(size_t)b->host_ids[(size_t)i]] = 0;
+  // one outstanding row less: an env sent twice before a recv stays marked until BOTH rows were received,
+  // so the send after the first recv is still joined behind the second launch
+  for (int i = first; i < first + count; ++i) {
+    uint32_t& c = busy_[(size_t)b->host_ids[(size_t)i]];
+    if (c > 0) --c;
+  }
 }
 
 Pool::Staging& Pool::NextStaging(size_t bytes) {
@@ -632,8 +646,11 @@ size_t Pool::RecvLayout(int rows, size_t* offsets, int n_keys) const {
 // RecvLayout(want); waits for completion.
 void Pool::CopyRowsToHost(char* dst, const std::vector<size_t>& off, int want) {
   size_t total = off.back() + Align((size_t)want * keys_.back().row_bytes());
-  // small batches: copy on the kernel stream itself (no event round trip)
-  hipStream_t cs = total >= kSplitStreamBytes ? d2h_stream_ : stream_;
+  // small batches of a single-stream pool: copy on the kernel stream itself (no event round trip).  With
+  // several compute streams `stream_` is whichever stream the NEWEST launch went to, not the producer of the
+  // rows being received: the copy would queue behind an unrelated step kernel, so those pools always use the
+  // download stream (ordered behind each batch's own `done` event below)
+  hipStream_t cs = (total >= kSplitStreamBytes || compute_.size() > 1) ? d2h_stream_ : stream_;
   int got = 0;
   while (got < want) {
     Batch* b = pending_.front();

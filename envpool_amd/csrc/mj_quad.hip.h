@@ -146,9 +146,11 @@ template <int CTRL>
 __device__ __forceinline__ int DppMov(int x) {
   // bound_ctrl = true: a quad_perm never reads out of bounds, and with full row/bank masks the compiler then
   // knows the `old` operand is dead -- with bound_ctrl = false every DPP move carries a `v_mov_b32 dst, 0` in
-  // front of it (864 of the 1116 DPP moves of the Humanoid kernel).  Measured: Ant +3 % without those moves;
-  // the Humanoid quad kernel 1.2 % SLOWER (its reductions sit in dependent chains, where the init moves were
-  // filling the two wait states a DPP read needs after a VALU write), so that TU keeps them (EPA_DPP_OLD_ZERO).
+  // front of it (864 of the 1116 DPP moves of the round-2 Humanoid kernel).  Measured: Ant +3 % without those
+  // moves.  The round-2 Humanoid quad kernel was 1.2 % slower without them and kept them (-DEPA_DPP_OLD_ZERO,
+  // profiles/r2u_bench.jsonl); since the hybrid-PGS rewrite of round 3 it is faster WITHOUT them
+  // (profiles/r3s_standup_hybrid_pgs.md: Humanoid 10.85 -> 9.97 ms with the leaner visits + bound_ctrl), so no
+  // TU of the Makefile defines EPA_DPP_OLD_ZERO any more; the switch stays for A/B builds.
 #ifdef EPA_DPP_OLD_ZERO
   return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false);
 #else

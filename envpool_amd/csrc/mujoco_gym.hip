@@ -355,11 +355,14 @@ class CheetahPool : public Pool {
     spread_ = cfg.Get("planar_spread", 1) != 0;  // extension key, see Launch
     // "planar_layout" (extension key): 1 = one env per lane (CheetahStepKernel), 2 / 4 = one env per
     // group of 2 / 4 lanes (mujoco_planar_lg.hip; fp64, HalfCheetah / Walker2d, frame_stack 1),
-    // 0 (default) = chosen HERE from the rows a launch of this pool normally has (batch_size in async
-    // mode, else num_envs): 2 lanes per env from 24576 rows up, 4 below (profiles/r3i_lane_group_sweep.txt:
+    // 0 (default) = chosen HERE from the rows this pool normally has in flight (num_envs in sync mode,
+    // min(num_envs, 4 x batch_size) in async mode, see below): 2 lanes per env from 24576 rows up, 4 below
+    // (profiles/r3i_lane_group_sweep.txt:
     // N = 32768: 2.5e8 vs 2.0e8, N = 16384: 1.3e8 vs 1.7e8).  Fixed per pool, not per launch: the two
     // layouts sum the contact rows in different orders, and an env's bits must not depend on how
-    // many other envs a particular send happens to carry.
+    // many other envs a particular send happens to carry.  It DOES depend on num_envs / batch_size of
+    // the pool (to rounding: the two layouts agree with the oracle to 1e-9 each, tests/test_gpu_mujoco.py);
+    // pass planar_layout explicitly where two pools of different shape must agree bit for bit.
     layout_ = (int)cfg.Get("planar_layout", 0);
     if (layout_ != 0 && layout_ != 1 && layout_ != 2 && layout_ != 4) {
       throw std::invalid_argument("planar_layout must be 0, 1, 2 or 4");

@@ -68,7 +68,11 @@ typedef struct epa_pool epa_pool;
  *   "planar_layout" HalfCheetah / Walker2d, fp64: lanes per env of the step kernel -- 2 or 4 (one env per
  *                 lane group, mujoco_planar_lg.hip), 1 (one env per lane, mujoco_gym.hip), 0 (default)
  *                 chosen once per pool: 2 from 24576 rows up, else 4 (rows = num_envs in sync mode,
- *                 min(num_envs, 4 x batch_size) in async mode: what is in flight on the compute streams)
+ *                 min(num_envs, 4 x batch_size) in async mode: what is in flight on the compute streams).
+ *                 The two layouts sum the contact rows in different orders: with the default, an env's
+ *                 low-order bits therefore depend on the pool's num_envs / batch_size (never on the rows
+ *                 of a particular send); set the key explicitly where pools of different shape must agree
+ *                 bit for bit.  Each layout is within 1e-9 of the oracle per env-step.
  *   "planar_waves" lane-group kernel: register budget for 1 (default) or 2 waves per SIMD
  *   "planar_lpt"  lane-group kernel: 1 (default) whole-pool launches serve the chunks of envs slowest
  *                 first, by their duration in the previous launch; 0 index order.  Never changes results.

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/kernel_resources.sh <tu.hip> [extra hipcc flags...]   (mujoco_humanoid4.hip: -mllvm -disable-machine-licm -DEPA_DPP_OLD_ZERO, as in the Makefile)
+# usage: tools/kernel_resources.sh <tu.hip> [extra hipcc flags...]   (mujoco_humanoid4.hip: -mllvm -disable-machine-licm, as in the Makefile)
 # Compiles the device side of one translation unit for gfx950 and prints one line
 # per kernel: VGPRs / AGPRs / SGPR spills / scratch bytes per lane / LDS / occupancy.
 set -e
