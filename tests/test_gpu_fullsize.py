@@ -186,3 +186,48 @@ def test_classic_config2_size(name):
     if name in ("CartPole-v1", "FrozenLake-v1"):  # the others rarely end an episode within the horizon
         assert n_done > 0  # auto-resets happened at full size
     print(f"{name} N={N} vs oracle kind={orc.kind}: {steps} steps, {n_done} episode ends")
+
+
+# ---------------------------------------------------------------------------
+# Headline-size parity on MID-EPISODE states (feet down, joint limits active): the oracle follows a
+# random rollout of the tail envs for 400 steps; at steps 200, 240, ... 400 its state is forced
+# into the tail rows of the full-size launch and one env-step of both is compared at the
+# teacher-forced bar (1e-9).  The reset-adjacent test above never sees these states.
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("task,n,adim,params", [
+    ("HalfCheetah", 65536, 6, {"precision": 1}),
+    ("Walker2d", 65536, 6, {"precision": 1}),
+    ("Ant", 32768, 8, None),
+])
+def test_full_size_mid_episode_states(task, n, adim, params):
+    rng = np.random.default_rng(5)
+    big = DevicePool(task, n, seed=3, max_episode_steps=1000, params=params)
+    orc = Oracle(task, TAIL, seed=3 + n - TAIL, max_episode_steps=1000)
+    tail = slice(n - TAIL, n)
+    tail_ids = np.arange(n - TAIL, n, dtype=np.int32)
+    _reset(big), orc.reset()
+    for _ in range(3):  # the other rows leave their reset states too
+        _step(big, rng.uniform(-1, 1, size=(n, adim)))
+    worst, checked, contacts = 0.0, 0, 0
+    for t in range(1, 401):
+        act_tail = rng.uniform(-1, 1, size=(TAIL, adim))
+        if t >= 200 and t % 40 == 0:
+            st = orc.get_state()
+            big.set_state(st, tail_ids)
+            act = rng.uniform(-1, 1, size=(n, adim))
+            act[tail] = act_tail
+            a, o = _step(big, act), orc.step(act_tail)
+            np.testing.assert_allclose(a["obs"][tail], o["obs"], rtol=1e-9, atol=1e-10, err_msg=f"{task} t={t}")
+            for key in ("done", "trunc", "elapsed_step", "step_type"):
+                np.testing.assert_array_equal(a[key].ravel()[tail], o[key].ravel(), err_msg=f"{key}@{t}")
+            np.testing.assert_allclose(a["reward"].ravel()[tail], o["reward"].ravel(), rtol=1e-6, atol=1e-6)
+            worst = max(worst, float(np.abs(a["obs"][tail] - o["obs"]).max()))
+            checked += 1
+            # the states are mid-episode ones: most envs are past step 20 of their episode
+            contacts += int((o["elapsed_step"].ravel() > 20).sum())
+            assert np.isfinite(a["obs"]).all()
+        else:
+            orc.step(act_tail)
+    assert checked == 6 and contacts > 0
+    print(f"{task} N={n}: worst teacher-forced |d obs| on mid-episode states = {worst:.3e} "
+          f"({contacts} env-steps past step 20 of their episode)")
