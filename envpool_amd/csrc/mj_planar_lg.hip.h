@@ -40,6 +40,19 @@
 
 #include "mj_cheetah.hip.h"  // EPA_HD, static_for, V3 / In4 algebra, Rsqrt, SinCos, WaveAny, CheetahModel
 
+// Stage timers of the diagnostic build (-DEPA_LG_TIMERS, tools/build_alt_lg.sh; never in the product
+// library): EPA_LG_TICK(cx, K) books the cycles since the previous tick to category K of the wave
+// (0 load / store / integrate, 1 kinematics + smooth forces + constraint rows, 2 pass over the rows +
+// group sums + stop tests, 3 factor / solve / products with M, 4 line search), EPA_LG_COUNT(cx, K)
+// counts wave-level loop trips (0 Newton trips, 1 line-search evaluations, 2 forward passes).
+#if defined(EPA_LG_TIMERS) && defined(__HIP_DEVICE_COMPILE__)
+#define EPA_LG_TICK(cx, K) (cx).template TickEnd<K>()
+#define EPA_LG_COUNT(cx, K) (cx).template Count<K>()
+#else
+#define EPA_LG_TICK(cx, K) ((void)0)
+#define EPA_LG_COUNT(cx, K) ((void)0)
+#endif
+
 namespace epa {
 namespace mj {
 namespace plg {
@@ -930,6 +943,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
     static_for<0, kLTri>([&](auto kc) { H[decltype(kc)::value] = V(0); });
     static_for<0, kLV>([&](auto ic) { gc[decltype(ic)::value] = V(0); });
     U mask = LT::Fill(0u);
+    EPA_LG_TICK(cx, 3);
     RowsPass<KL, true>(m, cx, p, lim, ends, qacc, gc, H, mask);
     // group sums: the torso entries collect every lane of the env, the leg entries the leg's lanes
     static_for<0, kLV>([&](auto jc) {
@@ -956,7 +970,9 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
     const B stop = (gn2 <= gstop2) | (full_step & same) |
                    ((prev_gn2 >= V(0)) & (gn2 <= gfloor2) & (gn2 >= V(0.0625) * prev_gn2));
     live = live & !stop;
+    EPA_LG_TICK(cx, 2);
     if (!AnyWave(live)) break;
+    EPA_LG_COUNT(cx, 0);
     iter += Sel(live, V(1), V(0));
     prev_gn2 = gn2;
     prev_mask = mask;
@@ -977,7 +993,9 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
     const V ls_tol = V(T(1e-10)) * Abs(g1);
     B searching = live;
     B exact = LT::False();
+    EPA_LG_TICK(cx, 3);
     for (int ls = 0; ls < 24; ++ls) {
+      EPA_LG_COUNT(cx, 1);
       V d1p = V(0), d2p = V(0);
       U mask1 = LT::Fill(0u);
       if (ls == 0) {
@@ -1005,6 +1023,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
       alpha = Sel(searching, next, alpha);
       if (!AnyWave(searching)) break;
     }
+    EPA_LG_TICK(cx, 4);
     const V step = Sel(live, alpha, V(0));
     static_for<0, kLV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
@@ -1046,13 +1065,17 @@ template <int KL, typename T, typename V, typename Cx>
 EPA_HD V Forward(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, const V* q, const V* v,
                  V* warm, const V* ctrl, Pos<V>& p, V* qacc, V* Ma, V* grad) {
   cx.Refresh();
+  EPA_LG_TICK(cx, 0);
+  EPA_LG_COUNT(cx, 2);
   Kinematics<KL>(m, cx, q, p);
   V qfrc_smooth[kLV];
   SmoothForces<KL>(m, cx, p, q, v, ctrl, qfrc_smooth);
   LimitRows<V> lim;
   const unsigned ends = MakeConstraint<KL>(m, cx, p, q, v, lim);
   static_for<0, kLV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
+  EPA_LG_TICK(cx, 1);
   const V iters = Solve<KL>(m, cx, p, lim, ends, qfrc_smooth, cfg, qacc, Ma, grad);
+  EPA_LG_TICK(cx, 2);
   static_for<0, kLV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
   return iters;
 }

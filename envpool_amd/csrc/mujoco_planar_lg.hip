@@ -41,7 +41,24 @@ struct DevCx {
   // constants are read from LDS where they are used (~90 ds_read_b64 per forward pass, ~100 cycles
   // each, off the VALU); from global memory every one of them was an L2 round trip.
   __device__ __forceinline__ void Refresh() { asm volatile("" : "+v"(tab)); }
+#ifdef EPA_LG_TIMERS  // diagnostic build only (mj_planar_lg.hip.h: EPA_LG_TICK)
+  long long t_last{0};
+  long long acc[5]{0, 0, 0, 0, 0};
+  unsigned cnt[3]{0, 0, 0};
+  template <int K>
+  __device__ __forceinline__ void TickEnd() {
+    const long long now = clock64();
+    acc[K] += now - t_last;
+    t_last = now;
+  }
+  template <int K>
+  __device__ __forceinline__ void Count() { ++cnt[K]; }
+#endif
 };
+#ifdef EPA_LG_TIMERS
+// [0..4] cycles per category, [5..7] trip counters, [8] chunks, [9] cycles of whole chunks
+__device__ unsigned long long g_lg_timers[16];
+#endif
 
 // Everything the kernel is given, as ONE by-value argument: it sits at offset 0 of the kernarg
 // segment and is read from there (scalar loads) where it is needed, see KernArgs().
@@ -180,6 +197,10 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
       for (int i = 0; i < kNU; ++i) ctrl_cost += task.ctrl_cost_weight * act[i] * act[i];
     }
     DevCx<KL> cx{(LdsConstDouble*)tab_lds + c, lds_buf + lane};
+#ifdef EPA_LG_TIMERS
+    cx.t_last = clock64();
+    const long long t_chunk0 = cx.t_last;
+#endif
     double iters = 0.0;
     for (int s = 0; s < task.frame_skip; ++s) {  // mujoco_env.h:142-144
       if constexpr (kWalker) {
@@ -188,6 +209,15 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
         iters += plg::StepEuler<KL>(m, scfg, cx, q, v, w, ctrl);
       }
     }
+#ifdef EPA_LG_TIMERS
+    cx.template TickEnd<0>();
+    if (__builtin_amdgcn_readfirstlane(lane) == lane) {  // the wave's first active lane
+      for (int i = 0; i < 5; ++i) atomicAdd(&g_lg_timers[i], (unsigned long long)cx.acc[i]);
+      for (int i = 0; i < 3; ++i) atomicAdd(&g_lg_timers[5 + i], (unsigned long long)cx.cnt[i]);
+      atomicAdd(&g_lg_timers[8], 1ull);
+      atomicAdd(&g_lg_timers[9], (unsigned long long)(clock64() - t_chunk0));
+    }
+#endif
     const double x_after = x_before + q[0];
     xv = (x_after - x_before) / task.dt;  // half_cheetah.h:148-149
     xpos = x_after;
@@ -379,6 +409,21 @@ void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots
   }
 #undef EPA_LG
 }
+
+#ifdef EPA_LG_TIMERS
+}  // namespace epa
+// diagnostic build only: read (and clear) the stage timers
+extern "C" int epa_debug_lg_timers(unsigned long long* out16, int clear) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(epa::g_lg_timers), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (clear) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(epa::g_lg_timers), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+namespace epa {
+#endif
 
 size_t PlanarLgOrderBytes(int cap) { return sizeof(unsigned) * 3 * LptGenWords(cap); }
 

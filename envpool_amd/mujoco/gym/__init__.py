@@ -7,7 +7,8 @@ Spec tables restate `HalfCheetahEnvFns` (half_cheetah.h:31-62), `AntEnvFns`
 `ReacherEnvFns` (reacher.h:30-65), `SwimmerEnvFns` (swimmer.h:30-66), `HopperEnvFns` (hopper.h:30-70),
 `HumanoidEnvFns` (humanoid.h:30-82), `HumanoidStandupEnvFns` (humanoid_standup.h:30-73); the pixel
 variants are out of scope.  `precision` is an extension key: 64 (default, the
-reference's mjtNum=double) or 32 (fp32 arithmetic, fp64 state and I/O).
+reference's mjtNum=double); Ant also accepts 32 (fp32 arithmetic, fp64 state and I/O, within
+1e-5).  The planar families' fp32 mode was removed in round 4 (outside 1e-5, slower than fp64).
 """
 
 import numpy as np
@@ -29,6 +30,14 @@ def _precision(c):
     if c["precision"] not in (32, 64):
         raise ValueError("precision must be 32 or 64")
     return 1 if c["precision"] == 64 else 0
+
+
+def _precision64(c):
+    """HalfCheetah / Walker2d / Hopper: fp64 only (their fp32 arithmetic mode is gone)."""
+    if c["precision"] != 64:
+        raise ValueError("precision must be 64 for this family (the fp32 mode of the planar "
+                         "kernels was removed: outside 1e-5 and slower than fp64)")
+    return 1
 
 
 _HalfCheetah = FamilyDef(
@@ -59,7 +68,7 @@ _HalfCheetah = FamilyDef(
         "ctrl_cost_weight": c["ctrl_cost_weight"],
         "forward_reward_weight": c["forward_reward_weight"],
         "reset_noise_scale": c["reset_noise_scale"],
-        "precision": _precision(c),
+        "precision": _precision64(c),
     },
     # the model constants are compiled in from half_cheetah_envpool.xml
     unsupported={"xml_file": "half_cheetah.xml"},
@@ -167,7 +176,7 @@ _Walker2d = FamilyDef(
         "velocity_min": c["velocity_min"], "velocity_max": c["velocity_max"],
         "reset_noise_scale": c["reset_noise_scale"],
         "xml_v5": _walker_xml(c),
-        "precision": _precision(c),
+        "precision": _precision64(c),
     },
 )
 
@@ -369,7 +378,7 @@ _Hopper = FamilyDef(
         "healthy_angle_max": c["healthy_angle_max"],
         "healthy_z_min": c["healthy_z_min"],
         "reset_noise_scale": c["reset_noise_scale"],
-        "precision": _precision(c),
+        "precision": _precision64(c),
     },
     unsupported={"xml_file": "hopper.xml"},
 )

@@ -56,7 +56,8 @@ typedef struct epa_pool epa_pool;
  * the reference's `XxxEnvFns::DefaultConfig()` keys (e.g. "version" for
  * Pendulum, "size" for FrozenLake, "frame_skip", "ctrl_cost_weight", ...).
  * Unknown keys are ignored.  Engine extensions (not reference keys):
- *   "precision"   planar / Ant MuJoCo kernels: 1 fp64 (default), 0 fp32 (throughput mode)
+ *   "precision"   Ant: 1 fp64 (default), 0 fp32 arithmetic (meets 1e-5).  HalfCheetah / Walker2d / Hopper: only 1
+ *                 (their fp32 mode was removed in round 4: outside 1e-5 and slower than the fp64 kernel)
  *   "xml_v5"      Walker2d / Pusher: 1 selects the *_v5 model (the reference's xml_file)
  *   "planar_spread" HalfCheetah / Walker2d / Hopper / Pusher: 1 (default) a batch of 16 .. 64 (Pusher: 32 .. 64) envs
  *                 per SIMD is spread over all SIMDs with 16 / 32 / 48 envs per wave; 0 always 64 envs per wave

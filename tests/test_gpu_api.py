@@ -88,7 +88,7 @@ def test_send_recv_async_api():
     assert seen == set(range(16))
 
 
-@pytest.mark.parametrize("task,adim,precision", [("HalfCheetah-v4", 6, 32), ("Ant-v4", 8, 64),
+@pytest.mark.parametrize("task,adim,precision", [("HalfCheetah-v4", 6, 64), ("Hopper-v4", 3, 64), ("Ant-v4", 8, 64),
                                                  ("Ant-v4", 8, 32), ("Humanoid-v5", 17, None),
                                                  ("HumanoidStandup-v4", 17, None)])
 def test_mujoco_run_to_run_determinism(task, adim, precision):
@@ -105,6 +105,18 @@ def test_mujoco_run_to_run_determinism(task, adim, precision):
         r0, r1 = e0.step(a), e1.step(a)
         np.testing.assert_array_equal(r0[0], r1[0])
         np.testing.assert_array_equal(r0[1], r1[1])
+
+
+def test_planar_fp32_mode_is_gone():
+    """precision=32 on the planar families is refused loudly (removed in round 4: outside 1e-5 and
+    slower than the fp64 lane-group kernel); Ant keeps its fp32 mode."""
+    for task in ("HalfCheetah-v4", "Walker2d-v4", "Hopper-v4"):
+        with pytest.raises(ValueError, match="precision must be 64"):
+            envpool.make_gym(task, num_envs=4, precision=32)
+    from envpool_amd.core.device_pool import DevicePool
+    with pytest.raises(Exception, match="precision"):
+        DevicePool("HalfCheetah", 4, seed=0, max_episode_steps=10, params={"precision": 0})
+    envpool.make_gym("Ant-v4", num_envs=4, precision=32).reset()
 
 
 def test_halfcheetah_api_shapes_and_determinism():

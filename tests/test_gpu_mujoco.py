@@ -3,10 +3,9 @@ fp64 oracle (oracle/mjcpu — parity of that oracle vs real MuJoCo is UNPINNED,
 see oracle/mjcpu/mjcpu.h).
 
 Tolerances (stated): teacher-forced per env-step (5 mj_steps):
-  precision=fp64 kernel (default): obs rtol 1e-9 / atol 1e-10
-  precision=fp32 kernel : |d obs| median <= 2e-5, p99 <= 5e-4, max <= 1e-2
-      (fp32 arithmetic on a cond~1e4 Newton system; the input-rounding
-       sensitivity of the step map itself is ~10x below these figures)
+  fp64 kernel (the only one since round 4): obs rtol 1e-9 / atol 1e-10
+  (the fp32 arithmetic mode of rounds 1-3 -- |d obs| p99 1.6e-4 on a cond~1e4 Newton system, outside
+   the 1e-5 bar, and slower than the fp64 lane-group kernel -- was removed)
 """
 import numpy as np
 import pytest
@@ -34,7 +33,7 @@ def hip_step(pool, act):
     return pool.recv_dict()
 
 
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [1])
 def test_reset_matches_oracle(precision):
     pool, orc = make_pair(64, 5, precision)
     a, b = hip_reset(pool), orc.reset()
@@ -44,25 +43,6 @@ def test_reset_matches_oracle(precision):
     for k in ("elapsed_step", "done", "reward", "discount", "step_type", "trunc",
               "info:env_id"):
         np.testing.assert_array_equal(a[k].ravel(), b[k].ravel())
-
-
-def test_teacher_forced_step_fp32_distribution():
-    n, steps = 256, 120
-    pool, orc = make_pair(n, 9, 0)
-    hip_reset(pool), orc.reset()
-    rng = np.random.default_rng(3)
-    errs = []
-    for t in range(steps):
-        pool.set_state(orc.get_state())
-        act = rng.uniform(-1.2, 1.2, size=(n, 6))
-        a, b = hip_step(pool, act), orc.step(act)
-        errs.append(np.abs(a["obs"] - b["obs"]).max(axis=1))
-        np.testing.assert_allclose(a["reward"].ravel(), b["reward"].ravel(),
-                                   rtol=1e-3, atol=2e-2)
-    errs = np.concatenate(errs)
-    med, p99, mx = np.median(errs), np.percentile(errs, 99), errs.max()
-    print(f"fp32 teacher-forced |d obs|: median {med:.2e} p99 {p99:.2e} max {mx:.2e}")
-    assert med <= 2e-5 and p99 <= 5e-4 and mx <= 1e-2
 
 
 @pytest.mark.parametrize("precision,rtol,atol", [(1, 1e-9, 1e-10)])
@@ -87,7 +67,7 @@ def test_teacher_forced_step(precision, rtol, atol):
     print(f"precision={precision}: worst teacher-forced |d obs| = {worst:.3e}")
 
 
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [1])
 def test_free_running_horizon(precision):
     n, steps = 128, 300
     pool, orc = make_pair(n, 1, precision)
@@ -125,11 +105,10 @@ def test_episode_bookkeeping_and_autoreset():
     assert b["elapsed_step"].max() <= 7
 
 
-def test_fp32_energy_sanity():
-    """The fp32 kernel must stay finite and bounded over a long random rollout."""
+def test_long_rollout_stays_bounded():
+    """The kernel must stay finite and bounded over a long random rollout."""
     n = 1024
-    pool = DevicePool("HalfCheetah", n, seed=0, max_episode_steps=1000,
-                      params={"precision": 0})
+    pool = DevicePool("HalfCheetah", n, seed=0, max_episode_steps=1000)
     hip_reset(pool)
     rng = np.random.default_rng(0)
     for t in range(400):
@@ -227,7 +206,7 @@ def make_walker_pair(n, seed, precision, task="Walker2d", max_steps=1000):
     return pool, orc
 
 
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [1])
 def test_walker_reset_matches_oracle(precision):
     pool, orc = make_walker_pair(64, 5, precision)
     a, b = hip_reset(pool), orc.reset()
@@ -264,25 +243,6 @@ def test_walker_teacher_forced_step(task):
         worst = max(worst, float(np.abs(a["obs"] - b["obs"]).max()))
     print(f"{task} fp64: worst teacher-forced |d obs| = {worst:.3e}")
     assert seen_term  # random actions make the walker fall within ~30 steps
-
-
-def test_walker_teacher_forced_fp32_distribution():
-    n, steps = 256, 100
-    pool, orc = make_walker_pair(n, 9, 0)
-    hip_reset(pool), orc.reset()
-    rng = np.random.default_rng(3)
-    errs = []
-    for t in range(steps):
-        pool.set_state(orc.get_state())
-        act = rng.uniform(-1.2, 1.2, size=(n, 6))
-        a, b = hip_step(pool, act), orc.step(act)
-        errs.append((np.abs(a["obs"] - b["obs"]) / (1.0 + np.abs(b["obs"]))).max(axis=1))
-    errs = np.concatenate(errs)
-    med, p99, mx = np.median(errs), np.percentile(errs, 99), errs.max()
-    print(f"Walker2d fp32 teacher-forced rel |d obs|: median {med:.2e} p99 {p99:.2e} max {mx:.2e}")
-    # fp32 arithmetic through 16 Newton solves with stiff default contacts
-    # (solimp .9 .95 .001): distribution asserted, max only reported
-    assert med <= 5e-5 and p99 <= 2e-3
 
 
 def test_walker_deterministic():
@@ -618,21 +578,7 @@ def test_hopper_matches_oracle():
     assert seen_term and self_hits > 100 and compared > 0.8 * n * 100
 
 
-def test_hopper_fp32_distribution_and_determinism():
-    n, steps = 256, 60
-    pool, orc = make_hopper_pair(n, 9, 0)
-    hip_reset(pool), orc.reset()
-    rng = np.random.default_rng(3)
-    errs = []
-    for t in range(steps):
-        pool.set_state(orc.get_state())
-        act = rng.uniform(-1.2, 1.2, size=(n, 3))
-        a, b = hip_step(pool, act), orc.step(act)
-        errs.append((np.abs(a["obs"] - b["obs"]) / (1.0 + np.abs(b["obs"]))).max(axis=1))
-    errs = np.concatenate(errs)
-    med, p99 = np.median(errs), np.percentile(errs, 99)
-    print(f"Hopper fp32 teacher-forced rel |d obs|: median {med:.2e} p99 {p99:.2e} max {errs.max():.2e}")
-    assert med <= 5e-5 and p99 <= 2e-3
+def test_hopper_determinism():
     outs = []
     for _ in range(2):
         p2 = DevicePool("Hopper", 512, seed=3, max_episode_steps=1000, params={"precision": 1})
@@ -858,12 +804,13 @@ def test_product_library_refuses_debug_switches():
 
 
 # ---- one env per LANE GROUP (mj_planar_lg.hip.h): HalfCheetah / Walker2d, fp64 --------------------
-@pytest.mark.parametrize("layout,waves", [(2, 2), (2, 1), (4, 2), (4, 1)])
+@pytest.mark.parametrize("layout,waves", [(2, 1), (4, 2), (4, 1)])
 @pytest.mark.parametrize("task,otask", [("HalfCheetah", "HalfCheetah"), ("Walker2d", "Walker2d"),
                                         ("Walker2d", "Walker2dV5")])
 def test_planar_lane_group_matches_oracle(task, otask, layout, waves):
-    """Every variant of the lane-group kernel (2 or 4 lanes per env; register budget for 1 or 2 waves per
-    SIMD), teacher forced against the oracle: obs rtol 1e-9 / atol 1e-10, info keys, bookkeeping exact.
+    """Every variant of the lane-group kernel (2 or 4 lanes per env; at 4 lanes the register budget for 1 or
+    2 waves per SIMD -- at 2 lanes LDS allows one wave whatever the budget, so (2, 2) is the (2, 1) code and is
+    not a case), teacher forced against the oracle: obs rtol 1e-9 / atol 1e-10, info keys, bookkeeping exact.
     n = 200 leaves the last wave partially filled; resets are bit-identical to the one-env-per-lane
     kernel's (the group's first lane makes the same mt19937 draws)."""
     n, steps = 200, 60
