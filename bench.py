@@ -50,31 +50,40 @@ def cpu_baseline(task="HalfCheetah", target_s=12.0, action_hi=1.0):
     probe.lib.mjcpu_num_threads.restype = ctypes.c_int
     cores = int(probe.lib.mjcpu_num_threads())
     num_envs = 64 * cores
-    threadpool = orc.have_ref_mujoco()
-    if threadpool:
-        o = Oracle(task, num_envs, seed=0, max_episode_steps=1000, kind="reference_mujoco",
-                   num_threads=cores)
-    else:
-        o = Oracle(task, num_envs, seed=0, max_episode_steps=1000)
-    o.reset()
     rng = np.random.default_rng(0)
-    act = rng.uniform(-action_hi, action_hi, size=(num_envs, o.action_elems))
-    o.time_steps(5, act)  # warm caches / leave the reset steps behind
-    t = o.time_steps(20, act)
-    steps = max(5, int(target_s / max(t / 20, 1e-6)))
-    steps = min(steps, 20000)
-    t = o.time_steps(steps, act)
-    how = (f"the reference's own AsyncEnvPool threadpool + task wrapper (oracle/_ref/libref_mujoco.so), "
-           f"num_threads={cores}, sync Send/Recv" if threadpool
-           else f"plain port, {cores} OpenMP threads")
+
+    def leg(o, budget_s):
+        o.reset()
+        act = rng.uniform(-action_hi, action_hi, size=(num_envs, o.action_elems))
+        o.time_steps(5, act)  # warm caches / leave the reset steps behind
+        t = o.time_steps(20, act)
+        steps = min(20000, max(5, int(budget_s / max(t / 20, 1e-6))))
+        t = o.time_steps(steps, act)
+        return num_envs * steps / t, steps, t
+
+    threadpool = orc.have_ref_mujoco()
+    # the same engine in a bare OpenMP loop over the envs (no queues): what the cores can do at best
+    omp_value, omp_steps, omp_t = leg(Oracle(task, num_envs, seed=0, max_episode_steps=1000),
+                                      target_s / 3 if threadpool else target_s)
+    omp = {"value": omp_value, "unit": "env-steps/s", "runtime": "OpenMP loop over the envs",
+           "sample": f"{num_envs} envs x {omp_steps} steps, {cores} OpenMP threads, {omp_t:.1f}s"}
+    if not threadpool:
+        return {**omp, "cores": cores, "kind": "port",
+                "sample": "oracle/mjcpu fp64 engine, plain port; " + omp["sample"] +
+                          " (reference mj_step not runnable: MuJoCo 3.6.0 un-vendored)"}
+    value, steps, t = leg(Oracle(task, num_envs, seed=0, max_episode_steps=1000, kind="reference_mujoco",
+                                 num_threads=cores), 2 * target_s / 3)
     return {
-        "value": num_envs * steps / t,
+        "value": value,
         "unit": "env-steps/s",
         "cores": cores,
         "kind": "port",
-        "runtime": "reference AsyncEnvPool + reference task wrapper" if threadpool else "OpenMP loop",
-        "sample": f"oracle/mjcpu fp64 engine inside {how}; {num_envs} envs x {steps} steps, "
-                  f"{t:.1f}s (reference mj_step not runnable: MuJoCo 3.6.0 un-vendored)",
+        "runtime": "reference AsyncEnvPool + reference task wrapper",
+        "sample": f"oracle/mjcpu fp64 engine inside the reference's own AsyncEnvPool threadpool + task wrapper "
+                  f"(oracle/_ref/libref_mujoco.so), num_threads={cores}, sync Send/Recv; {num_envs} envs x {steps} "
+                  f"steps, {t:.1f}s (reference mj_step not runnable: MuJoCo 3.6.0 un-vendored; moodycamel's "
+                  f"semaphore is a spin-then-block shim)",
+        "openmp_port": omp,
     }
 
 
@@ -85,7 +94,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--num-envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--task", default="HalfCheetah")
-    ap.add_argument("--precision", default="fp64", choices=["fp32", "fp64"])
+    ap.add_argument("--precision", default="fp64", choices=["fp32", "fp64"],
+                    help="fp32 exists for --task Ant only (the planar families are fp64 only since round 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--action-scale", type=float, default=None,
                     help="actions are uniform in [-s, s]; default: the task's action-space bound")
@@ -125,6 +135,8 @@ def main():
     from envpool_amd.core.device_pool import DevicePool
 
     n = args.num_envs
+    if args.precision == "fp32" and args.task != "Ant":
+        raise SystemExit("--precision fp32: only the Ant kernel has an fp32 arithmetic mode")
     params = {"precision": 1 if args.precision == "fp64" else 0}
     for kv in args.param:
         key, val = kv.split("=", 1)
@@ -285,7 +297,6 @@ def main():
                      "Humanoid": 4402, "HumanoidStandup": 4362, "Pusher": 842}[args.task]
         frame_skip = {"HalfCheetah": 5, "Ant": 5, "Walker2d": 4, "Hopper": 4,
                       "Humanoid": 5, "HumanoidStandup": 5, "Pusher": 5}[args.task]
-        # counted fp32 flops / env-step from the kernel's ISA
         achieved_gbs = alg_bytes * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # HBM traffic and flop counts come from the committed rocprofv3 PMC passes of
         # this same command (tools/profile_bench.sh -> profiles/pmc.json): PMC

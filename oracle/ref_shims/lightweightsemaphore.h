@@ -4,7 +4,9 @@
 // (envpool/core/action_buffer_queue.h:47-80, state_buffer.h:51,129,141,
 // circular_buffer.h:38-75): wait() -> bool, tryWait() -> bool, signal(n).
 // Spin-then-block, like upstream, so CPU-baseline timings are not penalised
-// by a pure mutex/condvar implementation.
+// by a pure mutex/condvar implementation; signal() touches the mutex only when a
+// waiter is (about to be) asleep, as upstream's does (a lock per signal serialised
+// the 128 workers of the GPU box's CPU baseline on this one mutex).
 #ifndef ORACLE_SHIM_LIGHTWEIGHTSEMAPHORE_H_
 #define ORACLE_SHIM_LIGHTWEIGHTSEMAPHORE_H_
 #include <atomic>
@@ -19,7 +21,7 @@ class LightweightSemaphore {
   explicit LightweightSemaphore(std::ptrdiff_t initial = 0) : count_(initial) {}
 
   bool tryWait() {
-    std::ptrdiff_t old = count_.load(std::memory_order_relaxed);
+    std::ptrdiff_t old = count_.load();  // seq_cst: pairs with signal()
     while (old > 0) {
       if (count_.compare_exchange_weak(old, old - 1, std::memory_order_acquire,
                                        std::memory_order_relaxed)) {
@@ -30,21 +32,27 @@ class LightweightSemaphore {
   }
 
   bool wait() {
-    for (int spin = 0; spin < 2000; ++spin) {
+    // upstream's waitWithPartialSpinning polls 10000 times without a system call, then blocks in the
+    // kernel.  In this sandbox a futex sleep / wake pair costs milliseconds (measured: with 10000 polls the
+    // reference's 4 workers sat in futex_wait 65 % of a Humanoid batch and 1, 2, 4, 8 threads all gave
+    // 3.0e3 env-steps/s; with long polling 7.1e3 / 1.05e4 / 1.45e4 at 2 / 4 / 8), which would bill the
+    // reference's runtime for the container.  So: poll ~10 ms worth before blocking -- the fairness rule
+    // SURVEY.md section 8d asks for ("vendor-equivalent spin semaphore").
+    for (int spin = 0; spin < 400000; ++spin) {
       if (tryWait()) return true;
-      if ((spin & 63) == 63) std::this_thread::yield();
+      __builtin_ia32_pause();
     }
     std::unique_lock<std::mutex> lk(mu_);
-    ++sleepers_;
-    cv_.wait(lk, [this] { return tryWait(); });
-    --sleepers_;
+    sleepers_.fetch_add(1);  // seq_cst: ordered against the count_ update of a concurrent signal()
+    cv_.wait(lk, [this] { return tryWait(); });  // the predicate is evaluated before the first block
+    sleepers_.fetch_sub(1);
     return true;
   }
 
   void signal(std::ptrdiff_t n = 1) {
-    count_.fetch_add(n, std::memory_order_release);
-    std::lock_guard<std::mutex> lk(mu_);
-    if (sleepers_ > 0) {
+    count_.fetch_add(n);  // seq_cst, see wait(): either the waiter sees the count or we see the sleeper
+    if (sleepers_.load() > 0) {
+      std::lock_guard<std::mutex> lk(mu_);
       if (n == 1) cv_.notify_one(); else cv_.notify_all();
     }
   }
@@ -53,7 +61,7 @@ class LightweightSemaphore {
   std::atomic<std::ptrdiff_t> count_;
   std::mutex mu_;
   std::condition_variable cv_;
-  int sleepers_{0};
+  std::atomic<int> sleepers_{0};
 };
 }  // namespace moodycamel
 #endif  // ORACLE_SHIM_LIGHTWEIGHTSEMAPHORE_H_

@@ -119,7 +119,7 @@ def test_ant_config4_shard_size():
 
 # ---------------------------------------------------------------------------
 # BASELINE.json config 3: HalfCheetah-v4, 8192 envs on one GPU.  Run in fp64 (the reference's
-# mjtNum; the fp32 arithmetic mode of the planar kernel is a throughput mode).
+# mjtNum; BASELINE's "fp32" wording predates the removal of the planar fp32 mode).
 # ---------------------------------------------------------------------------
 def test_halfcheetah_config3_every_env():
     """All 8192 envs of config 3 against the oracle, teacher forced, fp64: obs rtol 1e-9 / atol
@@ -217,11 +217,16 @@ def test_full_size_mid_episode_states(task, n, adim, params):
             act = rng.uniform(-1, 1, size=(n, adim))
             act[tail] = act_tail
             a, o = _step(big, act), orc.step(act_tail)
-            np.testing.assert_allclose(a["obs"][tail], o["obs"], rtol=1e-9, atol=1e-10, err_msg=f"{task} t={t}")
+            # rows whose env was done are RESET rows: fresh mt19937 draws, and the two generators are not
+            # in step here (set_state carries the physics state, not the generator) -- every other row
+            # is an env-step from the forced state
+            live = o["elapsed_step"].ravel() > 0
+            np.testing.assert_allclose(a["obs"][tail][live], o["obs"][live], rtol=1e-9, atol=1e-10,
+                                       err_msg=f"{task} t={t}")
             for key in ("done", "trunc", "elapsed_step", "step_type"):
                 np.testing.assert_array_equal(a[key].ravel()[tail], o[key].ravel(), err_msg=f"{key}@{t}")
             np.testing.assert_allclose(a["reward"].ravel()[tail], o["reward"].ravel(), rtol=1e-6, atol=1e-6)
-            worst = max(worst, float(np.abs(a["obs"][tail] - o["obs"]).max()))
+            worst = max(worst, float(np.abs(a["obs"][tail][live] - o["obs"][live]).max()))
             checked += 1
             # the states are mid-episode ones: most envs are past step 20 of their episode
             contacts += int((o["elapsed_step"].ravel() > 20).sum())

@@ -4,7 +4,10 @@ tools/build_alt_lg.sh lgtimers ... -DEPA_LG_TIMERS, copied over libenvpool_amd.s
     python tools/lg_stage_timers.py [task] [num_envs] [steps]
 """
 import ctypes
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import numpy as np
 import torch
