@@ -306,6 +306,9 @@ def main():
         lg_layout = int(params.get("planar_layout", 0)) or (2 if n >= 24576 else 4)  # the pool's own rule
         lg = (args.task in ("HalfCheetah", "Walker2d") and args.precision == "fp64" and lg_layout > 1
               and params.get("frame_stack", 1) == 1)
+        if args.task == "Hopper":  # a group of ONE lane (default) unless planar_layout = 1
+            lg = int(params.get("planar_layout", 0)) != 1
+            lg_layout = 1
         kbase = ("AntStepKernel" if args.task == "Ant" else
                  ("Humanoid4StepKernel" if hum_quad else "HumanoidStepKernel")
                  if args.task.startswith("Humanoid") else

@@ -66,22 +66,32 @@ EPA_HD constexpr bool LInChain(int j, int b) { return j < 3 || (j - 2) <= b; }
 
 template <int KL>
 struct Grp {
-  static_assert(KL == 2 || KL == 4, "lane group of 2 or 4");
+  static_assert(KL == 1 || KL == 2 || KL == 4, "lane group of 1, 2 or 4");
   static constexpr int kLanes = KL;
-  static constexpr int kEnds = 16 / KL;  // end-sphere slots of a lane
-  // local body of slot s (KL = 2: both ends of a body are consecutive slots; KL = 4: one end per body)
-  EPA_HD static constexpr int SlotBody(int s) { return KL == 2 ? s / 2 : s; }
+  // KL = 1: the single-leg Hopper -- a lane IS the env (torso + its only leg): no cross-lane traffic
+  // at all, 64 envs per wave; the torso capsule's two ends + the leg's six are its 8 slots
+  static constexpr int kEnds = KL == 1 ? 8 : 16 / KL;  // end-sphere slots of a lane
+  // body-body capsule pairs (frictionless rows) exist in the Hopper model only
+  static constexpr bool kPairs = KL == 1;
+  // line-search cache per end-sphere slot: (Jn.a, Jx.a) and, where the LDS budget of 40 KB per wave
+  // allows it, (Jn.s, Jx.s); the Hopper spends those slots on its three body pairs
+  static constexpr int kCachePerEnd = KL == 1 ? 2 : 4;
+  // local body of slot s (KL = 1, 2: both ends of a body are consecutive slots; KL = 4: one end per body)
+  EPA_HD static constexpr int SlotBody(int s) { return KL == 4 ? s : s / 2; }
   // lane coordinate c (0 .. KL-1) -> leg, parity
-  EPA_HD static constexpr int Leg(int c) { return KL == 2 ? c : c >> 1; }
-  EPA_HD static constexpr int Par(int c) { return KL == 2 ? 0 : c & 1; }
+  EPA_HD static constexpr int Leg(int c) { return KL == 1 ? 0 : (KL == 2 ? c : c >> 1); }
+  EPA_HD static constexpr int Par(int c) { return KL == 4 ? c & 1 : 0; }
   // global end-sphere index (mj_cheetah.hip.h numbering: 2 * geom + end) of slot s of lane c
   EPA_HD static constexpr int GlobalEnd(int c, int s) {
     const int b = SlotBody(s), leg = Leg(c);
     const int geom = b == 0 ? leg : 1 + 3 * leg + b;
-    const int end = KL == 2 ? (s & 1) : Par(c);
+    const int end = KL == 4 ? Par(c) : (s & 1);
     return 2 * geom + end;
   }
 };
+// Body-body collision candidates of the Hopper (mj_cheetah.hip.h: kNPair, PairBody1 / PairBody2): torso-leg,
+// torso-foot, thigh-foot; bit 16 + k of the `ends` set, bit 27 + k of the active-row mask
+constexpr int kPairEndBit = 16, kPairMaskBit = 27;
 
 // ---- per-lane constant table -----------------------------------------------------------------
 // [id][c], c = lane coordinate in the group.  Ids of the leg's bodies / hinges are relative
@@ -143,11 +153,15 @@ inline void BuildTable(const CheetahModel<double>& m, double* tab) {
 // end-sphere slot that live for one Newton iteration: (Jn.a, Jx.a) left by the pass over the rows and
 // (Jn.s, Jx.s) left by the first line-search evaluation, so that the further evaluations of that
 // line search (2.1 per iteration on average) do not rebuild the Jacobian columns
-constexpr int kSlotsPerEnd = 5, kCachePerEnd = 4;
+// The Hopper (KL = 1) keeps only (Jn.a, Jx.a) and rebuilds (Jn.s, Jx.s) per evaluation; behind the cache its
+// three body pairs take kSlotsPerPair each (nx nz cx cz aref D, as in mj_cheetah.hip.h).
+constexpr int kSlotsPerEnd = 5;
 template <int KL>
 constexpr int CacheBase() { return Grp<KL>::kEnds * kSlotsPerEnd; }
 template <int KL>
-constexpr int LdsSlots() { return Grp<KL>::kEnds * (kSlotsPerEnd + kCachePerEnd); }
+constexpr int PairBase() { return Grp<KL>::kEnds * (kSlotsPerEnd + Grp<KL>::kCachePerEnd); }
+template <int KL>
+constexpr int LdsSlots() { return PairBase<KL>() + (Grp<KL>::kPairs ? kNPair * kSlotsPerPair : 0); }
 
 // ================================================================================================
 // The lane vocabulary.  Device: a value IS a lane's scalar, conditions are bool, the group
@@ -216,6 +230,12 @@ inline LV<T, K> Sel(LB<K> c, const LV<T, K>& a, const LV<T, K>& b) {
   return r;
 }
 template <typename T, int K>
+inline LV<T, K> SqrtV(const LV<T, K>& x) {
+  LV<T, K> r;
+  for (int i = 0; i < K; ++i) r.v[i] = std::sqrt(x.v[i]);
+  return r;
+}
+template <typename T, int K>
 inline LV<T, K> Rsq(const LV<T, K>& x) {
   LV<T, K> r;
   for (int i = 0; i < K; ++i) r.v[i] = T(1) / std::sqrt(x.v[i]);
@@ -223,9 +243,10 @@ inline LV<T, K> Rsq(const LV<T, K>& x) {
 }
 // lane permutations of a group: legs <-> the other leg's lane (same parity), par <-> the other parity
 template <int KL>
-constexpr int OtherLeg(int c) { return KL == 2 ? c ^ 1 : c ^ 2; }
+constexpr int OtherLeg(int c) { return KL == 1 ? c : (KL == 2 ? c ^ 1 : c ^ 2); }
 template <int KL, typename T>
 inline LV<T, KL> SumLegs(const LV<T, KL>& x) {
+  if (KL == 1) return x;  // one leg
   LV<T, KL> r;
   for (int c = 0; c < KL; ++c) r.v[c] = x.v[c] + x.v[OtherLeg<KL>(c)];
   return r;
@@ -238,7 +259,7 @@ inline LV<T, KL> MaxLegs(const LV<T, KL>& x) {
 }
 template <int KL, typename T>
 inline LV<T, KL> SumPar(const LV<T, KL>& x) {
-  if (KL == 2) return x;
+  if (KL != 4) return x;
   LV<T, KL> r;
   for (int c = 0; c < KL; ++c) r.v[c] = x.v[c] + x.v[c ^ 1];
   return r;
@@ -288,6 +309,7 @@ EPA_HD T Sel(bool c, T a, T b) {
   return c ? a : b;
 }
 EPA_HD double Rsq(double x) { return Rsqrt(x); }
+EPA_HD double SqrtV(double x) { return Sqrt(x); }
 EPA_HD float Rsq(float x) { return Rsqrt(x); }
 EPA_HD bool AnyWave(bool c) { return WaveAny(c); }
 EPA_HD void MaskSet(unsigned& m, bool on, int bit) { m |= (on ? 1u : 0u) << bit; }
@@ -328,16 +350,24 @@ __device__ __forceinline__ double DppMovD(double x) {
 }
 template <int KL>
 __device__ __forceinline__ double SumLegs(double x) {
-  return x + DppMovD<KL == 2 ? kDppNeighbour : kDppPair>(x);
+  if constexpr (KL == 1) {
+    return x;  // one leg: the lane is the env
+  } else {
+    return x + DppMovD<KL == 2 ? kDppNeighbour : kDppPair>(x);
+  }
 }
 template <int KL>
 __device__ __forceinline__ double MaxLegs(double x) {
-  const double y = DppMovD<KL == 2 ? kDppNeighbour : kDppPair>(x);
-  return x > y ? x : y;
+  if constexpr (KL == 1) {
+    return x;
+  } else {
+    const double y = DppMovD<KL == 2 ? kDppNeighbour : kDppPair>(x);
+    return x > y ? x : y;
+  }
 }
 template <int KL>
 __device__ __forceinline__ double SumPar(double x) {
-  if constexpr (KL == 2) {
+  if constexpr (KL != 4) {
     return x;
   } else {
     return x + DppMovD<kDppNeighbour>(x);
@@ -345,10 +375,14 @@ __device__ __forceinline__ double SumPar(double x) {
 }
 template <int KL>
 __device__ __forceinline__ bool AllEnvI(bool c) {
-  int x = c ? 1 : 0;
-  x &= DppMovI<kDppNeighbour>(x);
-  if constexpr (KL == 4) x &= DppMovI<kDppPair>(x);
-  return x != 0;
+  if constexpr (KL == 1) {
+    return c;
+  } else {
+    int x = c ? 1 : 0;
+    x &= DppMovI<kDppNeighbour>(x);
+    if constexpr (KL == 4) x &= DppMovI<kDppPair>(x);
+    return x != 0;
+  }
 }
 #else
 template <int KL>
@@ -645,7 +679,110 @@ EPA_HD unsigned MakeConstraint(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p
     cx.Lds(s * kSlotsPerEnd + 3) = ax;
     cx.Lds(s * kSlotsPerEnd + 4) = D;
   });
+  // body-body capsule pairs of the Hopper (mjc_CapsuleCapsule: closest points of the two axis segments,
+  // then sphere-sphere; the arithmetic of mj_cheetah.hip.h::CheetahMakeConstraint with selects for its
+  // branches): one frictionless row each (condim 1)
+  if constexpr (Grp<KL>::kPairs) {
+    static_for<0, kNPair>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int b1 = PairBody1(k), b2 = PairBody2(k);
+      constexpr int s1 = 2 * b1, s2 = 2 * b2;  // the end-sphere slots of the two capsules
+      auto end_pos = [&](auto bc, int sl, V* x, V* z) {
+        constexpr int b = decltype(bc)::value;
+        const V ex = cx.C(kTEx + sl), ez = cx.C(Tab<KL>::kEz + sl);
+        *x = p.px[b] + p.cs[b] * ex + p.sn[b] * ez;
+        *z = p.pz[b] - p.sn[b] * ex + p.cs[b] * ez;
+      };
+      V ax1, az1, bx1, bz1, ax2, az2, bx2, bz2;
+      end_pos(IC<b1>{}, s1, &ax1, &az1);
+      end_pos(IC<b1>{}, s1 + 1, &bx1, &bz1);
+      end_pos(IC<b2>{}, s2, &ax2, &az2);
+      end_pos(IC<b2>{}, s2 + 1, &bx2, &bz2);
+      const V c1x = V(0.5) * (ax1 + bx1), c1z = V(0.5) * (az1 + bz1);
+      const V c2x = V(0.5) * (ax2 + bx2), c2z = V(0.5) * (az2 + bz2);
+      const V h1x = V(0.5) * (ax1 - bx1), h1z = V(0.5) * (az1 - bz1);
+      const V h2x = V(0.5) * (ax2 - bx2), h2z = V(0.5) * (az2 - bz2);
+      const V dfx = c1x - c2x, dfz = c1z - c2z;
+      const V ma = h1x * h1x + h1z * h1z, mb = -(h1x * h2x + h1z * h2z), mc = h2x * h2x + h2z * h2z;
+      const V u = -(h1x * dfx + h1z * dfz), w = h2x * dfx + h2z * dfz;
+      const V det = ma * mc - mb * mb;
+      auto clamp1 = [](V x) { return Sel(x > V(1), V(1), Sel(x < V(-1), V(-1), x)); };
+      const auto par = Abs(det) < V(kMinVal);
+      const V den = Sel(par, V(1), det);
+      V x1 = (mc * u - mb * w) / den;
+      V x2 = (ma * w - mb * u) / den;
+      {
+        const auto hi1 = x1 > V(1), lo1 = x1 < V(-1);
+        x2 = Sel(hi1, (w - mb) / mc, Sel(lo1, (w + mb) / mc, x2));
+        x1 = clamp1(x1);
+        const auto hi2 = x2 > V(1), lo2 = x2 < V(-1);
+        const V x1b = clamp1(Sel(hi2, (u - mb) / ma, (u + mb) / ma));
+        x1 = Sel(hi2 | lo2, x1b, x1);
+        x2 = clamp1(x2);
+      }
+      {
+        const V amb = Abs(mb);
+        V lo = (u - amb) / ma, hi = (u + amb) / ma;
+        lo = Sel(lo < V(-1), V(-1), lo);
+        hi = Sel(hi > V(1), V(1), hi);
+        const V xp1 = Sel(lo <= hi, V(0.5) * (lo + hi), Sel(lo > V(1), V(1), V(-1)));
+        const V xp2 = clamp1((w - mb * xp1) / mc);
+        x1 = Sel(par, xp1, x1);
+        x2 = Sel(par, xp2, x2);
+      }
+      const V p1x = c1x + h1x * x1, p1z = c1z + h1z * x1;
+      const V p2x = c2x + h2x * x2, p2z = c2z + h2z * x2;
+      const V ddx = p2x - p1x, ddz = p2z - p1z;
+      const V cd = SqrtV(ddx * ddx + ddz * ddz);
+      const V r1 = cx.C(Tab<KL>::kEr + s1), r2 = cx.C(Tab<KL>::kEr + s2);
+      const V dist = cd - r1 - r2;
+      const auto touch = dist < V(m.con_margin);
+      V nx = V(1), nz = V(0), ccx = V(0), ccz = V(0), aref = V(0), D = V(0);
+      if (AnyWave(touch)) {
+        ends |= 1u << (kPairEndBit + k);
+        const auto tiny = cd < V(kMinVal);
+        const V inv = V(1) / Sel(tiny, V(1), cd);
+        nx = Sel(tiny, V(1), ddx * inv);
+        nz = Sel(tiny, V(0), ddz * inv);
+        ccx = p1x + nx * (r1 + V(0.5) * dist);
+        ccz = p1z + nz * (r1 + V(0.5) * dist);
+        // relative normal velocity: only the hinges between the two bodies contribute
+        V vel = V(0);
+        static_for<b1 + 3, b2 + 3>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          constexpr int jb = LDofBody(j);
+          vel += (nx * (ccz - p.pz[jb]) - nz * (ccx - p.px[jb])) * v[j];
+        });
+        const V r = dist - V(m.con_margin);
+        const V imp = ImpedanceV(m.con_d0, m.con_dmax, m.con_width, r);
+        const V num = (V(1) - imp) * V(m.body_invw[b1] + m.body_invw[b2]);  // condim 1: tran1 + tran2
+        const V invR = Sel(num < V(kMinVal) * imp, V(T(1) / kMinVal), imp / num);
+        D = Sel(touch, invR, V(0));
+        aref = Sel(touch, -V(m.con_B) * vel - V(m.con_K) * imp * r, V(0));
+      }
+      cx.Lds(PairBase<KL>() + k * kSlotsPerPair + 0) = nx;
+      cx.Lds(PairBase<KL>() + k * kSlotsPerPair + 1) = nz;
+      cx.Lds(PairBase<KL>() + k * kSlotsPerPair + 2) = ccx;
+      cx.Lds(PairBase<KL>() + k * kSlotsPerPair + 3) = ccz;
+      cx.Lds(PairBase<KL>() + k * kSlotsPerPair + 4) = aref;
+      cx.Lds(PairBase<KL>() + k * kSlotsPerPair + 5) = D;
+    });
+  }
   return WaveUniform(ends);
+}
+
+// Jacobian entries of pair contact K (Hopper): f(j, J_j) for the hinges between its two bodies -- the dofs
+// shared by both chains move both bodies alike and drop out of the relative normal velocity
+template <int KL, int K, typename V, typename Cx, typename F>
+EPA_HD void ForPairCols(const Pos<V>& p, Cx& cx, F&& f) {
+  constexpr int b1 = PairBody1(K), b2 = PairBody2(K);
+  const V nx = cx.Lds(PairBase<KL>() + K * kSlotsPerPair + 0), nz = cx.Lds(PairBase<KL>() + K * kSlotsPerPair + 1);
+  const V ccx = cx.Lds(PairBase<KL>() + K * kSlotsPerPair + 2), ccz = cx.Lds(PairBase<KL>() + K * kSlotsPerPair + 3);
+  static_for<b1 + 3, b2 + 3>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    constexpr int jb = LDofBody(j);
+    f(jc, nx * (ccz - p.pz[jb]) - nz * (ccx - p.px[jb]));
+  });
 }
 
 // One pass over the lane's constraint rows at acceleration `a`: accumulates THIS LANE's part of
@@ -662,8 +799,35 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
     if constexpr (kHess) Hc[Tri(j + 3, j + 3)] += w;
     MaskSetNZ(mask, w, j);
   });
+  if constexpr (Grp<KL>::kPairs) {  // frictionless body-body rows (Hopper)
+    if ((ends >> kPairEndBit) != 0) {
+      static_for<0, kNPair>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (ends & (1u << (kPairEndBit + k))) {
+          const V aref = cx.Lds(PairBase<KL>() + k * kSlotsPerPair + 4);
+          const V D = cx.Lds(PairBase<KL>() + k * kSlotsPerPair + 5);
+          V ja = V(0);
+          ForPairCols<KL, k>(p, cx, [&](auto jc, V J) { ja += J * a[decltype(jc)::value]; });
+          const V jar = ja - aref;
+          const V w = Sel(jar < V(0), D, V(0));  // D == 0 on lanes whose pair does not touch
+          MaskSetNZ(mask, w, kPairMaskBit + k);
+          ForPairCols<KL, k>(p, cx, [&](auto ic, V Ji) {
+            constexpr int i = decltype(ic)::value;
+            gc[i] += Ji * (w * jar);
+            if constexpr (kHess) {
+              const V wi = w * Ji;
+              ForPairCols<KL, k>(p, cx, [&](auto jc2, V Jk) {
+                constexpr int kk = decltype(jc2)::value;
+                if constexpr (kk >= i) Hc[Tri(i, kk)] += wi * Jk;
+              });
+            }
+          });
+        }
+      });
+    }
+  }
   EPA_NO_UNROLL
-  for (unsigned rem = ends; rem != 0; rem &= rem - 1) {  // scalar loop over the touching slots
+  for (unsigned rem = ends & 0xFFFFu; rem != 0; rem &= rem - 1) {  // scalar loop over the touching slots
     const int s = __builtin_ctz(rem);
     const V D = cx.Lds(s * kSlotsPerEnd + 4);
     DispatchLocalBody(Grp<KL>::SlotBody(s), [&](auto bc) {
@@ -677,8 +841,8 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
         jxa += jx * a[j];
       });
       if constexpr (kHess) {  // the per-iteration pass: kept for the line search
-        cx.Lds(CacheBase<KL>() + s * kCachePerEnd + 0) = jna;
-        cx.Lds(CacheBase<KL>() + s * kCachePerEnd + 1) = jxa;
+        cx.Lds(CacheBase<KL>() + s * Grp<KL>::kCachePerEnd + 0) = jna;
+        cx.Lds(CacheBase<KL>() + s * Grp<KL>::kCachePerEnd + 1) = jxa;
       }
       // rows: 2 x (Jn), (Jn - mu Jx), (Jn + mu Jx); D == 0 for lanes not in contact, which
       // zeroes every weight below
@@ -727,15 +891,38 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
     *d2 += w * jv * jv;
     if constexpr (kMask) MaskSetNZ(mask, w, j);
   });
+  if constexpr (Grp<KL>::kPairs) {
+    if ((ends >> kPairEndBit) != 0) {
+      static_for<0, kNPair>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (ends & (1u << (kPairEndBit + k))) {
+          const V aref = cx.Lds(PairBase<KL>() + k * kSlotsPerPair + 4);
+          const V D = cx.Lds(PairBase<KL>() + k * kSlotsPerPair + 5);
+          V ja = V(0), jv = V(0);
+          ForPairCols<KL, k>(p, cx, [&](auto jc, V J) {
+            ja += J * a[decltype(jc)::value];
+            jv += J * s[decltype(jc)::value];
+          });
+          const V x = (ja - aref) + alpha * jv;
+          const V cw = Sel(x < V(0), D, V(0));
+          *d1 += cw * x * jv;
+          *d2 += cw * jv * jv;
+          if constexpr (kMask) MaskSetNZ(mask, cw, kPairMaskBit + k);
+        }
+      });
+    }
+  }
   EPA_NO_UNROLL
-  for (unsigned rem = ends; rem != 0; rem &= rem - 1) {
+  for (unsigned rem = ends & 0xFFFFu; rem != 0; rem &= rem - 1) {
     const int sl = __builtin_ctz(rem);
     const V D = cx.Lds(sl * kSlotsPerEnd + 4);
     const V an = cx.Lds(sl * kSlotsPerEnd + 2), ax = cx.Lds(sl * kSlotsPerEnd + 3);
-    const V jna = cx.Lds(CacheBase<KL>() + sl * kCachePerEnd + 0);  // RowsPass<true> at the same `a`
-    const V jxa = cx.Lds(CacheBase<KL>() + sl * kCachePerEnd + 1);
+    const V jna = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 0);  // RowsPass<true> at the same `a`
+    const V jxa = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 1);
     V jns, jxs;
-    if constexpr (kMask) {  // first evaluation of this line search: J . s, kept for the others
+    // first evaluation of this line search: J . s, kept for the others (without the (Jn.s, Jx.s) slots -- the
+    // Hopper -- rebuilt by every evaluation)
+    if constexpr (kMask || Grp<KL>::kCachePerEnd < 4) {
       const V cpx = cx.Lds(sl * kSlotsPerEnd + 0), cpz = cx.Lds(sl * kSlotsPerEnd + 1);
       // s . (Jacobian columns of a point on local body b): torso dofs, then the hinges up to b
       jns = s[1] - (cpx - p.px[0]) * s[2];
@@ -753,11 +940,13 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
         jns -= (cpx - p.px[3]) * s[5];
         jxs += (cpz - p.pz[3]) * s[5];
       }
-      cx.Lds(CacheBase<KL>() + sl * kCachePerEnd + 2) = jns;
-      cx.Lds(CacheBase<KL>() + sl * kCachePerEnd + 3) = jxs;
+      if constexpr (Grp<KL>::kCachePerEnd >= 4) {
+        cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 2) = jns;
+        cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 3) = jxs;
+      }
     } else {
-      jns = cx.Lds(CacheBase<KL>() + sl * kCachePerEnd + 2);
-      jxs = cx.Lds(CacheBase<KL>() + sl * kCachePerEnd + 3);
+      jns = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 2);
+      jxs = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 3);
     }
     const V mu = cx.C(kTMu + Grp<KL>::SlotBody(sl));  // (the table also carries the torso's)
     const V jar1 = jna - an, jv1 = jns;

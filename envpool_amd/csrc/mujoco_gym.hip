@@ -370,18 +370,22 @@ class CheetahPool : public Pool {
     // many other envs a particular send happens to carry.  It DOES depend on num_envs / batch_size of
     // the pool (to rounding: the two layouts agree with the oracle to 1e-9 each, tests/test_gpu_mujoco.py);
     // pass planar_layout explicitly where two pools of different shape must agree bit for bit.
+    // Hopper (one leg): 0 (default) = the lane-group kernel with a group of ONE lane -- the lane's 6 local
+    // dofs (torso + leg) are the whole robot: packed 6 x 6 instead of the ghost-leg 9 x 9 of CheetahStepKernel,
+    // no scratch; 1 = CheetahStepKernel as for the others; 2 / 4 do not exist.
     layout_ = (int)cfg.Get("planar_layout", 0);
     if (layout_ != 0 && layout_ != 1 && layout_ != 2 && layout_ != 4) {
       throw std::invalid_argument("planar_layout must be 0, 1, 2 or 4");
     }
+    if (hopper && layout_ > 1) throw std::invalid_argument("planar_layout: the Hopper takes 0 or 1");
     // frame_stack > 1 on the fp64 two-legged models: the generic ring of the engine (EnableObsStack; the
     // kernels then write one frame per row), so that stacked and plain pools run the same step kernel
     // and agree bit for bit; the other configurations keep this file's in-kernel ring (dev_.stack)
-    if (task_.frame_stack > 1 && fp64_ && !hopper) {
+    if (task_.frame_stack > 1 && fp64_) {
       EnableObsStack();
       task_.frame_stack = 1;
     }
-    lg_ok_ = fp64_ && !hopper && task_.frame_stack == 1;
+    lg_ok_ = fp64_ && task_.frame_stack == 1;
     // (async mode: several batches are in flight on the pool's compute streams, so what fills the machine is
     // batch_size x streams, not one batch: 8 x 8192 of 65536 envs measured 2.83e8 with 2 lanes per env against
     // 2.06e8 with 4, profiles/r3r_async_probe.jsonl; and partly filled waves -- made to occupy more SIMDs with ONE
@@ -393,6 +397,7 @@ class CheetahPool : public Pool {
       // do not depend on that knob: tests compare 1 stream with several bit for bit)
       if (async_) rows = std::min<long long>(cfg.num_envs, 4ll * cfg.batch_size);
       layout_ = rows >= 24576 ? 2 : 4;
+      if (hopper) layout_ = kLayoutHopperLg;
     }
     // register budget of the lane-group kernel: one wave per SIMD with all 512 registers (default;
     // measured faster at every batch size, profiles/r3f_lane_group_sweep.txt) or two with 256 + spills
@@ -400,8 +405,9 @@ class CheetahPool : public Pool {
     lpt_ = cfg.Get("planar_lpt", 1) != 0;
     if (lg_ok_) {
       for (int i = 0; i < 2; ++i) {
+        if (hopper && i == 1) break;  // one table: a group of one lane
         std::vector<double> tab(kPlanarLgTabMax, 0.0);
-        const int cnt = PlanarLgBuildTable(i == 0 ? 2 : 4, model_id_, tab.data());
+        const int cnt = PlanarLgBuildTable(hopper ? 1 : (i == 0 ? 2 : 4), model_id_, tab.data());
         EPA_HIP(hipMalloc(&d_tab_[i], sizeof(double) * cnt));
         EPA_HIP(hipMemcpy(d_tab_[i], tab.data(), sizeof(double) * cnt, hipMemcpyHostToDevice));
       }
@@ -481,7 +487,7 @@ class CheetahPool : public Pool {
           order_.gen = 0;
           order_shape_ = -1;
         }
-        const int shape = nchunks * 8 + layout;
+        const int shape = nchunks * 16 + layout;
         order_.use = (shape == order_shape_ && order_stream_ == stream_) ? 1 : 0;
         lo = order_;
         ++order_.gen;
@@ -490,8 +496,10 @@ class CheetahPool : public Pool {
       } else {
         order_shape_ = -1;  // the chain of same-shape launches is broken
       }
-      PlanarLgLaunch(stream_, layout, lg_waves_, model_id_, wave_slots_, spread_ && !async_, dev_, common_, a,
-                     static_cast<const double*>(d_action), out, task_, d_tab_[layout == 2 ? 0 : 1], tk.d, &tk.base, lo);
+      const bool lg1 = layout == kLayoutHopperLg;  // lanes per env: 1 (Hopper), 2 or 4
+      PlanarLgLaunch(stream_, lg1 ? 1 : layout, lg_waves_, model_id_, wave_slots_, spread_ && !async_, dev_, common_, a,
+                     static_cast<const double*>(d_action), out, task_, d_tab_[(lg1 || layout == 2) ? 0 : 1], tk.d,
+                     &tk.base, lo);
       return;
     }
     int lanes = kCheetahBlock;
@@ -524,6 +532,7 @@ class CheetahPool : public Pool {
   bool spread_{true};
   bool async_{false};
   int wave_slots_{1024};
+  static constexpr int kLayoutHopperLg = 8;  // layout_: the Hopper on the lane-group kernel (group of one lane)
   int layout_{0};
   bool lg_ok_{false};
   int lg_waves_{1};

@@ -113,7 +113,10 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
 #define out (ap->out)
   using G = plg::Grp<KL>;
   constexpr CheetahModel<double> m = PlanarModel<double, kModel>();
-  constexpr bool kWalker = kModel != mj::kPlanarCheetah;  // RK4, mirrored hinges
+  constexpr bool kWalker = kModel != mj::kPlanarCheetah;  // Walker2d or Hopper: RK4, mirrored hinges
+  constexpr bool kHopper = kModel == mj::kPlanarHopper;   // KL = 1: dofs 0..5 / motors 0..2 of the 9-dof tree
+  static_assert(kHopper == (KL == 1), "a group of one lane is the one-legged model, and only it");
+  constexpr int kNVr = kHopper ? 6 : kNV, kNUr = kHopper ? 3 : kNU;
   const int lane = threadIdx.x;
   const int n = cm.n;
   const int c = lane & (KL - 1);  // lane coordinate in the group
@@ -126,7 +129,7 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
   bool done = cm.done[e] != 0;
   int cur = cm.cur_step[e];
   const bool reset = a.force_reset || done;  // async_envpool.h:127
-  const int nobs = 2 * kNV - task.obs_skip;
+  const int nobs = 2 * kNVr - task.obs_skip;
   double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
   float reward = 0.0f;
   double xv = 0.0, ctrl_cost = 0.0, xpos = 0.0, qz = 0.0, qang = 0.0;
@@ -141,11 +144,12 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
       double saved = dev.nsaved[e];
       int avail = dev.navail[e];
       double qpos[kNV], qvel[kNV];
-      for (int i = 0; i < kNV; ++i) {
-        const double q0 = (kWalker && i == 1) ? 1.25 : 0.0;  // rootz ref (walker2d_envpool.xml:36)
+      for (int i = kNVr; i < kNV; ++i) qpos[i] = qvel[i] = 0.0;  // the dofs the Hopper does not have
+      for (int i = 0; i < kNVr; ++i) {
+        const double q0 = (kWalker && i == 1) ? 1.25 : 0.0;  // rootz ref (walker2d_envpool.xml:36, hopper :39)
         qpos[i] = q0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
       }
-      for (int i = 0; i < kNV; ++i) {
+      for (int i = 0; i < kNVr; ++i) {
         if constexpr (kWalker) {
           qvel[i] = 0.0 + g.UniformReal(-task.reset_noise_scale, task.reset_noise_scale);
         } else {
@@ -160,9 +164,9 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
         dev.qpos[(size_t)i * n + e] = qpos[i];
         dev.qvel[(size_t)i * n + e] = qvel[i];
         dev.warm[(size_t)i * n + e] = 0.0;
-        if (i >= task.obs_skip) *(o++) = qpos[i];
+        if (i >= task.obs_skip && i < kNVr) *(o++) = qpos[i];
       }
-      for (int i = 0; i < kNV; ++i) {
+      for (int i = 0; i < kNVr; ++i) {
         double x = qvel[i];
         if constexpr (kWalker) {  // walker2d.h:210-215
           x = x < task.velocity_max ? x : task.velocity_max;
@@ -186,7 +190,7 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
       w[i] = sg * dev.warm[(size_t)gi * n + e];
     });
     q[0] = 0.0;  // the root x is carried as a local offset per env-step
-    const double* act = action + (size_t)row * kNU;
+    const double* act = action + (size_t)row * kNUr;
     mj::static_for<0, 3>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const double ai = act[3 * leg + i];
@@ -194,7 +198,7 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
       ctrl[i] = ai < -1.0 ? -1.0 : (ai > 1.0 ? 1.0 : ai);
     });
     if (first) {  // half_cheetah.h:143-146: summed in the reference's order
-      for (int i = 0; i < kNU; ++i) ctrl_cost += task.ctrl_cost_weight * act[i] * act[i];
+      for (int i = 0; i < kNUr; ++i) ctrl_cost += task.ctrl_cost_weight * act[i] * act[i];
     }
     DevCx<KL> cx{(LdsConstDouble*)tab_lds + c, lds_buf + lane};
 #ifdef EPA_LG_TIMERS
@@ -223,7 +227,8 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
     xpos = x_after;
     qz = q[1];
     qang = q[2];
-    const int no = kNV - task.obs_skip;  // position entries of the observation
+    const int no = kNVr - task.obs_skip;  // position entries of the observation
+    bool state_ok = true;  // Hopper: every qpos[2:] and qvel inside (healthy_state_min, healthy_state_max)
     mj::static_for<0, plg::kLV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const bool mine = i < 3 ? first : leg_first;
@@ -231,6 +236,10 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
       const double sg = (kWalker && i >= 3) ? -1.0 : 1.0;
       const double qq = i == 0 ? x_after : sg * q[i];
       const double vv = sg * v[i];
+      if constexpr (kHopper) {  // hopper.h:192-203 (the lane holds the whole state)
+        if (i >= 2 && (qq <= task.healthy_state_min || qq >= task.healthy_state_max)) state_ok = false;
+        if (vv <= task.healthy_state_min || vv >= task.healthy_state_max) state_ok = false;
+      }
       if (mine) {
         dev.qpos[(size_t)gi * n + e] = qq;
         dev.qvel[(size_t)gi * n + e] = vv;
@@ -245,9 +254,15 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
       }
     });
     if (first) dev.iters[e] = (int)iters;
-    if constexpr (kWalker) {  // walker2d.h:162-177,181-190
-      const bool healthy = !(qz < task.healthy_z_min || qz > task.healthy_z_max ||
-                             qang < task.healthy_angle_min || qang > task.healthy_angle_max);
+    if constexpr (kWalker) {  // walker2d.h:162-177,181-190 / hopper.h:170-203
+      bool healthy;
+      if constexpr (kHopper) {
+        healthy = !(qang <= task.healthy_angle_min || qang >= task.healthy_angle_max || qz <= task.healthy_z_min) &&
+                  state_ok;
+      } else {
+        healthy = !(qz < task.healthy_z_min || qz > task.healthy_z_max ||
+                    qang < task.healthy_angle_min || qang > task.healthy_angle_max);
+      }
       bool give = healthy;
       if (task.legacy_healthy_reward) give = task.terminate_when_unhealthy || healthy;
       const double healthy_reward = give ? task.healthy_reward : 0.0;
@@ -358,7 +373,7 @@ void LaunchKl(hipStream_t st, int model, int wave_slots, bool spread, const Chee
               const StepArgs& a, const double* action, const OutPtrs& out, const CheetahTask& task,
               const double* tab, unsigned* ticket, unsigned* ticket_base, const planar::LgOrder& lo) {
   // waves resident at once: W per SIMD by registers (LDS allows no more than one at KL = 2)
-  const int resident = wave_slots * ((KL == 2 || W == 1) ? 1 : 2);
+  const int resident = wave_slots * ((KL <= 2 || W == 1) ? 1 : 2);
   // A wave runs as long as its slowest env and visits the union of its envs' touching slots: while
   // there are fewer full chunks than resident waves, smaller chunks (partly filled waves) on more
   // SIMDs are faster (N = 8192 at 4 lanes per env: 512 waves of 16 envs 95 us, 1024 waves of 8 envs
@@ -374,16 +389,23 @@ void LaunchKl(hipStream_t st, int model, int wave_slots, bool spread, const Chee
   *ticket_base = base + (unsigned)nchunks;  // see PlanarLgStepKernel
   const LgArgs args{dev, cm, a, action, out, task, plg::SolverCfgLg<double>{50, 1e-13}, tab, ticket, base, nchunks,
                     per, lo.d, lo.cap, lo.gen, lo.use};
-  switch (model) {
-    case mj::kPlanarCheetah:
-      hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarCheetah, W>), dim3(blocks), dim3(kBlock), 0, st, args);
-      break;
-    case mj::kPlanarWalker:
-      hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarWalker, W>), dim3(blocks), dim3(kBlock), 0, st, args);
-      break;
-    default:
-      hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarWalkerV5, W>), dim3(blocks), dim3(kBlock), 0, st, args);
-      break;
+  if constexpr (KL == 1) {  // a group of one lane: the one-legged model
+    if (model != mj::kPlanarHopper) throw std::invalid_argument("lane group of 1: the Hopper only");
+    hipLaunchKernelGGL((PlanarLgStepKernel<1, mj::kPlanarHopper, W>), dim3(blocks), dim3(kBlock), 0, st, args);
+  } else {
+    switch (model) {
+      case mj::kPlanarCheetah:
+        hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarCheetah, W>), dim3(blocks), dim3(kBlock), 0, st, args);
+        break;
+      case mj::kPlanarWalker:
+        hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarWalker, W>), dim3(blocks), dim3(kBlock), 0, st, args);
+        break;
+      case mj::kPlanarWalkerV5:
+        hipLaunchKernelGGL((PlanarLgStepKernel<KL, mj::kPlanarWalkerV5, W>), dim3(blocks), dim3(kBlock), 0, st, args);
+        break;
+      default:
+        throw std::invalid_argument("lane groups of 2 / 4: HalfCheetah and Walker2d");
+    }
   }
 }
 
@@ -396,7 +418,9 @@ void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots
                     const planar::LgOrder& lo) {
 #define EPA_LG(KL, W) \
   LaunchKl<KL, W>(st, model, wave_slots, spread, dev, cm, a, action, out, task, tab, ticket, ticket_base, lo)
-  if (kl == 2) {
+  if (kl == 1) {
+    EPA_LG(1, 1);
+  } else if (kl == 2) {
     if (waves == 1) {
       EPA_LG(2, 1);
     } else {
@@ -430,7 +454,12 @@ size_t PlanarLgOrderBytes(int cap) { return sizeof(unsigned) * 3 * LptGenWords(c
 int PlanarLgBuildTable(int kl, int model, double* tab) {
   const CheetahModel<double> m = model == mj::kPlanarCheetah  ? kCheetahModelConst
                                  : model == mj::kPlanarWalker ? kWalkerModelConst
+                                 : model == mj::kPlanarHopper ? kHopperModelConst
                                                               : kWalkerV5ModelConst;
+  if (kl == 1) {
+    plg::BuildTable<1>(m, tab);
+    return plg::Tab<1>::kSize;
+  }
   if (kl == 2) {
     static_assert(plg::Tab<2>::kSize <= kPlanarLgTabMax && plg::Tab<4>::kSize <= kPlanarLgTabMax, "table size");
     plg::BuildTable<2>(m, tab);

@@ -31,8 +31,10 @@ static int Run(int model, const double* q, const double* v, const double* warm, 
                int nsub, double* qo, double* vo, double* wo, int* iters) {
   using V = plg::LV<double, KL>;
   using G = plg::Grp<KL>;
-  const CheetahModel<double> m = model == 0 ? BuildCheetahModel() : BuildWalkerModel(model == 2);
-  const int pm = model == 0 ? kPlanarCheetah : kPlanarWalker;
+  // model: 0 HalfCheetah, 1 Walker2d, 2 Walker2d-v5, 3 Hopper (KL = 1: the lane is the env)
+  const CheetahModel<double> m = model == 0 ? BuildCheetahModel()
+                                 : model == 3 ? BuildHopperModel() : BuildWalkerModel(model == 2);
+  const int pm = model == 0 ? kPlanarCheetah : (model == 3 ? kPlanarHopper : kPlanarWalker);
   double tab[plg::Tab<KL>::kSize];
   plg::BuildTable<KL>(m, tab);
   HostCx<KL> cx;
@@ -86,6 +88,7 @@ static int Run(int model, const double* q, const double* v, const double* warm, 
 extern "C" int planar_lg_step(int model, int kl, const double* q, const double* v, const double* warm,
                               const double* ctrl, int nsub, double* qo, double* vo, double* wo,
                               int* iters) {
+  if (kl == 1) return Run<1>(model, q, v, warm, ctrl, nsub, qo, vo, wo, iters);
   return kl == 2 ? Run<2>(model, q, v, warm, ctrl, nsub, qo, vo, wo, iters)
                  : Run<4>(model, q, v, warm, ctrl, nsub, qo, vo, wo, iters);
 }

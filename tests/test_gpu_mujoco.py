@@ -500,9 +500,11 @@ def test_swimmer_matches_oracle():
 
 
 # ---- Hopper (planar kernel, ghost second leg, margin 0.001, body-body capsule contacts) ----
-def make_hopper_pair(n, seed, precision, max_steps=1000):
+def make_hopper_pair(n, seed, precision, max_steps=1000, layout=0):
+    # planar_layout 0 (default): the lane-group kernel with a group of one lane (mj_planar_lg.hip.h, KL = 1);
+    # 1: the one-env-per-lane 9-dof kernel with the ghost leg (mj_cheetah.hip.h)
     pool = DevicePool("Hopper", n, seed=seed, max_episode_steps=max_steps,
-                      params={"precision": precision})
+                      params={"precision": precision, "planar_layout": layout})
     orc = Oracle("Hopper", n, seed=seed, max_episode_steps=max_steps)
     return pool, orc
 
@@ -529,12 +531,14 @@ def _deep_self_penetration(orc, n, depth=-0.03):
     return deep
 
 
-def test_hopper_matches_oracle():
+@pytest.mark.parametrize("layout", [0, 1])
+def test_hopper_matches_oracle(layout):
     """Reset bit-exact (uniform draws); teacher-forced env-steps (4 RK4 mj_steps) incl.
     folded configurations where the torso-leg / torso-foot / thigh-foot capsule pairs
-    touch: obs rtol 1e-9 / atol 1e-10, bookkeeping exact."""
+    touch: obs rtol 1e-9 / atol 1e-10, bookkeeping exact.  Both kernels: the lane-group form with a
+    group of one lane (default since round 4) and the 9-dof ghost-leg form."""
     n = 256
-    pool, orc = make_hopper_pair(n, 5, 1)
+    pool, orc = make_hopper_pair(n, 5, 1, layout=layout)
     a, b = hip_reset(pool), orc.reset()
     assert list(a.keys()) == list(b.keys()) and a["obs"].shape == (n, 11)
     np.testing.assert_array_equal(a["obs"], b["obs"])
@@ -573,21 +577,44 @@ def test_hopper_matches_oracle():
         seen_term |= bool((b["done"] & ~b["trunc"]).any())
         self_hits += int((np.abs(b["obs"] - c["obs"]).max(axis=1)[ok] > 1e-9).sum())
         worst = max(worst, float(np.abs(a["obs"] - b["obs"])[ok].max()))
-    print(f"Hopper fp64: worst teacher-forced |d obs| = {worst:.3e}; env-steps with active "
+    print(f"Hopper fp64 layout {layout}: worst teacher-forced |d obs| = {worst:.3e}; env-steps with active "
           f"body-body contacts: {self_hits}")
     assert seen_term and self_hits > 100 and compared > 0.8 * n * 100
 
 
-def test_hopper_determinism():
+@pytest.mark.parametrize("layout", [0, 1])
+def test_hopper_determinism(layout):
     outs = []
     for _ in range(2):
-        p2 = DevicePool("Hopper", 512, seed=3, max_episode_steps=1000, params={"precision": 1})
+        p2 = DevicePool("Hopper", 512, seed=3, max_episode_steps=1000, params={"planar_layout": layout})
         hip_reset(p2)
         r2 = np.random.default_rng(5)
         for t in range(30):
             a = hip_step(p2, r2.uniform(-1, 1, size=(512, 3)))
         outs.append(a["obs"].copy())
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_hopper_layouts_share_state_and_agree():
+    """The two Hopper kernels work on the same device state (qpos / qvel / warm start [9][N], the ghost dofs
+    zero): free-running from the same seed they stay within rounding of each other for a short horizon, reset
+    rows are bit-identical, and a partly filled last wave (n = 200) is handled."""
+    n = 200
+    a_pool = DevicePool("Hopper", n, seed=8, max_episode_steps=40, params={"planar_layout": 0})
+    b_pool = DevicePool("Hopper", n, seed=8, max_episode_steps=40, params={"planar_layout": 1})
+    a, b = hip_reset(a_pool), hip_reset(b_pool)
+    rng = np.random.default_rng(1)
+    for t in range(12):
+        for k in a:
+            if t == 0:
+                assert a[k].tobytes() == b[k].tobytes(), k
+        np.testing.assert_allclose(a["obs"], b["obs"], rtol=1e-7, atol=1e-8, err_msg=f"step {t}")
+        for k in ("done", "trunc", "elapsed_step", "step_type"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"{k}@{t}")
+        act = rng.uniform(-1, 1, size=(n, 3))
+        a, b = hip_step(a_pool, act), hip_step(b_pool, act)
+    with pytest.raises(Exception, match="planar_layout"):
+        DevicePool("Hopper", 8, seed=0, max_episode_steps=10, params={"planar_layout": 2})
 
 
 # ---- generic observation frame stack (engine-level TypedFrameStackBuffer) ----

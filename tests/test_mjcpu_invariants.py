@@ -622,31 +622,35 @@ def test_product_planar_lane_group_code_matches_oracle_on_cpu():
     vp = ctypes.c_void_p
     L.planar_lg_step.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp]
     rng = np.random.default_rng(3)
-    for task, model, nsub in (("HalfCheetah", 0, 5), ("Walker2d", 1, 4), ("Walker2dV5", 2, 4)):
-        for kl in (2, 4):
+    for task, model, nsub in (("HalfCheetah", 0, 5), ("Walker2d", 1, 4), ("Walker2dV5", 2, 4), ("Hopper", 3, 4)):
+        for kl in ((1,) if model == 3 else (2, 4)):  # the one-legged Hopper: a group of ONE lane
             n = 8
             orc = Oracle(task, n, seed=9, max_episode_steps=1000)
             orc.reset()
             worst, worst_lane = 0.0, 0.0
             for t in range(40):
                 st = orc.get_state()
-                act = rng.uniform(-1, 1, size=(n, 6))
+                act = rng.uniform(-1, 1, size=(n, 3 if model == 3 else 6))
                 b = orc.step(act)
                 for e in range(n):
                     if b["elapsed_step"][e, 0] == 0:
                         continue
-                    q, v, w = st[e, :9].copy(), st[e, 9:18].copy(), st[e, 18:27].copy()
-                    a = np.ascontiguousarray(act[e])
+                    nd = 6 if model == 3 else 9  # the Hopper owns dofs 0..5 / motors 0..2 of the 9-dof tree
+                    q, v, w, a = np.zeros(9), np.zeros(9), np.zeros(9), np.zeros(6)
+                    q[:nd], v[:nd], w[:nd] = st[e, :nd], st[e, nd:2 * nd], st[e, 2 * nd:3 * nd]
+                    a[:nd - 3] = act[e]
                     qo, vo, wo, it = np.zeros(9), np.zeros(9), np.zeros(9), ctypes.c_int(0)
                     rc = L.planar_lg_step(model, kl, q.ctypes.data, v.ctypes.data, w.ctypes.data, a.ctypes.data,
                                           nsub, qo.ctypes.data, vo.ctypes.data, wo.ctypes.data, ctypes.byref(it))
                     assert rc == 0, (task, kl, rc)  # replicated values agree bit for bit
                     vv = np.clip(vo, -10, 10) if model else vo
-                    worst = max(worst, np.abs(np.concatenate([qo[1:], vv]) - b["obs"][e]).max())
+                    worst = max(worst, np.abs(np.concatenate([qo[1:nd], vv[:nd]]) - b["obs"][e]).max())
                     q2, v2, w2, it2 = np.zeros(9), np.zeros(9), np.zeros(9), ctypes.c_int(0)
                     args = [x.ctypes.data_as(vp) for x in (q, v, w, a)]
                     outs = [x.ctypes.data_as(vp) for x in (q2, v2, w2)]
-                    if model:
+                    if model == 3:
+                        Lo.hopper_host_step(*args, 4, 0, *outs, ctypes.byref(it2))
+                    elif model:
                         Lo.walker_host_step(*args, 4, int(model == 2), 0, *outs, ctypes.byref(it2))
                     else:
                         Lo.cheetah_host_step(*args, 5, 0, *outs, ctypes.byref(it2))

@@ -30,7 +30,7 @@ for path in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}*",
     tr = re.search(r"\| %s \| (\d+) \| ([0-9.]+) \|" % re.escape(kernel), text)
     lg = re.search(r"PlanarLgStepKernel<(\d), (\d), (\d)>", kernel)  # <lanes per env, model, waves per SIMD>
     if lg:  # canonical name (bench.py builds the same): all lane-group kernels are fp64
-        model = {"0": "", "1": "[Walker2d]", "2": "[Walker2d-v5]"}[lg.group(2)]
+        model = {"0": "", "1": "[Walker2d]", "2": "[Walker2d-v5]", "3": "[Hopper]"}[lg.group(2)]
         kernel = f"PlanarLgStepKernel<{lg.group(1)},{lg.group(3)}>{model}"
     f64 = "<double>" in kernel or lg is not None
     sfx = "F64" if f64 else "F32"
