@@ -826,14 +826,26 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
       });
     }
   }
-  EPA_NO_UNROLL
-  for (unsigned rem = ends & 0xFFFFu; rem != 0; rem &= rem - 1) {  // scalar loop over the touching slots
-    const int s = __builtin_ctz(rem);
-    const V D = cx.Lds(s * kSlotsPerEnd + 4);
+  // scalar loop over the touching slots (reading the NEXT slot's numbers while this one is used -- a software
+  // pipeline by one slot -- measured -0.4 % on HalfCheetah / Walker2d / Hopper, profiles/r4f_prefetch_ab.txt:
+  // the LDS round trip is not what the wave waits for)
+  struct EndVals {
+    V cpx, cpz, an, ax, D, mu;
+  };
+  auto load = [&](int s) {
+    EndVals e;
+    e.cpx = cx.Lds(s * kSlotsPerEnd + 0);
+    e.cpz = cx.Lds(s * kSlotsPerEnd + 1);
+    e.an = cx.Lds(s * kSlotsPerEnd + 2);
+    e.ax = cx.Lds(s * kSlotsPerEnd + 3);
+    e.D = cx.Lds(s * kSlotsPerEnd + 4);
+    e.mu = cx.C(kTMu + Grp<KL>::SlotBody(s));  // (== MuOf<b>: the table also carries the torso's)
+    return e;
+  };
+  auto visit = [&](const EndVals& e, int s) {
     DispatchLocalBody(Grp<KL>::SlotBody(s), [&](auto bc) {
       constexpr int b = decltype(bc)::value;
-      const V cpx = cx.Lds(s * kSlotsPerEnd + 0), cpz = cx.Lds(s * kSlotsPerEnd + 1);
-      const V an = cx.Lds(s * kSlotsPerEnd + 2), ax = cx.Lds(s * kSlotsPerEnd + 3);
+      const V cpx = e.cpx, cpz = e.cpz, an = e.an, ax = e.ax, D = e.D, mu = e.mu;
       V jna = V(0), jxa = V(0);
       ForChainCols<b>(p, cpx, cpz, [&](auto jc, V jn, V jx) {
         constexpr int j = decltype(jc)::value;
@@ -846,7 +858,6 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
       }
       // rows: 2 x (Jn), (Jn - mu Jx), (Jn + mu Jx); D == 0 for lanes not in contact, which
       // zeroes every weight below
-      const V mu = MuOf<b, T, V>(m, cx);
       const V jar1 = jna - an;
       const V jar2 = jna - mu * jxa - (an + ax);
       const V jar3 = jna + mu * jxa - (an - ax);
@@ -873,6 +884,11 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
         });
       }
     });
+  };
+  EPA_NO_UNROLL
+  for (unsigned rem = ends & 0xFFFFu; rem != 0; rem &= rem - 1) {
+    const int s = __builtin_ctz(rem);
+    visit(load(s), s);
   }
 }
 
@@ -912,18 +928,34 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
       });
     }
   }
-  EPA_NO_UNROLL
-  for (unsigned rem = ends & 0xFFFFu; rem != 0; rem &= rem - 1) {
-    const int sl = __builtin_ctz(rem);
-    const V D = cx.Lds(sl * kSlotsPerEnd + 4);
-    const V an = cx.Lds(sl * kSlotsPerEnd + 2), ax = cx.Lds(sl * kSlotsPerEnd + 3);
-    const V jna = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 0);  // RowsPass<true> at the same `a`
-    const V jxa = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 1);
+  // the scalar loop over the touching slots (plain: see RowsPass for the pipelined variant that was measured)
+  constexpr bool kBuildJs = kMask || Grp<KL>::kCachePerEnd < 4;  // J . s rebuilt here (else read from the cache)
+  struct EndVals {
+    V D, an, ax, jna, jxa, u0, u1, mu;  // (u0, u1) = (cpx, cpz) if kBuildJs else (Jn.s, Jx.s)
+  };
+  auto load = [&](int sl) {
+    EndVals e;
+    e.D = cx.Lds(sl * kSlotsPerEnd + 4);
+    e.an = cx.Lds(sl * kSlotsPerEnd + 2);
+    e.ax = cx.Lds(sl * kSlotsPerEnd + 3);
+    e.jna = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 0);  // RowsPass<true> at the same `a`
+    e.jxa = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 1);
+    if constexpr (kBuildJs) {
+      e.u0 = cx.Lds(sl * kSlotsPerEnd + 0);
+      e.u1 = cx.Lds(sl * kSlotsPerEnd + 1);
+    } else {
+      e.u0 = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 2);
+      e.u1 = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 3);
+    }
+    e.mu = cx.C(kTMu + Grp<KL>::SlotBody(sl));  // (the table also carries the torso's)
+    return e;
+  };
+  auto visit = [&](const EndVals& e, int sl) {
     V jns, jxs;
     // first evaluation of this line search: J . s, kept for the others (without the (Jn.s, Jx.s) slots -- the
     // Hopper -- rebuilt by every evaluation)
-    if constexpr (kMask || Grp<KL>::kCachePerEnd < 4) {
-      const V cpx = cx.Lds(sl * kSlotsPerEnd + 0), cpz = cx.Lds(sl * kSlotsPerEnd + 1);
+    if constexpr (kBuildJs) {
+      const V cpx = e.u0, cpz = e.u1;
       // s . (Jacobian columns of a point on local body b): torso dofs, then the hinges up to b
       jns = s[1] - (cpx - p.px[0]) * s[2];
       jxs = s[0] + (cpz - p.pz[0]) * s[2];
@@ -945,10 +977,10 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
         cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 3) = jxs;
       }
     } else {
-      jns = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 2);
-      jxs = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 3);
+      jns = e.u0;
+      jxs = e.u1;
     }
-    const V mu = cx.C(kTMu + Grp<KL>::SlotBody(sl));  // (the table also carries the torso's)
+    const V mu = e.mu, D = e.D, an = e.an, ax = e.ax, jna = e.jna, jxa = e.jxa;
     const V jar1 = jna - an, jv1 = jns;
     const V jar2 = jna - mu * jxa - (an + ax), jv2 = jns - mu * jxs;
     const V jar3 = jna + mu * jxa - (an - ax), jv3 = jns + mu * jxs;
@@ -964,6 +996,11 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
       MaskSetNZ(mask, c2, 4 + 3 * sl);
       MaskSetNZ(mask, c3, 5 + 3 * sl);
     }
+  };
+  EPA_NO_UNROLL
+  for (unsigned rem = ends & 0xFFFFu; rem != 0; rem &= rem - 1) {
+    const int sl = __builtin_ctz(rem);
+    visit(load(sl), sl);
   }
 }
 
