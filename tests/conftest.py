@@ -35,7 +35,7 @@ def _torch_runtime_first():
     bundles its own ROCm runtime; libenvpool_amd.so links the system one.  Both work in one process
     (the device-path tests rely on it), but a torch runtime that comes up late -- after the other
     one has created and destroyed dozens of pools with six streams each -- was once refused its
-    devices ("No HIP GPUs are available", profiles/r3l_*): the order is made deterministic here."""
+    devices ("No HIP GPUs are available", profiles/archive/r3l_*): the order is made deterministic here."""
     if not os.path.exists("/dev/kfd"):
         return
     try:
