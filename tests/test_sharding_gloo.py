@@ -69,3 +69,53 @@ def test_all_gather_rows_gloo_world2(total):
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def _env_worker(rank, world, port, total, steps, q):
+    """Each rank steps ITS shard of a `total`-env CartPole pool (the CPU oracle stands in for the device pool: the
+    partition rule -- env i of the job is seeded seed + i whatever rank owns it, `info:env_id` global -- is the
+    same `env_id_offset` arithmetic), all-gathers the obs / reward / env_id rows every step and compares with the
+    single pool of `total` envs stepped with the same actions."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.orc import Oracle
+
+    off, cnt = shard_range(total, rank, world)
+    shard = Oracle("CartPole", cnt, seed=7 + off, max_episode_steps=11)  # env j of the shard: seed 7 + off + j
+    whole = Oracle("CartPole", total, seed=7, max_episode_steps=11)
+    a, w = shard.reset(), whole.reset()
+    rng = np.random.default_rng(3)
+    ok = True
+    for t in range(steps):
+        obs = all_gather_rows(torch.from_numpy(a["obs"]), total)
+        rew = all_gather_rows(torch.from_numpy(a["reward"]), total)
+        ids = all_gather_rows(torch.from_numpy(a["info:env_id"] + off), total)  # the pool adds env_id_offset
+        ok &= bool(np.array_equal(obs.numpy(), w["obs"])) and bool(np.array_equal(rew.numpy(), w["reward"]))
+        ok &= bool(np.array_equal(ids.numpy().ravel(), np.arange(total)))
+        act = rng.integers(0, 2, total).astype(np.int32)  # the same stream on every rank
+        a, w = shard.step(act[off:off + cnt]), whole.step(act)
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [32, 33])
+def test_sharded_rollout_equals_the_single_pool(total):
+    """world_size 2, even and uneven shards, 40 steps with truncations + auto-resets inside: the union of the
+    shards IS the single-pool rollout, row for row."""
+    from oracle import orc
+    if not orc.have_port():
+        pytest.skip("oracle/_build/liboracle.so not built")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_env_worker, args=(r, world, port, total, 40, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, True), (1, True)]
