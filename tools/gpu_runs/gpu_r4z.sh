@@ -1,10 +1,14 @@
 #!/bin/bash
 # Round-4 measurement pass on the final kernels: probes, full GPU suite + smoke, the bench lines, and
 # rocprofv3 kernel trace + PMC passes (tools/profile_bench.sh) of every MuJoCo kernel -> profiles/pmc.json
+# usage: gpu_r4z.sh [a|b|c|all]   a = probes, suite, smoke, bench lines; b / c = the profile passes (three calls, so
+# that an interrupted session loses at most one of them)
 set -u
 export TMPDIR=/tmp
+PART=${1:-all}
 O=gpurun_out/r4z
 mkdir -p $O
+if [ "$PART" = a ] || [ "$PART" = all ]; then
 bash tools/probe_refs.sh > $O/probe_gpu_box.log 2>&1
 timeout 1800 python -m pytest tests -m gpu -q -s > $O/gpu_tests.log 2>&1; echo "rc=$?" >> $O/gpu_tests.log; grep -E "passed|failed|rc=|FAILED" $O/gpu_tests.log | tail -6
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> $O/gpu_tests.log 2>&1; tail -1 $O/gpu_tests.log
@@ -22,17 +26,22 @@ for l in open('gpurun_out/r4z/bench.jsonl'):
     d=json.loads(l); print(d['metric'], d['dtype'], d['config']['params'], '%.3e'%d['value'], 'kernel_ms %.3f'%d['roofline']['kernel_ms'])
 PY
 timeout 600 python tools/bench_numpy_api.py > $O/numpy_api.jsonl 2>>$O/err
+fi
 P() { tag=$1; shift; bash tools/profile_bench.sh $tag "$@" > $O/$tag.log 2>&1; }
+if [ "$PART" = b ] || [ "$PART" = all ]; then
 P r4z_cheetah_lg2
 P r4z_cheetah_lg4_8k --num-envs 8192
 P r4z_walker_lg2 --task Walker2d
 P r4z_hopper_lg1 --task Hopper
 P r4z_hopper_lane_f64 --task Hopper --param planar_layout=1
 P r4z_cheetah_lane_f64 --param planar_layout=1
+P r4z_pusher --task Pusher --num-envs 65536
+fi
+if [ "$PART" = c ] || [ "$PART" = all ]; then
 P r4z_ant32k_f64 --task Ant --num-envs 32768
 P r4z_ant64k_f64 --task Ant --num-envs 65536
 P r4z_ant64k_f32 --task Ant --num-envs 65536 --precision fp32
 P r4z_humanoid4 --task Humanoid --num-envs 65536
 P r4z_standup4 --task HumanoidStandup --num-envs 65536
-P r4z_pusher --task Pusher --num-envs 65536
+fi
 for d in gpurun_out/prof_r4z_*; do echo "== $d"; sed -n '/timed window/,/^$/p' $d/summary.md | head -4; done
