@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--precision", default="fp64", choices=["fp32", "fp64"],
                     help="fp32 exists for --task Ant only (the planar families are fp64 only since round 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-timed", action="store_true",
+                    help="skip the reset / numpy-API / async legs: under rocprofv3 their launches (half-size async "
+                         "batches of the SAME kernel) would pollute the per-kernel means (tools/profile_bench.sh)")
     ap.add_argument("--action-scale", type=float, default=None,
                     help="actions are uniform in [-s, s]; default: the task's action-space bound")
     ap.add_argument("--min-time", type=float, default=5.0,
@@ -217,7 +220,7 @@ def main():
     reset_ms = None
     numpy_api = None
     gpu_legs_s = elapsed  # wall time of the legs that keep the GPU busy (for the driver's busy sampler)
-    if world == 1:
+    if world == 1 and not args.only_timed:
         # (a) one step in which EVERY env resets (mt19937 draws + state init + reset frame):
         #     the spike an episode boundary costs, outside the steady-state figure above
         pool.set_timing(True)
@@ -246,7 +249,7 @@ def main():
                      "steps": k_np, "note": "send(numpy) + recv() -> numpy, PCIe inclusive"}
 
     async_mode = None
-    if world == 1 and n % 2 == 0:
+    if world == 1 and n % 2 == 0 and not args.only_timed:
         # (c) the reference benchmark's OWN loop (benchmark/test_envpool.py:94-105): async mode,
         #     `recv()` then `send(action, env_id)` of batch_size rows with num_envs / batch_size batches
         #     in flight -- here on the device path, batch_size = num_envs / 2.  Successive batches run
