@@ -28,6 +28,9 @@ for path in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}*",
     kernel = m.group(1).strip()
     ctr = {k: float(v) for k, v in re.findall(r"\| (\w+) \| ([0-9.e+-]+) \| \d+ \|", text)}
     tr = re.search(r"\| %s \| (\d+) \| ([0-9.]+) \|" % re.escape(kernel), text)
+    # the bench's timed window inside the trace, when the summary has it (steady state; the all-launch average of
+    # --stats includes the cheap steps right after the common reset)
+    win = re.search(r"launches \d+\.\.\d+ of \d+: avg ([0-9.]+) us", text)
     lg = re.search(r"PlanarLgStepKernel<(\d), (\d), (\d)>", kernel)  # <lanes per env, model, waves per SIMD>
     if lg:  # canonical name (bench.py builds the same): all lane-group kernels are fp64
         model = {"0": "", "1": "[Walker2d]", "2": "[Walker2d-v5]", "3": "[Hopper]"}[lg.group(2)]
@@ -48,7 +51,8 @@ for path in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}*",
         "valu_insts_per_wave": ctr.get("SQ_INSTS_VALU", 0) / waves,
         "lds_insts_per_wave": ctr.get("SQ_INSTS_LDS", 0) / waves,
         "wait_frac_of_wave_cycles": ctr.get("SQ_WAIT_ANY", 0) / max(ctr.get("SQ_WAVE_CYCLES", 1), 1),
-        "rocprof_avg_us": float(tr.group(2)) if tr else None,
+        "rocprof_avg_us": float(win.group(1)) if win else (float(tr.group(2)) if tr else None),
+        "rocprof_avg_us_all_launches": float(tr.group(2)) if tr else None,
         "note": "gfx950: FETCH_SIZE counts half the bytes of a coalesced stream -> x2",
         "source": f"profiles/{os.path.basename(os.path.dirname(path)).replace('prof_', '')}_summary.md",
         "num_envs": num_envs,

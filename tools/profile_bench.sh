@@ -8,10 +8,10 @@ export TMPDIR=/tmp
 TAG=${1:-r1}; shift || true
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
-# one 200-step block of the bench's timed region and nothing else: the reset / numpy-API / async legs launch the
+# one 200-step block of the bench's timed region after 300 warm-up steps (steady state) and nothing else: the reset / numpy-API / async legs launch the
 # same kernel on other batch shapes (the async leg: thousands of HALF-size launches) and would pull every
 # per-kernel mean -- duration, PMC counts per launch -- towards theirs
-ARGS="--steps 200 --warmup 20 --min-time 0 --no-cpu-baseline --only-timed $*"
+ARGS="--steps 200 --warmup 300 --min-time 0 --no-cpu-baseline --only-timed $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python bench.py $ARGS > "$OUT/trace.log" 2>&1
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM" \

@@ -50,8 +50,10 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
                   f"{float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {r['Percentage']} |")
     print()
 # the bench's timed window inside the trace: bench.py launches 1 reset + W warm-up + K timed steps (then
-# reset / numpy-API legs); tools/profile_bench.sh runs it with --steps 200 --warmup 20
-W, K = int(os.environ.get("EPA_PROF_WARMUP", 20)), int(os.environ.get("EPA_PROF_STEPS", 200))
+# reset / numpy-API legs unless --only-timed); tools/profile_bench.sh runs it with --steps 200 --warmup 300, so that the
+# window holds the de-synchronised steady state the bench line measures (right after the common reset every env of the
+# episodic tasks is upright and cheap: Hopper 0.22 ms per launch over the first 200 steps, 0.35 ms in steady state)
+W, K = int(os.environ.get("EPA_PROF_WARMUP", 300)), int(os.environ.get("EPA_PROF_STEPS", 200))
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
     rows = defaultdict(list)
     for r in csv.DictReader(open(f)):
@@ -75,14 +77,15 @@ for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), r
     for r in csv.DictReader(open(f)):
         name = r.get("Kernel_Name", "")
         if any(k in name for k in KEY):
-            agg[short(name)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[short(name)][r["Counter_Name"]].append((int(r.get("Dispatch_Id", 0)), float(r["Counter_Value"])))
 for k, ctrs in agg.items():
     print(f"## PMC per launch (mean over launches): {k}\n")
     print("| counter | mean | launches |")
     print("|---|---|---|")
     for c in sorted(ctrs):
-        v = ctrs[c]
-        # drop the first launch (reset path) from the mean when there are many
-        vv = v[1:] if len(v) > 5 else v
-        print(f"| {c} | {sum(vv)/len(vv):.4g} | {len(v)} |")
+        v = [x for _, x in sorted(ctrs[c])]  # dispatch order
+        # the bench's timed window (the launches after the reset + warm-up ones) when the run has it,
+        # else everything but the first launch (reset path)
+        vv = v[1 + W:1 + W + K] if len(v) >= 1 + W + K else (v[1:] if len(v) > 5 else v)
+        print(f"| {c} | {sum(vv)/len(vv):.4g} | {len(vv)} |")
     print()
