@@ -5,7 +5,7 @@ envpool/mujoco/gym/mujoco_gym_align_test.py:120-171 (obs atol 1e-6 / rtol 1e-7
 against mujoco 3.6.0); those tolerances are used here.
 
 MuJoCo 3.6.0 is reachable from neither the build container nor the GPU boxes
-(profiles/archive/r2_probe_*.log, profiles/r4_probe_*.log), so until somebody runs the pin script on a machine
+(profiles/archive/r2_probe_*.log, profiles/r4_probe_container.log, profiles/r4z_probe_gpu_box.log), so until somebody runs the pin script on a machine
 that has the wheel the golden files do not exist, the `*_real_mujoco` tests
 SKIP, and MuJoCo parity stays UNPINNED.  Dropping the .npz files into
 tests/golden/ flips every test below without a code change; the `*_harness_*`
