@@ -170,7 +170,7 @@ class AtariPool : public Pool {
     // the step and wants every core.  An emulator that costs ~1 us per frame (the synthetic
     // console of the tests) is better served by fewer workers (emulate phase of a 1024-env step:
     // 0.9 ms with 32 workers, 4.3 ms with 128, 5.0 ms with 256 on a 256-thread host,
-    // profiles/r2e): set num_threads, or EPA_ATARI_THREADS for a process-wide default.
+    // profiles/archive/r2e): set num_threads, or EPA_ATARI_THREADS for a process-wide default.
     int nthreads = a_.num_threads;
     if (nthreads <= 0) {
       const char* ev = getenv("EPA_ATARI_THREADS");

@@ -13,7 +13,7 @@
 //    A lane therefore carries an 8x8 packed matrix (36 numbers) instead of the
 //    81 structural non-zeros of the 14x14, an 8-vector instead of a 14-vector,
 //    and the kernel needs no scratch memory (the one-env-per-lane version moved
-//    3 GB of spills per launch, profiles/r1g_ant_f64_summary.md);
+//    3 GB of spills per launch, profiles/archive/r1g_ant_f64_summary.md);
 //  * the legs differ only by mirror signs (sx, sy, ankle-axis sign, ankle range),
 //    which are per-lane values: all four legs execute the SAME instructions, the
 //    9-way body switch of mj_ant.hip.h becomes a 3-way switch on the sphere's link

@@ -1724,7 +1724,7 @@ struct Hum4 {
             // (entries of rows / columns beyond the wave's row count are stale but finite: they only
             // ever meet a zero force)
             // (the run-time index here; the compile-time form of the overflow visits -- ShGetTriRow -- measured
-            // 3 % slower for HumanoidStandup in this place, profiles/r3zj_*)
+            // 3 % slower for HumanoidStandup in this place, profiles/archive/r3zj_*)
             const V a = c.ShGetTriLane(4 * k, cidx, base);
             AR[k][cidx] = Sel(c.RowIndexLane(4 * k) == V(cidx), arr[k], Sel(have, a, V(0)));
           }
@@ -1829,7 +1829,7 @@ struct Hum4 {
       // one scalar compare per visit decides whether the wave runs it
       const int nlive = done ? 0 : nrow_e;
       // (MP::kLazyNact: the wave-level maximum changes only when an env finishes -- Humanoid + 2.5 %, HumanoidStandup
-      // - 1 %, profiles/r3zj_*; otherwise every sweep)
+      // - 1 %, profiles/archive/r3zj_*; otherwise every sweep)
       if (!MP::kLazyNact || AnyWave(done != done_seen)) {
         nact = WaveMax(nlive);
         done_seen = done;

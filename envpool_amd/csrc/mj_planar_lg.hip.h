@@ -1,5 +1,5 @@
-// K3' — `mj_step` of the planar two-legged gym robots (HalfCheetah, Walker2d) with ONE ENV
-// SPLIT OVER A LANE GROUP of 2 or 4 adjacent lanes of a wavefront.
+// K3' — `mj_step` of the planar legged gym robots with ONE ENV PER LANE GROUP: the two-legged HalfCheetah and
+// Walker2d split over 2 or 4 adjacent lanes of a wavefront, the one-legged Hopper on a group of ONE lane.
 //
 // Same arithmetic as mj_cheetah.hip.h (MuJoCo 3.6.0's mj_step for
 // third_party/mujoco_gym_xml_patches/{half_cheetah,walker2d,walker2d_v5}_envpool.xml, called
@@ -12,8 +12,9 @@
 //    capsule end spheres, its 3x3 + 3x3 blocks; the torso quantities (pose, velocity, the
 //    reduced 3x3) are replicated over the group.  A lane therefore carries a packed 6x6 (21
 //    numbers) instead of the 39 structural non-zeros of the 9x9 and 6-vectors instead of
-//    9-vectors: the one-env-per-lane kernel needs all 512 registers of a SIMD lane plus scratch
-//    and runs at one wave per SIMD; this one runs at two or more;
+//    9-vectors: the one-env-per-lane kernel needs all 512 registers of a SIMD lane plus scratch;
+//    this one needs 256 + ~200 accumulation registers and no scratch.  Both run at ONE wave per SIMD
+//    (a second wave would need <= 256 registers in all: measured, it spills 200+ and is slower);
 //  * both legs execute the SAME instructions: everything that differs between the back and the
 //    front leg (link offsets, masses, joint ranges, gears, end spheres) is a per-lane constant
 //    read from a small table (`Cx::C(id)`), everything that is the same for the whole robot is an

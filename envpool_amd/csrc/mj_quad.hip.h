@@ -148,8 +148,8 @@ __device__ __forceinline__ int DppMov(int x) {
   // knows the `old` operand is dead -- with bound_ctrl = false every DPP move carries a `v_mov_b32 dst, 0` in
   // front of it (864 of the 1116 DPP moves of the round-2 Humanoid kernel).  Measured: Ant +3 % without those
   // moves.  The round-2 Humanoid quad kernel was 1.2 % slower without them and kept them (-DEPA_DPP_OLD_ZERO,
-  // profiles/r2u_bench.jsonl); since the hybrid-PGS rewrite of round 3 it is faster WITHOUT them
-  // (profiles/r3s_standup_hybrid_pgs.md: Humanoid 10.85 -> 9.97 ms with the leaner visits + bound_ctrl), so no
+  // profiles/archive/r2u_bench.jsonl); since the hybrid-PGS rewrite of round 3 it is faster WITHOUT them
+  // (profiles/archive/r3s_standup_hybrid_pgs.md: Humanoid 10.85 -> 9.97 ms with the leaner visits + bound_ctrl), so no
   // TU of the Makefile defines EPA_DPP_OLD_ZERO any more; the switch stays for A/B builds.
 #ifdef EPA_DPP_OLD_ZERO
   return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false);

@@ -63,7 +63,7 @@ constexpr int kAntEnvsPerBlock = kAntBlock / 4;
 
 // waves per SIMD the register allocator targets: fp64 needs the whole 512-entry file
 // (486 registers, no scratch); fp32 fits two waves (25 spilled registers) and gains 50 %
-// from the second wave (profiles/r2b: 1.94e7 -> 2.93e7 env-steps/s at N=32768)
+// from the second wave (profiles/archive/r2b: 1.94e7 -> 2.93e7 env-steps/s at N=32768)
 template <typename T>
 constexpr int kAntWavesPerEu = sizeof(T) == 4 ? 2 : 1;
 

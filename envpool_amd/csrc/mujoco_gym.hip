@@ -364,7 +364,7 @@ class CheetahPool : public Pool {
     // group of 2 / 4 lanes (mujoco_planar_lg.hip; fp64, HalfCheetah / Walker2d, frame_stack 1),
     // 0 (default) = chosen HERE from the rows this pool normally has in flight (num_envs in sync mode,
     // min(num_envs, 4 x batch_size) in async mode, see below): 2 lanes per env from 24576 rows up, 4 below
-    // (profiles/r3i_lane_group_sweep.txt:
+    // (profiles/archive/r3i_lane_group_sweep.txt:
     // N = 32768: 2.5e8 vs 2.0e8, N = 16384: 1.3e8 vs 1.7e8).  Fixed per pool, not per launch: the two
     // layouts sum the contact rows in different orders, and an env's bits must not depend on how
     // many other envs a particular send happens to carry.  It DOES depend on num_envs / batch_size of
@@ -388,7 +388,7 @@ class CheetahPool : public Pool {
     lg_ok_ = fp64_ && task_.frame_stack == 1;
     // (async mode: several batches are in flight on the pool's compute streams, so what fills the machine is
     // batch_size x streams, not one batch: 8 x 8192 of 65536 envs measured 2.83e8 with 2 lanes per env against
-    // 2.06e8 with 4, profiles/r3r_async_probe.jsonl; and partly filled waves -- made to occupy more SIMDs with ONE
+    // 2.06e8 with 4, profiles/archive/r3r_async_probe.jsonl; and partly filled waves -- made to occupy more SIMDs with ONE
     // small batch -- only take lanes from the other batches there)
     async_ = cfg.batch_size > 0 && cfg.batch_size < cfg.num_envs;
     if (layout_ == 0) {
@@ -400,7 +400,7 @@ class CheetahPool : public Pool {
       if (hopper) layout_ = kLayoutHopperLg;
     }
     // register budget of the lane-group kernel: one wave per SIMD with all 512 registers (default;
-    // measured faster at every batch size, profiles/r3f_lane_group_sweep.txt) or two with 256 + spills
+    // measured faster at every batch size, profiles/archive/r3f_lane_group_sweep.txt) or two with 256 + spills
     lg_waves_ = (int)cfg.Get("planar_waves", 1) == 2 ? 2 : 1;
     lpt_ = cfg.Get("planar_lpt", 1) != 0;
     if (lg_ok_) {
@@ -465,7 +465,7 @@ class CheetahPool : public Pool {
     // A wave runs as long as its slowest lane and visits every end sphere that touches on ANY of its
     // lanes, and these kernels hold one wave per SIMD: a batch between 16 and 64 envs per SIMD is spread
     // over all SIMDs with 16 / 32 / 48 envs per wave (HalfCheetah N = 16384 .. 49152: +5 .. +8 %,
-    // profiles/r2ze_planar_spread.txt).  Not below 16 per SIMD: there partially filled waves measured
+    // profiles/archive/r2ze_planar_spread.txt).  Not below 16 per SIMD: there partially filled waves measured
     // SLOWER (N = 8192 as 512 waves of 16: 0.26 ms against 0.21 ms as 128 full waves).
     // One env per lane group (mj_planar_lg.hip.h) wherever it applies.
     int layout = lg_ok_ && trace_.d == nullptr ? layout_ : 1;

@@ -71,8 +71,8 @@ struct LgOrder {
 
 }  // namespace planar
 
-// mujoco_planar_lg.hip: one env per group of `kl` (2 or 4) lanes; `tab` = the device copy of
-// mj::plg::BuildTable<kl>(model); model = mj::PlanarModelId (not the Hopper); frame_stack must be 1;
+// mujoco_planar_lg.hip: one env per group of `kl` lanes -- 2 or 4 for HalfCheetah / Walker2d, 1 for the Hopper (and
+// only it); `tab` = the device copy of mj::plg::BuildTable<kl>(model); model = mj::PlanarModelId; frame_stack must be 1;
 // waves = 1 or 2: the kernel variant whose register allocation aims at that many waves per SIMD
 // `wave_slots`: SIMDs of the device; `ticket` / `ticket_base`: the chunk queue's device counter and the
 // host's copy of its value (one pair per stream that launches concurrently, see PlanarLgStepKernel)

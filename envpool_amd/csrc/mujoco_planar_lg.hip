@@ -1,10 +1,10 @@
-// K3' — batched step kernel of the planar two-legged gym robots (HalfCheetah, Walker2d) with one
-// env per LANE GROUP (2 or 4 adjacent lanes; mj_planar_lg.hip.h), fp64.
+// K3' — batched step kernel of the planar legged gym robots with one env per LANE GROUP
+// (mj_planar_lg.hip.h), fp64: HalfCheetah / Walker2d on 2 or 4 adjacent lanes, the one-legged Hopper on ONE.
 //
 // Replaces, for the whole batch in one launch, exactly what CheetahStepKernel (mujoco_gym.hip)
 // replaces -- MujocoEnv::{MujocoReset,MujocoStep} (envpool/mujoco/gym/mujoco_env.h:126-148),
 // HalfCheetahEnvBase::{MujocoResetModel,Reset,Step,WriteState} (gym/half_cheetah.h:105-185),
-// Walker2dEnvBase::{...} (gym/walker2d.h:119-219) and the runtime around them
+// Walker2dEnvBase::{...} (gym/walker2d.h:119-219), HopperEnvBase::{...} (gym/hopper.h:121-230) and the runtime around them
 // (async_envpool.h:118-132, env.h:184-256) -- on the same device state (SoA float64 qpos / qvel /
 // qacc_warmstart [9][N]), so a pool can switch between the two layouts from one launch to the next.
 //
@@ -294,7 +294,7 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
 
 // PERSISTENT waves over a dynamic queue of chunks.  A wave runs as long as its slowest env and
 // visits the union of its envs' touching slots, so chunks differ a lot in duration (mean wave 80 us,
-// slowest 143 us at N = 32768: profiles/r3e_*): with one chunk per wave the launch lasts as long as
+// slowest 143 us at N = 32768: profiles/archive/r3e_*): with one chunk per wave the launch lasts as long as
 // its slowest wave.  Here the grid is the number of waves that are resident at once, wave i starts
 // with chunk i and then takes the next chunk off an atomic ticket counter until none is left --
 // whoever finishes early does the extra work.  `ticket_base`: the counter's value before this
@@ -377,7 +377,7 @@ void LaunchKl(hipStream_t st, int model, int wave_slots, bool spread, const Chee
   // A wave runs as long as its slowest env and visits the union of its envs' touching slots: while
   // there are fewer full chunks than resident waves, smaller chunks (partly filled waves) on more
   // SIMDs are faster (N = 8192 at 4 lanes per env: 512 waves of 16 envs 95 us, 1024 waves of 8 envs
-  // 90 us; N = 12288 as 12 per wave: 96 -> 93 us; profiles/r3l_lane_group_spread_ab.txt).  Half, three
+  // 90 us; N = 12288 as 12 per wave: 96 -> 93 us; profiles/archive/r3l_lane_group_spread_ab.txt).  Half, three
   // quarters or all of a wave: quarter-filled waves measured SLOWER (N = 2048: 87 -> 112 us).
   const int full = kBlock / KL, q = full / 4;
   int per = ((a.k + resident - 1) / resident + q - 1) / q * q;
