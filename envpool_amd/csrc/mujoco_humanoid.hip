@@ -17,6 +17,8 @@
 // reference reads; the mass centre "before" a step is therefore the lagged one of the
 // previous step (persistent slot `lag`).
 #define EPA_SINCOS_MODE 0  // see mj_cheetah.hip.h; Humanoid: mode 1 lets the scheduler interleave 17 joints (2.3 k VGPR spills, 1.94 -> 1.77 M env-steps/s)
+#include <map>
+
 #include "mujoco_humanoid_common.h"
 #include "mj_tree.hip.h"
 #include "build/mj_humanoid_consts.inc"  // generated: kHumanoidModelConst, kHumanoidStandupModelConst
@@ -319,22 +321,30 @@ class HumanoidPool : public Pool {
     sort_ = quad_ && cfg.Get("hum_sort", 1) != 0;
     EPA_HIP(hipMalloc(&dev_.cost, sizeof(int) * (size_t)cfg.num_envs));
     EPA_HIP(hipMemsetAsync(dev_.cost, 0, sizeof(int) * (size_t)cfg.num_envs, stream_));
-    EPA_HIP(hipMalloc(&perm_, sizeof(int) * (size_t)cfg.num_envs));
-    const size_t blocks = ((size_t)cfg.num_envs + 63) / 64;
-    ws_bytes_ = quad_ ? Hum4WorkspaceBytes(cfg.num_envs) : sizeof(double) * blocks * 64 * (size_t)Total();
-    EPA_HIP(hipMalloc(&dev_.ws, ws_bytes_));
-    EPA_HIP(hipMemsetAsync(dev_.ws, 0, ws_bytes_, stream_));
+    if (!quad_) {  // (the quad kernel's per-launch scratch is per compute stream: ScratchFor)
+      const size_t blocks = ((size_t)cfg.num_envs + 63) / 64;
+      ws_bytes_ = sizeof(double) * blocks * 64 * (size_t)Total();
+      EPA_HIP(hipMalloc(&dev_.ws, ws_bytes_));
+      EPA_HIP(hipMemsetAsync(dev_.ws, 0, ws_bytes_, stream_));
+    }
     const size_t sb = sizeof(double) * (size_t)T::MakeLayout(kHumanoidModelConst).npersist * cfg.num_envs;
     EPA_HIP(hipMalloc(&dev_.state, sb));
     EPA_HIP(hipMemsetAsync(dev_.state, 0, sb, stream_));
     InitCommon();
   }
   ~HumanoidPool() override {
-    (void)hipFree(dev_.ws);
+    if (!quad_) (void)hipFree(dev_.ws);
+    for (auto& kv : scratch_) {
+      (void)hipFree(kv.second.ws);
+      (void)hipFree(kv.second.perm);
+    }
     (void)hipFree(dev_.state);
     (void)hipFree(dev_.cost);
-    (void)hipFree(perm_);
   }
+  // The quad kernel keeps what persists per ENV (dev_.state, dev_.cost); its workspace and the cost-sort
+  // permutation belong to a LAUNCH, so with one copy per compute stream batches of an async pool run
+  // concurrently like every other family's (round 4; they used to share one copy and one stream).
+  bool ConcurrentSafe() const override { return quad_; }
   int StateDim() const override { return kHumanoidModelConst.nq + 2 * kHumanoidModelConst.nv + 7; }
   void GetState(const int* d_ids, int k, double* d_out) override {
     (standup_ ? HumLaunchGetStandup : HumLaunchGetHumanoid)(stream_, k, dev_, common_, d_ids, d_out);
@@ -348,12 +358,15 @@ class HumanoidPool : public Pool {
               const OutPtrs& out) override {
     StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps, cfg_.env_id_offset};
     if (quad_) {
-      dev_.perm = nullptr;
+      const Scratch& sc = ScratchFor(stream_, k);
+      HumDev dev = dev_;
+      dev.ws = sc.ws;
+      dev.perm = nullptr;
       if (sort_ && k > 16) {
-        dev_.perm = perm_;
-        Hum4LaunchSort(stream_, dev_, a);
+        dev.perm = sc.perm;
+        Hum4LaunchSort(stream_, dev, a);
       }
-      Hum4LaunchStep(stream_, standup_, (k + 15) / 16, dev_, common_, a, static_cast<const double*>(d_action),
+      Hum4LaunchStep(stream_, standup_, (k + 15) / 16, dev, common_, a, static_cast<const double*>(d_action),
                      out, task_);
       return;
     }
@@ -366,12 +379,38 @@ class HumanoidPool : public Pool {
   int Total() const {
     return standup_ ? HumWorkspaceSlotsStandup() : HumWorkspaceSlotsHumanoid();
   }
+  // per-launch scratch of the quad kernel on compute stream `st`, for launches of up to `rows` rows: sized for
+  // the pool's usual launch (batch_size in async mode, else num_envs) and grown if a bigger one comes
+  // (e.g. the reset of all envs in one send); a regrowth waits for the stream and frees (rare)
+  struct Scratch {
+    double* ws{nullptr};
+    int* perm{nullptr};
+    int rows{0};
+  };
+  const Scratch& ScratchFor(hipStream_t st, int k) {
+    Scratch& sc = scratch_[st];
+    if (sc.rows < k) {
+      if (sc.ws != nullptr) {
+        EPA_HIP(hipStreamSynchronize(st));
+        (void)hipFree(sc.ws);
+        (void)hipFree(sc.perm);
+      }
+      const bool async = cfg_.batch_size > 0 && cfg_.batch_size < cfg_.num_envs;
+      const int usual = async ? cfg_.batch_size : cfg_.num_envs;
+      sc.rows = k > usual ? k : usual;
+      const size_t bytes = Hum4WorkspaceBytes(sc.rows);
+      EPA_HIP(hipMalloc(&sc.ws, bytes));
+      EPA_HIP(hipMemsetAsync(sc.ws, 0, bytes, st));
+      EPA_HIP(hipMalloc(&sc.perm, sizeof(int) * (size_t)sc.rows));
+    }
+    return sc;
+  }
   HumDev dev_{};
   HumTask task_{};
   size_t ws_bytes_{0};
   bool standup_;
   bool quad_{true}, sort_{true};
-  int* perm_{nullptr};
+  std::map<hipStream_t, Scratch> scratch_;
 };
 
 }  // namespace

@@ -364,6 +364,19 @@ def test_async_batches_on_several_streams_match_one_stream(task, adim, device_pa
     assert steps == recvs * b and max(len(v) for v in one.values()) >= 10
 
 
+@pytest.mark.parametrize("task", ["Humanoid", "HumanoidStandup"])
+def test_async_humanoid_batches_on_several_streams_match_one_stream(task):
+    """Round 4: the quad Humanoid kernels keep their per-launch scratch (workspace, cost-sort permutation) per
+    compute stream, so an async pool runs their batches concurrently too.  Same batches => same waves => every
+    env's sequence bit-identical to the single-stream run (host path and device path)."""
+    n, b, recvs = 1024, 256, 48
+    for device_path in (False, "lent"):
+        one = _async_rollout(task, 17, n, b, 1, recvs, device_path)
+        many = _async_rollout(task, 17, n, b, 4, recvs, device_path)
+        for e in range(n):
+            assert one[e] == many[e], (device_path, e)
+
+
 def test_async_streams_tolerate_a_resend_before_recv():
     """An env sent again before it was received (the reference would race) is ordered behind its own
     previous step: same per-env sequences as the single-stream engine."""
