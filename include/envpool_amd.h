@@ -81,9 +81,9 @@ typedef struct epa_pool epa_pool;
  *                 first, by their duration in the previous launch; 0 index order.  Never changes results.
  *   "compute_streams" async mode (batch_size < num_envs): successive batches run on this many
  *                 compute streams (default 4, 1 = one stream), like the reference's worker threads
- *                 step all queued slices in parallel (core/async_envpool.h:116-132).  Families whose
- *                 kernels share per-launch scratch (Humanoid*) and pools with the generic frame stack
- *                 keep one stream.  The rule for the caller is the reference's: an env may be sent
+ *                 step all queued slices in parallel (core/async_envpool.h:116-132).  Pools with the generic
+ *                 frame stack (frame_stack > 1) and the one-env-per-lane Humanoid kernel (hum_layout = 0, one
+ *                 shared workspace) keep one stream.  The rule for the caller is the reference's: an env may be sent
  *                 again only after recv handed it out (host path: a violation is detected and that
  *                 launch is ordered behind everything enqueued; device path: the env ids of a send
  *                 should be the `info:env_id` array of a batch recv_device returned -- the launch then
