@@ -16,25 +16,26 @@ from .utils import check_key_duplication
 
 def _env_ids_from_reset_options(options: dict[str, Any] | None,
                                 num_envs: int) -> np.ndarray | None:
-    # gymnasium_envpool.py:51-74
-    if options is None:
+    """`reset(options={"reset_mask": bool[num_envs]})` -> the env ids to reset, or None for "all envs".
+
+    Contract of envpool/python/gymnasium_envpool.py:51-74 (the only option EnvPool understands is
+    `reset_mask`; anything else, a mask of the wrong shape or an all-False mask is a ValueError with the
+    reference's wording, which callers match on)."""
+    mask = None
+    for key, value in (options or {}).items():
+        if key != "reset_mask":
+            bad = sorted(k for k in options if k != "reset_mask")
+            raise ValueError(f"Unsupported Gymnasium reset options for EnvPool: {bad}")
+        mask = value
+    if mask is None:
         return None
-    unknown = set(options) - {"reset_mask"}
-    if unknown:
-        raise ValueError(
-            f"Unsupported Gymnasium reset options for EnvPool: {sorted(unknown)}"
-        )
-    reset_mask = options.get("reset_mask")
-    if reset_mask is None:
-        return None
-    reset_mask = np.asarray(reset_mask, dtype=np.bool_)
-    if reset_mask.shape != (num_envs,):
-        raise ValueError(
-            f"reset_mask must have shape ({num_envs},), got {reset_mask.shape}"
-        )
-    if not np.any(reset_mask):
+    selected = np.asarray(mask, dtype=np.bool_)
+    if selected.shape != (num_envs,):
+        raise ValueError(f"reset_mask must have shape ({num_envs},), got {selected.shape}")
+    ids = np.nonzero(selected)[0].astype(np.int32)
+    if ids.size == 0:
         raise ValueError("reset_mask must select at least one environment.")
-    return np.flatnonzero(reset_mask).astype(np.int32)
+    return ids
 
 
 class GymnasiumEnvPoolMixin:
