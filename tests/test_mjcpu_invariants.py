@@ -658,6 +658,71 @@ def test_product_planar_lane_group_code_matches_oracle_on_cpu():
             assert worst < 1e-9 and worst_lane < 1e-9, (task, kl, worst, worst_lane)
 
 
+def test_hopper_lane_group_body_pair_rows_on_cpu():
+    """The Hopper's capsule-capsule body pairs (torso-leg, torso-foot, thigh-foot) in the lane-group form (a group of
+    ONE lane, mj_planar_lg.hip.h) on FOLDED poses, where they touch: host instantiation vs the one-env-per-lane form
+    (mj_cheetah.hip.h; must agree to rounding on every state, also the degenerate ones) and vs the oracle (the states
+    with deeply crossed capsule axes, where the contact normal is numerical noise in every implementation, show up
+    as rare outliers and are bounded in number, as in the GPU test)."""
+    from oracle.orc import Oracle
+
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    csrc = os.path.join(ROOT, "envpool_amd", "csrc")
+    for name, hdrs in (("planar_lg", ("mj_planar_lg.hip.h", "mj_cheetah.hip.h", "mj_cheetah_model.h")),
+                       ("cheetah", ("mj_cheetah.hip.h", "mj_cheetah_model.h"))):
+        so, src = os.path.join(h, f"lib{name}_host.so"), os.path.join(h, f"{name}_host.cpp")
+        newest = max(os.path.getmtime(f) for f in [src] + [os.path.join(csrc, x) for x in hdrs])
+        if not os.path.exists(so) or os.path.getmtime(so) < newest:
+            subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(os.path.join(h, "libplanar_lg_host.so"))
+    Lo = ctypes.CDLL(os.path.join(h, "libcheetah_host.so"))
+    vp = ctypes.c_void_p
+    L.planar_lg_step.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp]
+    n = 16
+    rng = np.random.default_rng(3)
+    orc = Oracle("Hopper", n, seed=9, max_episode_steps=1000)
+    noself = Oracle("Hopper", n, seed=9, max_episode_steps=1000,
+                    extra=(4, 1e-3, 1, 5e-3, 0, 0, 0, 0, -1, 0, 0, 3, 0, 0, 0, -1, 0, 1, 1))
+    orc.reset(), noself.reset()
+    worst_lane, pair_hits, compared, outliers = 0.0, 0, 0, 0
+    for t in range(80):
+        st = orc.get_state()
+        if t % 4 == 3:  # fold the leg: thigh / knee deep into their range, random height
+            st[:, 1] = rng.uniform(0.9, 1.4, n)
+            st[:, 2] = rng.uniform(-0.5, 0.5, n)
+            st[:, 3] = rng.uniform(-2.6, 0, n)
+            st[:, 4] = rng.uniform(-2.6, 0, n)
+            st[:, 5] = rng.uniform(-0.78, 0.78, n)
+            st[:, 6:12] = rng.uniform(-2, 2, (n, 6))
+            st[:, 12:18] = 0
+            st[:, 21] = 0
+            orc.set_state(st)
+        noself.set_state(st)
+        act = rng.uniform(-1.2, 1.2, size=(n, 3))
+        b, c = orc.step(act), noself.step(act)
+        for e in range(n):
+            if b["elapsed_step"][e, 0] == 0:
+                continue
+            q, v, w, a = np.zeros(9), np.zeros(9), np.zeros(9), np.zeros(6)
+            q[:6], v[:6], w[:6], a[:3] = st[e, :6], st[e, 6:12], st[e, 12:18], act[e]
+            qo, vo, wo, it = np.zeros(9), np.zeros(9), np.zeros(9), ctypes.c_int(0)
+            rc = L.planar_lg_step(3, 1, q.ctypes.data, v.ctypes.data, w.ctypes.data, a.ctypes.data, 4,
+                                  qo.ctypes.data, vo.ctypes.data, wo.ctypes.data, ctypes.byref(it))
+            assert rc == 0
+            q2, v2, w2, it2 = np.zeros(9), np.zeros(9), np.zeros(9), ctypes.c_int(0)
+            Lo.hopper_host_step(q.ctypes.data_as(vp), v.ctypes.data_as(vp), w.ctypes.data_as(vp), a.ctypes.data_as(vp),
+                                4, 0, q2.ctypes.data_as(vp), v2.ctypes.data_as(vp), w2.ctypes.data_as(vp),
+                                ctypes.byref(it2))
+            worst_lane = max(worst_lane, np.abs(qo - q2).max(), np.abs(vo - v2).max())
+            obs = np.concatenate([qo[1:6], np.clip(vo[:6], -10, 10)])
+            compared += 1
+            outliers += bool(np.abs(obs - b["obs"][e]).max() > 1e-9)
+            pair_hits += bool(np.abs(b["obs"][e] - c["obs"][e]).max() > 1e-9)
+    assert worst_lane < 1e-9, worst_lane           # the two product forms agree everywhere
+    assert pair_hits > 50, pair_hits               # the body-pair rows were exercised
+    assert outliers <= compared // 200, (outliers, compared)  # vs the oracle: crossed-axes states only
+
+
 def test_pusher_capsule_cylinder_rule_in_the_degenerate_poses():
     """Pusher's wrist capsule vs the object's cylinder goes through MuJoCo's convex collider; product
     (mj_pusher.hip.h::CapsuleCylinder) and oracle (oracle/mjcpu/engine.c::capcyl_contact) restate it as the
