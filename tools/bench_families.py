@@ -42,6 +42,11 @@ def main():
     ap.add_argument("--num-envs", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--big", type=int, default=1 << 22, help="also run at this N (HBM-resident)")
+    ap.add_argument("--families", default="", help="comma-separated subset (default: all)")
+    ap.add_argument("--no-atari", action="store_true")
+    ap.add_argument("--atari-sizes", default="1024,16384")
+    ap.add_argument("--plan-out", default="", help="write the ordered list of (kernel tag, family, N, launches) "
+                    "this run dispatched: tools/summarize_families.py splits a rocprofv3 trace by it")
     args = ap.parse_args()
     import torch
 
@@ -50,8 +55,13 @@ def main():
 
     dev = torch.device("cuda", 0)
     rows = []
-    for n in (args.num_envs, args.big):
+    plan = []
+    want = [f for f in args.families.split(",") if f]
+    sizes = [args.num_envs] + ([args.big] if args.big > 0 else [])
+    for n in sizes:
         for fam, params, max_steps, (kind, p), alg in FAMILIES:
+            if want and fam not in want:
+                continue
             pool = DevicePool(fam, n, seed=0, max_episode_steps=max_steps, params=params)
             if kind == "int":
                 ring = [torch.randint(0, p, (n,), device=dev, dtype=torch.int32) for _ in range(8)]
@@ -81,9 +91,12 @@ def main():
                    "achieved_GBps": gbs, "hbm_frac": gbs / 8000.0}
             rows.append(rec)
             print(json.dumps(rec))
+            # step-kernel launches of this configuration, in dispatch order: 1 reset + 10 warm-up + the timed ones
+            plan.append({"family": fam, "num_envs": n, "skip": 11, "timed": args.steps, "algorithmic_bytes": alg,
+                         "hip_event_us": ms * 1e3})
             pool.close()
     # Atari post-process (K4): frames resident on the device
-    for n in (1024, 16384):
+    for n in ([] if args.no_atari else [int(x) for x in args.atari_sizes.split(",") if x]):
         post = AtariPostProcess(n)
         frames = torch.randint(0, 256, (n, 2, 210, 160), device=dev, dtype=torch.uint8)
         obs = torch.empty((n, 4, 84, 84), device=dev, dtype=torch.uint8)
@@ -107,6 +120,11 @@ def main():
                "achieved_GBps": gbs, "hbm_frac": gbs / 8000.0}
         rows.append(rec)
         print(json.dumps(rec))
+        plan.append({"family": "AtariPostProcess", "num_envs": n, "skip": 5, "timed": 50, "algorithmic_bytes": alg,
+                     "hip_event_us": ms * 1e3})
+    if args.plan_out:
+        with open(args.plan_out, "w") as f:
+            json.dump(plan, f, indent=1)
     print("\n| family | N | kernel us | env-steps/s | alg B/step | GB/s | frac of 8 TB/s |")
     print("|---|---|---|---|---|---|---|")
     for r in rows:
