@@ -23,11 +23,21 @@ CASES = {
                                mode=1, difficulty=1, use_fire_reset=0), 5, 21, 27000, 120),
     "skip1_small": (dict(frame_skip=1, img_height=64, img_width=96, stack_num=3, rom=2), 4, 5, 50, 150),
 }
+# BASELINE.json config 5 ("Atari Pong-v5 num_envs=1024"): the default Pong-like configuration at the full
+# batch size.  Kept apart from CASES (which every small-case test iterates): its fixture holds scalars and
+# per-row CRCs only, no full observations.
+BIG_CASES = {
+    "config5_n1024": ({}, 1024, 13, 40, 48),
+}
+
+
+def case(name):
+    return CASES[name] if name in CASES else BIG_CASES[name]
 
 
 def config(name):
     c = dict(DEFAULT)
-    c.update(CASES[name][0])
+    c.update(case(name)[0])
     return c
 
 
@@ -37,7 +47,7 @@ def extra(c):
 
 
 def actions(name, num_actions):
-    _, n, seed, _, steps = CASES[name]
+    _, n, seed, _, steps = case(name)
     rng = np.random.default_rng(1000 + seed)
     return rng.integers(0, num_actions, size=(steps, n)).astype(np.int32)
 

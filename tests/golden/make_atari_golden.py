@@ -15,7 +15,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import atari_cases as ac  # noqa: E402
 from oracle.orc import Oracle  # noqa: E402
 
-for name, (_, n, seed, max_steps, steps) in ac.CASES.items():
+only = sys.argv[1:]  # e.g. `make_atari_golden.py config5_n1024`: regenerate just that fixture
+for name, (_, n, seed, max_steps, steps) in {**ac.CASES, **ac.BIG_CASES}.items():
+    if only and name not in only:
+        continue
     c = ac.config(name)
     orc = Oracle("Atari", n, seed=seed, max_episode_steps=max_steps, extra=ac.extra(c),
                  kind="reference_atari", num_threads=2)
@@ -29,7 +32,7 @@ for name, (_, n, seed, max_steps, steps) in ac.CASES.items():
             out[k].append(b[k].ravel().copy())
         obs_crc.append(ac.crc_rows(b["obs"]))
         ram_crc.append(ac.crc_rows(b["info:ram"]))
-        if t in (0, 1, 17, steps // 2, steps):
+        if name in ac.CASES and t in (0, 1, 17, steps // 2, steps):
             full[f"obs_{t}"] = b["obs"].copy()
         if t < steps:
             b = orc.step(acts[t])

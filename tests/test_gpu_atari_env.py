@@ -26,7 +26,7 @@ def make_pool(name, batch_size=0, num_threads=3, plugin="synth_plugin"):
     from envpool_amd.atari import AtariDevicePool
 
     c = ac.config(name)
-    _, n, seed, max_steps, _ = ac.CASES[name]
+    _, n, seed, max_steps, _ = ac.case(name)
     conf = {k: c[k] for k in ac.KEYS if k != "rom"}
     conf.update(num_envs=n, task=ac.ROMS[c["rom"]], base_path="/synthetic",
                 emulator_lib=PLUGINS[plugin](), num_threads=num_threads)
@@ -70,6 +70,43 @@ def test_atari_env_matches_reference_fixtures(name, plugin):
             pool.send(ids, acts[t])
             a = pool.recv_dict()
             b = ref.step(acts[t]) if ref else None
+    pool.close()
+
+
+def test_atari_env_at_baseline_config5_size():
+    """BASELINE.json config 5 (Atari Pong-v5, num_envs=1024) through the whole pool -- host emulator workers,
+    H2D of 2 x 1024 raw screens, AtariPostKernel over 1024 blocks, chunked D2H -- against the reference's
+    atari_env.h rollout of the same 1024 envs (fixture: scalars + per-row CRC32 of obs and RAM for every step,
+    incl. the step where all 1024 episodes are truncated and auto-reset; live reference library where present)."""
+    name = "config5_n1024"
+    g = np.load(os.path.join(GOLDEN, f"atari_{name}.npz"))
+    _, n, seed, max_steps, steps = ac.case(name)
+    assert n == 1024
+    pool = make_pool(name, num_threads=8)
+    ids = np.arange(n, dtype=np.int32)
+    ref = None
+    from oracle import orc
+    if orc.have_ref_atari():
+        ref = orc.Oracle("Atari", n, seed=seed, max_episode_steps=max_steps, extra=ac.extra(ac.config(name)),
+                         kind="reference_atari", num_threads=4)
+    pool.reset(ids)
+    a = pool.recv_dict()
+    b = ref.reset() if ref else None
+    acts = g["actions"]
+    ended = 0
+    for t in range(steps + 1):
+        for k in ac.SCALARS:
+            np.testing.assert_array_equal(a[k].ravel(), g[k.replace(":", "__")][t], err_msg=f"{k} @ {t}")
+        np.testing.assert_array_equal(ac.crc_rows(a["obs"]), g["obs_crc"][t], err_msg=f"obs crc @ {t}")
+        np.testing.assert_array_equal(ac.crc_rows(a["info:ram"]), g["ram_crc"][t], err_msg=f"ram @ {t}")
+        if ref:
+            np.testing.assert_array_equal(a["obs"].reshape(n, -1), b["obs"], err_msg=f"obs @ {t}")
+        ended += int(a["done"].sum())
+        if t < steps:
+            pool.send(ids, acts[t])
+            a = pool.recv_dict()
+            b = ref.step(acts[t]) if ref else None
+    assert ended >= n  # every env finished an episode and was auto-reset inside the window
     pool.close()
 
 

@@ -68,6 +68,26 @@ def test_post_process_bit_exact_with_resets_and_partial_ids():
     np.testing.assert_array_equal(a[:, :3], prev[:, 1:])
 
 
+def test_post_process_at_baseline_config5_size():
+    """BASELINE.json config 5: num_envs = 1024 (the size `tools/bench_families.py` times AtariPostKernel at):
+    full-batch pushes incl. the reset push, a partial shuffled push and a push with scattered resets, bit-exact."""
+    n = 1024
+    gpu, orc = AtariPostProcess(n), OraclePost(n)
+    rng = np.random.default_rng(5)
+    ids = np.arange(n, dtype=np.int32)
+    for t in range(6):
+        if t == 3:
+            sub = rng.permutation(n)[:333].astype(np.int32)
+            frames, mask = pong_like(rng, 333), (rng.random(333) < 0.3).astype(np.uint8)
+        else:
+            sub = ids
+            frames = pong_like(rng, n) if t % 2 == 0 else rng.integers(0, 256, (n, 2, 210, 160), dtype=np.uint8)
+            mask = np.ones(n, np.uint8) if t == 0 else ((rng.random(n) < 0.05).astype(np.uint8) if t == 5 else None)
+        a, b = gpu.push(frames, sub, mask), orc.push(frames, sub, mask)
+        assert a.shape == (len(sub), 4, 84, 84)
+        np.testing.assert_array_equal(a, b, err_msg=f"push {t}")
+
+
 @pytest.mark.parametrize("oh,ow", [(64, 64), (96, 75), (40, 30), (100, 150)])
 def test_post_process_other_sizes(oh, ow):
     """Non-default img_height / img_width: more taps per pixel than the 84x84

@@ -96,7 +96,7 @@ def test_atari_fixtures_come_from_the_reference_compiled_in_place():
 
     if not orc.have_ref_atari():
         pytest.skip("oracle/_ref/libref_atari.so not built (no /root/reference here)")
-    for name, (_, n, seed, max_steps, steps) in ac.CASES.items():
+    for name, (_, n, seed, max_steps, steps) in {**ac.CASES, **ac.BIG_CASES}.items():
         g = np.load(os.path.join(ROOT, "tests", "golden", f"atari_{name}.npz"))
         c = ac.config(name)
         o = orc.Oracle("Atari", n, seed=seed, max_episode_steps=max_steps, extra=ac.extra(c),
