@@ -118,9 +118,31 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` launched directly (no torchrun around it): start the N ranks here -- one
+        # process per GPU, the same launch the driver uses (python -m torch.distributed.run --nnodes=1
+        # --nproc-per-node N --master-addr 127.0.0.1), like the reference's benchmark/numa_test.sh:15-21 starts one
+        # process per NUMA node -- and let rank 0 print the one JSON line.
+        if args.backend == "nccl" and args.gpus > torch.cuda.device_count():
+            raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible (one rank per "
+                             f"GPU over RCCL); --backend gloo lets ranks share a GPU to exercise the plumbing")
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(torchrun --nproc-per-node {args.gpus}) or run `python bench.py --gpus {args.gpus}` directly")
     ngpu = torch.cuda.device_count()
     if args.backend == "nccl" and world > 1 and local_rank >= ngpu:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ngpu} GPU(s) visible")
@@ -211,9 +233,13 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     pool.set_timing(False)
+    per_rank_s = [elapsed]
     if world > 1:
         dist.barrier()
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)  # each rank's own wall time of the timed region (reported per rank)
+        per_rank_s = [float(x.item()) for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -419,6 +445,9 @@ def main():
             "gpu_active_s": gpu_legs_s,
             "gpu_kernel_s_timed_region": kernel_ms * launches * 1e-3,
         }
+        # every rank's own rate over its own wall time; `value` = all env-steps / the SLOWEST rank's time
+        out["per_rank"] = [{"rank": r, "device": r % max(ngpu, 1), "timed_s": ts,
+                            "env_steps_per_s": n * timed_steps / ts} for r, ts in enumerate(per_rank_s)]
         if world == 1:
             out["reset_step_ms"] = reset_ms
             out["numpy_api"] = numpy_api

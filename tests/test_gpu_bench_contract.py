@@ -50,6 +50,32 @@ def test_bench_line_schema():
     assert abs(am["value"] - am["batch_size"] * am["steps"] / (am["ms_per_step"] * 1e-3 * am["steps"])) / am["value"] < 1e-6
 
 
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no torchrun around it starts 2 ranks (one process per GPU, the driver's own
+    launch line) and rank 0 prints ONE line with n_gpus = 2 and the per-rank rates; on this 1-GPU box the two ranks
+    share device 0 over gloo (plumbing only).  With the RCCL backend more ranks than visible GPUs is refused."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5",
+         "--warmup", "2", "--num-envs", "4096", "--no-cpu-baseline", "--min-time", "0.5"],
+        capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["num_envs_per_gpu"] == 4096
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1]
+    assert abs(d["value"] - 2 * 4096 * d["timed_steps"] / d["timed_s"]) / d["value"] < 1e-6
+    assert d["timed_s"] >= max(r["timed_s"] for r in d["per_rank"]) - 1e-9  # MAX over ranks
+    assert "cpu_baseline" not in d and "async_mode" not in d  # rank 0 at N = 1 only
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"],
+                             capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+        assert bad.returncode != 0 and "GPU(s) visible" in bad.stderr
+
+
 def test_kernel_timing_modes_agree():
     """epa_set_timing: 1 = an event pair per launch, 2 = one pair around the window (what bench.py
     uses); both count every launch and give the same duration up to the inter-launch gaps."""
