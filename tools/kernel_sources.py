@@ -1,8 +1,22 @@
 """Which source files a step kernel is compiled from, and a hash over them + the Makefile.
 `tools/make_pmc_json.py` stamps every `profiles/pmc.json` entry with the hash of the build it profiled;
-`bench.py` recomputes it and refuses to price a changed kernel with old PMC counts ("stale": true)."""
+`bench.py` recomputes it and refuses to price a changed kernel with old PMC counts ("stale": true).
+The hash is over the CODE: comments and whitespace are stripped first, so that a comment-only edit does not
+turn the headline `roofline` into the HBM fallback (round 4: commit ebe05a1 did exactly that)."""
 import hashlib
 import os
+import re
+
+_TOKEN = re.compile(r"//[^\n]*|/\*.*?\*/|\"(?:\\.|[^\"\\])*\"|'(?:\\.|[^'\\])*'", re.S)
+
+
+def strip_comments(text: str) -> str:
+    """C / C++ / Makefile-rule text without comments, every whitespace run collapsed to one blank (string and
+    character literals are kept as they are)."""
+    def keep(m):
+        t = m.group(0)
+        return " " if t.startswith("/") else t
+    return " ".join(_TOKEN.sub(keep, text).split())
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "envpool_amd", "csrc")
@@ -42,13 +56,14 @@ def _makefile_lines(main_source: str) -> bytes:
             keep.append(line)
         else:
             take_cmd = False
-    return "".join(keep).encode()
+    # `#` starts a Makefile comment (none of the kept lines holds a literal '#')
+    return " ".join(" ".join(line.split("#", 1)[0] for line in keep).split()).encode()
 
 
 def source_hash(kernel: str) -> str:
     h = hashlib.sha256()
     h.update(_makefile_lines(SOURCES[base_name(kernel)][0]))
     for name in COMMON + SOURCES[base_name(kernel)]:
-        with open(os.path.join(CSRC, name), "rb") as f:
-            h.update(name.encode() + b"\0" + f.read() + b"\0")
+        with open(os.path.join(CSRC, name), encoding="utf-8") as f:
+            h.update(name.encode() + b"\0" + strip_comments(f.read()).encode() + b"\0")
     return h.hexdigest()[:16]
