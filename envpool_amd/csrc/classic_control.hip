@@ -396,6 +396,9 @@ class ClassicPool : public Pool {
       EPA_HIP(hipMemsetAsync(dev_.s[j], 0, sizeof(double) * cfg.num_envs,
                              stream_));
     }
+    // CartPole / Acrobot episodes end at their own times under any policy: tiled generator words
+    // (engine.h: mt_tile_default_); Pendulum and the MountainCars run to the step limit together
+    if (KIND == kCartPole || KIND == kAcrobot) mt_tile_default_ = 16;
     InitCommon();
   }
   ~ClassicPool() override {

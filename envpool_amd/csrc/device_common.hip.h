@@ -1,8 +1,9 @@
 // Device-side helpers shared by every family kernel.
 //
 //  * Mt19937: the per-env `std::mt19937 gen_` of the reference
-//    (envpool/core/env.h:78,109-117) kept in HBM as SoA `uint32 mt[624][N]`
-//    plus `int mti[N]`, and the libstdc++-11 distributions the env bodies use
+//    (envpool/core/env.h:78,109-117) kept in HBM as 624 words per env (`uint32 mt[624][N]`, or in
+//    tiles of 2^k words per env, CommonDev::mt_shift) plus the position `int mti[N]`, regenerated one
+//    word per draw, and the libstdc++-11 distributions the env bodies use
 //    (generate_canonical / uniform_real / uniform_int(Lemire) / normal(polar)),
 //    bit-exact with /usr/include/c++/11/bits/{random.tcc,uniform_int_dist.h}.
 //    The floating-point distributions carry `#pragma clang fp contract(off)`
@@ -43,46 +44,80 @@ struct StepArgs {
 };
 
 struct Mt19937 {
-  uint32_t* mt;  // base of this env's column: mt[j * n]
+  uint32_t* mt;  // base of the pool's generator words (layout: MtAt)
+  int e;         // this env's column
   int n;
+  int sh;        // log2 of the tile width (CommonDev::mt_shift)
   int idx;
   int idx0;
   int* idx_slot;
 
-  __device__ Mt19937(const CommonDev& c, int e)
-      : mt(c.mt + e), n(c.n), idx_slot(c.mti + e) {
+  __device__ Mt19937(const CommonDev& c, int env)
+      : mt(c.mt), e(env), n(c.n), sh(c.mt_shift), idx_slot(c.mti + env) {
     idx = idx0 = *idx_slot;
   }
   __device__ void Commit() {
     if (idx != idx0) *idx_slot = idx;
   }
-  __device__ uint32_t& At(int j) { return mt[(size_t)j * n]; }
-
-  __device__ void Twist() {
-    const uint32_t upper = 0x80000000u, lower = 0x7fffffffu;
-    uint32_t cur = At(0);
-    const uint32_t first = cur;
-    for (int k = 0; k < 624 - 397; ++k) {
-      uint32_t nxt = At(k + 1);
-      uint32_t y = (cur & upper) | (nxt & lower);
-      At(k) = At(k + 397) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-      cur = nxt;
+  // Word j of this env.  Two layouts (CommonDev::mt_shift): 0 = the structure of arrays mt[j][N] -- every env
+  // draws the same word in the same launch, a draw is one coalesced 4-byte column; 4 = tiles of 16 consecutive
+  // words of ONE env are contiguous (tile t of all envs is one [N][16] slab) -- envs that reset at their own
+  // times: the 8 .. 60 draws of a reset stay inside 1 .. 4 64-byte sectors instead of one sector per word.
+  __device__ uint32_t& At(int j) {
+    return mt[((((size_t)(j >> sh)) * n + e) << sh) | (size_t)(j & ((1 << sh) - 1))];
+  }
+  __device__ static uint32_t Twist1(uint32_t cur, uint32_t nxt, uint32_t partner) {
+    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+    return partner ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  }
+  // The 16 words [16 t, 16 t + 16) of the next block, in place (tiled layout): one 64-byte tile in and out as
+  // uint4, the neighbour word of the next tile, 16 partner words out of two other tiles.
+  __device__ void RegenTile16() {
+    const int t = idx >> 4;
+    uint4* own = reinterpret_cast<uint4*>(&At(idx));
+    uint32_t w[17];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 x = own[q];
+      w[4 * q] = x.x;
+      w[4 * q + 1] = x.y;
+      w[4 * q + 2] = x.z;
+      w[4 * q + 3] = x.w;
     }
-    for (int k = 624 - 397; k < 623; ++k) {
-      uint32_t nxt = At(k + 1);
-      uint32_t y = (cur & upper) | (nxt & lower);
-      At(k) = At(k - 227) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-      cur = nxt;
+    // the word after the tile: still the old block's, except behind the last tile, where it is word 0 of the
+    // block being generated (libstdc++ reads _M_x[0] there too)
+    w[16] = At(t == 38 ? 0 : idx + 16);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = idx + r;
+      // partner k + 397 (old block) for k < 227, k - 227 (already regenerated: an earlier tile, or -- in the
+      // tile that holds word 227 -- never one of this tile's own words) otherwise
+      w[r] = Twist1(w[r], w[r + 1], At(k >= 227 ? k - 227 : k + 397));
     }
-    (void)first;
-    uint32_t y = (cur & upper) | (At(0) & lower);
-    At(623) = At(396) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-    idx = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) own[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
   }
 
+  // std::mt19937::operator(): the generator is regenerated LAZILY, when a word is about to be consumed -- one word
+  // at a time in the [624][N] layout, one 16-word tile at a time in the tiled one.  Word i of the next block is
+  // s[i+397] ^ twist(s[i], s[i+1]) with the indices mod 624; at the moment word i (or its tile) is reached the
+  // words after it are still the old block's and the words before it the new block's, which is exactly what
+  // libstdc++'s block-wise _M_gen_rand reads for that word (bits/random.tcc:396-440): the same sequence, without
+  // the 624-iteration loop that a single lane of a wave used to run while the other 63 waited (one wave per SIMD
+  // in the MuJoCo kernels: the whole SIMD).  `idx` is the position of the next word, 0 .. 623, for ever.
   __device__ uint32_t Next() {
-    if (idx >= 624) Twist();
-    uint32_t y = At(idx++);
+    const int i = idx;
+    uint32_t y;
+    if (sh == 0) {
+      const int i1 = i == 623 ? 0 : i + 1;
+      uint32_t& cur = At(i);
+      y = Twist1(cur, At(i1), At(i >= 227 ? i - 227 : i + 397));
+      cur = y;
+    } else {
+      if ((i & 15) == 0) RegenTile16();
+      y = At(i);
+    }
+    idx = i == 623 ? 0 : i + 1;
     y ^= (y >> 11);
     y ^= (y << 7) & 0x9d2c5680u;
     y ^= (y << 15) & 0xefc60000u;

@@ -109,13 +109,16 @@ struct Batch {
 // Per-env bookkeeping shared by all families, SoA on device:
 //   cur_step  Env::current_step_ (env.h:86)      init -1
 //   done      XxxEnv::done_                       init 1 (first step resets)
-//   mt/mti    std::mt19937 gen_ (env.h:78)        [624][N] words + index
+//   mt/mti    std::mt19937 gen_ (env.h:78)        624 words per env + the position of the next word.
+//             Layout: mt_shift = 0 the plain [624][N] structure of arrays, mt_shift = 4 tiles of 16 consecutive
+//             words of one env, tile t of all envs = one [N][16] slab (device_common.hip.h: Mt19937::At)
 struct CommonDev {
   int* cur_step;
   unsigned char* done;
   uint32_t* mt;
   int* mti;
   int n;
+  int mt_shift;
 };
 
 class Pool {
@@ -180,6 +183,10 @@ class Pool {
   std::vector<KeySpec> keys_;
   KeySpec action_;
   bool needs_rng_;
+  // words of one env's generator kept contiguous (1 or 16; engine key "mt_tile" overrides): 1 for
+  // families whose envs all draw at the same launches (the word a wave reads is one coalesced column), 16 for
+  // families whose envs reset at their own times (a reset's draws then stay inside a few 64-byte sectors)
+  int mt_tile_default_{1};
   // The stream the NEXT step kernel goes on.  Sync mode (batch_size == num_envs): always
   // compute_[0].  Async mode: successive batches rotate over the compute streams so that
   // independent in-flight batches run concurrently, like the reference's workers run every queued

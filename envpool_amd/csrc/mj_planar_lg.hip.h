@@ -53,6 +53,16 @@
 #define EPA_LG_TICK(cx, K) ((void)0)
 #define EPA_LG_COUNT(cx, K) ((void)0)
 #endif
+// host experiments only (tools/lg_solver_stats.py): per Newton trip of one env, the line-search evaluations it ran
+#ifndef EPA_LG_HOST_TRIP
+#define EPA_LG_HOST_TRIP(evals) ((void)0)
+#endif
+#ifndef EPA_LG_HOST_ENDS
+#define EPA_LG_HOST_ENDS(ends) ((void)0)
+#endif
+#ifndef EPA_LG_LS_RTOL
+#define EPA_LG_LS_RTOL 1e-10
+#endif
 
 namespace epa {
 namespace mj {
@@ -1217,7 +1227,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
     const V g1 = DotEnv<KL>(s, r0), g2 = DotEnv<KL>(s, Ms);
     V alpha = V(1), lo = V(0), hi = V(-1);
     full_step = LT::False();
-    const V ls_tol = V(T(1e-10)) * Abs(g1);
+    const V ls_tol = V(T(EPA_LG_LS_RTOL)) * Abs(g1);
     B searching = live;
     B exact = LT::False();
     EPA_LG_TICK(cx, 3);
@@ -1248,7 +1258,10 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
       next = Sel(next <= V(0), V(0.5) * alpha, next);
       searching = searching & (next != alpha);
       alpha = Sel(searching, next, alpha);
-      if (!AnyWave(searching)) break;
+      if (!AnyWave(searching)) {
+        EPA_LG_HOST_TRIP(ls + 1);
+        break;
+      }
     }
     EPA_LG_TICK(cx, 4);
     const V step = Sel(live, alpha, V(0));
@@ -1299,6 +1312,7 @@ EPA_HD V Forward(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, co
   SmoothForces<KL>(m, cx, p, q, v, ctrl, qfrc_smooth);
   LimitRows<V> lim;
   const unsigned ends = MakeConstraint<KL>(m, cx, p, q, v, lim);
+  EPA_LG_HOST_ENDS(ends);
   static_for<0, kLV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
   EPA_LG_TICK(cx, 1);
   const V iters = Solve<KL>(m, cx, p, lim, ends, qfrc_smooth, cfg, qacc, Ma, grad);

@@ -399,6 +399,7 @@ class AntPool : public Pool {
     EPA_HIP(hipMemsetAsync(dev_.navail, 0, n, stream_));
     trace_.Init("EPA_ANT_TRACE", (n + kAntEnvsPerBlock - 1) / kAntEnvsPerBlock, stream_);
     dev_.trace = trace_.d;
+    mt_tile_default_ = 16;  // unhealthy terminations: every env resets at its own time
     InitCommon();
     EnableObsStack();  // frame_stack > 1: generic ring (envpool/mujoco/frame_stack.h:74-146)
   }

@@ -429,6 +429,9 @@ class CheetahPool : public Pool {
     EPA_HIP(hipMemsetAsync(dev_.warm, 0, sizeof(double) * kNV * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.nsaved, 0, sizeof(double) * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.navail, 0, n, stream_));
+    // Walker2d / Hopper terminate when unhealthy, each env at its own time: tiled generator words; the
+    // HalfCheetah never terminates early (all envs draw in the same launch)
+    if (walker) mt_tile_default_ = 16;
     InitCommon();
   }
   ~CheetahPool() override {

@@ -330,6 +330,7 @@ class HumanoidPool : public Pool {
     const size_t sb = sizeof(double) * (size_t)T::MakeLayout(kHumanoidModelConst).npersist * cfg.num_envs;
     EPA_HIP(hipMalloc(&dev_.state, sb));
     EPA_HIP(hipMemsetAsync(dev_.state, 0, sb, stream_));
+    mt_tile_default_ = 16;  // unhealthy terminations: every env resets at its own time
     InitCommon();
   }
   ~HumanoidPool() override {

@@ -545,6 +545,7 @@ class PendPool : public Pool {
     EPA_HIP(hipMemsetAsync(dev_.warm, 0, sizeof(double) * NV * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.nsaved, 0, sizeof(double) * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.navail, 0, n, stream_));
+    mt_tile_default_ = 16;  // the inverted pendulums fall over at their own times
     InitCommon();
   }
   ~PendPool() override {

@@ -59,6 +59,12 @@ struct DevCx {
 // [0..4] cycles per category, [5..7] trip counters, [8] chunks, [9] cycles of whole chunks
 __device__ unsigned long long g_lg_timers[16];
 #endif
+#ifdef EPA_LG_SCHED_TRACE
+// diagnostic build only (tools/lg_sched_trace.py): who ran which chunk when.  [0] = records filed, then
+// {wave (= block), chunk, start, end} per chunk in 100 MHz wall-clock ticks (s_memrealtime)
+constexpr int kSchedCap = 1 << 15;
+__device__ unsigned long long g_lg_sched[1 + 4 * kSchedCap];
+#endif
 
 // Everything the kernel is given, as ONE by-value argument: it sits at offset 0 of the kernarg
 // segment and is read from there (scalar loads) where it is needed, see KernArgs().
@@ -345,7 +351,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(W, W))) 
     }
     chunk = __builtin_amdgcn_readfirstlane(chunk);
     const long long t0 = clock64();
+#ifdef EPA_LG_SCHED_TRACE
+    const unsigned long long w0 = wall_clock64();
+#endif
     StepChunk<KL, kModel>(chunk, tab_lds, lds_buf);
+#ifdef EPA_LG_SCHED_TRACE
+    if (threadIdx.x == 0) {
+      const unsigned long long w1 = wall_clock64();
+      const unsigned long long i = atomicAdd(&g_lg_sched[0], 1ull);
+      if (i < (unsigned long long)kSchedCap) {
+        g_lg_sched[1 + 4 * i] = blockIdx.x;
+        g_lg_sched[2 + 4 * i] = (unsigned long long)chunk;
+        g_lg_sched[3 + 4 * i] = w0;
+        g_lg_sched[4 + 4 * i] = w1;
+      }
+    }
+#endif
     ap = KernArgs();
     unsigned t = 0;
     if (threadIdx.x == 0) {
@@ -445,6 +466,28 @@ extern "C" int epa_debug_lg_timers(unsigned long long* out16, int clear) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(epa::g_lg_timers), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;
+}
+namespace epa {
+#endif
+
+#ifdef EPA_LG_SCHED_TRACE
+}  // namespace epa
+// diagnostic build only: copy out (and clear) the chunk schedule records; returns the number filed
+extern "C" long long epa_debug_lg_sched(unsigned long long* out, int max_records, int clear) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  unsigned long long n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(epa::g_lg_sched), sizeof(n)) != hipSuccess) return -1;
+  unsigned long long k = n < (unsigned long long)epa::kSchedCap ? n : (unsigned long long)epa::kSchedCap;
+  if (k > (unsigned long long)max_records) k = max_records;
+  if (out != nullptr && k > 0 &&
+      hipMemcpyFromSymbol(out, HIP_SYMBOL(epa::g_lg_sched), sizeof(unsigned long long) * 4 * k, sizeof(unsigned long long)) != hipSuccess) {
+    return -1;
+  }
+  if (clear) {
+    const unsigned long long z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(epa::g_lg_sched), &z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return (long long)n;
 }
 namespace epa {
 #endif

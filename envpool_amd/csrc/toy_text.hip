@@ -423,6 +423,8 @@ class ToyPool : public Pool {
       EPA_HIP(hipMalloc(&dev_.w1, sizeof(int) * cfg.num_envs));
       EPA_HIP(hipMemsetAsync(dev_.w1, 0, sizeof(int) * cfg.num_envs, stream_));
     }
+    // envs that draw at their own times (a reset row draws, or skips the step's draw): tiled generator words
+    if (KIND == kFrozenLake || KIND == kTaxi || KIND == kBlackjack) mt_tile_default_ = 16;
     InitCommon();
   }
   ~ToyPool() override {

@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--num-envs", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--big", type=int, default=1 << 22, help="also run at this N (HBM-resident)")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed steps after the reset (e.g. 700: past the first "
+                    "exhaustion of every env's 624 generator words, where the block-wise mt19937 of rounds 1-4 paid its "
+                    "twists)")
     ap.add_argument("--families", default="", help="comma-separated subset (default: all)")
     ap.add_argument("--no-atari", action="store_true")
     ap.add_argument("--atari-sizes", default="1024,16384")
@@ -76,7 +79,7 @@ def main():
             torch.cuda.synchronize()
             pool.send_device(None)
             pool.recv_device()
-            for i in range(10):
+            for i in range(args.warmup):
                 pool.send_device(ring[i % 8].data_ptr())
                 pool.recv_device()
             pool.synchronize()
@@ -92,7 +95,7 @@ def main():
             rows.append(rec)
             print(json.dumps(rec))
             # step-kernel launches of this configuration, in dispatch order: 1 reset + 10 warm-up + the timed ones
-            plan.append({"family": fam, "num_envs": n, "skip": 11, "timed": args.steps, "algorithmic_bytes": alg,
+            plan.append({"family": fam, "num_envs": n, "skip": 1 + args.warmup, "timed": args.steps, "algorithmic_bytes": alg,
                          "hip_event_us": ms * 1e3})
             pool.close()
     # Atari post-process (K4): frames resident on the device
