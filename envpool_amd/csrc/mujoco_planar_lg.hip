@@ -64,6 +64,9 @@ __device__ unsigned long long g_lg_timers[16];
 // {wave (= block), chunk, start, end} per chunk in 100 MHz wall-clock ticks (s_memrealtime)
 constexpr int kSchedCap = 1 << 15;
 __device__ unsigned long long g_lg_sched[1 + 4 * kSchedCap];
+// [0] ticks between the top of a chunk and the start of its stepping branch (= the RESET branch of the lanes whose
+// env resets, which the wave executes first), [1] chunks counted, [2] chunks in which some env reset
+__device__ unsigned long long g_lg_reset[4];
 #endif
 
 // Everything the kernel is given, as ONE by-value argument: it sits at offset 0 of the kernarg
@@ -139,6 +142,10 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
   double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
   float reward = 0.0f;
   double xv = 0.0, ctrl_cost = 0.0, xpos = 0.0, qz = 0.0, qang = 0.0;
+#ifdef EPA_LG_SCHED_TRACE
+  const unsigned long long tr0 = wall_clock64();
+  const bool any_reset = __builtin_amdgcn_ballot_w64(reset) != 0;
+#endif
   if (reset) {
     // MujocoReset: mj_resetData + MujocoResetModel (half_cheetah.h:105-117, walker2d.h:119-126);
     // the env's RNG stream is sequential: the group's first lane draws everything and writes the
@@ -182,6 +189,14 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
       }
     }
   } else {
+#ifdef EPA_LG_SCHED_TRACE
+    const unsigned long long ts0 = wall_clock64();
+    if (lane == __builtin_amdgcn_readfirstlane(lane)) {
+      atomicAdd(&g_lg_reset[0], ts0 - tr0);
+      atomicAdd(&g_lg_reset[1], 1ull);
+      if (any_reset) atomicAdd(&g_lg_reset[2], 1ull);
+    }
+#endif
     ++cur;
     double q[plg::kLV], v[plg::kLV], w[plg::kLV], ctrl[3];
     double x_before = 0.0;
@@ -227,6 +242,9 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
       atomicAdd(&g_lg_timers[8], 1ull);
       atomicAdd(&g_lg_timers[9], (unsigned long long)(clock64() - t_chunk0));
     }
+#endif
+#ifdef EPA_LG_SCHED_TRACE
+    if (lane == __builtin_amdgcn_readfirstlane(lane)) atomicAdd(&g_lg_reset[3], wall_clock64() - ts0);  // the mj_steps
 #endif
     const double x_after = x_before + q[0];
     xv = (x_after - x_before) / task.dt;  // half_cheetah.h:148-149
@@ -483,9 +501,17 @@ extern "C" long long epa_debug_lg_sched(unsigned long long* out, int max_records
       hipMemcpyFromSymbol(out, HIP_SYMBOL(epa::g_lg_sched), sizeof(unsigned long long) * 4 * k, sizeof(unsigned long long)) != hipSuccess) {
     return -1;
   }
+  if (out != nullptr && max_records >= 4) {  // the reset-branch counters ride in front: out[-4 .. -1] is not possible,
+    // so they are appended after the records the caller asked for
+    unsigned long long r[4];
+    if (hipMemcpyFromSymbol(r, HIP_SYMBOL(epa::g_lg_reset), sizeof(r)) != hipSuccess) return -1;
+    for (int i = 0; i < 4; ++i) out[4 * (size_t)max_records + i] = r[i];
+  }
   if (clear) {
     const unsigned long long z = 0;
     if (hipMemcpyToSymbol(HIP_SYMBOL(epa::g_lg_sched), &z, sizeof(z)) != hipSuccess) return -1;
+    const unsigned long long z4[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(epa::g_lg_reset), z4, sizeof(z4)) != hipSuccess) return -1;
   }
   return (long long)n;
 }

@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10, help="untimed steps after the reset (e.g. 700: past the first "
                     "exhaustion of every env's 624 generator words, where the block-wise mt19937 of rounds 1-4 paid its "
                     "twists)")
+    ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE",
+                    help="extra engine key for every pool (A/B switches such as mt_tile=1)")
     ap.add_argument("--families", default="", help="comma-separated subset (default: all)")
     ap.add_argument("--no-atari", action="store_true")
     ap.add_argument("--atari-sizes", default="1024,16384")
@@ -65,7 +67,8 @@ def main():
         for fam, params, max_steps, (kind, p), alg in FAMILIES:
             if want and fam not in want:
                 continue
-            pool = DevicePool(fam, n, seed=0, max_episode_steps=max_steps, params=params)
+            extra = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in args.param}
+            pool = DevicePool(fam, n, seed=0, max_episode_steps=max_steps, params={**params, **extra})
             if kind == "int":
                 ring = [torch.randint(0, p, (n,), device=dev, dtype=torch.int32) for _ in range(8)]
             elif kind == "float64x2":

@@ -49,7 +49,7 @@ def main():
         pool.recv_device()
     pool.synchronize()
     cap = 1 << 15
-    buf = np.zeros(4 * cap, np.uint64)
+    buf = np.zeros(4 * cap + 4, np.uint64)  # + the reset-branch counters behind the records
     assert f(None, 0, 1) >= 0
     rows = []
     for i in range(launches):
@@ -58,6 +58,7 @@ def main():
         pool.synchronize()
         k = f(buf.ctypes.data, cap, 1)
         assert 0 < k <= cap, k
+        rst = buf[4 * cap:4 * cap + 4].astype(np.float64)
         r = buf[:4 * k].reshape(k, 4).astype(np.int64)
         t0 = r[:, 2].min()
         start, end = (r[:, 2] - t0) * 0.01, (r[:, 3] - t0) * 0.01  # us
@@ -72,7 +73,9 @@ def main():
                          ideal=dur.sum() / waves, lpt=lpt_makespan(dur, waves),
                          first_idle=per_wave_end.min(), end_p50=np.median(per_wave_end),
                          n1=int((per_wave_n == 1).sum()), n2=int((per_wave_n == 2).sum()), n3=int((per_wave_n >= 3).sum()),
-                         start_last=start.max()))
+                         start_last=start.max(),
+                         reset_branch_us=rst[0] * 0.01 / max(rst[1], 1), chunks_with_reset=rst[2] / max(rst[1], 1),
+                         mj_steps_us=rst[3] * 0.01 / max(rst[1], 1)))
     print(f"{task} N={n} params={params}: {launches} launches (after 300 warm-up steps), per launch:")
     keys = list(rows[0])
     for k in keys:
@@ -80,7 +83,9 @@ def main():
         print(f"  {k:12s} mean {v.mean():10.2f}   min {v.min():10.2f}   max {v.max():10.2f}")
     print("  (us; span = first chunk start .. last chunk end; busy = sum of chunk durations / (waves x span); ideal = sum / "
           "waves; lpt = clairvoyant longest-first list schedule of the same chunks; first_idle / end_p50 = when the first / "
-          "the median wave ran out of work; n1 n2 n3 = waves that ran 1 / 2 / >= 3 chunks; start_last = start of the last chunk)")
+          "the median wave ran out of work; n1 n2 n3 = waves that ran 1 / 2 / >= 3 chunks; start_last = start of the last chunk; reset_branch_us = mean time per chunk between its top and the start of its stepping branch, i.e. the reset "
+          "branch the wave runs first for the lanes whose env resets; chunks_with_reset = fraction of chunks in which some env reset; mj_steps_us = mean time per chunk inside the "
+          "frame_skip x mj_step loop incl. the state loads: chunk mean - mj_steps_us = reset branch + stores + bookkeeping)")
 
 
 if __name__ == "__main__":
