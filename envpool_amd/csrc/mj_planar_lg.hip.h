@@ -303,6 +303,13 @@ inline LB<K> MaskSame(const LU<K>& a, const LU<K>& b) {
   for (int i = 0; i < K; ++i) r.v[i] = a.v[i] == b.v[i];
   return r;
 }
+// slots (bits of `ends`) that touch on some lane whose env is still live: what a Newton trip has to visit
+template <int K>
+inline unsigned LiveSlots(const LU<K>& own, LB<K> live, unsigned ends) {
+  unsigned r = 0;
+  for (int i = 0; i < K; ++i) r |= live.v[i] ? own.v[i] : 0u;
+  return r & ends;
+}
 template <typename V>
 struct LaneTypes;
 template <typename T, int K>
@@ -325,6 +332,18 @@ EPA_HD float Rsq(float x) { return Rsqrt(x); }
 EPA_HD bool AnyWave(bool c) { return WaveAny(c); }
 EPA_HD void MaskSet(unsigned& m, bool on, int bit) { m |= (on ? 1u : 0u) << bit; }
 EPA_HD bool MaskSame(unsigned a, unsigned b) { return a == b; }
+EPA_HD unsigned LiveSlots(unsigned own, bool live, unsigned ends) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned r = 0;
+  for (unsigned rem = ends; rem != 0; rem &= rem - 1) {  // a handful of bits: one ballot each
+    const int b = __builtin_ctz(rem);
+    if (__builtin_amdgcn_ballot_w64(live && ((own >> b) & 1u)) != 0) r |= 1u << b;
+  }
+  return r;
+#else
+  return live ? (own & ends) : 0u;
+#endif
+}
 // bit set where w != 0, for a weight that is either +0.0 or a positive normal number: its high word is
 // then zero / non-zero, and min(1, high word) is the bit -- two integer VALU ops, no compare, no
 // lane-mask logic on the scalar unit (the row weights are already selected by `jar < 0` and carry
@@ -629,10 +648,12 @@ struct LimitRows {
 
 // mj_makeConstraint: limit rows into `lim`, contact constants into the lane's LDS slots.  Returns
 // the wave-uniform set of end-sphere SLOTS (bit s) that touch the plane on any lane of the wave.
+// `own`: the same bits, per LANE -- the slots that touch on this lane (its D != 0).
 template <int KL, typename T, typename V, typename Cx>
 EPA_HD unsigned MakeConstraint(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const V* q,
-                               const V* v, LimitRows<V>& lim) {
+                               const V* v, LimitRows<V>& lim, typename LaneTypes<V>::U& own) {
   const T kMinVal = T(1e-15);
+  own = LaneTypes<V>::Fill(0u);
   static_for<0, 3>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const V qq = q[j + 3];
@@ -661,6 +682,7 @@ EPA_HD unsigned MakeConstraint(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p
     const auto touch = dist < V(m.con_margin);
     if (AnyWave(touch)) {
       ends |= 1u << s;
+      MaskSet(own, touch, s);
       V vn = V(0), vx = V(0);
       ForChainCols<b>(p, cpx, cpz, [&](auto jc, V jn, V jx) {
         constexpr int j = decltype(jc)::value;
@@ -751,6 +773,7 @@ EPA_HD unsigned MakeConstraint(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p
       V nx = V(1), nz = V(0), ccx = V(0), ccz = V(0), aref = V(0), D = V(0);
       if (AnyWave(touch)) {
         ends |= 1u << (kPairEndBit + k);
+        MaskSet(own, touch, kPairEndBit + k);
         const auto tiny = cd < V(kMinVal);
         const V inv = V(1) / Sel(tiny, V(1), cd);
         nx = Sel(tiny, V(1), ddx * inv);
@@ -1147,9 +1170,12 @@ struct SolverCfgLg {
 // piecewise-quadratic line search, finite termination (same active set after a full Newton step),
 // wave-uniform control flow.  Outputs qacc, Ma = M qacc and the final gradient
 // (qfrc_constraint = Ma - qfrc_smooth - grad); returns the env's Newton iterations.
-template <int KL, typename T, typename V, typename Cx>
+// kLiveSlots: a trip visits only the slots of the envs that are still live (measured on the GPU: HalfCheetah +2.9 %;
+// Walker2d / Hopper -1.4 %: their kernels have no registers to spare for the per-lane slot set) -- see below.
+template <int KL, bool kLiveSlots, typename T, typename V, typename Cx>
 EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRows<V>& lim,
-               unsigned ends, const V* qfrc_smooth, const SolverCfgLg<T>& cfg, V* qacc, V* Ma, V* grad) {
+               unsigned ends, const typename LaneTypes<V>::U& own, const V* qfrc_smooth,
+               const SolverCfgLg<T>& cfg, V* qacc, V* Ma, V* grad) {
   using LT = LaneTypes<V>;
   using B = typename LT::B;
   using U = typename LT::U;
@@ -1168,20 +1194,28 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
   const V gfloor2 = gfloor * gfloor;
   V prev_gn2 = V(-1);
   MulArrow<KL>(p.M, qacc, Ma);  // kept current incrementally: Ma += alpha * M s
+  if constexpr (kLiveSlots) {  // (the first trip writes every env's gradient: this is for the Sel in it only)
+    static_for<0, kLV>([&](auto ic) { grad[decltype(ic)::value] = V(0); });
+  }
   U prev_mask = LT::Fill(~0u);
   B full_step = LT::False();
   B live = LT::True();
   B at_min = LT::False();  // the env stopped at an exact minimiser (finite termination in the line search)
   V iter = V(0);
   for (int it = 0; it < cfg.max_iter; ++it) {
-    // Every lane (also those of finished envs, whose qacc and Ma are frozen) rebuilds H and grad
-    // at its current qacc, so both are current on exit.
+    // A trip visits the slots that touch on some env that is still LIVE (a wave-uniform subset of `ends`: after
+    // the first trip of a forward pass a third of the envs are left, after the second one in twenty --
+    // tools/lg_solver_stats.py): the envs that have finished keep the gradient of the trip they finished in
+    // (their qacc and Ma are frozen, so it is the gradient at their result); H, the masks and the line-search
+    // sums are only ever used for live envs.
+    const unsigned ends_t = (!kLiveSlots || it == 0) ? ends : LiveSlots(own, live, ends);
+    const B live0 = live;
     V H[kLTri], gc[kLV];
     static_for<0, kLTri>([&](auto kc) { H[decltype(kc)::value] = V(0); });
     static_for<0, kLV>([&](auto ic) { gc[decltype(ic)::value] = V(0); });
     U mask = LT::Fill(0u);
     EPA_LG_TICK(cx, 3);
-    RowsPass<KL, true>(m, cx, p, lim, ends, qacc, gc, H, mask);
+    RowsPass<KL, true>(m, cx, p, lim, ends_t, qacc, gc, H, mask);
     // group sums: the torso entries collect every lane of the env, the leg entries the leg's lanes
     static_for<0, kLV>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
@@ -1190,7 +1224,11 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
       } else {
         gc[j] = SumPar<KL>(gc[j]);
       }
-      grad[j] = (Ma[j] - qfrc_smooth[j]) + gc[j];
+      if constexpr (kLiveSlots) {
+        grad[j] = Sel(live0, (Ma[j] - qfrc_smooth[j]) + gc[j], grad[j]);
+      } else {  // every lane rebuilt its complete rows: current for finished envs too
+        grad[j] = (Ma[j] - qfrc_smooth[j]) + gc[j];
+      }
       static_for<0, j + 1>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         if constexpr (j < 3) {
@@ -1236,9 +1274,9 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
       V d1p = V(0), d2p = V(0);
       U mask1 = LT::Fill(0u);
       if (ls == 0) {
-        LineEval<KL, true>(m, cx, p, lim, ends, qacc, s, alpha, &d1p, &d2p, mask1);
+        LineEval<KL, true>(m, cx, p, lim, ends_t, qacc, s, alpha, &d1p, &d2p, mask1);
       } else {
-        LineEval<KL, false>(m, cx, p, lim, ends, qacc, s, alpha, &d1p, &d2p, mask1);
+        LineEval<KL, false>(m, cx, p, lim, ends_t, qacc, s, alpha, &d1p, &d2p, mask1);
       }
       const V d1 = (g1 + alpha * g2) + SumEnv<KL>(d1p), d2 = g2 + SumEnv<KL>(d2p);
       const B hit = Abs(d1) <= ls_tol;
@@ -1267,8 +1305,13 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
     const V step = Sel(live, alpha, V(0));
     static_for<0, kLV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      qacc[i] += step * s[i];
-      Ma[i] += step * Ms[i];
+      if constexpr (kLiveSlots) {  // (a select, not a zero step: s of a finished env is built from partial rows)
+        qacc[i] = Sel(live, qacc[i] + alpha * s[i], qacc[i]);
+        Ma[i] = Sel(live, Ma[i] + alpha * Ms[i], Ma[i]);
+      } else {
+        qacc[i] += step * s[i];
+        Ma[i] += step * Ms[i];
+      }
     });
     at_min = at_min | exact;
     live = live & !exact;
@@ -1301,7 +1344,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
 }
 
 // mj_forward: qacc at (q, v) under ctrl; `warm` is qacc_warmstart in/out; `p` keeps M for the caller
-template <int KL, typename T, typename V, typename Cx>
+template <int KL, bool kLiveSlots, typename T, typename V, typename Cx>
 EPA_HD V Forward(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, const V* q, const V* v,
                  V* warm, const V* ctrl, Pos<V>& p, V* qacc, V* Ma, V* grad) {
   cx.Refresh();
@@ -1311,11 +1354,12 @@ EPA_HD V Forward(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, co
   V qfrc_smooth[kLV];
   SmoothForces<KL>(m, cx, p, q, v, ctrl, qfrc_smooth);
   LimitRows<V> lim;
-  const unsigned ends = MakeConstraint<KL>(m, cx, p, q, v, lim);
+  typename LaneTypes<V>::U own;
+  const unsigned ends = MakeConstraint<KL>(m, cx, p, q, v, lim, own);
   EPA_LG_HOST_ENDS(ends);
   static_for<0, kLV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
   EPA_LG_TICK(cx, 1);
-  const V iters = Solve<KL>(m, cx, p, lim, ends, qfrc_smooth, cfg, qacc, Ma, grad);
+  const V iters = Solve<KL, kLiveSlots>(m, cx, p, lim, ends, own, qfrc_smooth, cfg, qacc, Ma, grad);
   EPA_LG_TICK(cx, 2);
   static_for<0, kLV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
   return iters;
@@ -1328,7 +1372,7 @@ EPA_HD V StepEuler(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, 
                    const V* ctrl) {
   Pos<V> p;
   V qacc[kLV], Ma[kLV], grad[kLV];
-  const V iters = Forward<KL>(m, cfg, cx, q, v, warm, ctrl, p, qacc, Ma, grad);
+  const V iters = Forward<KL, true>(m, cfg, cx, q, v, warm, ctrl, p, qacc, Ma, grad);
   // (M + h diag(damping)) qacc_d = qfrc_smooth + qfrc_constraint = Ma - grad
   V rhs[kLV];
   static_for<0, kLV>([&](auto ic) {
@@ -1368,7 +1412,7 @@ EPA_HD V StepRK4(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, V*
   for (int stage = 0; stage < 4; ++stage) {
     Pos<V> p;
     V Ma[kLV], grad[kLV];
-    it += Forward<KL>(m, cfg, cx, qs, vs, warm, ctrl, p, F, Ma, grad);
+    it += Forward<KL, false>(m, cfg, cx, qs, vs, warm, ctrl, p, F, Ma, grad);
     const V bw = V((stage == 0 || stage == 3) ? T(1.0 / 6.0) : T(1.0 / 3.0));
     const V a = V(stage == 2 ? T(1) : T(0.5));
     static_for<0, kLV>([&](auto ic) {

@@ -460,11 +460,7 @@ void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots
   if (kl == 1) {
     EPA_LG(1, 1);
   } else if (kl == 2) {
-    if (waves == 1) {
-      EPA_LG(2, 1);
-    } else {
-      EPA_LG(2, 2);
-    }
+    EPA_LG(2, 1);  // LDS (38 KB per wave) allows one wave per SIMD whatever the register budget: no <2, *, 2> build
   } else if (waves == 1) {
     EPA_LG(4, 1);
   } else {

@@ -76,7 +76,8 @@ typedef struct epa_pool epa_pool;
  *                 bit for bit.  Each layout is within 1e-9 of the oracle per env-step.
  *                 Hopper: 0 (default) the lane-group kernel with a group of ONE lane (the lane's 6 dofs are
  *                 the robot), 1 the one-env-per-lane kernel on the 9-dof tree with a ghost leg; 2 / 4 refused.
- *   "planar_waves" lane-group kernel: register budget for 1 (default) or 2 waves per SIMD
+ *   "planar_waves" lane-group kernel with 4 lanes per env: register budget for 1 (default) or 2 waves per SIMD
+ *                 (A/B switch; with 1 or 2 lanes per env LDS allows one wave and the key has no effect)
  *   "planar_lpt"  lane-group kernel: 1 (default) whole-pool launches serve the chunks of envs slowest
  *                 first, by their duration in the previous launch; 0 index order.  Never changes results.
  *   "compute_streams" async mode (batch_size < num_envs): successive batches run on this many
