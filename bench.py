@@ -31,7 +31,7 @@ def cpu_baseline(task="HalfCheetah", target_s=12.0, action_hi=1.0):
 
     Where oracle/_ref/libref_mujoco.so travelled (built in the container that holds
     /root/reference): the reference's OWN AsyncEnvPool thread pool and task wrapper
-    (envpool/core/async_envpool.h, envpool/mujoco/gym/*.h compiled in place), num_threads = cores,
+    (envpool/core/async_envpool.h, envpool/mujoco/gym/*.h compiled in place), num_threads = cores - 1,
     sync Send / Recv loop -- over the oracle/mjcpu fp64 engine, because mj_step itself lives in
     un-vendored MuJoCo 3.6.0 ("our fp64 CPU restatement inside the reference
     threadpool on all cores").  The engine does the arithmetic, so kind stays "port".
@@ -71,8 +71,10 @@ def cpu_baseline(task="HalfCheetah", target_s=12.0, action_hi=1.0):
         return {**omp, "cores": cores, "kind": "port",
                 "sample": "oracle/mjcpu fp64 engine, plain port; " + omp["sample"] +
                           " (reference mj_step not runnable: MuJoCo 3.6.0 un-vendored)"}
+    # cores - 1 workers + the driving thread (it polls Recv): with `cores` workers the pool ran oversubscribed by one
+    workers = max(1, cores - 1)
     value, steps, t = leg(Oracle(task, num_envs, seed=0, max_episode_steps=1000, kind="reference_mujoco",
-                                 num_threads=cores), 2 * target_s / 3)
+                                 num_threads=workers), 2 * target_s / 3)
     return {
         "value": value,
         "unit": "env-steps/s",
@@ -80,9 +82,9 @@ def cpu_baseline(task="HalfCheetah", target_s=12.0, action_hi=1.0):
         "kind": "port",
         "runtime": "reference AsyncEnvPool + reference task wrapper",
         "sample": f"oracle/mjcpu fp64 engine inside the reference's own AsyncEnvPool threadpool + task wrapper "
-                  f"(oracle/_ref/libref_mujoco.so), num_threads={cores}, sync Send/Recv; {num_envs} envs x {steps} "
-                  f"steps, {t:.1f}s (reference mj_step not runnable: MuJoCo 3.6.0 un-vendored; moodycamel's "
-                  f"semaphore is a spin-then-block shim)",
+                  f"(oracle/_ref/libref_mujoco.so), num_threads={workers} + the driving thread, sync Send/Recv; "
+                  f"{num_envs} envs x {steps} steps, {t:.1f}s (reference mj_step not runnable: MuJoCo 3.6.0 "
+                  f"un-vendored; moodycamel's semaphore is a shim that polls 400000 times (~10 ms) before it blocks)",
         "openmp_port": omp,
     }
 
@@ -346,7 +348,10 @@ def main():
         kname = kbase + ("<double>" if args.precision == "fp64" or fp64_only else "<float>")
         if lg:
             kbase = "PlanarLgStepKernel"
-            kname = f"PlanarLgStepKernel<{lg_layout},{int(params.get('planar_waves', 1))}>"
+            # waves per SIMD the build aims at: "planar_waves" only exists for 4 lanes per env (with 1 or 2 lanes
+            # per env LDS allows one wave and PlanarLgLaunch ignores the key)
+            lg_waves = int(params.get("planar_waves", 1)) if lg_layout == 4 else 1
+            kname = f"PlanarLgStepKernel<{lg_layout},{lg_waves}>"
         if args.task in ("Walker2d", "Hopper"):
             kname += f"[{args.task}]"
         if args.task == "HumanoidStandup":

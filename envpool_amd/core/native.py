@@ -17,7 +17,9 @@ from typing import Sequence
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libenvpool_amd.so")
+# ENVPOOL_AMD_LIB: another build of the same C ABI (the cross-check tests load lib/libenvpool_amd_alt.so, the
+# product library plus the superseded Humanoid kernels: `make -C envpool_amd/csrc EPA_ALT_KERNELS=1`)
+LIB_PATH = os.environ.get("ENVPOOL_AMD_LIB") or os.path.join(_PKG, "lib", "libenvpool_amd.so")
 
 EPA_OK, EPA_ERR_INVALID, EPA_ERR_RUNTIME, EPA_ERR_DEVICE = 0, 1, 2, 3
 DTYPES = {0: np.int32, 1: np.float32, 2: np.float64, 3: np.bool_, 4: np.uint8}

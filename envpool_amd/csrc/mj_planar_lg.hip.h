@@ -60,6 +60,12 @@
 #ifndef EPA_LG_HOST_ENDS
 #define EPA_LG_HOST_ENDS(ends) ((void)0)
 #endif
+#ifndef EPA_LG_HOST_OWN
+#define EPA_LG_HOST_OWN(own) ((void)0)
+#endif
+#ifndef EPA_LG_HOST_ROWS
+#define EPA_LG_HOST_ROWS() ((void)0)
+#endif
 #ifndef EPA_LG_LS_RTOL
 #define EPA_LG_LS_RTOL 1e-10
 #endif
@@ -1215,6 +1221,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
     static_for<0, kLV>([&](auto ic) { gc[decltype(ic)::value] = V(0); });
     U mask = LT::Fill(0u);
     EPA_LG_TICK(cx, 3);
+    EPA_LG_HOST_ROWS();
     RowsPass<KL, true>(m, cx, p, lim, ends_t, qacc, gc, H, mask);
     // group sums: the torso entries collect every lane of the env, the leg entries the leg's lanes
     static_for<0, kLV>([&](auto jc) {
@@ -1357,6 +1364,7 @@ EPA_HD V Forward(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, co
   typename LaneTypes<V>::U own;
   const unsigned ends = MakeConstraint<KL>(m, cx, p, q, v, lim, own);
   EPA_LG_HOST_ENDS(ends);
+  EPA_LG_HOST_OWN(own);
   static_for<0, kLV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
   EPA_LG_TICK(cx, 1);
   const V iters = Solve<KL, kLiveSlots>(m, cx, p, lim, ends, own, qfrc_smooth, cfg, qacc, Ma, grad);

@@ -197,11 +197,9 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
   cm.cur_step[e] = cur;
   // WriteState, half_cheetah.h:158-185
   const int nobs = 2 * kNVr - task.obs_skip;
-  const int S = task.frame_stack;
-  double* obs0 = (double*)out.p[kKeyEnv0] + (size_t)row * nobs * S;
-  double* newest = obs0 + (size_t)(S - 1) * nobs;
+  // (frame_stack > 1: the engine's generic ring, Pool::EnableObsStack -- the kernel always writes one frame per row)
   {
-    double* obs = newest;
+    double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
     for (int i = task.obs_skip; i < kNVr; ++i) *(obs++) = qpos[i];
     for (int i = 0; i < kNVr; ++i) {
       double x = qvel[i];
@@ -210,22 +208,6 @@ __global__ __launch_bounds__(kCheetahBlock) void CheetahStepKernel(
         x = x > task.velocity_min ? x : task.velocity_min;  // std::max(vmin, x)
       }
       *(obs++) = x;
-    }
-  }
-  if (S > 1) {  // FrameStackBuffer::Commit, frame_stack.h:109-135
-    double* st = dev.stack + (size_t)e * S * nobs;
-    if (reset) {
-      for (int f = 0; f < S - 1; ++f) {
-        for (int i = 0; i < nobs; ++i) obs0[f * nobs + i] = newest[i];
-      }
-      for (int j = 0; j < S * nobs; ++j) st[j] = obs0[j];
-    } else {
-      for (int j = 0; j < (S - 1) * nobs; ++j) {
-        double x = st[j + nobs];
-        st[j] = x;
-        obs0[j] = x;
-      }
-      for (int i = 0; i < nobs; ++i) st[(S - 1) * nobs + i] = newest[i];
     }
   }
   if constexpr (kWalker) {  // walker2d.h:218-219
@@ -329,7 +311,6 @@ class CheetahPool : public Pool {
                                   "families (HalfCheetah, Walker2d, Hopper); only 1 (fp64, the reference's "
                                   "mjtNum) is accepted");
     }
-    fp64_ = true;
     // defaults: half_cheetah.h:33-43 / walker2d.h:32-47
     task_.frame_skip = (int)cfg.Get("frame_skip", walker ? 4 : 5);
     task_.obs_skip =
@@ -378,14 +359,14 @@ class CheetahPool : public Pool {
       throw std::invalid_argument("planar_layout must be 0, 1, 2 or 4");
     }
     if (hopper && layout_ > 1) throw std::invalid_argument("planar_layout: the Hopper takes 0 or 1");
-    // frame_stack > 1 on the fp64 two-legged models: the generic ring of the engine (EnableObsStack; the
-    // kernels then write one frame per row), so that stacked and plain pools run the same step kernel
-    // and agree bit for bit; the other configurations keep this file's in-kernel ring (dev_.stack)
-    if (task_.frame_stack > 1 && fp64_) {
+    // frame_stack > 1: the generic ring of the engine (EnableObsStack; the kernels write one frame per row), so
+    // that stacked and plain pools run the same step kernel and agree bit for bit (the in-kernel ring the
+    // one-env-per-lane kernel had in rounds 1-3 went with the fp32 mode that was its last user)
+    if (task_.frame_stack > 1) {
       EnableObsStack();
       task_.frame_stack = 1;
     }
-    lg_ok_ = fp64_ && task_.frame_stack == 1;
+    lg_ok_ = true;
     // (async mode: several batches are in flight on the pool's compute streams, so what fills the machine is
     // batch_size x streams, not one batch: 8 x 8192 of 65536 envs measured 2.83e8 with 2 lanes per env against
     // 2.06e8 with 4, profiles/archive/r3r_async_probe.jsonl; and partly filled waves -- made to occupy more SIMDs with ONE
@@ -418,11 +399,6 @@ class CheetahPool : public Pool {
       wave_slots_ = prop.multiProcessorCount * 4;  // one wave per SIMD, four SIMDs per CU
       if (wave_slots_ < 1) wave_slots_ = 1;
     }
-    if (task_.frame_stack > 1) {
-      size_t sb = sizeof(double) * n * task_.frame_stack * (2 * kNV - task_.obs_skip);
-      EPA_HIP(hipMalloc(&dev_.stack, sb));
-      EPA_HIP(hipMemsetAsync(dev_.stack, 0, sb, stream_));
-    }
     EPA_HIP(hipMemsetAsync(dev_.iters, 0, sizeof(int) * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.qpos, 0, sizeof(double) * kNV * n, stream_));
     EPA_HIP(hipMemsetAsync(dev_.qvel, 0, sizeof(double) * kNV * n, stream_));
@@ -442,7 +418,6 @@ class CheetahPool : public Pool {
     (void)hipFree(dev_.nsaved);
     (void)hipFree(dev_.navail);
     (void)hipFree(dev_.iters);
-    if (dev_.stack) (void)hipFree(dev_.stack);
     for (double* t : d_tab_) {
       if (t) (void)hipFree(t);
     }
@@ -531,7 +506,6 @@ class CheetahPool : public Pool {
   WaveTrace trace_;
   int model_id_;
   CheetahTask task_{};
-  bool fp64_{false};
   bool spread_{true};
   bool async_{false};
   int wave_slots_{1024};

@@ -42,6 +42,11 @@ struct HumanoidMP {
 constexpr int kHumBlock = 64;
 
 
+// The step kernel of this file is the SUPERSEDED one-env-per-lane form ("hum_layout" = 0; the product kernel is
+// mujoco_humanoid4.hip).  It is built only into the alternate library (`make EPA_ALT_KERNELS=1` ->
+// libenvpool_amd_alt.so, ~90 s per model) that the cross-check tests load; the default library keeps this file's
+// pool class, state accessors and layout constants and refuses hum_layout = 0.
+#ifdef EPA_ALT_KERNELS
 template <class MP, bool kStandup>
 __global__ __launch_bounds__(kHumBlock) void HumanoidStepKernel(
     HumDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
@@ -176,6 +181,8 @@ __global__ __launch_bounds__(kHumBlock) void HumanoidStepKernel(
   WriteCommon(out, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
 }
 
+#endif  // EPA_ALT_KERNELS
+
 // flat state like oracle/mjcpu: qpos[24] qvel[23] warm[23] time xlag ylag done cur_step
 // normal_saved normal_avail (the last two unused: uniform noise only; xlag / ylag: the lagged
 // mass centre)
@@ -229,8 +236,13 @@ constexpr bool kThisStandup = false;
 #endif
 void EPA_HUM_FN(HumLaunchStep)(hipStream_t st, int blocks, HumDev dev, CommonDev cm, StepArgs a,
                                const double* act, OutPtrs out, HumTask task) {
+#ifdef EPA_ALT_KERNELS
   hipLaunchKernelGGL((HumanoidStepKernel<HumModelP, kThisStandup>), dim3(blocks), dim3(kHumBlock), 0,
                      st, dev, cm, a, act, out, task);
+#else
+  (void)kThisStandup;
+  throw std::runtime_error("the one-env-per-lane Humanoid kernel is not in this build (make EPA_ALT_KERNELS=1)");
+#endif
 }
 void EPA_HUM_FN(HumLaunchGet)(hipStream_t st, int k, HumDev dev, CommonDev cm, const int* ids,
                               double* out) {
@@ -317,6 +329,13 @@ class HumanoidPool : public Pool {
     // "hum_layout": 1 (default) one env per lane quad (mj_hum4.hip.h), 0 one env per lane with
     // the HBM workspace (mj_tree.hip.h; kept for A/B runs)
     quad_ = cfg.Get("hum_layout", 1) != 0;
+#ifndef EPA_ALT_KERNELS
+    if (!quad_) {
+      throw std::invalid_argument("\"hum_layout\" = 0 (the superseded one-env-per-lane Humanoid kernel) is only built "
+                                  "into the alternate library: make -C envpool_amd/csrc EPA_ALT_KERNELS=1 and load "
+                                  "lib/libenvpool_amd_alt.so (ENVPOOL_AMD_LIB)");
+    }
+#endif
     // "hum_sort": 1 (default) waves are formed from envs of similar solver cost (Hum4SortKernel)
     sort_ = quad_ && cfg.Get("hum_sort", 1) != 0;
     EPA_HIP(hipMalloc(&dev_.cost, sizeof(int) * (size_t)cfg.num_envs));
@@ -339,6 +358,9 @@ class HumanoidPool : public Pool {
       (void)hipFree(kv.second.ws);
       (void)hipFree(kv.second.perm);
     }
+    (void)hipFree(big_.ws);
+    (void)hipFree(big_.perm);
+    if (big_ev_) (void)hipEventDestroy(big_ev_);
     (void)hipFree(dev_.state);
     (void)hipFree(dev_.cost);
   }
@@ -369,6 +391,10 @@ class HumanoidPool : public Pool {
       }
       Hum4LaunchStep(stream_, standup_, (k + 15) / 16, dev, common_, a, static_cast<const double*>(d_action),
                      out, task_);
+      if (big_used_) {
+        EPA_HIP(hipEventRecord(big_ev_, stream_));
+        big_used_ = false;
+      }
       return;
     }
     const int blocks = (k + kHumBlock - 1) / kHumBlock;
@@ -380,31 +406,40 @@ class HumanoidPool : public Pool {
   int Total() const {
     return standup_ ? HumWorkspaceSlotsStandup() : HumWorkspaceSlotsHumanoid();
   }
-  // per-launch scratch of the quad kernel on compute stream `st`, for launches of up to `rows` rows: sized for
-  // the pool's usual launch (batch_size in async mode, else num_envs) and grown if a bigger one comes
-  // (e.g. the reset of all envs in one send); a regrowth waits for the stream and frees (rare)
+  // per-launch scratch of the quad kernel on compute stream `st`: one copy per stream, sized ONCE for the pool's
+  // usual launch (batch_size in async mode, else num_envs).  A bigger launch (the reset of all envs of an async pool
+  // in one send) does not regrow it -- that took a hipFree, which waits for the whole device and stalled every
+  // other compute stream mid-run -- but goes to ONE shared copy sized for num_envs, allocated at the first such
+  // launch; launches that use it are chained by an event, whichever stream they run on.  Bound on the memory:
+  // compute_streams x Hum4WorkspaceBytes(batch_size) + Hum4WorkspaceBytes(num_envs) (include/envpool_amd.h).
   struct Scratch {
     double* ws{nullptr};
     int* perm{nullptr};
     int rows{0};
   };
+  void AllocScratch(Scratch& sc, int rows, hipStream_t st) {
+    sc.rows = rows;
+    const size_t bytes = Hum4WorkspaceBytes(sc.rows);
+    EPA_HIP(hipMalloc(&sc.ws, bytes));
+    EPA_HIP(hipMemsetAsync(sc.ws, 0, bytes, st));
+    EPA_HIP(hipMalloc(&sc.perm, sizeof(int) * (size_t)sc.rows));
+  }
   const Scratch& ScratchFor(hipStream_t st, int k) {
-    Scratch& sc = scratch_[st];
-    if (sc.rows < k) {
-      if (sc.ws != nullptr) {
-        EPA_HIP(hipStreamSynchronize(st));
-        (void)hipFree(sc.ws);
-        (void)hipFree(sc.perm);
-      }
-      const bool async = cfg_.batch_size > 0 && cfg_.batch_size < cfg_.num_envs;
-      const int usual = async ? cfg_.batch_size : cfg_.num_envs;
-      sc.rows = k > usual ? k : usual;
-      const size_t bytes = Hum4WorkspaceBytes(sc.rows);
-      EPA_HIP(hipMalloc(&sc.ws, bytes));
-      EPA_HIP(hipMemsetAsync(sc.ws, 0, bytes, st));
-      EPA_HIP(hipMalloc(&sc.perm, sizeof(int) * (size_t)sc.rows));
+    const bool async = cfg_.batch_size > 0 && cfg_.batch_size < cfg_.num_envs;
+    const int usual = async ? cfg_.batch_size : cfg_.num_envs;
+    if (k <= usual) {
+      Scratch& sc = scratch_[st];
+      if (sc.ws == nullptr) AllocScratch(sc, usual, st);
+      return sc;
     }
-    return sc;
+    if (big_.ws == nullptr) {
+      AllocScratch(big_, cfg_.num_envs, st);
+      EPA_HIP(hipEventCreateWithFlags(&big_ev_, hipEventDisableTiming));
+    } else {
+      EPA_HIP(hipStreamWaitEvent(st, big_ev_, 0));  // behind the previous launch that used the shared copy
+    }
+    big_used_ = true;
+    return big_;
   }
   HumDev dev_{};
   HumTask task_{};
@@ -412,6 +447,9 @@ class HumanoidPool : public Pool {
   bool standup_;
   bool quad_{true}, sort_{true};
   std::map<hipStream_t, Scratch> scratch_;
+  Scratch big_;  // shared by the launches that exceed the usual size
+  hipEvent_t big_ev_{nullptr};
+  bool big_used_{false};
 };
 
 }  // namespace

@@ -21,7 +21,6 @@ struct CheetahDev {
   double* qvel;  // [9][N]
   double* warm;  // [9][N]
   int* iters;              // Newton iterations of the last step (profiling)
-  double* stack;           // [N][frame_stack * nobs] obs ring (frame_stack > 1 only)
   double* nsaved;          // normal_distribution::_M_saved
   unsigned char* navail;   // normal_distribution::_M_saved_available
   // diagnostic (EPA_PLANAR_TRACE=<file>): per wave of the last launch {wall clock begin,
@@ -32,7 +31,7 @@ struct CheetahDev {
 
 struct CheetahTask {
   int frame_skip;
-  int frame_stack;  // TypedFrameStackBuffer depth (envpool/mujoco/frame_stack.h:74-146)
+  int frame_stack;  // always 1 for the kernels: TypedFrameStackBuffer (envpool/mujoco/frame_stack.h:74-146) is Pool::EnableObsStack
   int obs_skip;  // 1 if exclude_current_positions_from_observation
   double ctrl_cost_weight, forward_reward_weight, reset_noise_scale;
   double dt;     // frame_skip * timestep, computed in fp64 like the reference

@@ -521,12 +521,14 @@ int PlanarLgBuildTable(int kl, int model, double* tab) {
                                  : model == mj::kPlanarWalker ? kWalkerModelConst
                                  : model == mj::kPlanarHopper ? kHopperModelConst
                                                               : kWalkerV5ModelConst;
+  static_assert(plg::Tab<1>::kSize <= kPlanarLgTabMax && plg::Tab<2>::kSize <= kPlanarLgTabMax &&
+                    plg::Tab<4>::kSize <= kPlanarLgTabMax,
+                "table size");
   if (kl == 1) {
     plg::BuildTable<1>(m, tab);
     return plg::Tab<1>::kSize;
   }
   if (kl == 2) {
-    static_assert(plg::Tab<2>::kSize <= kPlanarLgTabMax && plg::Tab<4>::kSize <= kPlanarLgTabMax, "table size");
     plg::BuildTable<2>(m, tab);
     return plg::Tab<2>::kSize;
   }

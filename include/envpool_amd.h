@@ -84,7 +84,12 @@ typedef struct epa_pool epa_pool;
  *                 compute streams (default 4, 1 = one stream), like the reference's worker threads
  *                 step all queued slices in parallel (core/async_envpool.h:116-132).  Pools with the generic
  *                 frame stack (frame_stack > 1) and the one-env-per-lane Humanoid kernel (hum_layout = 0, one
- *                 shared workspace) keep one stream.  The rule for the caller is the reference's: an env may be sent
+ *                 shared workspace) keep one stream.  Device memory of the Humanoid quad pools' per-launch scratch:
+ *                 compute_streams x W(batch_size) + W(num_envs), W(rows) = 1.9 MB per 16 rows (the second term only
+ *                 once a send exceeds batch_size rows, e.g. the reset of all envs; such sends share one copy and are
+ *                 ordered behind each other).  A device-path send whose env ids do not continue a handed-out batch
+ *                 (identity ids, ids from elsewhere) is ordered behind EVERY batch still executing or pending.
+ *                 The rule for the caller is the reference's: an env may be sent
  *                 again only after recv handed it out (host path: a violation is detected and that
  *                 launch is ordered behind everything enqueued; device path: the env ids of a send
  *                 should be the `info:env_id` array of a batch recv_device returned -- the launch then

@@ -40,7 +40,11 @@ class LightweightSemaphore {
     // SURVEY.md section 8d asks for ("vendor-equivalent spin semaphore").
     for (int spin = 0; spin < 400000; ++spin) {
       if (tryWait()) return true;
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
+#else
+      std::this_thread::yield();
+#endif
     }
     std::unique_lock<std::mutex> lk(mu_);
     sleepers_.fetch_add(1);  // seq_cst: ordered against the count_ update of a concurrent signal()

@@ -7,6 +7,8 @@ Tolerances (stated): teacher-forced per env-step (5 mj_steps):
   (the fp32 arithmetic mode of rounds 1-3 -- |d obs| p99 1.6e-4 on a cond~1e4 Newton system, outside
    the 1e-5 bar, and slower than the fp64 lane-group kernel -- was removed)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -619,11 +621,14 @@ def test_hopper_layouts_share_state_and_agree():
 
 # ---- generic observation frame stack (engine-level TypedFrameStackBuffer) ----
 @pytest.mark.parametrize("task,adim,amax,S", [("InvertedPendulum", 1, 3.0, 3), ("Swimmer", 2, 1.0, 2),
-                                              ("Reacher", 2, 1.0, 4)])
+                                              ("Reacher", 2, 1.0, 4), ("Hopper", 3, 1.0, 3),
+                                              ("Walker2d", 6, 1.0, 2)])
 def test_chain_families_frame_stack(task, adim, amax, S):
     """frame_stack = S: obs[:, -1] is the newest frame, older frames shift towards 0,
     a reset fills all S slots (envpool/mujoco/frame_stack.h:109-135).  Checked against
-    the oracle's un-stacked observations stacked in numpy, across auto-resets."""
+    the oracle's un-stacked observations stacked in numpy, across auto-resets.  Hopper / Walker2d: the
+    planar pools use the same engine-level ring since round 4 (the lane-group kernels write one frame per
+    row); their unhealthy terminations put the auto-reset rows at a different step for every env."""
     n, max_steps = 256, 12
     pool = DevicePool(task, n, seed=2, max_episode_steps=max_steps, params={"frame_stack": S})
     orc = Oracle(task, n, seed=2, max_episode_steps=max_steps)
@@ -763,18 +768,39 @@ def test_humanoid_deterministic_and_partial_batches():
         np.testing.assert_allclose(got, a["obs"], rtol=1e-9, atol=1e-10, err_msg=f"step {t}")
 
 
+ALT_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "envpool_amd", "lib",
+                       "libenvpool_amd_alt.so")
+_ALT_LEG = """
+import sys, numpy as np
+from envpool_amd.core.device_pool import DevicePool
+task, n, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+acts = np.random.default_rng(5).uniform(-0.4, 0.4, size=(25, n, 17))
+p = DevicePool(task, n, seed=3, max_episode_steps=1000, params={"post_constraint": 1, "hum_layout": 0})
+ids = np.arange(n, dtype=np.int32)
+p.reset(ids); p.recv_dict()
+seq = []
+for t in range(25):
+    p.send(ids, acts[t]); a = p.recv_dict()
+    assert a["info:env_id"].ravel().tolist() == list(range(n))
+    seq.append(np.concatenate([a["obs"], a["reward"].reshape(n, 1), a["done"].reshape(n, 1)], axis=1))
+np.save(out, np.stack(seq))
+"""
+
+
 @pytest.mark.parametrize("task", ["Humanoid", "HumanoidStandup"])
-def test_humanoid_layouts_and_scheduling_agree(task):
+def test_humanoid_layouts_and_scheduling_agree(task, tmp_path):
     """The one-env-per-lane-quad kernel (mj_hum4.hip.h, default), with and without the cost-sorted
     scheduling of its waves, and the one-env-per-lane kernel (mj_tree.hip.h, hum_layout=0) are three
     schedules of the same arithmetic: free running from the same seed with the same actions they
     stay together to PGS-rounding level (which solver formulation an env gets depends on the envs
-    that share its wave), and the rows come back in send order whatever order the waves ran in."""
+    that share its wave), and the rows come back in send order whatever order the waves ran in.
+    The one-env-per-lane kernel lives in the alternate library only (make EPA_ALT_KERNELS=1; the product
+    library refuses hum_layout = 0): that leg runs in a subprocess that loads it through ENVPOOL_AMD_LIB."""
     n = 512  # 32 waves of 16 envs: the sort has something to reorder
     rng = np.random.default_rng(5)
     acts = rng.uniform(-0.4, 0.4, size=(25, n, 17))
     outs = []
-    for params in ({"hum_layout": 1, "hum_sort": 1}, {"hum_layout": 1, "hum_sort": 0}, {"hum_layout": 0}):
+    for params in ({"hum_layout": 1, "hum_sort": 1}, {"hum_layout": 1, "hum_sort": 0}):
         p = DevicePool(task, n, seed=3, max_episode_steps=1000, params={"post_constraint": 1, **params})
         hip_reset(p)
         seq = []
@@ -783,7 +809,21 @@ def test_humanoid_layouts_and_scheduling_agree(task):
             assert a["info:env_id"].ravel().tolist() == list(range(n))
             seq.append(np.concatenate([a["obs"], a["reward"].reshape(n, 1), a["done"].reshape(n, 1)], axis=1))
         outs.append(np.stack(seq))
-    for other, what in ((outs[1], "sorted vs unsorted waves"), (outs[2], "quad vs one-env-per-lane layout")):
+    with pytest.raises(Exception, match="hum_layout"):
+        DevicePool(task, 16, seed=3, max_episode_steps=10, params={"hum_layout": 0})
+    pairs = [(outs[1], "sorted vs unsorted waves")]
+    if os.path.exists(ALT_LIB):
+        import subprocess
+        import sys
+
+        out = str(tmp_path / "alt.npy")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        subprocess.run([sys.executable, "-c", _ALT_LEG, task, str(n), out], check=True, cwd=root,
+                       env={**os.environ, "ENVPOOL_AMD_LIB": ALT_LIB, "PYTHONPATH": root})
+        pairs.append((np.load(out), "quad vs one-env-per-lane layout"))
+    else:
+        print("libenvpool_amd_alt.so not built: the one-env-per-lane leg is skipped")
+    for other, what in pairs:
         rel = np.abs(outs[0] - other) / (1.0 + np.abs(other))
         # a free-running humanoid amplifies rounding differences: bulk tight, tail bounded
         assert np.median(rel.max(axis=2)) < 1e-10, what
