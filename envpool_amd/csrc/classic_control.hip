@@ -70,23 +70,21 @@ struct Traits<kAcrobot> {
 // ---- reset bodies ---------------------------------------------------------
 template <int KIND>
 __device__ inline void ResetBody(double* s, Mt19937& g) {
+  // (the draws of a reset as ONE burst of generator words: Mt19937::NextWords)
   if constexpr (KIND == kCartPole) {  // cartpole.h:82-90
-    s[0] = g.UniformReal(-0.05, 0.05);
-    s[1] = g.UniformReal(-0.05, 0.05);
-    s[2] = g.UniformReal(-0.05, 0.05);
-    s[3] = g.UniformReal(-0.05, 0.05);
+    g.UniformReals<4>(-0.05, 0.05, s);
   } else if constexpr (KIND == kPendulum) {  // pendulum.h:77-85
-    s[0] = g.UniformReal(-kPi, kPi);
-    s[1] = g.UniformReal(-1, 1);
+#pragma clang fp contract(off)
+    uint32_t w[4];
+    g.NextWords<4>(w);
+    s[0] = (Mt19937::CanonicalOf(w[0], w[1]) * (kPi - (-kPi))) + (-kPi);
+    s[1] = (Mt19937::CanonicalOf(w[2], w[3]) * (1.0 - (-1.0))) + (-1.0);
   } else if constexpr (KIND == kMountainCar ||
                        KIND == kMountainCarContinuous) {  // mountain_car.h:76-82
     s[0] = g.UniformReal(-0.6, -0.4);
     s[1] = 0.0;
   } else {  // acrobot.h:94-103
-    s[0] = g.UniformReal(-0.1, 0.1);
-    s[1] = g.UniformReal(-0.1, 0.1);
-    s[2] = g.UniformReal(-0.1, 0.1);
-    s[3] = g.UniformReal(-0.1, 0.1);
+    g.UniformReals<4>(-0.1, 0.1, s);
     s[4] = 0;
   }
 }

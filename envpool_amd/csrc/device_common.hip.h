@@ -72,7 +72,8 @@ struct Mt19937 {
   }
   // The 16 words [16 t, 16 t + 16) of the next block, in place (tiled layout): one 64-byte tile in and out as
   // uint4, the neighbour word of the next tile, 16 partner words out of two other tiles.
-  __device__ void RegenTile16() {
+  __device__ void RegenTile16() { RegenTile16At(idx); }
+  __device__ void RegenTile16At(int idx) {  // idx: the tile's first word, a multiple of 16
     const int t = idx >> 4;
     uint4* own = reinterpret_cast<uint4*>(&At(idx));
     uint32_t w[17];
@@ -125,17 +126,67 @@ struct Mt19937 {
     return y;
   }
 
+  // The next K outputs in ONE burst (K <= 16).  Tiled layout: Next() costs a dependent global round trip per word
+  // (the compiler cannot move a load across the conditional tile regeneration in front of it), and a reset lane
+  // runs them one after the other while the other 63 lanes of its wave wait; here the one tile boundary the K words
+  // can cross is regenerated first (regenerating a tile before the rest of the previous one is consumed reads
+  // nothing that consumption writes) and the K words are then K independent loads.  Same words, same order.
+  template <int K>
+  __device__ void NextWords(uint32_t (&y)[K]) {
+    static_assert(K >= 1 && K <= 16, "one tile boundary at most");
+    if (sh == 0) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) y[r] = Next();
+      return;
+    }
+    const int i0 = idx;
+    const int d = (16 - (i0 & 15)) & 15;  // words in front of the next tile start (0: i0 starts a tile)
+    if (d < K) {
+      const int p = i0 + d;
+      RegenTile16At(p >= 624 ? p - 624 : p);  // (624 = 39 tiles: the wrap lands on a tile start)
+    }
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      const int p = i0 + r;
+      y[r] = At(p >= 624 ? p - 624 : p);
+    }
+    idx = i0 + K >= 624 ? i0 + K - 624 : i0 + K;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      uint32_t t = y[r];
+      t ^= (t >> 11);
+      t ^= (t << 7) & 0x9d2c5680u;
+      t ^= (t << 15) & 0xefc60000u;
+      t ^= (t >> 18);
+      y[r] = t;
+    }
+  }
+
   // std::generate_canonical<double, 53>: random.tcc:3348-3380
-  __device__ double Canonical() {
+  __device__ static double CanonicalOf(uint32_t w0, uint32_t w1) {
 #pragma clang fp contract(off)
     double sum = 0.0, tmp = 1.0;
-    sum += (double)Next() * tmp;
+    sum += (double)w0 * tmp;
     tmp *= 4294967296.0;
-    sum += (double)Next() * tmp;
+    sum += (double)w1 * tmp;
     tmp *= 4294967296.0;
     double ret = sum / tmp;
     if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;  // nextafter(1.0, 0.0)
     return ret;
+  }
+  __device__ double Canonical() {
+    const uint32_t w0 = Next();
+    const uint32_t w1 = Next();
+    return CanonicalOf(w0, w1);
+  }
+  // K draws of std::uniform_real_distribution<double>(a, b), in order, as one burst of 2 K words (K <= 8)
+  template <int K>
+  __device__ void UniformReals(double a, double b, double* out) {
+#pragma clang fp contract(off)
+    uint32_t w[2 * K];
+    NextWords<2 * K>(w);
+#pragma unroll
+    for (int r = 0; r < K; ++r) out[r] = (CanonicalOf(w[2 * r], w[2 * r + 1]) * (b - a)) + a;
   }
   // std::uniform_real_distribution<double>(a, b)
   __device__ double UniformReal(double a, double b) {
