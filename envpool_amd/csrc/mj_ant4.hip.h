@@ -433,6 +433,8 @@ EPA_HD void MulM(Lds&& lds, const V* x, V* y) {
   });
 }
 
+constexpr int kLsExactAfter = 8;  // see Solve
+
 // mj_fwdConstraint: exact Newton on the primal objective (mj_ant.hip.h, AntSolve), with
 // the leg blocks eliminated inside each lane.
 template <typename U, typename T, typename V, typename B, typename Lds>
@@ -548,7 +550,12 @@ EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned
     const V ls_tol = V(sizeof(T) == 4 ? T(1e-4) : T(1e-10)) * Abs(g1);
     B searching = live;
     B exact = V(0) > V(0);
-    for (int ls = 0; ls < 24; ++ls) {
+    // ONE evaluation, at the full step: if phi'(1) vanishes the full step is taken (and is the minimiser if the
+    // active set is the one H was built with), otherwise one Newton step of the 1-D problem, unverified -- an env
+    // takes as many Newton trips as with the exact search of rounds 1-4 and ends on the same minimiser, see
+    // mj_planar_lg.hip.h::Solve.  From trip kLsExactAfter on a wave searches exactly again (never seen to happen).
+    const int ls_max = it < kLsExactAfter ? 1 : 24;
+    for (int ls = 0; ls < ls_max; ++ls) {
       V p1 = V(0), p2 = V(0);
       U m1 = MaskFill(U(), 0u);
       if (ls == 0) {

@@ -69,6 +69,9 @@
 #ifndef EPA_LG_LS_RTOL
 #define EPA_LG_LS_RTOL 1e-10
 #endif
+#ifndef EPA_LG_LS_MAX  // evaluations of one line search (1: see plg::Solve; A/B builds and host experiments: 2, 24)
+#define EPA_LG_LS_MAX 1
+#endif
 
 namespace epa {
 namespace mj {
@@ -90,9 +93,9 @@ struct Grp {
   static constexpr int kEnds = KL == 1 ? 8 : 16 / KL;  // end-sphere slots of a lane
   // body-body capsule pairs (frictionless rows) exist in the Hopper model only
   static constexpr bool kPairs = KL == 1;
-  // line-search cache per end-sphere slot: (Jn.a, Jx.a) and, where the LDS budget of 40 KB per wave
-  // allows it, (Jn.s, Jx.s); the Hopper spends those slots on its three body pairs
-  static constexpr int kCachePerEnd = KL == 1 ? 2 : 4;
+  // line-search cache per end-sphere slot: (Jn.a, Jx.a), left by the pass over the rows (round 5: the (Jn.s, Jx.s)
+  // slots of the exact search went with it, see Solve)
+  static constexpr int kCachePerEnd = 2;
   // local body of slot s (KL = 1, 2: both ends of a body are consecutive slots; KL = 4: one end per body)
   EPA_HD static constexpr int SlotBody(int s) { return KL == 4 ? s : s / 2; }
   // lane coordinate c (0 .. KL-1) -> leg, parity
@@ -166,12 +169,10 @@ inline void BuildTable(const CheetahModel<double>& m, double* tab) {
   }
 }
 
-// LDS slots of a lane, [slot][lane]: 5 per end-sphere slot (cpx cpz aref_n B*mu*vx D), then 4 per
-// end-sphere slot that live for one Newton iteration: (Jn.a, Jx.a) left by the pass over the rows and
-// (Jn.s, Jx.s) left by the first line-search evaluation, so that the further evaluations of that
-// line search (2.1 per iteration on average) do not rebuild the Jacobian columns
-// The Hopper (KL = 1) keeps only (Jn.a, Jx.a) and rebuilds (Jn.s, Jx.s) per evaluation; behind the cache its
-// three body pairs take kSlotsPerPair each (nx nz cx cz aref D, as in mj_cheetah.hip.h).
+// LDS slots of a lane, [slot][lane]: 5 per end-sphere slot (cpx cpz aref_n B*mu*vx D), then 2 per
+// end-sphere slot that live for one Newton iteration: (Jn.a, Jx.a) left by the pass over the rows for the
+// line-search evaluation (which builds J . s itself: one evaluation per iteration, see Solve).  Behind the cache the
+// Hopper's three body pairs take kSlotsPerPair each (nx nz cx cz aref D, as in mj_cheetah.hip.h).
 constexpr int kSlotsPerEnd = 5;
 template <int KL>
 constexpr int CacheBase() { return Grp<KL>::kEnds * kSlotsPerEnd; }
@@ -932,9 +933,9 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
   }
 }
 
-// this lane's part of phi'(alpha), phi''(alpha) from its rows along `s` from `a`; kMask: also the
-// lane's active-row mask AT a + alpha s (same bits as RowsPass)
-template <int KL, bool kMask, typename T, typename V, typename Cx, typename U>
+// this lane's part of phi'(alpha), phi''(alpha) from its rows along `s` from `a`, and the lane's active-row mask
+// AT a + alpha s (same bits as RowsPass)
+template <int KL, typename T, typename V, typename Cx, typename U>
 EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRows<V>& lim,
                      unsigned ends, const V* a, const V* s, V alpha, V* d1, V* d2, U& mask) {
   static_for<0, 3>([&](auto jc) {
@@ -945,7 +946,7 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
     const V w = Sel(x < V(0), lim.D[j], V(0));
     *d1 += w * x * jv;
     *d2 += w * jv * jv;
-    if constexpr (kMask) MaskSetNZ(mask, w, j);
+    MaskSetNZ(mask, w, j);
   });
   if constexpr (Grp<KL>::kPairs) {
     if ((ends >> kPairEndBit) != 0) {
@@ -963,15 +964,14 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
           const V cw = Sel(x < V(0), D, V(0));
           *d1 += cw * x * jv;
           *d2 += cw * jv * jv;
-          if constexpr (kMask) MaskSetNZ(mask, cw, kPairMaskBit + k);
+          MaskSetNZ(mask, cw, kPairMaskBit + k);
         }
       });
     }
   }
   // the scalar loop over the touching slots (plain: see RowsPass for the pipelined variant that was measured)
-  constexpr bool kBuildJs = kMask || Grp<KL>::kCachePerEnd < 4;  // J . s rebuilt here (else read from the cache)
   struct EndVals {
-    V D, an, ax, jna, jxa, u0, u1, mu;  // (u0, u1) = (cpx, cpz) if kBuildJs else (Jn.s, Jx.s)
+    V D, an, ax, jna, jxa, cpx, cpz, mu;
   };
   auto load = [&](int sl) {
     EndVals e;
@@ -980,45 +980,28 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
     e.ax = cx.Lds(sl * kSlotsPerEnd + 3);
     e.jna = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 0);  // RowsPass<true> at the same `a`
     e.jxa = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 1);
-    if constexpr (kBuildJs) {
-      e.u0 = cx.Lds(sl * kSlotsPerEnd + 0);
-      e.u1 = cx.Lds(sl * kSlotsPerEnd + 1);
-    } else {
-      e.u0 = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 2);
-      e.u1 = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 3);
-    }
+    e.cpx = cx.Lds(sl * kSlotsPerEnd + 0);
+    e.cpz = cx.Lds(sl * kSlotsPerEnd + 1);
     e.mu = cx.C(kTMu + Grp<KL>::SlotBody(sl));  // (the table also carries the torso's)
     return e;
   };
   auto visit = [&](const EndVals& e, int sl) {
-    V jns, jxs;
-    // first evaluation of this line search: J . s, kept for the others (without the (Jn.s, Jx.s) slots -- the
-    // Hopper -- rebuilt by every evaluation)
-    if constexpr (kBuildJs) {
-      const V cpx = e.u0, cpz = e.u1;
-      // s . (Jacobian columns of a point on local body b): torso dofs, then the hinges up to b
-      jns = s[1] - (cpx - p.px[0]) * s[2];
-      jxs = s[0] + (cpz - p.pz[0]) * s[2];
-      const int b = Grp<KL>::SlotBody(sl);  // wave uniform
-      if (b >= 1) {
-        jns -= (cpx - p.px[1]) * s[3];
-        jxs += (cpz - p.pz[1]) * s[3];
-      }
-      if (b >= 2) {
-        jns -= (cpx - p.px[2]) * s[4];
-        jxs += (cpz - p.pz[2]) * s[4];
-      }
-      if (b >= 3) {
-        jns -= (cpx - p.px[3]) * s[5];
-        jxs += (cpz - p.pz[3]) * s[5];
-      }
-      if constexpr (Grp<KL>::kCachePerEnd >= 4) {
-        cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 2) = jns;
-        cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 3) = jxs;
-      }
-    } else {
-      jns = e.u0;
-      jxs = e.u1;
+    const V cpx = e.cpx, cpz = e.cpz;
+    // s . (Jacobian columns of a point on local body b): torso dofs, then the hinges up to b
+    V jns = s[1] - (cpx - p.px[0]) * s[2];
+    V jxs = s[0] + (cpz - p.pz[0]) * s[2];
+    const int b = Grp<KL>::SlotBody(sl);  // wave uniform
+    if (b >= 1) {
+      jns -= (cpx - p.px[1]) * s[3];
+      jxs += (cpz - p.pz[1]) * s[3];
+    }
+    if (b >= 2) {
+      jns -= (cpx - p.px[2]) * s[4];
+      jxs += (cpz - p.pz[2]) * s[4];
+    }
+    if (b >= 3) {
+      jns -= (cpx - p.px[3]) * s[5];
+      jxs += (cpz - p.pz[3]) * s[5];
     }
     const V mu = e.mu, D = e.D, an = e.an, ax = e.ax, jna = e.jna, jxa = e.jxa;
     const V jar1 = jna - an, jv1 = jns;
@@ -1031,11 +1014,9 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
     const V c3 = Sel(x3 < V(0), D, V(0));
     *d1 += c1 * x1 * jv1 + c2 * x2 * jv2 + c3 * x3 * jv3;
     *d2 += c1 * jv1 * jv1 + c2 * jv2 * jv2 + c3 * jv3 * jv3;
-    if constexpr (kMask) {
-      MaskSetNZ(mask, c1, 3 + 3 * sl);
-      MaskSetNZ(mask, c2, 4 + 3 * sl);
-      MaskSetNZ(mask, c3, 5 + 3 * sl);
-    }
+    MaskSetNZ(mask, c1, 3 + 3 * sl);
+    MaskSetNZ(mask, c2, 4 + 3 * sl);
+    MaskSetNZ(mask, c3, 5 + 3 * sl);
   };
   EPA_NO_UNROLL
   for (unsigned rem = ends & 0xFFFFu; rem != 0; rem &= rem - 1) {
@@ -1164,6 +1145,9 @@ EPA_HD V DotEnv(const V* a, const V* b) {
   return t + SumLegs<KL>(l);
 }
 
+// Newton trip of a forward pass from which a wave searches its lines exactly again (plg::Solve)
+constexpr int kLsExactAfter = 8;
+
 template <typename T>
 struct SolverCfgLg {
   int max_iter;
@@ -1172,9 +1156,18 @@ struct SolverCfgLg {
 
 // mj_fwdConstraint: exact Newton on the primal objective
 //   1/2 (a-a0)^T M (a-a0) + sum_r 1/2 D_r min(0, J_r a - aref_r)^2
-// started from qacc (= qacc_warmstart).  Same iteration as mj_cheetah.hip.h::CheetahSolve: exact
-// piecewise-quadratic line search, finite termination (same active set after a full Newton step),
-// wave-uniform control flow.  Outputs qacc, Ma = M qacc and the final gradient
+// started from qacc (= qacc_warmstart).  The iteration of mj_cheetah.hip.h::CheetahSolve -- finite termination
+// (same active set after a full Newton step), wave-uniform control flow -- with a ONE-EVALUATION line search:
+// phi'(1) and phi''(1) are evaluated at the full step; if phi'(1) vanishes the full step is taken (and, with the
+// active set H was built with, it IS the minimiser), otherwise the step is 1 - phi'(1) / phi''(1), one Newton
+// step of the 1-D problem, taken unverified.  Rounds 1-4 ran the 1-D Newton iteration to |phi'| <= 1e-10 |phi'(0)|
+// (an exact search, 2.0 evaluations per trip of a wave = 36 % of its time): measured on 1.2 M forward passes of the
+// benchmark (tools/lg_desync_sim.py ls, profiles/r5k_*), an env takes exactly as many Newton trips either way (6.74
+// per env-step, histogram 1: 70.5 %, 2: 24.4 %, 3: 4.8 %, ...) -- whenever the full step misses, the active set
+// changes along the line and the env needs the next trip's Hessian anyway -- and it ends on the same minimiser
+// (finite termination decides, not the search).  MuJoCo's own Newton solver searches to a tolerance of 0.01.
+// Safety net: from trip kLsExactAfter on (no env of the benchmark ever gets there) a wave falls back to the exact
+// search, whose steps cannot increase the objective.  Outputs qacc, Ma = M qacc and the final gradient
 // (qfrc_constraint = Ma - qfrc_smooth - grad); returns the env's Newton iterations.
 // kLiveSlots: a trip visits only the slots of the envs that are still live (measured on the GPU: HalfCheetah +2.9 %;
 // Walker2d / Hopper -1.4 %: their kernels have no registers to spare for the per-lane slot set) -- see below.
@@ -1276,15 +1269,13 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
     B searching = live;
     B exact = LT::False();
     EPA_LG_TICK(cx, 3);
-    for (int ls = 0; ls < 24; ++ls) {
+    // one evaluation (at the full step) + one Newton step of the 1-D problem; the exact search only as the fallback
+    const int ls_max = it < kLsExactAfter ? EPA_LG_LS_MAX : 24;
+    for (int ls = 0; ls < ls_max; ++ls) {
       EPA_LG_COUNT(cx, 1);
       V d1p = V(0), d2p = V(0);
       U mask1 = LT::Fill(0u);
-      if (ls == 0) {
-        LineEval<KL, true>(m, cx, p, lim, ends_t, qacc, s, alpha, &d1p, &d2p, mask1);
-      } else {
-        LineEval<KL, false>(m, cx, p, lim, ends_t, qacc, s, alpha, &d1p, &d2p, mask1);
-      }
+      LineEval<KL>(m, cx, p, lim, ends_t, qacc, s, alpha, &d1p, &d2p, mask1);
       const V d1 = (g1 + alpha * g2) + SumEnv<KL>(d1p), d2 = g2 + SumEnv<KL>(d2p);
       const B hit = Abs(d1) <= ls_tol;
       // a full Newton step is exact for the active set H was built with: if the rows active at
@@ -1307,6 +1298,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
         EPA_LG_HOST_TRIP(ls + 1);
         break;
       }
+      if (ls + 1 == ls_max) EPA_LG_HOST_TRIP(ls + 1);
     }
     EPA_LG_TICK(cx, 4);
     const V step = Sel(live, alpha, V(0));

@@ -136,3 +136,29 @@ if len(sys.argv) > 1 and sys.argv[1] == "chunks":
 
 if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def ls_variants():
+    """the shipped schedule's cost per chunk under solver knobs compiled into the host rollout (-D flags)"""
+    src = os.path.join(ROOT, "tools", "lg_desync", "rollout_host.cpp")
+    # EPA_LG_LS_MAX: evaluations of a line search at most (24 = the exact search of rounds 1-4, 1 = the product since
+    # round 5); EPA_LG_LS_RTOL: |phi'| <= rtol |phi'(0)| ends a search
+    for flags in (["-DEPA_LG_LS_MAX=24"], ["-DEPA_LG_LS_MAX=3"], ["-DEPA_LG_LS_MAX=2"], ["-DEPA_LG_LS_MAX=1"],
+                  ["-DEPA_LG_LS_MAX=24", "-DEPA_LG_LS_RTOL=1e-6"], ["-DEPA_LG_LS_MAX=24", "-DEPA_LG_LS_RTOL=1e-3"]):
+        so = "/tmp/liblg_rollout_v%d.so" % abs(hash(tuple(flags)))  # (dlopen caches by path)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", so] + flags, check=True)
+        L = ctypes.CDLL(so)
+        envs, warm, steps = 2048, 150, 24
+        d = np.zeros((steps, envs, 5, 14), np.int16)
+        L.lg_rollout(envs, warm, steps, 1, d.ctypes.data_as(ctypes.c_void_p))
+        del L
+        c = np.mean([cost_sync(d[t, 32 * w:32 * w + 32]) for t in range(steps) for w in range(envs // 32)])
+        wt = np.mean([sum(d[t, 32 * w:32 * w + 32, s, 1].max() for s in range(5)) for t in range(steps) for w in range(envs // 32)])
+        we = np.mean([sum(d[t, 32 * w:32 * w + 32, s, 2 + k].max() for s in range(5) for k in range(12))
+                      for t in range(steps) for w in range(envs // 32)])
+        print("%-44s per env: trips %.2f evals %.2f | wave: trips %.2f evals %.2f | model cycles per chunk %.0f" % (
+            " ".join(flags), d[..., 1].sum(-1).mean(), d[..., 2:].sum((-1, -2)).mean(), wt, we, c), flush=True)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "ls":
+    ls_variants()
