@@ -1,18 +1,20 @@
-"""Copies what the round-4 measurement pass (tools/gpu_runs/gpu_r4z.sh) left under gpurun_out/ into profiles/
+"""Copies what a measurement pass (tools/gpu_runs/gpu_r<N>z.sh; tag r4z, r5z, ...) left under gpurun_out/ into profiles/
 (summaries, kernel stats, bench lines, logs) and prints the numbers DESIGN.md section 5 quotes:
 per kernel the rocprof average duration, issued flops per env-step and fraction, algorithmic flops and useful
-fraction, HBM traffic vs algorithmic bytes.  Run after `python tools/make_pmc_json.py r4z <num_envs>` for every size.
+fraction, HBM traffic vs algorithmic bytes.  Run after `python tools/make_pmc_json.py <tag> <num_envs>` for every size.
 
-    python tools/collect_r4z.py            # copy + print
+    python tools/collect_pass.py r5z       # copy + print
 """
 import glob
 import json
 import os
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r5z"
 
 
 def copy(src, dst):
@@ -21,15 +23,15 @@ def copy(src, dst):
 
 
 def main():
-    for d in sorted(glob.glob(os.path.join(G, "prof_r4z_*"))):
+    for d in sorted(glob.glob(os.path.join(G, f"prof_{TAG}_*"))):
         tag = os.path.basename(d)[len("prof_"):]
         copy(os.path.join(d, "summary.md"), f"{tag}_summary.md")
         copy(os.path.join(d, "trace", "t_kernel_stats.csv"), f"{tag}_kernel_stats.csv")
-    copy(os.path.join(G, "r4z", "bench_default.json"), "r4z_bench_default.json")
-    copy(os.path.join(G, "r4z", "bench.jsonl"), "r4z_bench.jsonl")
-    copy(os.path.join(G, "r4z", "numpy_api.jsonl"), "r4z_numpy_api.jsonl")
-    copy(os.path.join(G, "r4z", "gpu_tests.log"), "r4z_gpu_tests.log")
-    copy(os.path.join(G, "r4z", "probe_gpu_box.log"), "r4z_probe_gpu_box.log")
+    copy(os.path.join(G, TAG, "bench_default.json"), f"{TAG}_bench_default.json")
+    copy(os.path.join(G, TAG, "bench.jsonl"), f"{TAG}_bench.jsonl")
+    copy(os.path.join(G, TAG, "numpy_api.jsonl"), f"{TAG}_numpy_api.jsonl")
+    copy(os.path.join(G, TAG, "gpu_tests.log"), f"{TAG}_gpu_tests.log")
+    copy(os.path.join(G, TAG, "probe_gpu_box.log"), f"{TAG}_probe_gpu_box.log")
     pmc = json.load(open(os.path.join(P, "pmc.json")))
     alg = json.load(open(os.path.join(P, "flops_algorithmic.json")))
     alg_bytes = {"HalfCheetah": 708, "Ant": 1132, "Walker2d": 692, "Hopper": 476, "Humanoid": 4402,
@@ -42,8 +44,8 @@ def main():
             ("Humanoid4StepKernel<double>@65536", "Humanoid"), ("Humanoid4StepKernel<double>[Standup]@65536", "HumanoidStandup")]
     for key, task in rows:
         e = pmc.get(key)
-        if not e or "r4z" not in e.get("source", ""):
-            print(f"{key}: no round-4 entry")
+        if not e or TAG not in e.get("source", ""):
+            print(f"{key}: no {TAG} entry")
             continue
         n, us = e["num_envs"], e["rocprof_avg_us"]
         peak = 157.3e12 if "<float>" in key else 78.6e12
@@ -54,7 +56,7 @@ def main():
               f"{a * n / t / peak:.3f} | issued/alg {iss / a:.2f} | traffic {e['traffic_bytes_per_launch'] / 1e6:.1f} MB / "
               f"{alg_bytes[task] * n / 1e6:.1f} MB = {e['traffic_bytes_per_launch'] / (alg_bytes[task] * n):.2f}x | "
               f"wait {e['wait_frac_of_wave_cycles']:.2f} | env-steps/s at the rocprof duration {n / t:.3g}")
-    for f in ("r4z_bench_default.json", "r4z_bench.jsonl"):
+    for f in (f"{TAG}_bench_default.json", f"{TAG}_bench.jsonl"):
         path = os.path.join(P, f)
         if not os.path.exists(path):
             continue
