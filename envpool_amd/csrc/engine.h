@@ -99,6 +99,9 @@ struct Batch {
   int consumed{0};                // rows already handed to recv (async mode)
   std::vector<size_t> offsets;    // byte offset of each key's section
   hipEvent_t done{nullptr};
+  // single-stream pools record `done` only when somebody needs it (Pool::EnsureDone): an event record behind
+  // every launch keeps consecutive step kernels further apart than the launch path alone
+  bool done_recorded{false};
   hipStream_t stream{nullptr};    // the compute stream its kernel was launched on ...
   int stream_idx{0};              // ... and always will be: blocks are recycled per stream
   // async mode with several compute streams: the local env of every row (host-path sends / resets;
@@ -205,6 +208,7 @@ class Pool {
   void Enqueue(const int* d_ids, int k, const void* d_action, bool force);
   // chooses stream_ for the next launch and orders it behind what it may depend on
   void PickStream(const int32_t* host_ids, int k, bool device_path, const void* d_env_id = nullptr);
+  void EnsureDone(Batch* b);  // records b->done on the batch's stream if nobody has yet
   void JoinCompute(hipStream_t into);  // `into` waits for everything enqueued on every compute stream
   void SyncCompute();                  // host waits for every compute stream
   void MarkIdle(Batch* b, int first, int count);
