@@ -43,8 +43,9 @@
 
 // Stage timers of the diagnostic build (-DEPA_LG_TIMERS, tools/build_alt_lg.sh; never in the product
 // library): EPA_LG_TICK(cx, K) books the cycles since the previous tick to category K of the wave
-// (0 load / store / integrate, 1 kinematics + smooth forces + constraint rows, 2 pass over the rows +
-// group sums + stop tests, 3 factor / solve / products with M, 4 line search), EPA_LG_COUNT(cx, K)
+// (0 load / store / loop overhead (RK4: + the stage updates), 1 kinematics + smooth forces + constraint rows, 2 pass
+// over the rows + group sums + stop tests, 3 factor / solve / products with M, 4 line search, 5 the Euler integration
+// with implicit damping), EPA_LG_COUNT(cx, K)
 // counts wave-level loop trips (0 Newton trips, 1 line-search evaluations, 2 forward passes).
 #if defined(EPA_LG_TIMERS) && defined(__HIP_DEVICE_COMPILE__)
 #define EPA_LG_TICK(cx, K) (cx).template TickEnd<K>()
@@ -1387,6 +1388,7 @@ EPA_HD V StepEuler(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, 
     v[i] += V(m.timestep) * rhs[i];
     q[i] += V(m.timestep) * v[i];
   });
+  EPA_LG_TICK(cx, 5);
   return iters;
 }
 

@@ -43,7 +43,7 @@ struct DevCx {
   __device__ __forceinline__ void Refresh() { asm volatile("" : "+v"(tab)); }
 #ifdef EPA_LG_TIMERS  // diagnostic build only (mj_planar_lg.hip.h: EPA_LG_TICK)
   long long t_last{0};
-  long long acc[5]{0, 0, 0, 0, 0};
+  long long acc[6]{0, 0, 0, 0, 0, 0};
   unsigned cnt[3]{0, 0, 0};
   template <int K>
   __device__ __forceinline__ void TickEnd() {
@@ -56,7 +56,8 @@ struct DevCx {
 #endif
 };
 #ifdef EPA_LG_TIMERS
-// [0..4] cycles per category, [5..7] trip counters, [8] chunks, [9] cycles of whole chunks
+// [0..4] cycles per category, [5..7] trip counters, [8] chunks, [9] cycles of whole chunks, [10] category 5
+// (the integration of an mj_step: what follows the forward pass)
 __device__ unsigned long long g_lg_timers[16];
 #endif
 #ifdef EPA_LG_SCHED_TRACE
@@ -238,6 +239,7 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
     cx.template TickEnd<0>();
     if (__builtin_amdgcn_readfirstlane(lane) == lane) {  // the wave's first active lane
       for (int i = 0; i < 5; ++i) atomicAdd(&g_lg_timers[i], (unsigned long long)cx.acc[i]);
+      atomicAdd(&g_lg_timers[10], (unsigned long long)cx.acc[5]);
       for (int i = 0; i < 3; ++i) atomicAdd(&g_lg_timers[5 + i], (unsigned long long)cx.cnt[i]);
       atomicAdd(&g_lg_timers[8], 1ull);
       atomicAdd(&g_lg_timers[9], (unsigned long long)(clock64() - t_chunk0));

@@ -1,7 +1,7 @@
 """Where a wave of the lane-group planar kernel spends its cycles (diagnostic build -DEPA_LG_TIMERS:
 tools/build_alt_lg.sh lgtimers ... -DEPA_LG_TIMERS, copied over libenvpool_amd.so on the GPU box).
 
-    python tools/lg_stage_timers.py [task] [num_envs] [steps]
+    python tools/lg_stage_timers.py [task] [num_envs] [steps] [planar_layout]
 """
 import ctypes
 import os
@@ -15,8 +15,9 @@ import torch
 from envpool_amd.core import native
 from envpool_amd.core.device_pool import DevicePool
 
-CATS = ["load / store / integrate", "kinematics + smooth forces + constraint rows",
-        "row pass + group sums + stop tests", "factor / solve / M products", "line search"]
+CATS = ["load / store / loop overhead (RK4: + stage updates)", "kinematics + smooth forces + constraint rows",
+        "row pass + group sums + stop tests", "factor / solve / M products", "line search",
+        "Euler integration (implicit damping)"]
 
 
 def main():
@@ -26,7 +27,10 @@ def main():
     lib = native.lib()
     f = lib.epa_debug_lg_timers
     f.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    pool = DevicePool(task, n, seed=0, max_episode_steps=1000, params={"precision": 1})
+    params = {"precision": 1}
+    if len(sys.argv) > 4:
+        params["planar_layout"] = int(sys.argv[4])
+    pool = DevicePool(task, n, seed=0, max_episode_steps=1000, params=params)
     adim = int(np.prod(pool.action_shape))
     ring = [torch.rand((n, adim), device="cuda", dtype=torch.float64) * 2 - 1 for _ in range(8)]
     pool.send_device(None)
@@ -42,10 +46,10 @@ def main():
         pool.recv_device()
     pool.synchronize()
     assert f(out.ctypes.data, 1) == 0
-    cyc = out[:5].astype(np.float64)
+    cyc = np.concatenate([out[:5], out[10:11]]).astype(np.float64)
     chunks = float(out[8])
     tot = cyc.sum()
-    print(f"{task} N={n}: {steps} launches, {chunks / steps:.0f} chunks per launch, "
+    print(f"{task} N={n} {params}: {steps} launches, {chunks / steps:.0f} chunks per launch, "
           f"{float(out[9]) / chunks:.0f} cycles per chunk (100 MHz s_memtime ticks x core ratio: relative only)")
     for name, c in zip(CATS, cyc):
         print(f"  {name:48s} {100 * c / tot:5.1f} %   {c / chunks:9.0f} ticks / chunk")
