@@ -745,6 +745,14 @@ EPA_HD unsigned MakeConstraint(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p
       const V h2x = V(0.5) * (ax2 - bx2), h2z = V(0.5) * (az2 - bz2);
       const V dfx = c1x - c2x, dfz = c1z - c2z;
       const V ma = h1x * h1x + h1z * h1z, mb = -(h1x * h2x + h1z * h2z), mc = h2x * h2x + h2z * h2z;
+      const V r1 = cx.C(Tab<KL>::kEr + s1), r2 = cx.C(Tab<KL>::kEr + s2);
+      // Broad phase (round 5; the three narrow phases were a third of the Hopper's set-up): two points of the
+      // segments are at least |c1 - c2| - |h1| - |h2| apart, the pair touches only below rr = r1 + r2 + margin, and
+      // (|h1| + |h2| + rr)^2 <= 3 (|h1|^2 + |h2|^2 + rr^2): beyond that no lane can touch, the pair's bit of `ends`
+      // stays clear and its LDS slots are never read -- what the narrow phase would have found, without running it.
+      const V rr = r1 + r2 + V(m.con_margin);
+      const auto near = dfx * dfx + dfz * dfz <= V(3) * (ma + mc + rr * rr);
+      if (!AnyWave(near)) return;
       const V u = -(h1x * dfx + h1z * dfz), w = h2x * dfx + h2z * dfz;
       const V det = ma * mc - mb * mb;
       auto clamp1 = [](V x) { return Sel(x > V(1), V(1), Sel(x < V(-1), V(-1), x)); };
@@ -775,7 +783,6 @@ EPA_HD unsigned MakeConstraint(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p
       const V p2x = c2x + h2x * x2, p2z = c2z + h2z * x2;
       const V ddx = p2x - p1x, ddz = p2z - p1z;
       const V cd = SqrtV(ddx * ddx + ddz * ddz);
-      const V r1 = cx.C(Tab<KL>::kEr + s1), r2 = cx.C(Tab<KL>::kEr + s2);
       const V dist = cd - r1 - r2;
       const auto touch = dist < V(m.con_margin);
       V nx = V(1), nz = V(0), ccx = V(0), ccz = V(0), aref = V(0), D = V(0);
