@@ -311,12 +311,45 @@ inline LB<K> MaskSame(const LU<K>& a, const LU<K>& b) {
   for (int i = 0; i < K; ++i) r.v[i] = a.v[i] == b.v[i];
   return r;
 }
-// slots (bits of `ends`) that touch on some lane whose env is still live: what a Newton trip has to visit
+// ---- per-lane slot sets (round 5: a lane visits ITS OWN touching slots, not the wave's union) -------------------
+// the lane's set of end-sphere slots to visit: `own` where `on`, else empty
 template <int K>
-inline unsigned LiveSlots(const LU<K>& own, LB<K> live, unsigned ends) {
-  unsigned r = 0;
-  for (int i = 0; i < K; ++i) r |= live.v[i] ? own.v[i] : 0u;
-  return r & ends;
+inline LU<K> SlotsWhere(const LU<K>& own, LB<K> on) {
+  LU<K> r;
+  for (int i = 0; i < K; ++i) r.v[i] = on.v[i] ? (own.v[i] & 0xFFFFu) : 0u;
+  return r;
+}
+template <int K>
+inline LB<K> AnySlot(const LU<K>& rem) {
+  LB<K> r;
+  for (int i = 0; i < K; ++i) r.v[i] = rem.v[i] != 0u;
+  return r;
+}
+// takes the lowest slot out of the lane's set (slot 0 where the set is empty: the caller masks it with AnySlot)
+template <int K>
+inline LU<K> PopSlot(LU<K>& rem) {
+  LU<K> r;
+  for (int i = 0; i < K; ++i) {
+    r.v[i] = rem.v[i] ? (unsigned)__builtin_ctz(rem.v[i]) : 0u;
+    rem.v[i] &= rem.v[i] - 1u;
+  }
+  return r;
+}
+template <int KL, int K>
+inline LU<K> SlotBodyOf(const LU<K>& s) {
+  LU<K> r;
+  for (int i = 0; i < K; ++i) r.v[i] = KL == 4 ? s.v[i] : s.v[i] >> 1;
+  return r;
+}
+template <int K>
+inline LB<K> AtLeast(const LU<K>& a, unsigned b) {
+  LB<K> r;
+  for (int i = 0; i < K; ++i) r.v[i] = a.v[i] >= b;
+  return r;
+}
+template <typename T, int K>
+inline void MaskSetNZAt(LU<K>& m, const LV<T, K>& w, const LU<K>& slot, int base) {  // bit base + 3 slot where w != 0
+  for (int i = 0; i < K; ++i) m.v[i] |= (w.v[i] != T(0) ? 1u : 0u) << (base + 3 * (int)slot.v[i]);
 }
 template <typename V>
 struct LaneTypes;
@@ -340,16 +373,22 @@ EPA_HD float Rsq(float x) { return Rsqrt(x); }
 EPA_HD bool AnyWave(bool c) { return WaveAny(c); }
 EPA_HD void MaskSet(unsigned& m, bool on, int bit) { m |= (on ? 1u : 0u) << bit; }
 EPA_HD bool MaskSame(unsigned a, unsigned b) { return a == b; }
-EPA_HD unsigned LiveSlots(unsigned own, bool live, unsigned ends) {
+EPA_HD unsigned SlotsWhere(unsigned own, bool on) { return on ? (own & 0xFFFFu) : 0u; }
+EPA_HD bool AnySlot(unsigned rem) { return rem != 0u; }
+EPA_HD unsigned PopSlot(unsigned& rem) {
+  const unsigned s = rem ? (unsigned)__builtin_ctz(rem) : 0u;
+  rem &= rem - 1u;
+  return s;
+}
+template <int KL>
+EPA_HD unsigned SlotBodyOf(unsigned s) { return KL == 4 ? s : s >> 1; }
+EPA_HD bool AtLeast(unsigned a, unsigned b) { return a >= b; }
+EPA_HD void MaskSetNZAt(unsigned& m, double w, unsigned slot, int base) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  unsigned r = 0;
-  for (unsigned rem = ends; rem != 0; rem &= rem - 1) {  // a handful of bits: one ballot each
-    const int b = __builtin_ctz(rem);
-    if (__builtin_amdgcn_ballot_w64(live && ((own >> b) & 1u)) != 0) r |= 1u << b;
-  }
-  return r;
+  const unsigned hi = (unsigned)__double2hiint(w);  // see MaskSetNZ
+  m |= (hi < 1u ? hi : 1u) << (base + 3 * slot);
 #else
-  return live ? (own & ends) : 0u;
+  m |= (w != 0.0 ? 1u : 0u) << (base + 3 * slot);
 #endif
 }
 // bit set where w != 0, for a weight that is either +0.0 or a positive normal number: its high word is
@@ -630,15 +669,6 @@ EPA_HD void ForChainCols(const Pos<V>& p, V cpx, V cpz, F&& f) {
     }
   });
 }
-template <typename F>
-EPA_HD void DispatchLocalBody(int b, F&& f) {  // wave-uniform switch
-  switch (b) {
-    case 0: f(IC<0>{}); break;
-    case 1: f(IC<1>{}); break;
-    case 2: f(IC<2>{}); break;
-    default: f(IC<3>{}); break;
-  }
-}
 // friction coefficient of the floor pair of local body B
 template <int B, typename T, typename V, typename Cx>
 EPA_HD V MuOf(const CheetahModel<T>& m, const Cx& cx) {
@@ -837,9 +867,11 @@ EPA_HD void ForPairCols(const Pos<V>& p, Cx& cx, F&& f) {
 // One pass over the lane's constraint rows at acceleration `a`: accumulates THIS LANE's part of
 // J^T f into gc (6) and, if kHess, of J^T D_active J into Hc (21); the lane's active-row mask in
 // `mask`.  The caller sums the torso entries over the group.
+// `vis`: the lane's set of end-sphere slots to visit (its own touching slots, or none if its env has finished);
+// `ends`: the wave-uniform set MakeConstraint returned (only its body-pair bits are used here).
 template <int KL, bool kHess, typename T, typename V, typename Cx, typename U>
 EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRows<V>& lim,
-                     unsigned ends, const V* a, V* gc, V* Hc, U& mask) {
+                     unsigned ends, const U& vis, const V* a, V* gc, V* Hc, U& mask) {
   static_for<0, 3>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const V jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
@@ -875,69 +907,68 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
       });
     }
   }
-  // scalar loop over the touching slots (reading the NEXT slot's numbers while this one is used -- a software
-  // pipeline by one slot -- measured -0.4 % on HalfCheetah / Walker2d / Hopper, profiles/r4f_prefetch_ab.txt:
-  // the LDS round trip is not what the wave waits for)
-  struct EndVals {
-    V cpx, cpz, an, ax, D, mu;
-  };
-  auto load = [&](int s) {
-    EndVals e;
-    e.cpx = cx.Lds(s * kSlotsPerEnd + 0);
-    e.cpz = cx.Lds(s * kSlotsPerEnd + 1);
-    e.an = cx.Lds(s * kSlotsPerEnd + 2);
-    e.ax = cx.Lds(s * kSlotsPerEnd + 3);
-    e.D = cx.Lds(s * kSlotsPerEnd + 4);
-    e.mu = cx.C(kTMu + Grp<KL>::SlotBody(s));  // (== MuOf<b>: the table also carries the torso's)
-    return e;
-  };
-  auto visit = [&](const EndVals& e, int s) {
-    DispatchLocalBody(Grp<KL>::SlotBody(s), [&](auto bc) {
-      constexpr int b = decltype(bc)::value;
-      const V cpx = e.cpx, cpz = e.cpz, an = e.an, ax = e.ax, D = e.D, mu = e.mu;
-      V jna = V(0), jxa = V(0);
-      ForChainCols<b>(p, cpx, cpz, [&](auto jc, V jn, V jx) {
-        constexpr int j = decltype(jc)::value;
-        jna += jn * a[j];
-        jxa += jx * a[j];
-      });
-      if constexpr (kHess) {  // the per-iteration pass: kept for the line search
-        cx.Lds(CacheBase<KL>() + s * Grp<KL>::kCachePerEnd + 0) = jna;
-        cx.Lds(CacheBase<KL>() + s * Grp<KL>::kCachePerEnd + 1) = jxa;
-      }
-      // rows: 2 x (Jn), (Jn - mu Jx), (Jn + mu Jx); D == 0 for lanes not in contact, which
-      // zeroes every weight below
-      const V jar1 = jna - an;
-      const V jar2 = jna - mu * jxa - (an + ax);
-      const V jar3 = jna + mu * jxa - (an - ax);
-      const V w1 = Sel(jar1 < V(0), V(2) * D, V(0));
-      const V w2 = Sel(jar2 < V(0), D, V(0));
-      const V w3 = Sel(jar3 < V(0), D, V(0));
-      MaskSetNZ(mask, w1, 3 + 3 * s);
-      MaskSetNZ(mask, w2, 4 + 3 * s);
-      MaskSetNZ(mask, w3, 5 + 3 * s);
-      const V gn = w1 * jar1 + w2 * jar2 + w3 * jar3;  // coefficient of Jn
-      const V gx = mu * (w3 * jar3 - w2 * jar2);      // coefficient of Jx
-      const V A = w1 + w2 + w3, Bc = mu * (w3 - w2), C = mu * mu * (w2 + w3);
-      if (AnyWave(A > V(0))) {
-        ForChainCols<b>(p, cpx, cpz, [&](auto ic, V jni, V jxi) {
-          constexpr int i = decltype(ic)::value;
-          gc[i] += jni * gn + jxi * gx;
-          if constexpr (kHess) {
-            const V ui = A * jni + Bc * jxi, wi = Bc * jni + C * jxi;
-            ForChainCols<b>(p, cpx, cpz, [&](auto kc, V jnk, V jxk) {
-              constexpr int k = decltype(kc)::value;
-              if constexpr (k >= i) Hc[Tri(i, k)] += ui * jnk + wi * jxk;
-            });
-          }
-        });
-      }
+  // The lane's OWN touching slots, one per trip of the loop (round 5; rounds 3-4 looped over the wave-uniform UNION of
+  // the touching slots with a body-specialised visit: 2.5 visits per pass where the busiest lane has 1.6 slots --
+  // tools/lg_desync_sim.py).  What differs between lanes -- the slot, its body and so the depth of the chain -- is
+  // data: LDS / table reads at per-lane addresses, the columns of hinges beyond the slot's body are selected to zero
+  // (exact zeros: the sums they enter are unchanged), a lane whose set has run out visits with weight D = 0.
+  // (A software pipeline by one slot measured -0.4 % in round 4, profiles/r4f_prefetch_ab.txt.)
+  U rem = vis;
+  while (AnyWave(AnySlot(rem))) {
+    const auto has = AnySlot(rem);
+    const U sl = PopSlot(rem);
+    const U body = SlotBodyOf<KL>(sl);
+    const V cpx = cx.LdsL(sl, kSlotsPerEnd, 0), cpz = cx.LdsL(sl, kSlotsPerEnd, 1);
+    const V an = cx.LdsL(sl, kSlotsPerEnd, 2), ax = cx.LdsL(sl, kSlotsPerEnd, 3);
+    const V D = Sel(has, cx.LdsL(sl, kSlotsPerEnd, 4), V(0));
+    const V mu = cx.CL(kTMu, body);  // (the table also carries the torso's)
+    // Jacobian columns of the contact point: dofs 0, 1 (slides), 2 (torso hinge), then the leg's hinges up to the body
+    V jn[kLV], jx[kLV];
+    jn[0] = V(0), jx[0] = V(1);
+    jn[1] = V(1), jx[1] = V(0);
+    jn[2] = -(cpx - p.px[0]), jx[2] = cpz - p.pz[0];
+    static_for<3, kLV>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const auto in = AtLeast(body, (unsigned)(j - 2));
+      jn[j] = Sel(in, -(cpx - p.px[j - 2]), V(0));
+      jx[j] = Sel(in, cpz - p.pz[j - 2], V(0));
     });
-  };
-  EPA_NO_UNROLL
-  for (unsigned rem = ends & 0xFFFFu; rem != 0; rem &= rem - 1) {
-    const int s = __builtin_ctz(rem);
-    visit(load(s), s);
+    V jna = V(0), jxa = V(0);
+    static_for<0, kLV>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      jna += jn[j] * a[j];
+      jxa += jx[j] * a[j];
+    });
+    if constexpr (kHess) {  // the per-iteration pass: kept for the line search
+      cx.LdsLStore(sl, Grp<KL>::kCachePerEnd, CacheBase<KL>() + 0, jna, has);
+      cx.LdsLStore(sl, Grp<KL>::kCachePerEnd, CacheBase<KL>() + 1, jxa, has);
+    }
+    // rows: 2 x (Jn), (Jn - mu Jx), (Jn + mu Jx); D == 0 for lanes not in contact, which zeroes every weight below
+    const V jar1 = jna - an;
+    const V jar2 = jna - mu * jxa - (an + ax);
+    const V jar3 = jna + mu * jxa - (an - ax);
+    const V w1 = Sel(jar1 < V(0), V(2) * D, V(0));
+    const V w2 = Sel(jar2 < V(0), D, V(0));
+    const V w3 = Sel(jar3 < V(0), D, V(0));
+    MaskSetNZAt(mask, w1, sl, 3);
+    MaskSetNZAt(mask, w2, sl, 4);
+    MaskSetNZAt(mask, w3, sl, 5);
+    const V gn = w1 * jar1 + w2 * jar2 + w3 * jar3;  // coefficient of Jn
+    const V gx = mu * (w3 * jar3 - w2 * jar2);      // coefficient of Jx
+    const V A = w1 + w2 + w3, Bc = mu * (w3 - w2), C = mu * mu * (w2 + w3);
+    if (AnyWave(A > V(0))) {
+      static_for<0, kLV>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        gc[i] += jn[i] * gn + jx[i] * gx;
+        if constexpr (kHess) {
+          const V ui = A * jn[i] + Bc * jx[i], wi = Bc * jn[i] + C * jx[i];
+          static_for<i, kLV>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            Hc[Tri(i, k)] += ui * jn[k] + wi * jx[k];
+          });
+        }
+      });
+    }
   }
 }
 
@@ -945,7 +976,7 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
 // AT a + alpha s (same bits as RowsPass)
 template <int KL, typename T, typename V, typename Cx, typename U>
 EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRows<V>& lim,
-                     unsigned ends, const V* a, const V* s, V alpha, V* d1, V* d2, U& mask) {
+                     unsigned ends, const U& vis, const V* a, const V* s, V alpha, V* d1, V* d2, U& mask) {
   static_for<0, 3>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const V jar = lim.sgn[j] * a[j + 3] - lim.aref[j];
@@ -977,41 +1008,29 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
       });
     }
   }
-  // the scalar loop over the touching slots (plain: see RowsPass for the pipelined variant that was measured)
-  struct EndVals {
-    V D, an, ax, jna, jxa, cpx, cpz, mu;
-  };
-  auto load = [&](int sl) {
-    EndVals e;
-    e.D = cx.Lds(sl * kSlotsPerEnd + 4);
-    e.an = cx.Lds(sl * kSlotsPerEnd + 2);
-    e.ax = cx.Lds(sl * kSlotsPerEnd + 3);
-    e.jna = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 0);  // RowsPass<true> at the same `a`
-    e.jxa = cx.Lds(CacheBase<KL>() + sl * Grp<KL>::kCachePerEnd + 1);
-    e.cpx = cx.Lds(sl * kSlotsPerEnd + 0);
-    e.cpz = cx.Lds(sl * kSlotsPerEnd + 1);
-    e.mu = cx.C(kTMu + Grp<KL>::SlotBody(sl));  // (the table also carries the torso's)
-    return e;
-  };
-  auto visit = [&](const EndVals& e, int sl) {
-    const V cpx = e.cpx, cpz = e.cpz;
-    // s . (Jacobian columns of a point on local body b): torso dofs, then the hinges up to b
+  // the lane's own touching slots, as in RowsPass
+  U rem = vis;
+  while (AnyWave(AnySlot(rem))) {
+    const auto has = AnySlot(rem);
+    const U sl = PopSlot(rem);
+    const U body = SlotBodyOf<KL>(sl);
+    const V cpx = cx.LdsL(sl, kSlotsPerEnd, 0), cpz = cx.LdsL(sl, kSlotsPerEnd, 1);
+    const V an = cx.LdsL(sl, kSlotsPerEnd, 2), ax = cx.LdsL(sl, kSlotsPerEnd, 3);
+    const V D = Sel(has, cx.LdsL(sl, kSlotsPerEnd, 4), V(0));
+    // (RowsPass<true> at the same `a` left them for the slots it visited: a lane whose set has run out reads
+    // slot 0's, which may never have been written -- 0 x NaN would poison the sums)
+    const V jna = Sel(has, cx.LdsL(sl, Grp<KL>::kCachePerEnd, CacheBase<KL>() + 0), V(0));
+    const V jxa = Sel(has, cx.LdsL(sl, Grp<KL>::kCachePerEnd, CacheBase<KL>() + 1), V(0));
+    const V mu = cx.CL(kTMu, body);
+    // s . (Jacobian columns of a point on the slot's body): torso dofs, then the hinges up to the body
     V jns = s[1] - (cpx - p.px[0]) * s[2];
     V jxs = s[0] + (cpz - p.pz[0]) * s[2];
-    const int b = Grp<KL>::SlotBody(sl);  // wave uniform
-    if (b >= 1) {
-      jns -= (cpx - p.px[1]) * s[3];
-      jxs += (cpz - p.pz[1]) * s[3];
-    }
-    if (b >= 2) {
-      jns -= (cpx - p.px[2]) * s[4];
-      jxs += (cpz - p.pz[2]) * s[4];
-    }
-    if (b >= 3) {
-      jns -= (cpx - p.px[3]) * s[5];
-      jxs += (cpz - p.pz[3]) * s[5];
-    }
-    const V mu = e.mu, D = e.D, an = e.an, ax = e.ax, jna = e.jna, jxa = e.jxa;
+    static_for<3, kLV>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const auto in = AtLeast(body, (unsigned)(j - 2));
+      jns -= Sel(in, cpx - p.px[j - 2], V(0)) * s[j];
+      jxs += Sel(in, cpz - p.pz[j - 2], V(0)) * s[j];
+    });
     const V jar1 = jna - an, jv1 = jns;
     const V jar2 = jna - mu * jxa - (an + ax), jv2 = jns - mu * jxs;
     const V jar3 = jna + mu * jxa - (an - ax), jv3 = jns + mu * jxs;
@@ -1022,14 +1041,9 @@ EPA_HD void LineEval(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
     const V c3 = Sel(x3 < V(0), D, V(0));
     *d1 += c1 * x1 * jv1 + c2 * x2 * jv2 + c3 * x3 * jv3;
     *d2 += c1 * jv1 * jv1 + c2 * jv2 * jv2 + c3 * jv3 * jv3;
-    MaskSetNZ(mask, c1, 3 + 3 * sl);
-    MaskSetNZ(mask, c2, 4 + 3 * sl);
-    MaskSetNZ(mask, c3, 5 + 3 * sl);
-  };
-  EPA_NO_UNROLL
-  for (unsigned rem = ends & 0xFFFFu; rem != 0; rem &= rem - 1) {
-    const int sl = __builtin_ctz(rem);
-    visit(load(sl), sl);
+    MaskSetNZAt(mask, c1, sl, 3);
+    MaskSetNZAt(mask, c2, sl, 4);
+    MaskSetNZAt(mask, c3, sl, 5);
   }
 }
 
@@ -1210,12 +1224,12 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
   B at_min = LT::False();  // the env stopped at an exact minimiser (finite termination in the line search)
   V iter = V(0);
   for (int it = 0; it < cfg.max_iter; ++it) {
-    // A trip visits the slots that touch on some env that is still LIVE (a wave-uniform subset of `ends`: after
-    // the first trip of a forward pass a third of the envs are left, after the second one in twenty --
-    // tools/lg_solver_stats.py): the envs that have finished keep the gradient of the trip they finished in
+    // A lane visits its own touching slots while its env is still LIVE (after the first trip of a forward pass a
+    // third of the envs are left, after the second one in twenty): the envs that have finished keep the gradient of
+    // the trip they finished in
     // (their qacc and Ma are frozen, so it is the gradient at their result); H, the masks and the line-search
     // sums are only ever used for live envs.
-    const unsigned ends_t = (!kLiveSlots || it == 0) ? ends : LiveSlots(own, live, ends);
+    const U vis = SlotsWhere(own, (!kLiveSlots || it == 0) ? LT::True() : live);
     const B live0 = live;
     V H[kLTri], gc[kLV];
     static_for<0, kLTri>([&](auto kc) { H[decltype(kc)::value] = V(0); });
@@ -1223,7 +1237,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
     U mask = LT::Fill(0u);
     EPA_LG_TICK(cx, 3);
     EPA_LG_HOST_ROWS();
-    RowsPass<KL, true>(m, cx, p, lim, ends_t, qacc, gc, H, mask);
+    RowsPass<KL, true>(m, cx, p, lim, ends, vis, qacc, gc, H, mask);
     // group sums: the torso entries collect every lane of the env, the leg entries the leg's lanes
     static_for<0, kLV>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
@@ -1283,7 +1297,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
       EPA_LG_COUNT(cx, 1);
       V d1p = V(0), d2p = V(0);
       U mask1 = LT::Fill(0u);
-      LineEval<KL>(m, cx, p, lim, ends_t, qacc, s, alpha, &d1p, &d2p, mask1);
+      LineEval<KL>(m, cx, p, lim, ends, vis, qacc, s, alpha, &d1p, &d2p, mask1);
       const V d1 = (g1 + alpha * g2) + SumEnv<KL>(d1p), d2 = g2 + SumEnv<KL>(d2p);
       const B hit = Abs(d1) <= ls_tol;
       // a full Newton step is exact for the active set H was built with: if the rows active at
@@ -1335,7 +1349,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
     V gc[kLV];
     static_for<0, kLV>([&](auto ic) { gc[decltype(ic)::value] = V(0); });
     U mask = LT::Fill(0u);
-    RowsPass<KL, false>(m, cx, p, lim, ends, qacc, gc, static_cast<V*>(nullptr), mask);
+    RowsPass<KL, false>(m, cx, p, lim, ends, SlotsWhere(own, LT::True()), qacc, gc, static_cast<V*>(nullptr), mask);
     static_for<0, kLV>([&](auto jc) {  // only for the envs that did hit the cap
       constexpr int j = decltype(jc)::value;
       V g;

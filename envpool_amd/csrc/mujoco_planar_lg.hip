@@ -36,6 +36,12 @@ struct DevCx {
   double* lds;        // the wave's LDS block at this lane: lds[slot * 64]
   __device__ __forceinline__ double C(int id) const { return tab[id * KL]; }
   __device__ __forceinline__ double& Lds(int slot) { return lds[slot * kBlock]; }
+  // per-lane addressing (a lane visits its own touching slots): LDS slot `s * mul + add`, table entry `base + idx`
+  __device__ __forceinline__ double LdsL(unsigned s, int mul, int add) const { return lds[(s * mul + add) * kBlock]; }
+  __device__ __forceinline__ void LdsLStore(unsigned s, int mul, int add, double x, bool on) {
+    if (on) lds[(s * mul + add) * kBlock] = x;
+  }
+  __device__ __forceinline__ double CL(int base, unsigned idx) const { return tab[(base + idx) * KL]; }
   // the table pointer becomes opaque to the optimiser: what is read through it afterwards cannot be
   // hoisted above this point (out of the mj_step loop, into registers that then spill).  The
   // constants are read from LDS where they are used (~90 ds_read_b64 per forward pass, ~100 cycles

@@ -21,6 +21,22 @@ struct HostCx {
     return r;
   }
   V& Lds(int slot) { return lds[slot]; }
+  // per-lane addressing (a lane visits its own touching slots)
+  V LdsL(const plg::LU<KL>& s, int mul, int add) const {
+    V r;
+    for (int c = 0; c < KL; ++c) r.v[c] = lds[s.v[c] * mul + add].v[c];
+    return r;
+  }
+  void LdsLStore(const plg::LU<KL>& s, int mul, int add, const V& x, plg::LB<KL> on) {
+    for (int c = 0; c < KL; ++c) {
+      if (on.v[c]) lds[s.v[c] * mul + add].v[c] = x.v[c];
+    }
+  }
+  V CL(int base, const plg::LU<KL>& idx) const {
+    V r;
+    for (int c = 0; c < KL; ++c) r.v[c] = tab[(base + idx.v[c]) * KL + c];
+    return r;
+  }
   void Refresh() {}
 };
 

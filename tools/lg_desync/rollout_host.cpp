@@ -29,6 +29,21 @@ struct HostCx {
     return r;
   }
   V& Lds(int slot) { return lds[slot]; }
+  V LdsL(const plg::LU<2>& s, int mul, int add) const {
+    V r;
+    for (int c = 0; c < 2; ++c) r.v[c] = lds[s.v[c] * mul + add].v[c];
+    return r;
+  }
+  void LdsLStore(const plg::LU<2>& s, int mul, int add, const V& x, plg::LB<2> on) {
+    for (int c = 0; c < 2; ++c) {
+      if (on.v[c]) lds[s.v[c] * mul + add].v[c] = x.v[c];
+    }
+  }
+  V CL(int base, const plg::LU<2>& idx) const {
+    V r;
+    for (int c = 0; c < 2; ++c) r.v[c] = tab[(base + idx.v[c]) * 2 + c];
+    return r;
+  }
   void Refresh() {}
 };
 
