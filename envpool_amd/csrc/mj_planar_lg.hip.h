@@ -1191,9 +1191,9 @@ struct SolverCfgLg {
 // Safety net: from trip kLsExactAfter on (no env of the benchmark ever gets there) a wave falls back to the exact
 // search, whose steps cannot increase the objective.  Outputs qacc, Ma = M qacc and the final gradient
 // (qfrc_constraint = Ma - qfrc_smooth - grad); returns the env's Newton iterations.
-// kLiveSlots: a trip visits only the slots of the envs that are still live (measured on the GPU: HalfCheetah +2.9 %;
-// Walker2d / Hopper -1.4 %: their kernels have no registers to spare for the per-lane slot set) -- see below.
-template <int KL, bool kLiveSlots, typename T, typename V, typename Cx>
+// A lane visits its own touching slots only while its env is still live (with the wave-uniform slot union of round 4
+// that was +2.9 % for HalfCheetah and -1.4 % for the RK4 models; with per-lane slot sets it costs nothing: all models).
+template <int KL, typename T, typename V, typename Cx>
 EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRows<V>& lim,
                unsigned ends, const typename LaneTypes<V>::U& own, const V* qfrc_smooth,
                const SolverCfgLg<T>& cfg, V* qacc, V* Ma, V* grad) {
@@ -1215,9 +1215,8 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
   const V gfloor2 = gfloor * gfloor;
   V prev_gn2 = V(-1);
   MulArrow<KL>(p.M, qacc, Ma);  // kept current incrementally: Ma += alpha * M s
-  if constexpr (kLiveSlots) {  // (the first trip writes every env's gradient: this is for the Sel in it only)
-    static_for<0, kLV>([&](auto ic) { grad[decltype(ic)::value] = V(0); });
-  }
+  // (the first trip writes every env's gradient: this is for the Sel in it only)
+  static_for<0, kLV>([&](auto ic) { grad[decltype(ic)::value] = V(0); });
   U prev_mask = LT::Fill(~0u);
   B full_step = LT::False();
   B live = LT::True();
@@ -1229,7 +1228,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
     // the trip they finished in
     // (their qacc and Ma are frozen, so it is the gradient at their result); H, the masks and the line-search
     // sums are only ever used for live envs.
-    const U vis = SlotsWhere(own, (!kLiveSlots || it == 0) ? LT::True() : live);
+    const U vis = SlotsWhere(own, it == 0 ? LT::True() : live);
     const B live0 = live;
     V H[kLTri], gc[kLV];
     static_for<0, kLTri>([&](auto kc) { H[decltype(kc)::value] = V(0); });
@@ -1246,11 +1245,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
       } else {
         gc[j] = SumPar<KL>(gc[j]);
       }
-      if constexpr (kLiveSlots) {
-        grad[j] = Sel(live0, (Ma[j] - qfrc_smooth[j]) + gc[j], grad[j]);
-      } else {  // every lane rebuilt its complete rows: current for finished envs too
-        grad[j] = (Ma[j] - qfrc_smooth[j]) + gc[j];
-      }
+      grad[j] = Sel(live0, (Ma[j] - qfrc_smooth[j]) + gc[j], grad[j]);
       static_for<0, j + 1>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         if constexpr (j < 3) {
@@ -1323,16 +1318,11 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
       if (ls + 1 == ls_max) EPA_LG_HOST_TRIP(ls + 1);
     }
     EPA_LG_TICK(cx, 4);
-    const V step = Sel(live, alpha, V(0));
     static_for<0, kLV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      if constexpr (kLiveSlots) {  // (a select, not a zero step: s of a finished env is built from partial rows)
-        qacc[i] = Sel(live, qacc[i] + alpha * s[i], qacc[i]);
-        Ma[i] = Sel(live, Ma[i] + alpha * Ms[i], Ma[i]);
-      } else {
-        qacc[i] += step * s[i];
-        Ma[i] += step * Ms[i];
-      }
+      // (a select, not a zero step: s of a finished env is built from partial rows)
+      qacc[i] = Sel(live, qacc[i] + alpha * s[i], qacc[i]);
+      Ma[i] = Sel(live, Ma[i] + alpha * Ms[i], Ma[i]);
     });
     at_min = at_min | exact;
     live = live & !exact;
@@ -1365,7 +1355,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
 }
 
 // mj_forward: qacc at (q, v) under ctrl; `warm` is qacc_warmstart in/out; `p` keeps M for the caller
-template <int KL, bool kLiveSlots, typename T, typename V, typename Cx>
+template <int KL, typename T, typename V, typename Cx>
 EPA_HD V Forward(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, const V* q, const V* v,
                  V* warm, const V* ctrl, Pos<V>& p, V* qacc, V* Ma, V* grad) {
   cx.Refresh();
@@ -1381,7 +1371,7 @@ EPA_HD V Forward(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, co
   EPA_LG_HOST_OWN(own);
   static_for<0, kLV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
   EPA_LG_TICK(cx, 1);
-  const V iters = Solve<KL, kLiveSlots>(m, cx, p, lim, ends, own, qfrc_smooth, cfg, qacc, Ma, grad);
+  const V iters = Solve<KL>(m, cx, p, lim, ends, own, qfrc_smooth, cfg, qacc, Ma, grad);
   EPA_LG_TICK(cx, 2);
   static_for<0, kLV>([&](auto ic) { warm[decltype(ic)::value] = qacc[decltype(ic)::value]; });
   return iters;
@@ -1394,7 +1384,7 @@ EPA_HD V StepEuler(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, 
                    const V* ctrl) {
   Pos<V> p;
   V qacc[kLV], Ma[kLV], grad[kLV];
-  const V iters = Forward<KL, true>(m, cfg, cx, q, v, warm, ctrl, p, qacc, Ma, grad);
+  const V iters = Forward<KL>(m, cfg, cx, q, v, warm, ctrl, p, qacc, Ma, grad);
   // (M + h diag(damping)) qacc_d = qfrc_smooth + qfrc_constraint = Ma - grad
   V rhs[kLV];
   static_for<0, kLV>([&](auto ic) {
@@ -1435,7 +1425,7 @@ EPA_HD V StepRK4(const CheetahModel<T>& m, const SolverCfgLg<T>& cfg, Cx& cx, V*
   for (int stage = 0; stage < 4; ++stage) {
     Pos<V> p;
     V Ma[kLV], grad[kLV];
-    it += Forward<KL, false>(m, cfg, cx, qs, vs, warm, ctrl, p, F, Ma, grad);
+    it += Forward<KL>(m, cfg, cx, qs, vs, warm, ctrl, p, F, Ma, grad);
     const V bw = V((stage == 0 || stage == 3) ? T(1.0 / 6.0) : T(1.0 / 3.0));
     const V a = V(stage == 2 ? T(1) : T(0.5));
     static_for<0, kLV>([&](auto ic) {
