@@ -744,11 +744,15 @@ EPA_HD unsigned MakeConstraint(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p
       an = Sel(touch, -V(m.con_B) * vn - V(m.con_K) * imp * r, V(0));
       ax = Sel(touch, V(m.con_B) * mu * vx, V(0));
     }
-    cx.Lds(s * kSlotsPerEnd + 0) = cpx;
-    cx.Lds(s * kSlotsPerEnd + 1) = cpz;
-    cx.Lds(s * kSlotsPerEnd + 2) = an;
-    cx.Lds(s * kSlotsPerEnd + 3) = ax;
-    cx.Lds(s * kSlotsPerEnd + 4) = D;
+    // A slot's numbers are only read by lanes that visit it, i.e. whose own bit is set -- then some lane touches and
+    // the wave is in here; slot 0 is also what a lane whose set has run out reads (weight 0): always written.
+    if (s == 0 || (ends & (1u << s)) != 0) {
+      cx.Lds(s * kSlotsPerEnd + 0) = cpx;
+      cx.Lds(s * kSlotsPerEnd + 1) = cpz;
+      cx.Lds(s * kSlotsPerEnd + 2) = an;
+      cx.Lds(s * kSlotsPerEnd + 3) = ax;
+      cx.Lds(s * kSlotsPerEnd + 4) = D;
+    }
   });
   // body-body capsule pairs of the Hopper (mjc_CapsuleCapsule: closest points of the two axis segments,
   // then sphere-sphere; the arithmetic of mj_cheetah.hip.h::CheetahMakeConstraint with selects for its
@@ -1167,8 +1171,12 @@ EPA_HD V DotEnv(const V* a, const V* b) {
   return t + SumLegs<KL>(l);
 }
 
-// Newton trip of a forward pass from which a wave searches its lines exactly again (plg::Solve)
-constexpr int kLsExactAfter = 8;
+// Newton trip of a forward pass from which a wave searches its lines exactly again (plg::Solve); the CPU harness
+// builds the source a second time with 1, so that the fallback -- never reached in the benchmark -- is tested too
+#ifndef EPA_LG_LS_EXACT_AFTER
+#define EPA_LG_LS_EXACT_AFTER 8
+#endif
+constexpr int kLsExactAfter = EPA_LG_LS_EXACT_AFTER;
 
 template <typename T>
 struct SolverCfgLg {

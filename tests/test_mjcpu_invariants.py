@@ -617,8 +617,24 @@ def test_product_planar_lane_group_code_matches_oracle_on_cpu():
         newest = max(os.path.getmtime(f) for f in [src] + [os.path.join(csrc, x) for x in hdrs])
         if not os.path.exists(so) or os.path.getmtime(so) < newest:
             subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
-    L = ctypes.CDLL(os.path.join(h, "libplanar_lg_host.so"))
+    # the same source with the exact line search from the SECOND Newton trip of a forward pass on (the product: one
+    # evaluation per trip, exact search only as a fallback from trip 8 that the benchmark never reaches): the fallback's
+    # code path, and that both searches end on the oracle's minimiser
+    so2, src2 = os.path.join(h, "libplanar_lg_host_exact.so"), os.path.join(h, "planar_lg_host.cpp")
+    newest = max(os.path.getmtime(f) for f in [src2] + [os.path.join(csrc, x) for x in
+                                                       ("mj_planar_lg.hip.h", "mj_cheetah.hip.h", "mj_cheetah_model.h")])
+    if not os.path.exists(so2) or os.path.getmtime(so2) < newest:
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DEPA_LG_LS_EXACT_AFTER=1", src2, "-o", so2],
+                       check=True)
     Lo = ctypes.CDLL(os.path.join(h, "libcheetah_host.so"))
+    vp = ctypes.c_void_p
+    for L in (ctypes.CDLL(os.path.join(h, "libplanar_lg_host.so")), ctypes.CDLL(so2)):
+        _planar_lane_group_vs_oracle(L, Lo)
+
+
+def _planar_lane_group_vs_oracle(L, Lo):
+    from oracle.orc import Oracle
+
     vp = ctypes.c_void_p
     L.planar_lg_step.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp]
     rng = np.random.default_rng(3)

@@ -15,11 +15,13 @@ python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> $O/gpu_
 python bench.py > $O/bench_default_before_pmc.json 2> $O/bench_default.err; cut -c1-400 $O/bench_default_before_pmc.json
 fi
 P() { tag=$1; shift; bash tools/profile_bench.sh $tag "$@" > $O/$tag.log 2>&1; sed -n '/timed window/,/^$/p' gpurun_out/prof_$tag/summary.md | head -3; }
-if [ "$PART" = b ]; then
+if [ "$PART" = b ] || [ "$PART" = b4 ]; then  # b4: the four lane-group entries only
 P r5z_cheetah_lg2
 P r5z_cheetah_lg4_8k --num-envs 8192
 P r5z_walker_lg2 --task Walker2d
 P r5z_hopper_lg1 --task Hopper
+fi
+if [ "$PART" = b ]; then
 export PMC_GROUPS=min
 P r5z_hopper_lane_f64 --task Hopper --param planar_layout=1
 P r5z_cheetah_lane_f64 --param planar_layout=1
