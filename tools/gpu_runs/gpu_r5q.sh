@@ -10,7 +10,7 @@ cp envpool_amd/lib/libenvpool_amd.so /tmp/new.so
 for rep in 1 2; do
 for v in prev new; do
   if [ $v = new ]; then cp /tmp/new.so envpool_amd/lib/libenvpool_amd.so; else cp envpool_amd/lib/libenvpool_amd_prev.so envpool_amd/lib/libenvpool_amd.so; fi
-  for cfg in "Walker2d 65536" "Hopper 65536"; do
+  for cfg in "HalfCheetah 65536" "HalfCheetah 8192" "Walker2d 65536" "Hopper 65536"; do
     set -- $cfg
     timeout 600 python bench.py --task $1 --num-envs $2 --no-cpu-baseline --min-time 2 2>>$O/err | python -c "
 import json,sys
