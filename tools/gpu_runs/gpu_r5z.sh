@@ -52,3 +52,6 @@ PY
 timeout 600 python tools/bench_numpy_api.py > $O/numpy_api.jsonl 2>>$O/err
 timeout 900 python tools/bench_families.py > $O/bench_families.md 2>>$O/err
 fi
+if [ "$PART" = e ]; then  # trip counts of every env on the final build (the one-evaluation search; its soak on the exact search: gpu_r5m.sh)
+timeout 900 python tools/lg_iter_soak.py 400 > $O/iter_soak.txt 2>>$O/err; cut -c1-300 $O/iter_soak.txt
+fi
