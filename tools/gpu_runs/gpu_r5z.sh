@@ -21,6 +21,11 @@ P r5z_cheetah_lg4_8k --num-envs 8192
 P r5z_walker_lg2 --task Walker2d
 P r5z_hopper_lg1 --task Hopper
 fi
+if [ "$PART" = b ] || [ "$PART" = b2 ]; then  # the headline kernel at the other two sizes of the throughput table
+export PMC_GROUPS=min
+P r5z_cheetah_lg2_32k --num-envs 32768
+P r5z_cheetah_lg2_128k --num-envs 131072
+fi
 if [ "$PART" = b ]; then
 export PMC_GROUPS=min
 P r5z_hopper_lane_f64 --task Hopper --param planar_layout=1
