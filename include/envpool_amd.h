@@ -61,7 +61,9 @@ typedef struct epa_pool epa_pool;
  *   "xml_v5"      Walker2d / Pusher: 1 selects the *_v5 model (the reference's xml_file)
  *   "planar_spread" HalfCheetah / Walker2d / Hopper / Pusher: 1 (default) a batch of 16 .. 64 (Pusher: 32 .. 64) envs
  *                 per SIMD is spread over all SIMDs with 16 / 32 / 48 envs per wave; 0 always 64 envs per wave
- *   "hum_layout"  Humanoid / HumanoidStandup: 1 one env per lane quad (default), 0 one env per lane
+ *   "hum_layout"  Humanoid / HumanoidStandup: 1 one env per lane quad (default), 0 one env per lane -- the superseded
+ *                 kernel, built only into lib/libenvpool_amd_alt.so (`make -C envpool_amd/csrc EPA_ALT_KERNELS=1`, the
+ *                 cross-check tests load it through ENVPOOL_AMD_LIB); the product library refuses 0
  *   "hum_sort"    quad layout: 1 cost-sorted waves (default), 0 rows in send order
  *   "hum_debug"   quad layout: stages switched off (bits 1 2 4 8), solver statistics (16) or cycles per stage
  *                 (32 64 128 256) routed into the info keys; accepted by the diagnostic build only
