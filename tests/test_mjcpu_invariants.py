@@ -799,3 +799,55 @@ def test_pusher_capsule_cylinder_rule_in_the_degenerate_poses():
     o = both(c + [0.01, 0, -0.01], c + [0.02, 0, 0.01], rc, c, R, H)
     np.testing.assert_allclose(o[0], -rc, atol=1e-12)
     np.testing.assert_allclose(o[4:7], [-1, 0, 0], atol=1e-9)
+
+
+def test_lane_group_solver_on_adversarial_states():
+    """The one-evaluation line search of the lane-group Newton solver (mj_planar_lg.hip.h::Solve; exact search only
+    as a fallback from trip 8) far from the benchmark's states: deep penetrations, joints beyond their ranges,
+    velocities ~ N(0, 8), a garbage warm start ~ N(0, 50).  One env-step from each such state, host instantiation of
+    the kernel source vs the oracle (whose solver searches its lines exactly): same result to rounding, i.e. the
+    solver still ends on the minimiser, and the trip counts stay far from the cap of 50 per forward pass."""
+    from oracle.orc import Oracle
+
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    csrc = os.path.join(ROOT, "envpool_amd", "csrc")
+    so, src = os.path.join(h, "libplanar_lg_host.so"), os.path.join(h, "planar_lg_host.cpp")
+    newest = max(os.path.getmtime(f) for f in [src] + [os.path.join(csrc, x) for x in
+                                                      ("mj_planar_lg.hip.h", "mj_cheetah.hip.h", "mj_cheetah_model.h")])
+    if not os.path.exists(so) or os.path.getmtime(so) < newest:
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(so)
+    vp = ctypes.c_void_p
+    L.planar_lg_step.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp]
+    rng = np.random.default_rng(11)
+    for task, model, nsub, nd, passes in (("HalfCheetah", 0, 5, 9, 5), ("Walker2d", 1, 4, 9, 16), ("Hopper", 3, 4, 6, 16)):
+        n = 96
+        orc = Oracle(task, n, seed=5, max_episode_steps=1000)
+        orc.reset()
+        worst, its = 0.0, []
+        for rep in range(3):
+            st = orc.get_state()
+            st[:, 1] = rng.uniform(-0.3, 0.6, n) if model == 0 else rng.uniform(0.3, 1.5, n)
+            st[:, 2] = rng.uniform(-3, 3, n)
+            st[:, 3:nd] = rng.uniform(-1.5, 1.5, (n, nd - 3))
+            st[:, nd:2 * nd] = rng.normal(0, 8, (n, nd))
+            st[:, 2 * nd:3 * nd] = rng.normal(0, 50, (n, nd))
+            orc.set_state(st)
+            act = rng.uniform(-1, 1, (n, nd - 3))
+            b = orc.step(act)
+            for e in range(n):
+                if b["elapsed_step"][e, 0] == 0:
+                    continue
+                q, v, w, a = np.zeros(9), np.zeros(9), np.zeros(9), np.zeros(6)
+                q[:nd], v[:nd], w[:nd] = st[e, :nd], st[e, nd:2 * nd], st[e, 2 * nd:3 * nd]
+                a[:nd - 3] = act[e]
+                qo, vo, wo, it = np.zeros(9), np.zeros(9), np.zeros(9), ctypes.c_int(0)
+                rc = L.planar_lg_step(model, 1 if model == 3 else 2, q.ctypes.data, v.ctypes.data, w.ctypes.data,
+                                      a.ctypes.data, nsub, qo.ctypes.data, vo.ctypes.data, wo.ctypes.data, ctypes.byref(it))
+                assert rc == 0
+                vv = np.clip(vo, -10, 10) if model else vo
+                ref, got = b["obs"][e], np.concatenate([qo[1:nd], vv[:nd]])
+                worst = max(worst, (np.abs(got - ref) / (1 + np.abs(ref))).max())
+                its.append(it.value)
+        assert len(its) > n and worst < 1e-9, (task, worst)
+        assert max(its) < 8 * passes, (task, max(its))  # no forward pass anywhere near the cap
