@@ -95,6 +95,7 @@ class DevicePool:
         self._pending: collections.deque[int] = collections.deque()
         self._is_sync = self.batch_size == self.num_envs
         self._blocks = _PinnedBlocks(self._lib)
+        self._step_ptrs = None  # step_device: reusable ctypes output array + cache of pointer lists
         self._layouts: dict[int, tuple[list[int], int]] = {}
 
     def _create(self, family: str, cfg: Any, params: dict[str, float] | None) -> ctypes.c_void_p:
@@ -219,6 +220,24 @@ class DevicePool:
         k = ctypes.c_int32(0)
         native.check(self._lib.epa_recv_device(self._h, ptrs, n, ctypes.byref(k)))
         return [int(p) if p else 0 for p in ptrs], k.value
+
+    def step_device(self, d_action: int | None, k: int | None = None, d_env_id: int | None = None,
+                    wait_event: int | None = None) -> tuple[list[int], int]:
+        """send_device + recv_device in one library call (the sync `step()` of the device path).  A pool hands out
+        its result blocks in rotation, so the pointer lists are cached per block."""
+        k = self.num_envs if k is None else int(k)
+        n = len(self.state_keys)
+        if self._step_ptrs is None:
+            self._step_ptrs, self._step_k, self._step_cache = (ctypes.c_void_p * n)(), ctypes.c_int32(0), {}
+        ptrs = self._step_ptrs
+        rc = self._lib.epa_step_device(self._h, d_env_id, k, d_action, wait_event, ptrs, n, ctypes.byref(self._step_k))
+        if rc:
+            native.check(rc)
+        key = (ptrs[0], ptrs[n - 1])  # first and last section: the block and its layout
+        out = self._step_cache.get(key)
+        if out is None:
+            out = self._step_cache[key] = [int(p) if p else 0 for p in ptrs]
+        return out, self._step_k.value
 
     @property
     def stream(self) -> int:

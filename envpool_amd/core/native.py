@@ -94,6 +94,7 @@ def lib() -> ctypes.CDLL:
         "epa_wait_stream": (i32, [vp, vp]),
         "epa_consumer_wait": (i32, [vp, vp]),
         "epa_recv_device": (i32, [vp, P(vp), i32, P(i32)]),
+        "epa_step_device": (i32, [vp, vp, i32, vp, vp, P(vp), i32, P(i32)]),
         "epa_stream": (vp, [vp]),
         "epa_synchronize": (i32, [vp]),
         "epa_set_timing": (i32, [vp, i32]),
@@ -129,7 +130,7 @@ EXPORTED_SYMBOLS = [
     "epa_num_families", "epa_family_name", "epa_describe_state",
     "epa_describe_action", "epa_create", "epa_destroy", "epa_send", "epa_reset",
     "epa_recv", "epa_recv_layout", "epa_recv_block", "epa_recv_into", "epa_pending_rows",
-    "epa_send_device", "epa_recv_device", "epa_wait_stream", "epa_consumer_wait",
+    "epa_send_device", "epa_recv_device", "epa_step_device", "epa_wait_stream", "epa_consumer_wait",
     "epa_stream", "epa_synchronize", "epa_set_timing", "epa_kernel_time_ms",
     "epa_state_dim", "epa_get_state", "epa_set_state", "epa_atari_post_create",
     "epa_atari_post_create_ex", "epa_atari_create", "epa_atari_num_actions",

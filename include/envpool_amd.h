@@ -231,6 +231,12 @@ int epa_wait_stream(epa_pool* pool, void* producer_stream);
 int epa_recv_device(epa_pool* pool, void** d_out_ptrs, int32_t n_ptrs,
                     int32_t* k_out);
 
+/* epa_send_device followed by epa_recv_device in ONE call -- the device-path form of the reference's sync `step()`
+ * (envpool/python/envpool.py:345-349: send, then recv).  At the sizes where a step kernel takes a few microseconds
+ * (classic_control / toy_text at num_envs = 65536) the two calls of a binding are most of a step's time. */
+int epa_step_device(epa_pool* pool, const int32_t* d_env_id, int32_t k, const void* d_action,
+                    void* wait_event, void** d_out_ptrs, int32_t n_ptrs, int32_t* k_out);
+
 /* The mirror of epa_wait_stream for the outputs: `consumer_stream` waits for the
  * step kernel of the batch the LAST epa_recv_device handed out (a consumer on
  * epa_stream() itself needs no call).  The consumer must be done with a batch's

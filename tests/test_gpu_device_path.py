@@ -186,3 +186,30 @@ def test_empty_send_keeps_the_pool_usable():
     assert out["obs"].shape == (n, 4)
     with pytest.raises(RuntimeError):
         pool.recv()
+
+
+def test_step_device_is_send_device_plus_recv_device():
+    """epa_step_device (the device path's sync step(): envpool/python/envpool.py:345-349 send, then recv) hands out
+    the same batches as the two calls it replaces, bit for bit, and its cached pointer lists follow the blocks."""
+    from envpool_amd.torch_interop import _DevArray
+
+    n = 4096
+    a = DevicePool("CartPole", n, seed=3, max_episode_steps=50)
+    b = DevicePool("CartPole", n, seed=3, max_episode_steps=50)
+    acts = [torch.randint(0, 2, (n,), device="cuda", dtype=torch.int32) for _ in range(6)]
+    torch.cuda.synchronize()
+    a.send_device(None)
+    a.recv_device()
+    b.step_device(None)
+
+    def tensors(pool, ptrs, k):
+        pool.synchronize()
+        return {name: torch.as_tensor(_DevArray(p, (k, *shape), dtype), device="cuda").cpu().numpy()
+                for (name, dtype, shape), p in zip(pool.state_keys, ptrs)}
+
+    for t in range(60):
+        a.send_device(acts[t % 6].data_ptr())
+        pa, ka = a.recv_device()
+        pb, kb = b.step_device(acts[t % 6].data_ptr())
+        assert ka == kb == n
+        _assert_same(tensors(a, pa, ka), tensors(b, pb, kb), f"step {t}")

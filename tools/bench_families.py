@@ -83,18 +83,30 @@ def main():
             pool.send_device(None)
             pool.recv_device()
             for i in range(args.warmup):
-                pool.send_device(ring[i % 8].data_ptr())
-                pool.recv_device()
+                pool.step_device(ring[i % 8].data_ptr())  # send + recv in one library call
             pool.synchronize()
             pool.set_timing(True)
             for i in range(args.steps):
-                pool.send_device(ring[i % 8].data_ptr())
-                pool.recv_device()
+                pool.step_device(ring[i % 8].data_ptr())  # send + recv in one library call
             ms, launches = pool.kernel_time_ms()
             gbs = alg * n / (ms * 1e-3) / 1e9
+            # what a caller of the device path gets per step, gaps between the launches included: one event pair
+            # around the whole window (timing mode 2), with step_device and with the send_device + recv_device pair
+            pool.set_timing(2)
+            for i in range(args.steps):
+                pool.step_device(ring[i % 8].data_ptr())
+            step_ms, _ = pool.kernel_time_ms()
+            pool.set_timing(2)
+            for i in range(args.steps):
+                pool.send_device(ring[i % 8].data_ptr())
+                pool.recv_device()
+            pair_ms, _ = pool.kernel_time_ms()
+            pool.set_timing(False)
             rec = {"family": fam, "num_envs": n, "kernel_us": ms * 1e3, "launches": launches,
                    "env_steps_per_s": n / (ms * 1e-3), "algorithmic_bytes": alg,
-                   "achieved_GBps": gbs, "hbm_frac": gbs / 8000.0}
+                   "achieved_GBps": gbs, "hbm_frac": gbs / 8000.0,
+                   "step_us_step_device": step_ms * 1e3, "step_us_send_recv": pair_ms * 1e3,
+                   "env_steps_per_s_step_device": n / (step_ms * 1e-3)}
             rows.append(rec)
             print(json.dumps(rec))
             # step-kernel launches of this configuration, in dispatch order: 1 reset + 10 warm-up + the timed ones
@@ -131,11 +143,14 @@ def main():
     if args.plan_out:
         with open(args.plan_out, "w") as f:
             json.dump(plan, f, indent=1)
-    print("\n| family | N | kernel us | env-steps/s | alg B/step | GB/s | frac of 8 TB/s |")
-    print("|---|---|---|---|---|---|---|")
+    # kernel us: HIP event pair around every launch; step us: one event pair around the whole window of launches (what a
+    # caller of the device path gets per step, gaps included) with epa_step_device / with epa_send_device + epa_recv_device
+    print("\n| family | N | kernel us | env-steps/s | alg B/step | GB/s | frac of 8 TB/s | step us (step_device) | step us (send + recv) |")
+    print("|---|---|---|---|---|---|---|---|---|")
     for r in rows:
         print(f"| {r['family']} | {r['num_envs']} | {r['kernel_us']:.1f} | {r['env_steps_per_s']:.3g} | "
-              f"{r['algorithmic_bytes']} | {r['achieved_GBps']:.0f} | {r['hbm_frac']:.3f} |")
+              f"{r['algorithmic_bytes']} | {r['achieved_GBps']:.0f} | {r['hbm_frac']:.3f} | "
+              f"{r.get('step_us_step_device', float('nan')):.1f} | {r.get('step_us_send_recv', float('nan')):.1f} |")
 
 
 if __name__ == "__main__":
