@@ -131,4 +131,6 @@ def main(xml_dir: str) -> None:
 
 
 if __name__ == "__main__":
+    if len(sys.argv) < 2:
+        sys.exit(__doc__)
     main(sys.argv[1])
