@@ -535,7 +535,7 @@ EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned
       s[6] = t6 * inv6;
       s[7] = (t7 - H[Tri(6, 7)] * s[6]) * inv7;
     }
-    // ---- exact line search on the piecewise-quadratic cost
+    // ---- line search on the piecewise-quadratic cost (one evaluation at the full step, see below)
     V Ms[kL];
     EPA_LDS_FENCE();
     MulM(lds, s, Ms);

@@ -28,12 +28,13 @@
 //    per number) and every lane factors the same 3x3 torso block.  Cross-lane traffic per Newton
 //    iteration: 9 numbers for H and the gradient, 9 for the factorisation / solve, 5 for the
 //    products with M, 2 per line-search evaluation -- all in registers, no LDS;
-//  * as in mj_cheetah.hip.h: per-contact constants live in LDS [slot][lane], the solver passes run
-//    a scalar loop over the wave-uniform set of touching end-sphere slots, and there is no
+//  * as in mj_cheetah.hip.h: per-contact constants live in LDS [slot][lane] and there is no
 //    lane-divergent control flow in the solver (branches are on wave-wide ballots, per-lane
-//    differences are selects / zero weights).
-// A wave runs as long as its slowest env and visits the union of its envs' touching slots: with
-// 32 or 16 envs per wave instead of 64 both maxima shrink.
+//    differences are selects / zero weights); since round 5 a lane visits ITS OWN touching
+//    end-sphere slots, one per trip of a loop that runs as often as the busiest lane needs
+//    (rounds 3-4: a scalar loop over the wave-uniform union of the touching slots).
+// A wave runs as long as its slowest env and as its busiest lane: with 32 or 16 envs per wave
+// instead of 64 both maxima shrink.
 // The same source runs on the host with V = LV<T, KL> (tests/cpu_harness/planar_lg_host.cpp), so
 // it is diffed against oracle/mjcpu on a CPU box before it ever sees a GPU.
 #ifndef ENVPOOL_AMD_CSRC_MJ_PLANAR_LG_HIP_H_
@@ -1280,7 +1281,7 @@ EPA_HD V Solve(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const LimitRow
     static_for<0, kLV>([&](auto ic) { s[decltype(ic)::value] = -grad[decltype(ic)::value]; });
     FactorArrow<KL>(H);
     SolveArrow<KL>(H, s);
-    // exact line search on the convex piecewise-quadratic phi(alpha)
+    // line search on the convex piecewise-quadratic phi(alpha): one evaluation at the full step (see above)
     V Ms[kLV], r0[kLV];
     MulArrow<KL>(p.M, s, Ms);
     static_for<0, kLV>([&](auto ic) {

@@ -325,8 +325,8 @@ __device__ __forceinline__ void StepChunk(int chunk, const double* tab_lds, doub
 }
 
 // PERSISTENT waves over a dynamic queue of chunks.  A wave runs as long as its slowest env and
-// visits the union of its envs' touching slots, so chunks differ a lot in duration (mean wave 80 us,
-// slowest 143 us at N = 32768: profiles/archive/r3e_*): with one chunk per wave the launch lasts as long as
+// as its busiest lane has touching slots, so chunks differ a lot in duration (mean wave 80 us,
+// slowest 143 us at N = 32768 in round 3: profiles/archive/r3e_*): with one chunk per wave the launch lasts as long as
 // its slowest wave.  Here the grid is the number of waves that are resident at once, wave i starts
 // with chunk i and then takes the next chunk off an atomic ticket counter until none is left --
 // whoever finishes early does the extra work.  `ticket_base`: the counter's value before this
@@ -421,7 +421,7 @@ void LaunchKl(hipStream_t st, int model, int wave_slots, bool spread, const Chee
               const double* tab, unsigned* ticket, unsigned* ticket_base, const planar::LgOrder& lo) {
   // waves resident at once: W per SIMD by registers (LDS allows no more than one at KL = 2)
   const int resident = wave_slots * ((KL <= 2 || W == 1) ? 1 : 2);
-  // A wave runs as long as its slowest env and visits the union of its envs' touching slots: while
+  // A wave runs as long as its slowest env (and its busiest lane): while
   // there are fewer full chunks than resident waves, smaller chunks (partly filled waves) on more
   // SIMDs are faster (N = 8192 at 4 lanes per env: 512 waves of 16 envs 95 us, 1024 waves of 8 envs
   // 90 us; N = 12288 as 12 per wave: 96 -> 93 us; profiles/archive/r3l_lane_group_spread_ab.txt).  Half, three
