@@ -11,7 +11,8 @@ import pytest
 
 from oracle.orc import Oracle
 from oracle_cases import CASES, INTEGER_EXACT, sample_actions
-from hip_util import HipAsOracle, make_hip_pool
+from envpool_amd.core.device_pool import DevicePool
+from hip_util import PARAM_NAMES, HipAsOracle, make_hip_pool
 from test_oracle_pinned import replay_golden
 
 pytestmark = pytest.mark.gpu
@@ -194,3 +195,32 @@ def test_errors():
         pool.reset(np.array([7], dtype=np.int32))  # id out of range
     with pytest.raises(ValueError):
         make_hip_pool("CartPole-v1", 4, 0, batch_size=9)
+
+
+@pytest.mark.parametrize("name", ["CartPole-v1", "Acrobot-v1", "Pendulum-v1", "MountainCar-v0"])
+def test_classic_reset_draws_across_generator_wraps(name):
+    """The reset draws of classic_control come out of Mt19937::NextWords as one burst (tile boundary regenerated first,
+    then K independent loads; generator words in tiles of 16, regenerated lazily).  With max_episode_steps = 2 every
+    env resets every third step: 8 words (CartPole, Acrobot), 4 (Pendulum) or 2 (MountainCar) per reset, so 1500 steps
+    walk the 624-word block of every env 1.6 - 6.4 times, bursts straddling tile boundaries and the wrap at every
+    offset.  Every reset row bit-exact on every key against the plain-C port (std::mt19937 semantics), and the
+    bookkeeping of every row."""
+    c = CASES[name]
+    n, steps = 128, 1500
+    params = dict(zip(PARAM_NAMES.get(c["task"], ()), c["extra"]))
+    hip = HipAsOracle(DevicePool(c["task"], n, seed=17, max_episode_steps=2, params=params))
+    orc = Oracle(c["task"], n, seed=17, max_episode_steps=2, extra=c["extra"], kind="port")
+    a, b = hip.reset(), orc.reset()
+    rng = np.random.default_rng(3)
+    resets = 0
+    for t in range(steps):
+        rows = np.nonzero(b["elapsed_step"].ravel() == 0)[0]
+        resets += len(rows)
+        for k in b:
+            if k in ("elapsed_step", "done", "trunc", "info:env_id"):
+                assert np.array_equal(a[k], b[k]), (name, t, k)
+            else:
+                assert np.array_equal(np.asarray(a[k])[rows], np.asarray(b[k])[rows]), (name, t, k)
+        act = sample_actions(c, rng, n)
+        a, b = hip.step(act), orc.step(act)
+    assert resets >= n * (steps // 3)
