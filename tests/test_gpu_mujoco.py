@@ -943,3 +943,33 @@ def test_planar_lane_group_batch_independent(task, layout):
         part.send(rest, acts[t][rest])
         part.recv_dict()
     assert np.array_equal(full[0].get_state(), part.get_state())
+
+
+@pytest.mark.parametrize("task,adim,amax,exact", [("HalfCheetah", 6, 1.0, 8), ("Hopper", 3, 1.0, 11), ("Walker2d", 6, 1.0, 17),
+                                                   ("Ant", 8, 1.0, 13), ("InvertedPendulum", 1, 3.0, 4),
+                                                   ("Humanoid", 17, 0.4, 22)])
+def test_reset_draws_across_generator_wraps(task, adim, amax, exact):
+    """The per-env mt19937 is regenerated lazily (one word per draw in the [624][N] layout -- HalfCheetah: every env
+    draws in the same launch --, one 16-word tile at a time for the families whose envs reset at their own times).
+    With max_episode_steps = 1 every env resets every second step; a reset draws 20 - 100 words (uniform positions,
+    normal or uniform velocities), so 260 steps walk every env's 624-word block 4 - 20 times.  The first `exact`
+    observations of a reset row are uniform draws -- bit-exact against the oracle (libstdc++ std::mt19937 +
+    distributions); the rest go through log / sqrt (normal draws: HalfCheetah, Ant) or mj_forward (Humanoid) and agree
+    to rounding -- a generator out of step would show as errors of the size of the noise, 1e-2 .. 1e-1."""
+    n, steps = 64, 260
+    pool = DevicePool(task, n, seed=23, max_episode_steps=1)
+    orc = Oracle(task, n, seed=23, max_episode_steps=1)
+    a, b = hip_reset(pool), orc.reset()
+    rng = np.random.default_rng(9)
+    resets = 0
+    for t in range(steps):
+        rows = np.nonzero(b["elapsed_step"].ravel() == 0)[0]
+        resets += len(rows)
+        assert np.array_equal(a["elapsed_step"].ravel(), b["elapsed_step"].ravel()), (task, t)
+        ao, bo = np.asarray(a["obs"])[rows], np.asarray(b["obs"])[rows]
+        assert np.array_equal(np.ascontiguousarray(ao[:, :exact]).view(np.uint8),
+                              np.ascontiguousarray(bo[:, :exact]).view(np.uint8)), (task, t)
+        np.testing.assert_allclose(ao, bo, rtol=1e-9, atol=1e-11, err_msg=f"{task} t={t}")
+        act = rng.uniform(-amax, amax, size=(n, adim))
+        a, b = hip_step(pool, act), orc.step(act)
+    assert resets >= n * (steps // 2)
