@@ -27,6 +27,8 @@ for task, adim, nv, passes in (("HalfCheetah", 6, 9, 5), ("Walker2d", 6, 9, 16),
         it = pool.get_state()[:, 3 * nv].astype(np.int64)
         live = out["elapsed_step"].ravel() > 0  # (a reset row keeps the count of the step before it)
         it = it[live]
+        if it.size == 0:  # (every env reset in this launch: the common truncation of the HalfCheetah at step 1000)
+            continue
         hist += np.bincount(np.minimum(it, 1023), minlength=1024)
         worst = max(worst, int(it.max()))
         bad += int(np.isnan(out["obs"]).any())
