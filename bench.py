@@ -334,7 +334,7 @@ def main():
         # collection needs its own rocprofv3 runs and cannot happen inside the bench.
         hum_quad = params.get("hum_layout", 1) != 0  # one env per lane quad (default)
         # HalfCheetah / Walker2d in fp64 run on the lane-group kernel (planar_layout 2 or 4, default 2)
-        lg_layout = int(params.get("planar_layout", 0)) or (2 if n >= 24576 else 4)  # the pool's own rule
+        lg_layout = int(params.get("planar_layout", 0)) or (2 if n > 16384 else 4)  # the pool's own rule
         lg = (args.task in ("HalfCheetah", "Walker2d") and args.precision == "fp64" and lg_layout > 1
               and params.get("frame_stack", 1) == 1)
         if args.task == "Hopper":  # a group of ONE lane (default) unless planar_layout = 1

@@ -344,9 +344,9 @@ class CheetahPool : public Pool {
     // "planar_layout" (extension key): 1 = one env per lane (CheetahStepKernel), 2 / 4 = one env per
     // group of 2 / 4 lanes (mujoco_planar_lg.hip; fp64, HalfCheetah / Walker2d, frame_stack 1),
     // 0 (default) = chosen HERE from the rows this pool normally has in flight (num_envs in sync mode,
-    // min(num_envs, 4 x batch_size) in async mode, see below): 2 lanes per env from 24576 rows up, 4 below
-    // (profiles/archive/r3i_lane_group_sweep.txt:
-    // N = 32768: 2.5e8 vs 2.0e8, N = 16384: 1.3e8 vs 1.7e8).  Fixed per pool, not per launch: the two
+    // min(num_envs, 4 x batch_size) in async mode, see below): 4 lanes per env while one round of 16-env chunks
+    // covers the rows (16384 = 1024 SIMDs x 16), 2 above (round 5, profiles/r5aa_layout_sweep.txt: N = 16384
+    // 2.17e8 with 4 lanes vs 1.84e8 with 2, N = 20480 1.57e8 vs 2.30e8; rounds 3-4 switched at 24576).  Fixed per pool, not per launch: the two
     // layouts sum the contact rows in different orders, and an env's bits must not depend on how
     // many other envs a particular send happens to carry.  It DOES depend on num_envs / batch_size of
     // the pool (to rounding: the two layouts agree with the oracle to 1e-9 each, tests/test_gpu_mujoco.py);
@@ -377,7 +377,7 @@ class CheetahPool : public Pool {
       // (4 = the default number of compute streams; NOT the pool's own "compute_streams", so that an env's bits
       // do not depend on that knob: tests compare 1 stream with several bit for bit)
       if (async_) rows = std::min<long long>(cfg.num_envs, 4ll * cfg.batch_size);
-      layout_ = rows >= 24576 ? 2 : 4;
+      layout_ = rows > 16384 ? 2 : 4;
       if (hopper) layout_ = kLayoutHopperLg;
     }
     // register budget of the lane-group kernel: one wave per SIMD with all 512 registers (default;

@@ -70,7 +70,7 @@ typedef struct epa_pool epa_pool;
  *                 (-DEPA_HUM_DEBUG: tools/build_trace_lib.sh, tools/build_alt_hum4.sh), the product library refuses it
  *   "planar_layout" HalfCheetah / Walker2d, fp64: lanes per env of the step kernel -- 2 or 4 (one env per
  *                 lane group, mujoco_planar_lg.hip), 1 (one env per lane, mujoco_gym.hip), 0 (default)
- *                 chosen once per pool: 2 from 24576 rows up, else 4 (rows = num_envs in sync mode,
+ *                 chosen once per pool: 2 above 16384 rows, else 4 (rows = num_envs in sync mode,
  *                 min(num_envs, 4 x batch_size) in async mode: what is in flight on the compute streams).
  *                 The two layouts sum the contact rows in different orders: with the default, an env's
  *                 low-order bits therefore depend on the pool's num_envs / batch_size (never on the rows

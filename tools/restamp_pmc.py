@@ -13,7 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from kernel_sources import base_name, source_hash  # noqa: E402
 
-FLAGS = {"mujoco_planar_lg.hip": ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-spill-sgpr-to-vgpr=false"]}
+_MJ = ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-spill-sgpr-to-vgpr=false"]
+FLAGS = {"mujoco_planar_lg.hip": _MJ, "mujoco_gym.hip": _MJ, "mujoco_pusher.hip": _MJ,
+         "mujoco_ant.hip": _MJ + ["-fno-slp-vectorize"]}
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
