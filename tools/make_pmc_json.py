@@ -20,7 +20,10 @@ prefix = sys.argv[1] if len(sys.argv) > 1 else "r1f"
 num_envs = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
-for path in sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}*", "summary.md"))):
+# a prefix that names one pass exactly means that pass only (prof_r5z_cheetah_lg2 must not pull in ..._lg2_32k)
+exact = os.path.join(root, "gpurun_out", f"prof_{prefix}", "summary.md")
+paths = [exact] if os.path.exists(exact) else sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}*", "summary.md")))
+for path in paths:
     text = open(path).read()
     m = re.search(r"## PMC per launch \(mean over launches\): (.+)", text)
     if not m:
