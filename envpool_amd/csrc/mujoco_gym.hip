@@ -383,7 +383,11 @@ class CheetahPool : public Pool {
     // register budget of the lane-group kernel: one wave per SIMD with all 512 registers (default;
     // measured faster at every batch size, profiles/archive/r3f_lane_group_sweep.txt) or two with 256 + spills
     lg_waves_ = (int)cfg.Get("planar_waves", 1) == 2 ? 2 : 1;
-    lpt_ = cfg.Get("planar_lpt", 1) != 0;
+    // longest-first dispatch by the previous launch's timing: on by default for the RK4 models only.  With the
+    // round-5 solver a HalfCheetah chunk's duration no longer says anything about the next one (host model:
+    // correlation 0.06) and the bookkeeping costs more than the order gives: N = 65536 4.05e8 with, 4.14e8 without;
+    // Walker2d 1.733e8 with, 1.720e8 without (profiles/r5ab_lpt_ab.txt)
+    lpt_ = cfg.Get("planar_lpt", walker ? 1 : 0) != 0;
     if (lg_ok_) {
       for (int i = 0; i < 2; ++i) {
         if (hopper && i == 1) break;  // one table: a group of one lane

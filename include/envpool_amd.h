@@ -80,8 +80,9 @@ typedef struct epa_pool epa_pool;
  *                 the robot), 1 the one-env-per-lane kernel on the 9-dof tree with a ghost leg; 2 / 4 refused.
  *   "planar_waves" lane-group kernel with 4 lanes per env: register budget for 1 (default) or 2 waves per SIMD
  *                 (A/B switch; with 1 or 2 lanes per env LDS allows one wave and the key has no effect)
- *   "planar_lpt"  lane-group kernel: 1 (default) whole-pool launches serve the chunks of envs slowest
- *                 first, by their duration in the previous launch; 0 index order.  Never changes results.
+ *   "planar_lpt"  lane-group kernel: 1 whole-pool launches serve the chunks of envs slowest first, by their
+ *                 duration in the previous launch (default for Walker2d / Hopper); 0 index order (default for
+ *                 HalfCheetah since round 5).  Never changes results.
  *   "compute_streams" async mode (batch_size < num_envs): successive batches run on this many
  *                 compute streams (default 4, 1 = one stream), like the reference's worker threads
  *                 step all queued slices in parallel (core/async_envpool.h:116-132).  Pools with the generic
