@@ -851,3 +851,48 @@ def test_lane_group_solver_on_adversarial_states():
                 its.append(it.value)
         assert len(its) > n and worst < 1e-9, (task, worst)
         assert max(its) < 8 * passes, (task, max(its))  # no forward pass anywhere near the cap
+
+
+def test_ant_solver_on_adversarial_states():
+    """The Ant quad kernel's Newton solver (mj_ant4.hip.h: one line-search evaluation per trip, exact search as a
+    fallback from trip 8) far from the benchmark's states: random torso orientation and height (legs deep in the floor ..
+    airborne), joints anywhere, velocities ~ N(0, 4), a garbage warm start ~ N(0, 30).  One env-step from each state,
+    host instantiation (lane quad emulated by Q4<double>) vs the oracle, whose solver searches exactly."""
+    from oracle.orc import Oracle
+
+    h = os.path.join(ROOT, "tests", "cpu_harness")
+    so, src = os.path.join(h, "libant_host.so"), os.path.join(h, "ant_host.cpp")
+    hdrs = [os.path.join(ROOT, "envpool_amd", "csrc", f) for f in
+            ("mj_ant.hip.h", "mj_ant4.hip.h", "mj_quad.hip.h", "mj_ant_model.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(so)
+    rng = np.random.default_rng(12)
+    n, nq, nv, nu = 64, 15, 14, 8
+    orc = Oracle("Ant", n, seed=5, max_episode_steps=1000)
+    orc.reset()
+    worst, its = 0.0, []
+    for rep in range(3):
+        st = orc.get_state()
+        st[:, 2] = rng.uniform(0.15, 0.9, n)
+        quat = rng.normal(0, 1, (n, 4))
+        st[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+        st[:, 7:15] = rng.uniform(-1.2, 1.2, (n, 8))
+        st[:, nq:nq + nv] = rng.normal(0, 4, (n, nv))
+        st[:, nq + nv:nq + 2 * nv] = rng.normal(0, 30, (n, nv))
+        orc.set_state(st)
+        act = rng.uniform(-1, 1, (n, nu))
+        b = orc.step(act)
+        for e in range(n):
+            if b["elapsed_step"][e, 0] == 0 or not np.isfinite(b["obs"][e]).all():
+                continue
+            q, v, w = st[e, :nq].copy(), st[e, nq:nq + nv].copy(), st[e, nq + nv:nq + 2 * nv].copy()
+            qo, vo, wo, it, lag = np.zeros(nq), np.zeros(nv), np.zeros(nv), ctypes.c_int(0), np.zeros(2)
+            args = [x.ctypes.data_as(ctypes.c_void_p) for x in (q, v, w, np.ascontiguousarray(act[e]))]
+            outs = [x.ctypes.data_as(ctypes.c_void_p) for x in (qo, vo, wo)]
+            L.ant_host_step(*args, 5, 0, *outs, lag.ctypes.data_as(ctypes.c_void_p), ctypes.byref(it))
+            ref, got = b["obs"][e], np.concatenate([qo[2:], vo])
+            worst = max(worst, (np.abs(got - ref) / (1 + np.abs(ref))).max())
+            its.append(it.value)
+    assert len(its) > n and worst < 1e-9, worst
+    assert max(its) < 8 * 20, max(its)  # 20 forward passes per env-step: none anywhere near the cap of 50 trips
