@@ -55,7 +55,7 @@
 #define EPA_LG_TICK(cx, K) ((void)0)
 #define EPA_LG_COUNT(cx, K) ((void)0)
 #endif
-// host experiments only (tools/lg_solver_stats.py): per Newton trip of one env, the line-search evaluations it ran
+// host experiments only (tools/lg_desync/rollout_host.cpp, tools/lg_desync_sim.py): per Newton trip of one env, the line-search evaluations it ran
 #ifndef EPA_LG_HOST_TRIP
 #define EPA_LG_HOST_TRIP(evals) ((void)0)
 #endif
