@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import collections
 import ctypes
+import threading
 from dataclasses import dataclass, field
 from typing import Any, Callable, Sequence
 
@@ -70,6 +71,9 @@ COMMON_CONFIG: list[tuple[str, Any]] = [
 EXTENSION_CONFIG: list[tuple[str, Any]] = [
     ("device", 0),          # HIP device ordinal, or a list of ordinals to shard over
     ("env_id_offset", 0),   # global id of local env 0 (one shard of a bigger pool)
+    # how long recv() waits for rows nobody has sent yet: -1 forever, like the reference's blocking Recv
+    # (async_envpool.h:169-181), 0 raise RuntimeError at once, > 0 raise after that many milliseconds
+    ("recv_timeout_ms", -1),
 ]
 COMMON_ACTION_SPEC = [
     ("env_id", spec(np.int32, [])),
@@ -135,6 +139,9 @@ class _ShardedPools:
         ]
         self.state_keys = self.pools[0].state_keys
         self._pending: collections.deque = collections.deque()
+        # recv() blocks until a send / reset has been split over the shards (a consumer thread may arrive first)
+        self._cv = threading.Condition()
+        self._timeout_ms = float((kw.get("params") or {}).get("recv_timeout_ms", -1))
         # one host thread per GPU: the C ABI calls release the GIL (ctypes)
         self._exec = concurrent.futures.ThreadPoolExecutor(len(self.pools))
         self._blocks = self.pools[0]._blocks
@@ -164,18 +171,24 @@ class _ShardedPools:
         action = np.asarray(action)
         parts, grouped = self._split(env_id)
         self._each(lambda s, p, part: p.send(env_id[part], action[part]), parts)
-        self._pending.append((len(env_id), parts, grouped))
+        with self._cv:
+            self._pending.append((len(env_id), parts, grouped))
+            self._cv.notify_all()
 
     def reset(self, env_ids: np.ndarray) -> None:
         env_ids = np.ascontiguousarray(env_ids, dtype=np.int32)
         parts, grouped = self._split(env_ids)
         self._each(lambda s, p, part: p.reset(env_ids[part]), parts)
-        self._pending.append((len(env_ids), parts, grouped))
+        with self._cv:
+            self._pending.append((len(env_ids), parts, grouped))
+            self._cv.notify_all()
 
     def recv(self) -> list[np.ndarray]:
-        if not self._pending:
-            raise RuntimeError("recv: nothing pending")
-        k, parts, grouped = self._pending.popleft()
+        with self._cv:
+            timeout = None if self._timeout_ms < 0 else self._timeout_ms / 1000.0
+            if not self._cv.wait_for(lambda: bool(self._pending), timeout):
+                raise RuntimeError(f"recv: nothing pending (recv_timeout_ms = {self._timeout_ms:g})")
+            k, parts, grouped = self._pending.popleft()
         if not grouped:
             outs = [np.empty((k, *shape), dtype=dtype) for _, dtype, shape in self.state_keys]
 
@@ -282,6 +295,8 @@ def make_native_classes(fd: FamilyDef, static_action_spec: list | None = None) -
             if conf["max_num_players"] != 1:
                 raise ValueError("only single-player envs are on the MI355X path")
             params = {k: float(v) for k, v in fd.native_params(conf).items()}
+            if conf["recv_timeout_ms"] != -1:
+                params["recv_timeout_ms"] = float(conf["recv_timeout_ms"])
             kw = dict(
                 batch_size=conf["batch_size"],
                 seed=conf["seed"],

@@ -222,9 +222,10 @@ class DevicePool:
         return [int(p) if p else 0 for p in ptrs], k.value
 
     def step_device(self, d_action: int | None, k: int | None = None, d_env_id: int | None = None,
-                    wait_event: int | None = None) -> tuple[list[int], int]:
+                    wait_event: int | None = None) -> tuple[tuple[int, ...], int]:
         """send_device + recv_device in one library call (the sync `step()` of the device path).  A pool hands out
-        its result blocks in rotation, so the pointer lists are cached per block."""
+        its result blocks in rotation, so the pointer tuples are cached per block (immutable: the same object is
+        returned for every step on that block)."""
         k = self.num_envs if k is None else int(k)
         n = len(self.state_keys)
         if self._step_ptrs is None:
@@ -236,7 +237,7 @@ class DevicePool:
         key = (ptrs[0], ptrs[n - 1])  # first and last section: the block and its layout
         out = self._step_cache.get(key)
         if out is None:
-            out = self._step_cache[key] = [int(p) if p else 0 for p in ptrs]
+            out = self._step_cache[key] = tuple(int(p) if p else 0 for p in ptrs)
         return out, self._step_k.value
 
     @property

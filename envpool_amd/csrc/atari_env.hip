@@ -429,15 +429,19 @@ class AtariPool : public Pool {
 
   OutBatch* WaitFront() {
     std::unique_lock<std::mutex> lk(b_mu_);
-    if (sync_) {
-      if (out_queue_.empty()) throw std::runtime_error("recv: nothing pending");
-    } else if (inflight_ < batch_size_) {
-      // fewer envs are stepping than a batch holds: the reference would block forever
-      throw std::runtime_error("recv: fewer than batch_size envs in flight");
-    }
-    done_cv_.wait(lk, [&] {
+    auto ready = [&] {
       return !out_queue_.empty() && out_queue_.front()->finished.load() >= out_queue_.front()->rows;
-    });
+    };
+    // blocks like the reference's Recv (async_envpool.h:169-181): a consumer thread may arrive before the
+    // producer's send; engine key "recv_timeout_ms" as in Pool::WantRows (engine.hip)
+    const int timeout = (int)cfg_.Get("recv_timeout_ms", -1);
+    const bool can_finish = sync_ ? !out_queue_.empty() : inflight_ >= batch_size_;
+    if (timeout < 0 || can_finish) {
+      done_cv_.wait(lk, ready);
+    } else if (timeout == 0 || !done_cv_.wait_for(lk, std::chrono::milliseconds(timeout), ready)) {
+      throw std::runtime_error(sync_ ? "recv: nothing pending"
+                                     : "recv: fewer than batch_size envs in flight");
+    }
     return out_queue_.front();
   }
   int PopFront() {

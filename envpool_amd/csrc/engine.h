@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
 #include <deque>
@@ -200,8 +201,12 @@ class Pool {
   CommonDev common_{};
 
  private:
-  int WantRows();  // rows the next Recv returns (validates the pending queue)
-  void CopyRowsToHost(char* dst, const std::vector<size_t>& off, int want);
+  // Rows the next Recv returns.  BLOCKS (mu_ released) until that many rows are pending -- AsyncEnvPool::Recv /
+  // StateBufferQueue::Wait of the reference block on a semaphore (envpool/core/async_envpool.h:169-181,
+  // state_buffer_queue.h:148-163), so a consumer thread may call recv before the producer's send.  Engine key
+  // "recv_timeout_ms": < 0 (default) wait forever like the reference, 0 raise at once, > 0 raise after that long.
+  int WantRows(std::unique_lock<std::mutex>& lk);
+  void CopyRowsToHost(char* dst, const std::vector<size_t>& off, int want, std::unique_lock<std::mutex>& lk);
   Batch* AcquireBatch(int k);
   void ReleaseBatch(Batch* b);
   OutPtrs PtrsOf(const Batch& b) const;
@@ -232,6 +237,9 @@ class Pool {
   int* stack_head_{nullptr};     // [N] slot holding the oldest frame
   double* stack_tmp_{nullptr};   // [N][nobs] un-stacked obs of the current launch
   std::mutex mu_;
+  std::mutex recv_mu_;               // recv is single-consumer (state_buffer_queue.h:143-147): callers are serialised
+  std::condition_variable pending_cv_;  // signalled by Enqueue; WantRows waits on it
+  int recv_timeout_ms_{-1};
   std::deque<Batch*> pending_;
   std::vector<std::vector<Batch*>> free_;  // per compute stream
   std::vector<std::unique_ptr<Batch>> all_;

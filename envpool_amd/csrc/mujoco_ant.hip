@@ -41,7 +41,7 @@ struct AntDev {
   double* lag;   // [2][N]
   double* nsaved;
   unsigned char* navail;
-  double* cost;  // [N] profiling: Newton iterations of the last step, see AntGetState
+  double* cost;  // [N] Newton iterations of the last step (the sort key of the next launch), see AntGetState
   // diagnostic (EPA_ANT_TRACE=<file>): per wave of the last launch {wall clock begin, end
   // (100 MHz), core clock begin, end, slot, HW_ID}; nullptr otherwise
   long long* trace;
@@ -67,35 +67,97 @@ constexpr int kAntEnvsPerBlock = kAntBlock / 4;
 template <typename T>
 constexpr int kAntWavesPerEu = sizeof(T) == 4 ? 2 : 1;
 
+// ---- the work queue -------------------------------------------------------------------------
+// A launch is a queue of UNITS served by persistent waves (grid = the waves resident at once; tickets from one
+// device counter).  A unit is (chunk of 16 rows, `sub` consecutive mj_steps of the env-step): with sub = 1 an
+// env-step of a chunk is frame_skip units of ~1/5 of the work, and the state of the chunk's envs goes through HBM
+// between them (43 numbers per env: nothing next to 4e5 flops per mj_step).  Why: a wave runs as long as the
+// slowest of its 16 envs in every one of the 20 forward passes, a chunk's env-step lasts 0.5 ms on average and
+// 1.1 ms at worst, and with whole env-steps as the unit of work (round 2-5: one block per chunk) the launch at
+// N = 32768 -- two chunks per SIMD -- ended with a few long waves running alone: 1.45 ms where the sum of the wave
+// durations / 1024 SIMDs is 1.04.  Units are handed out substep-major (every chunk's units of substep range 0,
+// then range 1, ...) so that what is left at the end of the launch is short units.  Unit (c, j + 1) reads what
+// (c, j) wrote, maybe on another XCD: (c, j) publishes `progress[c] = epoch + j + 1` behind a device-scope fence
+// and the taker of (c, j + 1) -- a LATER ticket, so (c, j) is running or done: no deadlock, every ticket is taken
+// with the atomic by a wave that is resident -- waits for it.
+// Rows are dealt to chunks through `perm`: most expensive first by the Newton iterations the env needed in its
+// previous env-step (AntSortKernel; persistence 0.64), so that the 16 envs of a wave need similar numbers of
+// trips (a wave executes the max) and the long units start first.  Results do not depend on either: an env's
+// arithmetic never involves another env, and the output row of an env is its row of the send.
+struct AntArgs {
+  AntDev dev;
+  CommonDev cm;
+  StepArgs a;
+  const double* action;
+  OutPtrs out;
+  AntTask task;
+  unsigned* ticket;
+  unsigned ticket_base;
+  int nchunks;           // ceil(k / 16)
+  int sub;               // mj_steps per unit
+  int units_per_chunk;   // ceil(frame_skip / sub)
+  const int* perm;       // [k] row served at position p (nullptr: p)
+  unsigned char* rowflag;  // [k] 1: the row was a reset row of this launch (units after the first skip it)
+  unsigned* progress;    // [nchunks] epoch + units of the chunk completed
+  unsigned epoch;
+  int max_iter;          // mj::SolverCfg
+  double gtol;
+};
+using AntArgsK = const __attribute__((address_space(4))) AntArgs;
+#if defined(__HIP_DEVICE_COMPILE__)
+// the kernel's arguments re-read from the kernarg segment per unit (see mujoco_planar_lg.hip, KernArgs): as
+// by-value parameters they would be loop invariants of the persistent loop held in SGPRs across the solver
+__device__ __forceinline__ AntArgsK* AntKernArgs() {
+  AntArgsK* p = (AntArgsK*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+#endif
+
+// One unit: mj_steps [s0, s1) of the env-step of the rows at positions 16 ci .. 16 ci + 15.
 // kWrench: the Ant-v5 variant that also evaluates cfrc_ext (separate instantiation
 // so that Ant-v3/v4 do not pay registers for the extra pass)
 template <typename T, bool kWrench>
-__global__ __launch_bounds__(kAntBlock)
-__attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void AntStepKernel(
-    AntDev dev, CommonDev cm, StepArgs a, const double* __restrict__ action, OutPtrs out,
-    AntTask task, mj::SolverCfg<T> scfg) {
+__device__ __forceinline__ void AntUnit(int ci, int s0, int s1, T* lds_buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // The kernel arguments are read from the kernarg segment where they are used, before AND again after the physics
+  // (486 of the 512 registers are its own, and SGPRs held across it spill): `ap` is refreshed behind a barrier the
+  // optimiser cannot see through, and nothing per-row -- the row, its env, the output pointers -- stays live either.
+  AntArgsK* ap = AntKernArgs();
+#define task (ap->task)
+#define out (ap->out)
+// WriteState, ant.h:231-278: obs = qpos[skip:] ++ qvel ++ clamped cfrc_ext
+#define cf0 (task.exclude_worldbody ? 6 : 0)
+#define ncf (task.use_contact_force ? kAntMjBodies * 6 - cf0 : 0)
+#define nobs (A::kNQ + A::kNV - task.obs_skip + ncf)
   constexpr A::AntModel<T> m = A::CastAntModel<T>(kAntModelConst);
-  // the wave's LDS block: quad-shared and lane-private slots (mj_ant4.hip.h, LdsOffset): local M,
-  // the contact geometry and the contact constants of the current forward pass
-  __shared__ T lds_buf[A4::kLdsElems];
+  const mj::SolverCfg<T> scfg{ap->max_iter, (T)ap->gtol};
   const int lane = threadIdx.x;
   const int l = lane & 3;  // the leg this lane owns
+  if (ci * kAntEnvsPerBlock + (lane >> 2) >= ap->a.k) return;  // whole quads leave together
+  const bool first_unit = s0 == 0;
+  T q[9], v[A4::kL], w[A4::kL], ctrl[2];
+  {
+  const AntDev dev = ap->dev;
+  const CommonDev cm = ap->cm;
+  const StepArgs a = ap->a;
   const int n = cm.n;
-  const int row = blockIdx.x * kAntEnvsPerBlock + (lane >> 2);
-  if (row >= a.k) return;  // whole quads leave together
+  const int pos = ci * kAntEnvsPerBlock + (lane >> 2);
+  const bool last_unit = s1 >= task.frame_skip;
+  const int row = ap->perm ? ap->perm[pos] : pos;
   const int e = a.ids ? a.ids[row] - a.id_offset : row;
-  bool done = cm.done[e] != 0;
-  int cur = cm.cur_step[e];
-  const bool reset = a.force_reset || done;
-  // WriteState, ant.h:231-278: obs = qpos[skip:] ++ qvel ++ clamped cfrc_ext
-  const int cf0 = task.exclude_worldbody ? 6 : 0;
-  const int ncf = task.use_contact_force ? kAntMjBodies * 6 - cf0 : 0;
-  const int nobs = A::kNQ + A::kNV - task.obs_skip + ncf;
-  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
-  double* obs_v = obs + A::kNQ - task.obs_skip;
-  double* obs_c = obs_v + A::kNV;
+  bool reset;
+  if (first_unit) {
+    reset = a.force_reset || cm.done[e] != 0;
+    if (!last_unit && l == 0) ap->rowflag[row] = reset ? 1 : 0;
+  } else {
+    reset = ap->rowflag[row] != 0;
+  }
   if (reset) {
-    if (l != 0) return;  // the RNG stream of an env is sequential: its first lane draws
+    if (!first_unit || l != 0) return;  // the RNG stream of an env is sequential: its first lane draws
+    double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
+    double* obs_v = obs + A::kNQ - task.obs_skip;
+    double* obs_c = obs_v + A::kNV;
     // MujocoReset (mujoco_env.h:126-131) + MujocoResetModel (ant.h:135-147)
     double qpos[A::kNQ], qvel[A::kNV];
     Mt19937 g(cm, e);
@@ -139,9 +201,7 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
     WriteCommon(out, row, e + a.id_offset, 0, false, 0.0f, a.max_episode_steps);
     return;
   }
-  ++cur;
   // lane layout: q = torso pose (7) + hip, ankle of leg l; v, w likewise (6 + 2)
-  T q[9], v[A4::kL], w[A4::kL], ctrl[2];
   mj::static_for<0, 7>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     q[i] = (T)dev.qpos[(size_t)i * n + e];
@@ -157,14 +217,14 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
     v[6 + c] = (T)dev.qvel[(size_t)(6 + 2 * l + c) * n + e];
     w[6 + c] = (T)dev.warm[(size_t)(6 + 2 * l + c) * n + e];
   });
-  const double x_before = dev.lag[e], y_before = dev.lag[(size_t)n + e];
-  const double* act = action + (size_t)row * A::kNU;
+  const double* act0 = ap->action + (size_t)row * A::kNU;
   // ctrl[u] drives dof CtrlDof(u): hip_4 ankle_4 hip_1 ankle_1 hip_2 ... (ant_envpool.xml:85-94)
   mj::static_for<0, 2>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
-    const double ai = act[(2 + 2 * l + c) & 7];
+    const double ai = act0[(2 + 2 * l + c) & 7];
     ctrl[c] = (T)(ai < -1.0 ? -1.0 : (ai > 1.0 ? 1.0 : ai));
   });
+  }
   A4::Leg<T, bool> lg;
   lg.sx = (l == 0 || l == 3) ? T(1) : T(-1);
   lg.sy = l < 2 ? T(1) : T(-1);
@@ -187,11 +247,24 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
   const long long t_begin = clock64();
   const long long w_begin = wall_clock64();
 #endif
-  for (int s = 0; s < task.frame_skip; ++s) {
+  for (int s = s0; s < s1; ++s) {
     A4::Step<unsigned, kWrench>(m, lg, scfg, q, v, w, ctrl, &lagx, &lagy, lds,
                                 kWrench && s == task.frame_skip - 1, cf, cft, &n_env, &n_wave);
   }
-  const double x_after = (double)lagx, y_after = (double)lagy;
+  ap = AntKernArgs();
+  const AntDev dev = ap->dev;
+  const CommonDev cm = ap->cm;
+  const StepArgs a = ap->a;
+  const int n = cm.n;
+  const bool last_unit = s1 >= task.frame_skip;
+  int pos2 = ci * kAntEnvsPerBlock + (lane >> 2);
+  asm volatile("" : "+v"(pos2));
+  const int row = ap->perm ? ap->perm[pos2] : pos2;
+  const int e = a.ids ? a.ids[row] - a.id_offset : row;
+  double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
+  double* obs_v = obs + A::kNQ - task.obs_skip;
+  double* obs_c = obs_v + A::kNV;
+  const double* act = ap->action + (size_t)row * A::kNU;
   // new state; IsHealthy, ant.h:214-229
   bool healthy = true;
   mj::static_for<0, 2>([&](auto cc) {
@@ -201,9 +274,39 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
     dev.qpos[(size_t)(7 + 2 * l + c) * n + e] = qq;
     dev.qvel[(size_t)(6 + 2 * l + c) * n + e] = vv;
     dev.warm[(size_t)(6 + 2 * l + c) * n + e] = (double)w[6 + c];
-    if (7 + 2 * l + c >= task.obs_skip) obs[7 + 2 * l + c - task.obs_skip] = qq;
-    obs_v[6 + 2 * l + c] = vv;
+    if (last_unit) {
+      if (7 + 2 * l + c >= task.obs_skip) obs[7 + 2 * l + c - task.obs_skip] = qq;
+      obs_v[6 + 2 * l + c] = vv;
+    }
   });
+  // this env's Newton iterations + 1e4 x (those its wave executed + 1e3 x sphere classes visited)
+  // + 1e10 x thousands of core clocks the wave spent in the physics; summed over the units of the env-step
+  double cost = (double)n_env + 1.0e4 * (double)(n_wave % 1000000);
+#ifdef EPA_WAVE_TRACE
+  cost += 1.0e10 * (double)((clock64() - t_begin) / 1000);
+  if (dev.trace && lane == 0 && first_unit) {
+    long long* tr = dev.trace + (size_t)ci * 6;
+    tr[0] = w_begin;
+    tr[1] = wall_clock64();
+    tr[2] = t_begin;
+    tr[3] = clock64();
+    tr[4] = ci * kAntEnvsPerBlock;
+    tr[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+  }
+#endif
+  if (!last_unit) {  // the state goes through HBM to the wave that takes the chunk's next unit
+    if (l != 0) return;
+    mj::static_for<0, 7>([&](auto ic) { dev.qpos[(size_t)decltype(ic)::value * n + e] = (double)q[decltype(ic)::value]; });
+    mj::static_for<0, 6>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      dev.qvel[(size_t)i * n + e] = (double)v[i];
+      dev.warm[(size_t)i * n + e] = (double)w[i];
+    });
+    dev.cost[e] = (first_unit ? 0.0 : dev.cost[e]) + cost;
+    return;
+  }
+  const double x_before = dev.lag[e], y_before = dev.lag[(size_t)n + e];
+  const double x_after = (double)lagx, y_after = (double)lagy;
   mj::static_for<0, 7>([&](auto ic) { healthy = healthy && isfinite((double)q[decltype(ic)::value]); });
   mj::static_for<0, 6>([&](auto ic) { healthy = healthy && isfinite((double)v[decltype(ic)::value]); });
   healthy = mj::All4(healthy);
@@ -266,21 +369,8 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
   });
   dev.lag[e] = x_after;
   dev.lag[(size_t)n + e] = y_after;
-  // this env's Newton iterations + 1e4 x (those its wave executed + 1e3 x sphere classes visited)
-  // + 1e10 x thousands of core clocks the wave spent in the physics
-  dev.cost[e] = (double)n_env + 1.0e4 * (double)(n_wave % 1000000);
-#ifdef EPA_WAVE_TRACE
-  dev.cost[e] += 1.0e10 * (double)((clock64() - t_begin) / 1000);
-  if (dev.trace && lane == 0) {
-    long long* tr = dev.trace + (size_t)blockIdx.x * 6;
-    tr[0] = w_begin;
-    tr[1] = wall_clock64();
-    tr[2] = t_begin;
-    tr[3] = clock64();
-    tr[4] = row;
-    tr[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
-  }
-#endif
+  dev.cost[e] = (first_unit ? 0.0 : dev.cost[e]) + cost;
+  const int cur = cm.cur_step[e] + 1;
   double ctrl_cost = 0.0;
   for (int i = 0; i < A::kNU; ++i) ctrl_cost += task.ctrl_cost_weight * act[i] * act[i];  // ant.h:176-179
   const double xv = (x_after - x_before) / task.dt;
@@ -290,7 +380,7 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
   const double healthy_reward = give ? task.healthy_reward : 0.0;
   const float reward = static_cast<float>(xv * task.forward_reward_weight + healthy_reward -
                                           ctrl_cost - contact_cost);
-  done = (task.terminate_when_unhealthy ? !healthy : false) || (cur >= a.max_episode_steps);
+  const bool done = (task.terminate_when_unhealthy ? !healthy : false) || (cur >= a.max_episode_steps);
   const double info[9] = {xv * task.forward_reward_weight, -ctrl_cost, -contact_cost,
                           healthy_reward, x_after, y_after,
                           sqrt(x_after * x_after + y_after * y_after), xv, yv};
@@ -298,6 +388,98 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
   cm.cur_step[e] = cur;
   for (int i = 0; i < 9; ++i) ((double*)out.p[kKeyEnv0 + 1 + i])[row] = info[i];
   WriteCommon(out, row, e + a.id_offset, cur, done, reward, a.max_episode_steps);
+#undef task
+#undef out
+#undef cf0
+#undef ncf
+#undef nobs
+#endif
+}
+
+// waves per SIMD the register allocator targets: fp64 needs the whole 512-entry file
+// (486 registers, no scratch); fp32 fits two waves (25 spilled registers) and gains 50 %
+// from the second wave (profiles/archive/r2b: 1.94e7 -> 2.93e7 env-steps/s at N=32768)
+template <typename T, bool kWrench>
+__global__ __launch_bounds__(kAntBlock)
+__attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void AntStepKernel(AntArgs args) {
+  // the wave's LDS block: quad-shared and lane-private slots (mj_ant4.hip.h, LdsOffset): local M,
+  // the contact geometry and the contact constants of the current forward pass
+  __shared__ T lds_buf[A4::kLdsElems];
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (;;) {
+    AntArgsK* ap = AntKernArgs();
+    unsigned t = 0;
+    if (threadIdx.x == 0) t = atomicAdd(ap->ticket, 1u);
+    const int u = (int)((unsigned)__builtin_amdgcn_readfirstlane(t) - ap->ticket_base);
+    if (u >= ap->nchunks * ap->units_per_chunk) break;
+    const int j = u / ap->nchunks, ci = u - j * ap->nchunks;  // substep-major
+    if (j > 0) {  // the chunk's previous unit: a lower ticket, so it is running or done
+      const unsigned want = ap->epoch + (unsigned)j;
+      if (threadIdx.x == 0) {
+        while ((int)(__hip_atomic_load(&ap->progress[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+          __builtin_amdgcn_s_sleep(16);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    const int s0 = j * ap->sub;
+    const int s1 = s0 + ap->sub;
+    AntUnit<T, kWrench>(ci, s0, s1, lds_buf);
+    ap = AntKernArgs();
+    if (j + 1 < ap->units_per_chunk) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the wave's state stores, before the flag
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(&ap->progress[ci], ap->epoch + (unsigned)j + 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+#endif
+}
+
+// Rows in descending order of predicted cost: a stable counting sort on the Newton iterations the env needed in
+// its previous env-step (dev.cost; own iterations = the part below 1e4).  One block; see Hum4SortKernel.
+constexpr int kAntSortThreads = 256, kAntSortBuckets = 32;
+__device__ __forceinline__ int AntCostBucket(double cost) {
+  const double w = floor(cost * 1.0e-4);
+  const int it = (int)(cost - 1.0e4 * w);  // own Newton iterations over the 20 forward passes
+  const int b = (it - 16) >> 1;            // 16 .. 80 iterations in steps of 2
+  return b < 0 ? 0 : (b > kAntSortBuckets - 1 ? kAntSortBuckets - 1 : b);
+}
+__global__ __launch_bounds__(kAntSortThreads) void AntSortKernel(AntDev dev, StepArgs a, int* perm) {
+  __shared__ int cnt[kAntSortBuckets][kAntSortThreads + 1];
+  __shared__ int base[kAntSortBuckets + 1];
+  const int t = threadIdx.x;
+  const int chunk = (a.k + kAntSortThreads - 1) / kAntSortThreads;
+  const int lo = t * chunk, hi = lo + chunk < a.k ? lo + chunk : a.k;
+  for (int b = 0; b < kAntSortBuckets; ++b) cnt[b][t] = 0;
+  for (int r = lo; r < hi; ++r) {
+    const int e = a.ids ? a.ids[r] - a.id_offset : r;
+    ++cnt[AntCostBucket(dev.cost[e])][t];
+  }
+  __syncthreads();
+  // exclusive scan over threads, per bucket (thread b scans bucket b: 256 adds)
+  if (t < kAntSortBuckets) {
+    int run = 0;
+    for (int i = 0; i < kAntSortThreads; ++i) {
+      const int v = cnt[t][i];
+      cnt[t][i] = run;
+      run += v;
+    }
+    base[t + 1] = run;
+  }
+  __syncthreads();
+  if (t == 0) {
+    base[0] = 0;
+    for (int b = 0; b < kAntSortBuckets; ++b) base[b + 1] += base[b];
+  }
+  __syncthreads();
+  // most expensive bucket first: the long units start early, the short ones fill the tail
+  for (int r = lo; r < hi; ++r) {
+    const int e = a.ids ? a.ids[r] - a.id_offset : r;
+    const int b = AntCostBucket(dev.cost[e]);
+    perm[(a.k - base[b + 1]) + cnt[b][t]++] = r;
+  }
 }
 
 // flat state like oracle/mjcpu: qpos[15] qvel[14] warm[14] time xlag ylag done
@@ -370,6 +552,13 @@ class AntPool : public Pool {
     task_.contact_force_min = cfg.Get("contact_force_min", -1.0);
     task_.contact_force_max = cfg.Get("contact_force_max", 1.0);
     fp64_ = (int)cfg.Get("precision", 1) == 1;
+    sub_ = (int)cfg.Get("ant_sub", 1);
+    sort_ = cfg.Get("ant_sort", 1) != 0;
+    {
+      hipDeviceProp_t prop;
+      EPA_HIP(hipGetDeviceProperties(&prop, cfg.device));
+      wave_slots_ = prop.multiProcessorCount * 4;
+    }
     model_ = A::BuildAntModel();
     task_.frame_skip = (int)cfg.Get("frame_skip", 5);
     task_.obs_skip = cfg.Get("exclude_current_positions_from_observation", 1) != 0 ? 2 : 0;
@@ -382,6 +571,7 @@ class AntPool : public Pool {
     task_.healthy_z_max = cfg.Get("healthy_z_max", 1.0);
     task_.reset_noise_scale = cfg.Get("reset_noise_scale", 0.1);
     task_.dt = task_.frame_skip * model_.timestep;
+    if (sub_ < 1 || sub_ > task_.frame_skip) sub_ = task_.frame_skip;
     size_t n = cfg.num_envs;
     EPA_HIP(hipMalloc(&dev_.qpos, sizeof(double) * A::kNQ * n));
     EPA_HIP(hipMalloc(&dev_.qvel, sizeof(double) * A::kNV * n));
@@ -412,6 +602,12 @@ class AntPool : public Pool {
     (void)hipFree(dev_.navail);
     trace_.DumpAndFree();
     (void)hipFree(dev_.cost);
+    for (auto& kv : queues_) {
+      (void)hipFree(kv.second.ticket);
+      (void)hipFree(kv.second.perm);
+      (void)hipFree(kv.second.rowflag);
+      (void)hipFree(kv.second.progress);
+    }
   }
   int StateDim() const override { return kAntStateDim; }
   void GetState(const int* d_ids, int k, double* d_out) override {
@@ -427,23 +623,70 @@ class AntPool : public Pool {
   void Launch(const int* d_ids, int k, const void* d_action, bool force_reset,
               const OutPtrs& out) override {
     StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps, cfg_.env_id_offset};
-    int blocks = (k + kAntEnvsPerBlock - 1) / kAntEnvsPerBlock;
-    const double* act = static_cast<const double*>(d_action);
-    const mj::SolverCfg<double> sd{50, 1e-13};
-    const mj::SolverCfg<float> sf{12, 1e-6f};
+    // launches on different streams run concurrently (async mode): a queue and its scratch each
+    Queue& qu = queues_[stream_];
+    if (qu.ticket == nullptr) {
+      const size_t n = (size_t)cfg_.num_envs, nch = (n + kAntEnvsPerBlock - 1) / kAntEnvsPerBlock;
+      EPA_HIP(hipMalloc(&qu.ticket, sizeof(unsigned)));
+      EPA_HIP(hipMalloc(&qu.perm, sizeof(int) * n));
+      EPA_HIP(hipMalloc(&qu.rowflag, n));
+      EPA_HIP(hipMalloc(&qu.progress, sizeof(unsigned) * nch));
+      EPA_HIP(hipMemsetAsync(qu.ticket, 0, sizeof(unsigned), stream_));
+      EPA_HIP(hipMemsetAsync(qu.progress, 0, sizeof(unsigned) * nch, stream_));
+    }
+    AntArgs args{};
+    args.dev = dev_;
+    args.cm = common_;
+    args.a = a;
+    args.action = static_cast<const double*>(d_action);
+    args.out = out;
+    args.task = task_;
+    args.nchunks = (k + kAntEnvsPerBlock - 1) / kAntEnvsPerBlock;
+    // a reset launch has nothing to balance: one unit per chunk, rows in order
+    args.sub = force_reset ? task_.frame_skip : sub_;
+    args.units_per_chunk = (task_.frame_skip + args.sub - 1) / args.sub;
+    args.rowflag = qu.rowflag;
+    args.progress = qu.progress;
+    args.epoch = qu.epoch;
+    qu.epoch += (unsigned)args.units_per_chunk + 1u;
+    args.max_iter = fp64_ ? 50 : 12;
+    args.gtol = fp64_ ? 1e-13 : 1e-6;
+    args.perm = nullptr;
+    // cost order pays when chunks queue for waves; a wave of a small batch starts at once whatever its place
+    const int resident = wave_slots_ * (fp64_ ? 1 : 2);
+    if (sort_ && !force_reset && args.nchunks > resident) {
+      hipLaunchKernelGGL(AntSortKernel, dim3(1), dim3(kAntSortThreads), 0, stream_, dev_, a, qu.perm);
+      args.perm = qu.perm;
+    }
+    const int units = args.nchunks * args.units_per_chunk;
+    const int blocks = units < resident ? units : resident;
+    args.ticket = qu.ticket;
+    args.ticket_base = qu.base;
+    qu.base += (unsigned)(units + blocks);  // every wave takes one ticket past the end
     const bool wrench = task_.use_contact_force && task_.post_constraint;
-#define EPA_LAUNCH_ANT(T, W, SC)                                                          \
-  hipLaunchKernelGGL((AntStepKernel<T, W>), dim3(blocks), dim3(kAntBlock), 0, stream_, dev_, \
-                     common_, a, act, out, task_, SC)
+#define EPA_LAUNCH_ANT(T, W) \
+  hipLaunchKernelGGL((AntStepKernel<T, W>), dim3(blocks), dim3(kAntBlock), 0, stream_, args)
     if (fp64_) {
-      if (wrench) EPA_LAUNCH_ANT(double, true, sd); else EPA_LAUNCH_ANT(double, false, sd);
+      if (wrench) EPA_LAUNCH_ANT(double, true); else EPA_LAUNCH_ANT(double, false);
     } else {
-      if (wrench) EPA_LAUNCH_ANT(float, true, sf); else EPA_LAUNCH_ANT(float, false, sf);
+      if (wrench) EPA_LAUNCH_ANT(float, true); else EPA_LAUNCH_ANT(float, false);
     }
 #undef EPA_LAUNCH_ANT
   }
 
  private:
+  struct Queue {
+    unsigned* ticket{nullptr};
+    unsigned base{0};
+    int* perm{nullptr};
+    unsigned char* rowflag{nullptr};
+    unsigned* progress{nullptr};
+    unsigned epoch{1};
+  };
+  std::map<hipStream_t, Queue> queues_;
+  int wave_slots_{1024};  // SIMDs of the device
+  int sub_{1};            // "ant_sub": mj_steps per unit of the work queue
+  bool sort_{true};       // "ant_sort": rows dealt to chunks in descending order of predicted cost
   AntDev dev_{};
   WaveTrace trace_;
   A::AntModel<double> model_;

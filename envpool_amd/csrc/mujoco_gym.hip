@@ -460,8 +460,9 @@ class CheetahPool : public Pool {
       // longest-chunk-first dispatch: whole-pool batches only (the chunks are then the same envs
       // from launch to launch); "planar_lpt" = 0 switches it off (A/B)
       planar::LgOrder lo;
-      if (lpt_ && d_ids == nullptr && !force_reset) {
-        const int nchunks = k;  // (only its sameness from launch to launch matters here)
+      const bool chain = lpt_ && d_ids == nullptr && !force_reset;
+      const int shape = k * 16 + layout;  // (only its sameness from launch to launch matters)
+      if (chain) {
         if (order_.d == nullptr) {
           order_.cap = (cfg_.num_envs + 3) / 4;  // the smallest chunk is a quarter wave of 4 lanes per env
           EPA_HIP(hipMalloc(&order_.d, PlanarLgOrderBytes(order_.cap)));
@@ -469,19 +470,25 @@ class CheetahPool : public Pool {
           order_.gen = 0;
           order_shape_ = -1;
         }
-        const int shape = nchunks * 16 + layout;
         order_.use = (shape == order_shape_ && order_stream_ == stream_) ? 1 : 0;
         lo = order_;
+      }
+      const bool lg1 = layout == kLayoutHopperLg;  // lanes per env: 1 (Hopper), 2 or 4
+      const bool filed =
+          PlanarLgLaunch(stream_, lg1 ? 1 : layout, lg_waves_, model_id_, wave_slots_, spread_ && !async_, dev_, common_,
+                         a, static_cast<const double*>(d_action), out, task_, d_tab_[(lg1 || layout == 2) ? 0 : 1], tk.d,
+                         &tk.base, lo);
+      // A generation is advanced only by a launch that filed its chunks into gen + 1 AND cleared gen + 2 (the
+      // kernel skips both while chunks do not queue for waves): every increment comes with a clear, or a later
+      // launch would file into a buffer that still holds an older launch's chunk lists (chunks dispatched twice /
+      // never).  Any other launch breaks the chain of same-shape launches.
+      if (chain && filed) {
         ++order_.gen;
         order_shape_ = shape;
         order_stream_ = stream_;
       } else {
-        order_shape_ = -1;  // the chain of same-shape launches is broken
+        order_shape_ = -1;
       }
-      const bool lg1 = layout == kLayoutHopperLg;  // lanes per env: 1 (Hopper), 2 or 4
-      PlanarLgLaunch(stream_, lg1 ? 1 : layout, lg_waves_, model_id_, wave_slots_, spread_ && !async_, dev_, common_, a,
-                     static_cast<const double*>(d_action), out, task_, d_tab_[(lg1 || layout == 2) ? 0 : 1], tk.d,
-                     &tk.base, lo);
       return;
     }
     int lanes = kCheetahBlock;

@@ -76,7 +76,9 @@ struct LgOrder {
 // `wave_slots`: SIMDs of the device; `ticket` / `ticket_base`: the chunk queue's device counter and the
 // host's copy of its value (one pair per stream that launches concurrently, see PlanarLgStepKernel)
 // spread: partly filled waves while there are fewer full chunks than resident waves ("planar_spread")
-void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots, bool spread,
+// Returns whether the launch took part in the longest-first protocol of `order` (it skips it while chunks do not
+// queue for waves): only then has generation order.gen + 2 been cleared, and only then may the host advance gen.
+bool PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots, bool spread,
                     const planar::CheetahDev& dev,
                     const CommonDev& cm, const StepArgs& a, const double* action, const OutPtrs& out,
                     const planar::CheetahTask& task, const double* tab, unsigned* ticket, unsigned* ticket_base,

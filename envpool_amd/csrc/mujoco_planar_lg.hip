@@ -415,8 +415,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(W, W))) 
 #endif
 }
 
+// returns whether the launch took part in the longest-first protocol (filed its chunks for generation gen + 1 and
+// cleared generation gen + 2): the host advances `gen` only then
 template <int KL, int W>
-void LaunchKl(hipStream_t st, int model, int wave_slots, bool spread, const CheetahDev& dev, const CommonDev& cm,
+bool LaunchKl(hipStream_t st, int model, int wave_slots, bool spread, const CheetahDev& dev, const CommonDev& cm,
               const StepArgs& a, const double* action, const OutPtrs& out, const CheetahTask& task,
               const double* tab, unsigned* ticket, unsigned* ticket_base, const planar::LgOrder& lo) {
   // waves resident at once: W per SIMD by registers (LDS allows no more than one at KL = 2)
@@ -457,26 +459,23 @@ void LaunchKl(hipStream_t st, int model, int wave_slots, bool spread, const Chee
         throw std::invalid_argument("lane groups of 2 / 4: HalfCheetah and Walker2d");
     }
   }
+  return lpt != nullptr;
 }
 
 }  // namespace
 
-void PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots, bool spread,
+bool PlanarLgLaunch(hipStream_t st, int kl, int waves, int model, int wave_slots, bool spread,
                     const planar::CheetahDev& dev,
                     const CommonDev& cm, const StepArgs& a, const double* action, const OutPtrs& out,
                     const planar::CheetahTask& task, const double* tab, unsigned* ticket, unsigned* ticket_base,
                     const planar::LgOrder& lo) {
 #define EPA_LG(KL, W) \
   LaunchKl<KL, W>(st, model, wave_slots, spread, dev, cm, a, action, out, task, tab, ticket, ticket_base, lo)
-  if (kl == 1) {
-    EPA_LG(1, 1);
-  } else if (kl == 2) {
-    EPA_LG(2, 1);  // LDS (38 KB per wave) allows one wave per SIMD whatever the register budget: no <2, *, 2> build
-  } else if (waves == 1) {
-    EPA_LG(4, 1);
-  } else {
-    EPA_LG(4, 2);
-  }
+  if (kl == 1) return EPA_LG(1, 1);
+  // LDS (38 KB per wave) allows one wave per SIMD whatever the register budget: no <2, *, 2> build
+  if (kl == 2) return EPA_LG(2, 1);
+  if (waves == 1) return EPA_LG(4, 1);
+  return EPA_LG(4, 2);
 #undef EPA_LG
 }
 

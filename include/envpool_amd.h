@@ -83,6 +83,8 @@ typedef struct epa_pool epa_pool;
  *   "planar_lpt"  lane-group kernel: 1 whole-pool launches serve the chunks of envs slowest first, by their
  *                 duration in the previous launch (default for Walker2d / Hopper); 0 index order (default for
  *                 HalfCheetah since round 5).  Never changes results.
+ *   "recv_timeout_ms" every family: how long epa_recv* waits for rows that have not been sent yet (see epa_recv):
+ *                 < 0 forever (default, the reference's behaviour), 0 not at all, > 0 milliseconds
  *   "compute_streams" async mode (batch_size < num_envs): successive batches run on this many
  *                 compute streams (default 4, 1 = one stream), like the reference's worker threads
  *                 step all queued slices in parallel (core/async_envpool.h:116-132).  Pools with the generic
@@ -174,7 +176,14 @@ int epa_reset(epa_pool* pool, const int32_t* env_ids, int32_t k);
  *   async mode (batch_size <  num_envs): returns exactly batch_size rows in
  *         completion (= submission) order, a legal schedule of
  *         state_buffer_queue.h:123-163.
- * EPA_ERR_RUNTIME if nothing is pending (the reference would block forever). */
+ * BLOCKS, like the reference (StateBufferQueue::Wait sits on a semaphore, state_buffer_queue.h:148-163; the binding
+ * releases the GIL around it, py_envpool.h:255-262): a consumer thread may call epa_recv BEFORE the producer thread's
+ * epa_send / epa_reset -- it returns once enough rows have been enqueued and computed.  send / reset from other
+ * threads are not held up by a waiting or downloading consumer.  recv itself is single-consumer
+ * (state_buffer_queue.h:143-147): concurrent calls are serialised.  Extension key "recv_timeout_ms" (epa_config
+ * params): < 0 (default) wait forever; 0 EPA_ERR_RUNTIME at once when fewer rows are pending than a batch holds (for
+ * single-threaded callers that would otherwise hang); > 0 EPA_ERR_RUNTIME after that many milliseconds.
+ * epa_recv_block / epa_recv_into / epa_recv_device / epa_step_device wait the same way. */
 int epa_recv(epa_pool* pool, void* const* out_ptrs, int32_t n_ptrs,
              int32_t cap_rows, int32_t* k_out);
 

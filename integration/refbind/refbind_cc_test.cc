@@ -4,10 +4,18 @@
 // Send(Action{env_id, players.env_id, action}) -> Recv(), and its FrameStack checks -- with
 // the pool class swapped from AsyncEnvPool<HalfCheetahEnv> to the device pool.  Also a
 // CartPole pool for the classic family and an ownership check (arrays of an earlier Recv are
-// not overwritten by later steps).  Exit code 0 = all checks passed; needs a GPU.
+// not overwritten by later steps), and a producer / consumer pair of std::threads whose consumer
+// is inside Recv() BEFORE the producer's Reset / Send (Recv blocks: async_envpool.h:169-181,
+// state_buffer_queue.h:148-163), sync and async mode.  Exit code 0 = all checks passed; needs a GPU.
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "envpool/classic_control/cartpole.h"
@@ -190,7 +198,79 @@ static void CartPoleEpisode() {  // the classic family through the same interfac
   EXPECT(threw);
 }
 
+// Recv blocks until the producer has sent (async_envpool.h:169-181): the consumer thread enters
+// Recv() first, the producer resets / steps afterwards.  Sync mode: T steps, batches arrive in
+// send order.  Async mode (batch_size < num_envs): the consumer hands the env ids of each batch
+// to the producer, which sends their next actions -- the actor loop of the reference's README.
+static void ProducerConsumer(int num_envs, int batch_size, int steps) {
+  auto config = classic_control::CartPoleEnvSpec::kDefaultConfig;
+  config["num_envs"_] = num_envs;
+  config["batch_size"_] = batch_size;
+  config["max_episode_steps"_] = 1000000;
+  config["seed"_] = 5;
+  classic_control::CartPoleEnvSpec spec(config);
+  DeviceCartPolePool envpool(spec);
+  using Action = typename DeviceCartPolePool::Action;
+  using State = typename DeviceCartPolePool::State;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::vector<int>> handed;  // env ids of received batches, consumer -> producer
+  std::atomic<int> received{0};
+  const int batches = steps * (num_envs / batch_size) + num_envs / batch_size;  // resets + steps
+  std::vector<int> rows_of_env(num_envs, 0);
+  std::thread consumer([&] {
+    for (int b = 0; b < batches; ++b) {
+      std::vector<Array> vec = envpool.Recv();  // the first call arrives before any Reset
+      State st(&vec);
+      const int k = static_cast<int>(st["info:env_id"_].Shape(0));
+      EXPECT(k == batch_size);
+      std::vector<int> ids(k);
+      for (int i = 0; i < k; ++i) {
+        ids[i] = At<int>(st["info:env_id"_], i);
+        EXPECT(ids[i] >= 0 && ids[i] < num_envs);
+        // row r of env e is its r-th result: elapsed_step counts them (no episode ends here
+        // before the pole falls; a finished env restarts at 0)
+        int el = At<int>(st["elapsed_step"_], i);
+        EXPECT(el >= 0 && el <= rows_of_env[ids[i]]);
+        ++rows_of_env[ids[i]];
+      }
+      received.fetch_add(1);
+      std::lock_guard<std::mutex> lk(mu);
+      handed.push_back(std::move(ids));
+      cv.notify_one();
+    }
+  });
+  std::this_thread::sleep_for(std::chrono::milliseconds(150));
+  EXPECT(received.load() == 0);  // nothing was sent: the consumer is blocked inside Recv
+  Array all_ids(Spec<int>({num_envs}));
+  for (int i = 0; i < num_envs; ++i) all_ids[i] = i;
+  envpool.Reset(all_ids);
+  for (int b = 0; b < batches - num_envs / batch_size; ++b) {
+    std::vector<int> ids;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return !handed.empty(); });
+      ids = std::move(handed.front());
+      handed.pop_front();
+    }
+    const int k = static_cast<int>(ids.size());
+    std::vector<Array> raw({Array(Spec<int>({k})), Array(Spec<int>({k})), Array(Spec<int>({k}))});
+    Action action(&raw);
+    for (int i = 0; i < k; ++i) {
+      action["env_id"_][i] = ids[i];
+      action["players.env_id"_][i] = ids[i];
+      action["action"_][i] = (ids[i] + b) & 1;
+    }
+    envpool.Send(action);
+  }
+  consumer.join();
+  EXPECT(received.load() == batches);
+  for (int e = 0; e < num_envs; ++e) EXPECT(rows_of_env[e] == steps + 1);
+}
+
 int main() {
+  ProducerConsumer(64, 64, 40);   // sync mode
+  ProducerConsumer(64, 16, 40);   // async mode
   CheckAction();
   FrameStack();
   CartPoleEpisode();

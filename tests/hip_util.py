@@ -13,9 +13,10 @@ PARAM_NAMES = {
 }
 
 
-def make_hip_pool(name, n, seed, **kw):
+def make_hip_pool(name, n, seed, extra_params=None, **kw):
     c = CASES[name]
     params = dict(zip(PARAM_NAMES.get(c["task"], ()), c["extra"]))
+    params.update(extra_params or {})
     return DevicePool(c["task"], n, seed=seed, max_episode_steps=c["max_steps"],
                       params=params, **kw)
 

@@ -188,7 +188,9 @@ def test_async_mode_batches():
 
 
 def test_errors():
-    pool = make_hip_pool("CartPole-v1", 4, 0)
+    # recv blocks like the reference's (tests/test_gpu_blocking_recv.py); recv_timeout_ms = 0 turns "nothing was
+    # sent" into an error for single-threaded callers
+    pool = make_hip_pool("CartPole-v1", 4, 0, extra_params={"recv_timeout_ms": 0})
     with pytest.raises(RuntimeError):
         pool.recv()  # nothing pending
     with pytest.raises(ValueError):

@@ -175,7 +175,8 @@ def test_send_device_is_ordered_behind_the_action_producer(how):
 def test_empty_send_keeps_the_pool_usable():
     """a k == 0 send/reset enqueues nothing and must not desync recv."""
     n = 64
-    pool = DevicePool("CartPole", n, seed=0, max_episode_steps=100)
+    # recv_timeout_ms = 0: "nothing pending" is an error instead of a wait (tests/test_gpu_blocking_recv.py)
+    pool = DevicePool("CartPole", n, seed=0, max_episode_steps=100, params={"recv_timeout_ms": 0})
     ids = np.arange(n, dtype=np.int32)
     pool.reset(ids)
     pool.recv()

@@ -101,11 +101,11 @@ def test_spec_surface_equals_the_reference_pybind_classes(stem, module, ours, ta
     for attr in ("_send", "_recv", "_reset", "_render", "_xla", "_state_keys", "_action_keys"):
         assert hasattr(ref_pool, attr)
     nref = len(ref_spec._config_keys)
-    # envpool_amd appends its extension keys (device, env_id_offset) AFTER the reference's
+    # envpool_amd appends its extension keys (device, env_id_offset, recv_timeout_ms) AFTER the reference's
     assert list(our_spec._config_keys[:nref]) == list(ref_spec._config_keys)
     extra = list(our_spec._config_keys[nref:])  # (MuJoCo families: + precision)
-    assert extra[-2:] == ["device", "env_id_offset"] and set(extra) <= {"precision", "device",
-                                                                        "env_id_offset"}
+    assert extra[-3:] == ["device", "env_id_offset", "recv_timeout_ms"]
+    assert set(extra) <= {"precision", "device", "env_id_offset", "recv_timeout_ms"}
     assert _norm(our_spec._default_config_values[:nref]) == _norm(ref_spec._default_config_values)
     assert list(our_spec._state_keys) == list(ref_spec._state_keys)
     assert list(our_spec._action_keys) == list(ref_spec._action_keys)
