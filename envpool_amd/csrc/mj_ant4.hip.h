@@ -32,6 +32,18 @@
 #ifndef ENVPOOL_AMD_CSRC_MJ_ANT4_HIP_H_
 #define ENVPOOL_AMD_CSRC_MJ_ANT4_HIP_H_
 
+// Stage timers of the diagnostic build (-DEPA_ANT_TIMERS, tools/build_ant_timers.sh; never in the product
+// library): EPA_ANT_TICK(K) books the wave's cycles since its previous tick to category K (mujoco_ant.hip:
+// 0 unit overhead: ticket, state loads / stores, outputs; 1 front end: kinematics, inertias, smooth forces, limit
+// rows; 2 contact set-up; 3 pass over the rows + quad sums + stop tests; 4 factor / solve; 5 line search (M s
+// and the evaluation); 6 RK4 stage updates + position integration; 7 waiting for the chunk's previous unit),
+// EPA_ANT_COUNT(K) counts wave-level events (0 Newton trips, 1 forward passes, 2 units).
+#ifndef EPA_ANT_TICK
+#define EPA_ANT_TICK(K) ((void)0)
+#define EPA_ANT_COUNT(K) ((void)0)
+#define EPA_ANT_CLASSES(sph, own) ((void)0)
+#endif
+
 #include "mj_ant.hip.h"
 #include "mj_quad.hip.h"
 
@@ -249,6 +261,34 @@ EPA_HD void LoadContact(const G& g, int w, T radius, Lds&& lds, Contact<V>& c, V
   c.ax = lds(base + 2);
   c.D = lds(base + 3);
 }
+// The same for a sphere class that differs from lane to lane (w: the lane's own class, `has`: the lane has one): the
+// class, its link and so the number of Jacobian columns are DATA -- LDS reads at per-lane addresses, the columns of
+// the hinges beyond the class's link are exact zeros (the sums they enter are unchanged), a lane without a class
+// carries D = 0 (and reads no cache slot: SetupContact wrote only the classes inside the margin).  All six leg
+// spheres have one radius (CheckLegSymmetry), the torso sphere its own.
+constexpr unsigned long long kCenterSlotTab =
+    (unsigned long long)kSlotPosA | ((unsigned long long)kSlotPos0 << 6) | ((unsigned long long)kSlotPosF << 12) |
+    ((unsigned long long)kSlotPosA << 18) | ((unsigned long long)kSlotTip << 24) | ((unsigned long long)kSlotPosF << 30) |
+    ((unsigned long long)kSlotPos0 << 36);
+template <typename T, typename V, typename B, typename U, typename G>
+EPA_HD void LoadContactAt(const AntModel<T>& m, const G& g, const U& w, B has, Contact<V>& c, Vec3<V>* C) {
+  const U cs = Tab6(kCenterSlotTab, w);
+  const Vec3<V> ctr = {GatherSlot(g.lds, cs), GatherSlot(g.lds, UMad(cs, 1u, 1u)), GatherSlot(g.lds, UMad(cs, 1u, 2u))};
+  const B torso = UEq(w, 6u);
+  const V radius = Sel(torso, V(m.sph_r[0]), V(m.sph_r[1]));
+  const Vec3<V> cp = {ctr.x, ctr.y, V(0.5) * (ctr.z - radius)};
+  const Vec3<V> r0 = cp - g.Pos0();
+  static_for<0, 3>([&](auto kc) { C[decltype(kc)::value] = Cross(g.Rot(decltype(kc)::value), r0); });
+  const B k1 = UGe(w, 2u) & !torso, k2 = UGe(w, 4u) & !torso;  // link >= 1 (aux), == 2 (foot)
+  const Vec3<V> c3 = Cross(g.Rot(2), cp - g.PosA()), c4 = Cross(g.Ank(), cp - g.PosF());
+  C[3] = {Sel(k1, c3.x, V(0)), Sel(k1, c3.y, V(0)), Sel(k1, c3.z, V(0))};
+  C[4] = {Sel(k2, c4.x, V(0)), Sel(k2, c4.y, V(0)), Sel(k2, c4.z, V(0))};
+  const U base = UMad(w, 4u, (unsigned)kSlotCache);
+  c.an = Sel(has, GatherSlot(g.lds, base), V(0));
+  c.ay = Sel(has, GatherSlot(g.lds, UMad(base, 1u, 1u)), V(0));
+  c.ax = Sel(has, GatherSlot(g.lds, UMad(base, 1u, 2u)), V(0));
+  c.D = Sel(has, GatherSlot(g.lds, UMad(base, 1u, 3u)), V(0));
+}
 template <int K, typename V>
 EPA_HD Vec3<V> JacMul(const Vec3<V>* C, const V* a) {  // J a
   Vec3<V> r = {a[0], a[1], a[2]};
@@ -291,7 +331,7 @@ EPA_HD void DispatchSphere(const AntModel<T>& m, int w, F&& f) {
 // gradient / Hessian contributions of the lane's rows at acceleration a:
 // g[0..5] and H[0..20] receive the lane's PARTIAL torso sums, the rest is local.
 template <typename T, typename V, typename B, typename U, typename G>
-EPA_HD void RowsPass(const AntModel<T>& m, const Leg<V, B>& lg, const G& g, unsigned sph,
+EPA_HD void RowsPass(const AntModel<T>& m, const Leg<V, B>& lg, const G& g, const U& vis,
                      const Rows<V>& r, const V* v, const V* a, V* grad, V* H, U* mask) {
   U m0 = MaskFill(*mask, 0u);
   static_for<0, 2>([&](auto jc) {
@@ -303,58 +343,61 @@ EPA_HD void RowsPass(const AntModel<T>& m, const Leg<V, B>& lg, const G& g, unsi
     H[Tri(6 + j, 6 + j)] += w;
     MaskSet(m0, on, j);
   });
+  // The lane's OWN touching classes, one per trip of the loop (round 6; rounds 2-5 looped over the wave-uniform UNION
+  // of the touching classes with a link-specialised visit: 3.0 visits per pass in the benchmark's steady state where
+  // the busiest lane has 1.6 classes -- profiles/r6c_ant_stage_timers.txt).
+  U rem = vis;
   EPA_ANT4_NO_UNROLL
-  for (unsigned rem = sph; rem != 0; rem &= rem - 1) {  // scalar loop over touching classes
-    const int w = __builtin_ctz(rem);
+  while (AnyWave(AnySlot(rem))) {
+    const B has = AnySlot(rem);
+    const U w = PopSlot(rem);
     EPA_LDS_FENCE();
-    DispatchSphere(m, w, [&](auto kc, T radius, T invw) {
-      constexpr int K = decltype(kc)::value;
-      Contact<V> c;
-      Vec3<V> C[5];
-      LoadContact<K>(g, w, radius, g.lds, c, C);
-      V jar[4], wt[4];
-      ContactJar(m, JacMul<K>(C, a), c, jar);
-      static_for<0, 4>([&](auto kk) {
-        constexpr int k = decltype(kk)::value;
-        const B on = (c.D > V(0)) & (jar[k] < V(0));
-        wt[k] = Sel(on, c.D, V(0));
-        MaskSet(m0, on, 2 + 4 * w + k);
-      });
-      const V wsum = wt[0] + wt[1] + wt[2] + wt[3];
-      if (AnyWave(wsum > V(0))) {
-        const V mu = V(m.mu);
-        const V gz = wt[0] * jar[0] + wt[1] * jar[1] + wt[2] * jar[2] + wt[3] * jar[3];
-        const V gy = mu * (wt[0] * jar[0] - wt[1] * jar[1]);
-        const V gx = mu * (wt[3] * jar[3] - wt[2] * jar[2]);
-        const V hzz = wsum;
-        const V hyy = V(m.mu * m.mu) * (wt[0] + wt[1]), hxx = V(m.mu * m.mu) * (wt[2] + wt[3]);
-        const V hzy = mu * (wt[0] - wt[1]), hzx = mu * (wt[3] - wt[2]);
-        // J = [I3 | C]: J^T g and J^T Hc J with Hc = [hxx 0 hzx; 0 hyy hzy; hzx hzy hzz]
-        grad[0] += gx;
-        grad[1] += gy;
-        grad[2] += gz;
-        H[Tri(0, 0)] += hxx;
-        H[Tri(1, 1)] += hyy;
-        H[Tri(2, 2)] += hzz;
-        H[Tri(0, 2)] += hzx;
-        H[Tri(1, 2)] += hzy;
-        Vec3<V> Uc[5];
-        static_for<0, 3 + K>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          const Vec3<V> ci = C[i];
-          grad[3 + i] += ci.x * gx + ci.y * gy + ci.z * gz;
-          Uc[i] = {hxx * ci.x + hzx * ci.z, hyy * ci.y + hzy * ci.z,
-                   hzx * ci.x + hzy * ci.y + hzz * ci.z};
-          H[Tri(0, 3 + i)] += Uc[i].x;
-          H[Tri(1, 3 + i)] += Uc[i].y;
-          H[Tri(2, 3 + i)] += Uc[i].z;
-          static_for<0, i + 1>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            H[Tri(3 + j, 3 + i)] += Dot(C[j], Uc[i]);
-          });
-        });
-      }
+    Contact<V> c;
+    Vec3<V> C[5];
+    LoadContactAt(m, g, w, has, c, C);
+    V jar[4], wt[4];
+    ContactJar(m, JacMul<2>(C, a), c, jar);
+    const U bit0 = UMad(w, 4u, 2u);
+    static_for<0, 4>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      const B on = (c.D > V(0)) & (jar[k] < V(0));
+      wt[k] = Sel(on, c.D, V(0));
+      MaskSetAt(m0, on, UMad(bit0, 1u, (unsigned)k));
     });
+    const V wsum = wt[0] + wt[1] + wt[2] + wt[3];
+    if (AnyWave(wsum > V(0))) {
+      const V mu = V(m.mu);
+      const V gz = wt[0] * jar[0] + wt[1] * jar[1] + wt[2] * jar[2] + wt[3] * jar[3];
+      const V gy = mu * (wt[0] * jar[0] - wt[1] * jar[1]);
+      const V gx = mu * (wt[3] * jar[3] - wt[2] * jar[2]);
+      const V hzz = wsum;
+      const V hyy = V(m.mu * m.mu) * (wt[0] + wt[1]), hxx = V(m.mu * m.mu) * (wt[2] + wt[3]);
+      const V hzy = mu * (wt[0] - wt[1]), hzx = mu * (wt[3] - wt[2]);
+      // J = [I3 | C]: J^T g and J^T Hc J with Hc = [hxx 0 hzx; 0 hyy hzy; hzx hzy hzz]
+      grad[0] += gx;
+      grad[1] += gy;
+      grad[2] += gz;
+      H[Tri(0, 0)] += hxx;
+      H[Tri(1, 1)] += hyy;
+      H[Tri(2, 2)] += hzz;
+      H[Tri(0, 2)] += hzx;
+      H[Tri(1, 2)] += hzy;
+      Vec3<V> Uc[5];
+      static_for<0, 5>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const Vec3<V> ci = C[i];
+        grad[3 + i] += ci.x * gx + ci.y * gy + ci.z * gz;
+        Uc[i] = {hxx * ci.x + hzx * ci.z, hyy * ci.y + hzy * ci.z,
+                 hzx * ci.x + hzy * ci.y + hzz * ci.z};
+        H[Tri(0, 3 + i)] += Uc[i].x;
+        H[Tri(1, 3 + i)] += Uc[i].y;
+        H[Tri(2, 3 + i)] += Uc[i].z;
+        static_for<0, i + 1>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          H[Tri(3 + j, 3 + i)] += Dot(C[j], Uc[i]);
+        });
+      });
+    }
   }
   *mask = m0;
 }
@@ -362,7 +405,7 @@ EPA_HD void RowsPass(const AntModel<T>& m, const Leg<V, B>& lg, const G& g, unsi
 // lane-partial first / second derivative of the constraint cost along s at step alpha; kMask: also
 // the lane's active-row mask AT a + alpha s (the bits of RowsPass)
 template <bool kMask, typename T, typename V, typename B, typename U, typename G>
-EPA_HD void LineEval(const AntModel<T>& m, const Leg<V, B>& lg, const G& g, unsigned sph,
+EPA_HD void LineEval(const AntModel<T>& m, const Leg<V, B>& lg, const G& g, const U& vis,
                      const Rows<V>& r, const V* v, const V* a, const V* s, V alpha, V* d1, V* d2,
                      U* mask) {
   U m1 = MaskFill(*mask, 0u);
@@ -377,28 +420,28 @@ EPA_HD void LineEval(const AntModel<T>& m, const Leg<V, B>& lg, const G& g, unsi
     *d2 += w * jv * jv;
     if constexpr (kMask) MaskSet(m1, on, j);
   });
+  U rem = vis;  // the lane's own touching classes, as in RowsPass
   EPA_ANT4_NO_UNROLL
-  for (unsigned rem = sph; rem != 0; rem &= rem - 1) {
-    const int w = __builtin_ctz(rem);
+  while (AnyWave(AnySlot(rem))) {
+    const B has = AnySlot(rem);
+    const U w = PopSlot(rem);
     EPA_LDS_FENCE();
-    DispatchSphere(m, w, [&](auto kc, T radius, T invw) {
-      constexpr int K = decltype(kc)::value;
-      Contact<V> c;
-      Vec3<V> C[5];
-      LoadContact<K>(g, w, radius, g.lds, c, C);
-      V jar[4];
-      ContactJar(m, JacMul<K>(C, a), c, jar);
-      const Vec3<V> js = JacMul<K>(C, s);
-      const V mu = V(m.mu);
-      const V jv[4] = {js.z + mu * js.y, js.z - mu * js.y, js.z - mu * js.x, js.z + mu * js.x};
-      static_for<0, 4>([&](auto kk) {
-        constexpr int k = decltype(kk)::value;
-        const V x = jar[k] + alpha * jv[k];
-        const V wt = Sel(x < V(0), c.D, V(0));  // D == 0 on lanes without contact
-        *d1 += wt * x * jv[k];
-        *d2 += wt * jv[k] * jv[k];
-        if constexpr (kMask) MaskSet(m1, (c.D > V(0)) & (x < V(0)), 2 + 4 * w + k);
-      });
+    Contact<V> c;
+    Vec3<V> C[5];
+    LoadContactAt(m, g, w, has, c, C);
+    V jar[4];
+    ContactJar(m, JacMul<2>(C, a), c, jar);
+    const Vec3<V> js = JacMul<2>(C, s);
+    const V mu = V(m.mu);
+    const V jv[4] = {js.z + mu * js.y, js.z - mu * js.y, js.z - mu * js.x, js.z + mu * js.x};
+    const U bit0 = UMad(w, 4u, 2u);
+    static_for<0, 4>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      const V x = jar[k] + alpha * jv[k];
+      const V wt = Sel(x < V(0), c.D, V(0));  // D == 0 on lanes without contact
+      *d1 += wt * x * jv[k];
+      *d2 += wt * jv[k] * jv[k];
+      if constexpr (kMask) MaskSetAt(m1, (c.D > V(0)) & (x < V(0)), UMad(bit0, 1u, (unsigned)k));
     });
   }
   if constexpr (kMask) *mask = m1;
@@ -438,7 +481,7 @@ constexpr int kLsExactAfter = 8;  // see Solve
 // mj_fwdConstraint: exact Newton on the primal objective (mj_ant.hip.h, AntSolve), with
 // the leg blocks eliminated inside each lane.
 template <typename U, typename T, typename V, typename B, typename Lds>
-EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned sph,
+EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, const U& own,
                   const Rows<V>& r, const V* v, const V* qfrc, const SolverCfg<T>& cfg, V* qacc,
                   V* n_env, int* n_wave) {
   const Geo<V, typename std::remove_reference<Lds>::type> g{lds};
@@ -468,7 +511,10 @@ EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned
     s[6] = res[6];
     s[7] = res[7];
     U m0 = MaskFill(U(), 0u);
-    RowsPass(m, lg, g, sph, r, v, qacc, s, H, &m0);
+    EPA_ANT_TICK(4);
+    // a lane visits its own touching classes while its env is still iterating (a finished env's qacc is frozen)
+    const U vis = SlotsWhere(own, live);
+    RowsPass(m, lg, g, vis, r, v, qacc, s, H, &m0);
     // full gradient: torso = smooth part + sum of the lanes' contact parts
     static_for<0, 6>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
@@ -480,7 +526,9 @@ EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned
     const B stop = (gn2 <= gstop2) | (full_step & same) |
                    ((prev_gn2 >= V(0)) & (gn2 <= gfloor2) & (gn2 >= V(0.0625) * prev_gn2));
     live = live & !stop;
+    EPA_ANT_TICK(3);
     if (!AnyWave(live)) break;
+    EPA_ANT_COUNT(0);
     *n_env += Sel(live, V(1), V(0));  // Newton iterations of this env / executed by the wave
     *n_wave += 1;
     prev_gn2 = gn2;
@@ -536,6 +584,7 @@ EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned
       s[7] = (t7 - H[Tri(6, 7)] * s[6]) * inv7;
     }
     // ---- line search on the piecewise-quadratic cost (one evaluation at the full step, see below)
+    EPA_ANT_TICK(4);
     V Ms[kL];
     EPA_LDS_FENCE();
     MulM(lds, s, Ms);
@@ -559,9 +608,9 @@ EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned
       V p1 = V(0), p2 = V(0);
       U m1 = MaskFill(U(), 0u);
       if (ls == 0) {
-        LineEval<true>(m, lg, g, sph, r, v, qacc, s, alpha, &p1, &p2, &m1);
+        LineEval<true>(m, lg, g, vis, r, v, qacc, s, alpha, &p1, &p2, &m1);
       } else {
-        LineEval<false>(m, lg, g, sph, r, v, qacc, s, alpha, &p1, &p2, &m1);
+        LineEval<false>(m, lg, g, vis, r, v, qacc, s, alpha, &p1, &p2, &m1);
       }
       const V d1 = g1 + alpha * g2 + Sum4(p1), d2 = g2 + Sum4(p2);
       const B hit = Abs(d1) <= ls_tol;
@@ -589,8 +638,10 @@ EPA_HD void Solve(const AntModel<T>& m, const Leg<V, B>& lg, Lds&& lds, unsigned
       res[i] += step * Ms[i];
     });
     live = live & !exact;
+    EPA_ANT_TICK(5);
     if (!AnyWave(live)) break;
   }
+  EPA_ANT_TICK(4);
 }
 
 // ---- fused front end of one forward pass, one leg per lane ------------------------
@@ -848,7 +899,11 @@ EPA_HD void Forward(const AntModel<T>& m, const Leg<V, B>& lg, const SolverCfg<T
   Rows<V> rows;
   EPA_LDS_FENCE();
   U own;
+  EPA_ANT_TICK(6);
+  EPA_ANT_COUNT(1);
   const unsigned sph = FrontEnd(m, lg, q, v, ctrl, lds, rows, qfrc, &own);
+  EPA_ANT_TICK(1);
+  EPA_ANT_CLASSES(sph, own);
   EPA_LDS_FENCE();
   {
     const Geo<V, typename std::remove_reference<Lds>::type> g{lds};
@@ -862,7 +917,9 @@ EPA_HD void Forward(const AntModel<T>& m, const Leg<V, B>& lg, const SolverCfg<T
     }
   }
   EPA_LDS_FENCE();
-  Solve<U>(m, lg, lds, sph, rows, v, qfrc, cfg, qacc, n_env, n_wave);
+  EPA_ANT_TICK(2);
+  // (the torso sphere is probed on every lane of the quad and owned by the first one)
+  Solve<U>(m, lg, lds, MaskClear(own, !lg.first, 1u << 6), rows, v, qfrc, cfg, qacc, n_env, n_wave);
   // profiling: + 1e3 x sphere classes the wave visits + 1e6 x those of this env
   *n_wave += 1000 * __builtin_popcount(sph) + 1000000 * MaskCount4(own);
   if constexpr (kWrench) {

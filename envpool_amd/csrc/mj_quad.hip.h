@@ -117,6 +117,45 @@ inline B4 MaskSame(const U4& a, const U4& b) {
 }
 inline U4 MaskFill(U4, unsigned x) { return {{x, x, x, x}}; }
 inline int MaskCount4(const U4& m) { return __builtin_popcount(m.v[0] | m.v[1] | m.v[2] | m.v[3]); }
+// per-lane sets of small integers (sphere classes): a lane pops ITS lowest member per trip of a wave-level loop
+inline B4 AnySlot(const U4& rem) { return {{rem.v[0] != 0u, rem.v[1] != 0u, rem.v[2] != 0u, rem.v[3] != 0u}}; }
+inline U4 PopSlot(U4& rem) {  // (0 where the set is empty: the caller masks with AnySlot)
+  U4 r;
+  for (int i = 0; i < 4; ++i) {
+    r.v[i] = rem.v[i] ? (unsigned)__builtin_ctz(rem.v[i]) : 0u;
+    rem.v[i] &= rem.v[i] - 1u;
+  }
+  return r;
+}
+inline U4 SlotsWhere(const U4& own, B4 on) {
+  return {{on.v[0] ? own.v[0] : 0u, on.v[1] ? own.v[1] : 0u, on.v[2] ? own.v[2] : 0u, on.v[3] ? own.v[3] : 0u}};
+}
+inline U4 MaskClear(const U4& m, B4 where, unsigned bits) {
+  U4 r;
+  for (int i = 0; i < 4; ++i) r.v[i] = where.v[i] ? (m.v[i] & ~bits) : m.v[i];
+  return r;
+}
+inline B4 UGe(const U4& a, unsigned b) { return {{a.v[0] >= b, a.v[1] >= b, a.v[2] >= b, a.v[3] >= b}}; }
+inline B4 UEq(const U4& a, unsigned b) { return {{a.v[0] == b, a.v[1] == b, a.v[2] == b, a.v[3] == b}}; }
+// 6-bit entry number idx of a packed table
+inline U4 Tab6(unsigned long long tab, const U4& idx) {
+  U4 r;
+  for (int i = 0; i < 4; ++i) r.v[i] = (unsigned)(tab >> (6u * idx.v[i])) & 63u;
+  return r;
+}
+inline U4 UMad(const U4& a, unsigned mul, unsigned add) {
+  return {{a.v[0] * mul + add, a.v[1] * mul + add, a.v[2] * mul + add, a.v[3] * mul + add}};
+}
+inline void MaskSetAt(U4& m, B4 on, const U4& bit) {
+  for (int i = 0; i < 4; ++i) m.v[i] |= (on.v[i] ? 1u : 0u) << bit.v[i];
+}
+// lane i reads ITS slot slot.v[i] of a per-lane block
+template <typename Lds>
+inline auto GatherSlot(Lds&& lds, const U4& slot) -> typename std::decay<decltype(lds(0))>::type {
+  typename std::decay<decltype(lds(0))>::type r;
+  for (int i = 0; i < 4; ++i) r.v[i] = lds((int)slot.v[i]).v[i];
+  return r;
+}
 template <typename T>
 inline Q4<T> Rsq(const Q4<T>& x) {
   Q4<T> r;
@@ -139,6 +178,23 @@ EPA_HD bool AnyWave(bool c) { return WaveAny(c); }
 EPA_HD void MaskSet(unsigned& m, bool on, int bit) { m |= (on ? 1u : 0u) << bit; }
 EPA_HD bool MaskSame(unsigned a, unsigned b) { return a == b; }
 EPA_HD unsigned MaskFill(unsigned, unsigned x) { return x; }
+EPA_HD bool AnySlot(unsigned rem) { return rem != 0u; }
+EPA_HD unsigned PopSlot(unsigned& rem) {
+  const unsigned s = rem ? (unsigned)__builtin_ctz(rem) : 0u;
+  rem &= rem - 1u;
+  return s;
+}
+EPA_HD unsigned SlotsWhere(unsigned own, bool on) { return on ? own : 0u; }
+EPA_HD unsigned MaskClear(unsigned m, bool where, unsigned bits) { return where ? (m & ~bits) : m; }
+EPA_HD bool UGe(unsigned a, unsigned b) { return a >= b; }
+EPA_HD bool UEq(unsigned a, unsigned b) { return a == b; }
+EPA_HD unsigned Tab6(unsigned long long tab, unsigned idx) { return (unsigned)(tab >> (6u * idx)) & 63u; }
+EPA_HD unsigned UMad(unsigned a, unsigned mul, unsigned add) { return a * mul + add; }
+EPA_HD void MaskSetAt(unsigned& m, bool on, unsigned bit) { m |= (on ? 1u : 0u) << bit; }
+template <typename Lds>
+EPA_HD auto GatherSlot(Lds&& lds, unsigned slot) -> typename std::decay<decltype(lds(0))>::type {
+  return lds((int)slot);  // the device accessor takes a per-lane slot number as it takes a uniform one
+}
 #if defined(__HIP_DEVICE_COMPILE__)
 // quad_perm selectors: [1,0,3,2] swaps neighbours, [2,3,0,1] swaps pairs
 constexpr int kDppSwap1 = 0xB1, kDppSwap2 = 0x4E;

@@ -21,6 +21,42 @@
 #define EPA_SINCOS_MODE 1
 #include "device_common.hip.h"
 #include "engine.h"
+#if defined(EPA_ANT_TIMERS) && defined(__HIP_DEVICE_COMPILE__)
+// diagnostic build (tools/build_ant_timers.sh): per-wave stage timers in LDS, summed into g_ant_timers when the wave
+// leaves the queue; categories: mj_ant4.hip.h
+namespace epa {
+__shared__ unsigned long long ant_t_acc[16];  // [0] last tick, [1..8] cycles per category, [9..15] counts
+__device__ unsigned long long g_ant_timers[16];
+}  // namespace epa
+#define EPA_ANT_TICK(K)                                   \
+  do {                                                    \
+    if (threadIdx.x == 0) {                               \
+      const unsigned long long c_ = clock64();            \
+      ::epa::ant_t_acc[1 + (K)] += c_ - ::epa::ant_t_acc[0]; \
+      ::epa::ant_t_acc[0] = c_;                           \
+    }                                                     \
+  } while (0)
+#define EPA_ANT_COUNT(K)                                  \
+  do {                                                    \
+    if (threadIdx.x == 0) ::epa::ant_t_acc[9 + (K)] += 1; \
+  } while (0)
+// classes per forward pass: [12] the wave's union (what the class loops run over), [13] the busiest lane's own,
+// [14] the busiest QUAD's union (sum over its lanes' own sets, as a set)
+#define EPA_ANT_CLASSES(sph, own)                                                              \
+  do {                                                                                         \
+    const int mine_ = __builtin_popcount((unsigned)(own));                                     \
+    int mx_ = 0;                                                                               \
+    for (int b_ = 1; b_ <= 7; ++b_) mx_ = __builtin_amdgcn_ballot_w64(mine_ >= b_) ? b_ : mx_; \
+    if (threadIdx.x == 0) {                                                                    \
+      ::epa::ant_t_acc[12] += __builtin_popcount(sph);                                         \
+      ::epa::ant_t_acc[13] += mx_;                                                             \
+    }                                                                                          \
+  } while (0)
+#elif defined(EPA_ANT_TIMERS)
+namespace epa {
+__device__ unsigned long long g_ant_timers[16];
+}
+#endif
 #include "mj_ant4.hip.h"
 #include "mj_ant_model.h"
 #include "build/mj_ant_consts.inc"  // generated: kAntModelConst (gen_mj_consts.cpp)
@@ -247,10 +283,12 @@ __device__ __forceinline__ void AntUnit(int ci, int s0, int s1, T* lds_buf) {
   const long long t_begin = clock64();
   const long long w_begin = wall_clock64();
 #endif
+  EPA_ANT_TICK(0);
   for (int s = s0; s < s1; ++s) {
     A4::Step<unsigned, kWrench>(m, lg, scfg, q, v, w, ctrl, &lagx, &lagy, lds,
                                 kWrench && s == task.frame_skip - 1, cf, cft, &n_env, &n_wave);
   }
+  EPA_ANT_TICK(6);
   ap = AntKernArgs();
   const AntDev dev = ap->dev;
   const CommonDev cm = ap->cm;
@@ -406,6 +444,13 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
   // the contact geometry and the contact constants of the current forward pass
   __shared__ T lds_buf[A4::kLdsElems];
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifdef EPA_ANT_TIMERS
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) ant_t_acc[i] = 0;
+    ant_t_acc[0] = clock64();
+  }
+  const long long t_wave0 = clock64();
+#endif
   for (;;) {
     AntArgsK* ap = AntKernArgs();
     unsigned t = 0;
@@ -422,6 +467,8 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    EPA_ANT_TICK(7);
+    EPA_ANT_COUNT(2);
     const int s0 = j * ap->sub;
     const int s1 = s0 + ap->sub;
     AntUnit<T, kWrench>(ci, s0, s1, lds_buf);
@@ -433,7 +480,17 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
                            __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    EPA_ANT_TICK(0);
   }
+#ifdef EPA_ANT_TIMERS
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 11; ++i) atomicAdd(&g_ant_timers[i], ant_t_acc[1 + i]);
+    atomicAdd(&g_ant_timers[11], (unsigned long long)(clock64() - t_wave0));  // the wave's life
+    atomicAdd(&g_ant_timers[12], 1ull);                                        // waves
+    atomicAdd(&g_ant_timers[13], ant_t_acc[12]);
+    atomicAdd(&g_ant_timers[14], ant_t_acc[13]);
+  }
+#endif
 #endif
 }
 
@@ -695,6 +752,21 @@ class AntPool : public Pool {
 };
 
 }  // namespace
+
+}  // namespace epa
+#ifdef EPA_ANT_TIMERS
+// diagnostic build only: read (and clear) the stage timers
+extern "C" int epa_debug_ant_timers(unsigned long long* out16, int clear) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(epa::g_ant_timers), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (clear) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(epa::g_ant_timers), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
+namespace epa {
 
 bool DescribeAnt(const std::string& family, const Config& cfg,
                  std::vector<KeySpec>* state, KeySpec* action) {

@@ -21,105 +21,92 @@ from .protocol import ArraySpec
 ACTION_THRESHOLD = 2**20
 
 
-def _maybe_scalar_int(value: Any) -> int | None:
-    arr = np.asarray(value)
-    if arr.size != 1:
+def _as_whole_number(value: Any) -> int | None:
+    """`value` as a Python int when it is ONE finite number with no fractional part (up to np.isclose), else None:
+    the reference's bound test for "this spec is a discrete range" (envpool/python/data.py:32-42)."""
+    flat = np.ravel(np.asarray(value))
+    if flat.size != 1:
         return None
-    scalar = arr.item()
-    if not np.isfinite(scalar):
+    x = flat[0].item()
+    if not np.isfinite(x) or not np.isclose(x, int(x)):
         return None
-    integer = int(scalar)
-    if not np.isclose(scalar, integer):
-        return None
-    return integer
+    return int(x)
 
 
 def _maybe_discrete_range(spec: ArraySpec, spec_type: str) -> tuple[int, int] | None:
-    # envpool/python/data.py:46-62
-    if np.prod(np.abs(spec.shape)) != 1:
-        return None
-    minimum = _maybe_scalar_int(spec.minimum)
-    maximum = _maybe_scalar_int(spec.maximum)
-    if minimum is None or maximum is None or maximum >= ACTION_THRESHOLD:
-        return None
+    """(start, number of values) when `spec` describes a scalar integer range, else None (data.py:45-62).
+    An action spec also counts when it is flagged discrete; a state spec must have an integer dtype."""
+    integral = np.issubdtype(spec.dtype, np.integer)
     if spec_type == "act":
-        if not (spec.is_discrete or np.issubdtype(spec.dtype, np.integer)):
-            return None
-    elif not np.issubdtype(spec.dtype, np.integer):
+        integral = integral or bool(spec.is_discrete)
+    scalar = int(np.prod(np.abs(spec.shape))) == 1
+    if not (integral and scalar):
         return None
-    return minimum, maximum - minimum + 1
+    lo, hi = _as_whole_number(spec.minimum), _as_whole_number(spec.maximum)
+    if lo is None or hi is None or hi >= ACTION_THRESHOLD:
+        return None
+    return lo, hi - lo + 1
+
+
+def _static_shape(spec: ArraySpec) -> list[int]:
+    """the spec's shape without the per-player placeholder (-1)"""
+    return [dim for dim in spec.shape if dim != -1]
 
 
 def to_nested_dict(flatten_dict: dict[str, Any], generator: type = dict) -> dict[str, Any]:
     """{"a.b": 1, "a.c": 2} -> {"a": {"b": 1, "c": 2}} (data.py:65-93)."""
-    ret: dict[str, Any] = generator()
-    for k, v in flatten_dict.items():
-        segments = k.split(".")
-        ptr = ret
-        for s in segments[:-1]:
-            if s not in ptr:
-                ptr[s] = generator()
-            ptr = ptr[s]
-        ptr[segments[-1]] = v
-    return ret
+    tree: dict[str, Any] = generator()
+    for dotted, leaf in flatten_dict.items():
+        *parents, last = dotted.split(".")
+        node = tree
+        for name in parents:
+            if name not in node:
+                node[name] = generator()
+            node = node[name]
+        node[last] = leaf
+    return tree
 
 
 def _identifier(name: str) -> str:
+    """a legal namedtuple type / field name for `name` (data.py:98-100, 104-106)"""
     ident = re.sub(r"\W", "_", name)
-    if not ident or ident[0].isdigit() or keyword.iskeyword(ident):
-        ident = f"_{ident}"
-    return ident
+    needs_prefix = ident == "" or ident[0].isdigit() or keyword.iskeyword(ident)
+    return "_" + ident if needs_prefix else ident
 
 
 def to_namedtuple(name: str, hdict: dict) -> tuple:
-    """Hierarchical dict -> (nested) namedtuple (data.py:96-117)."""
-    field_names = []
-    used: dict[str, int] = {}
-    for key in hdict.keys():
+    """Hierarchical dict -> (nested) namedtuple (data.py:96-117); a field name that repeats after
+    sanitising gets the suffix _1, _2, ..."""
+    seen: dict[str, int] = {}
+    fields, values = [], []
+    for key, child in hdict.items():
         field = _identifier(key)
-        if field in used:
-            used[field] += 1
-            field = f"{field}_{used[field]}"
-        else:
-            used[field] = 0
-        field_names.append(field)
-    return namedtuple(_identifier(name), field_names)(*[
-        to_namedtuple(k, v) if isinstance(v, dict) else v for k, v in hdict.items()
-    ])
+        repeats = seen.get(field)
+        seen[field] = 0 if repeats is None else repeats + 1
+        fields.append(field if repeats is None else f"{field}_{repeats + 1}")
+        values.append(to_namedtuple(key, child) if isinstance(child, dict) else child)
+    return namedtuple(_identifier(name), fields)(*values)
 
 
 def dm_spec_transform(name: str, spec: ArraySpec, spec_type: str) -> Any:
-    """ArraySpec -> dm_env spec (data.py:120-139)."""
-    discrete_range = _maybe_discrete_range(spec, spec_type)
-    if discrete_range is not None and discrete_range[0] == 0:
-        return dm_specs.DiscreteArray(
-            name=name,
-            dtype=spec.dtype if np.issubdtype(spec.dtype, np.integer) else np.int32,
-            num_values=discrete_range[1],
-        )
-    return dm_specs.BoundedArray(
-        name=name,
-        shape=[s for s in spec.shape if s != -1],
-        dtype=spec.dtype,
-        minimum=spec.minimum,
-        maximum=spec.maximum,
-    )
+    """ArraySpec -> dm_env spec (data.py:120-139): a zero-based discrete range becomes a DiscreteArray
+    (dm_env has no other kind), everything else a BoundedArray."""
+    rng = _maybe_discrete_range(spec, spec_type)
+    if rng is None or rng[0] != 0:
+        return dm_specs.BoundedArray(name=name, shape=_static_shape(spec), dtype=spec.dtype,
+                                     minimum=spec.minimum, maximum=spec.maximum)
+    int_dtype = spec.dtype if np.issubdtype(spec.dtype, np.integer) else np.int32
+    return dm_specs.DiscreteArray(name=name, dtype=int_dtype, num_values=rng[1])
 
 
 def gym_spec_transform(name: str, spec: ArraySpec, spec_type: str) -> Any:
-    """ArraySpec -> gymnasium space (data.py:142-157)."""
-    discrete_range = _maybe_discrete_range(spec, spec_type)
-    if discrete_range is not None:
-        start, num_values = discrete_range
-        return spaces.Discrete(n=num_values, start=start)
+    """ArraySpec -> gymnasium space (data.py:142-157): Discrete (any start), MultiBinary for bool, else Box."""
+    rng = _maybe_discrete_range(spec, spec_type)
+    if rng is not None:
+        return spaces.Discrete(n=rng[1], start=rng[0])
     if np.issubdtype(spec.dtype, np.bool_):
-        return spaces.MultiBinary([s for s in spec.shape if s != -1])
-    return spaces.Box(
-        shape=[s for s in spec.shape if s != -1],
-        dtype=spec.dtype,
-        low=spec.minimum,
-        high=spec.maximum,
-    )
+        return spaces.MultiBinary(_static_shape(spec))
+    return spaces.Box(low=spec.minimum, high=spec.maximum, shape=_static_shape(spec), dtype=spec.dtype)
 
 
 gymnasium_spec_transform = gym_spec_transform
@@ -149,15 +136,14 @@ gymnasium_structure = gym_structure
 def dm_structure(root_name: str, keys: list[str]) -> Callable[[list[Any]], tuple]:
     """Returns f(state_values) -> namedtuple tree of the reference's
     `dm_structure` (data.py:160-189): obs:* and info:* merge under `State`."""
-    new_keys = []
-    for key in keys:
-        if key in ["obs", "info"]:
-            key = f"obs:{key}"
-        key = key.replace("info:", "obs:")
-        key = key.replace("obs:", f"{root_name}:")
-        new_keys.append(key.replace(":", "."))
-    dict_tree = to_nested_dict(dict(zip(new_keys, range(len(new_keys)))))
-    template = to_namedtuple(root_name, dict_tree)
+    def dotted(key: str) -> str:
+        # a bare "obs" / "info" key is a leaf of the root; info:* joins obs:* under the root's name
+        if key in ("obs", "info"):
+            key = "obs:" + key
+        return key.replace("info:", "obs:").replace("obs:", root_name + ":").replace(":", ".")
+
+    index_of = {dotted(key): i for i, key in enumerate(keys)}
+    template = to_namedtuple(root_name, to_nested_dict(index_of))
 
     def fill(node: Any, values: list[Any]) -> Any:
         if isinstance(node, tuple):

@@ -17,15 +17,14 @@ import numpy as np
 
 
 def _normalize_env_id(env_id: Any) -> Any:
-    if isinstance(env_id, np.ndarray):
-        env_id = env_id.astype(np.int32, copy=False)
-    elif hasattr(env_id, "astype"):
-        env_id = env_id.astype(np.int32)
+    """env ids as an int32 array of at least one dimension (envpool.py:38-48).  Array-likes with their own `astype`
+    (device arrays) keep their type; everything else goes through numpy."""
+    if hasattr(env_id, "astype"):
+        # numpy: no copy when the dtype already matches; other array types: their own conversion
+        ids = env_id.astype(np.int32, copy=False) if isinstance(env_id, np.ndarray) else env_id.astype(np.int32)
     else:
-        env_id = np.asarray(env_id, dtype=np.int32)
-    if getattr(env_id, "ndim", 0) == 0:
-        env_id = env_id.reshape(1)
-    return env_id
+        ids = np.asarray(env_id, dtype=np.int32)
+    return ids.reshape(1) if getattr(ids, "ndim", 0) == 0 else ids
 
 
 def _flatten_action_dict(action: dict, prefix: tuple = ()) -> dict[str, Any]:
@@ -43,26 +42,23 @@ class EnvPoolMixin(ABC):
     """Mixin class for EnvPool, exposed to the gymnasium / dm metaclasses."""
 
     def _check_action(self, actions: list[np.ndarray]) -> None:
-        # envpool.py:151-172 — checked once, then trusted
-        if hasattr(self, "_check_action_finished"):
+        """dtype and per-row shape of every action array against the spec -- on the FIRST send only
+        (envpool.py:151-172); the messages are the reference's."""
+        if getattr(self, "_check_action_finished", False):
             return
         self._check_action_finished = True
-        for a, (k, v) in zip(actions, self.spec.action_array_spec.items()):
-            if v.dtype != a.dtype:
-                raise RuntimeError(
-                    f'Expected dtype {v.dtype} with action "{k}", got {a.dtype}'
-                )
-            shape = tuple(v.shape)
-            if len(shape) > 0 and shape[0] == -1:
-                if a.shape[1:] != shape[1:]:
-                    raise RuntimeError(
-                        f'Expected shape {shape} with action "{k}", got {a.shape}'
-                    )
+        specs = self.spec.action_array_spec
+        for arr, (name, want) in zip(actions, specs.items()):
+            if arr.dtype != want.dtype:
+                raise RuntimeError(f'Expected dtype {want.dtype} with action "{name}", got {arr.dtype}')
+            shape = tuple(want.shape)
+            per_player = len(shape) > 0 and shape[0] == -1  # leading -1: one row per player
+            if per_player:
+                ok, shown = arr.shape[1:] == shape[1:], shape
             else:
-                if len(a.shape) == 0 or a.shape[1:] != shape:
-                    raise RuntimeError(
-                        f'Expected shape {("num_env", *shape)} with action "{k}", got {a.shape}'
-                    )
+                ok, shown = arr.ndim > 0 and arr.shape[1:] == shape, ("num_env", *shape)
+            if not ok:
+                raise RuntimeError(f'Expected shape {shown} with action "{name}", got {arr.shape}')
 
     def _from(self, action: dict[str, Any] | np.ndarray,
               env_id: np.ndarray | None = None) -> list[np.ndarray]:
@@ -70,26 +66,25 @@ class EnvPoolMixin(ABC):
         if isinstance(action, dict):
             adict = _flatten_action_dict(action)
         else:
-            if not hasattr(self, "_last_action_type"):
-                self._last_action_type = self._spec._action_spec[-1][0]
+            # a bare array is the LAST action key (the other two are the env ids); its dtype comes from the spec
             if not hasattr(self, "_last_action_name"):
                 self._last_action_name = self._spec._action_keys[-1]
+                self._last_action_type = self._spec._action_spec[-1][0]
             if isinstance(action, np.ndarray):
                 # (the reference copies here; the pool stages the rows before `send` returns, so an
                 # array that already has the dtype and layout can be passed through)
                 action = action.astype(self._last_action_type, order="C", copy=False)
             adict = {self._last_action_name: action}
-        if env_id is None:
-            if "env_id" not in adict:
-                adict["env_id"] = self.all_env_ids
-        else:
+        if env_id is not None:
             adict["env_id"] = env_id.astype(np.int32, copy=False)
+        else:
+            adict.setdefault("env_id", self.all_env_ids)
         if "players.env_id" not in adict:
             # all hot-path envs are single player: players.env_id == env_id
             adict["players.env_id"] = _normalize_env_id(adict["env_id"])
         if not hasattr(self, "_action_names"):
             self._action_names = self._spec._action_keys
-        return [adict[k] for k in self._action_names]
+        return [adict[name] for name in self._action_names]
 
     def __len__(self) -> int:
         return self.config["num_envs"]
