@@ -19,12 +19,14 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <atomic>
 #include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/envpool_amd.h"
@@ -103,6 +105,10 @@ struct Batch {
   // single-stream pools record `done` only when somebody needs it (Pool::EnsureDone): an event record behind
   // every launch keeps consecutive step kernels further apart than the launch path alone
   bool done_recorded{false};
+  // A whole-pool host-path step of a sync pool may be cut into TWO launches (Pool::Send, "step_pipeline"): rows
+  // [0, part_rows) are complete at `part_ev`, so their download overlaps the second launch
+  int part_rows{0};               // 0: one launch
+  hipEvent_t part_ev{nullptr};
   hipStream_t stream{nullptr};    // the compute stream its kernel was launched on ...
   int stream_idx{0};              // ... and always will be: blocks are recycled per stream
   // async mode with several compute streams: the local env of every row (host-path sends / resets;
@@ -123,6 +129,41 @@ struct CommonDev {
   int* mti;
   int n;
   int mt_shift;
+};
+
+// A few helper threads that copy one big host buffer into the pinned staging slot in pieces, together with the
+// calling thread: a 3 MB action batch takes one thread 0.12 ms (25 GB/s), and in the sync step() that copy is in front
+// of everything else (the reference hands its workers POINTERS into the caller's array, py_envpool.h:89-101; a
+// device cannot read pageable memory).  Pieces are claimed with an atomic counter; the caller watches the in-order
+// frontier of finished pieces and uploads behind it.  Workers poll for ~0.3 ms after a job (the next step's send
+// is that close in a step loop) and sleep on a condition variable otherwise.
+class HostCopier {
+ public:
+  static constexpr size_t kPiece = 256u << 10;
+  explicit HostCopier(int threads);
+  ~HostCopier();
+  HostCopier(const HostCopier&) = delete;
+  HostCopier& operator=(const HostCopier&) = delete;
+  void Start(char* dst, const char* src, size_t bytes);
+  // The caller copies pieces too until bytes [0, upto) are in place; returns the bytes in place (a multiple of
+  // kPiece, or the total), which may be more.
+  size_t Advance(size_t upto);
+
+ private:
+  void Work();
+  bool CopyOne();
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::atomic<uint64_t> gen_{0};
+  std::atomic<bool> stop_{false};
+  std::atomic<int> active_{0};  // helpers that have not finished the current job's claim loop
+  char* dst_{nullptr};
+  const char* src_{nullptr};
+  size_t bytes_{0}, pieces_{0};
+  std::atomic<size_t> next_{0};
+  std::vector<std::atomic<uint8_t>> done_;
+  size_t frontier_{0};  // pieces [0, frontier_) are complete (the caller's view)
 };
 
 class Pool {
@@ -191,6 +232,10 @@ class Pool {
   // families whose envs all draw at the same launches (the word a wave reads is one coalesced column), 16 for
   // families whose envs reset at their own times (a reset's draws then stay inside a few 64-byte sectors)
   int mt_tile_default_{1};
+  // default of "step_pipeline" (see Pool::SendPipelined): 0 unless the family's constructor says otherwise -- it pays
+  // where a step kernel takes about as long as its results need for the way down (the planar MuJoCo tasks: +18 %)
+  // and costs where the kernel dominates (Ant: two half launches have two tails, -10 %)
+  int pipeline_default_{0};
   // The stream the NEXT step kernel goes on.  Sync mode (batch_size == num_envs): always
   // compute_[0].  Async mode: successive batches rotate over the compute streams so that
   // independent in-flight batches run concurrently, like the reference's workers run every queued
@@ -198,6 +243,9 @@ class Pool {
   hipStream_t stream_{nullptr};
   hipStream_t h2d_stream_{nullptr};   // action uploads of the host path
   hipStream_t d2h_stream_{nullptr};   // result downloads of the host path
+  // a pipelined step's big sections by DMA: first half on stream 2, second half on stream 3 (the small ones by a
+  // gather kernel on d2h_stream_ / the kernel stream)
+  hipStream_t d2h_stream2_{nullptr}, d2h_stream3_{nullptr};
   CommonDev common_{};
 
  private:
@@ -211,6 +259,13 @@ class Pool {
   void ReleaseBatch(Batch* b);
   OutPtrs PtrsOf(const Batch& b) const;
   void Enqueue(const int* d_ids, int k, const void* d_action, bool force);
+  Batch* BeginBatch(int k);
+  // one launch of the family's step kernel for rows [row0, row0 + kp) of batch b
+  void LaunchPart(Batch* b, const int* d_ids, int row0, int kp, const void* d_action, bool force);
+  void FinishBatch(Batch* b);
+  struct Staging;
+  void SendPipelined(Staging& s, int k, const void* action, size_t id_bytes, size_t act_bytes);
+  bool HostBlockVisible(const void* p);
   // chooses stream_ for the next launch and orders it behind what it may depend on
   void PickStream(const int32_t* host_ids, int k, bool device_path, const void* d_env_id = nullptr);
   void EnsureDone(Batch* b);  // records b->done on the batch's stream if nobody has yet
@@ -240,6 +295,9 @@ class Pool {
   std::mutex recv_mu_;               // recv is single-consumer (state_buffer_queue.h:143-147): callers are serialised
   std::condition_variable pending_cv_;  // signalled by Enqueue; WantRows waits on it
   int recv_timeout_ms_{-1};
+  int pipeline_rows_{-1};            // "step_pipeline": whole-pool host-path steps of at least this many rows (0: never)
+  int* iota_dev_{nullptr};           // [num_envs] global env ids in order (the second half's id list)
+  std::unique_ptr<HostCopier> copier_;  // "copy_threads" helpers (default 2, 0 = none) for pipelined steps
   std::deque<Batch*> pending_;
   std::vector<std::vector<Batch*>> free_;  // per compute stream
   std::vector<std::unique_ptr<Batch>> all_;

@@ -223,33 +223,7 @@ EPA_HD void ContactCols(const G& g, Vec3<V> cp, Vec3<V>* C) {
   if constexpr (K >= 1) C[3] = Cross(g.Rot(2), cp - g.PosA());  // hip axis = torso z
   if constexpr (K >= 2) C[4] = Cross(g.Ank(), cp - g.PosF());
 }
-// once per forward pass and touching class: impedance, regulariser and reference
-// accelerations (they depend on the pose and the velocity only) -> the lane's cache slots
-template <int K, typename T, typename V, typename B, typename G, typename Lds>
-EPA_HD void SetupContact(const AntModel<T>& m, const G& g, B active, const V* v, int w, T radius,
-                         T invw, Lds&& lds) {
-  const Vec3<V> ctr = g.At(CenterSlot(w));  // w is wave uniform: a scalar base
-  const V dist = ctr.z - V(radius);
-  const B touch = active & (dist < V(m.margin));
-  const Vec3<V> cp = {ctr.x, ctr.y, V(0.5) * dist};
-  Vec3<V> C[5];
-  ContactCols<K>(g, cp, C);
-  Vec3<V> vel = {v[0], v[1], v[2]};
-  static_for<0, 3 + K>([&](auto kc) {
-    constexpr int k = decltype(kc)::value;
-    vel = vel + C[k] * v[3 + k];
-  });
-  const V rr = dist - V(m.margin);
-  const V imp = ImpedanceV(m.imp_d0, m.imp_dmax, m.imp_width, rr);
-  const V num = (V(1) - imp) * V(invw * (T(1) + m.mu * m.mu));  // R = max(mjMINVAL, num / imp)
-  const V invR = Sel(num < V(1e-15) * imp, V(1e15), imp / num);
-  const int base = kSlotCache + 4 * w;
-  lds(base) = Sel(touch, -V(m.con_B) * vel.z - V(m.con_K) * imp * rr, V(0));      // an
-  lds(base + 1) = Sel(touch, V(m.con_B * m.mu) * vel.y, V(0));                   // ay
-  lds(base + 2) = Sel(touch, V(m.con_B * m.mu) * vel.x, V(0));                   // ax
-  lds(base + 3) = Sel(touch, invR * V(T(1) / (T(2) * m.mu * m.mu)), V(0));       // D_py = 1 / (2 mu^2 R)
-}
-// every solver pass: the cached constants + the Jacobian columns rebuilt from the pose
+// ContactWrench: the cached constants (SetupContactAt) + the Jacobian columns rebuilt from the pose
 template <int K, typename T, typename V, typename G, typename Lds>
 EPA_HD void LoadContact(const G& g, int w, T radius, Lds&& lds, Contact<V>& c, Vec3<V>* C) {
   const Vec3<V> ctr = g.At(CenterSlot(w));
@@ -288,6 +262,33 @@ EPA_HD void LoadContactAt(const AntModel<T>& m, const G& g, const U& w, B has, C
   c.ay = Sel(has, GatherSlot(g.lds, UMad(base, 1u, 1u)), V(0));
   c.ax = Sel(has, GatherSlot(g.lds, UMad(base, 1u, 2u)), V(0));
   c.D = Sel(has, GatherSlot(g.lds, UMad(base, 1u, 3u)), V(0));
+}
+// SetupContact for the lane's own class w (see LoadContactAt): once per forward pass
+template <typename T, typename V, typename B, typename U, typename G>
+EPA_HD void SetupContactAt(const AntModel<T>& m, const G& g, const U& w, B has, const V* v) {
+  Contact<V> unused;
+  Vec3<V> C[5];
+  LoadContactAt(m, g, w, has, unused, C);
+  const U cs = Tab6(kCenterSlotTab, w);
+  const B torso = UEq(w, 6u);
+  const V dist = GatherSlot(g.lds, UMad(cs, 1u, 2u)) - Sel(torso, V(m.sph_r[0]), V(m.sph_r[1]));
+  Vec3<V> vel = {v[0], v[1], v[2]};
+  static_for<0, 5>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    vel = vel + C[k] * v[3 + k];
+  });
+  // body_invweight0 of the class's geom: torso sphere, stub, leg capsule, ankle capsule
+  const V invw = Sel(torso, V(m.geom_body_invw[0]),
+                     Sel(UGe(w, 4u), V(m.geom_body_invw[3]), Sel(UGe(w, 2u), V(m.geom_body_invw[2]), V(m.geom_body_invw[1]))));
+  const V rr = dist - V(m.margin);
+  const V imp = ImpedanceV(m.imp_d0, m.imp_dmax, m.imp_width, rr);
+  const V num = (V(1) - imp) * (invw * V(T(1) + m.mu * m.mu));  // R = max(mjMINVAL, num / imp)
+  const V invR = Sel(num < V(1e-15) * imp, V(1e15), imp / num);
+  const U base = UMad(w, 4u, (unsigned)kSlotCache);
+  ScatterSlot(g.lds, base, -V(m.con_B) * vel.z - V(m.con_K) * imp * rr, has);               // an
+  ScatterSlot(g.lds, UMad(base, 1u, 1u), V(m.con_B * m.mu) * vel.y, has);                    // ay
+  ScatterSlot(g.lds, UMad(base, 1u, 2u), V(m.con_B * m.mu) * vel.x, has);                    // ax
+  ScatterSlot(g.lds, UMad(base, 1u, 3u), invR * V(T(1) / (T(2) * m.mu * m.mu)), has);        // D_py = 1 / (2 mu^2 R)
 }
 template <int K, typename V>
 EPA_HD Vec3<V> JacMul(const Vec3<V>* C, const V* a) {  // J a
@@ -905,21 +906,33 @@ EPA_HD void Forward(const AntModel<T>& m, const Leg<V, B>& lg, const SolverCfg<T
   EPA_ANT_TICK(1);
   EPA_ANT_CLASSES(sph, own);
   EPA_LDS_FENCE();
+  // (the torso sphere is probed on every lane of the quad and owned by the first one)
+  const U vis = MaskClear(own, !lg.first, 1u << 6);
   {
     const Geo<V, typename std::remove_reference<Lds>::type> g{lds};
+    if constexpr (kWrench) {
+      // ContactWrench walks the wave's UNION of classes and reads every lane's cache of them: D = 0 where a
+      // lane does not own the class
+      if (wrench) {
+        EPA_ANT4_NO_UNROLL
+        for (unsigned rem = sph; rem != 0; rem &= rem - 1) {
+          const int base = kSlotCache + 4 * __builtin_ctz(rem);
+          static_for<0, 4>([&](auto kc) { lds(base + decltype(kc)::value) = V(0); });
+        }
+        EPA_LDS_FENCE();
+      }
+    }
+    U rem = vis;  // the lane's own touching classes, one per trip (see RowsPass)
     EPA_ANT4_NO_UNROLL
-    for (unsigned rem = sph; rem != 0; rem &= rem - 1) {
-      const int w = __builtin_ctz(rem);
-      DispatchSphere(m, w, [&](auto kc, T radius, T invw) {
-        const B active = w == 6 ? lg.first : (lg.first | !lg.first);
-        SetupContact<decltype(kc)::value>(m, g, active, v, w, radius, invw, lds);
-      });
+    while (AnyWave(AnySlot(rem))) {
+      const B has = AnySlot(rem);
+      const U w = PopSlot(rem);
+      SetupContactAt(m, g, w, has, v);
     }
   }
   EPA_LDS_FENCE();
   EPA_ANT_TICK(2);
-  // (the torso sphere is probed on every lane of the quad and owned by the first one)
-  Solve<U>(m, lg, lds, MaskClear(own, !lg.first, 1u << 6), rows, v, qfrc, cfg, qacc, n_env, n_wave);
+  Solve<U>(m, lg, lds, vis, rows, v, qfrc, cfg, qacc, n_env, n_wave);
   // profiling: + 1e3 x sphere classes the wave visits + 1e6 x those of this env
   *n_wave += 1000 * __builtin_popcount(sph) + 1000000 * MaskCount4(own);
   if constexpr (kWrench) {

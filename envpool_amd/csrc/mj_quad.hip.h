@@ -149,6 +149,13 @@ inline U4 UMad(const U4& a, unsigned mul, unsigned add) {
 inline void MaskSetAt(U4& m, B4 on, const U4& bit) {
   for (int i = 0; i < 4; ++i) m.v[i] |= (on.v[i] ? 1u : 0u) << bit.v[i];
 }
+// lane i writes ITS slot slot.v[i] of a per-lane block, where `on`
+template <typename Lds, typename T>
+inline void ScatterSlot(Lds&& lds, const U4& slot, const Q4<T>& x, B4 on) {
+  for (int i = 0; i < 4; ++i) {
+    if (on.v[i]) lds((int)slot.v[i]).v[i] = x.v[i];
+  }
+}
 // lane i reads ITS slot slot.v[i] of a per-lane block
 template <typename Lds>
 inline auto GatherSlot(Lds&& lds, const U4& slot) -> typename std::decay<decltype(lds(0))>::type {
@@ -191,6 +198,10 @@ EPA_HD bool UEq(unsigned a, unsigned b) { return a == b; }
 EPA_HD unsigned Tab6(unsigned long long tab, unsigned idx) { return (unsigned)(tab >> (6u * idx)) & 63u; }
 EPA_HD unsigned UMad(unsigned a, unsigned mul, unsigned add) { return a * mul + add; }
 EPA_HD void MaskSetAt(unsigned& m, bool on, unsigned bit) { m |= (on ? 1u : 0u) << bit; }
+template <typename Lds, typename T>
+EPA_HD void ScatterSlot(Lds&& lds, unsigned slot, T x, bool on) {
+  if (on) lds((int)slot) = x;
+}
 template <typename Lds>
 EPA_HD auto GatherSlot(Lds&& lds, unsigned slot) -> typename std::decay<decltype(lds(0))>::type {
   return lds((int)slot);  // the device accessor takes a per-lane slot number as it takes a uniform one

@@ -77,7 +77,7 @@ struct AntDev {
   double* lag;   // [2][N]
   double* nsaved;
   unsigned char* navail;
-  double* cost;  // [N] Newton iterations of the last step (the sort key of the next launch), see AntGetState
+  double* cost;  // [N] profiling: Newton iterations of the last step, see AntGetState
   // diagnostic (EPA_ANT_TRACE=<file>): per wave of the last launch {wall clock begin, end
   // (100 MHz), core clock begin, end, slot, HW_ID}; nullptr otherwise
   long long* trace;
@@ -116,10 +116,11 @@ constexpr int kAntWavesPerEu = sizeof(T) == 4 ? 2 : 1;
 // (c, j) wrote, maybe on another XCD: (c, j) publishes `progress[c] = epoch + j + 1` behind a device-scope fence
 // and the taker of (c, j + 1) -- a LATER ticket, so (c, j) is running or done: no deadlock, every ticket is taken
 // with the atomic by a wave that is resident -- waits for it.
-// Rows are dealt to chunks through `perm`: most expensive first by the Newton iterations the env needed in its
-// previous env-step (AntSortKernel; persistence 0.64), so that the 16 envs of a wave need similar numbers of
-// trips (a wave executes the max) and the long units start first.  Results do not depend on either: an env's
-// arithmetic never involves another env, and the output row of an env is its row of the send.
+// Dealing the rows to chunks in descending order of the Newton iterations their env needed in its previous env-step
+// (the cost-ordered dispatch of round 2: +7 % then, at a persistence of 0.64) was rebuilt on this queue and measured
+// out: since the one-evaluation line search an env's trip count is noise from step to step (correlation 0.098,
+// profiles/r6b_ant_iter_stats.txt), grouping by it leaves the wave maxima where they are (48.2 vs 48.3) and the
+// sort plus the scattered state accesses cost 5 % (profiles/r6b_ant_queue_ab.md).  Not kept.
 struct AntArgs {
   AntDev dev;
   CommonDev cm;
@@ -132,7 +133,6 @@ struct AntArgs {
   int nchunks;           // ceil(k / 16)
   int sub;               // mj_steps per unit
   int units_per_chunk;   // ceil(frame_skip / sub)
-  const int* perm;       // [k] row served at position p (nullptr: p)
   unsigned char* rowflag;  // [k] 1: the row was a reset row of this launch (units after the first skip it)
   unsigned* progress;    // [nchunks] epoch + units of the chunk completed
   unsigned epoch;
@@ -180,7 +180,7 @@ __device__ __forceinline__ void AntUnit(int ci, int s0, int s1, T* lds_buf) {
   const int n = cm.n;
   const int pos = ci * kAntEnvsPerBlock + (lane >> 2);
   const bool last_unit = s1 >= task.frame_skip;
-  const int row = ap->perm ? ap->perm[pos] : pos;
+  const int row = pos;
   const int e = a.ids ? a.ids[row] - a.id_offset : row;
   bool reset;
   if (first_unit) {
@@ -297,7 +297,7 @@ __device__ __forceinline__ void AntUnit(int ci, int s0, int s1, T* lds_buf) {
   const bool last_unit = s1 >= task.frame_skip;
   int pos2 = ci * kAntEnvsPerBlock + (lane >> 2);
   asm volatile("" : "+v"(pos2));
-  const int row = ap->perm ? ap->perm[pos2] : pos2;
+  const int row = pos2;
   const int e = a.ids ? a.ids[row] - a.id_offset : row;
   double* obs = (double*)out.p[kKeyEnv0] + (size_t)row * nobs;
   double* obs_v = obs + A::kNQ - task.obs_skip;
@@ -494,51 +494,6 @@ __attribute__((amdgpu_waves_per_eu(kAntWavesPerEu<T>, kAntWavesPerEu<T>))) void 
 #endif
 }
 
-// Rows in descending order of predicted cost: a stable counting sort on the Newton iterations the env needed in
-// its previous env-step (dev.cost; own iterations = the part below 1e4).  One block; see Hum4SortKernel.
-constexpr int kAntSortThreads = 256, kAntSortBuckets = 32;
-__device__ __forceinline__ int AntCostBucket(double cost) {
-  const double w = floor(cost * 1.0e-4);
-  const int it = (int)(cost - 1.0e4 * w);  // own Newton iterations over the 20 forward passes
-  const int b = (it - 16) >> 1;            // 16 .. 80 iterations in steps of 2
-  return b < 0 ? 0 : (b > kAntSortBuckets - 1 ? kAntSortBuckets - 1 : b);
-}
-__global__ __launch_bounds__(kAntSortThreads) void AntSortKernel(AntDev dev, StepArgs a, int* perm) {
-  __shared__ int cnt[kAntSortBuckets][kAntSortThreads + 1];
-  __shared__ int base[kAntSortBuckets + 1];
-  const int t = threadIdx.x;
-  const int chunk = (a.k + kAntSortThreads - 1) / kAntSortThreads;
-  const int lo = t * chunk, hi = lo + chunk < a.k ? lo + chunk : a.k;
-  for (int b = 0; b < kAntSortBuckets; ++b) cnt[b][t] = 0;
-  for (int r = lo; r < hi; ++r) {
-    const int e = a.ids ? a.ids[r] - a.id_offset : r;
-    ++cnt[AntCostBucket(dev.cost[e])][t];
-  }
-  __syncthreads();
-  // exclusive scan over threads, per bucket (thread b scans bucket b: 256 adds)
-  if (t < kAntSortBuckets) {
-    int run = 0;
-    for (int i = 0; i < kAntSortThreads; ++i) {
-      const int v = cnt[t][i];
-      cnt[t][i] = run;
-      run += v;
-    }
-    base[t + 1] = run;
-  }
-  __syncthreads();
-  if (t == 0) {
-    base[0] = 0;
-    for (int b = 0; b < kAntSortBuckets; ++b) base[b + 1] += base[b];
-  }
-  __syncthreads();
-  // most expensive bucket first: the long units start early, the short ones fill the tail
-  for (int r = lo; r < hi; ++r) {
-    const int e = a.ids ? a.ids[r] - a.id_offset : r;
-    const int b = AntCostBucket(dev.cost[e]);
-    perm[(a.k - base[b + 1]) + cnt[b][t]++] = r;
-  }
-}
-
 // flat state like oracle/mjcpu: qpos[15] qvel[14] warm[14] time xlag ylag done
 // cur_step normal_saved normal_avail
 constexpr int kAntStateDim = A::kNQ + 2 * A::kNV + 7;
@@ -610,7 +565,6 @@ class AntPool : public Pool {
     task_.contact_force_max = cfg.Get("contact_force_max", 1.0);
     fp64_ = (int)cfg.Get("precision", 1) == 1;
     sub_ = (int)cfg.Get("ant_sub", 1);
-    sort_ = cfg.Get("ant_sort", 1) != 0;
     {
       hipDeviceProp_t prop;
       EPA_HIP(hipGetDeviceProperties(&prop, cfg.device));
@@ -661,7 +615,6 @@ class AntPool : public Pool {
     (void)hipFree(dev_.cost);
     for (auto& kv : queues_) {
       (void)hipFree(kv.second.ticket);
-      (void)hipFree(kv.second.perm);
       (void)hipFree(kv.second.rowflag);
       (void)hipFree(kv.second.progress);
     }
@@ -685,7 +638,6 @@ class AntPool : public Pool {
     if (qu.ticket == nullptr) {
       const size_t n = (size_t)cfg_.num_envs, nch = (n + kAntEnvsPerBlock - 1) / kAntEnvsPerBlock;
       EPA_HIP(hipMalloc(&qu.ticket, sizeof(unsigned)));
-      EPA_HIP(hipMalloc(&qu.perm, sizeof(int) * n));
       EPA_HIP(hipMalloc(&qu.rowflag, n));
       EPA_HIP(hipMalloc(&qu.progress, sizeof(unsigned) * nch));
       EPA_HIP(hipMemsetAsync(qu.ticket, 0, sizeof(unsigned), stream_));
@@ -708,13 +660,7 @@ class AntPool : public Pool {
     qu.epoch += (unsigned)args.units_per_chunk + 1u;
     args.max_iter = fp64_ ? 50 : 12;
     args.gtol = fp64_ ? 1e-13 : 1e-6;
-    args.perm = nullptr;
-    // cost order pays when chunks queue for waves; a wave of a small batch starts at once whatever its place
     const int resident = wave_slots_ * (fp64_ ? 1 : 2);
-    if (sort_ && !force_reset && args.nchunks > resident) {
-      hipLaunchKernelGGL(AntSortKernel, dim3(1), dim3(kAntSortThreads), 0, stream_, dev_, a, qu.perm);
-      args.perm = qu.perm;
-    }
     const int units = args.nchunks * args.units_per_chunk;
     const int blocks = units < resident ? units : resident;
     args.ticket = qu.ticket;
@@ -735,7 +681,6 @@ class AntPool : public Pool {
   struct Queue {
     unsigned* ticket{nullptr};
     unsigned base{0};
-    int* perm{nullptr};
     unsigned char* rowflag{nullptr};
     unsigned* progress{nullptr};
     unsigned epoch{1};
@@ -743,7 +688,6 @@ class AntPool : public Pool {
   std::map<hipStream_t, Queue> queues_;
   int wave_slots_{1024};  // SIMDs of the device
   int sub_{1};            // "ant_sub": mj_steps per unit of the work queue
-  bool sort_{true};       // "ant_sort": rows dealt to chunks in descending order of predicted cost
   AntDev dev_{};
   WaveTrace trace_;
   A::AntModel<double> model_;

@@ -412,6 +412,11 @@ class CheetahPool : public Pool {
     // Walker2d / Hopper terminate when unhealthy, each env at its own time: tiled generator words; the
     // HalfCheetah never terminates early (all envs draw in the same launch)
     if (walker) mt_tile_default_ = 16;
+    // A whole-pool host-path step as two half launches (Pool::SendPipelined): pays where half the rows take about
+    // half the time, i.e. with 2 lanes per env, where 65536 rows are two rounds of chunks (HalfCheetah 1.09e8 ->
+    // 1.3e8, Walker2d 8.1e7 -> 9.2e7 env-steps/s through the numpy API); a Hopper launch (64 envs per wave) or a
+    // Pusher launch is ONE round at that size, and two half launches take twice as long (profiles/r6g_numpy_step_ab.txt)
+    if (layout_ == 2) pipeline_default_ = 32768;
     InitCommon();
   }
   ~CheetahPool() override {
