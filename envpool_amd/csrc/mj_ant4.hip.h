@@ -366,7 +366,10 @@ EPA_HD void RowsPass(const AntModel<T>& m, const Leg<V, B>& lg, const G& g, cons
       MaskSetAt(m0, on, UMad(bit0, 1u, (unsigned)k));
     });
     const V wsum = wt[0] + wt[1] + wt[2] + wt[3];
-    if (AnyWave(wsum > V(0))) {
+    // unconditional (lanes without an active row add zeros): a branch around the update makes the 8 gradient and 36
+    // Hessian accumulators values with two reaching definitions, copied at the head of the class loop and back at its
+    // end -- 92 v_mov_b64 of the loop's 434 instructions (mj_planar_lg.hip.h, RowsPass: the same finding)
+    {
       const V mu = V(m.mu);
       const V gz = wt[0] * jar[0] + wt[1] * jar[1] + wt[2] * jar[2] + wt[3] * jar[3];
       const V gy = mu * (wt[0] * jar[0] - wt[1] * jar[1]);

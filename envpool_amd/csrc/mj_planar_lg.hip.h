@@ -938,8 +938,10 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
       jn[j] = Sel(in, -(cpx - p.px[j - 2]), V(0));
       jx[j] = Sel(in, cpz - p.pz[j - 2], V(0));
     });
-    V jna = V(0), jxa = V(0);
-    static_for<0, kLV>([&](auto jc) {
+    // (the two slides' columns are the unit vectors: jn = (0, 1, ...), jx = (1, 0, ...); written out, because
+    // 0 x a[j] is an FMA the compiler must keep)
+    V jna = a[1], jxa = a[0];
+    static_for<2, kLV>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       jna += jn[j] * a[j];
       jxa += jx[j] * a[j];
@@ -961,15 +963,40 @@ EPA_HD void RowsPass(const CheetahModel<T>& m, Cx& cx, const Pos<V>& p, const Li
     const V gn = w1 * jar1 + w2 * jar2 + w3 * jar3;  // coefficient of Jn
     const V gx = mu * (w3 * jar3 - w2 * jar2);      // coefficient of Jx
     const V A = w1 + w2 + w3, Bc = mu * (w3 - w2), C = mu * mu * (w2 + w3);
-    if (AnyWave(A > V(0))) {
+    // Unconditional (lanes whose rows are inactive add zeros).  Rounds 3-5 skipped the update when no lane of the wave
+    // had an active row in the visit; the branch made every accumulator -- 6 gradient and 21 Hessian doubles -- a
+    // value with two reaching definitions, and the compiler copied all 27 at the head of the slot loop and back at
+    // its end: 54 v_mov_b64 of the loop's 258 instructions.  HalfCheetah 4.13e8 -> 4.33e8, Walker2d +6 %, Hopper +6 %
+    // (profiles/r6i_lg_rowpass_ab.txt).
+    {
       static_for<0, kLV>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        gc[i] += jn[i] * gn + jx[i] * gx;
+        // dofs 0 and 1 (the slides): jn = 0, jx = 1 and jn = 1, jx = 0
+        if constexpr (i == 0) {
+          gc[0] += gx;
+        } else if constexpr (i == 1) {
+          gc[1] += gn;
+        } else {
+          gc[i] += jn[i] * gn + jx[i] * gx;
+        }
         if constexpr (kHess) {
-          const V ui = A * jn[i] + Bc * jx[i], wi = Bc * jn[i] + C * jx[i];
+          V ui, wi;
+          if constexpr (i == 0) {
+            ui = Bc, wi = C;
+          } else if constexpr (i == 1) {
+            ui = A, wi = Bc;
+          } else {
+            ui = A * jn[i] + Bc * jx[i], wi = Bc * jn[i] + C * jx[i];
+          }
           static_for<i, kLV>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            Hc[Tri(i, k)] += ui * jn[k] + wi * jx[k];
+            if constexpr (k == 0) {
+              Hc[Tri(i, k)] += wi;
+            } else if constexpr (k == 1) {
+              Hc[Tri(i, k)] += ui;
+            } else {
+              Hc[Tri(i, k)] += ui * jn[k] + wi * jx[k];
+            }
           });
         }
       });

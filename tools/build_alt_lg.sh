@@ -7,6 +7,6 @@ set -e
 TAG=$1; shift
 cd "$(dirname "$0")/../envpool_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result "$@" -c mujoco_planar_lg.hip -o build/mujoco_planar_lg_$TAG.o 2>&1 | grep -E "error" -A5 || true
-OBJ=$(ls build/*.o | grep -v "_trace.o" | grep -v "alt_" | grep -v "mujoco_planar_lg" | tr '\n' ' ')
+OBJ="build/engine.o build/classic_control.o build/toy_text.o build/mujoco_gym.o build/mujoco_ant.o build/mujoco_pendulum.o build/mujoco_humanoid.o build/mujoco_humanoid_standup.o build/mujoco_humanoid4.o build/mujoco_pusher.o build/atari_post.o build/atari_env.o"  # the product's objects (Makefile: OBJ) minus the ones replaced
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJ build/mujoco_planar_lg_$TAG.o -o ../lib/libenvpool_amd_$TAG.so -ldl -lpthread
 ls -la ../lib/libenvpool_amd_$TAG.so
