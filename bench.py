@@ -413,6 +413,27 @@ def main():
                 "profiles/flops_algorithmic.json: oracle/mjcpu (general 3-D dense restatement) with an "
                 "operation-counting scalar, mean over a random-action rollout; the planar kernels exploit "
                 "the 2-D structure and can issue fewer")
+        # What of the issued work an env NEEDS: a wave executes every Newton trip until its slowest env has converged
+        # (the solver share of a wave's cycles is paid max-over-the-wave's-envs times), so
+        #   frac_necessary = frac x ((1 - solver_share) + solver_share x trips_needed / trips_executed),
+        # shares from the stage timers of the diagnostic builds, trip counts from the kernels' own counters
+        # (profiles/necessary_work.json names the source files).  And how busy the fp64 pipe is: every arithmetic
+        # wave instruction (an FMA once) holds a SIMD's issue slot for 4 cycles.
+        try:
+            with open(os.path.join(ROOT, "profiles", "necessary_work.json")) as f:
+                nw = json.load(f).get(f"{kname}@{n}")
+        except OSError:
+            nw = None
+        if nw and valu is not None and roof.get("bound") == "valu":
+            share = nw["solver_share"]
+            roof["frac_necessary"] = roof["frac"] * ((1.0 - share) + share * nw["trips_needed"] / nw["trips_executed"])
+            roof["frac_necessary_source"] = nw["source"]
+        if pmc and not stale and pmc.get("arith_wave_insts_per_launch") and kernel_ms > 0:
+            simds, clock_hz = 1024, 2.4e9  # 256 CUs x 4 SIMDs at the peak clock the 78.6 TFLOP/s figure assumes
+            roof["fp64_issue_slot_util" if args.precision == "fp64" or fp64_only else "fp32_issue_slot_util"] = (
+                pmc["arith_wave_insts_per_launch"] * 4.0 / (simds * kernel_ms * 1e-3 * clock_hz))
+            if pmc.get("valu_wave_insts_per_launch"):
+                roof["arith_share_of_valu_insts"] = pmc["arith_wave_insts_per_launch"] / pmc["valu_wave_insts_per_launch"]
         if stale:
             roof["stale"] = True  # profiles/pmc.json holds counts of an older build of this kernel: not used
         roof.update({"kernel": kbase, "kernel_ms": kernel_ms, "launches": launches,

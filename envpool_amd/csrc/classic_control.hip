@@ -397,6 +397,11 @@ class ClassicPool : public Pool {
     // CartPole / Acrobot episodes end at their own times under any policy: tiled generator words
     // (engine.h: mt_tile_default_); Pendulum and the MountainCars run to the step limit together
     if (KIND == kCartPole || KIND == kAcrobot) mt_tile_default_ = 16;
+    block_ = (int)cfg.Get("classic_block", 0);
+    rows_ = (int)cfg.Get("classic_rows", 1);
+    if ((block_ != 0 && block_ != 64 && block_ != 128 && block_ != 256) || rows_ < 1 || rows_ > 8) {
+      throw std::invalid_argument("classic_block must be 64, 128 or 256 and classic_rows 1 .. 8");
+    }
     InitCommon();
   }
   ~ClassicPool() override {
@@ -419,8 +424,18 @@ class ClassicPool : public Pool {
               const OutPtrs& out) override {
     StepArgs a{d_ids, k, force_reset ? 1 : 0, cfg_.max_episode_steps,
                cfg_.env_id_offset};
-    int blocks = std::min((k + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL(ClassicStepKernel<KIND>, dim3(blocks), dim3(256), 0,
+    // "classic_block" threads per block (64 / 128 / 256; 0 = default), "classic_rows" rows per thread of the
+    // grid-stride loop: A/B keys.  At num_envs = 65536 (BASELINE config 2) a step is one wave per SIMD and one
+    // dependent load -> store chain: an EMPTY kernel takes 1.54 us per back-to-back launch on this machine and a
+    // kernel with nothing but this step's loads and stores 2.85 us (tools/probes/launch_floor_probe.hip); the step
+    // takes 4.0 - 5.7 us.  64-thread blocks are ~10 % faster there for the short bodies (MountainCar 4.71 -> 4.11,
+    // Pendulum 4.44 -> 4.04 us), not for CartPole / Acrobot; two or more rows per thread are slower for every family
+    // (profiles/r6j_classic_launch_shape_ab.txt).
+    const bool short_body = KIND != kCartPole && KIND != kAcrobot;
+    const int block = block_ > 0 ? block_ : (short_body && k <= 131072 ? 64 : 256);
+    const int per = block * rows_;
+    int blocks = std::min((k + per - 1) / per, 256 * 8 * (256 / block));
+    hipLaunchKernelGGL(ClassicStepKernel<KIND>, dim3(blocks), dim3(block), 0,
                        stream_, dev_, common_, a,
                        static_cast<const typename Traits<KIND>::Act*>(d_action),
                        out, version_);
@@ -430,6 +445,7 @@ class ClassicPool : public Pool {
   static constexpr int NS = Traits<KIND>::kNumState;
   ClassicDev dev_{};
   int version_;
+  int block_{0}, rows_{1};
 };
 
 }  // namespace

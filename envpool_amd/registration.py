@@ -27,33 +27,35 @@ class EnvRegistry:
 
     def register(self, task_id: str, import_path: str, spec_cls: str, dm_cls: str,
                  gymnasium_cls: str, aliases: Sequence[str] = (), **kwargs: Any) -> None:
-        """registration.py:72-92."""
-        if "base_path" not in kwargs:
-            kwargs["base_path"] = base_path
-        for alias in (task_id, *aliases):
-            assert alias not in self.specs
-            self.specs[alias] = (import_path, spec_cls, dict(kwargs))
-            self.envpools[alias] = {
-                "dm": (import_path, dm_cls),
-                "gymnasium": (import_path, gymnasium_cls),
-            }
+        """One task id (and its aliases) -> where its spec class and its two pool classes live, plus the
+        config defaults of the id (registration.py:72-92)."""
+        kwargs.setdefault("base_path", base_path)
+        pools = {"dm": (import_path, dm_cls), "gymnasium": (import_path, gymnasium_cls)}
+        for name in (task_id, *aliases):
+            assert name not in self.specs
+            self.specs[name] = (import_path, spec_cls, dict(kwargs))
+            self.envpools[name] = dict(pools)
 
-    @staticmethod
-    def _extract_make_options(kwargs: dict[str, Any]) -> tuple[bool, dict[str, Any]]:
-        """registration.py:94-139 (render bookkeeping only)."""
+    _RENDER_MODES = (None, "rgb_array", "human")
+    _RENDER_KEYS = ("render_width", "render_height", "render_camera_id")
+
+    @classmethod
+    def _extract_make_options(cls, kwargs: dict[str, Any]) -> tuple[bool, dict[str, Any]]:
+        """Takes the wrapper-level options out of `kwargs` (registration.py:94-139; render bookkeeping only:
+        they become attributes of the env object, nothing is rendered here)."""
         from_pixels = bool(kwargs.pop("from_pixels", False))
-        wrapper_kwargs = {
-            key: kwargs.pop(key) for key in ("render_mode", "render_env_id") if key in kwargs
-        }
-        render_mode = wrapper_kwargs.get("render_mode")
-        if render_mode not in {None, "rgb_array", "human"}:
+        wrapper_kwargs = {}
+        for key in ("render_mode", "render_env_id"):
+            if key in kwargs:
+                wrapper_kwargs[key] = kwargs.pop(key)
+        if wrapper_kwargs.get("render_mode") not in cls._RENDER_MODES:
             raise ValueError("render_mode must be one of None, 'rgb_array', or 'human'")
         if from_pixels:
             raise ValueError(
                 "from_pixels=True needs the reference's offscreen renderer, which is "
                 "outside the batched-step path this engine replaces."
             )
-        for key in ("render_width", "render_height", "render_camera_id"):
+        for key in cls._RENDER_KEYS:
             if key in kwargs:
                 wrapper_kwargs[key] = kwargs.pop(key)
         return from_pixels, wrapper_kwargs
@@ -65,38 +67,34 @@ class EnvRegistry:
         return env
 
     def _make_env_spec(self, task_id: str, **make_kwargs: Any) -> Any:
-        """registration.py:187-234."""
-        import_path, spec_cls, kwargs = self.specs[task_id]
-        kwargs = {**kwargs, **make_kwargs}
-        if "seed" in kwargs:  # reference issue 214
-            if self._is_env_seed_sequence(kwargs["seed"]):
+        """The id's registered defaults overridden by the caller's kwargs, checked like the reference checks them
+        (registration.py:187-234: AssertionError for out-of-range values), then the spec class's gen_config."""
+        import_path, spec_cls, defaults = self.specs[task_id]
+        kwargs = dict(defaults)
+        kwargs.update(make_kwargs)
+        num_envs = kwargs.get("num_envs", 1)
+        if "seed" in kwargs:
+            seed = kwargs["seed"]
+            if self._is_env_seed_sequence(seed):  # a list of seeds is the per-env form (reference issue 214)
                 assert "env_seed" not in kwargs, (
                     "Pass either `seed` as an int or seed list, or `env_seed`, but not both."
                 )
-                kwargs["env_seed"] = self._normalize_env_seed(
-                    kwargs["seed"], kwargs.get("num_envs", 1))
-                kwargs["seed"] = 0
+                kwargs["env_seed"], kwargs["seed"] = seed, 0
             else:
-                self._assert_int32_seed(kwargs["seed"])
+                self._assert_int32_seed(seed)
         if "env_seed" in kwargs:
-            kwargs["env_seed"] = self._normalize_env_seed(
-                kwargs["env_seed"], kwargs.get("num_envs", 1))
-        if "num_envs" in kwargs:
-            assert kwargs["num_envs"] >= 1
+            kwargs["env_seed"] = self._normalize_env_seed(kwargs["env_seed"], num_envs)
+        assert kwargs.get("num_envs", 1) >= 1
         if "batch_size" in kwargs:
             assert 0 <= kwargs["batch_size"] <= kwargs["num_envs"]
-        if "max_num_players" in kwargs:
-            assert 1 <= kwargs["max_num_players"]
+        assert kwargs.get("max_num_players", 1) >= 1
         spec_type = getattr(importlib.import_module(import_path), spec_cls)
-        config = spec_type.gen_config(**kwargs)
-        return spec_type(config)
+        return spec_type(spec_type.gen_config(**kwargs))
 
     def make(self, task_id: str, env_type: str, **kwargs: Any) -> Any:
         """registration.py:250-281."""
         _, wrapper_kwargs = self._extract_make_options(kwargs)
-        if "gym_reset_return_info" not in kwargs:
-            kwargs["gym_reset_return_info"] = True
-        if not kwargs["gym_reset_return_info"]:
+        if not kwargs.setdefault("gym_reset_return_info", True):
             raise ValueError(
                 "EnvPool's gym API now follows gymnasium reset semantics and "
                 "always returns an info dictionary after resets."
@@ -131,21 +129,17 @@ class EnvRegistry:
             isinstance(seed, np.ndarray)
 
     def _normalize_env_seed(self, seed: Any, num_envs: int) -> list[int]:
+        """per-env seeds as a list of num_envs Python ints, each an int32 (registration.py:313-330)"""
         if isinstance(seed, np.ndarray):
-            assert seed.ndim == 1, (
-                f"`seed` as an array must be 1-dimensional, got shape {seed.shape}"
-            )
-            seed = seed.tolist()
-        else:
-            seed = list(seed)
-        assert len(seed) == num_envs, (
+            assert seed.ndim == 1, f"`seed` as an array must be 1-dimensional, got shape {seed.shape}"
+        seeds = [int(x) for x in (seed.tolist() if isinstance(seed, np.ndarray) else seed)]
+        assert len(seeds) == num_envs, (
             "When `seed` is a sequence, its length must match `num_envs`, "
-            f"got len(seed) = {len(seed)} and num_envs = {num_envs}"
+            f"got len(seed) = {len(seeds)} and num_envs = {num_envs}"
         )
-        normalized = [int(s) for s in seed]
-        for s in normalized:
-            self._assert_int32_seed(s)
-        return normalized
+        for x in seeds:
+            self._assert_int32_seed(x)
+        return seeds
 
     def list_all_envs(self) -> list[str]:
         return list(self.specs.keys())

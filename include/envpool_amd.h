@@ -83,6 +83,21 @@ typedef struct epa_pool epa_pool;
  *   "planar_lpt"  lane-group kernel: 1 whole-pool launches serve the chunks of envs slowest first, by their
  *                 duration in the previous launch (default for Walker2d / Hopper); 0 index order (default for
  *                 HalfCheetah since round 5).  Never changes results.
+ *   "step_pipeline" sync pools, host path (epa_send): a whole-pool send of at least this many rows runs as TWO launches
+ *                 over the two halves of the rows, and epa_recv* downloads the first half while the second computes (the
+ *                 rows still arrive as ONE batch in send order, every value bit-identical to the single launch).
+ *                 Default 32768 for HalfCheetah / Walker2d pools with 2 lanes per env (where half the rows take half
+ *                 the time: numpy API +20 %), 0 = off for every other family (measured slower there); 0 switches it off.
+ *   "copy_threads" helper threads (default 2, 0 .. 8) that copy the action rows of a pipelined step into the pinned
+ *                 staging slot together with the calling thread; they poll ~0.3 ms after a step, then sleep
+ *   "ant_sub"     Ant: mj_steps per unit of the step kernel's work queue (default 1: an env-step of a 16-env chunk is
+ *                 frame_skip units, the chunk's state goes through HBM between them; frame_skip = one unit per chunk,
+ *                 the schedule of rounds 2-5).  Never changes results.
+ *   "selftest"    MuJoCo families with a self-test table (HalfCheetah, Walker2d, Hopper, Ant, Humanoid,
+ *                 HumanoidStandup): 0 skips the load-time self-test for this pool (see epa_create); the environment
+ *                 variable EPA_SELFTEST=0 skips it for the process
+ *   "classic_block", "classic_rows" classic_control: threads per block (64 / 128 / 256, default by family and size) and
+ *                 rows per thread of the step kernel (A/B keys; never change results)
  *   "recv_timeout_ms" every family: how long epa_recv* waits for rows that have not been sent yet (see epa_recv):
  *                 < 0 forever (default, the reference's behaviour), 0 not at all, > 0 milliseconds
  *   "compute_streams" async mode (batch_size < num_envs): successive batches run on this many
@@ -146,7 +161,12 @@ int epa_describe_action(const char* family, const epa_config* cfg,
 /* Replaces AsyncEnvPool<Env>::AsyncEnvPool(spec) (async_envpool.h:90-149):
  * allocates SoA state for num_envs envs on `cfg->device`, seeds every env's
  * mt19937 (env.h:101-117) and marks every env done so that the first step is a
- * reset (cartpole.h:67 `done_{true}`, async_envpool.h:127). */
+ * reset (cartpole.h:67 `done_{true}`, async_envpool.h:127).
+ * The FIRST pool of a MuJoCo family in a process (per device) also runs the library's self-test: fixed states are
+ * stepped once in every kernel variant of the family and compared with the same arithmetic evaluated on the host at
+ * build time (envpool_amd/csrc/gen_selftest.cpp), and the launch is repeated and must be bit-identical; a library that
+ * was not built the way envpool_amd/csrc/Makefile builds it is refused with EPA_ERR_DEVICE (~25 ms; EPA_SELFTEST=0 or
+ * the engine key "selftest" = 0 skip it). */
 int epa_create(const char* family, const epa_config* cfg, epa_pool** out);
 
 /* Replaces ~AsyncEnvPool (async_envpool.h:151-162). */

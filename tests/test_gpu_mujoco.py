@@ -973,3 +973,52 @@ def test_reset_draws_across_generator_wraps(task, adim, amax, exact):
         act = rng.uniform(-amax, amax, size=(n, adim))
         a, b = hip_step(pool, act), orc.step(act)
     assert resets >= n * (steps // 2)
+
+
+@pytest.mark.parametrize("task", ["HalfCheetah", "Walker2d", "Hopper", "Ant"])
+def test_one_evaluation_solvers_on_adversarial_states(task):
+    """the one-evaluation line search (mj_planar_lg.hip.h / mj_ant4.hip.h: one Newton step of the 1-D problem
+    per trip, unverified; exact search only as a fallback from trip 8) ON THE DEVICE, far from the benchmark's states
+    -- deep penetrations, joints beyond their ranges, velocities ~ N(0, 8), a garbage warm start -- against the oracle,
+    whose solver searches its lines exactly: one env-step from each state, same result to 1e-9 (the CPU twins:
+    tests/test_mjcpu_invariants.py::test_lane_group_solver_on_adversarial_states / test_ant_solver_...)."""
+    from oracle.orc import Oracle
+
+    n = 512
+    rng = np.random.default_rng(21)
+    orc = Oracle(task, n, seed=5, max_episode_steps=1000)
+    orc.reset()
+    pool = DevicePool(task, n, seed=5, max_episode_steps=1000)
+    ids = np.arange(n, dtype=np.int32)
+    pool.reset(ids)
+    pool.recv()
+    for rep in range(3):
+        st = orc.get_state()
+        if task == "Ant":
+            nq, nv, adim = 15, 14, 8
+            st[:, 2] = rng.uniform(0.15, 0.9, n)
+            quat = rng.normal(0, 1, (n, 4))
+            st[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+            st[:, 7:15] = rng.uniform(-1.2, 1.2, (n, 8))
+            st[:, nq:nq + nv] = rng.normal(0, 4, (n, nv))
+            st[:, nq + nv:nq + 2 * nv] = rng.normal(0, 30, (n, nv))
+        else:
+            nd = 6 if task == "Hopper" else 9
+            adim = nd - 3
+            st[:, 1] = rng.uniform(-0.3, 0.6, n) if task == "HalfCheetah" else rng.uniform(0.3, 1.5, n)
+            st[:, 2] = rng.uniform(-3, 3, n)
+            st[:, 3:nd] = rng.uniform(-1.5, 1.5, (n, nd - 3))
+            st[:, nd:2 * nd] = rng.normal(0, 8, (n, nd))
+            st[:, 2 * nd:3 * nd] = rng.normal(0, 50, (n, nd))
+        orc.set_state(st)
+        pool.set_state(orc.get_state())
+        act = rng.uniform(-1, 1, (n, adim))
+        b = orc.step(act)
+        pool.send(ids, act)
+        a = pool.recv_dict()
+        ok = (b["elapsed_step"].ravel() > 0) & np.isfinite(b["obs"]).all(axis=1)
+        assert ok.sum() > n // 2
+        ref, got = b["obs"][ok], a["obs"][ok]
+        err = np.abs(got - ref) / (1 + np.abs(ref))
+        assert err.max() < 1e-9, (task, rep, float(err.max()))
+        orc.reset(), pool.reset(ids), pool.recv()

@@ -51,6 +51,11 @@ for path in paths:
         "traffic_bytes_per_launch": 1024.0 * (2 * ctr.get("FETCH_SIZE", 0) + ctr.get("WRITE_SIZE", 0)),
         "flops_per_launch": flops,
         "flops_per_env_step": flops / num_envs,
+        # wave-level arithmetic instructions of the kernel's type (an FMA counts once): x 4 cycles each = the issue
+        # slots they occupy on a SIMD (bench.py: roofline.fp64_issue_slot_util)
+        "arith_wave_insts_per_launch": (ctr.get(f"SQ_INSTS_VALU_FMA_{sfx}", 0) + ctr.get(f"SQ_INSTS_VALU_ADD_{sfx}", 0) +
+                                        ctr.get(f"SQ_INSTS_VALU_MUL_{sfx}", 0) + ctr.get(f"SQ_INSTS_VALU_TRANS_{sfx}", 0)),
+        "valu_wave_insts_per_launch": ctr.get("SQ_INSTS_VALU", 0),
         "valu_insts_per_wave": ctr.get("SQ_INSTS_VALU", 0) / waves,
         "lds_insts_per_wave": ctr.get("SQ_INSTS_LDS", 0) / waves,
         "wait_frac_of_wave_cycles": ctr.get("SQ_WAIT_ANY", 0) / max(ctr.get("SQ_WAVE_CYCLES", 1), 1),
