@@ -263,10 +263,10 @@ def main():
         ids = np.arange(rank * n, rank * n + n, dtype=np.int32)
         rng = np.random.default_rng(0)
         hact = [rng.uniform(-ahi, ahi, size=(n, adim)) for _ in range(4)]
-        for i in range(10):  # (the first host-path steps allocate the pinned result blocks and the staging slots)
+        for i in range(30):  # (the first host-path steps allocate the pinned result blocks, the staging slots and start the copy helpers)
             pool.send(ids, hact[i % 4])
             pool.recv()
-        k_np = max(5, min(args.steps, 100))
+        k_np = max(5, min(args.steps, 200))
         t1 = time.perf_counter()
         for i in range(k_np):
             pool.send(ids, hact[i % 4])

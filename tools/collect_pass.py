@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r5z"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r6z"
 
 
 def copy(src, dst):
@@ -31,6 +31,7 @@ def main():
     copy(os.path.join(G, TAG, "bench.jsonl"), f"{TAG}_bench.jsonl")
     copy(os.path.join(G, TAG, "numpy_api.jsonl"), f"{TAG}_numpy_api.jsonl")
     copy(os.path.join(G, TAG, "gpu_tests.log"), f"{TAG}_gpu_tests.log")
+    copy(os.path.join(G, TAG, "bench_families.md"), f"{TAG}_bench_families.md")
     copy(os.path.join(G, TAG, "probe_gpu_box.log"), f"{TAG}_probe_gpu_box.log")
     pmc = json.load(open(os.path.join(P, "pmc.json")))
     alg = json.load(open(os.path.join(P, "flops_algorithmic.json")))

@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r5z"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r6z"
 ALG_BYTES = {"HalfCheetah": 708, "Ant": 1132, "Walker2d": 692, "Hopper": 476, "Humanoid": 4402, "HumanoidStandup": 4362,
              "Pusher": 842}
 ROWS = [
@@ -19,7 +19,7 @@ ROWS = [
     ("PlanarLgStepKernel<1,1>[Hopper]@65536", "Hopper", "`PlanarLgStepKernel<1>` Hopper @65536",
      "no replication at all (one lane = the robot), planar 6-dof form; max over 64 envs per trip"),
     ("AntStepKernel<double>@32768", "Ant", "`AntStepKernel<double>` @32768 (config-4 shard)",
-     "3.2 executed trips per pass vs 1.7, torso replicated ×4"),
+     "3.2 executed trips per pass vs 1.7, torso replicated ×4; traffic: the chunk's state goes through HBM between the 5 units of its env-step"),
     ("PusherStepKernel<double>@65536", "Pusher", "`PusherStepKernel` @65536", "welded bodies merged, rows built only when touching"),
     ("Humanoid4StepKernel<double>@65536", "Humanoid", "`Humanoid4StepKernel` @65536", "trunk replicated ×4, wave-level sweep counts"),
     ("Humanoid4StepKernel<double>[Standup]@65536", "HumanoidStandup", "`Humanoid4StepKernel[Standup]` @65536",
@@ -30,8 +30,12 @@ ROWS = [
 def main():
     pmc = json.load(open(os.path.join(P, "pmc.json")))
     alg = json.load(open(os.path.join(P, "flops_algorithmic.json")))
-    print("| kernel @N | µs | issued flops / env-step → frac | algorithmic → frac_useful | issued / algorithmic, why | traffic / algorithmic bytes |")
-    print("|---|---|---|---|---|---|")
+    try:
+        nw = json.load(open(os.path.join(P, "necessary_work.json")))
+    except OSError:
+        nw = {}
+    print("| kernel @N | µs | issued flops / env-step → frac | → frac_necessary | fp64 issue slots busy | algorithmic → frac_useful | issued / algorithmic, why | traffic / algorithmic bytes |")
+    print("|---|---|---|---|---|---|---|---|")
     for key, task, label, why in ROWS:
         e = pmc[key]
         n, us = e["num_envs"], e["rocprof_avg_us"]
@@ -39,7 +43,11 @@ def main():
         iss, a = e["flops_per_env_step"], alg[task]["flops_per_env_step"]
         tr, ab = e["traffic_bytes_per_launch"], ALG_BYTES[task] * n
         trs = f"{tr / 1e9:.1f} GB / {ab / 1e6:.0f} MB = **{tr / ab:.0f}×**" if tr > 1e9 else f"{tr / 1e6:.1f} / {ab / 1e6:.1f} MB = {tr / ab:.2f}×"
-        print(f"| {label} | {us:.1f} | {iss:.3g} → {iss * n / t / 78.6e12:.3f} | {a:.3g} → {a * n / t / 78.6e12:.3f} | {iss / a:.2f}: {why} | {trs} |")
+        frac = iss * n / t / 78.6e12
+        w = nw.get(key)
+        nec = f"{frac * ((1 - w['solver_share']) + w['solver_share'] * w['trips_needed'] / w['trips_executed']):.3f}" if w else "—"
+        slots = f"{e['arith_wave_insts_per_launch'] * 4 / (1024 * t * 2.4e9):.2f}" if e.get("arith_wave_insts_per_launch") else "—"
+        print(f"| {label} | {us:.1f} | {iss:.3g} → {frac:.3f} | {nec} | {slots} | {a:.3g} → {a * n / t / 78.6e12:.3f} | {iss / a:.2f}: {why} | {trs} |")
     print()
     lines = {}
     d = json.load(open(os.path.join(P, f"{TAG}_bench_default.json")))

@@ -25,11 +25,17 @@ exact = os.path.join(root, "gpurun_out", f"prof_{prefix}", "summary.md")
 paths = [exact] if os.path.exists(exact) else sorted(glob.glob(os.path.join(root, "gpurun_out", f"prof_{prefix}*", "summary.md")))
 for path in paths:
     text = open(path).read()
-    m = re.search(r"## PMC per launch \(mean over launches\): (.+)", text)
-    if not m:
+    # the kernel of the bench's timed window (since round 6 a trace also holds the few launches of OTHER kernel
+    # variants that the library's load-time self-test makes), and ITS counter section only
+    w = re.search(r"## timed window of the bench inside this trace: (.+)", text)
+    sections = re.split(r"## PMC per launch \(mean over launches\): ", text)[1:]
+    if not w or not sections:
         continue
-    kernel = m.group(1).strip()
-    ctr = {k: float(v) for k, v in re.findall(r"\| (\w+) \| ([0-9.e+-]+) \| \d+ \|", text)}
+    kernel = w.group(1).strip()
+    mine = [sec for sec in sections if sec.split("\n", 1)[0].strip() == kernel]
+    if not mine:
+        continue
+    ctr = {k: float(v) for k, v in re.findall(r"\| (\w+) \| ([0-9.e+-]+) \| \d+ \|", mine[0])}
     tr = re.search(r"\| %s \| (\d+) \| ([0-9.]+) \|" % re.escape(kernel), text)
     # the bench's timed window inside the trace, when the summary has it (steady state; the all-launch average of
     # --stats includes the cheap steps right after the common reset)
