@@ -150,20 +150,25 @@ class HostCopier {
   size_t Advance(size_t upto);
 
  private:
+  // One copy job; immutable but for the claim counter and the per-piece flags.  A helper that is late for a job finds
+  // every piece claimed and leaves it alone: the next job never has to wait for stragglers.
+  struct Job {
+    char* dst;
+    const char* src;
+    size_t bytes, pieces;
+    std::atomic<size_t> next{0};
+    std::unique_ptr<std::atomic<uint8_t>[]> done;
+  };
   void Work();
-  bool CopyOne();
+  static bool CopyOne(Job& j);
   std::vector<std::thread> th_;
   std::mutex mu_;
   std::condition_variable cv_;
   std::atomic<uint64_t> gen_{0};
   std::atomic<bool> stop_{false};
-  std::atomic<int> active_{0};  // helpers that have not finished the current job's claim loop
-  char* dst_{nullptr};
-  const char* src_{nullptr};
-  size_t bytes_{0}, pieces_{0};
-  std::atomic<size_t> next_{0};
-  std::vector<std::atomic<uint8_t>> done_;
-  size_t frontier_{0};  // pieces [0, frontier_) are complete (the caller's view)
+  std::shared_ptr<Job> job_;   // guarded by mu_
+  std::shared_ptr<Job> mine_;  // the caller's handle on the current job
+  size_t frontier_{0};         // pieces [0, frontier_) are complete (the caller's view)
 };
 
 class Pool {
