@@ -109,6 +109,10 @@ def main():
                          "seconds (same repeat count on every rank); 0 = exactly K steps")
     ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE",
                     help="extra pool parameter (A/B switches such as sort_by_cost=0)")
+    ap.add_argument("--no-bind", action="store_true",
+                    help="leave the rank's host threads to the scheduler (default: each rank runs on the CPUs of its "
+                         "GPU's NUMA node, envpool_amd.bind_host_to_device -- what the reference's "
+                         "benchmark/numa_test.sh does with numactl)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (nccl = RCCL; gloo only to exercise the "
                          "multi-process path on a box with fewer GPUs than ranks)")
@@ -159,7 +163,13 @@ def main():
     dev = torch.device("cuda", dev_index)
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
+    from envpool_amd.core.affinity import bind_host_to_device
     from envpool_amd.core.device_pool import DevicePool
+
+    # one process per GPU, on the CPUs of that GPU's NUMA node (doorbells, completion signals and pinned memory are
+    # local from there); the CPU-baseline leg gets the process's original CPUs back
+    cpus_before = os.sched_getaffinity(0)
+    host_binding = {"node": None, "cpus": 0, "bound": False} if args.no_bind else bind_host_to_device(dev_index)
 
     n = args.num_envs
     if args.precision == "fp32" and args.task != "Ant":
@@ -464,6 +474,7 @@ def main():
                 "frames_per_sec": value * frame_skip,
                 "sharding": f"env ids sharded over {world} GPU(s), no collective",
                 "params": params,  # every engine key the pool was created with, --param overrides included
+                "host_binding": host_binding,  # the rank's CPUs: its GPU's NUMA node unless --no-bind
             },
             "roofline": roof,
             # wall seconds of the GPU legs (timed sync region + numpy-API leg + async leg), which run
@@ -479,6 +490,7 @@ def main():
             out["numpy_api"] = numpy_api
             out["async_mode"] = async_mode
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
+            os.sched_setaffinity(0, cpus_before)  # every host core the process was given
             out["cpu_baseline"] = cpu_baseline(args.task, action_hi=ahi)
         print(json.dumps(out))
     if world > 1:

@@ -8,6 +8,7 @@ mirrors `envpool/__init__.py` of the reference for the hot-path env families
 """
 
 from . import entry  # noqa: F401  (registers the envs)
+from .core.affinity import bind_host_to_device, device_local_cpus, device_numa_node
 from .registration import (
     list_all_envs,
     make,
@@ -28,4 +29,7 @@ __all__ = [
     "make_gymnasium",
     "make_spec",
     "list_all_envs",
+    "bind_host_to_device",
+    "device_local_cpus",
+    "device_numa_node",
 ]

@@ -137,10 +137,14 @@ struct CommonDev {
 // device cannot read pageable memory).  Pieces are claimed with an atomic counter; the caller watches the in-order
 // frontier of finished pieces and uploads behind it.  Workers poll for ~0.3 ms after a job (the next step's send
 // is that close in a step loop) and sleep on a condition variable otherwise.
+// CPUs of the NUMA node of `device` (empty if unknown), engine.hip
+std::vector<int> DeviceLocalCpus(int device);
+
 class HostCopier {
  public:
   static constexpr size_t kPiece = 256u << 10;
-  explicit HostCopier(int threads);
+  // `cpus`: where the helpers may run (the device's NUMA node, DeviceLocalCpus; empty = anywhere)
+  HostCopier(int threads, const std::vector<int>& cpus);
   ~HostCopier();
   HostCopier(const HostCopier&) = delete;
   HostCopier& operator=(const HostCopier&) = delete;

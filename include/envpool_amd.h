@@ -90,6 +90,10 @@ typedef struct epa_pool epa_pool;
  *                 the time: numpy API +20 %), 0 = off for every other family (measured slower there); 0 switches it off.
  *   "copy_threads" helper threads (default 2, 0 .. 8) that copy the action rows of a pipelined step into the pinned
  *                 staging slot together with the calling thread; they poll ~0.3 ms after a step, then sleep
+ *   "numa_bind"   1 (default): those helper threads run on the CPUs of the device's NUMA node (where this runtime
+ *                 allocates pinned memory); 0 leaves them to the scheduler.  The CALLING thread is never moved by the
+ *                 library: envpool_amd.bind_host_to_device() (Python) does that for a process that wants it, as the
+ *                 reference's benchmark/numa_test.sh does with numactl
  *   "ant_sub"     Ant: mj_steps per unit of the step kernel's work queue (default 1: an env-step of a 16-env chunk is
  *                 frame_skip units, the chunk's state goes through HBM between them; frame_skip = one unit per chunk,
  *                 the schedule of rounds 2-5).  Never changes results.

@@ -364,3 +364,22 @@ def test_registry_matches_reference_registration_modules():
         assert mine == want, (task_id, mine, want)
         checked += 1
     assert checked >= 40
+
+
+def test_affinity_helpers_without_a_device():
+    """`bind_host_to_device` (host placement on a multi-socket box, the reference's numactl recipe): the cpulist parser,
+    and that a box without a device (or without NUMA information) is left alone."""
+    import os
+
+    from envpool_amd.core import affinity
+
+    assert affinity._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert affinity._parse_cpulist("") == []
+    before = os.sched_getaffinity(0)
+    out = envpool.bind_host_to_device(0)
+    if not out["bound"]:
+        assert os.sched_getaffinity(0) == before and out["cpus"] == 0
+    else:  # (a GPU box: bound to a non-empty subset of what it had)
+        now = os.sched_getaffinity(0)
+        assert now and now <= before
+        os.sched_setaffinity(0, before)

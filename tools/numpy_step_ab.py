@@ -1,11 +1,15 @@
 """A/B of the host path's sync step (send(numpy) + recv() -> numpy) with and without the two-launch pipeline
-(engine key "step_pipeline"):  python tools/numpy_step_ab.py <task> <num_envs> <step_pipeline rows, 0 = off> <action dim>"""
+(engine key "step_pipeline"):  python tools/numpy_step_ab.py <task> <num_envs> <step_pipeline rows, 0 = off> <action dim>
+[bind: the process on the CPUs of the GPU's NUMA node first]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time
 import numpy as np
 from envpool_amd.core.device_pool import DevicePool
+if len(sys.argv) > 5 and sys.argv[5] == "bind":
+    from envpool_amd.core.affinity import bind_host_to_device
+    print(bind_host_to_device(0), end=" ")
 task = sys.argv[1]; n = int(sys.argv[2]); sp = int(sys.argv[3]); adim = int(sys.argv[4])
 pool = DevicePool(task, n, seed=0, max_episode_steps=1000, params={"step_pipeline": sp})
 ids = np.arange(n, dtype=np.int32); rng = np.random.default_rng(0)
