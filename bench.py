@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (nccl = RCCL; gloo only to exercise the "
                          "multi-process path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="join the process group and run the multi-rank code path (barriers, MAX / gather of the "
+                         "times, --allgather) even with ONE rank: exercises the RCCL calls on a 1-GPU box")
     ap.add_argument("--allgather", action="store_true",
                     help="also all-gather the obs batch over RCCL every step (optional "
                          "exchange of SURVEY §8e; off by default: the path needs no collective)")
@@ -153,8 +156,12 @@ def main():
     if args.backend == "nccl" and world > 1 and local_rank >= ngpu:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ngpu} GPU(s) visible")
     dev_index = local_rank % max(ngpu, 1)  # gloo test mode may share a GPU between ranks
-    if world > 1:
+    use_pg = world > 1 or args.force_process_group
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -193,7 +200,7 @@ def main():
     obs_shape = pool.state_keys[obs_index][2]
     pool_stream = torch.cuda.ExternalStream(pool.stream, device=dev)
     gathered = None
-    if args.allgather and world > 1:
+    if args.allgather and use_pg:
         gathered = torch.empty((world * n, *obs_shape), device=dev, dtype=torch.float64)
 
     def step(i):
@@ -224,13 +231,13 @@ def main():
         pool.synchronize()
         torch.cuda.synchronize()
         tc = time.perf_counter() - tc
-        if world > 1:
+        if use_pg:
             t = torch.tensor([tc], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tc = float(t.item())
         repeats = max(1, min(int(np.ceil(args.min_time / max(tc, 1e-6))), max(1, 200000 // max(args.steps, 1))))
     timed_steps = repeats * args.steps
-    if world > 1:
+    if use_pg:
         dist.barrier()
     # HIP events on the pool's stream around the whole timed region (first launch .. after the last):
     # kernel_ms = that / launches.  (An event pair around EVERY launch keeps consecutive step
@@ -246,7 +253,7 @@ def main():
     elapsed = time.perf_counter() - t0
     pool.set_timing(False)
     per_rank_s = [elapsed]
-    if world > 1:
+    if use_pg:
         dist.barrier()
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
@@ -493,7 +500,7 @@ def main():
             os.sched_setaffinity(0, cpus_before)  # every host core the process was given
             out["cpu_baseline"] = cpu_baseline(args.task, action_hi=ahi)
         print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

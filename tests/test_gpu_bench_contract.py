@@ -76,6 +76,25 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
         assert bad.returncode != 0 and "GPU(s) visible" in bad.stderr
 
 
+def test_bench_rccl_code_path_with_one_rank():
+    """The multi-rank code path over RCCL -- process group on the device, barriers around the timed region, MAX and
+    gather of the ranks' times on device tensors, the optional obs all-gather on the pool's stream -- with ONE rank
+    (`--force-process-group`): two RCCL ranks cannot share this box's single GPU, and the 8-GPU run is the driver's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-process-group", "--allgather",
+         "--backend", "nccl", "--steps", "5", "--warmup", "2", "--num-envs", "4096", "--no-cpu-baseline",
+         "--only-timed", "--min-time", "0.5"],
+        capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and [r["rank"] for r in d["per_rank"]] == [0]
+    assert abs(d["value"] - 4096 * d["timed_steps"] / d["timed_s"]) / d["value"] < 1e-6
+
+
 def test_kernel_timing_modes_agree():
     """epa_set_timing: 1 = an event pair per launch, 2 = one pair around the window (what bench.py
     uses); both count every launch and give the same duration up to the inter-launch gaps."""
