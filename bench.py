@@ -159,7 +159,12 @@ def main():
     use_pg = world > 1 or args.force_process_group
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
+        if "MASTER_PORT" not in os.environ:  # (--force-process-group without a launcher: any free port)
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
