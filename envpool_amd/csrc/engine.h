@@ -306,6 +306,11 @@ class Pool {
   int recv_timeout_ms_{-1};
   int pipeline_rows_{-1};            // "step_pipeline": whole-pool host-path steps of at least this many rows (0: never)
   int* iota_dev_{nullptr};           // [num_envs] global env ids in order (the second half's id list)
+  int zero_copy_small_{-1};          // "small_zero_copy" (-1: not read yet)
+  bool ZeroCopySmall() {
+    if (zero_copy_small_ < 0) zero_copy_small_ = cfg_.Get("small_zero_copy", 1) != 0 ? 1 : 0;
+    return zero_copy_small_ == 1;
+  }
   std::unique_ptr<HostCopier> copier_;  // "copy_threads" helpers (default 2, 0 = none) for pipelined steps
   std::deque<Batch*> pending_;
   std::vector<std::vector<Batch*>> free_;  // per compute stream

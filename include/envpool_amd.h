@@ -90,6 +90,10 @@ typedef struct epa_pool epa_pool;
  *                 the time: numpy API +20 %), 0 = off for every other family (measured slower there); 0 switches it off.
  *   "copy_threads" helper threads (default 2, 0 .. 8) that copy the action rows of a pipelined step into the pinned
  *                 staging slot together with the calling thread; they poll ~0.3 ms after a step, then sleep
+ *   "small_zero_copy" 1 (default): host-path batches of up to 64 KB go without DMA commands -- the step kernel reads ids
+ *                 and action rows straight out of the pinned staging slot, epa_recv's landing block is filled by a copy
+ *                 kernel on the kernel stream (CartPole num_envs = 64: send + recv 32.4 -> 29.4 us); 0 = DMA as for
+ *                 bigger batches.  Never changes results.
  *   "numa_bind"   1 (default): those helper threads run on the CPUs of the device's NUMA node (where this runtime
  *                 allocates pinned memory); 0 leaves them to the scheduler.  The CALLING thread is never moved by the
  *                 library: envpool_amd.bind_host_to_device() (Python) does that for a process that wants it, as the
