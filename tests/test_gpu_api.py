@@ -385,3 +385,30 @@ def test_async_streams_tolerate_a_resend_before_recv():
     many = _async_rollout("HalfCheetah", 6, n, b, 4, recvs, False, break_rule=True)
     for e in range(n):
         assert one[e] == many[e], e
+
+
+@pytest.mark.parametrize("streams", [1, 4])
+def test_tiny_batches_read_in_place_see_every_rewrite_of_the_staging_slot(streams):
+    """Engine key small_zero_copy: the step kernel of a tiny host-path batch reads ids and action rows straight out of
+    the pinned staging slot (a ring of three).  Eight sends back to back -- no host synchronisation in between, every
+    slot rewritten and re-read several times -- must use the actions of THEIR send: the rollout equals the one of a
+    pool that uploads by DMA, bit for bit."""
+    from envpool_amd.core.device_pool import DevicePool
+
+    n, b = 512, 64
+    pools = [DevicePool("Pendulum", n, batch_size=b, seed=11, max_episode_steps=50,
+                        params={"small_zero_copy": z, "compute_streams": streams}) for z in (0, 1)]
+    rng = np.random.default_rng(5)
+    ids = np.arange(n, dtype=np.int32)
+    for p in pools:
+        p.reset(ids)
+    got = [[p.recv_dict() for _ in range(n // b)] for p in pools]
+    for rnd in range(40):
+        acts = rng.uniform(-2, 2, size=(n // b, b, 1)).astype(np.float32)
+        for p, g in zip(pools, got):
+            for j in range(n // b):
+                p.send(g[j]["info:env_id"], acts[j])
+        got = [[p.recv_dict() for _ in range(n // b)] for p in pools]
+        for a, z in zip(got[0], got[1]):
+            for k in a:
+                assert a[k].tobytes() == z[k].tobytes(), (k, rnd)
