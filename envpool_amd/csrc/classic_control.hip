@@ -289,35 +289,62 @@ __device__ inline void WriteObs(const OutPtrs& out, int row, const double* s) {
   }
 }
 
-template <int KIND>
+// kEarly: every input of the row -- state, action, generator position -- is read together with `done`, in front of the
+// reset branch.  At BASELINE config 2's size (num_envs = 65536: one wave per SIMD) a step is a chain of dependent
+// round trips to memory, `done` -> state -> compute -> stores, and for a wave with a reset row (4.5 % of CartPole's
+// rows reset per step: every wave has one) `done` -> generator position -> words -> stores; read early, both are one
+// round trip shorter.  The price is one generator position (4 bytes) per row and step that only reset rows need.
+// Measured (rocprofv3 kernel trace, profiles/r6o_classic_early_kernel_trace.txt, num_envs = 65536): CartPole 5.98 ->
+// 5.60 us (4 M rows: 156.6 -> 150.3), Pendulum / MountainCar unchanged (3.7 - 4.0 us: their waves rarely hold a reset
+// row), Acrobot 9.5 -> 9.9: on for CartPole only ("classic_early" = 0 / 1 overrides).
+template <int KIND, bool kEarly>
 __global__ __launch_bounds__(256) void ClassicStepKernel(
     ClassicDev dev, CommonDev cm, StepArgs a,
     const typename Traits<KIND>::Act* __restrict__ action, OutPtrs out,
     int version) {
   constexpr int NS = Traits<KIND>::kNumState;
+  using Act = typename Traits<KIND>::Act;
+  static_assert(sizeof(Act) == 4, "the stand-in address below");
   for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < a.k;
        row += gridDim.x * blockDim.x) {
     int e = a.ids ? a.ids[row] - a.id_offset : row;
-    bool done = cm.done[e] != 0;
+    const unsigned char done_in = cm.done[e];
     int cur = cm.cur_step[e];
+    double s[NS];
+    Act act{};
+    int position = 0;
+    if constexpr (kEarly) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) s[j] = dev.s[j][e];
+      // (a launch that resets every row has no actions: any readable word stands in, the value is never used)
+      const Act* src = action != nullptr ? action + row : reinterpret_cast<const Act*>(cm.cur_step + e);
+      act = *src;
+      position = cm.mti[e];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) asm volatile("" : "+v"(s[j]));  // (issued here, not sunk into the branches)
+      asm volatile("" : "+v"(act), "+v"(position));
+    }
+    bool done = done_in != 0;
     // async_envpool.h:127: reset = force_reset || env->IsDone()
     bool reset = a.force_reset || done;
-    double s[NS];
     float reward = 0.0f;
     if (reset) {
       cur = 0;  // env.h:211-212
-      Mt19937 g(cm, e);
+      Mt19937 g = kEarly ? Mt19937(cm, e, position) : Mt19937(cm, e);
       ResetBody<KIND>(s, g);
       g.Commit();
       done = false;
     } else {
       ++cur;  // env.h:214
+      if constexpr (!kEarly) {
 #pragma unroll
-      for (int j = 0; j < NS; ++j) s[j] = dev.s[j][e];
+        for (int j = 0; j < NS; ++j) s[j] = dev.s[j][e];
+        act = action[row];
+      }
       // `done_ = (++elapsed_step_ >= max_episode_steps_)`: elapsed_step_ and
       // current_step_ coincide once an env has been reset.
       done = cur >= a.max_episode_steps;
-      reward = StepBody<KIND>(s, action[row], &done, version);
+      reward = StepBody<KIND>(s, act, &done, version);
     }
 #pragma unroll
     for (int j = 0; j < NS; ++j) dev.s[j][e] = s[j];
@@ -399,6 +426,7 @@ class ClassicPool : public Pool {
     if (KIND == kCartPole || KIND == kAcrobot) mt_tile_default_ = 16;
     block_ = (int)cfg.Get("classic_block", 0);
     rows_ = (int)cfg.Get("classic_rows", 1);
+    early_ = (int)cfg.Get("classic_early", -1);
     if ((block_ != 0 && block_ != 64 && block_ != 128 && block_ != 256) || rows_ < 1 || rows_ > 8) {
       throw std::invalid_argument("classic_block must be 64, 128 or 256 and classic_rows 1 .. 8");
     }
@@ -435,17 +463,21 @@ class ClassicPool : public Pool {
     const int block = block_ > 0 ? block_ : (short_body && k <= 131072 ? 64 : 256);
     const int per = block * rows_;
     int blocks = std::min((k + per - 1) / per, 256 * 8 * (256 / block));
-    hipLaunchKernelGGL(ClassicStepKernel<KIND>, dim3(blocks), dim3(block), 0,
-                       stream_, dev_, common_, a,
-                       static_cast<const typename Traits<KIND>::Act*>(d_action),
-                       out, version_);
+    const bool early = early_ >= 0 ? early_ != 0 : KIND == kCartPole;
+    if (early) {
+      hipLaunchKernelGGL((ClassicStepKernel<KIND, true>), dim3(blocks), dim3(block), 0, stream_, dev_, common_, a,
+                         static_cast<const typename Traits<KIND>::Act*>(d_action), out, version_);
+    } else {
+      hipLaunchKernelGGL((ClassicStepKernel<KIND, false>), dim3(blocks), dim3(block), 0, stream_, dev_, common_, a,
+                         static_cast<const typename Traits<KIND>::Act*>(d_action), out, version_);
+    }
   }
 
  private:
   static constexpr int NS = Traits<KIND>::kNumState;
   ClassicDev dev_{};
   int version_;
-  int block_{0}, rows_{1};
+  int block_{0}, rows_{1}, early_{-1};
 };
 
 }  // namespace

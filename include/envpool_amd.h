@@ -106,6 +106,9 @@ typedef struct epa_pool epa_pool;
  *                 variable EPA_SELFTEST=0 skips it for the process
  *   "classic_block", "classic_rows" classic_control: threads per block (64 / 128 / 256, default by family and size) and
  *                 rows per thread of the step kernel (A/B keys; never change results)
+ *   "classic_early" classic_control: 1 = the step kernel reads state, action and generator position together with
+ *                 `done`, in front of the reset branch (default: CartPole only, where every wave holds a reset row:
+ *                 -6 % kernel time at num_envs = 65536); never changes results
  *   "recv_timeout_ms" every family: how long epa_recv* waits for rows that have not been sent yet (see epa_recv):
  *                 < 0 forever (default, the reference's behaviour), 0 not at all, > 0 milliseconds
  *   "compute_streams" async mode (batch_size < num_envs): successive batches run on this many
