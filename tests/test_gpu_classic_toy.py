@@ -226,3 +226,22 @@ def test_classic_reset_draws_across_generator_wraps(name):
         act = sample_actions(c, rng, n)
         a, b = hip.step(act), orc.step(act)
     assert resets >= n * (steps // 3)
+
+
+@pytest.mark.parametrize("height,width,n", [(10, 5, 1000), (7, 3, 517), (4, 4, 256), (3, 1, 70), (16, 9, 300)])
+def test_catch_one_hot_observation_for_any_board(height, width, n):
+    """Catch's [H, W] one-hot observation (catch.h:88-93: two ones in a zeroed buffer) is written by the whole block with
+    16-byte stores that straddle rows whenever H x W is not a multiple of 4: every board, batches that do not fill the
+    last block, against the oracle bit for bit over resets."""
+    pool = DevicePool("Catch", n, seed=4, max_episode_steps=10 ** 6, params={"height": height, "width": width})
+    orc = Oracle("Catch", n, seed=4, max_episode_steps=10 ** 6, extra=(height, width))
+    ids = np.arange(n, dtype=np.int32)
+    pool.reset(ids)
+    a, b = pool.recv_dict(), orc.reset()
+    rng = np.random.default_rng(1)
+    for t in range(3 * height):
+        assert a["obs"].reshape(n, -1).tobytes() == b["obs"].reshape(n, -1).astype(np.float32).tobytes(), t
+        assert a["obs"].reshape(n, -1).sum(axis=1).max() <= 2.0
+        act = rng.integers(0, 3, n).astype(np.int32)
+        pool.send(ids, act)
+        a, b = pool.recv_dict(), orc.step(act)
