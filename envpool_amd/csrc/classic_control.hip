@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256) void ClassicStepKernel(
     float reward = 0.0f;
     if (reset) {
       cur = 0;  // env.h:211-212
-      Mt19937 g = kEarly ? Mt19937(cm, e, position) : Mt19937(cm, e);
+      Mt19937 g(cm, e);  // (kEarly: its read of the position is the one above, or hits the line that one brought in)
+      if constexpr (kEarly) g.idx = g.idx0 = position;
       ResetBody<KIND>(s, g);
       g.Commit();
       done = false;

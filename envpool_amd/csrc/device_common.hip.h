@@ -56,11 +56,6 @@ struct Mt19937 {
       : mt(c.mt), e(env), n(c.n), sh(c.mt_shift), idx_slot(c.mti + env) {
     idx = idx0 = *idx_slot;
   }
-  // ... with the position already read (a kernel that reads it together with the row's other inputs)
-  __device__ Mt19937(const CommonDev& c, int env, int position)
-      : mt(c.mt), e(env), n(c.n), sh(c.mt_shift), idx_slot(c.mti + env) {
-    idx = idx0 = position;
-  }
   __device__ void Commit() {
     if (idx != idx0) *idx_slot = idx;
   }
