@@ -283,6 +283,7 @@ EPA_HD int PendForward(const PendModel<T, NL, kBase>& m, const SolverCfg<T>& cfg
     aref[j] = -m.lim_B * (s * v[j]) - m.lim_K * imp * (dist - m.margin[j]);
   });
   // mj_fwdConstraint: Newton on 1/2 (a-a0)^T M (a-a0) + sum 1/2 D min(0, sgn a_j - aref)^2
+  constexpr int kChainLsExactAfter = 8;
   static_for<0, NV>([&](auto ic) { qacc[decltype(ic)::value] = warm[decltype(ic)::value]; });
   T fs = T(0);
   static_for<0, NV>([&](auto ic) {
@@ -339,19 +340,31 @@ EPA_HD int PendForward(const PendModel<T, NL, kBase>& m, const SolverCfg<T>& cfg
     const T ag1 = g1 < T(0) ? -g1 : g1;
     const T ls_tol = (sizeof(T) == 4 ? T(1e-4) : T(1e-10)) * ag1;
     bool searching = live;
-    for (int ls = 0; ls < 24; ++ls) {
+    // Round 6 (the planar kernels' solver, mj_planar_lg.hip.h::Solve): ONE evaluation, at the full step -- phi'(1) = 0
+    // with the active set H was built with means a + s IS the minimiser (the env is done, without the pass over the
+    // rows that would only have confirmed it); otherwise one Newton step of the 1-D problem, unverified.  From trip
+    // kChainLsExactAfter on the search is exact again (its steps cannot increase the objective).
+    bool exact = false;
+    const int ls_max = it < kChainLsExactAfter ? 1 : 24;
+    for (int ls = 0; ls < ls_max; ++ls) {
       T d1 = g1 + alpha * g2, d2 = g2;
+      unsigned mask1 = 0;
       static_for<0, NV>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const T jar = sgn[i] * qacc[i] - aref[i], jv = sgn[i] * s[i];
         const T x = jar + alpha * jv;
-        const T w = (sgn[i] != T(0) && x < T(0)) ? D[i] : T(0);
+        const bool on1 = sgn[i] != T(0) && x < T(0);
+        const T w = on1 ? D[i] : T(0);
         d1 += w * x * jv;
         d2 += w * jv * jv;
+        mask1 |= (on1 ? 1u : 0u) << i;
       });
       const T ad1 = d1 < T(0) ? -d1 : d1;
       const bool hit = ad1 <= ls_tol;
-      full_step = full_step || (searching && hit && ls == 0);
+      if (ls == 0) {
+        full_step = searching && hit;
+        exact = full_step && mask1 == mask;
+      }
       searching = searching && !hit;
       lo = (searching && d1 < T(0)) ? alpha : lo;
       hi = (searching && !(d1 < T(0))) ? alpha : hi;
@@ -364,6 +377,8 @@ EPA_HD int PendForward(const PendModel<T, NL, kBase>& m, const SolverCfg<T>& cfg
     }
     const T step = live ? alpha : T(0);
     static_for<0, NV>([&](auto ic) { qacc[decltype(ic)::value] += step * s[decltype(ic)::value]; });
+    live = live && !exact;
+    if (!WaveAny(live)) break;
   }
   static_for<0, NV>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
