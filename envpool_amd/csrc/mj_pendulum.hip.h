@@ -302,10 +302,12 @@ EPA_HD int PendForward(const PendModel<T, NL, kBase>& m, const SolverCfg<T>& cfg
     static_for<0, NV * NV>([&](auto kc) { H[decltype(kc)::value] = M[decltype(kc)::value]; });
     unsigned mask = 0;
     T gn2 = T(0);
+    T r0[NV];  // M qacc - qfrc_smooth: the smooth part of the gradient, again the line search's phi'(0) term
     static_for<0, NV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       T g = -qfrc_smooth[i];
       static_for<0, NV>([&](auto jc) { g += M[i * NV + decltype(jc)::value] * qacc[decltype(jc)::value]; });
+      r0[i] = g;
       const T jar = sgn[i] * qacc[i] - aref[i];
       const bool on = sgn[i] != T(0) && jar < T(0);
       const T w = on ? D[i] : T(0);
@@ -327,12 +329,9 @@ EPA_HD int PendForward(const PendModel<T, NL, kBase>& m, const SolverCfg<T>& cfg
     T g1 = T(0), g2 = T(0);
     static_for<0, NV>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      T ms = T(0), ma = -qfrc_smooth[i];
-      static_for<0, NV>([&](auto jc) {
-        ms += M[i * NV + decltype(jc)::value] * s[decltype(jc)::value];
-        ma += M[i * NV + decltype(jc)::value] * qacc[decltype(jc)::value];
-      });
-      g1 += s[i] * ma;
+      T ms = T(0);
+      static_for<0, NV>([&](auto jc) { ms += M[i * NV + decltype(jc)::value] * s[decltype(jc)::value]; });
+      g1 += s[i] * r0[i];
       g2 += s[i] * ms;
     });
     T alpha = T(1), lo = T(0), hi = T(-1);
