@@ -93,6 +93,8 @@ class DevicePool:
         del keep
         self._h = h
         self._pending: collections.deque[int] = collections.deque()
+        # sync pools: per pending batch, the pinned block named at send time (None: recv takes one)
+        self._posted: collections.deque[Any] = collections.deque()
         self._is_sync = self.batch_size == self.num_envs
         self._blocks = _PinnedBlocks(self._lib)
         self._step_ptrs = None  # step_device: reusable ctypes output array + cache of pointer lists
@@ -120,11 +122,26 @@ class DevicePool:
             raise RuntimeError(
                 f"Expected action of shape {want}, got {action.shape}"
             )
-        native.check(
-            self._lib.epa_send(self._h, env_id.ctypes.data, k, action.ctypes.data)
-        )
+        # A whole-pool step of a sync pool names the block its results shall land in NOW (epa_send_into): the step
+        # kernel then writes them straight into it and recv only waits for the kernel.  Whether the engine takes the
+        # offer (ids in order, pinned block, "direct_out") is its business: recv hands the same block to
+        # epa_recv_block either way.
+        block = None
+        if self._is_sync and k == self.num_envs:
+            _, total = self._layout(k)
+            if total >= self._SMALL_BATCH_BYTES:
+                block = self._blocks.take(total)
+        if block is not None:
+            native.check(self._lib.epa_send_into(self._h, env_id.ctypes.data, k, action.ctypes.data,
+                                                 block.ctypes.data, block.nbytes))
+        else:
+            native.check(
+                self._lib.epa_send(self._h, env_id.ctypes.data, k, action.ctypes.data)
+            )
         if k > 0:  # an empty send enqueues nothing (Pool::Send returns early)
             self._pending.append(k)
+            if self._is_sync:
+                self._posted.append(block)
 
     def reset(self, env_ids: np.ndarray) -> None:
         env_ids = np.ascontiguousarray(env_ids, dtype=np.int32)
@@ -132,6 +149,8 @@ class DevicePool:
         native.check(self._lib.epa_reset(self._h, env_ids.ctypes.data, k))
         if k > 0:
             self._pending.append(k)
+            if self._is_sync:
+                self._posted.append(None)
 
     def _layout(self, rows: int) -> tuple[list[int], int]:
         lay = self._layouts.get(rows)
@@ -162,7 +181,9 @@ class DevicePool:
             ptrs = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
             native.check(self._lib.epa_recv(self._h, ptrs, n, cap, ctypes.byref(k)))
         else:
-            block = self._blocks.take(total)
+            block = self._posted[0] if (self._is_sync and self._posted) else None
+            if block is None or block.nbytes < total:
+                block = self._blocks.take(total)
             offs = (ctypes.c_size_t * n)()
             native.check(
                 self._lib.epa_recv_block(self._h, block.ctypes.data, block.nbytes, offs, n,
@@ -171,6 +192,8 @@ class DevicePool:
         if self._is_sync:
             if self._pending:
                 self._pending.popleft()
+            if self._posted:
+                self._posted.popleft()
         else:
             # async: rows drain across submissions in order
             left = k.value

@@ -84,6 +84,7 @@ def lib() -> ctypes.CDLL:
         "epa_create": (i32, [cp, P(EpaConfig), P(vp)]),
         "epa_destroy": (i32, [vp]),
         "epa_send": (i32, [vp, vp, i32, vp]),
+        "epa_send_into": (i32, [vp, vp, i32, vp, vp, ctypes.c_size_t]),
         "epa_reset": (i32, [vp, vp, i32]),
         "epa_recv": (i32, [vp, P(vp), i32, i32, P(i32)]),
         "epa_recv_layout": (i32, [vp, i32, P(ctypes.c_size_t), i32, P(ctypes.c_size_t)]),
@@ -129,7 +130,7 @@ def lib() -> ctypes.CDLL:
 EXPORTED_SYMBOLS = [
     "epa_num_families", "epa_family_name", "epa_describe_state",
     "epa_describe_action", "epa_create", "epa_destroy", "epa_send", "epa_reset",
-    "epa_recv", "epa_recv_layout", "epa_recv_block", "epa_recv_into", "epa_pending_rows",
+    "epa_recv", "epa_recv_layout", "epa_recv_block", "epa_send_into", "epa_recv_into", "epa_pending_rows",
     "epa_send_device", "epa_recv_device", "epa_step_device", "epa_wait_stream", "epa_consumer_wait",
     "epa_stream", "epa_synchronize", "epa_set_timing", "epa_kernel_time_ms",
     "epa_state_dim", "epa_get_state", "epa_set_state", "epa_atari_post_create",

@@ -275,6 +275,9 @@ class AtariPool : public Pool {
     CheckIds(env_ids, k);
     Enqueue(env_ids, k, nullptr, true);
   }
+  void SendInto(const int32_t* env_id, int k, const void* action, void*, size_t) override {
+    Send(env_id, k, action);  // (the host executor writes its own result blocks)
+  }
   void SendDevice(const int32_t*, int, const void*, hipEvent_t) override {
     throw std::runtime_error("Atari: the emulator runs on the host, there is no device-resident send");
   }

@@ -96,7 +96,11 @@ struct OutPtrs {
 };
 
 struct Batch {
+  // where the batch's kernels write and recv reads: the block's own device allocation (`dev_buf`), or -- a DIRECT
+  // step, Pool::SendInto -- the caller's pinned host block, where the results then already are when recv wants them
   char* dbuf{nullptr};
+  char* dev_buf{nullptr};
+  bool direct{false};
   size_t cap_rows{0};
   int k{0};
   int consumed{0};                // rows already handed to recv (async mode)
@@ -190,6 +194,8 @@ class Pool {
   // (Atari: ALE stays on the CPU, north star) replaces the stream-ordered execution with
   // its own executor and keeps the C ABI (atari_env.hip).
   virtual void Send(const int32_t* env_id, int k, const void* action);
+  // Send whose results may land straight in `block` (see epa_send_into); families with their own executor ignore the block
+  virtual void SendInto(const int32_t* env_id, int k, const void* action, void* block, size_t block_bytes);
   virtual void Reset(const int32_t* env_ids, int k);
   virtual void SendDevice(const int32_t* d_env_id, int k, const void* d_action,
                           hipEvent_t wait_event = nullptr);
@@ -245,6 +251,9 @@ class Pool {
   // where a step kernel takes about as long as its results need for the way down (the planar MuJoCo tasks: +18 %)
   // and costs where the kernel dominates (Ant: two half launches have two tails, -10 %)
   int pipeline_default_{0};
+  // default of "direct_out" (Pool::SendInto): whether a whole-pool host-path step writes its results straight into
+  // the block the caller named at send time
+  int direct_default_{1};
   // The stream the NEXT step kernel goes on.  Sync mode (batch_size == num_envs): always
   // compute_[0].  Async mode: successive batches rotate over the compute streams so that
   // independent in-flight batches run concurrently, like the reference's workers run every queued
@@ -273,7 +282,14 @@ class Pool {
   void LaunchPart(Batch* b, const int* d_ids, int row0, int kp, const void* d_action, bool force);
   void FinishBatch(Batch* b);
   struct Staging;
-  void SendPipelined(Staging& s, int k, const void* action, size_t id_bytes, size_t act_bytes);
+  void SendPipelined(Staging& s, int k, const void* action, size_t id_bytes, size_t act_bytes,
+                     char* direct_block);
+  void SendImpl(const int32_t* env_id, int k, const void* action, char* block, size_t block_bytes);
+  // a direct batch's rows [consumed, consumed + take) for recv: waits for its kernel, copies only if `dst` is not the
+  // block the kernel wrote (CopyRowsToHost / RecvInto)
+  void TakeDirect(Batch* b, int take, int got, char* dst, const size_t* dst_off, void* const* dst_ptrs,
+                  std::unique_lock<std::mutex>& lk);
+  int direct_out_{-1};  // "direct_out" (-1: not read yet)
   bool HostBlockVisible(const void* p);
   // chooses stream_ for the next launch and orders it behind what it may depend on
   void PickStream(const int32_t* host_ids, int k, bool device_path, const void* d_env_id = nullptr);

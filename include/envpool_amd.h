@@ -90,6 +90,8 @@ typedef struct epa_pool epa_pool;
  *                 the time: numpy API +20 %), 0 = off for every other family (measured slower there); 0 switches it off.
  *   "copy_threads" helper threads (default 2, 0 .. 8) that copy the action rows of a pipelined step into the pinned
  *                 staging slot together with the calling thread; they poll ~0.3 ms after a step, then sleep
+ *   "direct_out"  1 (default): epa_send_into may place a whole-pool step's results straight into the caller's block;
+ *                 0 = epa_send_into is epa_send
  *   "small_zero_copy" 1 (default): host-path batches of up to 64 KB go without DMA commands -- the step kernel reads ids
  *                 and action rows straight out of the pinned staging slot, epa_recv's landing block is filled by a copy
  *                 kernel on the kernel stream (CartPole num_envs = 64: send + recv 32.4 -> 29.4 us); 0 = DMA as for
@@ -232,6 +234,17 @@ int epa_recv_layout(epa_pool* pool, int32_t rows, size_t* offsets, int32_t n_key
                     size_t* total_bytes);
 int epa_recv_block(epa_pool* pool, void* block, size_t block_bytes,
                    size_t* offsets, int32_t n_keys, int32_t* k_out);
+
+/* epa_send for a caller that already knows WHERE the results shall go (the reference's StateBufferQueue allocates the
+ * batch's output buffers before the workers write them, state_buffer_queue.h:123-140): `block` is a pinned host block
+ * (epa_host_alloc) with room for k rows laid out by epa_recv_layout(k), which stays the caller's but must live until
+ * the epa_recv_block that returns this batch.  For a whole-pool step of a sync pool (env_id = every env in order) the
+ * step kernel then writes its rows STRAIGHT into the block -- they cross the link as the kernel's own stores, while
+ * it runs -- and epa_recv_block with the same block only waits for the kernel (any other recv call copies out of the
+ * block).  Every other send (partial, out of order, async pool, a block that is not pinned, extension key
+ * "direct_out" = 0) behaves exactly like epa_send and ignores the block.  Results are the same bytes either way. */
+int epa_send_into(epa_pool* pool, const int32_t* env_id, int32_t k, const void* action, void* block,
+                  size_t block_bytes);
 
 /* Same blocking / batching semantics as epa_recv, but every state key is copied
  * device->host DIRECTLY into `out_ptrs[key]` (no landing block, no host memcpy;

@@ -63,3 +63,77 @@ def test_pipelined_steps_interleave_with_partial_sends_and_resets():
     for x, y in zip(*outs):
         for u, v in zip(x, y):
             assert np.array_equal(u, v)
+
+
+# ---- the DIRECT step (Pool::SendInto / epa_send_into): results written by the step kernel into the block named at send time
+@pytest.mark.parametrize("task,n,adim", [("Hopper", 20000, 3), ("Ant", 9000, 8), ("HalfCheetah", 20000, 6),
+                                         ("Pusher", 8192, 7), ("CartPole", 300000, 0)])
+def test_direct_step_is_bit_identical_and_rows_keep_their_memory(task, n, adim):
+    """`DevicePool.send` of a whole sync pool names a pinned block; with "direct_out" the step kernel writes the rows
+    straight into it.  Same bytes as the download path over steps, auto-resets, a partial send, a forced reset and two
+    steps queued before a recv; and the arrays of an earlier step are never overwritten by a later one
+    (py_envpool.h:40-49: every batch owns its memory)."""
+    ids = np.arange(n, dtype=np.int32)
+    pools = [DevicePool(task, n, seed=13, max_episode_steps=6, params={"direct_out": d}) for d in (0, 1)]
+    rng = np.random.default_rng(8)
+
+    def act(k):
+        return rng.integers(0, 2, k).astype(np.int32) if adim == 0 else rng.uniform(-1, 1, (k, adim))
+
+    acts = [act(n) for _ in range(9)]
+    some = rng.permutation(n)[: n // 7].astype(np.int32)
+    seqs = []
+    for p in pools:
+        seq = []
+        p.reset(ids)
+        seq.append(p.recv())
+        for t in range(4):
+            p.send(ids, acts[t])
+            seq.append(p.recv())
+        p.send(some, acts[4][some])  # partial: an ordinary send
+        seq.append(p.recv())
+        p.reset(some[:50])
+        seq.append(p.recv())
+        p.send(ids, acts[5]), p.send(ids, acts[6])  # two blocks posted before a recv
+        seq.append(p.recv()), seq.append(p.recv())
+        p.send(ids, acts[7])
+        seq.append(p.recv())
+        seqs.append(seq)
+    kept = [[x.copy() for x in batch] for batch in seqs[1]]
+    for t, (a, b) in enumerate(zip(*seqs)):
+        for (name, _, _), x, y in zip(pools[0].state_keys, a, b):
+            assert x.shape == y.shape and x.tobytes() == y.tobytes(), (task, t, name)
+    pools[1].send(ids, acts[8])  # one more step: nothing handed out before may change
+    pools[1].recv()
+    for batch, copy in zip(seqs[1], kept):
+        for x, y in zip(batch, copy):
+            assert x.tobytes() == y.tobytes()
+
+
+def test_direct_step_with_the_consumer_already_waiting_in_recv():
+    """A consumer thread sits in recv() (with a block of its own) before the producer's send names another block: the
+    rows are copied out of the posted block -- same rows, no deadlock."""
+    import threading
+
+    n = 20000
+    ids = np.arange(n, dtype=np.int32)
+    pool = DevicePool("Hopper", n, seed=2, max_episode_steps=1000, params={"direct_out": 1})
+    ref = DevicePool("Hopper", n, seed=2, max_episode_steps=1000, params={"direct_out": 0})
+    rng = np.random.default_rng(1)
+    for p in (pool, ref):
+        p.reset(ids)
+        p.recv()
+    for t in range(3):
+        a = rng.uniform(-1, 1, (n, 3))
+        got = {}
+        th = threading.Thread(target=lambda: got.setdefault("out", pool.recv()))
+        th.start()
+        import time
+        time.sleep(0.05)  # the consumer is inside epa_recv_block by now
+        pool.send(ids, a)
+        th.join(timeout=30)
+        assert not th.is_alive()
+        ref.send(ids, a)
+        want = ref.recv()
+        for x, y in zip(got["out"], want):
+            assert x.tobytes() == y.tobytes(), t

@@ -12,7 +12,7 @@ if len(sys.argv) > 5 and sys.argv[5] == "bind":
     print(bind_host_to_device(0), end=" ")
 task = sys.argv[1]; n = int(sys.argv[2]); sp = int(sys.argv[3]); adim = int(sys.argv[4])
 extra = {k: float(v) for k, v in (kv.split("=") for kv in os.environ.get("EPA_PARAMS", "").split(",") if kv)}  # more engine keys
-pool = DevicePool(task, n, seed=0, max_episode_steps=1000, params={"step_pipeline": sp, **extra})
+pool = DevicePool(task, n, seed=0, max_episode_steps=1000, params={**({"step_pipeline": sp} if sp >= 0 else {}), **extra})
 ids = np.arange(n, dtype=np.int32); rng = np.random.default_rng(0)
 hact = [rng.uniform(-1, 1, size=(n, adim)) for _ in range(4)]
 pool.reset(ids); pool.recv()
