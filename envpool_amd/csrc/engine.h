@@ -252,8 +252,9 @@ class Pool {
   // and costs where the kernel dominates (Ant: two half launches have two tails, -10 %)
   int pipeline_default_{0};
   // default of "direct_out" (Pool::SendInto): whether a whole-pool host-path step writes its results straight into
-  // the block the caller named at send time
-  int direct_default_{1};
+  // the block the caller named at send time (1), and also reads its action rows in place out of the pinned staging
+  // slot instead of an uploaded copy (2: every family but the Ant, whose units would read them five times over)
+  int direct_default_{2};
   // The stream the NEXT step kernel goes on.  Sync mode (batch_size == num_envs): always
   // compute_[0].  Async mode: successive batches rotate over the compute streams so that
   // independent in-flight batches run concurrently, like the reference's workers run every queued

@@ -557,6 +557,7 @@ class AntPool : public Pool {
   bool ConcurrentSafe() const override { return true; }  // per-env state + the launch's own block only
   explicit AntPool(const Config& cfg)
       : Pool(cfg, AntKeys(cfg), KeySpec{"action", EPA_F64, {A::kNU}}, true) {
+    direct_default_ = 1;  // (a unit queue re-reads the action rows per unit: uploaded, not read in place -- engine.h)
     task_.use_contact_force = cfg.Get("use_contact_force", 0) != 0;
     task_.post_constraint = cfg.Get("post_constraint", 0) != 0;
     task_.exclude_worldbody = cfg.Get("exclude_worldbody_contact_forces", 0) != 0;

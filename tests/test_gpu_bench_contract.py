@@ -122,5 +122,5 @@ def test_kernel_timing_modes_agree():
     assert pool.kernel_time_ms() == (0.0, 0)
     pool.set_timing(0)
     a, b = min(res[1]), min(res[2])
-    assert 0.05 < a < 5.0 and 0.05 < b < 5.0
+    assert 0.02 < a < 5.0 and 0.02 < b < 5.0  # (a sanity range: ~0.05 ms on an MI355X)
     assert abs(a - b) / a < 0.25, res

@@ -66,15 +66,19 @@ def test_pipelined_steps_interleave_with_partial_sends_and_resets():
 
 
 # ---- the DIRECT step (Pool::SendInto / epa_send_into): results written by the step kernel into the block named at send time
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("task,n,adim", [("Hopper", 20000, 3), ("Ant", 9000, 8), ("HalfCheetah", 20000, 6),
-                                         ("Pusher", 8192, 7), ("CartPole", 300000, 0)])
-def test_direct_step_is_bit_identical_and_rows_keep_their_memory(task, n, adim):
+                                         ("HalfCheetah", 65536, 6), ("Pusher", 8192, 7), ("Humanoid", 2048, 17),
+                                         ("CartPole", 300000, 0)])
+def test_direct_step_is_bit_identical_and_rows_keep_their_memory(task, n, adim, mode):
     """`DevicePool.send` of a whole sync pool names a pinned block; with "direct_out" the step kernel writes the rows
     straight into it.  Same bytes as the download path over steps, auto-resets, a partial send, a forced reset and two
     steps queued before a recv; and the arrays of an earlier step are never overwritten by a later one
     (py_envpool.h:40-49: every batch owns its memory)."""
     ids = np.arange(n, dtype=np.int32)
-    pools = [DevicePool(task, n, seed=13, max_episode_steps=6, params={"direct_out": d}) for d in (0, 1)]
+    # (mode 2: the action rows are read in place out of the pinned staging slot too; it goes in front of the
+    # two-launch pipeline, mode 1 behind it)
+    pools = [DevicePool(task, n, seed=13, max_episode_steps=6, params={"direct_out": d}) for d in (0, mode)]
     rng = np.random.default_rng(8)
 
     def act(k):
@@ -117,7 +121,7 @@ def test_direct_step_with_the_consumer_already_waiting_in_recv():
 
     n = 20000
     ids = np.arange(n, dtype=np.int32)
-    pool = DevicePool("Hopper", n, seed=2, max_episode_steps=1000, params={"direct_out": 1})
+    pool = DevicePool("Hopper", n, seed=2, max_episode_steps=1000, params={"direct_out": 2})
     ref = DevicePool("Hopper", n, seed=2, max_episode_steps=1000, params={"direct_out": 0})
     rng = np.random.default_rng(1)
     for p in (pool, ref):
