@@ -170,7 +170,8 @@ class _ShardedPools:
         env_id = np.ascontiguousarray(env_id, dtype=np.int32)
         action = np.asarray(action)
         parts, grouped = self._split(env_id)
-        self._each(lambda s, p, part: p.send(env_id[part], action[part]), parts)
+        # (a shard's rows land in ITS row range of one block shared by all shards, epa_recv_into: no block to post)
+        self._each(lambda s, p, part: p.send(env_id[part], action[part], post_block=False), parts)
         with self._cv:
             self._pending.append((len(env_id), parts, grouped))
             self._cv.notify_all()
@@ -216,7 +217,7 @@ class _ShardedPools:
             native.check(self._lib.epa_recv_into(p._h, ptrs, n, part.stop - part.start,
                                                  ctypes.byref(got)))
             assert got.value == part.stop - part.start
-            p._pending.popleft()
+            p.pop_pending()
 
         self._each(land, parts)
         return [block[o:o + k * rb].view(dtype).reshape((k, *shape))

@@ -113,7 +113,7 @@ class DevicePool:
         return h
 
     # -- host path ---------------------------------------------------------
-    def send(self, env_id: np.ndarray, action: np.ndarray) -> None:
+    def send(self, env_id: np.ndarray, action: np.ndarray, post_block: bool = True) -> None:
         env_id = np.ascontiguousarray(env_id, dtype=np.int32)
         action = np.ascontiguousarray(action, dtype=self.action_dtype)
         k = int(env_id.shape[0])
@@ -127,7 +127,7 @@ class DevicePool:
         # offer (ids in order, pinned block, "direct_out") is its business: recv hands the same block to
         # epa_recv_block either way.
         block = None
-        if self._is_sync and k == self.num_envs:
+        if post_block and self._is_sync and k == self.num_envs:
             _, total = self._layout(k)
             if total >= self._SMALL_BATCH_BYTES:
                 block = self._blocks.take(total)
@@ -142,6 +142,12 @@ class DevicePool:
             self._pending.append(k)
             if self._is_sync:
                 self._posted.append(block)
+
+    def pop_pending(self) -> None:
+        """A batch was received through another recv entry point (epa_recv_into of the sharded pool)."""
+        self._pending.popleft()
+        if self._is_sync and self._posted:
+            self._posted.popleft()
 
     def reset(self, env_ids: np.ndarray) -> None:
         env_ids = np.ascontiguousarray(env_ids, dtype=np.int32)
