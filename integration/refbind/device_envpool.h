@@ -164,8 +164,25 @@ class DeviceEnvPool : public EnvPool<Spec> {
   // action = {env_id, players.env_id, <env action>}  (env_spec.h:32-35)
   void Send(const std::vector<Array>& action) override {
     int k = static_cast<int>(action[0].Shape(0));
-    Check(epa_send(h_, static_cast<const int32_t*>(action[0].Data()), k, action.back().Data()));
-    if (k > 0) Push(k);
+    // A whole-pool step of a sync pool names the block of ITS batch now (epa_send_into): the reference allocates a
+    // batch's output buffers before its workers write them too (state_buffer_queue.h:123-140), and here the step kernel
+    // then writes its rows straight into the block Recv() will hand out.  Whether the library takes the offer is its
+    // business: Recv passes the same block to epa_recv_block either way.
+    std::shared_ptr<char> block;
+    std::size_t total = 0;
+    if (sync_ && k == static_cast<int>(this->spec.config["num_envs"_])) {
+      const int n = static_cast<int>(state_specs_.size());
+      std::vector<std::size_t> off(n);
+      Check(epa_recv_layout(h_, k, off.data(), n, &total));
+      if (total >= kPostBytes) block = blocks_->Take(total);
+    }
+    if (block) {
+      Check(epa_send_into(h_, static_cast<const int32_t*>(action[0].Data()), k, action.back().Data(), block.get(),
+                          total));
+    } else {
+      Check(epa_send(h_, static_cast<const int32_t*>(action[0].Data()), k, action.back().Data()));
+    }
+    if (k > 0) Push(k, std::move(block));
   }
   void Send(std::vector<Array>&& action) override { Send(action); }
 
@@ -185,12 +202,18 @@ class DeviceEnvPool : public EnvPool<Spec> {
     std::vector<std::size_t> off(n);
     std::size_t total = 0;
     Check(epa_recv_layout(h_, cap, off.data(), n, &total));
-    std::shared_ptr<char> block = blocks_->Take(total > 0 ? total : 256);
+    std::shared_ptr<char> block;
+    if (sync_) {  // the block Send named for this batch, if it did
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!posted_.empty()) block = posted_.front();
+    }
+    if (!block) block = blocks_->Take(total > 0 ? total : 256);
     int32_t k = 0;
     Check(epa_recv_block(h_, block.get(), total, off.data(), n, &k));
     if (sync_) {
       std::lock_guard<std::mutex> lk(mu_);
       if (!pending_.empty()) pending_.pop_front();
+      if (!posted_.empty()) posted_.pop_front();
     }
     std::vector<Array> out;
     out.reserve(n);
@@ -209,16 +232,19 @@ class DeviceEnvPool : public EnvPool<Spec> {
   }
 
  private:
-  void Push(int k) {
+  void Push(int k, std::shared_ptr<char> block = nullptr) {
     std::lock_guard<std::mutex> lk(mu_);
     pending_.push_back(k);
+    if (sync_) posted_.push_back(std::move(block));
   }
+  static constexpr std::size_t kPostBytes = 256 * 1024;  // smaller batches: epa_recv_block's own download is as fast
   epa_pool* h_{nullptr};
   std::vector<ShapeSpec> state_specs_;
   std::shared_ptr<BlockPool> blocks_;
   bool sync_{true};
   std::mutex mu_;
   std::deque<int> pending_;  // rows of each outstanding Send / Reset (sync mode)
+  std::deque<std::shared_ptr<char>> posted_;  // ... and the block Send named for it (null: Recv takes one)
 };
 
 }  // namespace envpool_amd_binding
