@@ -228,3 +228,36 @@ def test_cc_driver_follows_the_reference_cc_test():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "refbind_cc_test: OK" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stem,module,ours", [("GymHalfCheetah", "envpool_amd.mujoco.gym", "GymHalfCheetah"),
+                                              ("GymHopper", "envpool_amd.mujoco.gym", "GymHopper")])
+def test_pybind_shim_posts_its_block_at_send_for_big_batches(stem, module, ours):
+    """`DeviceEnvPool::Send` of a whole sync pool names the batch's pinned block (epa_send_into) when the batch is big
+    enough for it to matter; the step kernel writes the rows into it.  Same bytes as the ctypes path (which does the
+    same from Python), arrays of earlier steps keep their values."""
+    rb = _refbind()
+    ref_spec, ref_pool = getattr(rb, f"_{stem}EnvSpec"), getattr(rb, f"_{stem}EnvPool")
+    our_spec, our_pool = _ours(module, ours)
+    n = 6000  # ~1 MB of results per batch: above the binding's posting threshold
+    conf = dict(zip(ref_spec._config_keys, ref_spec._default_config_values))
+    conf.update(num_envs=n, seed=5, max_episode_steps=7, post_constraint=False)
+    values = tuple(conf[k] for k in ref_spec._config_keys)
+    rs = ref_spec(values)
+    rp, op = ref_pool(rs), our_pool(our_spec(values + tuple(our_spec._default_config_values[len(values):])))
+    ids = np.arange(n, dtype=np.int32)
+    rng = np.random.default_rng(2)
+    rp._reset(ids), op._reset(ids)
+    a, b = rp._recv(), op._recv()
+    held = []
+    for t in range(12):
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and np.array_equal(x, y, equal_nan=True), t
+        held.append(([x for x in a], [x.copy() for x in a]))
+        act = _actions(rs, rng, n)
+        rp._send([ids, ids, act]), op._send([ids, ids, act])
+        a, b = rp._recv(), op._recv()
+    for arrays, copies in held:
+        for x, y in zip(arrays, copies):
+            assert np.array_equal(x, y, equal_nan=True)
