@@ -93,7 +93,7 @@ class DevicePool:
         del keep
         self._h = h
         self._pending: collections.deque[int] = collections.deque()
-        # sync pools: per pending batch, the pinned block named at send time (None: recv takes one)
+        # per pending send / reset, the pinned block named at send time (None: recv takes one)
         self._posted: collections.deque[Any] = collections.deque()
         self._is_sync = self.batch_size == self.num_envs
         self._blocks = _PinnedBlocks(self._lib)
@@ -127,7 +127,7 @@ class DevicePool:
         # offer (ids in order, pinned block, "direct_out") is its business: recv hands the same block to
         # epa_recv_block either way.
         block = None
-        if post_block and self._is_sync and k == self.num_envs:
+        if post_block and k == (self.num_envs if self._is_sync else self.batch_size):
             _, total = self._layout(k)
             if total >= self._SMALL_BATCH_BYTES:
                 block = self._blocks.take(total)
@@ -140,13 +140,12 @@ class DevicePool:
             )
         if k > 0:  # an empty send enqueues nothing (Pool::Send returns early)
             self._pending.append(k)
-            if self._is_sync:
-                self._posted.append(block)
+            self._posted.append(block)
 
     def pop_pending(self) -> None:
         """A batch was received through another recv entry point (epa_recv_into of the sharded pool)."""
         self._pending.popleft()
-        if self._is_sync and self._posted:
+        if self._posted:
             self._posted.popleft()
 
     def reset(self, env_ids: np.ndarray) -> None:
@@ -155,8 +154,7 @@ class DevicePool:
         native.check(self._lib.epa_reset(self._h, env_ids.ctypes.data, k))
         if k > 0:
             self._pending.append(k)
-            if self._is_sync:
-                self._posted.append(None)
+            self._posted.append(None)
 
     def _layout(self, rows: int) -> tuple[list[int], int]:
         lay = self._layouts.get(rows)
@@ -187,7 +185,10 @@ class DevicePool:
             ptrs = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
             native.check(self._lib.epa_recv(self._h, ptrs, n, cap, ctypes.byref(k)))
         else:
-            block = self._posted[0] if (self._is_sync and self._posted) else None
+            # the block named at send time for exactly these rows (async: the oldest send is a whole, untouched batch)
+            block = None
+            if self._posted and (self._is_sync or (self._pending and self._pending[0] == cap)):
+                block = self._posted[0]
             if block is None or block.nbytes < total:
                 block = self._blocks.take(total)
             offs = (ctypes.c_size_t * n)()
@@ -206,6 +207,8 @@ class DevicePool:
             while left > 0 and self._pending:
                 if self._pending[0] <= left:
                     left -= self._pending.popleft()
+                    if self._posted:
+                        self._posted.popleft()
                 else:
                     self._pending[0] -= left
                     left = 0

@@ -557,7 +557,10 @@ class AntPool : public Pool {
   bool ConcurrentSafe() const override { return true; }  // per-env state + the launch's own block only
   explicit AntPool(const Config& cfg)
       : Pool(cfg, AntKeys(cfg), KeySpec{"action", EPA_F64, {A::kNU}}, true) {
-    direct_default_ = 1;  // (a unit queue re-reads the action rows per unit: uploaded, not read in place -- engine.h)
+    // (a unit queue re-reads the action rows per unit: uploaded, not read in place -- engine.h; and with several
+    // batches in flight the long Ant kernels overlap their downloads anyway: direct batches measured 5-9 % slower
+    // there, profiles/r6m_async_numpy_*.jsonl)
+    direct_default_ = (cfg.batch_size > 0 && cfg.batch_size < cfg.num_envs) ? 0 : 1;
     task_.use_contact_force = cfg.Get("use_contact_force", 0) != 0;
     task_.post_constraint = cfg.Get("post_constraint", 0) != 0;
     task_.exclude_worldbody = cfg.Get("exclude_worldbody_contact_forces", 0) != 0;

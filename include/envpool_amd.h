@@ -240,12 +240,14 @@ int epa_recv_block(epa_pool* pool, void* block, size_t block_bytes,
 /* epa_send for a caller that already knows WHERE the results shall go (the reference's StateBufferQueue allocates the
  * batch's output buffers before the workers write them, state_buffer_queue.h:123-140): `block` is a pinned host block
  * (epa_host_alloc) with room for k rows laid out by epa_recv_layout(k), which stays the caller's but must live until
- * the epa_recv_block that returns this batch.  For a whole-pool step of a sync pool (env_id = every env in order) the
+ * the epa_recv_block that returns this batch.  For a batch that recv will return as a whole -- every env of a sync pool,
+ * or batch_size rows of an async pool -- the
  * step kernel then writes its rows STRAIGHT into the block -- they cross the link as the kernel's own stores, while
  * it runs -- and epa_recv_block with the same block only waits for the kernel (any other recv call copies out of the
  * block).  By default it also reads the action rows in place out of the pinned staging slot: no DMA command at all in
- * such a step.  Every other send (partial, out of order, async pool, a block that is not pinned, extension key
- * "direct_out" = 0) behaves exactly like epa_send and ignores the block.  Results are the same bytes either way. */
+ * such a step.  A send whose block is too small or not pinned, or with the extension key "direct_out" = 0, behaves
+ * exactly like epa_send and ignores the block; rows that a recv returns in pieces or together with other batches'
+ * rows are copied out of the block.  Results are the same bytes either way. */
 int epa_send_into(epa_pool* pool, const int32_t* env_id, int32_t k, const void* action, void* block,
                   size_t block_bytes);
 

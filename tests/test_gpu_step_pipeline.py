@@ -141,3 +141,24 @@ def test_direct_step_with_the_consumer_already_waiting_in_recv():
         want = ref.recv()
         for x, y in zip(got["out"], want):
             assert x.tobytes() == y.tobytes(), t
+
+
+@pytest.mark.parametrize("task,adim,streams", [("HalfCheetah", 6, 4), ("Hopper", 3, 1), ("Pusher", 7, 2)])
+def test_direct_batches_of_an_async_pool(task, adim, streams):
+    """Async mode (batch_size < num_envs): every send of batch_size rows -- the env ids of the last recv, in whatever order
+    they came -- names its block; the batch's kernel writes into it on whichever compute stream it runs.  The recv /
+    send loop of the reference benchmark (benchmark/test_envpool.py:94-105) gives the same bytes with and without."""
+    n, b = 24576, 4096
+    pools = [DevicePool(task, n, batch_size=b, seed=21, max_episode_steps=9,
+                        params={"direct_out": d, "compute_streams": streams}) for d in (0, 2)]
+    rng = np.random.default_rng(4)
+    ids = np.arange(n, dtype=np.int32)
+    for p in pools:
+        p.reset(ids)
+    for t in range(40):
+        a, z = pools[0].recv_dict(), pools[1].recv_dict()
+        for k in a:
+            assert a[k].tobytes() == z[k].tobytes(), (k, t)
+        act = rng.uniform(-1, 1, (b, adim))
+        for p, out in zip(pools, (a, z)):
+            p.send(out["info:env_id"], act)
