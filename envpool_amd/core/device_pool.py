@@ -215,11 +215,10 @@ class DevicePool:
         rows = k.value
         if small:
             return outs if rows == cap else [o[:rows] for o in outs]
-        outs = []
-        for (_, dtype, shape), off in zip(self.state_keys, offs):
-            nbytes = rows * int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
-            outs.append(block[off:off + nbytes].view(dtype).reshape((rows, *shape)))
-        return outs
+        # one view per key straight onto the block (each holds the block as its base: the block goes back to the free
+        # list when the last of them dies)
+        return [np.ndarray((rows, *shape), dtype=dtype, buffer=block, offset=int(off))
+                for (_, dtype, shape), off in zip(self.state_keys, offs)]
 
     def recv_dict(self) -> dict[str, np.ndarray]:
         return {k[0]: v for k, v in zip(self.state_keys, self.recv())}
