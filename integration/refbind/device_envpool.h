@@ -170,7 +170,7 @@ class DeviceEnvPool : public EnvPool<Spec> {
     // business: Recv passes the same block to epa_recv_block either way.
     std::shared_ptr<char> block;
     std::size_t total = 0;
-    if (sync_ && k == static_cast<int>(this->spec.config["num_envs"_])) {
+    if (k == static_cast<int>(sync_ ? this->spec.config["num_envs"_] : this->spec.config["batch_size"_])) {
       const int n = static_cast<int>(state_specs_.size());
       std::vector<std::size_t> off(n);
       Check(epa_recv_layout(h_, k, off.data(), n, &total));
@@ -203,17 +203,31 @@ class DeviceEnvPool : public EnvPool<Spec> {
     std::size_t total = 0;
     Check(epa_recv_layout(h_, cap, off.data(), n, &total));
     std::shared_ptr<char> block;
-    if (sync_) {  // the block Send named for this batch, if it did
+    {  // the block Send named for exactly these rows, if it did (async: the oldest send is a whole, untouched batch)
       std::lock_guard<std::mutex> lk(mu_);
-      if (!posted_.empty()) block = posted_.front();
+      if (!posted_.empty() && (sync_ || (!pending_.empty() && pending_.front() == cap))) block = posted_.front();
     }
     if (!block) block = blocks_->Take(total > 0 ? total : 256);
     int32_t k = 0;
     Check(epa_recv_block(h_, block.get(), total, off.data(), n, &k));
-    if (sync_) {
+    {
       std::lock_guard<std::mutex> lk(mu_);
-      if (!pending_.empty()) pending_.pop_front();
-      if (!posted_.empty()) posted_.pop_front();
+      if (sync_) {
+        if (!pending_.empty()) pending_.pop_front();
+        if (!posted_.empty()) posted_.pop_front();
+      } else {  // async: rows drain across the sends / resets in order
+        int left = k;
+        while (left > 0 && !pending_.empty()) {
+          if (pending_.front() <= left) {
+            left -= pending_.front();
+            pending_.pop_front();
+            if (!posted_.empty()) posted_.pop_front();
+          } else {
+            pending_.front() -= left;
+            left = 0;
+          }
+        }
+      }
     }
     std::vector<Array> out;
     out.reserve(n);
@@ -235,7 +249,7 @@ class DeviceEnvPool : public EnvPool<Spec> {
   void Push(int k, std::shared_ptr<char> block = nullptr) {
     std::lock_guard<std::mutex> lk(mu_);
     pending_.push_back(k);
-    if (sync_) posted_.push_back(std::move(block));
+    posted_.push_back(std::move(block));
   }
   static constexpr std::size_t kPostBytes = 256 * 1024;  // smaller batches: epa_recv_block's own download is as fast
   epa_pool* h_{nullptr};
@@ -243,7 +257,7 @@ class DeviceEnvPool : public EnvPool<Spec> {
   std::shared_ptr<BlockPool> blocks_;
   bool sync_{true};
   std::mutex mu_;
-  std::deque<int> pending_;  // rows of each outstanding Send / Reset (sync mode)
+  std::deque<int> pending_;  // rows (left) of each outstanding Send / Reset
   std::deque<std::shared_ptr<char>> posted_;  // ... and the block Send named for it (null: Recv takes one)
 };
 
